@@ -1,0 +1,236 @@
+#!/usr/bin/env python
+"""bench.py -- user-item pairs/s through one in-batch-softmax TRAIN STEP (forward,
+zero_grad, backward, dense-exact Adam: the body of ref:train/train.py:112-125) on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json metric: B=8192, d=128, 10 M-row item table): TwoTowerBaseRetrieval,
+N_u = 1 M users, N_i = 10 M items, D = 128, F = 8, T = 1, B = 8192 per GPU, synthetic
+batches of ref:train/train.py:47-65's distributions pre-generated in HBM, random-init
+weights.  With N > 1 the tables are row-sharded (N_i/N rows per GPU), each rank feeds its
+own B = 8192 batch and the in-batch negatives are global (N*B items per user): weak scaling
+in the batch, whole-job pairs/s = N*B*steps / time.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the Adam table sweep, HBM
+bound, timed live with HIP events on its own stream) and `cpu_baseline` (the CPU oracle
+oracle/cpu_ref.py -- kind "port" -- timed on this box's host cores, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
+
+WORKLOADS = {
+    # name: (n_users, n_items, D, F, B, H, model)
+    "P": dict(n_users=1_000_000, n_items=10_000_000, D=128, F=8, B=8192, H=4, model="base"),
+    "C2": dict(n_users=1_000_000, n_items=1_000_000, D=128, F=8, B=4096, H=4, model="base"),
+    "C3": dict(n_users=1_000_000, n_items=1_000_000, D=128, F=8, B=4096, H=50, model="hist"),
+    "tiny": dict(n_users=1024, n_items=10_000, D=32, F=8, B=128, H=4, model="base"),
+}
+
+
+def make_batches(cfg, n, device, seed=1234):
+    """Distributions of ref:train/train.py:47-65; labels as [B,1] (real weighting path)."""
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    B, F, H = cfg["B"], cfg["F"], cfg["H"]
+    out = []
+    for _ in range(n):
+        b = (
+            torch.randint(0, cfg["n_users"], (B,), generator=gen),
+            torch.randn(B, F, generator=gen),
+            torch.randint(0, cfg["n_items"], (B, H), generator=gen),
+            torch.randint(0, cfg["n_items"], (B,), generator=gen),
+            torch.randn(B, F, generator=gen),
+            torch.randint(0, 10, (B,), generator=gen),
+            torch.randint(0, 2, (B, 1), generator=gen).float(),
+        )
+        out.append(tuple(t.to(device) for t in b))
+    return out
+
+
+def build_model(cfg, device):
+    import two_tower_models_amd as A
+    torch.manual_seed(0)
+    with torch.device(device):  # initialise the 5.6 GB of tables directly in HBM
+        mips = A.BaselineMIPSModule(corpus_size=1024, embedding_dim=cfg["D"])
+        kw = dict(num_items=10, user_id_hash_size=cfg["n_users"], user_id_embedding_dim=cfg["D"],
+                  user_features_size=cfg["F"], item_id_hash_size=cfg["n_items"],
+                  item_id_embedding_dim=cfg["D"], item_features_size=cfg["F"],
+                  user_value_weights=[1.0], mips_module=mips)
+        if cfg["model"] == "hist":
+            model = A.TwoTowerWithUserHistoryEncoder(user_history_seqlen=cfg["H"], **kw)
+        else:
+            model = A.TwoTowerBaseRetrieval(**kw)
+    return model.to(device)
+
+
+def algorithmic_sweep_bytes(cfg, world):
+    """Adam reads+writes p, m, v of EVERY table row: 24 B per element."""
+    return 24.0 * (cfg["n_users"] + cfg["n_items"]) * cfg["D"] / world
+
+
+def cpu_baseline(cfg, seconds_budget=25.0):
+    """The CPU oracle (port of the reference's path) on this box's host cores, same shapes,
+    bounded sample.  Tables are shrunk only if host RAM cannot hold p, m, v and the gradient."""
+    import psutil
+    from oracle import cpu_ref as R
+    cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n_items, n_users, D, F, B = cfg["n_items"], cfg["n_users"], cfg["D"], cfg["F"], cfg["B"]
+    need = lambda ni: 4 * 4 * (ni + n_users) * D * 1.3
+    avail = psutil.virtual_memory().available
+    while need(n_items) > 0.5 * avail and n_items > 100_000:
+        n_items //= 2
+    torch.manual_seed(0)
+    p = {
+        "user_id_embedding_arch.weight": torch.randn(n_users, D),
+        "item_id_embedding_arch.weight": torch.randn(n_items, D),
+    }
+    for side, fin in (("user", F), ("item", F)):
+        p[f"{side}_features_arch.0.weight"] = torch.randn(256, fin) * 0.3
+        p[f"{side}_features_arch.0.bias"] = torch.zeros(256)
+        p[f"{side}_features_arch.2.weight"] = torch.randn(D, 256) * 0.06
+        p[f"{side}_features_arch.2.bias"] = torch.zeros(D)
+        p[f"{side}_tower_arch.weight"] = torch.randn(D, 2 * D) * 0.06
+        p[f"{side}_tower_arch.bias"] = torch.zeros(D)
+    state = R.AdamState(p)
+    small = dict(cfg, n_items=n_items)
+    batches = make_batches(small, 2, "cpu")
+    uvw = torch.tensor([1.0])
+    R.train_step(p, state, batches[0], uvw)  # warm-up (page-faults the 4 big arrays in)
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        R.train_step(p, state, batches[steps % 2], uvw)
+        steps += 1
+        if time.perf_counter() - t0 > seconds_budget * 0.6 or steps >= 8:
+            break
+    dt = time.perf_counter() - t0
+    return {
+        "value": B * steps / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+        "sample": f"{steps} train steps of oracle/cpu_ref.py (torch CPU, {cores} threads), B={B}, D={D}, "
+                  f"N_u={n_users}, N_i={n_items}" + ("" if n_items == cfg["n_items"] else " (shrunk to fit host RAM)")
+                  + f", {dt / steps * 1e3:.0f} ms/step",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="P", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--negatives", default="global", choices=["global", "local"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+    cfg = dict(WORKLOADS[args.workload])
+
+    import two_tower_models_amd as A
+    from two_tower_models_amd import _native as N
+    lib = N.load()
+
+    if world > 1:
+        import torch.distributed as dist
+        from two_tower_models_amd import sharded
+        dist.init_process_group("nccl", device_id=device)
+        trainer = sharded.ShardedTrainer(cfg, device, negatives=args.negatives)
+        step = trainer.step
+        batches = trainer.make_batches(16)
+    else:
+        model = build_model(cfg, device)
+        opt = A.DenseExactAdam(model.parameters(), lr=1e-3)
+        batches = make_batches(cfg, 16, device)
+        total_loss = torch.zeros((), device=device)
+
+        def step(batch):
+            loss = model.train_forward(*batch)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            total_loss.add_(loss.detach())  # the loop's loss accumulation, without the host sync
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(batches[i % len(batches)])
+    barrier()
+    lib.tt_profile_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(batches[i % len(batches)])
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    import ctypes as C
+    ms, cnt = C.c_double(0.0), C.c_int64(0)
+    N.check(lib.tt_profile_read(b"adam_sweep_kernel", C.byref(ms), C.byref(cnt)), "tt_profile_read")
+    lib.tt_profile_enable(0)
+
+    if rank == 0:
+        B = cfg["B"]
+        pairs = B * world * args.steps
+        sweep_bytes_step = algorithmic_sweep_bytes(cfg, world)  # per GPU per step (2 launches)
+        roof = None
+        if cnt.value > 0 and ms.value > 0:
+            achieved = sweep_bytes_step * args.steps / (ms.value * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                rec = json.load(open(tpath)).get(f"{args.workload}_gpus{world}")
+                if rec:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            roof = {"bound": "hbm", "kernel": "adam_sweep_kernel", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "launches": cnt.value,
+                    "avg_launch_ms": round(ms.value / cnt.value, 4),
+                    "algorithmic_bytes_per_launch": sweep_bytes_step * args.steps / cnt.value}
+        out = {
+            "metric": "user-item pairs/sec (in-batch softmax train step: fwd + zero_grad + bwd + dense-exact Adam)",
+            "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: TwoTowerBaseRetrieval train step, N_u={cfg['n_users']}, "
+                                   f"N_i={cfg['n_items']}, D={cfg['D']}, F={cfg['F']}, B={B}/GPU"
+                                   + (f", H={cfg['H']} history encoder" if cfg['model'] == 'hist' else ""),
+                       "global_batch": B * world,
+                       "parallelism": "single GPU" if world == 1 else
+                       f"row-sharded tables x{world}, {args.negatives} in-batch negatives, RCCL"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

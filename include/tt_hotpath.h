@@ -1,0 +1,220 @@
+/*
+ * tt_hotpath.h -- C ABI of libtt_hotpath.so: the MI355X (gfx950) hot path of a
+ * two-tower retrieval trainer, as hand-written HIP kernels.
+ *
+ * The reference (gauravchak/two_tower_models) has no FFI of its own: its
+ * boundary is the Python nn.Module surface.  Every entry point
+ * below replaces one torch call site of that surface; the site is cited as
+ * ref:<file>:<line> (paths relative to the reference root).  The Python
+ * modules in two_tower_models_amd/ bind these symbols with ctypes and keep the
+ * reference's class / method / keyword names (INTEGRATION.md shows the stub a
+ * maintainer of the reference would add).
+ *
+ * Conventions
+ *   - plain C, no torch / C++ types.  Pointers are DEVICE pointers unless a
+ *     parameter is documented "host".
+ *   - every function is asynchronous on `stream` (a hipStream_t passed as
+ *     void*), allocates nothing, frees nothing and keeps no pointer after it
+ *     returns.  Scratch comes in through (`ws`, `ws_bytes`); the matching
+ *     tt_*_workspace_bytes() says how much is needed.
+ *   - return value: 0 = ok; >0 = hipError_t of a failed launch; <0 = TT_E_*.
+ *     tt_last_error_string() describes the last failure on the calling thread.
+ *   - all tensors are row-major fp32 unless stated; `ld*` are row strides in
+ *     ELEMENTS; ids / indices are int64 (torch.long) at the boundary.
+ *   - out-of-range ids never fault: the kernel writes zeros for that row and
+ *     sets *oob_flag (device int32) to 1; the Python layer raises IndexError
+ *     (what torch's nn.Embedding raises) when it next reads the flag.
+ */
+#ifndef TT_HOTPATH_H
+#define TT_HOTPATH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TT_ABI_VERSION 1
+
+#define TT_E_BADARG (-1)      /* null pointer / negative size / unsupported shape */
+#define TT_E_WORKSPACE (-2)   /* ws_bytes smaller than tt_*_workspace_bytes()     */
+#define TT_E_UNSUPPORTED (-3) /* shape outside what the kernels implement         */
+
+typedef void* tt_stream_t; /* hipStream_t */
+
+int tt_abi_version(void);
+const char* tt_last_error_string(void);
+
+/* Per-kernel timing for the benchmark: when enabled, the launches of the named hot
+ * kernels ("adam_sweep_kernel", "ce_fwd_kernel", "ce_bwd_kernel", "mips_score_kernel")
+ * are bracketed by HIP events on their own stream.  tt_profile_read synchronises those
+ * events and returns the summed duration and the launch count. */
+int tt_profile_enable(int on);
+int tt_profile_read(const char* kernel, double* total_ms, int64_t* launches);
+
+/* ---------------------------------------------------------------- K1 gather
+ * out[i, 0:dim] = table[ids[i], 0:dim]          (out row stride ld_out >= dim)
+ * replaces nn.Embedding.__call__ at ref:src/two_tower_base_retrieval.py:126,209
+ * and the history lookup ref:src/two_tower_with_user_history_encoder.py:105.
+ * ld_out lets the caller write straight into a column slice of the tower
+ * input, which is how torch.cat (ref:...base_retrieval.py:159,214) disappears. */
+int tt_gather_rows(const float* table, int64_t n_rows, int64_t dim, const int64_t* ids,
+                   int64_t n_ids, float* out, int64_t ld_out, int32_t* oob_flag,
+                   tt_stream_t stream);
+
+/* ---------------------------------------------------------------- K3 GEMM
+ * C[M,N] (+)= A(M,K) * B(K,N) (+ bias[N]) with an optional epilogue, fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32).  `layout`:
+ *   TT_GEMM_NT  A is [M,K] row-major, B is [N,K] row-major   y = x W^T
+ *               (nn.Linear forward, ref:...base_retrieval.py:76-80,90-93,101-110)
+ *   TT_GEMM_NN  A is [M,K], B is [K,N]                        dx = dy W
+ *   TT_GEMM_TN  A is [K,M], B is [K,N]                        dW = dy^T x
+ * `epilogue`: 0 none; TT_EPI_RELU max(.,0); TT_EPI_RELU_MASK multiply by
+ * (aux[m,n] > 0) -- the ReLU backward mask (aux = saved forward activation).
+ * `accumulate` != 0 adds into C instead of overwriting it. */
+#define TT_GEMM_NT 0
+#define TT_GEMM_NN 1
+#define TT_GEMM_TN 2
+#define TT_EPI_NONE 0
+#define TT_EPI_RELU 1
+#define TT_EPI_RELU_MASK 2
+int64_t tt_gemm_workspace_bytes(int layout, int64_t M, int64_t N, int64_t K);
+int tt_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                int epilogue, const float* aux, int64_t ldaux, int accumulate, void* ws,
+                int64_t ws_bytes, tt_stream_t stream);
+
+/* out[n] = sum_m X[m,n]  (bias gradients), deterministic two-stage reduction */
+int64_t tt_colsum_workspace_bytes(int64_t M, int64_t N);
+int tt_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out, void* ws,
+                  int64_t ws_bytes, tt_stream_t stream);
+
+/* ---------------------------------------------------------------- K5 in-batch softmax CE
+ * Forward: S = U I^T is never written to memory.
+ *   row_lse[i] = logsumexp_j S[i,j]          (j over the N item rows)
+ *   row_ce[i]  = row_lse[i] - S[i, i+diag_offset]
+ * replaces torch.matmul + F.cross_entropy(reduction="none") at
+ * ref:src/two_tower_base_retrieval.py:287,301-312.  U is [M,D], I is [N,D];
+ * M == N and diag_offset == 0 for the reference; the sharded trainer passes
+ * the all-gathered item block (N = world*M, diag_offset = rank*M).
+ * Backward (recomputes S tile by tile): with G[i,j] = coef[i]*(softmax_j(S[i,:]) - [j == i+diag_offset]),
+ *   dU = G I   [M,D],   dI = G^T U   [N,D]
+ * where coef[i] = dLoss/d row_ce[i] (the normalised net_user_value weight / B,
+ * ref:...base_retrieval.py:334-343).  Requires D <= 128 (TT_E_UNSUPPORTED otherwise). */
+int64_t tt_inbatch_ce_workspace_bytes(int64_t M, int64_t N, int64_t D);
+int tt_inbatch_ce_fwd(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M,
+                      int64_t N, int64_t D, int64_t diag_offset, float* row_lse, float* row_ce,
+                      void* ws, int64_t ws_bytes, tt_stream_t stream);
+int tt_inbatch_ce_bwd(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M,
+                      int64_t N, int64_t D, int64_t diag_offset, const float* row_lse,
+                      const float* coef, float* dU, int64_t lddu, float* dI, int64_t lddi,
+                      void* ws, int64_t ws_bytes, tt_stream_t stream);
+
+/* net_user_value weights, ref:...base_retrieval.py:322,334-339 for 2-D labels:
+ *   nuv[i] = sum_t labels[i,t]*uvw[t];  w = clamp(nuv,1e-6);  w /= max_i w
+ * then loss = mean_i(row_ce[i]*w[i]) and coef[i] = w[i]/B (gradient seed 1). */
+int tt_weighted_mean_loss(const float* labels, int64_t B, int64_t T, const float* uvw,
+                          const float* row_ce, float* w_out, float* coef_out, float* loss_out,
+                          tt_stream_t stream);
+
+/* ---------------------------------------------------------------- K2 row-gradient plan + dense-exact Adam
+ * The embedding backward of the reference is a dense [n_rows,dim] gradient
+ * (autograd embedding_dense_backward) consumed by optim.Adam over EVERY row
+ * (ref:train/train.py:123-125,179).  Here the gradient stays in row form:
+ *   tt_rowgrad_plan   stable-sorts the looked-up ids, finds the unique rows and
+ *                     their occurrence lists  (deterministic, atomic-free)
+ *   tt_rowgrad_dense  materialises the dense gradient (for torch.optim users)
+ *   tt_adam_table     one dense-exact Adam step on the whole table: every row
+ *                     gets the zero-gradient update, rows that were looked up
+ *                     get the update with their summed gradient.
+ * Plan outputs (device): sorted_ids int32[n], perm int32[n] (original position
+ * of each sorted id), seg_begin int32[n+1] (start of each unique row's run in
+ * the sorted order; seg_begin[n_unique] == n), n_unique int32[1]. */
+int64_t tt_rowgrad_workspace_bytes(int64_t n_ids);
+int tt_rowgrad_plan(const int64_t* ids, int64_t n_ids, int64_t n_rows, int32_t* sorted_ids,
+                    int32_t* perm, int32_t* seg_begin, int32_t* n_unique, int32_t* oob_flag,
+                    void* ws, int64_t ws_bytes, tt_stream_t stream);
+
+/* up to TT_MAX_GRAD_SOURCES row-gradient blocks; occurrence p in [0,n_ids) lives in
+ * the block whose [first, first+rows) range contains p (e.g. item_id rows then
+ * history rows for the item table). */
+#define TT_MAX_GRAD_SOURCES 4
+typedef struct {
+  const float* rows[TT_MAX_GRAD_SOURCES];
+  int64_t ld[TT_MAX_GRAD_SOURCES];
+  int64_t first[TT_MAX_GRAD_SOURCES + 1]; /* first[k+1]-first[k] = rows in block k */
+  int32_t n_sources;
+} tt_grad_sources;
+
+int tt_rowgrad_dense(const tt_grad_sources* src /*host*/, int64_t n_ids, int64_t dim,
+                     const int32_t* sorted_ids, const int32_t* perm, const int32_t* seg_begin,
+                     const int32_t* n_unique, float* dense_grad /*[n_rows,dim], pre-zeroed*/,
+                     tt_stream_t stream);
+
+/* Adam hyper-parameters + step live in DEVICE memory (8 doubles) so that a
+ * captured hipGraph replays with a moving step count:
+ *   [0] lr [1] beta1 [2] beta2 [3] eps [4] step [5] lr/(1-beta1^step)
+ *   [6] sqrt(1-beta2^step) [7] reserved.   tt_adam_advance bumps [4] and
+ * recomputes [5],[6] in double, as torch.optim.Adam does on the host. */
+int tt_adam_advance(double* hyper, tt_stream_t stream);
+
+int64_t tt_adam_table_workspace_bytes(int64_t n_ids, int64_t dim);
+int tt_adam_table(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
+                  const tt_grad_sources* src /*host*/, int64_t n_ids, const int32_t* sorted_ids,
+                  const int32_t* perm, const int32_t* seg_begin, const int32_t* n_unique,
+                  void* ws, int64_t ws_bytes, tt_stream_t stream);
+
+/* dense parameters: `tensors` is a HOST array of n_tensors {p,g,m,v,n} descriptors
+ * (device pointers inside); they are passed to the kernel by value, 64 per launch. */
+typedef struct {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+} tt_adam_tensor;
+int tt_adam_dense(const tt_adam_tensor* tensors /*host*/, int32_t n_tensors, const double* hyper,
+                  tt_stream_t stream);
+
+/* ---------------------------------------------------------------- K4 history encoder pieces
+ * tt_hist_embed_pool: x[b,h,:] = table[ids[b,h],:] (+ pe[h,:]);  pooled[b,:] = mean_h table[ids[b,h],:]
+ *   (mean of the RAW rows, ref:src/user_history_encoder.py:89; PE add :91-95).
+ *   If `ids` is NULL, `table` is read as an already-embedded [B,H,dim] tensor
+ *   (the UserHistoryEncoder.forward([B,H,DI]) entry, ref:...encoder.py:80).
+ * tt_attn_fwd / tt_attn_bwd: unmasked multi-head softmax attention over one
+ *   sample's H rows, heads split along columns of the packed projection
+ *   qkv[B*H, 3D] = [Q | K | V]  (nn.MultiheadAttention internals,
+ *   ref:...encoder.py:103-108; algebra in SURVEY.md 3.3).  ctx is [B*H, D]
+ *   (heads concatenated), lse is [B, heads, H]. */
+int tt_hist_embed_pool(const float* table, int64_t n_rows, int64_t dim, const int64_t* ids,
+                       int64_t B, int64_t H, const float* pe, float* x, float* pooled,
+                       int64_t ld_pooled, int32_t* oob_flag, tt_stream_t stream);
+/* backward of the mean pool (ref:...encoder.py:89): dx[b,h,:] += d_pooled[b,:] / H */
+int tt_hist_pool_bwd(float* dx, int64_t B, int64_t H, int64_t dim, const float* d_pooled,
+                     int64_t ld_pooled, tt_stream_t stream);
+int tt_attn_fwd(const float* qkv, int64_t B, int64_t H, int64_t D, int64_t heads, float* ctx,
+                float* lse, tt_stream_t stream);
+int tt_attn_bwd(const float* qkv, const float* ctx, const float* lse, const float* d_ctx,
+                int64_t B, int64_t H, int64_t D, int64_t heads, float* d_qkv, tt_stream_t stream);
+
+/* ---------------------------------------------------------------- K6 MIPS top-K
+ * idx[b, 0:K], score[b, 0:K] = the K largest inner products q[b,:].corpus[c,:]
+ * sorted by (score desc, index asc); replaces torch.topk(torch.matmul(q,
+ * corpus.T), k) at ref:src/baseline_mips_module.py:57-61.  The [B,C] score
+ * matrix is never written.  dtype: TT_F32 (corpus/query fp32) or TT_BF16
+ * (both stored as bf16, fp32 accumulate -- BASELINE config 5). */
+#define TT_F32 0
+#define TT_BF16 1
+int64_t tt_mips_workspace_bytes(int64_t B, int64_t C, int64_t D, int64_t K, int dtype);
+int tt_mips_topk(const void* query, const void* corpus, int dtype, int64_t B, int64_t C,
+                 int64_t D, int64_t K, int64_t* idx_out, float* score_out, void* ws,
+                 int64_t ws_bytes, tt_stream_t stream);
+int tt_f32_to_bf16(const float* in, uint16_t* out, int64_t n, tt_stream_t stream);
+int tt_gather_rows_bf16(const uint16_t* table, int64_t n_rows, int64_t dim, const int64_t* ids,
+                        int64_t n_ids, float* out, int64_t ld_out, int32_t* oob_flag,
+                        tt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TT_HOTPATH_H */

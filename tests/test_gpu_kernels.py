@@ -1,0 +1,230 @@
+"""Kernel-level parity (run on MI355X via `pytest -m gpu`): every C-ABI entry point of
+libtt_hotpath.so against the CPU oracle / a float64 restatement on seeded inputs,
+including ragged shapes, strided views, duplicates and out-of-range ids."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import fixture_gen as fg
+from oracle import cpu_ref as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def T():
+    from two_tower_models_amd import _native as N
+    from two_tower_models_amd import ops
+    N.load()
+    return ops, N
+
+
+def g(shape, seed):
+    return torch.from_numpy(fg.gaussianish(shape, seed))
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,Nn,K", [(32, 50, 20), (256, 128, 256), (300, 77, 41), (8192, 128, 8),
+                                    (128, 384, 4100), (1000, 256, 130), (64, 64, 1)])
+def test_gemm_layouts(T, layout, M, Nn, K):
+    ops, N = T
+    a_shape = (M, K) if layout != 2 else (K, M)
+    b_shape = (Nn, K) if layout == 0 else (K, Nn)
+    A, B = g(a_shape, 1), g(b_shape, 2)
+    bias = g((Nn,), 3)
+    ref = ((A if layout != 2 else A.t()).double() @ (B.t() if layout == 0 else B).double()) + bias.double()
+    out = torch.empty(M, Nn, device=DEV)
+    ops.gemm(layout, A.to(DEV), B.to(DEV), out, M, Nn, K, bias=bias.to(DEV))
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 2e-6 * max(1.0, math.sqrt(K)) * float(ref.abs().max()), err
+
+
+def test_gemm_epilogues_strided_and_accumulate(T):
+    ops, N = T
+    M, Nn, K = 200, 96, 72
+    A, B = g((M, K + 8), 5)[:, 4:4 + K], g((Nn, K), 6)  # A is a column-slice view (ld > K, 16-B misaligned rows ok)
+    ref = A.double() @ B.double().t()
+    big = torch.zeros(M, 2 * Nn, device=DEV)
+    out = big[:, Nn:]  # write into a column slice
+    Ad = g((M, K + 8), 5).to(DEV)[:, 4:4 + K]
+    ops.gemm(N.TT_GEMM_NT, Ad, B.to(DEV), out, M, Nn, K, epilogue=N.TT_EPI_RELU)
+    assert torch.allclose(out.cpu().double(), ref.clamp(min=0), atol=1e-4)
+    assert float(big[:, :Nn].abs().max()) == 0.0
+    aux = g((M, Nn), 7)
+    out2 = torch.empty(M, Nn, device=DEV)
+    ops.gemm(N.TT_GEMM_NT, Ad, B.to(DEV), out2, M, Nn, K, epilogue=N.TT_EPI_RELU_MASK, aux=aux.to(DEV))
+    assert torch.allclose(out2.cpu().double(), ref * (aux > 0), atol=1e-4)
+    ops.gemm(N.TT_GEMM_NT, Ad, B.to(DEV), out2, M, Nn, K, accumulate=True)
+    assert torch.allclose(out2.cpu().double(), ref * (aux > 0) + ref, atol=2e-4)
+
+
+def test_colsum(T):
+    ops, N = T
+    X = g((1000, 300), 9)
+    got = ops.colsum(X.to(DEV)[:, 10:250])
+    assert torch.allclose(got.cpu().double(), X[:, 10:250].double().sum(0), atol=1e-3)
+
+
+# ------------------------------------------------------------------ gathers
+@pytest.mark.parametrize("D", [128, 50, 2, 32])
+def test_gather_rows_and_oob(T, D):
+    ops, N = T
+    table = g((777, D), 11)
+    ids = torch.from_numpy(fg.uniform_ids((333,), 777, 12))
+    out = torch.full((333, D + 4), -1.0, device=DEV)
+    ops.gather_rows_into(table.to(DEV), ids.to(DEV), out[:, :D])
+    assert torch.equal(out[:, :D].cpu(), table[ids])
+    assert float(out[:, D:].min()) == -1.0
+    bad = ids.clone()
+    bad[5] = 777
+    bad[9] = -1
+    ops.gather_rows_into(table.to(DEV), bad.to(DEV), out[:, :D])
+    assert float(out[5, :D].abs().max()) == 0.0
+    with pytest.raises(IndexError):
+        N.oob.poll(torch.device(DEV), blocking=True)
+    N.oob.poll(torch.device(DEV), blocking=True)  # flag was cleared
+
+
+# ------------------------------------------------------------------ in-batch softmax CE
+@pytest.mark.parametrize("M,Nn,D,off", [(32, 32, 40, 0), (200, 200, 50, 0), (256, 256, 128, 0), (1000, 1000, 128, 0),
+                                        (128, 512, 128, 256), (100, 300, 64, 200), (64, 64, 2, 0), (1, 1, 8, 0)])
+def test_inbatch_ce_forward_backward(T, M, Nn, D, off):
+    ops, N = T
+    U = (g((M, D), 21) * 0.5).requires_grad_(True)
+    I = (g((Nn, D), 22) * 0.5).requires_grad_(True)
+    coef = g((M,), 23).abs() / M
+    ce_ref = R.inbatch_rowwise_ce(U, I, off)
+    (ce_ref * coef).sum().backward()
+    Ud, Id = U.detach().to(DEV).requires_grad_(True), I.detach().to(DEV).requires_grad_(True)
+    ce = ops.InBatchSoftmaxCE.apply(Ud, Id, off)
+    assert torch.allclose(ce.cpu(), ce_ref.detach(), atol=2e-5, rtol=1e-5)
+    (ce * coef.to(DEV)).sum().backward()
+    scale = float(U.grad.abs().max())
+    assert torch.allclose(Ud.grad.cpu(), U.grad, atol=1e-5 * scale + 1e-9, rtol=1e-4)
+    assert torch.allclose(Id.grad.cpu(), I.grad, atol=1e-5 * float(I.grad.abs().max()) + 1e-9, rtol=1e-4)
+
+
+def test_inbatch_ce_large_logits_stable(T):
+    ops, N = T
+    U, I = g((96, 128), 31) * 3.0, g((96, 128), 32) * 3.0  # logits ~ +-100
+    ce = ops.InBatchSoftmaxCE.apply(U.to(DEV), I.to(DEV), 0)
+    ref = R.inbatch_rowwise_ce(U.double(), I.double())
+    assert torch.isfinite(ce).all()
+    assert torch.allclose(ce.cpu().double(), ref, atol=1e-3, rtol=1e-5)
+
+
+def test_weighted_mean_loss(T):
+    ops, N = T
+    B, Tn = 777, 3
+    ce = g((B,), 41).abs()
+    labels = (torch.from_numpy(fg.hashed_u64((B, Tn), 42) % np.uint64(2)).float())
+    uvw = torch.tensor([0.1, 0.2, 0.3])
+    ced = ce.to(DEV).requires_grad_(True)
+    loss = ops.WeightedMeanLoss.apply(ced, labels.to(DEV), uvw.to(DEV))
+    w = R.normalise_value_weights(R.net_user_value(labels, uvw))
+    assert abs(loss.item() - float((ce * w).mean())) < 1e-6
+    loss.backward()
+    assert torch.allclose(ced.grad.cpu(), w / B, atol=1e-8)
+
+
+# ------------------------------------------------------------------ row plan + Adam
+@pytest.mark.parametrize("n,n_rows", [(1, 10), (777, 100), (8192, 1_000_000), (50_000, 300), (4096, 70_000_000)])
+def test_rowgrad_plan_matches_stable_sort(T, n, n_rows):
+    ops, N = T
+    ids = torch.from_numpy(fg.uniform_ids((n,), n_rows, 51))
+    rows = torch.zeros(n, 4, device=DEV)
+    plan = ops.RowPlan([ops.RowGrad(ids.to(DEV), rows)], n_rows)
+    order = torch.sort(ids, stable=True)
+    assert torch.equal(plan.sorted_ids.cpu().long(), order.values)
+    assert torch.equal(plan.perm.cpu().long(), order.indices)
+    uniq, counts = torch.unique_consecutive(order.values, return_counts=True)
+    U = int(plan.n_unique.item())
+    assert U == len(uniq)
+    begins = torch.cumsum(counts, 0) - counts
+    assert torch.equal(plan.seg_begin.cpu()[:U].long(), begins)
+    assert int(plan.seg_begin[U]) == n
+
+
+@pytest.mark.parametrize("n_rows,D,n1,n2", [(300, 128, 256, 512), (97, 50, 64, 0), (5000, 32, 1000, 3000)])
+def test_adam_table_equals_dense_adam(T, n_rows, D, n1, n2):
+    """3 dense-exact steps on a table looked up through two id blocks (item ids + history
+    ids) == the oracle's Adam on the dense gradient, for touched AND untouched rows."""
+    import ctypes as C
+    ops, N = T
+    lib = N.load()
+    W = g((n_rows, D), 61)
+    p_ref, m_ref, v_ref = W.clone(), torch.zeros_like(W), torch.zeros_like(W)
+    Wd, Md, Vd = W.to(DEV), torch.zeros(n_rows, D, device=DEV), torch.zeros(n_rows, D, device=DEV)
+    hyper = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 0, 0, 0, 0], dtype=torch.float64, device=DEV)
+    for step in range(1, 4):
+        blocks, dense = [], torch.zeros(n_rows, D)
+        for k, n in enumerate((n1, n2)):
+            if n == 0:
+                continue
+            ids = torch.from_numpy(fg.uniform_ids((n,), n_rows, 70 + 10 * step + k))
+            rows = g((n, D), 80 + 10 * step + k) * 0.01
+            dense.index_add_(0, ids, rows)
+            blocks.append(ops.RowGrad(ids.to(DEV), rows.to(DEV)))
+        R.adam_update(p_ref, dense, m_ref, v_ref, step)
+        N.check(lib.tt_adam_advance(hyper.data_ptr(), N.stream()), "advance")
+        plan = ops.RowPlan(blocks, n_rows)
+        wsp, wsn = ops._ws(torch.device(DEV), lib.tt_adam_table_workspace_bytes(plan.n, D), "adam_side")
+        N.check(lib.tt_adam_table(Wd.data_ptr(), Md.data_ptr(), Vd.data_ptr(), n_rows, D, hyper.data_ptr(),
+                                  C.byref(plan.sources), plan.n, plan.sorted_ids.data_ptr(), plan.perm.data_ptr(),
+                                  plan.seg_begin.data_ptr(), plan.n_unique.data_ptr(), wsp, wsn, N.stream()), "adam")
+        dg = ops.dense_grad_from_rows(blocks, n_rows, D)
+        assert torch.allclose(dg.cpu(), dense, atol=1e-6)
+    assert torch.allclose(Wd.cpu(), p_ref, atol=3e-6, rtol=1e-5)
+    assert torch.allclose(Md.cpu(), m_ref, atol=1e-7, rtol=1e-4)
+    assert torch.allclose(Vd.cpu(), v_ref, atol=1e-9, rtol=1e-4)
+    assert float(hyper[4]) == 3.0
+
+
+# ------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,H,D,heads", [(3, 50, 128, 4), (2, 7, 40, 4), (1, 3, 2, 1), (2, 128, 64, 4), (5, 16, 40, 4)])
+def test_attention_forward_backward(T, B, H, D, heads):
+    ops, N = T
+    lib = N.load()
+    qkv = (g((B * H, 3 * D), 91) * 0.7).requires_grad_(True)
+    dh = D // heads
+
+    def split(t):
+        return t.reshape(B, H, heads, dh).permute(0, 2, 1, 3)
+
+    q, k, v = split(qkv[:, :D]), split(qkv[:, D:2 * D]), split(qkv[:, 2 * D:])
+    s = (q / math.sqrt(dh)) @ k.transpose(-1, -2)
+    ctx_ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * H, D)
+    cot = g((B * H, D), 92)
+    (ctx_ref * cot).sum().backward()
+    qd = qkv.detach().to(DEV)
+    ctx, lse = ops._attn_fwd(qd, B, H, D, heads)
+    assert torch.allclose(ctx.cpu(), ctx_ref.detach(), atol=2e-6, rtol=1e-5)
+    assert torch.allclose(lse.cpu(), torch.logsumexp(s, -1).detach(), atol=1e-5)
+    d_qkv = torch.empty_like(qd)
+    cot_d = cot.to(DEV)
+    N.check(lib.tt_attn_bwd(qd.data_ptr(), ctx.data_ptr(), lse.data_ptr(), cot_d.data_ptr(), B, H, D, heads,
+                            d_qkv.data_ptr(), N.stream()), "attn_bwd")
+    assert torch.allclose(d_qkv.cpu(), qkv.grad, atol=2e-6 * float(qkv.grad.abs().max()) + 1e-7, rtol=2e-4)
+
+
+@pytest.mark.parametrize("D,H,B", [(128, 50, 9), (50, 7, 4)])
+def test_hist_embed_pool(T, D, H, B):
+    ops, N = T
+    lib = N.load()
+    table = g((400, D), 95)
+    ids = torch.from_numpy(fg.uniform_ids((B, H), 400, 96))
+    pe = R.positional_table(H, D)
+    x = torch.empty(B * H, D, device=DEV)
+    out = torch.zeros(B, 2, D, device=DEV)
+    table_d, ids_d, pe_d = table.to(DEV), ids.to(DEV), pe.to(DEV)  # keep the device copies alive
+    N.check(lib.tt_hist_embed_pool(table_d.data_ptr(), 400, D, ids_d.data_ptr(), B, H,
+                                   pe_d.data_ptr(), x.data_ptr(), out[:, 1, :].data_ptr(), 2 * D,
+                                   N.oob.flag(torch.device(DEV)).data_ptr(), N.stream()), "hist_embed_pool")
+    emb = table[ids]
+    assert torch.allclose(x.cpu().view(B, H, D), emb + pe, atol=1e-7)
+    assert torch.allclose(out[:, 1, :].cpu(), emb.mean(1), atol=1e-6)
+    assert float(out[:, 0, :].abs().max()) == 0.0

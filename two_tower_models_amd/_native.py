@@ -1,0 +1,206 @@
+"""ctypes binding of libtt_hotpath.so (C ABI in include/tt_hotpath.h).
+
+The library is the product path: if it cannot be loaded this module raises --
+there is no CPU or eager-PyTorch fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libtt_hotpath.so")
+
+TT_GEMM_NT, TT_GEMM_NN, TT_GEMM_TN = 0, 1, 2
+TT_EPI_NONE, TT_EPI_RELU, TT_EPI_RELU_MASK = 0, 1, 2
+TT_F32, TT_BF16 = 0, 1
+TT_MAX_GRAD_SOURCES = 4
+ABI_VERSION = 1
+
+_vp, _i64, _i32, _int = C.c_void_p, C.c_int64, C.c_int32, C.c_int
+
+
+class GradSources(C.Structure):
+    """tt_grad_sources (host struct, passed by pointer)."""
+
+    _fields_ = [
+        ("rows", _vp * TT_MAX_GRAD_SOURCES),
+        ("ld", _i64 * TT_MAX_GRAD_SOURCES),
+        ("first", _i64 * (TT_MAX_GRAD_SOURCES + 1)),
+        ("n_sources", _i32),
+    ]
+
+
+class AdamTensor(C.Structure):
+    """tt_adam_tensor."""
+
+    _fields_ = [("p", _vp), ("g", _vp), ("m", _vp), ("v", _vp), ("n", _i64)]
+
+
+# name -> (restype, argtypes); mirrors include/tt_hotpath.h declaration by declaration
+SIGNATURES = {
+    "tt_abi_version": (_int, []),
+    "tt_last_error_string": (C.c_char_p, []),
+    "tt_profile_enable": (_int, [_int]),
+    "tt_profile_read": (_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "tt_gather_rows": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "tt_gemm_workspace_bytes": (_i64, [_int, _i64, _i64, _i64]),
+    "tt_gemm_f32": (_int, [_int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _int, _vp,
+                           _i64, _int, _vp, _i64, _vp]),
+    "tt_colsum_workspace_bytes": (_i64, [_i64, _i64]),
+    "tt_colsum_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp]),
+    "tt_inbatch_ce_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "tt_inbatch_ce_fwd": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "tt_inbatch_ce_bwd": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp,
+                                 _i64, _vp, _i64, _vp]),
+    "tt_weighted_mean_loss": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tt_rowgrad_workspace_bytes": (_i64, [_i64]),
+    "tt_rowgrad_plan": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "tt_rowgrad_dense": (_int, [C.POINTER(GradSources), _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tt_adam_advance": (_int, [_vp, _vp]),
+    "tt_adam_table_workspace_bytes": (_i64, [_i64, _i64]),
+    "tt_adam_table": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, C.POINTER(GradSources), _i64, _vp, _vp, _vp,
+                             _vp, _vp, _i64, _vp]),
+    "tt_adam_dense": (_int, [C.POINTER(AdamTensor), _i32, _vp, _vp]),
+    "tt_hist_embed_pool": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "tt_hist_pool_bwd": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "tt_attn_fwd": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "tt_attn_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "tt_mips_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64, _int]),
+    "tt_mips_topk": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "tt_f32_to_bf16": (_int, [_vp, _vp, _i64, _vp]),
+    "tt_gather_rows_bf16": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the shared library once and bind every declared entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m two_tower_models_amd.build` "
+            "(hipcc, gfx950).  two_tower_models_amd has no fallback path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover - build/ABI mismatch
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.tt_abi_version()
+    if got != ABI_VERSION:
+        raise NativeLibraryError(f"ABI version mismatch: library {got}, bindings {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().tt_last_error_string().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    """hipStream_t of torch's current stream (kernels run stream-ordered with torch ops)."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(*tensors: torch.Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "two_tower_models_amd runs on MI355X only: got a CPU tensor "
+                "(move the module and its inputs to the GPU; there is no CPU path)"
+            )
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+# ----------------------------------------------------------------- scratch
+class _Scratch:
+    """One growable byte buffer per (device, slot).  Calls are stream-ordered on the
+    current stream, so a buffer can be reused by the next call as soon as the previous
+    launch has been enqueued."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, dev: torch.device, nbytes: int, slot: str = "ws") -> torch.Tensor:
+        key = (dev.index, slot)
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("scratch buffer would grow during graph capture; run a warm-up step first")
+            buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=dev)
+            self._bufs[key] = buf
+        return buf
+
+
+scratch = _Scratch()
+
+
+class _OobFlags:
+    """Device-side out-of-range-id flag (one int32 per device) with a non-blocking
+    host mirror, so the training loop never synchronises for it.  `raise_if_set`
+    reports a bad id at the latest one call after the kernel that saw it."""
+
+    def __init__(self):
+        self._dev = {}
+        self._host = {}
+        self._event = {}
+
+    def flag(self, dev: torch.device) -> torch.Tensor:
+        f = self._dev.get(dev.index)
+        if f is None:
+            f = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._dev[dev.index] = f
+            self._host[dev.index] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        return f
+
+    def poll(self, dev: torch.device, blocking: bool = False) -> None:
+        if torch.cuda.is_current_stream_capturing():
+            return
+        f = self.flag(dev)
+        host = self._host[dev.index]
+        ev = self._event.get(dev.index)
+        if blocking:
+            if int(f.item()) != 0:
+                f.zero_()
+                raise IndexError("index out of range in self")  # torch's nn.Embedding message
+            return
+        if ev is not None and ev.query():
+            if int(host[0]) != 0:
+                f.zero_()
+                host.zero_()
+                self._event.pop(dev.index, None)
+                raise IndexError("index out of range in self")
+        host.copy_(f, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._event[dev.index] = ev
+
+
+oob = _OobFlags()

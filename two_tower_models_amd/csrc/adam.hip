@@ -1,0 +1,259 @@
+// K2b: dense-exact Adam.  torch.optim.Adam on an nn.Embedding(sparse=False)
+// updates EVERY row every step (ref:train/train.py:123-125,179): rows that were not
+// looked up still decay their moments and move by their momentum.  The table step is
+// therefore an HBM-bound streaming sweep -- 24 B per element (read+write p, m, v) --
+// and that sweep is the roofline of the whole train step.
+//
+//   adam_touched_kernel   rows that WERE looked up: sum their gradient rows (run order
+//                         from the plan => deterministic), full Adam update computed
+//                         from the OLD p,m,v, result parked in a side buffer
+//   adam_sweep_kernel     every row, gradient = 0, in place, pure float4 streaming
+//   adam_writeback_kernel side buffer -> the looked-up rows (overwrites the sweep's
+//                         zero-gradient result for them)
+//
+// Update rule, in torch's single-tensor operation order:
+//   m += (g - m)*(1-b1);  v = v*b2 + (1-b2)*g*g;
+//   p += -(lr/(1-b1^t)) * ( m / (sqrt(v)/sqrt(1-b2^t) + eps) )
+#include "common.hpp"
+
+namespace tt {
+
+struct AdamConst {
+  float one_minus_b1, b2, one_minus_b2, eps, neg_step_size, bc2_sqrt;
+};
+
+__device__ __forceinline__ AdamConst load_hyper(const double* __restrict__ h) {
+  AdamConst c;
+  c.one_minus_b1 = (float)(1.0 - h[1]);
+  c.b2 = (float)h[2];
+  c.one_minus_b2 = (float)(1.0 - h[2]);
+  c.eps = (float)h[3];
+  c.neg_step_size = (float)(-h[5]);
+  c.bc2_sqrt = (float)h[6];
+  return c;
+}
+
+__device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, const AdamConst& c) {
+  m = fmaf(c.one_minus_b1, g - m, m);
+  v = v * c.b2 + (c.one_minus_b2 * g) * g;
+  const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+  p = p + c.neg_step_size * (m / denom);
+}
+__device__ __forceinline__ void adam_elem_zero_grad(float& p, float& m, float& v, const AdamConst& c) {
+  m = fmaf(c.one_minus_b1, -m, m);
+  v = v * c.b2;
+  const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+  p = p + c.neg_step_size * (m / denom);
+}
+
+__global__ void adam_advance_kernel(double* h) {
+  const double step = h[4] + 1.0;
+  h[4] = step;
+  h[5] = h[0] / (1.0 - pow(h[1], step));
+  h[6] = sqrt(1.0 - pow(h[2], step));
+}
+
+__device__ __forceinline__ const float* source_row(const tt_grad_sources& s, int64_t pos) {
+  int k = 0;
+#pragma unroll
+  for (int q = 1; q < TT_MAX_GRAD_SOURCES; ++q)
+    if (q < s.n_sources && pos >= s.first[q]) k = q;
+  return s.rows[k] + (pos - s.first[k]) * s.ld[k];
+}
+
+// one wavefront per unique row; 4 rows per workgroup
+__global__ __launch_bounds__(256) void adam_touched_kernel(const float* __restrict__ W, const float* __restrict__ M,
+                                                           const float* __restrict__ V, int64_t dim,
+                                                           const double* __restrict__ hyper, const tt_grad_sources src,
+                                                           const int32_t* __restrict__ sorted_ids,
+                                                           const int32_t* __restrict__ perm,
+                                                           const int32_t* __restrict__ seg_begin,
+                                                           const int32_t* __restrict__ n_unique,
+                                                           float* __restrict__ side) {
+  const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= *n_unique) return;
+  const int lane = threadIdx.x & 63;
+  const AdamConst c = load_hyper(hyper);
+  const int32_t t0 = seg_begin[u], t1 = seg_begin[u + 1];
+  const int64_t row = sorted_ids[t0];
+  float* out = side + u * 3 * dim;
+  for (int64_t d = lane; d < dim; d += 64) {
+    float g = 0.f;
+    for (int32_t t = t0; t < t1; ++t) g += source_row(src, perm[t])[d];
+    float p = W[row * dim + d], m = M[row * dim + d], v = V[row * dim + d];
+    adam_elem(p, m, v, g, c);
+    out[d] = p;
+    out[dim + d] = m;
+    out[2 * dim + d] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_writeback_kernel(float* __restrict__ W, float* __restrict__ M,
+                                                             float* __restrict__ V, int64_t dim,
+                                                             const int32_t* __restrict__ sorted_ids,
+                                                             const int32_t* __restrict__ seg_begin,
+                                                             const int32_t* __restrict__ n_unique,
+                                                             const float* __restrict__ side) {
+  const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= *n_unique) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = sorted_ids[seg_begin[u]];
+  const float* in = side + u * 3 * dim;
+  for (int64_t d = lane; d < dim; d += 64) {
+    W[row * dim + d] = in[d];
+    M[row * dim + d] = in[dim + d];
+    V[row * dim + d] = in[2 * dim + d];
+  }
+}
+
+// the roofline kernel: 3 x 16-B loads + 3 x 16-B stores per lane per iteration
+__global__ __launch_bounds__(256) void adam_sweep_kernel(float4* __restrict__ W, float4* __restrict__ M,
+                                                         float4* __restrict__ V, int64_t n4,
+                                                         const double* __restrict__ hyper) {
+  const AdamConst c = load_hyper(hyper);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 p = W[i], m = M[i], v = V[i];
+    adam_elem_zero_grad(p.x, m.x, v.x, c);
+    adam_elem_zero_grad(p.y, m.y, v.y, c);
+    adam_elem_zero_grad(p.z, m.z, v.z, c);
+    adam_elem_zero_grad(p.w, m.w, v.w, c);
+    W[i] = p; M[i] = m; V[i] = v;
+  }
+}
+__global__ __launch_bounds__(256) void adam_sweep_scalar_kernel(float* __restrict__ W, float* __restrict__ M,
+                                                                float* __restrict__ V, int64_t i0, int64_t n,
+                                                                const double* __restrict__ hyper) {
+  const AdamConst c = load_hyper(hyper);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = i0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float p = W[i], m = M[i], v = V[i];
+    adam_elem_zero_grad(p, m, v, c);
+    W[i] = p; M[i] = m; V[i] = v;
+  }
+}
+
+// dense parameters: blockIdx.y = tensor, blockIdx.x = 1024-element chunk.  The descriptors
+// travel in the kernel arguments (by value), so there is no host->device copy to race with
+// and a captured graph keeps its own copy.
+constexpr int ADAM_BATCH = 64;
+struct AdamBatch { tt_adam_tensor t[ADAM_BATCH]; };
+__global__ __launch_bounds__(256) void adam_dense_kernel(const AdamBatch ts, const double* __restrict__ hyper) {
+  const tt_adam_tensor t = ts.t[blockIdx.y];
+  const AdamConst c = load_hyper(hyper);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < t.n; i += stride) {
+    float p = t.p[i], m = t.m[i], v = t.v[i];
+    adam_elem(p, m, v, t.g[i], c);
+    t.p[i] = p; t.m[i] = m; t.v[i] = v;
+  }
+}
+
+// dense gradient for torch.optim users: dense[row,:] = sum of that row's gradient rows
+__global__ __launch_bounds__(256) void rowgrad_dense_kernel(const tt_grad_sources src, int64_t dim,
+                                                            const int32_t* __restrict__ sorted_ids,
+                                                            const int32_t* __restrict__ perm,
+                                                            const int32_t* __restrict__ seg_begin,
+                                                            const int32_t* __restrict__ n_unique,
+                                                            float* __restrict__ dense) {
+  const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= *n_unique) return;
+  const int lane = threadIdx.x & 63;
+  const int32_t t0 = seg_begin[u], t1 = seg_begin[u + 1];
+  const int64_t row = sorted_ids[t0];
+  for (int64_t d = lane; d < dim; d += 64) {
+    float g = 0.f;
+    for (int32_t t = t0; t < t1; ++t) g += source_row(src, perm[t])[d];
+    dense[row * dim + d] = g;
+  }
+}
+
+static bool check_sources(const tt_grad_sources* s, int64_t n_ids, int64_t dim) {
+  if (!s || s->n_sources < 1 || s->n_sources > TT_MAX_GRAD_SOURCES || s->first[0] != 0) return false;
+  for (int k = 0; k < s->n_sources; ++k)
+    if (!s->rows[k] || s->ld[k] < dim || s->first[k + 1] < s->first[k]) return false;
+  return s->first[s->n_sources] == n_ids;
+}
+
+}  // namespace tt
+
+using namespace tt;
+
+extern "C" int tt_adam_advance(double* hyper, tt_stream_t stream) {
+  if (!hyper) return fail_arg("tt_adam_advance: null pointer");
+  adam_advance_kernel<<<1, 1, 0, S(stream)>>>(hyper);
+  return check_launch("adam_advance_kernel");
+}
+
+extern "C" int64_t tt_adam_table_workspace_bytes(int64_t n_ids, int64_t dim) {
+  if (n_ids <= 0 || dim <= 0) return 256;
+  return round_up(n_ids * 3 * dim * 4, 256);
+}
+
+extern "C" int tt_adam_table(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
+                             const tt_grad_sources* src, int64_t n_ids, const int32_t* sorted_ids,
+                             const int32_t* perm, const int32_t* seg_begin, const int32_t* n_unique,
+                             void* ws, int64_t ws_bytes, tt_stream_t stream) {
+  if (!W || !M || !V || !hyper) return fail_arg("tt_adam_table: null pointer");
+  if (n_rows <= 0 || dim <= 0 || n_ids < 0) return fail_arg("tt_adam_table: sizes");
+  hipStream_t st = S(stream);
+  int rc;
+  if (n_ids > 0) {
+    if (!sorted_ids || !perm || !seg_begin || !n_unique || !ws) return fail_arg("tt_adam_table: null plan");
+    if (!check_sources(src, n_ids, dim)) return fail_arg("tt_adam_table: gradient sources");
+    if (ws_bytes < tt_adam_table_workspace_bytes(n_ids, dim)) { set_error("tt_adam_table: workspace"); return TT_E_WORKSPACE; }
+    adam_touched_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, reinterpret_cast<float*>(ws));
+    if ((rc = check_launch("adam_touched_kernel"))) return rc;
+  }
+  const int64_t total = n_rows * dim;
+  const bool vec = ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(M) | reinterpret_cast<uintptr_t>(V)) & 15) == 0;
+  const int64_t n4 = vec ? total / 4 : 0;
+  if (n4 > 0) {
+    const int64_t blocks = ceil_div(n4, 256) < 256 * 8 ? ceil_div(n4, 256) : 256 * 8;
+    ProfScope prof("adam_sweep_kernel", st);
+    adam_sweep_kernel<<<(unsigned)blocks, 256, 0, st>>>(reinterpret_cast<float4*>(W), reinterpret_cast<float4*>(M), reinterpret_cast<float4*>(V), n4, hyper);
+    if ((rc = check_launch("adam_sweep_kernel"))) return rc;
+  }
+  if (n4 * 4 < total) {
+    const int64_t rem = total - n4 * 4;
+    const int64_t blocks = ceil_div(rem, 256) < 2048 ? ceil_div(rem, 256) : 2048;
+    adam_sweep_scalar_kernel<<<(unsigned)blocks, 256, 0, st>>>(W, M, V, n4 * 4, total, hyper);
+    if ((rc = check_launch("adam_sweep_scalar_kernel"))) return rc;
+  }
+  if (n_ids > 0) {
+    adam_writeback_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, dim, sorted_ids, seg_begin, n_unique, reinterpret_cast<const float*>(ws));
+    if ((rc = check_launch("adam_writeback_kernel"))) return rc;
+  }
+  return 0;
+}
+
+extern "C" int tt_adam_dense(const tt_adam_tensor* tensors, int32_t n_tensors, const double* hyper,
+                             tt_stream_t stream) {
+  if (!tensors || !hyper) return fail_arg("tt_adam_dense: null pointer");
+  if (n_tensors <= 0) return fail_arg("tt_adam_dense: sizes");
+  for (int32_t base = 0; base < n_tensors; base += ADAM_BATCH) {
+    const int32_t cnt = (n_tensors - base < ADAM_BATCH) ? n_tensors - base : ADAM_BATCH;
+    AdamBatch b;
+    int64_t max_n = 1;
+    for (int32_t i = 0; i < cnt; ++i) {
+      b.t[i] = tensors[base + i];
+      if (!b.t[i].p || !b.t[i].g || !b.t[i].m || !b.t[i].v || b.t[i].n < 0) return fail_arg("tt_adam_dense: descriptor");
+      if (b.t[i].n > max_n) max_n = b.t[i].n;
+    }
+    const int64_t bx = ceil_div(max_n, 1024) < 1024 ? ceil_div(max_n, 1024) : 1024;
+    adam_dense_kernel<<<dim3((unsigned)bx, (unsigned)cnt), 256, 0, S(stream)>>>(b, hyper);
+    const int rc = check_launch("adam_dense_kernel");
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int tt_rowgrad_dense(const tt_grad_sources* src, int64_t n_ids, int64_t dim, const int32_t* sorted_ids,
+                                const int32_t* perm, const int32_t* seg_begin, const int32_t* n_unique,
+                                float* dense_grad, tt_stream_t stream) {
+  if (!sorted_ids || !perm || !seg_begin || !n_unique || !dense_grad) return fail_arg("tt_rowgrad_dense: null pointer");
+  if (n_ids <= 0 || dim <= 0) return fail_arg("tt_rowgrad_dense: sizes");
+  if (!check_sources(src, n_ids, dim)) return fail_arg("tt_rowgrad_dense: gradient sources");
+  rowgrad_dense_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, S(stream)>>>(*src, dim, sorted_ids, perm, seg_begin, n_unique, dense_grad);
+  return check_launch("rowgrad_dense_kernel");
+}

@@ -1,0 +1,521 @@
+// K5: in-batch softmax cross entropy over S = U I^T without ever writing S.
+//
+// Decomposition (forward and both backward products share it):
+//   workgroup = 4 wavefronts; each wave owns 32 "stationary" rows a (users for the
+//   forward / dU, items for dI) and keeps them in REGISTERS as MFMA B-operand
+//   fragments for the whole kernel.  The "streamed" rows b arrive in 64-row tiles
+//   through double-buffered LDS (global -> registers -> LDS, one barrier per tile,
+//   next tile's loads in flight under the current tile's MFMAs).
+//   Per 32x32 sub-tile the wave computes the TRANSPOSED score tile
+//       St[b][a] = sum_k Y[b][k] * X[a][k]        (v_mfma_f32_32x32x2_f32)
+//   whose C/D register layout puts ONE stationary row a = lane&31 in each lane
+//   (the 16 registers hold 16 streamed rows b).  Consequences:
+//     * forward: the online-softmax state (running max, running sum) is two
+//       registers per lane; no cross-lane traffic until the single merge at the end.
+//     * backward: the gradient tile Gt[b][a] sits in exactly the A-operand layout of
+//       the second product dX[a][:] += sum_b G[a][b] * Y[b][:], whose reduction
+//       index b is permuted the same way on both operands -- the accumulator
+//       registers are fed to the MFMA directly, no LDS round trip, no shuffles.
+//   The streamed range is split over gridDim.y workgroups; partial softmax states
+//   / partial dX slabs are merged by a second tiny kernel in fixed order
+//   (deterministic, atomic-free).
+//   All exponentials are base-2 on pre-scaled logits (v_exp_f32).
+#include "common.hpp"
+
+namespace tt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BI = 128;  // stationary rows per workgroup (32 per wave)
+constexpr int BJ = 64;   // streamed rows per LDS tile
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float NEG_BIG = -3.0e38f;
+
+struct CeArgs {
+  const float* X;  // stationary [RX, D]
+  const float* Y;  // streamed   [RY, D]
+  int64_t ldx, ldy, RX, RY, D;
+  int64_t diag_offset;      // positive of user i is item i + diag_offset
+  int64_t tiles_per_split;  // streamed 64-row tiles per gridDim.y slice
+  int x_vec, y_vec;
+  // forward outputs (per split): running max (log2 domain), running sum, diagonal logit
+  float* part_m;
+  float* part_s;
+  float* diag;
+  // backward inputs / outputs
+  const float* lse;   // natural-log row LSE, indexed by USER row
+  const float* coef;  // dLoss/d row_ce, indexed by USER row
+  float* out;         // [splits][RX][D] slabs (or final [RX, ldo] when splits == 1)
+  int64_t ldo;
+  int splits;
+};
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// this wave's 32 stationary rows -> B-operand fragments: xr[g][c] = X[a][8g + 4h + c]
+template <int DP8>
+__device__ __forceinline__ void load_stationary(float (&xr)[DP8][4], const float* __restrict__ X,
+                                                int64_t ld, int64_t row, int64_t nrows, int64_t D,
+                                                int h, bool vec) {
+#pragma unroll
+  for (int g = 0; g < DP8; ++g) {
+    const int64_t k = 8 * g + 4 * h;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < nrows) {
+      const float* p = X + row * ld + k;
+      if (vec && k + 3 < D) {
+        v = *reinterpret_cast<const float4*>(p);
+      } else {
+        if (k + 0 < D) v.x = p[0];
+        if (k + 1 < D) v.y = p[1];
+        if (k + 2 < D) v.z = p[2];
+        if (k + 3 < D) v.w = p[3];
+      }
+    }
+    xr[g][0] = v.x; xr[g][1] = v.y; xr[g][2] = v.z; xr[g][3] = v.w;
+  }
+}
+
+// streamed tile [BJ][DP] : DP8/2 float4 per thread
+template <int DP8>
+__device__ __forceinline__ void tile_fetch(float4 (&st)[(DP8 + 1) / 2], const float* __restrict__ Y,
+                                           int64_t ld, int64_t row0, int64_t nrows, int64_t D, bool vec) {
+  constexpr int C4 = DP8 * 2;  // float4 per row
+#pragma unroll
+  for (int i = 0; i < (DP8 + 1) / 2; ++i) {
+    const int f = threadIdx.x + 256 * i;
+    const int64_t row = row0 + f / C4, k = 4 * (f % C4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < BJ * C4 && row < nrows) {
+      const float* p = Y + row * ld + k;
+      if (vec && k + 3 < D) {
+        v = *reinterpret_cast<const float4*>(p);
+      } else {
+        if (k + 0 < D) v.x = p[0];
+        if (k + 1 < D) v.y = p[1];
+        if (k + 2 < D) v.z = p[2];
+        if (k + 3 < D) v.w = p[3];
+      }
+    }
+    st[i] = v;
+  }
+}
+template <int DP8>
+__device__ __forceinline__ void tile_commit(const float4 (&st)[(DP8 + 1) / 2], float* Ys) {
+  constexpr int C4 = DP8 * 2, LD = DP8 * 8 + 4;
+#pragma unroll
+  for (int i = 0; i < (DP8 + 1) / 2; ++i) {
+    const int f = threadIdx.x + 256 * i;
+    if (f < BJ * C4) *reinterpret_cast<float4*>(Ys + (f / C4) * LD + 4 * (f % C4)) = st[i];
+  }
+}
+
+// St[b][a] for one 32-row sub-tile `jt` of the LDS tile
+template <int DP8>
+__device__ __forceinline__ f32x16 score_tile(const float* Ys, const float (&xr)[DP8][4], int jt, int r, int h) {
+  constexpr int LD = DP8 * 8 + 4;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const float* yrow = Ys + (jt * 32 + r) * LD + 4 * h;
+#pragma unroll
+  for (int g = 0; g < DP8; ++g) {
+    const float4 y = *reinterpret_cast<const float4*>(yrow + 8 * g);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.x, xr[g][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.y, xr[g][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.z, xr[g][2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.w, xr[g][3], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+__device__ __forceinline__ int brow(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
+
+// ------------------------------------------------------------------ forward
+template <int DP8>
+__global__ __launch_bounds__(256, (DP8 >= 16 ? 1 : 2)) void ce_fwd_kernel(const CeArgs p) {
+  constexpr int LD = DP8 * 8 + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* const smem = reinterpret_cast<float*>(smem_raw);
+  constexpr int TILE_FLOATS = BJ * LD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t a = (int64_t)blockIdx.x * BI + wave * 32 + r;  // this lane's user row
+
+  float xr[DP8][4];
+  load_stationary<DP8>(xr, p.X, p.ldx, a, p.RX, p.D, h, p.x_vec);
+
+  const int64_t ntiles_all = (p.RY + BJ - 1) / BJ;
+  const int64_t t0 = (int64_t)blockIdx.y * p.tiles_per_split;
+  const int64_t t1 = (t0 + p.tiles_per_split < ntiles_all) ? t0 + p.tiles_per_split : ntiles_all;
+
+  float m = NEG_BIG, s = 0.f, dg = 0.f;
+  bool has_dg = false;
+  const int64_t want = a + p.diag_offset;
+
+  float4 st[(DP8 + 1) / 2];
+  if (t0 < t1) {
+    tile_fetch<DP8>(st, p.Y, p.ldy, t0 * BJ, p.RY, p.D, p.y_vec);
+    tile_commit<DP8>(st, smem);
+  }
+  __syncthreads();
+  for (int64_t t = t0; t < t1; ++t) {
+    const int cur = (int)((t - t0) & 1);
+    if (t + 1 < t1) tile_fetch<DP8>(st, p.Y, p.ldy, (t + 1) * BJ, p.RY, p.D, p.y_vec);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      const f32x16 acc = score_tile<DP8>(smem + cur * TILE_FLOATS, xr, jt, r, h);
+      const int64_t b0 = t * BJ + jt * 32;
+      float v2[16];
+      float tmax = NEG_BIG;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t b = b0 + brow(e, h);
+        const bool valid = b < p.RY;
+        if (b == want) { dg = acc[e]; has_dg = true; }
+        v2[e] = valid ? acc[e] * LOG2E : NEG_BIG;
+        tmax = fmaxf(tmax, v2[e]);
+      }
+      const float mn = fmaxf(m, tmax);
+      float add = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) add += fast_exp2(v2[e] - mn);  // invalid -> exp2(-huge) = 0
+      s = s * fast_exp2(m - mn) + add;
+      m = mn;
+    }
+    if (t + 1 < t1) tile_commit<DP8>(st, smem + (cur ^ 1) * TILE_FLOATS);
+    __syncthreads();
+  }
+  // merge the two lane halves (same row a, disjoint b subsets)
+  const float mo = __shfl_xor(m, 32, 64), so = __shfl_xor(s, 32, 64), dgo = __shfl_xor(dg, 32, 64);
+  const bool has_o = __shfl_xor((int)has_dg, 32, 64) != 0;
+  const float M = fmaxf(m, mo);
+  const float Ssum = s * fast_exp2(m - M) + so * fast_exp2(mo - M);
+  if (h == 0 && a < p.RX) {
+    p.part_m[(int64_t)blockIdx.y * p.RX + a] = M;
+    p.part_s[(int64_t)blockIdx.y * p.RX + a] = Ssum;
+    if (has_dg || has_o) p.diag[a] = has_dg ? dg : dgo;
+  }
+}
+
+__global__ void ce_fwd_finish_kernel(const float* __restrict__ part_m, const float* __restrict__ part_s,
+                                     const float* __restrict__ diag, int64_t M, int splits,
+                                     float* __restrict__ row_lse, float* __restrict__ row_ce) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  float mx = NEG_BIG;
+  for (int z = 0; z < splits; ++z) mx = fmaxf(mx, part_m[(int64_t)z * M + i]);
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += part_s[(int64_t)z * M + i] * exp2f(part_m[(int64_t)z * M + i] - mx);
+  const float lse = (mx + log2f(s)) * LN2;
+  row_lse[i] = lse;
+  row_ce[i] = lse - diag[i];
+}
+
+// ------------------------------------------------------------------ backward
+// STREAM_STATS = false: stationary = users (stats per lane), streamed = items   -> dU
+// STREAM_STATS = true : stationary = items, streamed = users (stats per b)      -> dI
+template <int DP8, bool STREAM_STATS>
+__global__ __launch_bounds__(256, (DP8 >= 16 ? 1 : 2)) void ce_bwd_kernel(const CeArgs p) {
+  constexpr int LD = DP8 * 8 + 4;
+  constexpr int TD = (DP8 + 3) / 4;  // 32-column tiles of the output
+  constexpr int TILE_FLOATS = BJ * LD + (STREAM_STATS ? 2 * BJ : 0);
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* const smem = reinterpret_cast<float*>(smem_raw);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t a = (int64_t)blockIdx.x * BI + wave * 32 + r;
+
+  float xr[DP8][4];
+  load_stationary<DP8>(xr, p.X, p.ldx, a, p.RX, p.D, h, p.x_vec);
+
+  float lse2_a = 0.f, coef_a = 0.f;
+  if (!STREAM_STATS && a < p.RX) { lse2_a = p.lse[a] * LOG2E; coef_a = p.coef[a]; }
+
+  const int64_t ntiles_all = (p.RY + BJ - 1) / BJ;
+  const int64_t t0 = (int64_t)blockIdx.y * p.tiles_per_split;
+  const int64_t t1 = (t0 + p.tiles_per_split < ntiles_all) ? t0 + p.tiles_per_split : ntiles_all;
+
+  f32x16 dacc[TD];
+#pragma unroll
+  for (int d = 0; d < TD; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dacc[d][e] = 0.f;
+
+  float4 st[(DP8 + 1) / 2];
+  float st_lse = 0.f, st_coef = 0.f;  // threads 0..63 stage the streamed rows' stats
+  auto fetch = [&](int64_t t) {
+    tile_fetch<DP8>(st, p.Y, p.ldy, t * BJ, p.RY, p.D, p.y_vec);
+    if (STREAM_STATS && threadIdx.x < BJ) {
+      const int64_t b = t * BJ + threadIdx.x;
+      st_lse = (b < p.RY) ? p.lse[b] * LOG2E : 3.0e38f;
+      st_coef = (b < p.RY) ? p.coef[b] : 0.f;
+    }
+  };
+  auto commit = [&](int buf) {
+    float* yb = smem + buf * TILE_FLOATS;
+    tile_commit<DP8>(st, yb);
+    if (STREAM_STATS && threadIdx.x < BJ) {
+      yb[BJ * LD + threadIdx.x] = st_lse;
+      yb[BJ * LD + BJ + threadIdx.x] = st_coef;
+    }
+  };
+
+  if (t0 < t1) { fetch(t0); commit(0); }
+  __syncthreads();
+  for (int64_t t = t0; t < t1; ++t) {
+    const int cur = (int)((t - t0) & 1);
+    if (t + 1 < t1) fetch(t + 1);
+    const float* ys = smem + cur * TILE_FLOATS;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      const f32x16 acc = score_tile<DP8>(ys, xr, jt, r, h);
+      const int64_t b0 = t * BJ + jt * 32;
+      float gt[16];
+      if constexpr (!STREAM_STATS) {
+        const int64_t want = a + p.diag_offset;  // item index of this user's positive
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t b = b0 + brow(e, h);
+          const float pr = fast_exp2(fmaf(acc[e], LOG2E, -lse2_a));
+          const float gval = coef_a * (pr - ((b == want) ? 1.f : 0.f));
+          gt[e] = (b < p.RY) ? gval : 0.f;
+        }
+      } else {
+        const float* sl = ys + BJ * LD + jt * 32 + 4 * h;
+        const float* sc = sl + BJ;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 l4 = *reinterpret_cast<const float4*>(sl + 8 * q);
+          const float4 c4 = *reinterpret_cast<const float4*>(sc + 8 * q);
+          const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, cv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int e = 4 * q + c;
+            const int64_t b = b0 + brow(e, h);  // user row
+            const float pr = fast_exp2(fmaf(acc[e], LOG2E, -lv[c]));
+            gt[e] = cv[c] * (pr - ((a == b + p.diag_offset) ? 1.f : 0.f));  // coef 0 beyond RY
+          }
+        }
+      }
+      // dX[a][d] += sum_b G[a][b] * Y[b][d]; reduction index b = brow(e, h) on both operands
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float* yb = ys + (jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LD + r;
+#pragma unroll
+        for (int d = 0; d < TD; ++d)
+          dacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[e], yb[32 * d], dacc[d], 0, 0, 0);
+      }
+    }
+    if (t + 1 < t1) commit(cur ^ 1);
+    __syncthreads();
+  }
+
+  float* out = p.out + (p.splits > 1 ? (int64_t)blockIdx.y * p.RX * p.D : 0);
+  const int64_t ldo = p.splits > 1 ? p.D : p.ldo;
+  const int64_t abase = (int64_t)blockIdx.x * BI + wave * 32;
+#pragma unroll
+  for (int d = 0; d < TD; ++d) {
+    const int64_t col = 32 * d + r;
+    if (col >= p.D) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t row = abase + brow(e, h);
+      if (row < p.RX) out[row * ldo + col] = dacc[d][e];
+    }
+  }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, int splits, int64_t rows, int64_t D,
+                                   float* __restrict__ out, int64_t ldo) {
+  const int64_t total = rows * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += slabs[(int64_t)z * total + i];
+    out[(i / D) * ldo + (i % D)] = v;
+  }
+}
+
+// ref:src/two_tower_base_retrieval.py:322,334-343 for [B,T] labels, one workgroup.
+__global__ __launch_bounds__(1024) void weighted_mean_loss_kernel(const float* __restrict__ labels, int64_t B,
+                                                                  int64_t T, const float* __restrict__ uvw,
+                                                                  const float* __restrict__ row_ce,
+                                                                  float* __restrict__ w_out,
+                                                                  float* __restrict__ coef_out,
+                                                                  float* __restrict__ loss_out) {
+  __shared__ float red[16];
+  __shared__ float bcast;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float mx = NEG_BIG;
+  for (int64_t i = threadIdx.x; i < B; i += blockDim.x) {
+    float nuv = 0.f;
+    for (int64_t t = 0; t < T; ++t) nuv += labels[i * T + t] * uvw[t];
+    nuv = fmaxf(nuv, 0.000001f);
+    w_out[i] = nuv;
+    mx = fmaxf(mx, nuv);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = red[0];
+    for (int k = 1; k < (int)(blockDim.x >> 6); ++k) v = fmaxf(v, red[k]);
+    bcast = v;
+  }
+  __syncthreads();
+  const float wmax = bcast;
+  float acc = 0.f;
+  const float invB = 1.0f / (float)B;
+  for (int64_t i = threadIdx.x; i < B; i += blockDim.x) {
+    const float w = w_out[i] / wmax;
+    w_out[i] = w;
+    coef_out[i] = w * invB;
+    acc += row_ce[i] * w;
+  }
+  acc = wave_sum(acc);
+  __syncthreads();
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = 0.f;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) v += red[k];
+    *loss_out = v * invB;
+  }
+}
+
+struct CePlan {
+  int dp8, splits;
+  int64_t tiles_per_split;
+};
+static bool plan_ce(int64_t RX, int64_t RY, int64_t D, CePlan& pl) {
+  if (D <= 32) pl.dp8 = 4; else if (D <= 64) pl.dp8 = 8; else if (D <= 128) pl.dp8 = 16; else return false;
+  const int64_t rowblocks = ceil_div(RX, BI), tiles = ceil_div(RY, BJ);
+  int64_t splits = ceil_div(512, rowblocks);
+  if (splits > ceil_div(tiles, 4)) splits = ceil_div(tiles, 4);
+  if (splits > 64) splits = 64;
+  if (splits < 1) splits = 1;
+  pl.tiles_per_split = ceil_div(tiles, splits);
+  pl.splits = (int)ceil_div(tiles, pl.tiles_per_split);
+  return true;
+}
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename K>
+static int opt_in_lds(K kernel, size_t lds, const char* name) {
+  if (lds <= 64 * 1024) return 0;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
+template <int DP8>
+static int launch_fwd(const CeArgs& a, dim3 grid, hipStream_t st) {
+  const size_t lds = 2 * BJ * (DP8 * 8 + 4) * sizeof(float);
+  int rc = opt_in_lds(ce_fwd_kernel<DP8>, lds, "ce_fwd_kernel");
+  if (rc) return rc;
+  ProfScope prof("ce_fwd_kernel", st);
+  ce_fwd_kernel<DP8><<<grid, 256, lds, st>>>(a);
+  return check_launch("ce_fwd_kernel");
+}
+template <int DP8, bool SS>
+static int launch_bwd(const CeArgs& a, dim3 grid, hipStream_t st) {
+  const size_t lds = 2 * (BJ * (DP8 * 8 + 4) + (SS ? 2 * BJ : 0)) * sizeof(float);
+  int rc = opt_in_lds(ce_bwd_kernel<DP8, SS>, lds, "ce_bwd_kernel");
+  if (rc) return rc;
+  ProfScope prof("ce_bwd_kernel", st);
+  ce_bwd_kernel<DP8, SS><<<grid, 256, lds, st>>>(a);
+  return check_launch("ce_bwd_kernel");
+}
+
+}  // namespace tt
+
+using namespace tt;
+
+extern "C" int64_t tt_inbatch_ce_workspace_bytes(int64_t M, int64_t N, int64_t D) {
+  if (M <= 0 || N <= 0 || D <= 0) return 0;
+  CePlan pu, pi;
+  if (!plan_ce(M, N, D, pu) || !plan_ce(N, M, D, pi)) return 0;
+  const int64_t fwd = round_up((2 * (int64_t)pu.splits * M + M) * 4, 256);
+  const int64_t du = pu.splits > 1 ? round_up((int64_t)pu.splits * M * D * 4, 256) : 0;
+  const int64_t di = pi.splits > 1 ? round_up((int64_t)pi.splits * N * D * 4, 256) : 0;
+  const int64_t bwd = du + di;
+  return fwd > bwd ? fwd : bwd;
+}
+
+extern "C" int tt_inbatch_ce_fwd(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M,
+                                 int64_t N, int64_t D, int64_t diag_offset, float* row_lse, float* row_ce,
+                                 void* ws, int64_t ws_bytes, tt_stream_t stream) {
+  if (!U || !I || !row_lse || !row_ce || !ws) return fail_arg("tt_inbatch_ce_fwd: null pointer");
+  if (M <= 0 || N <= 0 || D <= 0 || ldu < D || ldi < D) return fail_arg("tt_inbatch_ce_fwd: sizes");
+  if (diag_offset < 0 || diag_offset + M > N) return fail_arg("tt_inbatch_ce_fwd: diagonal outside the item block");
+  CePlan pl;
+  if (!plan_ce(M, N, D, pl)) { set_error("tt_inbatch_ce: D=%lld > 128 not implemented", (long long)D); return TT_E_UNSUPPORTED; }
+  if (ws_bytes < tt_inbatch_ce_workspace_bytes(M, N, D)) { set_error("tt_inbatch_ce_fwd: workspace"); return TT_E_WORKSPACE; }
+  float* w = reinterpret_cast<float*>(ws);
+  CeArgs a{};
+  a.X = U; a.Y = I; a.ldx = ldu; a.ldy = ldi; a.RX = M; a.RY = N; a.D = D;
+  a.diag_offset = diag_offset; a.tiles_per_split = pl.tiles_per_split; a.splits = pl.splits;
+  a.x_vec = (ldu % 4 == 0) && al16(U); a.y_vec = (ldi % 4 == 0) && al16(I);
+  a.part_m = w; a.part_s = w + (int64_t)pl.splits * M; a.diag = w + 2 * (int64_t)pl.splits * M;
+  dim3 grid((unsigned)ceil_div(M, BI), (unsigned)pl.splits);
+  hipStream_t st = S(stream);
+  int rc = pl.dp8 == 4 ? launch_fwd<4>(a, grid, st) : pl.dp8 == 8 ? launch_fwd<8>(a, grid, st) : launch_fwd<16>(a, grid, st);
+  if (rc) return rc;
+  ce_fwd_finish_kernel<<<(unsigned)ceil_div(M, 256), 256, 0, st>>>(a.part_m, a.part_s, a.diag, M, pl.splits, row_lse, row_ce);
+  return check_launch("ce_fwd_finish_kernel");
+}
+
+extern "C" int tt_inbatch_ce_bwd(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M,
+                                 int64_t N, int64_t D, int64_t diag_offset, const float* row_lse,
+                                 const float* coef, float* dU, int64_t lddu, float* dI, int64_t lddi,
+                                 void* ws, int64_t ws_bytes, tt_stream_t stream) {
+  if (!U || !I || !row_lse || !coef || !dU || !dI || !ws) return fail_arg("tt_inbatch_ce_bwd: null pointer");
+  if (M <= 0 || N <= 0 || D <= 0 || ldu < D || ldi < D || lddu < D || lddi < D) return fail_arg("tt_inbatch_ce_bwd: sizes");
+  CePlan pu, pi;
+  if (!plan_ce(M, N, D, pu) || !plan_ce(N, M, D, pi)) { set_error("tt_inbatch_ce: D=%lld > 128 not implemented", (long long)D); return TT_E_UNSUPPORTED; }
+  if (ws_bytes < tt_inbatch_ce_workspace_bytes(M, N, D)) { set_error("tt_inbatch_ce_bwd: workspace"); return TT_E_WORKSPACE; }
+  hipStream_t st = S(stream);
+  char* wsb = reinterpret_cast<char*>(ws);
+  float* slab_u = reinterpret_cast<float*>(wsb);
+  float* slab_i = reinterpret_cast<float*>(wsb + (pu.splits > 1 ? round_up((int64_t)pu.splits * M * D * 4, 256) : 0));
+  int rc;
+  {  // dU: stationary users, streamed items
+    CeArgs a{};
+    a.X = U; a.Y = I; a.ldx = ldu; a.ldy = ldi; a.RX = M; a.RY = N; a.D = D; a.diag_offset = diag_offset;
+    a.tiles_per_split = pu.tiles_per_split; a.splits = pu.splits;
+    a.x_vec = (ldu % 4 == 0) && al16(U); a.y_vec = (ldi % 4 == 0) && al16(I);
+    a.lse = row_lse; a.coef = coef; a.out = pu.splits > 1 ? slab_u : dU; a.ldo = lddu;
+    dim3 grid((unsigned)ceil_div(M, BI), (unsigned)pu.splits);
+    rc = pu.dp8 == 4 ? launch_bwd<4, false>(a, grid, st) : pu.dp8 == 8 ? launch_bwd<8, false>(a, grid, st) : launch_bwd<16, false>(a, grid, st);
+    if (rc) return rc;
+    if (pu.splits > 1) {
+      slab_reduce_kernel<<<(unsigned)(ceil_div(M * D, 256) < 2048 ? ceil_div(M * D, 256) : 2048), 256, 0, st>>>(slab_u, pu.splits, M, D, dU, lddu);
+      if ((rc = check_launch("slab_reduce_kernel"))) return rc;
+    }
+  }
+  {  // dI: stationary items, streamed users
+    CeArgs a{};
+    a.X = I; a.Y = U; a.ldx = ldi; a.ldy = ldu; a.RX = N; a.RY = M; a.D = D; a.diag_offset = diag_offset;
+    a.tiles_per_split = pi.tiles_per_split; a.splits = pi.splits;
+    a.x_vec = (ldi % 4 == 0) && al16(I); a.y_vec = (ldu % 4 == 0) && al16(U);
+    a.lse = row_lse; a.coef = coef; a.out = pi.splits > 1 ? slab_i : dI; a.ldo = lddi;
+    dim3 grid((unsigned)ceil_div(N, BI), (unsigned)pi.splits);
+    rc = pi.dp8 == 4 ? launch_bwd<4, true>(a, grid, st) : pi.dp8 == 8 ? launch_bwd<8, true>(a, grid, st) : launch_bwd<16, true>(a, grid, st);
+    if (rc) return rc;
+    if (pi.splits > 1) {
+      slab_reduce_kernel<<<(unsigned)(ceil_div(N * D, 256) < 2048 ? ceil_div(N * D, 256) : 2048), 256, 0, st>>>(slab_i, pi.splits, N, D, dI, lddi);
+      if ((rc = check_launch("slab_reduce_kernel"))) return rc;
+    }
+  }
+  return 0;
+}
+
+extern "C" int tt_weighted_mean_loss(const float* labels, int64_t B, int64_t T, const float* uvw,
+                                     const float* row_ce, float* w_out, float* coef_out, float* loss_out,
+                                     tt_stream_t stream) {
+  if (!labels || !uvw || !row_ce || !w_out || !coef_out || !loss_out) return fail_arg("tt_weighted_mean_loss: null pointer");
+  if (B <= 0 || T <= 0) return fail_arg("tt_weighted_mean_loss: sizes");
+  weighted_mean_loss_kernel<<<1, 1024, 0, S(stream)>>>(labels, B, T, uvw, row_ce, w_out, coef_out, loss_out);
+  return check_launch("weighted_mean_loss_kernel");
+}

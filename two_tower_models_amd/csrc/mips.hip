@@ -1,0 +1,478 @@
+// K6: brute-force MIPS top-K (torch.topk(q @ corpus.T, K), ref:src/baseline_mips_module.py:57-61)
+// whose [B, C] score matrix never reaches HBM, exact under the total order
+// (score desc, index asc).
+//
+// Every score is mapped to a 64-bit key  (orderable(score) << 32) | ~index : larger key =
+// better item, all keys of one query are distinct.  Three stages per batch of queries:
+//   pass 1   score GEMM; each lane reduces the keys of a fixed group of 64 corpus rows to
+//            their max and stores it:  gmax[group][query]                (MFMA-bound)
+//   select   tau[q] = K-th largest group max of query q (MSD radix select).  At least K
+//            items have key >= tau, and every item with key >= tau lies in one of exactly K
+//            groups, so at most 64*K items qualify (typically ~1.01 K on random data).
+//   pass 2   the SAME score GEMM (bit-identical arithmetic); items with key >= tau[q] are
+//            appended to the query's candidate list                       (MFMA-bound)
+//   sort     one wavefront per query: stable LSD radix sort of the candidates, emit top K.
+//
+// GEMM structure = the in-batch-softmax kernel's: each wave keeps 32 queries in registers
+// as MFMA B-operand fragments, corpus rows stream through double-buffered LDS as the A
+// operand, so the C/D layout gives ONE query per lane and 16 corpus rows per tile in that
+// lane's registers -- the group max needs no cross-lane traffic.
+//   fp32 : v_mfma_f32_32x32x2_f32   (exact fp32 fmaf chain)
+//   bf16 : v_mfma_f32_32x32x16_bf16 (exact products, fp32 accumulate)
+#include "common.hpp"
+
+namespace tt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned long long u64;
+
+constexpr int QB_WG = 128;   // queries per workgroup (32 per wave)
+constexpr int CT = 64;       // corpus rows per LDS tile
+constexpr int CHUNK = 128;   // corpus rows per group-pair: lane-half h owns 64 of them
+constexpr int GROUP = 64;
+
+__device__ __forceinline__ uint32_t f2ord(float x) {
+  const uint32_t u = __float_as_uint(x);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+  const uint32_t u = o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ u64 make_key(float score, uint32_t idx) {
+  return ((u64)f2ord(score) << 32) | (u64)(0xFFFFFFFFu - idx);
+}
+
+struct MipsArgs {
+  const void* Q;       // [B, D] queries (fp32 or bf16)
+  const void* Cm;      // [C, D] corpus
+  int64_t B, C, D;
+  int64_t q0, nq;      // this batch: queries q0 .. q0+nq
+  int64_t chunks_per_split, n_chunks;
+  u64* gmax;           // [2*n_chunks][nq]
+  const u64* tau;      // [nq]
+  u64* cand;           // [nq][cap]
+  int32_t* count;      // [nq]
+  int64_t cap;
+  int vec_ok;
+};
+
+// ---------------------------------------------------------------- operand traits
+// F32: DPX = D padded / 8 ; BF16: DPX = D padded / 16
+template <int DT, int DPX>
+struct Op;
+
+template <int DPX>
+struct Op<TT_F32, DPX> {
+  static constexpr int DP = DPX * 8;
+  static constexpr int LDB = (DP + 4) * 4;  // LDS row stride in bytes
+  static constexpr int NLOAD = (CT * DP / 4 + 255) / 256;
+  struct Frag { float v[DPX][4]; };
+  static __device__ __forceinline__ void load_queries(Frag& f, const void* Q, int64_t row, int64_t nrows, int64_t D, int h, bool vec) {
+    const float* X = reinterpret_cast<const float*>(Q);
+#pragma unroll
+    for (int g = 0; g < DPX; ++g) {
+      const int64_t k = 8 * g + 4 * h;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < nrows) {
+        const float* p = X + row * D + k;
+        if (vec && k + 3 < D) v = *reinterpret_cast<const float4*>(p);
+        else {
+          if (k + 0 < D) v.x = p[0];
+          if (k + 1 < D) v.y = p[1];
+          if (k + 2 < D) v.z = p[2];
+          if (k + 3 < D) v.w = p[3];
+        }
+      }
+      f.v[g][0] = v.x; f.v[g][1] = v.y; f.v[g][2] = v.z; f.v[g][3] = v.w;
+    }
+  }
+  static __device__ __forceinline__ void fetch(uint4 (&st)[NLOAD], const void* Cm, int64_t row0, int64_t nrows, int64_t D, bool vec) {
+    constexpr int C4 = DP / 4;
+    const float* Y = reinterpret_cast<const float*>(Cm);
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      const int f = threadIdx.x + 256 * i;
+      const int64_t row = row0 + f / C4, k = 4 * (f % C4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < CT * C4 && row < nrows) {
+        const float* p = Y + row * D + k;
+        if (vec && k + 3 < D) v = *reinterpret_cast<const float4*>(p);
+        else {
+          if (k + 0 < D) v.x = p[0];
+          if (k + 1 < D) v.y = p[1];
+          if (k + 2 < D) v.z = p[2];
+          if (k + 3 < D) v.w = p[3];
+        }
+      }
+      st[i] = make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w));
+    }
+  }
+  static __device__ __forceinline__ void commit(const uint4 (&st)[NLOAD], char* Ys) {
+    constexpr int C4 = DP / 4;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      const int f = threadIdx.x + 256 * i;
+      if (f < CT * C4) *reinterpret_cast<uint4*>(Ys + (f / C4) * LDB + 16 * (f % C4)) = st[i];
+    }
+  }
+  static __device__ __forceinline__ f32x16 tile(const char* Ys, const Frag& q, int jt, int r, int h) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const char* yrow = Ys + (jt * 32 + r) * LDB + 16 * h;
+#pragma unroll
+    for (int g = 0; g < DPX; ++g) {
+      const float4 y = *reinterpret_cast<const float4*>(yrow + 32 * g);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.x, q.v[g][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.y, q.v[g][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.z, q.v[g][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.w, q.v[g][3], acc, 0, 0, 0);
+    }
+    return acc;
+  }
+};
+
+template <int DPX>
+struct Op<TT_BF16, DPX> {
+  static constexpr int DP = DPX * 16;
+  static constexpr int LDB = DP * 2 + 16;
+  static constexpr int NLOAD = (CT * DP / 8 + 255) / 256;
+  struct Frag { uint4 v[DPX]; };
+  static __device__ __forceinline__ uint4 load8(const uint16_t* X, int64_t row, int64_t k, int64_t D, bool vec) {
+    const uint16_t* p = X + row * D + k;
+    if (vec && k + 7 < D) return *reinterpret_cast<const uint4*>(p);
+    uint16_t t[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) t[c] = (k + c < D) ? p[c] : (uint16_t)0;
+    return make_uint4(t[0] | ((uint32_t)t[1] << 16), t[2] | ((uint32_t)t[3] << 16), t[4] | ((uint32_t)t[5] << 16), t[6] | ((uint32_t)t[7] << 16));
+  }
+  static __device__ __forceinline__ void load_queries(Frag& f, const void* Q, int64_t row, int64_t nrows, int64_t D, int h, bool vec) {
+    const uint16_t* X = reinterpret_cast<const uint16_t*>(Q);
+#pragma unroll
+    for (int g = 0; g < DPX; ++g)
+      f.v[g] = (row < nrows) ? load8(X, row, 16 * g + 8 * h, D, vec) : make_uint4(0, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void fetch(uint4 (&st)[NLOAD], const void* Cm, int64_t row0, int64_t nrows, int64_t D, bool vec) {
+    constexpr int C8 = DP / 8;
+    const uint16_t* Y = reinterpret_cast<const uint16_t*>(Cm);
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      const int f = threadIdx.x + 256 * i;
+      const int64_t row = row0 + f / C8, k = 8 * (f % C8);
+      st[i] = (f < CT * C8 && row < nrows) ? load8(Y, row, k, D, vec) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  static __device__ __forceinline__ void commit(const uint4 (&st)[NLOAD], char* Ys) {
+    constexpr int C8 = DP / 8;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      const int f = threadIdx.x + 256 * i;
+      if (f < CT * C8) *reinterpret_cast<uint4*>(Ys + (f / C8) * LDB + 16 * (f % C8)) = st[i];
+    }
+  }
+  static __device__ __forceinline__ f32x16 tile(const char* Ys, const Frag& q, int jt, int r, int h) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const char* yrow = Ys + (jt * 32 + r) * LDB + 16 * h;
+#pragma unroll
+    for (int g = 0; g < DPX; ++g) {
+      const uint4 y = *reinterpret_cast<const uint4*>(yrow + 32 * g);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, y), __builtin_bit_cast(bf16x8, q.v[g]), acc, 0, 0, 0);
+    }
+    return acc;
+  }
+};
+
+// ---------------------------------------------------------------- the two GEMM passes
+template <int DT, int DPX, int PASS>
+__global__ __launch_bounds__(256) void mips_score_kernel(const MipsArgs p) {
+  using O = Op<DT, DPX>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int TILE_BYTES = CT * O::LDB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t ql = (int64_t)blockIdx.x * QB_WG + wave * 32 + r;  // query index inside the batch
+  const bool q_ok = ql < p.nq;
+
+  typename O::Frag qf;
+  O::load_queries(qf, p.Q, p.q0 + ql, p.q0 + p.nq, p.D, h, p.vec_ok);
+
+  const int64_t c0 = (int64_t)blockIdx.y * p.chunks_per_split;
+  const int64_t c1 = (c0 + p.chunks_per_split < p.n_chunks) ? c0 + p.chunks_per_split : p.n_chunks;
+  const int64_t t0 = c0 * (CHUNK / CT), t1 = c1 * (CHUNK / CT);
+
+  u64 tau = 0;
+  if (PASS == 2 && q_ok) tau = p.tau[ql];
+
+  uint4 st[O::NLOAD];
+  if (t0 < t1) {
+    O::fetch(st, p.Cm, t0 * CT, p.C, p.D, p.vec_ok);
+    O::commit(st, smem_raw);
+  }
+  __syncthreads();
+  float best = 0.f;
+  uint32_t best_idx = 0;
+  bool have = false;
+  for (int64_t t = t0; t < t1; ++t) {
+    const int cur = (int)((t - t0) & 1);
+    if (t + 1 < t1) O::fetch(st, p.Cm, (t + 1) * CT, p.C, p.D, p.vec_ok);
+    const char* ys = smem_raw + cur * TILE_BYTES;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      const f32x16 acc = O::tile(ys, qf, jt, r, h);
+      const int64_t b0 = t * CT + jt * 32 + 4 * h;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = b0 + (e & 3) + 8 * (e >> 2);
+        const float s = acc[e];
+        if (row < p.C) {
+          if (PASS == 1) {
+            // rows are visited in increasing index order inside a lane: strict > keeps the
+            // smaller index on equal scores == max of the composite key
+            if (!have || s > best) { best = s; best_idx = (uint32_t)row; have = true; }
+          } else if (q_ok) {
+            const u64 key = make_key(s, (uint32_t)row);
+            if (key >= tau) {
+              const int pos = atomicAdd(&p.count[ql], 1);
+              if (pos < p.cap) p.cand[ql * p.cap + pos] = key;
+            }
+          }
+        }
+      }
+    }
+    if (PASS == 1 && ((t + 1) % (CHUNK / CT)) == 0) {  // a 128-row chunk is complete
+      const int64_t chunk = t / (CHUNK / CT);
+      if (q_ok) p.gmax[(2 * chunk + h) * p.nq + ql] = have ? make_key(best, best_idx) : 0ull;
+      have = false;
+    }
+    if (t + 1 < t1) O::commit(st, smem_raw + (cur ^ 1) * TILE_BYTES);
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- K-th largest group key
+// workgroup = 32 queries x 8 group slices; keys are read gmax[g][q] (256-B coalesced rows).
+__global__ __launch_bounds__(256) void mips_select_kernel(const u64* __restrict__ gmax, int64_t n_groups, int64_t nq,
+                                                          int64_t K, u64* __restrict__ tau) {
+  __shared__ int32_t hist[32][257];
+  __shared__ u64 prefix_s[32];
+  __shared__ int32_t want_s[32];
+  __shared__ int32_t done_s[32];
+  const int ql = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  const int64_t q = (int64_t)blockIdx.x * 32 + ql;
+  if (threadIdx.x < 32) { prefix_s[ql] = 0; want_s[ql] = (int32_t)K; done_s[ql] = 0; }
+  __syncthreads();
+  for (int pass = 0; pass < 8; ++pass) {
+    const int shift = 56 - 8 * pass;
+    for (int i = threadIdx.x; i < 32 * 257; i += 256) (&hist[0][0])[i] = 0;
+    __syncthreads();
+    const u64 prefix = prefix_s[ql];
+    const u64 himask = (pass == 0) ? 0ull : (~0ull << (shift + 8));
+    if (q < nq && !done_s[ql]) {
+      for (int64_t g = slice; g < n_groups; g += 8) {
+        const u64 key = gmax[g * nq + q];
+        if ((key & himask) == prefix) atomicAdd(&hist[ql][(int)((key >> shift) & 255)], 1);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && q < nq && !done_s[ql]) {
+      int32_t want = want_s[ql], acc = 0;
+      int d = 255;
+      for (; d > 0; --d) {
+        if (acc + hist[ql][d] >= want) break;
+        acc += hist[ql][d];
+      }
+      prefix_s[ql] = prefix | ((u64)d << shift);
+      want_s[ql] = want - acc;
+      // exactly the remaining `want` keys share this prefix: every key with the prefix is
+      // selected, so the smallest possible key with that prefix is an exact threshold
+      if (hist[ql][d] == want - acc) done_s[ql] = 1;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 32 && q < nq) tau[q] = prefix_s[ql];
+}
+
+// ---------------------------------------------------------------- per-query candidate sort
+// one wavefront per query: stable LSD radix sort (8-bit digits) on ~key (ascending ~key ==
+// descending key), ping-pong between the query's two candidate buffers, then emit top K.
+__global__ __launch_bounds__(64) void mips_sort_emit_kernel(u64* __restrict__ cand, u64* __restrict__ tmp,
+                                                            const int32_t* __restrict__ count, int64_t cap, int64_t K,
+                                                            int64_t q0, int64_t* __restrict__ idx_out,
+                                                            float* __restrict__ score_out, int32_t* __restrict__ status) {
+  __shared__ int32_t base[256];
+  const int lane = threadIdx.x;
+  const int64_t ql = blockIdx.x;
+  int32_t n = count[ql];
+  if (n > cap) { n = (int32_t)cap; if (lane == 0) atomicOr(status, 1); }  // cannot happen (bound proven above)
+  if (n < K && lane == 0) atomicOr(status, 2);
+  u64* a = cand + ql * cap;
+  u64* b = tmp + ql * cap;
+  const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int pass = 0; pass < 8; ++pass) {
+    const int shift = 8 * pass;
+    for (int d = lane; d < 256; d += 64) base[d] = 0;
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) atomicAdd(&base[(int)((~a[i] >> shift) & 255)], 1);
+    __syncthreads();
+    {  // exclusive scan of the 256 counters, 4 per lane
+      int32_t t[4], s = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { t[c] = base[4 * lane + c]; s += t[c]; }
+      int32_t inc = s;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int32_t u = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += u;
+      }
+      int32_t run = inc - s;
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { base[4 * lane + c] = run; run += t[c]; }
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int i = i0 + lane;
+      const bool active = i < n;
+      const u64 key = active ? a[i] : 0ull;
+      const int d = (int)((~key >> shift) & 255);
+      u64 mask = __ballot(active);
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit) {
+        const u64 bal = __ballot((d >> bit) & 1);
+        mask &= ((d >> bit) & 1) ? bal : ~bal;
+      }
+      const int rank = __popcll(mask & lt_mask);
+      int32_t pos = 0;
+      if (active) pos = base[d] + rank;
+      __builtin_amdgcn_wave_barrier();
+      if (active && rank == 0) base[d] += __popcll(mask);
+      __builtin_amdgcn_wave_barrier();
+      if (active) b[pos] = key;
+    }
+    __syncthreads();
+    u64* sw = a; a = b; b = sw;
+  }
+  // 8 passes: the sorted data is back in the first buffer (`a` == cand slice)
+  for (int64_t k = lane; k < K; k += 64) {
+    const u64 key = (k < n) ? a[k] : 0ull;
+    idx_out[(q0 + ql) * K + k] = (k < n) ? (int64_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) : (int64_t)-1;
+    score_out[(q0 + ql) * K + k] = (k < n) ? ord2f((uint32_t)(key >> 32)) : 0.f;
+  }
+}
+
+__global__ void mips_zero_kernel(u64* tau, int32_t* count, int64_t nq) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nq) { tau[i] = 0; count[i] = 0; }
+}
+
+constexpr int64_t MIPS_QBATCH = 1024;
+
+struct MipsPlan {
+  int dpx;
+  int64_t n_chunks, n_groups, cap, qb, splits, chunks_per_split;
+};
+static bool plan_mips(int64_t B, int64_t C, int64_t D, int64_t K, int dtype, MipsPlan& pl) {
+  if (dtype == TT_F32) {
+    if (D <= 32) pl.dpx = 4; else if (D <= 64) pl.dpx = 8; else if (D <= 128) pl.dpx = 16; else return false;
+  } else if (dtype == TT_BF16) {
+    if (D <= 32) pl.dpx = 2; else if (D <= 64) pl.dpx = 4; else if (D <= 128) pl.dpx = 8; else return false;
+  } else {
+    return false;
+  }
+  pl.n_chunks = ceil_div(C, CHUNK);
+  pl.n_groups = 2 * pl.n_chunks;
+  const int64_t sel = K < pl.n_groups ? K : pl.n_groups;
+  pl.cap = sel * GROUP;
+  pl.qb = B < MIPS_QBATCH ? B : MIPS_QBATCH;
+  const int64_t qblocks = ceil_div(pl.qb, QB_WG);
+  int64_t splits = ceil_div(1024, qblocks);
+  if (splits > pl.n_chunks) splits = pl.n_chunks;
+  if (splits < 1) splits = 1;
+  pl.chunks_per_split = ceil_div(pl.n_chunks, splits);
+  pl.splits = ceil_div(pl.n_chunks, pl.chunks_per_split);
+  return true;
+}
+
+template <int DT, int DPX, int PASS>
+static int launch_score(const MipsArgs& a, dim3 grid, hipStream_t st) {
+  const size_t lds = 2 * CT * Op<DT, DPX>::LDB;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mips_score_kernel<DT, DPX, PASS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("mips_score_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  ProfScope prof("mips_score_kernel", st);
+  mips_score_kernel<DT, DPX, PASS><<<grid, 256, lds, st>>>(a);
+  return check_launch("mips_score_kernel");
+}
+template <int PASS>
+static int dispatch_score(int dtype, int dpx, const MipsArgs& a, dim3 grid, hipStream_t st) {
+  if (dtype == TT_F32) {
+    if (dpx == 4) return launch_score<TT_F32, 4, PASS>(a, grid, st);
+    if (dpx == 8) return launch_score<TT_F32, 8, PASS>(a, grid, st);
+    return launch_score<TT_F32, 16, PASS>(a, grid, st);
+  }
+  if (dpx == 2) return launch_score<TT_BF16, 2, PASS>(a, grid, st);
+  if (dpx == 4) return launch_score<TT_BF16, 4, PASS>(a, grid, st);
+  return launch_score<TT_BF16, 8, PASS>(a, grid, st);
+}
+
+}  // namespace tt
+
+using namespace tt;
+
+extern "C" int64_t tt_mips_workspace_bytes(int64_t B, int64_t C, int64_t D, int64_t K, int dtype) {
+  MipsPlan pl;
+  if (B <= 0 || C <= 0 || D <= 0 || K <= 0 || K > C || !plan_mips(B, C, D, K, dtype, pl)) return 256;
+  return round_up(pl.n_groups * pl.qb * 8, 256)  // gmax
+         + round_up(pl.qb * 8, 256)              // tau
+         + round_up(pl.qb * 4, 256)              // count
+         + 2 * round_up(pl.qb * pl.cap * 8, 256) // candidates + sort ping-pong
+         + 256;                                  // status word
+}
+
+extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, int64_t B, int64_t C, int64_t D,
+                            int64_t K, int64_t* idx_out, float* score_out, void* ws, int64_t ws_bytes,
+                            tt_stream_t stream) {
+  if (!query || !corpus || !idx_out || !score_out || !ws) return fail_arg("tt_mips_topk: null pointer");
+  if (B <= 0 || C <= 0 || D <= 0 || K <= 0 || K > C || C >= ((int64_t)1 << 32)) return fail_arg("tt_mips_topk: sizes");
+  MipsPlan pl;
+  if (!plan_mips(B, C, D, K, dtype, pl)) { set_error("tt_mips_topk: D=%lld > 128 or unknown dtype", (long long)D); return TT_E_UNSUPPORTED; }
+  if (ws_bytes < tt_mips_workspace_bytes(B, C, D, K, dtype)) { set_error("tt_mips_topk: workspace"); return TT_E_WORKSPACE; }
+  hipStream_t st = S(stream);
+  Carver cv(ws);
+  u64* gmax = cv.take<u64>(pl.n_groups * pl.qb);
+  u64* tau = cv.take<u64>(pl.qb);
+  int32_t* count = cv.take<int32_t>(pl.qb);
+  u64* cand = cv.take<u64>(pl.qb * pl.cap);
+  u64* tmp = cv.take<u64>(pl.qb * pl.cap);
+  int32_t* status = cv.take<int32_t>(1);
+  const int esz = dtype == TT_F32 ? 4 : 2;
+  const bool vec = ((reinterpret_cast<uintptr_t>(query) | reinterpret_cast<uintptr_t>(corpus)) & 15) == 0 &&
+                   (D * esz) % 16 == 0;
+  hipError_t he = hipMemsetAsync(status, 0, 4, st);
+  if (he != hipSuccess) { set_error("tt_mips_topk: memset: %s", hipGetErrorString(he)); return (int)he; }
+  int rc;
+  for (int64_t q0 = 0; q0 < B; q0 += pl.qb) {
+    const int64_t nq = (B - q0 < pl.qb) ? B - q0 : pl.qb;
+    MipsArgs a{};
+    a.Q = query; a.Cm = corpus; a.B = B; a.C = C; a.D = D; a.q0 = q0; a.nq = nq;
+    a.chunks_per_split = pl.chunks_per_split; a.n_chunks = pl.n_chunks;
+    a.gmax = gmax; a.tau = tau; a.cand = cand; a.count = count; a.cap = pl.cap; a.vec_ok = vec ? 1 : 0;
+    dim3 grid((unsigned)ceil_div(nq, QB_WG), (unsigned)pl.splits);
+    mips_zero_kernel<<<(unsigned)ceil_div(nq, 256), 256, 0, st>>>(tau, count, nq);
+    if ((rc = check_launch("mips_zero_kernel"))) return rc;
+    if (pl.n_groups > K) {  // otherwise tau = 0: every item is a candidate (cap == n_groups*64 >= C)
+      if ((rc = dispatch_score<1>(dtype, pl.dpx, a, grid, st))) return rc;
+      mips_select_kernel<<<(unsigned)ceil_div(nq, 32), 256, 0, st>>>(gmax, pl.n_groups, nq, K, tau);
+      if ((rc = check_launch("mips_select_kernel"))) return rc;
+    }
+    if ((rc = dispatch_score<2>(dtype, pl.dpx, a, grid, st))) return rc;
+    mips_sort_emit_kernel<<<(unsigned)nq, 64, 0, st>>>(cand, tmp, count, pl.cap, K, q0, idx_out, score_out, status);
+    if ((rc = check_launch("mips_sort_emit_kernel"))) return rc;
+  }
+  return 0;
+}

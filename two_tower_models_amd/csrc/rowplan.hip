@@ -1,0 +1,257 @@
+// K2a: row-gradient plan.  The ids looked up in one step (8 K .. 420 K int64) are
+// stable-radix-sorted by row id (8-bit digits, only as many passes as the table
+// height needs), then cut into runs of equal id.  Everything downstream (summing
+// the gradient rows that hit the same table row, dense-exact Adam on those rows,
+// the dense gradient for torch.optim users) walks these runs in a fixed order, so
+// the embedding backward is atomic-free and bit-reproducible.
+//
+// All sizes are device-independent of the DATA: kernels are launched for the worst
+// case (n_ids runs) and read the actual run count from device memory, which keeps
+// the whole step capturable in a hipGraph.
+#include "common.hpp"
+
+namespace tt {
+
+constexpr int TILE = 1024;  // keys per workgroup per pass (one wavefront, 16 rounds)
+
+__global__ void plan_init_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t n_rows,
+                                 int32_t* __restrict__ keys, int32_t* __restrict__ vals, int32_t* oob_flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t id = ids[i];
+  if (id < 0 || id >= n_rows) { *oob_flag = 1; id = 0; }
+  keys[i] = (int32_t)id;
+  vals[i] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(64) void radix_hist_kernel(const int32_t* __restrict__ keys, int64_t n, int shift,
+                                                        int32_t* __restrict__ hist, int nblk) {
+  __shared__ int32_t h[256];
+  const int lane = threadIdx.x;
+  for (int d = lane; d < 256; d += 64) h[d] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * TILE;
+  for (int rnd = 0; rnd < TILE / 64; ++rnd) {
+    const int64_t i = base + rnd * 64 + lane;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255], 1);
+  }
+  __syncthreads();
+  for (int d = lane; d < 256; d += 64) hist[(int64_t)d * nblk + blockIdx.x] = h[d];
+}
+
+// one wavefront per digit: exclusive scan of that digit's per-block counts (in place) + digit total
+__global__ __launch_bounds__(64) void radix_scan_kernel(int32_t* __restrict__ hist, int nblk, int32_t* __restrict__ totals) {
+  const int lane = threadIdx.x;
+  int32_t* row = hist + (int64_t)blockIdx.x * nblk;
+  int32_t carry = 0;
+  for (int b0 = 0; b0 < nblk; b0 += 64) {
+    const int b = b0 + lane;
+    const int32_t v = (b < nblk) ? row[b] : 0;
+    int32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (b < nblk) row[b] = carry + inc - v;
+    carry += __shfl(inc, 63, 64);
+  }
+  if (lane == 0) totals[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(64) void radix_scatter_kernel(const int32_t* __restrict__ keys_in,
+                                                           const int32_t* __restrict__ vals_in, int64_t n, int shift,
+                                                           const int32_t* __restrict__ hist, int nblk,
+                                                           const int32_t* __restrict__ totals,
+                                                           int32_t* __restrict__ keys_out, int32_t* __restrict__ vals_out) {
+  __shared__ int32_t base[256];
+  const int lane = threadIdx.x;
+  {  // base[d] = (sum of totals of smaller digits) + (this digit's count in earlier blocks)
+    int32_t t[4], s = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { t[c] = totals[4 * lane + c]; s += t[c]; }
+    int32_t inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t u = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += u;
+    }
+    int32_t run = inc - s;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      base[4 * lane + c] = run + hist[(int64_t)(4 * lane + c) * nblk + blockIdx.x];
+      run += t[c];
+    }
+  }
+  __syncthreads();
+  const int64_t tile0 = (int64_t)blockIdx.x * TILE;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int rnd = 0; rnd < TILE / 64; ++rnd) {
+    const int64_t i = tile0 + rnd * 64 + lane;
+    const bool active = i < n;
+    const int32_t key = active ? keys_in[i] : 0;
+    const int32_t val = active ? vals_in[i] : 0;
+    const int d = (key >> shift) & 255;
+    unsigned long long mask = __ballot(active);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const unsigned long long bal = __ballot((d >> bit) & 1);
+      mask &= ((d >> bit) & 1) ? bal : ~bal;
+    }
+    // `mask` = active lanes holding the same digit; stable rank = those in lower lanes
+    const int rank = __popcll(mask & lt_mask);
+    int32_t pos = 0;
+    if (active) pos = base[d] + rank;
+    __builtin_amdgcn_wave_barrier();
+    if (active && rank == 0) base[d] += __popcll(mask);
+    __builtin_amdgcn_wave_barrier();
+    if (active) { keys_out[pos] = key; vals_out[pos] = val; }
+  }
+}
+
+// ---- runs of equal key -----------------------------------------------------
+constexpr int SEG_TILE = 2048;  // keys per workgroup (256 threads x 8)
+__global__ __launch_bounds__(256) void seg_count_kernel(const int32_t* __restrict__ keys, int64_t n,
+                                                        int32_t* __restrict__ blk_heads) {
+  __shared__ int32_t red[4];
+  const int64_t base = (int64_t)blockIdx.x * SEG_TILE;
+  int32_t c = 0;
+  for (int k = 0; k < 8; ++k) {
+    const int64_t i = base + k * 256 + threadIdx.x;
+    if (i < n) c += (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+  }
+  float dummy = 0.f; (void)dummy;
+  int32_t w = c;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) blk_heads[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// single workgroup: exclusive scan of the per-block head counts; writes n_unique and the end sentinel
+__global__ __launch_bounds__(256) void seg_scan_kernel(int32_t* __restrict__ blk_heads, int nblk, int64_t n,
+                                                       int32_t* __restrict__ n_unique, int32_t* __restrict__ seg_begin) {
+  __shared__ int32_t wsum[4];
+  __shared__ int32_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b0 = 0; b0 < nblk; b0 += 256) {
+    const int b = b0 + threadIdx.x;
+    const int32_t v = (b < nblk) ? blk_heads[b] : 0;
+    int32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const int32_t carry = carry_s;
+    if (b < nblk) blk_heads[b] = carry + woff + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = carry + woff + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    *n_unique = carry_s;
+    seg_begin[carry_s] = (int32_t)n;
+  }
+}
+
+__global__ __launch_bounds__(256) void seg_write_kernel(const int32_t* __restrict__ keys, int64_t n,
+                                                        const int32_t* __restrict__ blk_off,
+                                                        int32_t* __restrict__ seg_begin) {
+  __shared__ int32_t wsum[4];
+  __shared__ int32_t carry_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = blk_off[blockIdx.x];
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * SEG_TILE;
+  for (int k = 0; k < 8; ++k) {
+    const int64_t i = base + k * 256 + threadIdx.x;
+    const int32_t head = (i < n && (i == 0 || keys[i] != keys[i - 1])) ? 1 : 0;
+    int32_t inc = head;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const int32_t carry = carry_s;
+    if (head) seg_begin[carry + woff + inc - 1] = (int32_t)i;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = carry + woff + inc;
+    __syncthreads();
+  }
+}
+
+static int radix_passes(int64_t n_rows) {
+  int bits = 1;
+  while (bits < 31 && ((int64_t)1 << bits) < n_rows) ++bits;
+  return (bits + 7) / 8;
+}
+
+}  // namespace tt
+
+using namespace tt;
+
+extern "C" int64_t tt_rowgrad_workspace_bytes(int64_t n_ids) {
+  if (n_ids <= 0) return 256;
+  const int64_t nblk = ceil_div(n_ids, TILE);
+  const int64_t nseg = ceil_div(n_ids, SEG_TILE);
+  return round_up(n_ids * 4, 256) * 2      // ping-pong keys / vals
+         + round_up(256 * nblk * 4, 256)   // per-block digit histograms
+         + round_up(256 * 4, 256)          // digit totals
+         + round_up(nseg * 4, 256);        // per-block run-head counts
+}
+
+extern "C" int tt_rowgrad_plan(const int64_t* ids, int64_t n_ids, int64_t n_rows, int32_t* sorted_ids,
+                               int32_t* perm, int32_t* seg_begin, int32_t* n_unique, int32_t* oob_flag,
+                               void* ws, int64_t ws_bytes, tt_stream_t stream) {
+  if (!ids || !sorted_ids || !perm || !seg_begin || !n_unique || !oob_flag || !ws)
+    return fail_arg("tt_rowgrad_plan: null pointer");
+  if (n_ids <= 0 || n_ids >= ((int64_t)1 << 31) || n_rows <= 0 || n_rows > ((int64_t)1 << 31))
+    return fail_arg("tt_rowgrad_plan: sizes");
+  if (ws_bytes < tt_rowgrad_workspace_bytes(n_ids)) { set_error("tt_rowgrad_plan: workspace"); return TT_E_WORKSPACE; }
+  hipStream_t st = S(stream);
+  const int nblk = (int)ceil_div(n_ids, TILE);
+  const int nseg = (int)ceil_div(n_ids, SEG_TILE);
+  Carver cv(ws);
+  int32_t* tkeys = cv.take<int32_t>(n_ids);
+  int32_t* tvals = cv.take<int32_t>(n_ids);
+  int32_t* hist = cv.take<int32_t>((int64_t)256 * nblk);
+  int32_t* totals = cv.take<int32_t>(256);
+  int32_t* blk_heads = cv.take<int32_t>(nseg);
+
+  const int passes = radix_passes(n_rows);
+  // ping-pong so that the LAST pass lands in (sorted_ids, perm)
+  int32_t* kbuf[2] = {sorted_ids, tkeys};
+  int32_t* vbuf[2] = {perm, tvals};
+  int cur = (passes % 2 == 0) ? 0 : 1;
+  plan_init_kernel<<<(unsigned)ceil_div(n_ids, 256), 256, 0, st>>>(ids, n_ids, n_rows, kbuf[cur], vbuf[cur], oob_flag);
+  int rc = check_launch("plan_init_kernel");
+  if (rc) return rc;
+  for (int p = 0; p < passes; ++p) {
+    const int shift = 8 * p;
+    radix_hist_kernel<<<nblk, 64, 0, st>>>(kbuf[cur], n_ids, shift, hist, nblk);
+    if ((rc = check_launch("radix_hist_kernel"))) return rc;
+    radix_scan_kernel<<<256, 64, 0, st>>>(hist, nblk, totals);
+    if ((rc = check_launch("radix_scan_kernel"))) return rc;
+    radix_scatter_kernel<<<nblk, 64, 0, st>>>(kbuf[cur], vbuf[cur], n_ids, shift, hist, nblk, totals, kbuf[cur ^ 1], vbuf[cur ^ 1]);
+    if ((rc = check_launch("radix_scatter_kernel"))) return rc;
+    cur ^= 1;
+  }
+  seg_count_kernel<<<nseg, 256, 0, st>>>(sorted_ids, n_ids, blk_heads);
+  if ((rc = check_launch("seg_count_kernel"))) return rc;
+  seg_scan_kernel<<<1, 256, 0, st>>>(blk_heads, nseg, n_ids, n_unique, seg_begin);
+  if ((rc = check_launch("seg_scan_kernel"))) return rc;
+  seg_write_kernel<<<nseg, 256, 0, st>>>(sorted_ids, n_ids, blk_heads, seg_begin);
+  return check_launch("seg_write_kernel");
+}

@@ -1,0 +1,501 @@
+"""Kernel wrappers and autograd Functions over libtt_hotpath.so.
+
+Every tensor that reaches a kernel is an fp32 (or int64 id) HIP tensor owned by
+torch; the C side only sees raw pointers, sizes and the current stream
+(SURVEY.md 8b "Ownership").  Nothing here computes with torch ops: torch is the
+allocator, the autograd tape and the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _native as N
+
+
+# ----------------------------------------------------------------- helpers
+def _f32_2d(t: torch.Tensor, name: str) -> Tuple[int, int, int, int]:
+    """(ptr, rows, cols, ld) of a row-major fp32 matrix view (unit column stride)."""
+    if t.dtype != torch.float32 or t.dim() != 2:
+        raise TypeError(f"{name}: expected a 2-D float32 tensor, got {tuple(t.shape)} {t.dtype}")
+    if t.size(1) > 1 and t.stride(1) != 1:
+        raise ValueError(f"{name}: columns must be contiguous")
+    ld = t.stride(0) if t.size(0) > 1 else max(t.size(1), t.stride(0))
+    return t.data_ptr(), t.size(0), t.size(1), max(ld, t.size(1))
+
+
+def _rowmajor(t: torch.Tensor) -> torch.Tensor:
+    return t if (t.dim() == 2 and (t.size(1) == 1 or t.stride(1) == 1) and t.stride(0) >= t.size(1)) else t.contiguous()
+
+
+def _ws(dev: torch.device, nbytes: int, slot: str = "ws") -> Tuple[Optional[int], int]:
+    if nbytes <= 0:
+        return None, 0
+    buf = N.scratch.get(dev, nbytes, slot)
+    return buf.data_ptr(), buf.numel()
+
+
+def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, M: int, Nn: int, K: int,
+         bias: Optional[torch.Tensor] = None, epilogue: int = N.TT_EPI_NONE,
+         aux: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """out[M,N] (+)= op(A) op(B) (+bias) -- see tt_gemm_f32.  A/B/out may be strided row views."""
+    dev = N.require_device(A, B, out, bias, aux)
+    lib = N.load()
+    pa, _, _, lda = _f32_2d(A, "A")
+    pb, _, _, ldb = _f32_2d(B, "B")
+    pc, _, _, ldc = _f32_2d(out, "out")
+    paux, ldaux = (None, 0)
+    if aux is not None:
+        paux, _, _, ldaux = _f32_2d(aux, "aux")
+    wsp, wsn = _ws(dev, lib.tt_gemm_workspace_bytes(layout, M, Nn, K))
+    N.check(lib.tt_gemm_f32(layout, M, Nn, K, pa, lda, pb, ldb, pc, ldc, N.ptr(bias), epilogue, paux, ldaux,
+                            1 if accumulate else 0, wsp, wsn, N.stream()), "tt_gemm_f32")
+    return out
+
+
+def colsum(X: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    dev = N.require_device(X)
+    lib = N.load()
+    px, M, Nn, ldx = _f32_2d(X, "X")
+    if out is None:
+        out = torch.empty(Nn, dtype=torch.float32, device=dev)
+    wsp, wsn = _ws(dev, lib.tt_colsum_workspace_bytes(M, Nn))
+    N.check(lib.tt_colsum_f32(px, M, Nn, ldx, out.data_ptr(), wsp, wsn, N.stream()), "tt_colsum_f32")
+    return out
+
+
+def gather_rows_into(table: torch.Tensor, ids: torch.Tensor, out: torch.Tensor) -> None:
+    """out[i, :D] = table[ids[i]] ; `out` may be a column-slice view (row stride > D)."""
+    dev = N.require_device(table, ids, out)
+    if ids.dtype != torch.int64:
+        raise TypeError("ids must be int64 (torch.long)")
+    ids = ids.contiguous()
+    pt, n_rows, D, ldt = _f32_2d(table, "table")
+    if ldt != D:
+        raise ValueError("embedding table must be contiguous")
+    po, _, _, ldo = _f32_2d(out, "out")
+    N.check(N.load().tt_gather_rows(pt, n_rows, D, ids.data_ptr(), ids.numel(), po, ldo,
+                                    N.oob.flag(dev).data_ptr(), N.stream()), "tt_gather_rows")
+
+
+# ----------------------------------------------------------------- row-gradient plumbing
+class RowGrad:
+    """One block of embedding-row gradients: `rows[i]` is dLoss/d table[ids[i]]."""
+
+    __slots__ = ("ids", "rows")
+
+    def __init__(self, ids: torch.Tensor, rows: torch.Tensor):
+        self.ids = ids.reshape(-1)
+        self.rows = _rowmajor(rows)
+
+
+class RowPlan:
+    """Device-side run structure of the ids looked up in a step (tt_rowgrad_plan)."""
+
+    def __init__(self, blocks: Sequence[RowGrad], n_rows: int):
+        dev = blocks[0].ids.device
+        lib = N.load()
+        ids = blocks[0].ids if len(blocks) == 1 else torch.cat([b.ids for b in blocks])
+        n = ids.numel()
+        self.n = n
+        self.sorted_ids = torch.empty(n, dtype=torch.int32, device=dev)
+        self.perm = torch.empty(n, dtype=torch.int32, device=dev)
+        self.seg_begin = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        self.n_unique = torch.empty(1, dtype=torch.int32, device=dev)
+        wsp, wsn = _ws(dev, lib.tt_rowgrad_workspace_bytes(n), "plan")
+        N.check(lib.tt_rowgrad_plan(ids.data_ptr(), n, n_rows, self.sorted_ids.data_ptr(), self.perm.data_ptr(),
+                                    self.seg_begin.data_ptr(), self.n_unique.data_ptr(),
+                                    N.oob.flag(dev).data_ptr(), wsp, wsn, N.stream()), "tt_rowgrad_plan")
+        if len(blocks) > N.TT_MAX_GRAD_SOURCES:
+            raise RuntimeError(f"more than {N.TT_MAX_GRAD_SOURCES} lookups of one table in a step")
+        self.sources = N.GradSources()
+        first = 0
+        for k, b in enumerate(blocks):
+            p, r, _, ld = _f32_2d(b.rows, "grad rows")
+            self.sources.rows[k] = p
+            self.sources.ld[k] = ld
+            self.sources.first[k] = first
+            first += r
+        self.sources.first[len(blocks)] = first
+        self.sources.n_sources = len(blocks)
+        self._keep = list(blocks)
+        assert first == n
+
+
+def dense_grad_from_rows(blocks: Sequence[RowGrad], n_rows: int, dim: int) -> torch.Tensor:
+    """The dense [n_rows, dim] embedding gradient torch.optim expects."""
+    dev = blocks[0].ids.device
+    plan = RowPlan(blocks, n_rows)
+    dense = torch.zeros(n_rows, dim, dtype=torch.float32, device=dev)
+    N.check(N.load().tt_rowgrad_dense(C.byref(plan.sources), plan.n, dim, plan.sorted_ids.data_ptr(),
+                                      plan.perm.data_ptr(), plan.seg_begin.data_ptr(),
+                                      plan.n_unique.data_ptr(), dense.data_ptr(), N.stream()), "tt_rowgrad_dense")
+    return dense
+
+
+def _route_table_grad(weight: torch.Tensor, ids: torch.Tensor, rows: torch.Tensor) -> Optional[torch.Tensor]:
+    """Embedding backward.  If the optimiser that owns `weight` consumes row gradients
+    (two_tower_models_amd.optim.DenseExactAdam sets `_tt_rowgrads`), park them there and
+    return no dense gradient; otherwise build the dense gradient torch.optim needs."""
+    stash = getattr(weight, "_tt_rowgrads", None)
+    if stash is not None:
+        stash.append(RowGrad(ids, rows))
+        return None
+    return dense_grad_from_rows([RowGrad(ids, rows)], weight.shape[0], weight.shape[1])
+
+
+# ----------------------------------------------------------------- autograd Functions
+class EmbeddingLookup(torch.autograd.Function):
+    """nn.Embedding.__call__ (ref:src/two_tower_base_retrieval.py:126,209)."""
+
+    @staticmethod
+    def forward(ctx, weight: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+        out = torch.empty(ids.numel(), weight.shape[1], dtype=torch.float32, device=weight.device)
+        gather_rows_into(weight, ids.reshape(-1), out)
+        ctx.weight = weight
+        ctx.save_for_backward(ids)
+        return out.view(*ids.shape, weight.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids,) = ctx.saved_tensors
+        w = ctx.weight
+        return _route_table_grad(w, ids.reshape(-1), g.reshape(-1, w.shape[1])), None
+
+
+class Linear(torch.autograd.Function):
+    """y = x W^T + b.  nn.Linear at ref:...base_retrieval.py:90-93,107-110."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x = _rowmajor(x)
+        M, K = x.shape
+        Nn = W.shape[0]
+        y = torch.empty(M, Nn, dtype=torch.float32, device=x.device)
+        gemm(N.TT_GEMM_NT, x, W, y, M, Nn, K, bias=b)
+        ctx.save_for_backward(x, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = _rowmajor(dy)
+        M, K = x.shape
+        Nn = W.shape[0]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+            gemm(N.TT_GEMM_NN, dy, W, dx, M, K, Nn)
+        dW = torch.empty(Nn, K, dtype=torch.float32, device=dy.device)
+        gemm(N.TT_GEMM_TN, dy, x, dW, Nn, K, M)
+        db = colsum(dy)
+        return dx, dW, db
+
+
+class FeatureMLP(torch.autograd.Function):
+    """Linear(F->256) -> ReLU -> Linear(256->D)  (ref:...base_retrieval.py:76-80)."""
+
+    @staticmethod
+    def forward(ctx, feats, W1, b1, W2, b2):
+        dev = N.require_device(feats, W1, b1, W2, b2)
+        feats = _rowmajor(feats)
+        B, F = feats.shape
+        Hd, Dm = W1.shape[0], W2.shape[0]
+        h = torch.empty(B, Hd, dtype=torch.float32, device=dev)
+        gemm(N.TT_GEMM_NT, feats, W1, h, B, Hd, F, bias=b1, epilogue=N.TT_EPI_RELU)
+        y = torch.empty(B, Dm, dtype=torch.float32, device=dev)
+        gemm(N.TT_GEMM_NT, h, W2, y, B, Dm, Hd, bias=b2)
+        ctx.save_for_backward(feats, h, W1, W2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        feats, h, W1, W2 = ctx.saved_tensors
+        dy = _rowmajor(dy)
+        dev = dy.device
+        B, F = feats.shape
+        Dm, Hd = W2.shape
+        dW2 = torch.empty(Dm, Hd, dtype=torch.float32, device=dev)
+        gemm(N.TT_GEMM_TN, dy, h, dW2, Dm, Hd, B)
+        db2 = colsum(dy)
+        dh = torch.empty(B, Hd, dtype=torch.float32, device=dev)
+        gemm(N.TT_GEMM_NN, dy, W2, dh, B, Hd, Dm, epilogue=N.TT_EPI_RELU_MASK, aux=h)
+        dW1 = torch.empty(Hd, F, dtype=torch.float32, device=dev)
+        gemm(N.TT_GEMM_TN, dh, feats, dW1, Hd, F, B)
+        db1 = colsum(dh)
+        dfe = None
+        if ctx.needs_input_grad[0]:
+            dfe = torch.empty(B, F, dtype=torch.float32, device=dev)
+            gemm(N.TT_GEMM_NN, dh, W1, dfe, B, F, Hd)
+        return dfe, dW1, db1, dW2, db2
+
+
+class TowerInput(torch.autograd.Function):
+    """[ table[ids] | Linear(256->D)(ReLU(Linear(F->256)(features))) ] written as two
+    column slices of one [B, 2D] buffer -- the id lookup, the feature MLP and the
+    torch.cat of ref:src/two_tower_base_retrieval.py:129-162 / :209-216."""
+
+    @staticmethod
+    def forward(ctx, weight, ids, feats, W1, b1, W2, b2):
+        dev = N.require_device(weight, ids, feats, W1, b1, W2, b2)
+        feats = _rowmajor(feats)
+        B, F = feats.shape
+        D = weight.shape[1]
+        Dm = W2.shape[0]
+        Hd = W1.shape[0]
+        tin = torch.empty(B, D + Dm, dtype=torch.float32, device=dev)
+        gather_rows_into(weight, ids.reshape(-1), tin[:, :D])
+        h = torch.empty(B, Hd, dtype=torch.float32, device=dev)
+        gemm(N.TT_GEMM_NT, feats, W1, h, B, Hd, F, bias=b1, epilogue=N.TT_EPI_RELU)
+        gemm(N.TT_GEMM_NT, h, W2, tin[:, D:], B, Dm, Hd, bias=b2)
+        ctx.weight = weight
+        ctx.save_for_backward(ids, feats, h, W1, W2)
+        return tin
+
+    @staticmethod
+    def backward(ctx, d_tin):
+        ids, feats, h, W1, W2 = ctx.saved_tensors
+        w = ctx.weight
+        d_tin = _rowmajor(d_tin)
+        dev = d_tin.device
+        B, F = feats.shape
+        D = w.shape[1]
+        Dm, Hd = W2.shape
+        d_f = d_tin[:, D:]
+        dW2 = torch.empty(Dm, Hd, dtype=torch.float32, device=dev)
+        gemm(N.TT_GEMM_TN, d_f, h, dW2, Dm, Hd, B)
+        db2 = colsum(d_f)
+        dh = torch.empty(B, Hd, dtype=torch.float32, device=dev)
+        gemm(N.TT_GEMM_NN, d_f, W2, dh, B, Hd, Dm, epilogue=N.TT_EPI_RELU_MASK, aux=h)
+        dW1 = torch.empty(Hd, F, dtype=torch.float32, device=dev)
+        gemm(N.TT_GEMM_TN, dh, feats, dW1, Hd, F, B)
+        db1 = colsum(dh)
+        dweight = None
+        if ctx.needs_input_grad[0]:
+            dweight = _route_table_grad(w, ids.reshape(-1), d_tin[:, :D])
+        return dweight, None, None, dW1, db1, dW2, db2
+
+
+class InBatchSoftmaxCE(torch.autograd.Function):
+    """row_ce[i] = logsumexp_j (U I^T)[i, j] - (U I^T)[i, i + diag_offset]
+    (torch.matmul + F.cross_entropy(reduction="none"), ref:...base_retrieval.py:287-312)."""
+
+    @staticmethod
+    def forward(ctx, U, I, diag_offset: int = 0):
+        dev = N.require_device(U, I)
+        U, I = _rowmajor(U), _rowmajor(I)
+        M, D = U.shape
+        Nn = I.shape[0]
+        lib = N.load()
+        lse = torch.empty(M, dtype=torch.float32, device=dev)
+        ce = torch.empty(M, dtype=torch.float32, device=dev)
+        wsp, wsn = _ws(dev, lib.tt_inbatch_ce_workspace_bytes(M, Nn, D))
+        pu, _, _, ldu = _f32_2d(U, "U")
+        pi, _, _, ldi = _f32_2d(I, "I")
+        N.check(lib.tt_inbatch_ce_fwd(pu, ldu, pi, ldi, M, Nn, D, diag_offset, lse.data_ptr(), ce.data_ptr(),
+                                      wsp, wsn, N.stream()), "tt_inbatch_ce_fwd")
+        ctx.diag_offset = diag_offset
+        ctx.save_for_backward(U, I, lse)
+        return ce
+
+    @staticmethod
+    def backward(ctx, d_ce):
+        U, I, lse = ctx.saved_tensors
+        dev = U.device
+        M, D = U.shape
+        Nn = I.shape[0]
+        lib = N.load()
+        coef = d_ce.contiguous()
+        dU = torch.empty(M, D, dtype=torch.float32, device=dev)
+        dI = torch.empty(Nn, D, dtype=torch.float32, device=dev)
+        wsp, wsn = _ws(dev, lib.tt_inbatch_ce_workspace_bytes(M, Nn, D))
+        pu, _, _, ldu = _f32_2d(U, "U")
+        pi, _, _, ldi = _f32_2d(I, "I")
+        N.check(lib.tt_inbatch_ce_bwd(pu, ldu, pi, ldi, M, Nn, D, ctx.diag_offset, lse.data_ptr(),
+                                      coef.data_ptr(), dU.data_ptr(), D, dI.data_ptr(), D, wsp, wsn,
+                                      N.stream()), "tt_inbatch_ce_bwd")
+        return dU, dI, None
+
+
+class WeightedMeanLoss(torch.autograd.Function):
+    """mean_i(row_ce[i] * w[i]) with w = clamp(labels @ uvw, 1e-6) / max(...)
+    (ref:...base_retrieval.py:322,334-343, 2-D labels, identity debias hook)."""
+
+    @staticmethod
+    def forward(ctx, row_ce, labels, uvw):
+        dev = N.require_device(row_ce, labels, uvw)
+        labels = labels.contiguous()
+        B, T = labels.shape
+        w = torch.empty(B, dtype=torch.float32, device=dev)
+        coef = torch.empty(B, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        N.check(N.load().tt_weighted_mean_loss(labels.data_ptr(), B, T, uvw.data_ptr(), row_ce.data_ptr(),
+                                               w.data_ptr(), coef.data_ptr(), loss.data_ptr(), N.stream()),
+                "tt_weighted_mean_loss")
+        ctx.save_for_backward(coef)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (coef,) = ctx.saved_tensors
+        return coef * g, None, None
+
+
+# ----------------------------------------------------------------- history encoder
+def _attn_fwd(qkv, B, H, D, heads):
+    ctx_t = torch.empty(B * H, D, dtype=torch.float32, device=qkv.device)
+    lse = torch.empty(B, heads, H, dtype=torch.float32, device=qkv.device)
+    N.check(N.load().tt_attn_fwd(qkv.data_ptr(), B, H, D, heads, ctx_t.data_ptr(), lse.data_ptr(), N.stream()),
+            "tt_attn_fwd")
+    return ctx_t, lse
+
+
+class HistoryEncoder(torch.autograd.Function):
+    """UserHistoryEncoder.forward (ref:src/user_history_encoder.py:80-121), optionally
+    fused with the history id lookup (ref:src/two_tower_with_user_history_encoder.py:105).
+
+    source = embedding table [N, D] with ids [B, H]   (ids given), or
+    source = embedded history [B, H, D]               (ids None).
+    Returns [B, 2, D]: slot 0 = row 0 after L attention layers, slot 1 = mean of raw rows.
+    The last layer's out-projection is evaluated for row 0 only (the only row consumed)."""
+
+    @staticmethod
+    def forward(ctx, source, ids, pe, heads: int, *layer_params):
+        dev = N.require_device(source, ids, pe, *layer_params)
+        L = len(layer_params) // 4
+        lib = N.load()
+        if ids is not None:
+            ids = ids.contiguous()
+            B, H = ids.shape
+            n_rows, D = source.shape
+            src = source
+        else:
+            src = source.contiguous()
+            B, H, D = src.shape
+            n_rows = 0
+        out = torch.empty(B, 2, D, dtype=torch.float32, device=dev)
+        x = torch.empty(B * H, D, dtype=torch.float32, device=dev)
+        pooled = out[:, 1, :]
+        N.check(lib.tt_hist_embed_pool(src.data_ptr(), n_rows, D, N.ptr(ids), B, H, N.ptr(pe), x.data_ptr(),
+                                       pooled.data_ptr(), 2 * D, N.oob.flag(dev).data_ptr(), N.stream()),
+                "tt_hist_embed_pool")
+        saved: List[torch.Tensor] = []
+        for l in range(L):
+            w_in, b_in, w_out, b_out = layer_params[4 * l: 4 * l + 4]
+            qkv = torch.empty(B * H, 3 * D, dtype=torch.float32, device=dev)
+            gemm(N.TT_GEMM_NT, x, w_in, qkv, B * H, 3 * D, D, bias=b_in)
+            ctx_t, lse = _attn_fwd(qkv, B, H, D, heads)
+            saved += [x, qkv, ctx_t, lse]
+            if l + 1 < L:
+                x = torch.empty(B * H, D, dtype=torch.float32, device=dev)
+                gemm(N.TT_GEMM_NT, ctx_t, w_out, x, B * H, D, D, bias=b_out)
+            else:  # rows b*H + 0 only, straight into out[:, 0, :]
+                gemm(N.TT_GEMM_NT, ctx_t.view(B, H * D)[:, :D], w_out, out[:, 0, :], B, D, D, bias=b_out)
+        if L == 0:
+            out[:, 0, :].copy_(x.view(B, H, D)[:, 0, :])
+        ctx.dims = (B, H, D, L, heads)
+        ctx.table = source if ids is not None else None
+        ctx.has_ids = ids is not None
+        ctx.save_for_backward(ids, *layer_params, *saved)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        B, H, D, L, heads = ctx.dims
+        t = ctx.saved_tensors
+        ids = t[0]
+        layer_params = t[1: 1 + 4 * L]
+        saved = t[1 + 4 * L:]
+        dev = d_out.device
+        lib = N.load()
+        d_out = d_out.contiguous()
+        d_recent, d_pooled = d_out[:, 0, :], d_out[:, 1, :]
+        grads: List[Optional[torch.Tensor]] = [None] * (4 * L)
+        dx = None  # gradient wrt the current layer's OUTPUT x_{l+1}, [B*H, D]
+        for l in reversed(range(L)):
+            w_in, b_in, w_out, b_out = layer_params[4 * l: 4 * l + 4]
+            x, qkv, ctx_t, lse = saved[4 * l: 4 * l + 4]
+            dW_out = torch.empty(D, D, dtype=torch.float32, device=dev)
+            if l == L - 1:
+                rows0 = ctx_t.view(B, H * D)[:, :D]
+                gemm(N.TT_GEMM_TN, d_recent, rows0, dW_out, D, D, B)
+                db_out = colsum(d_recent)
+                d_ctx = torch.zeros(B * H, D, dtype=torch.float32, device=dev)
+                gemm(N.TT_GEMM_NN, d_recent, w_out, d_ctx.view(B, H * D)[:, :D], B, D, D)
+            else:
+                gemm(N.TT_GEMM_TN, dx, ctx_t, dW_out, D, D, B * H)
+                db_out = colsum(dx)
+                d_ctx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
+                gemm(N.TT_GEMM_NN, dx, w_out, d_ctx, B * H, D, D)
+            d_qkv = torch.empty(B * H, 3 * D, dtype=torch.float32, device=dev)
+            N.check(lib.tt_attn_bwd(qkv.data_ptr(), ctx_t.data_ptr(), lse.data_ptr(), d_ctx.data_ptr(), B, H, D,
+                                    heads, d_qkv.data_ptr(), N.stream()), "tt_attn_bwd")
+            dW_in = torch.empty(3 * D, D, dtype=torch.float32, device=dev)
+            gemm(N.TT_GEMM_TN, d_qkv, x, dW_in, 3 * D, D, B * H)
+            db_in = colsum(d_qkv)
+            dx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
+            gemm(N.TT_GEMM_NN, d_qkv, w_in, dx, B * H, D, 3 * D)
+            grads[4 * l: 4 * l + 4] = [dW_in, db_in, dW_out, db_out]
+        if dx is None:  # L == 0: slot 0 is row 0 of (x + pe)
+            dx = torch.zeros(B * H, D, dtype=torch.float32, device=dev)
+            dx.view(B, H, D)[:, 0, :].copy_(d_recent)
+        N.check(lib.tt_hist_pool_bwd(dx.data_ptr(), B, H, D, d_pooled.data_ptr(), 2 * D, N.stream()),
+                "tt_hist_pool_bwd")
+        d_source = None
+        if ctx.needs_input_grad[0]:
+            if ctx.has_ids:
+                d_source = _route_table_grad(ctx.table, ids.reshape(-1), dx)
+            else:
+                d_source = dx.view(B, H, D)
+        return (d_source, None, None, None, *grads)
+
+
+# ----------------------------------------------------------------- MIPS
+def mips_topk(query: torch.Tensor, corpus: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """torch.topk(query @ corpus.T, k) with (score desc, index asc) order
+    (ref:src/baseline_mips_module.py:57-61).  corpus fp32 or bf16 [C, D]; query fp32 [B, D]."""
+    dev = N.require_device(query, corpus)
+    lib = N.load()
+    query = query.detach()
+    if query.dtype != torch.float32 or query.dim() != 2:
+        raise TypeError("query_embedding must be a 2-D float32 tensor")
+    B, D = query.shape
+    Cn = corpus.shape[0]
+    if corpus.shape[1] != D:
+        raise RuntimeError(f"query dim {D} != corpus dim {corpus.shape[1]}")  # torch.matmul would raise too
+    if not (0 < k <= Cn):
+        raise RuntimeError("selected index k out of range")  # torch.topk's message
+    corpus = corpus.contiguous()
+    if corpus.dtype == torch.bfloat16:
+        dtype = N.TT_BF16
+        q = torch.empty(B, D, dtype=torch.bfloat16, device=dev)
+        N.check(lib.tt_f32_to_bf16(query.contiguous().data_ptr(), q.data_ptr(), B * D, N.stream()), "tt_f32_to_bf16")
+    elif corpus.dtype == torch.float32:
+        dtype = N.TT_F32
+        q = query.contiguous()
+    else:
+        raise TypeError("corpus must be float32 or bfloat16")
+    idx = torch.empty(B, k, dtype=torch.int64, device=dev)
+    scores = torch.empty(B, k, dtype=torch.float32, device=dev)
+    wsp, wsn = _ws(dev, lib.tt_mips_workspace_bytes(B, Cn, D, k, dtype), "mips")
+    N.check(lib.tt_mips_topk(q.data_ptr(), corpus.data_ptr(), dtype, B, Cn, D, k, idx.data_ptr(),
+                             scores.data_ptr(), wsp, wsn, N.stream()), "tt_mips_topk")
+    return idx, scores
+
+
+def gather_corpus_rows(corpus: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """corpus[idx] -> [B, K, D] fp32 (ref:src/baseline_mips_module.py:63-69)."""
+    dev = N.require_device(corpus, idx)
+    B, K = idx.shape
+    D = corpus.shape[1]
+    out = torch.empty(B * K, D, dtype=torch.float32, device=dev)
+    flat = idx.reshape(-1).contiguous()
+    if corpus.dtype == torch.bfloat16:
+        N.check(N.load().tt_gather_rows_bf16(corpus.data_ptr(), corpus.shape[0], D, flat.data_ptr(), B * K,
+                                             out.data_ptr(), D, N.oob.flag(dev).data_ptr(), N.stream()),
+                "tt_gather_rows_bf16")
+    else:
+        gather_rows_into(corpus, flat, out)
+    return out.view(B, K, D)

@@ -1,0 +1,170 @@
+"""TwoTowerBaseRetrieval on MI355X.
+
+Same constructor, methods, keyword names, Parameter names and initialisation
+stream as ref:src/two_tower_base_retrieval.py:25-394, so a caller of the
+reference (train loop, tests, a state_dict) can switch over unchanged.  The
+submodules created in ``__init__`` (nn.Embedding / nn.Sequential / nn.Linear)
+are parameter CONTAINERS only: they give the reference's state_dict keys and
+its default initialisation (same RNG draws in the same order), and are never
+called.  All arithmetic runs in libtt_hotpath.so through ``ops``.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _native as N
+from . import ops
+from .baseline_mips_module import BaselineMIPSModule
+
+_FEATURE_HIDDEN = 256  # ref:src/two_tower_base_retrieval.py:76-80
+
+
+def _feature_mlp(in_features: int, out_features: int) -> nn.Sequential:
+    return nn.Sequential(nn.Linear(in_features, _FEATURE_HIDDEN), nn.ReLU(), nn.Linear(_FEATURE_HIDDEN, out_features))
+
+
+def mark_table(weight: nn.Parameter) -> None:
+    """Tag an embedding table so DenseExactAdam consumes its gradient in row form."""
+    weight._tt_is_table = True
+
+
+class TwoTowerBaseRetrieval(nn.Module):
+    """Two-tower candidate retrieval: id-embedding + feature-MLP towers, in-batch
+    softmax loss weighted by net user value, MIPS top-K inference."""
+
+    def __init__(
+        self,
+        num_items: int,
+        user_id_hash_size: int,
+        user_id_embedding_dim: int,
+        user_features_size: int,
+        item_id_hash_size: int,
+        item_id_embedding_dim: int,
+        item_features_size: int,
+        user_value_weights: List[float],
+        mips_module: BaselineMIPSModule,
+    ) -> None:
+        super().__init__()
+        self.num_items = num_items
+        # plain tensor attribute, like the reference (:62); unlike the reference it
+        # follows .to()/.cuda() (see _apply) so the GPU path actually runs.
+        self.user_value_weights = torch.tensor(user_value_weights)
+        self.mips_module = mips_module
+        # creation order == reference order (:70-110) so a seeded init is bit-identical
+        self.user_id_embedding_arch = nn.Embedding(user_id_hash_size, user_id_embedding_dim)
+        self.user_features_arch = _feature_mlp(user_features_size, user_id_embedding_dim)
+        self.user_tower_arch = nn.Linear(2 * user_id_embedding_dim, item_id_embedding_dim)
+        self.item_id_embedding_arch = nn.Embedding(item_id_hash_size, item_id_embedding_dim)
+        self.item_features_arch = _feature_mlp(item_features_size, item_id_embedding_dim)
+        self.item_tower_arch = nn.Linear(2 * item_id_embedding_dim, item_id_embedding_dim)
+        mark_table(self.user_id_embedding_arch.weight)
+        mark_table(self.item_id_embedding_arch.weight)
+
+    # plain-tensor attributes travel with the module (the reference leaves them on the
+    # CPU, ref "TODO add device input" :61, which makes its GPU path unusable)
+    def _apply(self, fn, *a, **kw):
+        super()._apply(fn, *a, **kw)
+        self.user_value_weights = fn(self.user_value_weights)
+        return self
+
+    # ------------------------------------------------------------------ user tower
+    def get_user_embedding(self, user_id: torch.Tensor, user_features: torch.Tensor) -> torch.Tensor:
+        """[B] ids -> [B, DU] rows of the user table (ref :112-127)."""
+        return ops.EmbeddingLookup.apply(self.user_id_embedding_arch.weight, user_id)
+
+    def process_user_features(
+        self, user_id: torch.Tensor, user_features: torch.Tensor, user_history: torch.Tensor
+    ) -> torch.Tensor:
+        """[id embedding | feature MLP] -> [B, 2*DU] (ref :129-162).  ``user_history`` is
+        unused here, as upstream."""
+        if type(self).get_user_embedding is not TwoTowerBaseRetrieval.get_user_embedding:
+            # a subclass replaced the id representation: honour the hook, lose the fusion
+            id_emb = self.get_user_embedding(user_id=user_id, user_features=user_features)
+            mlp = self.user_features_arch
+            feat = ops.FeatureMLP.apply(user_features, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)
+            return torch.cat([id_emb, feat], dim=1)
+        mlp = self.user_features_arch
+        return ops.TowerInput.apply(
+            self.user_id_embedding_arch.weight, user_id, user_features,
+            mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias,
+        )
+
+    def compute_user_embedding(
+        self, user_id: torch.Tensor, user_features: torch.Tensor, user_history: torch.Tensor
+    ) -> torch.Tensor:
+        """Query embedding [B, DI] (ref :164-191)."""
+        if user_id.is_cuda:
+            N.oob.poll(user_id.device)  # surfaces an out-of-range id seen by an earlier launch
+        user_tower_input = self.process_user_features(
+            user_id=user_id, user_features=user_features, user_history=user_history
+        )
+        return ops.Linear.apply(user_tower_input, self.user_tower_arch.weight, self.user_tower_arch.bias)
+
+    # ------------------------------------------------------------------ item tower
+    def compute_item_embeddings(self, item_id: torch.Tensor, item_features: torch.Tensor) -> torch.Tensor:
+        """[B, DI] item embeddings (ref :193-219)."""
+        mlp = self.item_features_arch
+        item_tower_input = ops.TowerInput.apply(
+            self.item_id_embedding_arch.weight, item_id, item_features,
+            mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias,
+        )
+        return ops.Linear.apply(item_tower_input, self.item_tower_arch.weight, self.item_tower_arch.bias)
+
+    # ------------------------------------------------------------------ inference
+    def forward(self, user_id: torch.Tensor, user_features: torch.Tensor, user_history: torch.Tensor) -> torch.Tensor:
+        """Top ``num_items`` MIPS row indices per user, [B, num_items] int64 (ref :221-249)."""
+        user_embedding = self.compute_user_embedding(user_id, user_features, user_history)
+        top_items, _, _ = self.mips_module(query_embedding=user_embedding, num_items=self.num_items)
+        N.oob.poll(user_embedding.device, blocking=True)
+        return top_items
+
+    # ------------------------------------------------------------------ loss
+    def debias_net_user_value(
+        self, net_user_value: torch.Tensor, position: torch.Tensor, user_embedding: torch.Tensor
+    ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Identity hook (ref :251-277); subclasses return (debiased value, extra loss)."""
+        return net_user_value, 0
+
+    def compute_training_loss(
+        self,
+        user_embedding: torch.Tensor,  # [B, DI]
+        item_embeddings: torch.Tensor,  # [B, DI]
+        position: torch.Tensor,  # [B]
+        labels: torch.Tensor,  # [B, T]
+    ) -> torch.Tensor:
+        """In-batch softmax loss weighted by normalised net user value (ref :279-347).
+        The [B, B] logits are never materialised."""
+        row_ce = ops.InBatchSoftmaxCE.apply(user_embedding, item_embeddings, 0)  # [B]
+        hook_is_identity = type(self).debias_net_user_value is TwoTowerBaseRetrieval.debias_net_user_value
+        if hook_is_identity and labels.dim() == 2 and labels.shape[1] == self.user_value_weights.numel():
+            return ops.WeightedMeanLoss.apply(row_ce, labels, self.user_value_weights)
+        # General path: exactly the reference's expressions on [B]-sized tensors, so every
+        # broadcasting quirk (1-D labels collapsing to a scalar weight, SURVEY.md 3.1;
+        # debias heads that differentiate through the weights) behaves identically.
+        net_user_value = torch.sum(labels * self.user_value_weights, dim=-1)
+        net_user_value, additional_loss = self.debias_net_user_value(
+            net_user_value=net_user_value, position=position, user_embedding=user_embedding
+        )
+        net_user_value = torch.clamp(net_user_value, min=0.000001)
+        net_user_value = net_user_value / torch.max(net_user_value)
+        return torch.mean(row_ce * net_user_value) + additional_loss
+
+    def train_forward(
+        self,
+        user_id: torch.Tensor,  # [B]
+        user_features: torch.Tensor,  # [B, IU]
+        user_history: torch.Tensor,  # [B, H]
+        item_id: torch.Tensor,  # [B]
+        item_features: torch.Tensor,  # [B, II]
+        position: torch.Tensor,  # [B]
+        labels: torch.Tensor,  # [B, T]
+    ) -> torch.Tensor:
+        """Scalar training loss with an autograd graph (ref :349-394)."""
+        user_embedding = self.compute_user_embedding(user_id, user_features, user_history)
+        item_embeddings = self.compute_item_embeddings(item_id, item_features)
+        return self.compute_training_loss(
+            user_embedding=user_embedding, item_embeddings=item_embeddings, position=position, labels=labels
+        )

@@ -1,0 +1,65 @@
+"""TwoTowerWithUserHistoryEncoder on MI355X (mirror of
+ref:src/two_tower_with_user_history_encoder.py:14-122): the user tower input gains
+the [recent | mean] summary of the user's item history, looked up in the ITEM table."""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .two_tower_base_retrieval import TwoTowerBaseRetrieval
+from .user_history_encoder import UserHistoryEncoder
+
+
+class TwoTowerWithUserHistoryEncoder(TwoTowerBaseRetrieval):
+    def __init__(
+        self,
+        num_items: int,
+        user_id_hash_size: int,
+        user_id_embedding_dim: int,
+        user_features_size: int,
+        user_history_seqlen: int,
+        item_id_hash_size: int,
+        item_id_embedding_dim: int,
+        item_features_size: int,
+        user_value_weights: List[float],
+        mips_module: nn.Module,
+    ) -> None:
+        super().__init__(
+            num_items=num_items,
+            user_id_hash_size=user_id_hash_size,
+            user_id_embedding_dim=user_id_embedding_dim,
+            user_features_size=user_features_size,
+            item_id_hash_size=item_id_hash_size,
+            item_id_embedding_dim=item_id_embedding_dim,
+            item_features_size=item_features_size,
+            user_value_weights=user_value_weights,
+            mips_module=mips_module,
+        )
+        # 4 heads x 3 layers with positional encoding are hard-coded upstream (ref :64-70)
+        self.user_history_encoder = UserHistoryEncoder(
+            item_id_embedding_dim=item_id_embedding_dim,
+            history_len=user_history_seqlen,
+            num_attention_heads=4,
+            num_attention_layers=3,
+            use_positional_encoding=True,
+        )
+        # replaces the base tower: input = 2*DU + 2*DI (ref :81-83)
+        self.user_tower_arch = nn.Linear(
+            2 * user_id_embedding_dim + self.user_history_encoder.get_output_dim(), item_id_embedding_dim
+        )
+
+    def process_user_features(
+        self, user_id: torch.Tensor, user_features: torch.Tensor, user_history: torch.Tensor
+    ) -> torch.Tensor:
+        """[id emb | feature MLP | recent | mean] -> [B, 2*DU + 2*DI] (ref :85-122)."""
+        enc = self.user_history_encoder
+        if isinstance(enc, UserHistoryEncoder):
+            summary = enc.encode_ids(self.item_id_embedding_arch.weight, user_history)  # [B, 2, DI]
+        else:  # a user-supplied encoder module: plain lookup, then the module's own forward
+            summary = enc(ops.EmbeddingLookup.apply(self.item_id_embedding_arch.weight, user_history))
+        summary = summary.view(summary.shape[0], -1)
+        base = super().process_user_features(user_id=user_id, user_features=user_features, user_history=user_history)
+        return torch.cat([base, summary], dim=1)
