@@ -1,0 +1,75 @@
+"""TEST DOUBLE for two_tower_models_amd.sharded.ShardedTrainer's compute backend: the same
+interface as HipBackend, implemented with the CPU oracle (oracle/cpu_ref.py), so that the
+routing / collective logic can run under gloo on a box without a GPU.  Lives in tests/:
+the product never imports it."""
+import math
+
+import torch
+
+from oracle import cpu_ref as R
+
+
+class OracleBackend:
+    def __init__(self, device=torch.device("cpu")):
+        self.device = device
+
+    def empty(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32)
+
+    def gather(self, table, ids, out=None):
+        rows = table[ids]
+        if out is None:
+            return rows.clone()
+        out.copy_(rows)
+        return out
+
+    def tower_fwd(self, tin, feats, p):
+        W1, b1, W2, b2, W3, b3 = p
+        h = torch.clamp(feats @ W1.t() + b1, min=0.0)
+        D = W2.shape[0]
+        tin[:, tin.shape[1] - D:] = h @ W2.t() + b2
+        return h, tin @ W3.t() + b3
+
+    def tower_bwd(self, d_out, tin, h, feats, p, g):
+        W1, b1, W2, b2, W3, b3 = p
+        gW1, gb1, gW2, gb2, gW3, gb3 = g
+        Dm = W2.shape[0]
+        De = W3.shape[1] - Dm
+        gW3.copy_(d_out.t() @ tin)
+        gb3.copy_(d_out.sum(0))
+        d_tin = d_out @ W3
+        d_f = d_tin[:, De:]
+        gW2.copy_(d_f.t() @ h)
+        gb2.copy_(d_f.sum(0))
+        dh = (d_f @ W2) * (h > 0)
+        gW1.copy_(dh.t() @ feats)
+        gb1.copy_(dh.sum(0))
+        return d_tin[:, :De].contiguous()
+
+    def ce_fwd(self, U, I_all, off):
+        s = R.inbatch_logits(U, I_all)
+        lse = torch.logsumexp(s, dim=1)
+        idx = torch.arange(U.shape[0]) + off
+        return lse - s[torch.arange(U.shape[0]), idx], lse
+
+    def ce_bwd(self, U, I_all, off, lse, coef):
+        s = R.inbatch_logits(U, I_all)
+        G = torch.exp(s - lse[:, None])
+        G[torch.arange(U.shape[0]), torch.arange(U.shape[0]) + off] -= 1.0
+        G = G * coef[:, None]
+        return G @ I_all, G.t() @ U
+
+    def new_hyper(self, lr, betas, eps):
+        return {"lr": lr, "b1": betas[0], "b2": betas[1], "eps": eps, "step": 0}
+
+    def adam_advance(self, hyper):
+        hyper["step"] += 1
+
+    def adam_table(self, W, M, V, hyper, local_ids, grad_rows):
+        g = torch.zeros_like(W)
+        if local_ids.numel():
+            g.index_add_(0, local_ids, grad_rows)
+        R.adam_update(W, g, M, V, hyper["step"], hyper["lr"], hyper["b1"], hyper["b2"], hyper["eps"])
+
+    def adam_dense(self, p, g, m, v, hyper):
+        R.adam_update(p, g, m, v, hyper["step"], hyper["lr"], hyper["b1"], hyper["b2"], hyper["eps"])

@@ -112,7 +112,7 @@ def test_adam_trajectory_matches_torch_optim(golden):
         # ~1e-8 rounding noise that m/sqrt(v) normalises to O(lr) steps of
         # arbitrary sign.  Parity for them is bounded by steps*lr, not by ulps.
         noise_only = float(np.abs(g["g." + k]).max()) < 1e-6
-        atol = 3 * 1e-3 * 1.05 if noise_only else 2e-6
+        atol = 2 * 3 * 1e-3 * 1.05 if noise_only else 2e-6  # each run may step +-lr per step
         assert torch.allclose(v, after[k], atol=atol, rtol=1e-5), k
     # rows never looked up still moved?  (they must not: zero grad + zero state)
     touched = np.unique(np.concatenate([g[f"step{s}.in.item_id"] for s in range(3)]))

@@ -231,24 +231,34 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, GemmArgs g) {
 }
 
 // ---- column sums -----------------------------------------------------------
-constexpr int CS_ROWS = 256;  // rows per stage-1 workgroup
+// stage 1: workgroup = 64 columns x 4 row groups over a 64-row chunk (each wave reads one
+// 256-B row segment per instruction); the 4 row-group partials are combined in fixed order.
+constexpr int CS_ROWS = 64;
 __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ X, int64_t M, int64_t N,
                                                      int64_t ldx, float* __restrict__ part) {
-  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (col >= N) return;
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int64_t col = (int64_t)blockIdx.x * 64 + c;
   const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
   const int64_t r1 = (r0 + CS_ROWS < M) ? r0 + CS_ROWS : M;
   float s = 0.f;
-  for (int64_t rr = r0; rr < r1; ++rr) s += X[rr * ldx + col];
-  part[(int64_t)blockIdx.y * N + col] = s;
+  if (col < N)
+    for (int64_t rr = r0 + rg; rr < r1; rr += 4) s += X[rr * ldx + col];
+  red[rg][c] = s;
+  __syncthreads();
+  if (rg == 0 && col < N) part[(int64_t)blockIdx.y * N + col] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
 }
 __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ part, int64_t nparts,
                                                      int64_t N, float* __restrict__ out) {
-  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (col >= N) return;
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int64_t col = (int64_t)blockIdx.x * 64 + c;
   float s = 0.f;
-  for (int64_t p = 0; p < nparts; ++p) s += part[p * N + col];
-  out[col] = s;
+  if (col < N)
+    for (int64_t p = rg; p < nparts; p += 4) s += part[p * N + col];
+  red[rg][c] = s;
+  __syncthreads();
+  if (rg == 0 && col < N) out[col] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
 }
 
 struct GemmPlan {
@@ -362,9 +372,9 @@ extern "C" int tt_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, 
   if (!ws || ws_bytes < tt_colsum_workspace_bytes(M, N)) { set_error("tt_colsum_f32: workspace"); return TT_E_WORKSPACE; }
   const int64_t nparts = ceil_div(M, CS_ROWS);
   float* part = reinterpret_cast<float*>(ws);
-  colsum_stage1<<<dim3((unsigned)ceil_div(N, 256), (unsigned)nparts), 256, 0, S(stream)>>>(X, M, N, ldx, part);
+  colsum_stage1<<<dim3((unsigned)ceil_div(N, 64), (unsigned)nparts), 256, 0, S(stream)>>>(X, M, N, ldx, part);
   int rc = check_launch("colsum_stage1");
   if (rc) return rc;
-  colsum_stage2<<<(unsigned)ceil_div(N, 256), 256, 0, S(stream)>>>(part, nparts, N, out);
+  colsum_stage2<<<(unsigned)ceil_div(N, 64), 256, 0, S(stream)>>>(part, nparts, N, out);
   return check_launch("colsum_stage2");
 }
