@@ -1,0 +1,48 @@
+"""Time the in-batch-softmax CE kernels alone (MI355X).  Usage: python tools/bench_ce.py [M N]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from two_tower_models_amd import _native as N
+from two_tower_models_amd import ops
+
+lib = N.load()
+dev = torch.device("cuda:0")
+shapes = [(8192, 8192), (8192, 65536)] if len(sys.argv) < 3 else [(int(sys.argv[1]), int(sys.argv[2]))]
+D = 128
+for M, Nn in shapes:
+    U = torch.randn(M, D, device=dev) * 0.3
+    I = torch.randn(Nn, D, device=dev) * 0.3
+    coef = torch.rand(M, device=dev) / M
+    lse, ce = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    dU, dI = torch.empty(M, D, device=dev), torch.empty(Nn, D, device=dev)
+    wsn = lib.tt_inbatch_ce_workspace_bytes(M, Nn, D)
+    ws = torch.empty(wsn, dtype=torch.uint8, device=dev)
+
+    def fwd():
+        N.check(lib.tt_inbatch_ce_fwd(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, 0, lse.data_ptr(), ce.data_ptr(),
+                                      ws.data_ptr(), wsn, N.stream()), "fwd")
+
+    def bwd():
+        N.check(lib.tt_inbatch_ce_bwd(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, 0, lse.data_ptr(), coef.data_ptr(),
+                                      dU.data_ptr(), D, dI.data_ptr(), D, ws.data_ptr(), wsn, N.stream()), "bwd")
+
+    for name, fn, flops in (("fwd", fwd, 2.0 * M * Nn * D), ("bwd", bwd, 8.0 * M * Nn * D)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(5):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) / 5)
+        ms = sorted(ts)[2]
+        print(f"M={M} N={Nn} D={D} {name}: {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s "
+              f"(dma={'off' if os.environ.get('TT_CE_NO_DMA') else 'on'})", flush=True)

@@ -14,9 +14,14 @@
 // Update rule, in torch's single-tensor operation order:
 //   m += (g - m)*(1-b1);  v = v*b2 + (1-b2)*g*g;
 //   p += -(lr/(1-b1^t)) * ( m / (sqrt(v)/sqrt(1-b2^t) + eps) )
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace tt {
+
+constexpr int SWEEP_DEFAULT_VARIANT = 0;
+constexpr int SWEEP_DEFAULT_BPC = 8;
 
 struct AdamConst {
   float one_minus_b1, b2, one_minus_b2, eps, neg_step_size, bc2_sqrt;
@@ -106,13 +111,52 @@ __global__ __launch_bounds__(256) void adam_writeback_kernel(float* __restrict__
   }
 }
 
-// the roofline kernel: 3 x 16-B loads + 3 x 16-B stores per lane per iteration
+// the roofline kernel: 3 x 16-B loads + 3 x 16-B stores per lane per float4.
+// NT  : non-temporal (streaming) loads/stores -- every byte is touched exactly once per step
+// UNR : float4 triples in flight per lane per loop iteration
+template <bool NT>
+__device__ __forceinline__ float4 ld4(const float4* p) {
+  if constexpr (NT) {
+    float4 v;
+    v.x = __builtin_nontemporal_load(&p->x); v.y = __builtin_nontemporal_load(&p->y);
+    v.z = __builtin_nontemporal_load(&p->z); v.w = __builtin_nontemporal_load(&p->w);
+    return v;
+  } else {
+    return *p;
+  }
+}
+template <bool NT>
+__device__ __forceinline__ void st4(float4* p, const float4& v) {
+  if constexpr (NT) {
+    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
+    __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
+  } else {
+    *p = v;
+  }
+}
+template <bool NT, int UNR>
 __global__ __launch_bounds__(256) void adam_sweep_kernel(float4* __restrict__ W, float4* __restrict__ M,
                                                          float4* __restrict__ V, int64_t n4,
                                                          const double* __restrict__ hyper) {
   const AdamConst c = load_hyper(hyper);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + (UNR - 1) * stride < n4; i += UNR * stride) {
+    float4 p[UNR], m[UNR], v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      p[u] = ld4<NT>(W + i + u * stride); m[u] = ld4<NT>(M + i + u * stride); v[u] = ld4<NT>(V + i + u * stride);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      adam_elem_zero_grad(p[u].x, m[u].x, v[u].x, c);
+      adam_elem_zero_grad(p[u].y, m[u].y, v[u].y, c);
+      adam_elem_zero_grad(p[u].z, m[u].z, v[u].z, c);
+      adam_elem_zero_grad(p[u].w, m[u].w, v[u].w, c);
+      st4<NT>(W + i + u * stride, p[u]); st4<NT>(M + i + u * stride, m[u]); st4<NT>(V + i + u * stride, v[u]);
+    }
+  }
+  for (; i < n4; i += stride) {
     float4 p = W[i], m = M[i], v = V[i];
     adam_elem_zero_grad(p.x, m.x, v.x, c);
     adam_elem_zero_grad(p.y, m.y, v.y, c);
@@ -209,9 +253,20 @@ extern "C" int tt_adam_table(float* W, float* M, float* V, int64_t n_rows, int64
   const bool vec = ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(M) | reinterpret_cast<uintptr_t>(V)) & 15) == 0;
   const int64_t n4 = vec ? total / 4 : 0;
   if (n4 > 0) {
-    const int64_t blocks = ceil_div(n4, 256) < 256 * 8 ? ceil_div(n4, 256) : 256 * 8;
+    // tuning knobs (A/B'd on hardware, see profiles/): TT_SWEEP_VARIANT bit0 = non-temporal,
+    // bit1 = 2x unroll; TT_SWEEP_BLOCKS_PER_CU = workgroups per CU
+    static const int variant = getenv("TT_SWEEP_VARIANT") ? atoi(getenv("TT_SWEEP_VARIANT")) : SWEEP_DEFAULT_VARIANT;
+    static const int bpc = getenv("TT_SWEEP_BLOCKS_PER_CU") ? atoi(getenv("TT_SWEEP_BLOCKS_PER_CU")) : SWEEP_DEFAULT_BPC;
+    const int64_t cap = (int64_t)256 * (bpc > 0 ? bpc : 8);
+    const int64_t blocks = ceil_div(n4, 256) < cap ? ceil_div(n4, 256) : cap;
+    float4 *w4 = reinterpret_cast<float4*>(W), *m4 = reinterpret_cast<float4*>(M), *v4 = reinterpret_cast<float4*>(V);
     ProfScope prof("adam_sweep_kernel", st);
-    adam_sweep_kernel<<<(unsigned)blocks, 256, 0, st>>>(reinterpret_cast<float4*>(W), reinterpret_cast<float4*>(M), reinterpret_cast<float4*>(V), n4, hyper);
+    switch (variant & 3) {
+      case 0: adam_sweep_kernel<false, 1><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
+      case 1: adam_sweep_kernel<true, 1><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
+      case 2: adam_sweep_kernel<false, 2><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
+      default: adam_sweep_kernel<true, 2><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
+    }
     if ((rc = check_launch("adam_sweep_kernel"))) return rc;
   }
   if (n4 * 4 < total) {

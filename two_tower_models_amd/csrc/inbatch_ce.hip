@@ -20,6 +20,18 @@
 //   / partial dX slabs are merged by a second tiny kernel in fixed order
 //   (deterministic, atomic-free).
 //   All exponentials are base-2 on pre-scaled logits (v_exp_f32).
+//
+// Staging of the streamed tile, two forms (template GLDS):
+//   GLDS = true  (D in {32,64,128}, 16-B aligned rows): LDS-DMA (global_load_lds_dwordx4), no
+//     staging registers and no ds_write pass -> the D=128 kernels fit 2 waves per SIMD, so one
+//     wave's softmax epilogue hides under the other's MFMAs.  The DMA image is lane-linear
+//     (1 KiB per wave instruction), so the tile is UNPADDED [64][D] and bank conflicts are
+//     removed by an XOR swizzle of the 16-B chunk index, applied to the per-lane SOURCE
+//     address and again on every read:  chunk' = chunk ^ (row & min(D/4,16)-1).
+//   GLDS = false: global -> registers -> LDS with zero padding (any D <= 128, any alignment),
+//     row stride D+4 floats.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace tt {
@@ -111,21 +123,65 @@ __device__ __forceinline__ void tile_commit(const float4 (&st)[(DP8 + 1) / 2], f
   }
 }
 
-// St[b][a] for one 32-row sub-tile `jt` of the LDS tile
+// ---- LDS image of one streamed tile: addressing for both staging forms
+template <int DP8, bool GLDS>
+struct TileMap {
+  static constexpr int DP = DP8 * 8;
+  static constexpr int LD = GLDS ? DP : DP + 4;          // row stride in floats
+  static constexpr int CPR = DP / 4;                     // 16-B chunks per row
+  static constexpr int SW = (CPR < 16 ? CPR : 16) - 1;   // swizzle mask
+  // float offset of 16-B chunk `c` of row `row`
+  static __device__ __forceinline__ int chunk(int row, int c) {
+    return GLDS ? row * LD + 4 * (c ^ (row & SW)) : row * LD + 4 * c;
+  }
+  // float offset of element (row, col)
+  static __device__ __forceinline__ int elem(int row, int col) {
+    return GLDS ? row * LD + 4 * ((col >> 2) ^ (row & SW)) + (col & 3) : row * LD + col;
+  }
+};
+
+// LDS-DMA of one 64-row tile: each wave instruction lands 1 KiB (= 64/CPR rows); the lane
+// fetches the chunk that belongs at ITS linear LDS position after swizzling.
 template <int DP8>
+__device__ __forceinline__ void tile_dma(const float* __restrict__ Y, int64_t ld, int64_t row0, int64_t nrows,
+                                         float* Ys, int wave, int lane) {
+  using TM = TileMap<DP8, true>;
+  constexpr int RPI = 64 / TM::CPR;        // rows per wave instruction
+  constexpr int NI = BJ / RPI / 4;         // instructions per wave
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int rbase = (wave * NI + i) * RPI;
+    const int row = rbase + lane / TM::CPR;
+    const int c = (lane % TM::CPR) ^ (row & TM::SW);
+    int64_t grow = row0 + row;
+    grow = grow < nrows ? grow : nrows - 1;  // clamp: out-of-range rows are masked by the epilogue
+    const float* src = Y + grow * ld + 4 * c;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(Ys + rbase * TM::DP), 16, 0, 0);
+  }
+}
+
+// St[b][a] for one 32-row sub-tile `jt` of the LDS tile
+template <int DP8, bool GLDS>
 __device__ __forceinline__ f32x16 score_tile(const float* Ys, const float (&xr)[DP8][4], int jt, int r, int h) {
-  constexpr int LD = DP8 * 8 + 4;
+  using TM = TileMap<DP8, GLDS>;
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  const float* yrow = Ys + (jt * 32 + r) * LD + 4 * h;
+  const int row = jt * 32 + r;
+  // A-operand reads run one k-group ahead of the MFMAs (register double buffer); the
+  // scheduling barrier stops the compiler from hoisting all DP8 reads (64 VGPRs at D=128)
+  float4 y[2];
+  y[0] = *reinterpret_cast<const float4*>(Ys + TM::chunk(row, h));
 #pragma unroll
   for (int g = 0; g < DP8; ++g) {
-    const float4 y = *reinterpret_cast<const float4*>(yrow + 8 * g);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.x, xr[g][0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.y, xr[g][1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.z, xr[g][2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.w, xr[g][3], acc, 0, 0, 0);
+    if (g + 1 < DP8) y[(g + 1) & 1] = *reinterpret_cast<const float4*>(Ys + TM::chunk(row, 2 * (g + 1) + h));
+    const float4 v = y[g & 1];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, xr[g][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, xr[g][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, xr[g][2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, xr[g][3], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
   return acc;
 }
@@ -133,12 +189,28 @@ __device__ __forceinline__ f32x16 score_tile(const float* Ys, const float (&xr)[
 __device__ __forceinline__ int brow(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
 // ------------------------------------------------------------------ forward
-template <int DP8>
-__global__ __launch_bounds__(256, (DP8 >= 16 ? 1 : 2)) void ce_fwd_kernel(const CeArgs p) {
-  constexpr int LD = DP8 * 8 + 4;
+// Streams tile t+1 while tile t is on the MFMA pipe.  GLDS: DMA issued at the top of the
+// iteration, drained (vmcnt(0)) right before the barrier that ends it.
+template <int DP8, bool GLDS>
+struct Stager {
+  float4 st[GLDS ? 1 : (DP8 + 1) / 2];
+  __device__ __forceinline__ void issue(const float* Y, int64_t ld, int64_t row0, int64_t nrows, int64_t D, bool vec,
+                                        float* dst, int wave, int lane) {
+    if constexpr (GLDS) tile_dma<DP8>(Y, ld, row0, nrows, dst, wave, lane);
+    else tile_fetch<DP8>(st, Y, ld, row0, nrows, D, vec);
+  }
+  __device__ __forceinline__ void land(float* dst) {
+    if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else tile_commit<DP8>(st, dst);
+  }
+};
+
+template <int DP8, bool GLDS>
+__global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_kernel(const CeArgs p) {
+  using TM = TileMap<DP8, GLDS>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* const smem = reinterpret_cast<float*>(smem_raw);
-  constexpr int TILE_FLOATS = BJ * LD;
+  constexpr int TILE_FLOATS = BJ * TM::LD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int64_t a = (int64_t)blockIdx.x * BI + wave * 32 + r;  // this lane's user row
 
@@ -153,27 +225,31 @@ __global__ __launch_bounds__(256, (DP8 >= 16 ? 1 : 2)) void ce_fwd_kernel(const 
   bool has_dg = false;
   const int64_t want = a + p.diag_offset;
 
-  float4 st[(DP8 + 1) / 2];
+  Stager<DP8, GLDS> stg;
   if (t0 < t1) {
-    tile_fetch<DP8>(st, p.Y, p.ldy, t0 * BJ, p.RY, p.D, p.y_vec);
-    tile_commit<DP8>(st, smem);
+    stg.issue(p.Y, p.ldy, t0 * BJ, p.RY, p.D, p.y_vec, smem, wave, lane);
+    stg.land(smem);
   }
   __syncthreads();
   for (int64_t t = t0; t < t1; ++t) {
     const int cur = (int)((t - t0) & 1);
-    if (t + 1 < t1) tile_fetch<DP8>(st, p.Y, p.ldy, (t + 1) * BJ, p.RY, p.D, p.y_vec);
+    float* nxt = smem + (cur ^ 1) * TILE_FLOATS;
+    if (t + 1 < t1) stg.issue(p.Y, p.ldy, (t + 1) * BJ, p.RY, p.D, p.y_vec, nxt, wave, lane);
+    // tile-relative 32-bit indices with the lane term 4h folded in: row (li + 4h) of this tile
+    // is the diagonal iff li == want4, and is a real item iff li < lim4
+    const int64_t wrel = want - t * BJ, lrel = p.RY - t * BJ;
+    const int want4 = (wrel >= 0 && wrel < BJ) ? (int)wrel - 4 * h : -1000;
+    const int lim4 = (lrel < BJ ? (int)lrel : BJ) - 4 * h;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
-      const f32x16 acc = score_tile<DP8>(smem + cur * TILE_FLOATS, xr, jt, r, h);
-      const int64_t b0 = t * BJ + jt * 32;
+      const f32x16 acc = score_tile<DP8, GLDS>(smem + cur * TILE_FLOATS, xr, jt, r, h);
       float v2[16];
       float tmax = NEG_BIG;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int64_t b = b0 + brow(e, h);
-        const bool valid = b < p.RY;
-        if (b == want) { dg = acc[e]; has_dg = true; }
-        v2[e] = valid ? acc[e] * LOG2E : NEG_BIG;
+        const int li = jt * 32 + (e & 3) + 8 * (e >> 2);  // tile-local row, minus the 4h lane term
+        if (li == want4) { dg = acc[e]; has_dg = true; }
+        v2[e] = (li < lim4) ? acc[e] * LOG2E : NEG_BIG;
         tmax = fmaxf(tmax, v2[e]);
       }
       const float mn = fmaxf(m, tmax);
@@ -183,7 +259,7 @@ __global__ __launch_bounds__(256, (DP8 >= 16 ? 1 : 2)) void ce_fwd_kernel(const 
       s = s * fast_exp2(m - mn) + add;
       m = mn;
     }
-    if (t + 1 < t1) tile_commit<DP8>(st, smem + (cur ^ 1) * TILE_FLOATS);
+    if (t + 1 < t1) stg.land(nxt);
     __syncthreads();
   }
   // merge the two lane halves (same row a, disjoint b subsets)
@@ -215,11 +291,11 @@ __global__ void ce_fwd_finish_kernel(const float* __restrict__ part_m, const flo
 // ------------------------------------------------------------------ backward
 // STREAM_STATS = false: stationary = users (stats per lane), streamed = items   -> dU
 // STREAM_STATS = true : stationary = items, streamed = users (stats per b)      -> dI
-template <int DP8, bool STREAM_STATS>
-__global__ __launch_bounds__(256, (DP8 >= 16 ? 1 : 2)) void ce_bwd_kernel(const CeArgs p) {
-  constexpr int LD = DP8 * 8 + 4;
+template <int DP8, bool STREAM_STATS, bool GLDS>
+__global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_bwd_kernel(const CeArgs p) {
+  using TM = TileMap<DP8, GLDS>;
   constexpr int TD = (DP8 + 3) / 4;  // 32-column tiles of the output
-  constexpr int TILE_FLOATS = BJ * LD + (STREAM_STATS ? 2 * BJ : 0);
+  constexpr int TILE_FLOATS = BJ * TM::LD + (STREAM_STATS ? 2 * BJ : 0);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* const smem = reinterpret_cast<float*>(smem_raw);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -241,47 +317,56 @@ __global__ __launch_bounds__(256, (DP8 >= 16 ? 1 : 2)) void ce_bwd_kernel(const 
 #pragma unroll
     for (int e = 0; e < 16; ++e) dacc[d][e] = 0.f;
 
-  float4 st[(DP8 + 1) / 2];
+  // per-lane float offsets of the second product's B operand (see the loop below)
+  int ybase[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    ybase[q] = GLDS ? 4 * h * TM::LD + 4 * ((((r >> 2) ^ (4 * h)) & TM::SW) ^ q) + (r & 3) : 4 * h * TM::LD + r;
+
+  Stager<DP8, GLDS> stg;
   float st_lse = 0.f, st_coef = 0.f;  // threads 0..63 stage the streamed rows' stats
-  auto fetch = [&](int64_t t) {
-    tile_fetch<DP8>(st, p.Y, p.ldy, t * BJ, p.RY, p.D, p.y_vec);
+  auto issue = [&](int64_t t, float* dst) {
+    stg.issue(p.Y, p.ldy, t * BJ, p.RY, p.D, p.y_vec, dst, wave, lane);
     if (STREAM_STATS && threadIdx.x < BJ) {
       const int64_t b = t * BJ + threadIdx.x;
       st_lse = (b < p.RY) ? p.lse[b] * LOG2E : 3.0e38f;
       st_coef = (b < p.RY) ? p.coef[b] : 0.f;
     }
   };
-  auto commit = [&](int buf) {
-    float* yb = smem + buf * TILE_FLOATS;
-    tile_commit<DP8>(st, yb);
+  auto land = [&](float* dst) {
     if (STREAM_STATS && threadIdx.x < BJ) {
-      yb[BJ * LD + threadIdx.x] = st_lse;
-      yb[BJ * LD + BJ + threadIdx.x] = st_coef;
+      dst[BJ * TM::LD + threadIdx.x] = st_lse;
+      dst[BJ * TM::LD + BJ + threadIdx.x] = st_coef;
     }
+    stg.land(dst);
   };
 
-  if (t0 < t1) { fetch(t0); commit(0); }
+  if (t0 < t1) { issue(t0, smem); land(smem); }
   __syncthreads();
   for (int64_t t = t0; t < t1; ++t) {
     const int cur = (int)((t - t0) & 1);
-    if (t + 1 < t1) fetch(t + 1);
+    float* nxt = smem + (cur ^ 1) * TILE_FLOATS;
+    if (t + 1 < t1) issue(t + 1, nxt);
     const float* ys = smem + cur * TILE_FLOATS;
+    // tile-relative 32-bit indices, lane term 4h folded in (see ce_fwd_kernel).  The streamed
+    // row that pairs with stationary row a is  a + diag_offset (dU) / a - diag_offset (dI).
+    const int64_t wrel = (STREAM_STATS ? a - p.diag_offset : a + p.diag_offset) - t * BJ, lrel = p.RY - t * BJ;
+    const int want4 = (wrel >= 0 && wrel < BJ) ? (int)wrel - 4 * h : -1000;
+    const int lim4 = (lrel < BJ ? (int)lrel : BJ) - 4 * h;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
-      const f32x16 acc = score_tile<DP8>(ys, xr, jt, r, h);
-      const int64_t b0 = t * BJ + jt * 32;
+      const f32x16 acc = score_tile<DP8, GLDS>(ys, xr, jt, r, h);
       float gt[16];
       if constexpr (!STREAM_STATS) {
-        const int64_t want = a + p.diag_offset;  // item index of this user's positive
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int64_t b = b0 + brow(e, h);
+          const int li = jt * 32 + (e & 3) + 8 * (e >> 2);
           const float pr = fast_exp2(fmaf(acc[e], LOG2E, -lse2_a));
-          const float gval = coef_a * (pr - ((b == want) ? 1.f : 0.f));
-          gt[e] = (b < p.RY) ? gval : 0.f;
+          const float gval = coef_a * (pr - ((li == want4) ? 1.f : 0.f));
+          gt[e] = (li < lim4) ? gval : 0.f;
         }
       } else {
-        const float* sl = ys + BJ * LD + jt * 32 + 4 * h;
+        const float* sl = ys + BJ * TM::LD + jt * 32 + 4 * h;
         const float* sc = sl + BJ;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -291,22 +376,36 @@ __global__ __launch_bounds__(256, (DP8 >= 16 ? 1 : 2)) void ce_bwd_kernel(const 
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const int e = 4 * q + c;
-            const int64_t b = b0 + brow(e, h);  // user row
+            const int li = jt * 32 + (e & 3) + 8 * (e >> 2);
             const float pr = fast_exp2(fmaf(acc[e], LOG2E, -lv[c]));
-            gt[e] = cv[c] * (pr - ((a == b + p.diag_offset) ? 1.f : 0.f));  // coef 0 beyond RY
+            gt[e] = cv[c] * (pr - ((li == want4) ? 1.f : 0.f));  // coef 0 beyond RY
           }
         }
       }
-      // dX[a][d] += sum_b G[a][b] * Y[b][d]; reduction index b = brow(e, h) on both operands
+      // dX[a][d] += sum_b G[a][b] * Y[b][d]; reduction index b = brow(e, h) on both operands.
+      // B-operand element Y[b][32d + r].  In the swizzled image its chunk is
+      //   (8d + r/4) ^ (b & SW) = 8*(d ^ hi(e)) | ((r/4 ^ 4h) ^ (e & 3)),
+      // i.e. one of FOUR per-lane base offsets (ybase[e&3]) plus a compile-time immediate.
+      // Reads run one step ahead of the MFMAs that consume them (register double buffer);
+      // the scheduling barriers keep the compiler from hoisting all 64 reads at once.
+      float yv[2][TD];
+      auto yread = [&](int e, float (&dst)[TD]) {
+        const int E = (e & 3) + 8 * (e >> 2);
+        const int hi = (GLDS && TM::SW >= 8) ? ((e >> 2) & 1) : 0;
+#pragma unroll
+        for (int d = 0; d < TD; ++d) dst[d] = ys[(jt * 32 + E) * TM::LD + 32 * (d ^ hi) + ybase[e & 3]];
+      };
+      yread(0, yv[0]);
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float* yb = ys + (jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LD + r;
+        if (e + 1 < 16) yread(e + 1, yv[(e + 1) & 1]);
 #pragma unroll
         for (int d = 0; d < TD; ++d)
-          dacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[e], yb[32 * d], dacc[d], 0, 0, 0);
+          dacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[e], yv[e & 1][d], dacc[d], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (t + 1 < t1) commit(cur ^ 1);
+    if (t + 1 < t1) land(nxt);
     __syncthreads();
   }
 
@@ -409,23 +508,37 @@ static int opt_in_lds(K kernel, size_t lds, const char* name) {
   return 0;
 }
 
-template <int DP8>
+template <int DP8, bool GLDS>
 static int launch_fwd(const CeArgs& a, dim3 grid, hipStream_t st) {
-  const size_t lds = 2 * BJ * (DP8 * 8 + 4) * sizeof(float);
-  int rc = opt_in_lds(ce_fwd_kernel<DP8>, lds, "ce_fwd_kernel");
+  const size_t lds = 2 * BJ * TileMap<DP8, GLDS>::LD * sizeof(float);
+  int rc = opt_in_lds(ce_fwd_kernel<DP8, GLDS>, lds, "ce_fwd_kernel");
   if (rc) return rc;
   ProfScope prof("ce_fwd_kernel", st);
-  ce_fwd_kernel<DP8><<<grid, 256, lds, st>>>(a);
+  ce_fwd_kernel<DP8, GLDS><<<grid, 256, lds, st>>>(a);
   return check_launch("ce_fwd_kernel");
 }
-template <int DP8, bool SS>
+template <int DP8, bool SS, bool GLDS>
 static int launch_bwd(const CeArgs& a, dim3 grid, hipStream_t st) {
-  const size_t lds = 2 * (BJ * (DP8 * 8 + 4) + (SS ? 2 * BJ : 0)) * sizeof(float);
-  int rc = opt_in_lds(ce_bwd_kernel<DP8, SS>, lds, "ce_bwd_kernel");
+  const size_t lds = 2 * (BJ * TileMap<DP8, GLDS>::LD + (SS ? 2 * BJ : 0)) * sizeof(float);
+  int rc = opt_in_lds(ce_bwd_kernel<DP8, SS, GLDS>, lds, "ce_bwd_kernel");
   if (rc) return rc;
   ProfScope prof("ce_bwd_kernel", st);
-  ce_bwd_kernel<DP8, SS><<<grid, 256, lds, st>>>(a);
+  ce_bwd_kernel<DP8, SS, GLDS><<<grid, 256, lds, st>>>(a);
   return check_launch("ce_bwd_kernel");
+}
+// LDS-DMA staging needs an unpadded, fully valid row: D == padded D, 16-B aligned rows
+static bool can_dma(const float* Y, int64_t ld, int64_t D, int dp8) {
+  static const bool off = getenv("TT_CE_NO_DMA") != nullptr;
+  return !off && D == dp8 * 8 && (ld % 4 == 0) && al16(Y);
+}
+static int dispatch_fwd(int dp8, bool dma, const CeArgs& a, dim3 grid, hipStream_t st) {
+  if (dma) return dp8 == 4 ? launch_fwd<4, true>(a, grid, st) : dp8 == 8 ? launch_fwd<8, true>(a, grid, st) : launch_fwd<16, true>(a, grid, st);
+  return dp8 == 4 ? launch_fwd<4, false>(a, grid, st) : dp8 == 8 ? launch_fwd<8, false>(a, grid, st) : launch_fwd<16, false>(a, grid, st);
+}
+template <bool SS>
+static int dispatch_bwd(int dp8, bool dma, const CeArgs& a, dim3 grid, hipStream_t st) {
+  if (dma) return dp8 == 4 ? launch_bwd<4, SS, true>(a, grid, st) : dp8 == 8 ? launch_bwd<8, SS, true>(a, grid, st) : launch_bwd<16, SS, true>(a, grid, st);
+  return dp8 == 4 ? launch_bwd<4, SS, false>(a, grid, st) : dp8 == 8 ? launch_bwd<8, SS, false>(a, grid, st) : launch_bwd<16, SS, false>(a, grid, st);
 }
 
 }  // namespace tt
@@ -460,7 +573,7 @@ extern "C" int tt_inbatch_ce_fwd(const float* U, int64_t ldu, const float* I, in
   a.part_m = w; a.part_s = w + (int64_t)pl.splits * M; a.diag = w + 2 * (int64_t)pl.splits * M;
   dim3 grid((unsigned)ceil_div(M, BI), (unsigned)pl.splits);
   hipStream_t st = S(stream);
-  int rc = pl.dp8 == 4 ? launch_fwd<4>(a, grid, st) : pl.dp8 == 8 ? launch_fwd<8>(a, grid, st) : launch_fwd<16>(a, grid, st);
+  int rc = dispatch_fwd(pl.dp8, can_dma(I, ldi, D, pl.dp8), a, grid, st);
   if (rc) return rc;
   ce_fwd_finish_kernel<<<(unsigned)ceil_div(M, 256), 256, 0, st>>>(a.part_m, a.part_s, a.diag, M, pl.splits, row_lse, row_ce);
   return check_launch("ce_fwd_finish_kernel");
@@ -487,7 +600,7 @@ extern "C" int tt_inbatch_ce_bwd(const float* U, int64_t ldu, const float* I, in
     a.x_vec = (ldu % 4 == 0) && al16(U); a.y_vec = (ldi % 4 == 0) && al16(I);
     a.lse = row_lse; a.coef = coef; a.out = pu.splits > 1 ? slab_u : dU; a.ldo = lddu;
     dim3 grid((unsigned)ceil_div(M, BI), (unsigned)pu.splits);
-    rc = pu.dp8 == 4 ? launch_bwd<4, false>(a, grid, st) : pu.dp8 == 8 ? launch_bwd<8, false>(a, grid, st) : launch_bwd<16, false>(a, grid, st);
+    rc = dispatch_bwd<false>(pu.dp8, can_dma(I, ldi, D, pu.dp8), a, grid, st);
     if (rc) return rc;
     if (pu.splits > 1) {
       slab_reduce_kernel<<<(unsigned)(ceil_div(M * D, 256) < 2048 ? ceil_div(M * D, 256) : 2048), 256, 0, st>>>(slab_u, pu.splits, M, D, dU, lddu);
@@ -501,7 +614,7 @@ extern "C" int tt_inbatch_ce_bwd(const float* U, int64_t ldu, const float* I, in
     a.x_vec = (ldi % 4 == 0) && al16(I); a.y_vec = (ldu % 4 == 0) && al16(U);
     a.lse = row_lse; a.coef = coef; a.out = pi.splits > 1 ? slab_i : dI; a.ldo = lddi;
     dim3 grid((unsigned)ceil_div(N, BI), (unsigned)pi.splits);
-    rc = pi.dp8 == 4 ? launch_bwd<4, true>(a, grid, st) : pi.dp8 == 8 ? launch_bwd<8, true>(a, grid, st) : launch_bwd<16, true>(a, grid, st);
+    rc = dispatch_bwd<true>(pi.dp8, can_dma(U, ldu, D, pi.dp8), a, grid, st);
     if (rc) return rc;
     if (pi.splits > 1) {
       slab_reduce_kernel<<<(unsigned)(ceil_div(N * D, 256) < 2048 ? ceil_div(N * D, 256) : 2048), 256, 0, st>>>(slab_i, pi.splits, N, D, dI, lddi);

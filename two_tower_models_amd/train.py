@@ -1,0 +1,132 @@
+#!/usr/bin/env python
+"""Training driver: the loop of ref:train/train.py:85-183 on the HIP hot path.
+
+Same CLI flags and defaults (ref:train/train.py:186-255), same ``train_one_epoch(model,
+dataloader, optimizer, device)`` / ``main(args)`` entry points, same prints.  Two things
+differ, both because the upstream pipeline caps at ~46 K samples/s:
+  * ``DummyRecDataset`` keeps its tensors in HBM and ``DeviceBatches`` slices shuffled
+    batches on the device (the reference's DataLoader does per-sample __getitem__ on the
+    host); the fields and their distributions are the reference's (:47-65);
+  * the optimiser is DenseExactAdam (same update as optim.Adam, row-form embedding grads).
+``python -m two_tower_models_amd.train --model hist`` selects the history-encoder model
+(upstream's script only ever builds the base model).
+"""
+from __future__ import annotations
+
+import argparse
+
+import torch
+
+from . import BaselineMIPSModule, DenseExactAdam, TwoTowerBaseRetrieval, TwoTowerWithDebiasing, \
+    TwoTowerWithUserHistoryEncoder
+
+
+class DummyRecDataset:
+    """Random records: user_ids, user_features, user_history, item_ids, item_features,
+    positions, labels -- ref:train/train.py:20-79, generated once, resident on `device`."""
+
+    def __init__(self, num_samples: int, num_users: int, num_items: int, feature_dim: int,
+                 user_history_seqlen: int, device: torch.device = torch.device("cpu")):
+        self.num_samples, self.num_users, self.num_items, self.feature_dim = num_samples, num_users, num_items, feature_dim
+        self.user_ids = torch.randint(0, num_users, (num_samples,)).to(device)
+        self.item_ids = torch.randint(0, num_items, (num_samples,)).to(device)
+        self.labels = torch.randint(0, 2, (num_samples,)).float().to(device)
+        self.user_features = torch.randn(num_samples, feature_dim).to(device)
+        self.user_history = torch.randint(low=0, high=num_items, size=(num_samples, user_history_seqlen)).to(device)
+        self.item_features = torch.randn(num_samples, feature_dim).to(device)
+        self.positions = torch.randint(0, 10, (num_samples,)).to(device)
+
+    def __len__(self):
+        return self.num_samples
+
+    def fields(self):
+        return (self.user_ids, self.user_features, self.user_history, self.item_ids, self.item_features,
+                self.positions, self.labels)
+
+    def __getitem__(self, idx):
+        return tuple(f[idx] for f in self.fields())
+
+
+class DeviceBatches:
+    """DataLoader(dataset, batch_size, shuffle=True) semantics (ref:train/train.py:176) with
+    the permutation and the batch slicing done on the device."""
+
+    def __init__(self, dataset: DummyRecDataset, batch_size: int, shuffle: bool = True):
+        self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = len(self.dataset)
+        dev = self.dataset.user_ids.device
+        order = torch.randperm(n, device=dev) if self.shuffle else torch.arange(n, device=dev)
+        for lo in range(0, n, self.batch_size):
+            idx = order[lo:lo + self.batch_size]
+            yield tuple(f[idx] for f in self.dataset.fields())
+
+
+def train_one_epoch(model, dataloader, optimizer, device):
+    """ref:train/train.py:85-135: forward -> zero_grad -> backward -> step per batch; returns
+    the mean loss.  The per-step ``.item()`` of upstream is replaced by one at the end."""
+    model.train()
+    total_loss = None
+    for batch in dataloader:
+        user_ids, user_features, user_history, item_ids, item_features, positions, labels = (t.to(device) for t in batch)
+        batch_loss = model.train_forward(user_ids, user_features, user_history, item_ids, item_features,
+                                         positions, labels)
+        optimizer.zero_grad()
+        batch_loss.backward()
+        optimizer.step()
+        total_loss = batch_loss.detach() if total_loss is None else total_loss + batch_loss.detach()
+    return float(total_loss.item()) / len(dataloader)
+
+
+MODELS = {"base": TwoTowerBaseRetrieval, "hist": TwoTowerWithUserHistoryEncoder, "debias": TwoTowerWithDebiasing}
+
+
+def main(args):
+    if not torch.cuda.is_available():
+        raise SystemExit("two_tower_models_amd.train needs an MI355X (ROCm) device; there is no CPU path")
+    device = torch.device("cuda")
+    print(f"Running on device: {device}")
+    mips_module = BaselineMIPSModule(corpus_size=args.num_items, embedding_dim=args.embedding_dim)
+    kw = dict(num_items=args.num_items_to_return, user_id_hash_size=args.user_id_hash_size,
+              user_id_embedding_dim=args.embedding_dim, user_features_size=args.feature_dim,
+              item_id_hash_size=args.item_id_hash_size, item_id_embedding_dim=args.embedding_dim,
+              item_features_size=args.feature_dim, user_value_weights=[1.0], mips_module=mips_module)
+    if args.model != "base":
+        kw["user_history_seqlen"] = args.user_history_seqlen
+    model = MODELS[args.model](**kw).to(device)
+    dataset = DummyRecDataset(num_samples=args.num_samples, num_users=args.num_users, num_items=args.num_items,
+                              feature_dim=args.feature_dim, user_history_seqlen=args.user_history_seqlen, device=device)
+    dataloader = DeviceBatches(dataset, batch_size=args.batch_size, shuffle=True)
+    optimizer = DenseExactAdam(model.parameters(), lr=args.learning_rate)
+    for epoch in range(args.num_epochs):
+        avg_loss = train_one_epoch(model, dataloader, optimizer, device)
+        print(f"Epoch [{epoch + 1}/{args.num_epochs}] - Loss: {avg_loss:.4f}")
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="Train two-tower retrieval model")
+    for flag, typ, default, hlp in (
+        ("--num_users", int, 100, "number of users in the dataset"),
+        ("--num_items_to_return", int, 10, "number of items to return in the retrieval task"),
+        ("--user_id_hash_size", int, 1024, "embedding table size for user_id"),
+        ("--item_id_hash_size", int, 1024, "embedding table size for item_id"),
+        ("--user_history_seqlen", int, 10, "length of user history sequence"),
+        ("--num_items", int, 200, "number of items in the corpus/dataset"),
+        ("--embedding_dim", int, 32, "Dimension of user/item embeddings"),
+        ("--feature_dim", int, 8, "Dim of user_features, item_features, etc."),
+        ("--num_samples", int, 1000, "Number of samples in the dataset"),
+        ("--batch_size", int, 32, "Batch size in training loop"),
+        ("--num_epochs", int, 5, "Number of epochs to train"),
+        ("--learning_rate", float, 1e-3, "Learning rate"),
+    ):
+        p.add_argument(flag, type=typ, default=default, help=hlp)
+    p.add_argument("--model", choices=sorted(MODELS), default="base", help="model variant (upstream: base only)")
+    return p
+
+
+if __name__ == "__main__":
+    main(build_parser().parse_args())
