@@ -164,6 +164,25 @@ int tt_adam_table(float* W, float* M, float* V, int64_t n_rows, int64_t dim, con
                   const int32_t* perm, const int32_t* seg_begin, const int32_t* n_unique,
                   void* ws, int64_t ws_bytes, tt_stream_t stream);
 
+/* The same table step in three phases, for the overlapped schedule: the zero-gradient sweep
+ * does not depend on this step's gradients, only on the lookups having finished.
+ *   tt_adam_table_stash   park the OLD p,m,v of the looked-up rows in `side` (needs the plan)
+ *   tt_adam_table_sweep   every row, gradient = 0 -- run it on a SECOND stream, concurrently
+ *                         with the backward pass (HBM-bound vs MFMA/latency-bound)
+ *   tt_adam_table_finish  Adam on the looked-up rows from `side` + their summed gradients,
+ *                         then write them over the swept rows (after the sweep completed)
+ * stash -> sweep -> finish leaves bit-identical results to tt_adam_table.  `side` needs
+ * tt_adam_table_workspace_bytes(n_ids, dim) and must survive from stash to finish. */
+int tt_adam_table_stash(const float* W, const float* M, const float* V, int64_t n_rows, int64_t dim,
+                        int64_t n_ids, const int32_t* sorted_ids, const int32_t* seg_begin,
+                        const int32_t* n_unique, void* side, int64_t side_bytes, tt_stream_t stream);
+int tt_adam_table_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
+                        tt_stream_t stream);
+int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
+                         const tt_grad_sources* src /*host*/, int64_t n_ids, const int32_t* sorted_ids,
+                         const int32_t* perm, const int32_t* seg_begin, const int32_t* n_unique,
+                         void* side, int64_t side_bytes, tt_stream_t stream);
+
 /* dense parameters: `tensors` is a HOST array of n_tensors {p,g,m,v,n} descriptors
  * (device pointers inside); they are passed to the kernel by value, 64 per launch. */
 typedef struct {

@@ -65,10 +65,20 @@ class OracleBackend:
     def adam_advance(self, hyper):
         hyper["step"] += 1
 
-    def adam_table(self, W, M, V, hyper, local_ids, grad_rows):
+    # phased table step: this double keeps the old rows simply by not sweeping until finish
+    def adam_table_begin(self, W, M, V, local_ids):
+        return local_ids
+
+    def sweep_async(self, tables, hyper):
+        self._pending = list(tables)
+
+    def sweep_wait(self):
+        pass
+
+    def adam_table_finish(self, W, M, V, hyper, state, grad_rows):
         g = torch.zeros_like(W)
-        if local_ids.numel():
-            g.index_add_(0, local_ids, grad_rows)
+        if state is not None and state.numel():
+            g.index_add_(0, state, grad_rows)
         R.adam_update(W, g, M, V, hyper["step"], hyper["lr"], hyper["b1"], hyper["b2"], hyper["eps"])
 
     def adam_dense(self, p, g, m, v, hyper):

@@ -137,7 +137,7 @@ def test_rowgrad_plan_matches_stable_sort(T, n, n_rows):
     ops, N = T
     ids = torch.from_numpy(fg.uniform_ids((n,), n_rows, 51))
     rows = torch.zeros(n, 4, device=DEV)
-    plan = ops.RowPlan([ops.RowGrad(ids.to(DEV), rows)], n_rows)
+    plan = ops.RowPlan.from_grads([ops.RowGrad(ids.to(DEV), rows)], n_rows)
     order = torch.sort(ids, stable=True)
     assert torch.equal(plan.sorted_ids.cpu().long(), order.values)
     assert torch.equal(plan.perm.cpu().long(), order.indices)
@@ -171,7 +171,7 @@ def test_adam_table_equals_dense_adam(T, n_rows, D, n1, n2):
             blocks.append(ops.RowGrad(ids.to(DEV), rows.to(DEV)))
         R.adam_update(p_ref, dense, m_ref, v_ref, step)
         N.check(lib.tt_adam_advance(hyper.data_ptr(), N.stream()), "advance")
-        plan = ops.RowPlan(blocks, n_rows)
+        plan = ops.RowPlan.from_grads(blocks, n_rows)
         wsp, wsn = ops._ws(torch.device(DEV), lib.tt_adam_table_workspace_bytes(plan.n, D), "adam_side")
         N.check(lib.tt_adam_table(Wd.data_ptr(), Md.data_ptr(), Vd.data_ptr(), n_rows, D, hyper.data_ptr(),
                                   C.byref(plan.sources), plan.n, plan.sorted_ids.data_ptr(), plan.perm.data_ptr(),

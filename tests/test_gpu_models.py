@@ -205,3 +205,42 @@ def test_debias_model_loss_and_grads(golden):
     assert abs(loss.item() - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
     loss.backward()
     check_grads(model, g, rtol=5e-4)
+
+
+@pytest.mark.parametrize("kind,name", [("base", "g2_base_aligned"), ("hist", "g4_hist_d128")])
+def test_overlapped_sweep_is_bit_identical_to_serial(golden, kind, name):
+    """The side-stream schedule (zero_grad starts the sweep, step finishes from the stash) must
+    leave exactly the bits of the serial schedule, for touched and untouched rows alike."""
+    import two_tower_models_amd as A
+    g = golden(name)
+    finals = []
+    for overlap in (True, False):
+        model = make_model(kind, g)
+        opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep=overlap)
+        b = batch_of(g)
+        for _ in range(3):
+            loss = model.train_forward(*b)
+            opt.zero_grad()
+            assert (opt._begun is not None) == overlap
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        finals.append({k: v.clone() for k, v in model.state_dict().items()})
+        assert opt.step_count == 3
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
+
+
+def test_zero_grad_before_forward_takes_serial_schedule(golden):
+    import two_tower_models_amd as A
+    g = golden("g2_base_aligned")
+    model = make_model("base", g)
+    opt = A.DenseExactAdam(model.parameters(), lr=1e-3)
+    losses = []
+    for s in range(3):
+        opt.zero_grad()  # the other common loop order
+        loss = model.train_forward(*batch_of(g, prefix=f"step{s}.in."))
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert np.allclose(losses, g["adam_losses"], atol=1e-4)

@@ -66,7 +66,10 @@ __device__ __forceinline__ const float* source_row(const tt_grad_sources& s, int
   return s.rows[k] + (pos - s.first[k]) * s.ld[k];
 }
 
-// one wavefront per unique row; 4 rows per workgroup
+// one wavefront per unique row; 4 rows per workgroup.  FROM_SIDE: the row's OLD p,m,v were
+// parked in the side buffer by adam_stash_kernel (overlapped schedule: by now the sweep may
+// already have overwritten them in the table).
+template <bool FROM_SIDE>
 __global__ __launch_bounds__(256) void adam_touched_kernel(const float* __restrict__ W, const float* __restrict__ M,
                                                            const float* __restrict__ V, int64_t dim,
                                                            const double* __restrict__ hyper, const tt_grad_sources src,
@@ -85,11 +88,31 @@ __global__ __launch_bounds__(256) void adam_touched_kernel(const float* __restri
   for (int64_t d = lane; d < dim; d += 64) {
     float g = 0.f;
     for (int32_t t = t0; t < t1; ++t) g += source_row(src, perm[t])[d];
-    float p = W[row * dim + d], m = M[row * dim + d], v = V[row * dim + d];
+    float p, m, v;
+    if constexpr (FROM_SIDE) { p = out[d]; m = out[dim + d]; v = out[2 * dim + d]; }
+    else { p = W[row * dim + d]; m = M[row * dim + d]; v = V[row * dim + d]; }
     adam_elem(p, m, v, g, c);
     out[d] = p;
     out[dim + d] = m;
     out[2 * dim + d] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_stash_kernel(const float* __restrict__ W, const float* __restrict__ M,
+                                                         const float* __restrict__ V, int64_t dim,
+                                                         const int32_t* __restrict__ sorted_ids,
+                                                         const int32_t* __restrict__ seg_begin,
+                                                         const int32_t* __restrict__ n_unique,
+                                                         float* __restrict__ side) {
+  const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= *n_unique) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = sorted_ids[seg_begin[u]];
+  float* out = side + u * 3 * dim;
+  for (int64_t d = lane; d < dim; d += 64) {
+    out[d] = W[row * dim + d];
+    out[dim + d] = M[row * dim + d];
+    out[2 * dim + d] = V[row * dim + d];
   }
 }
 
@@ -219,6 +242,38 @@ static bool check_sources(const tt_grad_sources* s, int64_t n_ids, int64_t dim) 
   return s->first[s->n_sources] == n_ids;
 }
 
+static int launch_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
+                        hipStream_t st) {
+  int rc;
+  const int64_t total = n_rows * dim;
+  const bool vec = ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(M) | reinterpret_cast<uintptr_t>(V)) & 15) == 0;
+  const int64_t n4 = vec ? total / 4 : 0;
+  if (n4 > 0) {
+    // tuning knobs (A/B'd on hardware, see profiles/): TT_SWEEP_VARIANT bit0 = non-temporal,
+    // bit1 = 2x unroll; TT_SWEEP_BLOCKS_PER_CU = workgroups per CU
+    static const int variant = getenv("TT_SWEEP_VARIANT") ? atoi(getenv("TT_SWEEP_VARIANT")) : SWEEP_DEFAULT_VARIANT;
+    static const int bpc = getenv("TT_SWEEP_BLOCKS_PER_CU") ? atoi(getenv("TT_SWEEP_BLOCKS_PER_CU")) : SWEEP_DEFAULT_BPC;
+    const int64_t cap = (int64_t)256 * (bpc > 0 ? bpc : 8);
+    const int64_t blocks = ceil_div(n4, 256) < cap ? ceil_div(n4, 256) : cap;
+    float4 *w4 = reinterpret_cast<float4*>(W), *m4 = reinterpret_cast<float4*>(M), *v4 = reinterpret_cast<float4*>(V);
+    ProfScope prof("adam_sweep_kernel", st);
+    switch (variant & 3) {
+      case 0: adam_sweep_kernel<false, 1><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
+      case 1: adam_sweep_kernel<true, 1><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
+      case 2: adam_sweep_kernel<false, 2><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
+      default: adam_sweep_kernel<true, 2><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
+    }
+    if ((rc = check_launch("adam_sweep_kernel"))) return rc;
+  }
+  if (n4 * 4 < total) {
+    const int64_t rem = total - n4 * 4;
+    const int64_t blocks = ceil_div(rem, 256) < 2048 ? ceil_div(rem, 256) : 2048;
+    adam_sweep_scalar_kernel<<<(unsigned)blocks, 256, 0, st>>>(W, M, V, n4 * 4, total, hyper);
+    if ((rc = check_launch("adam_sweep_scalar_kernel"))) return rc;
+  }
+  return 0;
+}
+
 }  // namespace tt
 
 using namespace tt;
@@ -246,40 +301,52 @@ extern "C" int tt_adam_table(float* W, float* M, float* V, int64_t n_rows, int64
     if (!sorted_ids || !perm || !seg_begin || !n_unique || !ws) return fail_arg("tt_adam_table: null plan");
     if (!check_sources(src, n_ids, dim)) return fail_arg("tt_adam_table: gradient sources");
     if (ws_bytes < tt_adam_table_workspace_bytes(n_ids, dim)) { set_error("tt_adam_table: workspace"); return TT_E_WORKSPACE; }
-    adam_touched_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, reinterpret_cast<float*>(ws));
+    adam_touched_kernel<false><<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, reinterpret_cast<float*>(ws));
     if ((rc = check_launch("adam_touched_kernel"))) return rc;
   }
-  const int64_t total = n_rows * dim;
-  const bool vec = ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(M) | reinterpret_cast<uintptr_t>(V)) & 15) == 0;
-  const int64_t n4 = vec ? total / 4 : 0;
-  if (n4 > 0) {
-    // tuning knobs (A/B'd on hardware, see profiles/): TT_SWEEP_VARIANT bit0 = non-temporal,
-    // bit1 = 2x unroll; TT_SWEEP_BLOCKS_PER_CU = workgroups per CU
-    static const int variant = getenv("TT_SWEEP_VARIANT") ? atoi(getenv("TT_SWEEP_VARIANT")) : SWEEP_DEFAULT_VARIANT;
-    static const int bpc = getenv("TT_SWEEP_BLOCKS_PER_CU") ? atoi(getenv("TT_SWEEP_BLOCKS_PER_CU")) : SWEEP_DEFAULT_BPC;
-    const int64_t cap = (int64_t)256 * (bpc > 0 ? bpc : 8);
-    const int64_t blocks = ceil_div(n4, 256) < cap ? ceil_div(n4, 256) : cap;
-    float4 *w4 = reinterpret_cast<float4*>(W), *m4 = reinterpret_cast<float4*>(M), *v4 = reinterpret_cast<float4*>(V);
-    ProfScope prof("adam_sweep_kernel", st);
-    switch (variant & 3) {
-      case 0: adam_sweep_kernel<false, 1><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
-      case 1: adam_sweep_kernel<true, 1><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
-      case 2: adam_sweep_kernel<false, 2><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
-      default: adam_sweep_kernel<true, 2><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
-    }
-    if ((rc = check_launch("adam_sweep_kernel"))) return rc;
-  }
-  if (n4 * 4 < total) {
-    const int64_t rem = total - n4 * 4;
-    const int64_t blocks = ceil_div(rem, 256) < 2048 ? ceil_div(rem, 256) : 2048;
-    adam_sweep_scalar_kernel<<<(unsigned)blocks, 256, 0, st>>>(W, M, V, n4 * 4, total, hyper);
-    if ((rc = check_launch("adam_sweep_scalar_kernel"))) return rc;
-  }
+  if ((rc = launch_sweep(W, M, V, n_rows, dim, hyper, st))) return rc;
   if (n_ids > 0) {
     adam_writeback_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, dim, sorted_ids, seg_begin, n_unique, reinterpret_cast<const float*>(ws));
     if ((rc = check_launch("adam_writeback_kernel"))) return rc;
   }
   return 0;
+}
+
+// ---- the same table step in three phases, so the sweep can run on its own stream while
+// the backward pass is still producing the row gradients (DESIGN.md "overlap")
+extern "C" int tt_adam_table_stash(const float* W, const float* M, const float* V, int64_t n_rows, int64_t dim,
+                                   int64_t n_ids, const int32_t* sorted_ids, const int32_t* seg_begin,
+                                   const int32_t* n_unique, void* side, int64_t side_bytes, tt_stream_t stream) {
+  if (!W || !M || !V || !sorted_ids || !seg_begin || !n_unique || !side) return fail_arg("tt_adam_table_stash: null pointer");
+  if (n_rows <= 0 || dim <= 0 || n_ids <= 0) return fail_arg("tt_adam_table_stash: sizes");
+  if (side_bytes < tt_adam_table_workspace_bytes(n_ids, dim)) { set_error("tt_adam_table_stash: side buffer"); return TT_E_WORKSPACE; }
+  adam_stash_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, S(stream)>>>(W, M, V, dim, sorted_ids, seg_begin, n_unique, reinterpret_cast<float*>(side));
+  return check_launch("adam_stash_kernel");
+}
+
+extern "C" int tt_adam_table_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
+                                   tt_stream_t stream) {
+  if (!W || !M || !V || !hyper) return fail_arg("tt_adam_table_sweep: null pointer");
+  if (n_rows <= 0 || dim <= 0) return fail_arg("tt_adam_table_sweep: sizes");
+  return launch_sweep(W, M, V, n_rows, dim, hyper, S(stream));
+}
+
+extern "C" int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
+                                    const tt_grad_sources* src, int64_t n_ids, const int32_t* sorted_ids,
+                                    const int32_t* perm, const int32_t* seg_begin, const int32_t* n_unique,
+                                    void* side, int64_t side_bytes, tt_stream_t stream) {
+  if (!W || !M || !V || !hyper || !sorted_ids || !perm || !seg_begin || !n_unique || !side)
+    return fail_arg("tt_adam_table_finish: null pointer");
+  if (n_rows <= 0 || dim <= 0 || n_ids <= 0) return fail_arg("tt_adam_table_finish: sizes");
+  if (!check_sources(src, n_ids, dim)) return fail_arg("tt_adam_table_finish: gradient sources");
+  if (side_bytes < tt_adam_table_workspace_bytes(n_ids, dim)) { set_error("tt_adam_table_finish: side buffer"); return TT_E_WORKSPACE; }
+  hipStream_t st = S(stream);
+  float* sd = reinterpret_cast<float*>(side);
+  adam_touched_kernel<true><<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, sd);
+  int rc = check_launch("adam_touched_kernel");
+  if (rc) return rc;
+  adam_writeback_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, dim, sorted_ids, seg_begin, n_unique, sd);
+  return check_launch("adam_writeback_kernel");
 }
 
 extern "C" int tt_adam_dense(const tt_adam_tensor* tensors, int32_t n_tensors, const double* hyper,

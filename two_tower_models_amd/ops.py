@@ -82,52 +82,82 @@ def gather_rows_into(table: torch.Tensor, ids: torch.Tensor, out: torch.Tensor) 
 
 # ----------------------------------------------------------------- row-gradient plumbing
 class RowGrad:
-    """One block of embedding-row gradients: `rows[i]` is dLoss/d table[ids[i]]."""
+    """One block of embedding-row gradients: `rows[i]` is dLoss/d table[ids[i]].  `index` is
+    the position of the originating lookup among the table's lookups of this forward."""
 
-    __slots__ = ("ids", "rows")
+    __slots__ = ("ids", "rows", "index")
 
-    def __init__(self, ids: torch.Tensor, rows: torch.Tensor):
+    def __init__(self, ids: torch.Tensor, rows: torch.Tensor, index: Optional[int] = None):
         self.ids = ids.reshape(-1)
         self.rows = _rowmajor(rows)
+        self.index = index
 
 
 class RowPlan:
-    """Device-side run structure of the ids looked up in a step (tt_rowgrad_plan)."""
+    """Device-side run structure of the ids looked up in a step (tt_rowgrad_plan).  Built from
+    the ids alone (they are known at forward time); the gradient blocks are attached later."""
 
-    def __init__(self, blocks: Sequence[RowGrad], n_rows: int):
-        dev = blocks[0].ids.device
+    def __init__(self, id_blocks: Sequence[torch.Tensor], n_rows: int, slot: str = "plan"):
+        if len(id_blocks) > N.TT_MAX_GRAD_SOURCES:
+            raise RuntimeError(f"more than {N.TT_MAX_GRAD_SOURCES} lookups of one table in a step")
+        id_blocks = [b.reshape(-1) for b in id_blocks]
+        dev = id_blocks[0].device
         lib = N.load()
-        ids = blocks[0].ids if len(blocks) == 1 else torch.cat([b.ids for b in blocks])
+        ids = id_blocks[0] if len(id_blocks) == 1 else torch.cat(id_blocks)
         n = ids.numel()
         self.n = n
+        self.block_sizes = [b.numel() for b in id_blocks]
         self.sorted_ids = torch.empty(n, dtype=torch.int32, device=dev)
         self.perm = torch.empty(n, dtype=torch.int32, device=dev)
         self.seg_begin = torch.empty(n + 1, dtype=torch.int32, device=dev)
         self.n_unique = torch.empty(1, dtype=torch.int32, device=dev)
-        wsp, wsn = _ws(dev, lib.tt_rowgrad_workspace_bytes(n), "plan")
+        wsp, wsn = _ws(dev, lib.tt_rowgrad_workspace_bytes(n), slot)
         N.check(lib.tt_rowgrad_plan(ids.data_ptr(), n, n_rows, self.sorted_ids.data_ptr(), self.perm.data_ptr(),
                                     self.seg_begin.data_ptr(), self.n_unique.data_ptr(),
                                     N.oob.flag(dev).data_ptr(), wsp, wsn, N.stream()), "tt_rowgrad_plan")
-        if len(blocks) > N.TT_MAX_GRAD_SOURCES:
-            raise RuntimeError(f"more than {N.TT_MAX_GRAD_SOURCES} lookups of one table in a step")
-        self.sources = N.GradSources()
+        self.sources = None
+        self._keep = None
+
+    @classmethod
+    def from_grads(cls, blocks: Sequence[RowGrad], n_rows: int) -> "RowPlan":
+        plan = cls([b.ids for b in blocks], n_rows)
+        plan.attach([b.rows for b in blocks])
+        return plan
+
+    def attach(self, row_blocks: Sequence[torch.Tensor]) -> None:
+        """Bind the gradient rows, one block per id block, in the same order."""
+        if len(row_blocks) != len(self.block_sizes):
+            raise RuntimeError("number of gradient blocks differs from the number of lookups")
+        src = N.GradSources()
         first = 0
-        for k, b in enumerate(blocks):
-            p, r, _, ld = _f32_2d(b.rows, "grad rows")
-            self.sources.rows[k] = p
-            self.sources.ld[k] = ld
-            self.sources.first[k] = first
+        keep = []
+        for k, rows in enumerate(row_blocks):
+            rows = _rowmajor(rows)
+            p, r, _, ld = _f32_2d(rows, "grad rows")
+            if r != self.block_sizes[k]:
+                raise RuntimeError("gradient block size differs from its lookup")
+            src.rows[k], src.ld[k], src.first[k] = p, ld, first
             first += r
-        self.sources.first[len(blocks)] = first
-        self.sources.n_sources = len(blocks)
-        self._keep = list(blocks)
-        assert first == n
+            keep.append(rows)
+        src.first[len(row_blocks)] = first
+        src.n_sources = len(row_blocks)
+        self.sources, self._keep = src, keep
+
+
+def register_lookup(weight: torch.Tensor, ids: torch.Tensor) -> Optional[int]:
+    """Tell the optimiser that owns `weight` which rows this forward reads (it can then plan
+    the step and start the table sweep before the gradients exist).  Returns the lookup's index."""
+    reg = getattr(weight, "_tt_lookups", None)
+    if reg is None or not weight.requires_grad:
+        return None
+    reg.append(ids.reshape(-1))
+    return len(reg) - 1
 
 
 def dense_grad_from_rows(blocks: Sequence[RowGrad], n_rows: int, dim: int) -> torch.Tensor:
     """The dense [n_rows, dim] embedding gradient torch.optim expects."""
     dev = blocks[0].ids.device
-    plan = RowPlan(blocks, n_rows)
+    plan = RowPlan.from_grads(blocks, n_rows)
     dense = torch.zeros(n_rows, dim, dtype=torch.float32, device=dev)
     N.check(N.load().tt_rowgrad_dense(C.byref(plan.sources), plan.n, dim, plan.sorted_ids.data_ptr(),
                                       plan.perm.data_ptr(), plan.seg_begin.data_ptr(),
@@ -135,13 +165,14 @@ def dense_grad_from_rows(blocks: Sequence[RowGrad], n_rows: int, dim: int) -> to
     return dense
 
 
-def _route_table_grad(weight: torch.Tensor, ids: torch.Tensor, rows: torch.Tensor) -> Optional[torch.Tensor]:
+def _route_table_grad(weight: torch.Tensor, ids: torch.Tensor, rows: torch.Tensor,
+                      index: Optional[int] = None) -> Optional[torch.Tensor]:
     """Embedding backward.  If the optimiser that owns `weight` consumes row gradients
     (two_tower_models_amd.optim.DenseExactAdam sets `_tt_rowgrads`), park them there and
     return no dense gradient; otherwise build the dense gradient torch.optim needs."""
     stash = getattr(weight, "_tt_rowgrads", None)
     if stash is not None:
-        stash.append(RowGrad(ids, rows))
+        stash.append(RowGrad(ids, rows, index))
         return None
     return dense_grad_from_rows([RowGrad(ids, rows)], weight.shape[0], weight.shape[1])
 
@@ -155,6 +186,7 @@ class EmbeddingLookup(torch.autograd.Function):
         out = torch.empty(ids.numel(), weight.shape[1], dtype=torch.float32, device=weight.device)
         gather_rows_into(weight, ids.reshape(-1), out)
         ctx.weight = weight
+        ctx.lookup_index = register_lookup(weight, ids) if ctx.needs_input_grad[0] else None
         ctx.save_for_backward(ids)
         return out.view(*ids.shape, weight.shape[1])
 
@@ -162,7 +194,7 @@ class EmbeddingLookup(torch.autograd.Function):
     def backward(ctx, g):
         (ids,) = ctx.saved_tensors
         w = ctx.weight
-        return _route_table_grad(w, ids.reshape(-1), g.reshape(-1, w.shape[1])), None
+        return _route_table_grad(w, ids.reshape(-1), g.reshape(-1, w.shape[1]), ctx.lookup_index), None
 
 
 class Linear(torch.autograd.Function):
@@ -247,6 +279,7 @@ class TowerInput(torch.autograd.Function):
         Hd = W1.shape[0]
         tin = torch.empty(B, D + Dm, dtype=torch.float32, device=dev)
         gather_rows_into(weight, ids.reshape(-1), tin[:, :D])
+        ctx.lookup_index = register_lookup(weight, ids) if ctx.needs_input_grad[0] else None
         h = torch.empty(B, Hd, dtype=torch.float32, device=dev)
         gemm(N.TT_GEMM_NT, feats, W1, h, B, Hd, F, bias=b1, epilogue=N.TT_EPI_RELU)
         gemm(N.TT_GEMM_NT, h, W2, tin[:, D:], B, Dm, Hd, bias=b2)
@@ -274,7 +307,7 @@ class TowerInput(torch.autograd.Function):
         db1 = colsum(dh)
         dweight = None
         if ctx.needs_input_grad[0]:
-            dweight = _route_table_grad(w, ids.reshape(-1), d_tin[:, :D])
+            dweight = _route_table_grad(w, ids.reshape(-1), d_tin[:, :D], ctx.lookup_index)
         return dweight, None, None, dW1, db1, dW2, db2
 
 
@@ -396,6 +429,7 @@ class HistoryEncoder(torch.autograd.Function):
         if L == 0:
             out[:, 0, :].copy_(x.view(B, H, D)[:, 0, :])
         ctx.dims = (B, H, D, L, heads)
+        ctx.lookup_index = register_lookup(source, ids) if (ids is not None and ctx.needs_input_grad[0]) else None
         ctx.table = source if ids is not None else None
         ctx.has_ids = ids is not None
         ctx.save_for_backward(ids, *layer_params, *saved)
@@ -446,7 +480,7 @@ class HistoryEncoder(torch.autograd.Function):
         d_source = None
         if ctx.needs_input_grad[0]:
             if ctx.has_ids:
-                d_source = _route_table_grad(ctx.table, ids.reshape(-1), dx)
+                d_source = _route_table_grad(ctx.table, ids.reshape(-1), dx, ctx.lookup_index)
             else:
                 d_source = dx.view(B, H, D)
         return (d_source, None, None, None, *grads)

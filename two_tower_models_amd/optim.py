@@ -5,24 +5,36 @@
 ``nn.Embedding`` produces a dense gradient.  This optimiser is value-equivalent
 (same update rule, same bias correction, every row stepped) but never builds the
 dense gradient: the embedding backward leaves its row gradients with the table
-(``weight._tt_rowgrads``), and ``step()`` runs
+(``weight._tt_rowgrads``), and the table step is
 
     plan (stable sort of the looked-up ids)  ->  Adam on the looked-up rows
     ->  zero-gradient Adam sweep over the whole table (the HBM-bound part)
     ->  write the looked-up rows back,
 
 one multi-tensor launch for all dense parameters, and one 1-thread launch that
-advances the step count / bias corrections in device memory (so a captured
-hipGraph of the step replays correctly).
+advances the step count / bias corrections in device memory.
 
-Use exactly like the reference uses ``optim.Adam``:
-    opt = DenseExactAdam(model.parameters(), lr=1e-3)
+Overlapped schedule (``overlap_sweep=True``, default).  The sweep does not depend on the
+step's gradients, only on the forward's lookups having read the old rows.  The lookups
+register their ids with the table at forward time, so when the caller follows the
+reference loop order
+
     loss = model.train_forward(...); opt.zero_grad(); loss.backward(); opt.step()
+
+``zero_grad()`` -- which sits between forward and backward -- already knows the rows:
+it plans, parks the old p/m/v of the looked-up rows in a side buffer and launches the sweep
+on a second HIP stream, where it runs concurrently with the backward pass (HBM-bound next
+to MFMA/latency-bound work).  ``step()`` then updates the looked-up rows from the side
+buffer and writes them over the swept table.  Results are bit-identical to the serial
+schedule.  Any other call order (zero_grad before forward, no zero_grad at all) simply
+takes the serial schedule inside ``step()``.  The one thing the overlapped schedule
+assumes is that a ``zero_grad()`` issued after a forward IS followed by that forward's
+``backward()`` and ``step()``; pass ``overlap_sweep=False`` if that does not hold.
 """
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Iterable, List
+from typing import Dict, Iterable, List, Optional
 
 import torch
 
@@ -30,9 +42,18 @@ from . import _native as N
 from . import ops
 
 
+class _TableStep:
+    """State of one table between the overlapped begin (in zero_grad) and finish (in step)."""
+
+    __slots__ = ("plan", "side")
+
+    def __init__(self, plan, side):
+        self.plan, self.side = plan, side
+
+
 class DenseExactAdam(torch.optim.Optimizer):
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999),
-                 eps: float = 1e-8) -> None:
+                 eps: float = 1e-8, overlap_sweep: bool = True) -> None:
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
@@ -43,8 +64,14 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._dense = [p for p in self._params if not getattr(p, "_tt_is_table", False)]
         for p in self._tables:
             p._tt_rowgrads = []  # switches the embedding backward to row form
+            p._tt_lookups = []   # the forward's lookups register their ids here
+        self.overlap_sweep = overlap_sweep
         self._hyper = None
         self._ready = False
+        self._side_stream: Optional[torch.cuda.Stream] = None
+        self._begun: Optional[Dict[torch.nn.Parameter, _TableStep]] = None
+        self._sweep_done: Optional[torch.cuda.Event] = None
+        self._side_bufs: Dict[int, torch.Tensor] = {}
 
     # state is created lazily, on the parameters' device
     def _init_state(self) -> None:
@@ -58,16 +85,71 @@ class DenseExactAdam(torch.optim.Optimizer):
             st = self.state[p]
             st["exp_avg"] = torch.zeros_like(p)
             st["exp_avg_sq"] = torch.zeros_like(p)
+        self._side_stream = torch.cuda.Stream(device=dev)
         self._ready = True
 
     @property
     def step_count(self) -> int:
         return 0 if self._hyper is None else int(self._hyper[4].item())
 
+    def _side(self, p: torch.Tensor, nbytes: int) -> torch.Tensor:
+        buf = self._side_bufs.get(id(p))
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=p.device)
+            self._side_bufs[id(p)] = buf
+        return buf
+
+    # ------------------------------------------------------------------ overlapped begin
+    def _begin_overlapped(self) -> None:
+        lib = N.load()
+        if not self._ready:
+            self._init_state()
+        hyper = self._hyper.data_ptr()
+        N.check(lib.tt_adam_advance(hyper, N.stream()), "tt_adam_advance")
+        begun: Dict[torch.nn.Parameter, _TableStep] = {}
+        for p in self._tables:
+            if not p._tt_lookups:
+                continue
+            n_rows, dim = p.shape
+            st = self.state[p]
+            plan = ops.RowPlan(p._tt_lookups, n_rows, slot=f"plan{id(p)}")
+            side = self._side(p, lib.tt_adam_table_workspace_bytes(plan.n, dim))
+            N.check(lib.tt_adam_table_stash(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                            n_rows, dim, plan.n, plan.sorted_ids.data_ptr(),
+                                            plan.seg_begin.data_ptr(), plan.n_unique.data_ptr(), side.data_ptr(),
+                                            side.numel(), N.stream()), "tt_adam_table_stash")
+            begun[p] = _TableStep(plan, side)
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)  # lookups + stashes are complete at this point of the main stream
+        self._side_stream.wait_event(ready)
+        for p in begun:
+            st = self.state[p]
+            N.check(lib.tt_adam_table_sweep(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                            p.shape[0], p.shape[1], hyper, self._side_stream.cuda_stream),
+                    "tt_adam_table_sweep")
+        self._sweep_done = torch.cuda.Event()
+        self._sweep_done.record(self._side_stream)
+        self._begun = begun
+
     def zero_grad(self, set_to_none: bool = True) -> None:
         for p in self._tables:
             p._tt_rowgrads.clear()
         super().zero_grad(set_to_none=set_to_none)
+        if (self.overlap_sweep and self._begun is None and any(p._tt_lookups for p in self._tables)
+                and self._tables[0].is_cuda and not torch.cuda.is_current_stream_capturing()):
+            self._begin_overlapped()
+
+    # ------------------------------------------------------------------ step
+    @staticmethod
+    def _ordered_rows(p) -> List[torch.Tensor]:
+        """Gradient blocks in lookup order (backward delivers them in reverse)."""
+        blocks = p._tt_rowgrads
+        if len(blocks) != len(p._tt_lookups) or any(b.index is None for b in blocks):
+            raise RuntimeError(
+                "a table lookup of the last forward received no gradient (or more than one forward ran "
+                "before zero_grad()); use DenseExactAdam(..., overlap_sweep=False) for this call pattern")
+        return [b.rows for b in sorted(blocks, key=lambda b: b.index)]
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -77,23 +159,43 @@ class DenseExactAdam(torch.optim.Optimizer):
             self._init_state()
         lib = N.load()
         hyper = self._hyper.data_ptr()
-        N.check(lib.tt_adam_advance(hyper, N.stream()), "tt_adam_advance")
-
+        if self._begun is not None:
+            # overlapped schedule: hyper already advanced, tables already swept on the side stream
+            torch.cuda.current_stream().wait_event(self._sweep_done)
+            for p, ts in self._begun.items():
+                st = self.state[p]
+                ts.plan.attach(self._ordered_rows(p))
+                N.check(lib.tt_adam_table_finish(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                                 p.shape[0], p.shape[1], hyper, C.byref(ts.plan.sources), ts.plan.n,
+                                                 ts.plan.sorted_ids.data_ptr(), ts.plan.perm.data_ptr(),
+                                                 ts.plan.seg_begin.data_ptr(), ts.plan.n_unique.data_ptr(),
+                                                 ts.side.data_ptr(), ts.side.numel(), N.stream()),
+                        "tt_adam_table_finish")
+            self._begun = None
+        else:
+            N.check(lib.tt_adam_advance(hyper, N.stream()), "tt_adam_advance")
+            for p in self._tables:
+                blocks = p._tt_rowgrads
+                st = self.state[p]
+                n_rows, dim = p.shape
+                if p.grad is not None:
+                    raise RuntimeError("embedding table received a dense gradient while in row-gradient mode")
+                if blocks:
+                    if all(b.index is not None for b in blocks):
+                        # forward (lookup) order, like the overlapped schedule: duplicates of a row
+                        # across lookups are then summed in the same order by both schedules
+                        blocks = sorted(blocks, key=lambda b: b.index)
+                    plan = ops.RowPlan.from_grads(blocks, n_rows)
+                    wsp, wsn = ops._ws(p.device, lib.tt_adam_table_workspace_bytes(plan.n, dim), "adam_side")
+                    N.check(lib.tt_adam_table(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                              n_rows, dim, hyper, C.byref(plan.sources), plan.n,
+                                              plan.sorted_ids.data_ptr(), plan.perm.data_ptr(),
+                                              plan.seg_begin.data_ptr(), plan.n_unique.data_ptr(), wsp, wsn,
+                                              N.stream()), "tt_adam_table")
+                # a table with no lookups this step has grad None: torch.optim skips it too
         for p in self._tables:
-            blocks = p._tt_rowgrads
-            st = self.state[p]
-            n_rows, dim = p.shape
-            if p.grad is not None:
-                raise RuntimeError("embedding table received a dense gradient while in row-gradient mode")
-            if blocks:
-                plan = ops.RowPlan(blocks, n_rows)
-                wsp, wsn = ops._ws(p.device, lib.tt_adam_table_workspace_bytes(plan.n, dim), "adam_side")
-                N.check(lib.tt_adam_table(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                          n_rows, dim, hyper, C.byref(plan.sources), plan.n,
-                                          plan.sorted_ids.data_ptr(), plan.perm.data_ptr(),
-                                          plan.seg_begin.data_ptr(), plan.n_unique.data_ptr(), wsp, wsn,
-                                          N.stream()), "tt_adam_table")
-            # a table with no lookups this step has grad None: torch.optim skips it too
+            p._tt_lookups.clear()
+            p._tt_rowgrads.clear()
 
         live = [p for p in self._dense if p.grad is not None]
         if live:

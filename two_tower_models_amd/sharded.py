@@ -83,6 +83,9 @@ class HipBackend:
         self.N, self.ops = _native, ops
         self.lib = _native.load()
         self.device = device
+        self._sides = {}
+        self._side_stream = None
+        self._sweep_done = None
 
     def empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
@@ -158,19 +161,53 @@ class HipBackend:
     def adam_advance(self, hyper):
         self.N.check(self.lib.tt_adam_advance(hyper.data_ptr(), self.N.stream()), "tt_adam_advance")
 
-    def adam_table(self, W, M, V, hyper, local_ids: torch.Tensor, grad_rows: torch.Tensor):
+    # the table step in three phases (stash -> sweep on a side stream -> finish), see optim.py
+    def adam_table_begin(self, W, M, V, local_ids: torch.Tensor):
+        if local_ids.numel() == 0:
+            return None
         ops, N, lib = self.ops, self.N, self.lib
         n_rows, dim = W.shape
-        if local_ids.numel() == 0:  # nothing routed here this step: zero-gradient sweep only
-            N.check(lib.tt_adam_table(W.data_ptr(), M.data_ptr(), V.data_ptr(), n_rows, dim, hyper.data_ptr(), None,
-                                      0, None, None, None, None, None, 0, N.stream()), "tt_adam_table")
+        plan = ops.RowPlan([local_ids], n_rows, slot=f"plan{W.data_ptr()}")
+        key = W.data_ptr()
+        need = lib.tt_adam_table_workspace_bytes(plan.n, dim)
+        side = self._sides.get(key)
+        if side is None or side.numel() < need:
+            side = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.device)
+            self._sides[key] = side
+        N.check(lib.tt_adam_table_stash(W.data_ptr(), M.data_ptr(), V.data_ptr(), n_rows, dim, plan.n,
+                                        plan.sorted_ids.data_ptr(), plan.seg_begin.data_ptr(),
+                                        plan.n_unique.data_ptr(), side.data_ptr(), side.numel(), N.stream()),
+                "tt_adam_table_stash")
+        return plan, side
+
+    def sweep_async(self, tables, hyper):
+        """Zero-gradient sweep of every (W, M, V) on the side stream, after everything queued so
+        far on the main stream (the lookups and the stashes)."""
+        N, lib = self.N, self.lib
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        self._side_stream.wait_event(ready)
+        for W, M, V in tables:
+            N.check(lib.tt_adam_table_sweep(W.data_ptr(), M.data_ptr(), V.data_ptr(), W.shape[0], W.shape[1],
+                                            hyper.data_ptr(), self._side_stream.cuda_stream), "tt_adam_table_sweep")
+        self._sweep_done = torch.cuda.Event()
+        self._sweep_done.record(self._side_stream)
+
+    def sweep_wait(self):
+        torch.cuda.current_stream().wait_event(self._sweep_done)
+
+    def adam_table_finish(self, W, M, V, hyper, state, grad_rows: torch.Tensor):
+        if state is None:
             return
-        plan = ops.RowPlan([ops.RowGrad(local_ids, grad_rows)], n_rows)
-        wsp, wsn = ops._ws(self.device, lib.tt_adam_table_workspace_bytes(plan.n, dim), "adam_side")
-        N.check(lib.tt_adam_table(W.data_ptr(), M.data_ptr(), V.data_ptr(), n_rows, dim, hyper.data_ptr(),
-                                  C.byref(plan.sources), plan.n, plan.sorted_ids.data_ptr(), plan.perm.data_ptr(),
-                                  plan.seg_begin.data_ptr(), plan.n_unique.data_ptr(), wsp, wsn, N.stream()),
-                "tt_adam_table")
+        N, lib = self.N, self.lib
+        plan, side = state
+        plan.attach([grad_rows])
+        N.check(lib.tt_adam_table_finish(W.data_ptr(), M.data_ptr(), V.data_ptr(), W.shape[0], W.shape[1],
+                                         hyper.data_ptr(), C.byref(plan.sources), plan.n, plan.sorted_ids.data_ptr(),
+                                         plan.perm.data_ptr(), plan.seg_begin.data_ptr(), plan.n_unique.data_ptr(),
+                                         side.data_ptr(), side.numel(), N.stream()), "tt_adam_table_finish")
 
     def adam_dense(self, p, g, m, v, hyper):
         N = self.N
@@ -299,6 +336,13 @@ class ShardedTrainer:
         u_in, i_in = be.empty(B, 2 * D), be.empty(B, 2 * D)
         rt_u = self._lookup_into(self.users, user_id, u_in[:, :D])
         rt_i = self._lookup_into(self.items, item_id, i_in[:, :D])
+        # the tables' old rows have been read: plan, park the looked-up rows, and start the
+        # zero-gradient sweep on the side stream -- it overlaps everything up to step 6
+        be.adam_advance(self.hyper)
+        st_u = be.adam_table_begin(self.users.weight, self.users.m, self.users.v, rt_u.recv_local_ids)
+        st_i = be.adam_table_begin(self.items.weight, self.items.m, self.items.v, rt_i.recv_local_ids)
+        be.sweep_async([(self.users.weight, self.users.m, self.users.v),
+                        (self.items.weight, self.items.m, self.items.v)], self.hyper)
         pu, pi = self._tower_params("user"), self._tower_params("item")
         u_h, U = be.tower_fwd(u_in, user_feat, pu)
         i_h, I = be.tower_fwd(i_in, item_feat, pi)
@@ -328,9 +372,9 @@ class ShardedTrainer:
             dist.all_reduce(self.flat_g)
         g_u = self._return_row_grads(rt_u, d_urows)
         g_i = self._return_row_grads(rt_i, d_irows)
-        # 6. dense-exact Adam: every rank sweeps its own row block; replicas step in lockstep
-        be.adam_advance(self.hyper)
-        be.adam_table(self.users.weight, self.users.m, self.users.v, self.hyper, rt_u.recv_local_ids, g_u)
-        be.adam_table(self.items.weight, self.items.m, self.items.v, self.hyper, rt_i.recv_local_ids, g_i)
+        # 6. dense-exact Adam: the looked-up rows of this rank's blocks, over the swept tables
+        be.sweep_wait()
+        be.adam_table_finish(self.users.weight, self.users.m, self.users.v, self.hyper, st_u, g_u)
+        be.adam_table_finish(self.items.weight, self.items.m, self.items.v, self.hyper, st_i, g_i)
         be.adam_dense(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.hyper)
         return loss
