@@ -80,25 +80,30 @@ def test_adam_table_2m_rows_untouched_rows_and_sample(T):
     W = torch.randn(n_rows, D, generator=g)
     Wd, Md, Vd = W.to(DEV), torch.zeros(n_rows, D, device=DEV), torch.zeros(n_rows, D, device=DEV)
     hyper = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 0, 0, 0, 0], dtype=torch.float64, device=DEV)
-    touched = set()
-    ref = {}
-    for step in (1, 2):
+    steps = []
+    for _ in (1, 2):
         ids = torch.randint(0, n_rows, (n,), generator=g)
-        ids[:64] = ids[64:128]
-        rows = torch.randn(n, D, generator=g) * 0.01
+        ids[:64] = ids[64:128]  # duplicates inside a step
+        steps.append((ids, torch.randn(n, D, generator=g) * 0.01))
+    steps[1][0][:32] = steps[0][0][:32]  # rows touched in BOTH steps
+    touched = set()
+    for step, (ids, rows) in enumerate(steps, start=1):
         N.check(lib.tt_adam_advance(hyper.data_ptr(), N.stream()), "adv")
         plan = ops.RowPlan.from_grads([ops.RowGrad(ids.to(DEV), rows.to(DEV))], n_rows)
         wsp, wsn = ops._ws(torch.device(DEV), lib.tt_adam_table_workspace_bytes(plan.n, D), "adam_side")
         N.check(lib.tt_adam_table(Wd.data_ptr(), Md.data_ptr(), Vd.data_ptr(), n_rows, D, hyper.data_ptr(),
                                   C.byref(plan.sources), plan.n, plan.sorted_ids.data_ptr(), plan.perm.data_ptr(),
                                   plan.seg_begin.data_ptr(), plan.n_unique.data_ptr(), wsp, wsn, N.stream()), "adam")
-        for k in ids[:200].tolist():  # oracle on a sample of touched rows, every step they exist
-            if k not in ref:
-                ref[k] = (W[k].clone(), torch.zeros(D), torch.zeros(D))
-        for k, (p, m, v) in ref.items():
-            gk = rows[ids == k].sum(0) if bool((ids == k).any()) else torch.zeros(D)
-            R.adam_update(p, gk, m, v, step)
         touched |= set(ids.tolist())
+    # oracle on a sample of rows, each followed through BOTH steps with that step's summed gradient
+    sample = set(steps[0][0][:200].tolist()) | set(steps[1][0][:200].tolist())
+    ref = {}
+    for k in sample:
+        p, m, v = W[k].clone(), torch.zeros(D), torch.zeros(D)
+        for step, (ids, rows) in enumerate(steps, start=1):
+            hit = ids == k
+            R.adam_update(p, rows[hit].sum(0) if bool(hit.any()) else torch.zeros(D), m, v, step)
+        ref[k] = (p, m, v)
     got = Wd.cpu()
     for k, (p, m, v) in ref.items():
         assert torch.allclose(got[k], p, atol=3e-6), k
