@@ -253,46 +253,76 @@ __global__ __launch_bounds__(256) void mips_score_kernel(const MipsArgs p) {
 }
 
 // ---------------------------------------------------------------- K-th largest group key
-// workgroup = 32 queries x 8 group slices; keys are read gmax[g][q] (256-B coalesced rows).
-__global__ __launch_bounds__(256) void mips_select_kernel(const u64* __restrict__ gmax, int64_t n_groups, int64_t nq,
-                                                          int64_t K, u64* __restrict__ tau) {
-  __shared__ int32_t hist[32][257];
-  __shared__ u64 prefix_s[32];
-  __shared__ int32_t want_s[32];
-  __shared__ int32_t done_s[32];
-  const int ql = threadIdx.x & 31, slice = threadIdx.x >> 5;
-  const int64_t q = (int64_t)blockIdx.x * 32 + ql;
-  if (threadIdx.x < 32) { prefix_s[ql] = 0; want_s[ql] = (int32_t)K; done_s[ql] = 0; }
+// MSD radix select, 8 bits per pass, one (histogram, pick) kernel pair per pass.
+//   hist: workgroup = 32 queries x 8 group lanes over one slice of the groups (gridDim.y
+//         slices); keys are read gmax[g][q] as 256-B coalesced rows; per-query 256-bin
+//         histograms are built in LDS and merged into the global one with atomics.
+//   pick: one thread per query walks its 256 bins from the top, fixes the next digit of the
+//         threshold, and marks the query done as soon as the bin holds exactly the keys that
+//         are still wanted (then the prefix itself is an exact threshold).
+// `tau` doubles as the prefix being built.
+constexpr int SEL_Q = 32;
+__global__ __launch_bounds__(256) void mips_select_hist_kernel(const u64* __restrict__ gmax, int64_t n_groups,
+                                                               int64_t nq, int pass, const u64* __restrict__ tau,
+                                                               const int32_t* __restrict__ done,
+                                                               int32_t* __restrict__ ghist) {
+  __shared__ int32_t hist[SEL_Q][257];
+  __shared__ int32_t any_live;
+  const int ql = threadIdx.x & 31, lane8 = threadIdx.x >> 5;
+  const int64_t q = (int64_t)blockIdx.x * SEL_Q + ql;
+  if (threadIdx.x == 0) any_live = 0;
+  for (int i = threadIdx.x; i < SEL_Q * 257; i += 256) (&hist[0][0])[i] = 0;
   __syncthreads();
-  for (int pass = 0; pass < 8; ++pass) {
-    const int shift = 56 - 8 * pass;
-    for (int i = threadIdx.x; i < 32 * 257; i += 256) (&hist[0][0])[i] = 0;
-    __syncthreads();
-    const u64 prefix = prefix_s[ql];
-    const u64 himask = (pass == 0) ? 0ull : (~0ull << (shift + 8));
-    if (q < nq && !done_s[ql]) {
-      for (int64_t g = slice; g < n_groups; g += 8) {
-        const u64 key = gmax[g * nq + q];
-        if ((key & himask) == prefix) atomicAdd(&hist[ql][(int)((key >> shift) & 255)], 1);
-      }
+  const bool live = q < nq && !done[q];
+  if (live) any_live = 1;
+  __syncthreads();
+  if (!any_live) return;
+  const int shift = 56 - 8 * pass;
+  const u64 prefix = live ? tau[q] : 0ull;
+  const u64 himask = (pass == 0) ? 0ull : (~0ull << (shift + 8));
+  const int64_t per = (n_groups + gridDim.y - 1) / gridDim.y;
+  const int64_t g0 = (int64_t)blockIdx.y * per;
+  const int64_t g1 = (g0 + per < n_groups) ? g0 + per : n_groups;
+  if (live) {
+    for (int64_t g = g0 + lane8; g < g1; g += 8) {
+      const u64 key = gmax[g * nq + q];
+      if ((key & himask) == prefix) atomicAdd(&hist[ql][(int)((key >> shift) & 255)], 1);
     }
-    __syncthreads();
-    if (threadIdx.x < 32 && q < nq && !done_s[ql]) {
-      int32_t want = want_s[ql], acc = 0;
-      int d = 255;
-      for (; d > 0; --d) {
-        if (acc + hist[ql][d] >= want) break;
-        acc += hist[ql][d];
-      }
-      prefix_s[ql] = prefix | ((u64)d << shift);
-      want_s[ql] = want - acc;
-      // exactly the remaining `want` keys share this prefix: every key with the prefix is
-      // selected, so the smallest possible key with that prefix is an exact threshold
-      if (hist[ql][d] == want - acc) done_s[ql] = 1;
-    }
-    __syncthreads();
   }
-  if (threadIdx.x < 32 && q < nq) tau[q] = prefix_s[ql];
+  __syncthreads();
+  for (int i = threadIdx.x; i < SEL_Q * 256; i += 256) {
+    const int qq = i >> 8, d = i & 255;
+    const int32_t c = hist[qq][d];
+    const int64_t gq = (int64_t)blockIdx.x * SEL_Q + qq;
+    if (c && gq < nq) atomicAdd(&ghist[gq * 256 + d], c);
+  }
+}
+
+__global__ void mips_select_pick_kernel(int32_t* __restrict__ ghist, int64_t nq, int pass, u64* __restrict__ tau,
+                                        int32_t* __restrict__ want, int32_t* __restrict__ done) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq || done[q]) return;
+  int32_t* h = ghist + q * 256;
+  const int shift = 56 - 8 * pass;
+  const int32_t w = want[q];
+  int32_t acc = 0;
+  int d = 255;
+  for (; d > 0; --d) {
+    if (acc + h[d] >= w) break;
+    acc += h[d];
+  }
+  const int32_t in_bin = h[d];
+  tau[q] |= ((u64)d << shift);
+  want[q] = w - acc;
+  if (in_bin == w - acc || pass == 7) done[q] = 1;
+  for (int k = 0; k < 256; ++k) h[k] = 0;
+}
+
+__global__ void mips_select_init_kernel(int32_t* __restrict__ ghist, int32_t* __restrict__ want,
+                                        int32_t* __restrict__ done, int64_t nq, int32_t K) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nq * 256) ghist[i] = 0;
+  if (i < nq) { want[i] = K; done[i] = 0; }
 }
 
 // ---------------------------------------------------------------- per-query candidate sort
@@ -428,6 +458,8 @@ extern "C" int64_t tt_mips_workspace_bytes(int64_t B, int64_t C, int64_t D, int6
   MipsPlan pl;
   if (B <= 0 || C <= 0 || D <= 0 || K <= 0 || K > C || !plan_mips(B, C, D, K, dtype, pl)) return 256;
   return round_up(pl.n_groups * pl.qb * 8, 256)  // gmax
+         + round_up(pl.qb * 256 * 4, 256)        // select histograms
+         + 2 * round_up(pl.qb * 4, 256)          // select want / done
          + round_up(pl.qb * 8, 256)              // tau
          + round_up(pl.qb * 4, 256)              // count
          + 2 * round_up(pl.qb * pl.cap * 8, 256) // candidates + sort ping-pong
@@ -445,6 +477,9 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
   hipStream_t st = S(stream);
   Carver cv(ws);
   u64* gmax = cv.take<u64>(pl.n_groups * pl.qb);
+  int32_t* ghist = cv.take<int32_t>(pl.qb * 256);
+  int32_t* want = cv.take<int32_t>(pl.qb);
+  int32_t* done = cv.take<int32_t>(pl.qb);
   u64* tau = cv.take<u64>(pl.qb);
   int32_t* count = cv.take<int32_t>(pl.qb);
   u64* cand = cv.take<u64>(pl.qb * pl.cap);
@@ -467,8 +502,18 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
     if ((rc = check_launch("mips_zero_kernel"))) return rc;
     if (pl.n_groups > K) {  // otherwise tau = 0: every item is a candidate (cap == n_groups*64 >= C)
       if ((rc = dispatch_score<1>(dtype, pl.dpx, a, grid, st))) return rc;
-      mips_select_kernel<<<(unsigned)ceil_div(nq, 32), 256, 0, st>>>(gmax, pl.n_groups, nq, K, tau);
-      if ((rc = check_launch("mips_select_kernel"))) return rc;
+      mips_select_init_kernel<<<(unsigned)ceil_div(nq * 256, 256), 256, 0, st>>>(ghist, want, done, nq, (int32_t)K);
+      if ((rc = check_launch("mips_select_init_kernel"))) return rc;
+      const int64_t qblocks = ceil_div(nq, SEL_Q);
+      int64_t slices = ceil_div(2048, qblocks);
+      if (slices > ceil_div(pl.n_groups, 64)) slices = ceil_div(pl.n_groups, 64);
+      if (slices < 1) slices = 1;
+      for (int pass = 0; pass < 8; ++pass) {  // queries that finish early skip the later passes
+        mips_select_hist_kernel<<<dim3((unsigned)qblocks, (unsigned)slices), 256, 0, st>>>(gmax, pl.n_groups, nq, pass, tau, done, ghist);
+        if ((rc = check_launch("mips_select_hist_kernel"))) return rc;
+        mips_select_pick_kernel<<<(unsigned)ceil_div(nq, 64), 64, 0, st>>>(ghist, nq, pass, tau, want, done);
+        if ((rc = check_launch("mips_select_pick_kernel"))) return rc;
+      }
     }
     if ((rc = dispatch_score<2>(dtype, pl.dpx, a, grid, st))) return rc;
     mips_sort_emit_kernel<<<(unsigned)nq, 64, 0, st>>>(cand, tmp, count, pl.cap, K, q0, idx_out, score_out, status);
