@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--workload", default="P", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--negatives", default="global", choices=["global", "local"])
+    ap.add_argument("--sharded", action="store_true", help="use the row-sharded trainer even at --gpus 1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,9 +149,12 @@ def main():
     from two_tower_models_amd import _native as N
     lib = N.load()
 
-    if world > 1:
+    use_sharded = world > 1 or args.sharded
+    if use_sharded:
         import torch.distributed as dist
         from two_tower_models_amd import sharded
+        if "MASTER_ADDR" not in os.environ:  # plain `python bench.py --sharded`
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
         trainer = sharded.ShardedTrainer(cfg, device, negatives=args.negatives)
         step = trainer.step
@@ -219,7 +223,7 @@ def main():
                                    f"N_i={cfg['n_items']}, D={cfg['D']}, F={cfg['F']}, B={B}/GPU"
                                    + (f", H={cfg['H']} history encoder" if cfg['model'] == 'hist' else ""),
                        "global_batch": B * world,
-                       "parallelism": "single GPU" if world == 1 else
+                       "parallelism": "single GPU" if not use_sharded else
                        f"row-sharded tables x{world}, {args.negatives} in-batch negatives, RCCL"},
             "roofline": roof,
         }
@@ -227,9 +231,15 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        result = json.dumps(out)
+    if use_sharded:
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio; flush that first so the JSON line
+        # is the LAST line on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(result, flush=True)
 
 
 if __name__ == "__main__":

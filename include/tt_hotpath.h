@@ -57,7 +57,9 @@ int tt_profile_read(const char* kernel, double* total_ms, int64_t* launches);
  * replaces nn.Embedding.__call__ at ref:src/two_tower_base_retrieval.py:126,209
  * and the history lookup ref:src/two_tower_with_user_history_encoder.py:105.
  * ld_out lets the caller write straight into a column slice of the tower
- * input, which is how torch.cat (ref:...base_retrieval.py:159,214) disappears. */
+ * input, which is how torch.cat (ref:...base_retrieval.py:159,214) disappears.
+ * oob_flag may be NULL: out-of-range ids then zero-fill silently (the sharded trainer uses
+ * this to gather "my rows, zeros for everyone else's" ahead of a reduce-scatter). */
 int tt_gather_rows(const float* table, int64_t n_rows, int64_t dim, const int64_t* ids,
                    int64_t n_ids, float* out, int64_t ld_out, int32_t* oob_flag,
                    tt_stream_t stream);
@@ -129,7 +131,10 @@ int tt_weighted_mean_loss(const float* labels, int64_t B, int64_t T, const float
  *                     get the update with their summed gradient.
  * Plan outputs (device): sorted_ids int32[n], perm int32[n] (original position
  * of each sorted id), seg_begin int32[n+1] (start of each unique row's run in
- * the sorted order; seg_begin[n_unique] == n), n_unique int32[1]. */
+ * the sorted order; seg_begin[n_unique] == n), n_unique int32[1].
+ * Sentinel rows: tt_adam_table / _stash / _finish ignore runs whose row id is >= the
+ * n_rows THEY are given, so a caller may plan with n_rows+1 and map "not my row" ids to
+ * n_rows (the sharded trainer does, after all-gathering every rank's ids). */
 int64_t tt_rowgrad_workspace_bytes(int64_t n_ids);
 int tt_rowgrad_plan(const int64_t* ids, int64_t n_ids, int64_t n_rows, int32_t* sorted_ids,
                     int32_t* perm, int32_t* seg_begin, int32_t* n_unique, int32_t* oob_flag,
@@ -182,6 +187,11 @@ int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows, int64_t d
                          const tt_grad_sources* src /*host*/, int64_t n_ids, const int32_t* sorted_ids,
                          const int32_t* perm, const int32_t* seg_begin, const int32_t* n_unique,
                          void* side, int64_t side_bytes, tt_stream_t stream);
+
+/* A HIP stream of the device's least priority (hipStreamCreateWithPriority) for
+ * tt_adam_table_sweep, so the backward pass on the caller's stream is dispatched first. */
+int tt_stream_create_low_priority(void** out_stream);
+int tt_stream_destroy(void* stream);
 
 /* dense parameters: `tensors` is a HOST array of n_tensors {p,g,m,v,n} descriptors
  * (device pointers inside); they are passed to the kernel by value, 64 per launch. */

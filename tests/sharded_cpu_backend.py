@@ -16,26 +16,23 @@ class OracleBackend:
     def empty(self, *shape):
         return torch.zeros(*shape, dtype=torch.float32)
 
-    def gather(self, table, ids, out=None):
-        rows = table[ids]
-        if out is None:
-            return rows.clone()
-        out.copy_(rows)
+    def gather_owned(self, table, local, n_local):
+        out = torch.zeros(local.numel(), table.shape[1])
+        mine = local < n_local
+        out[mine] = table[local[mine]]
         return out
 
-    def tower_fwd(self, tin, feats, p):
+    def tower_fwd(self, emb, feats, p):
         W1, b1, W2, b2, W3, b3 = p
         h = torch.clamp(feats @ W1.t() + b1, min=0.0)
-        D = W2.shape[0]
-        tin[:, tin.shape[1] - D:] = h @ W2.t() + b2
-        return h, tin @ W3.t() + b3
+        f = h @ W2.t() + b2
+        return h, f, torch.cat([emb, f], dim=1) @ W3.t() + b3
 
-    def tower_bwd(self, d_out, tin, h, feats, p, g):
+    def tower_bwd(self, d_out, emb, h, f, feats, p, g):
         W1, b1, W2, b2, W3, b3 = p
         gW1, gb1, gW2, gb2, gW3, gb3 = g
-        Dm = W2.shape[0]
-        De = W3.shape[1] - Dm
-        gW3.copy_(d_out.t() @ tin)
+        De = emb.shape[1]
+        gW3.copy_(d_out.t() @ torch.cat([emb, f], dim=1))
         gb3.copy_(d_out.sum(0))
         d_tin = d_out @ W3
         d_f = d_tin[:, De:]
@@ -66,20 +63,22 @@ class OracleBackend:
         hyper["step"] += 1
 
     # phased table step: this double keeps the old rows simply by not sweeping until finish
-    def adam_table_begin(self, W, M, V, local_ids):
-        return local_ids
+    def adam_table_begin(self, W, M, V, n_local, local_ids):
+        return local_ids, n_local
 
     def sweep_async(self, tables, hyper):
-        self._pending = list(tables)
+        pass
 
     def sweep_wait(self):
         pass
 
     def adam_table_finish(self, W, M, V, hyper, state, grad_rows):
-        g = torch.zeros_like(W)
-        if state is not None and state.numel():
-            g.index_add_(0, state, grad_rows)
-        R.adam_update(W, g, M, V, hyper["step"], hyper["lr"], hyper["b1"], hyper["b2"], hyper["eps"])
+        local, n_local = state
+        mine = local < n_local
+        g = torch.zeros(n_local, W.shape[1])
+        g.index_add_(0, local[mine], grad_rows[mine])
+        R.adam_update(W[:n_local], g, M[:n_local], V[:n_local], hyper["step"], hyper["lr"], hyper["b1"],
+                      hyper["b2"], hyper["eps"])
 
     def adam_dense(self, p, g, m, v, hyper):
         R.adam_update(p, g, m, v, hyper["step"], hyper["lr"], hyper["b1"], hyper["b2"], hyper["eps"])

@@ -68,6 +68,8 @@ SIGNATURES = {
     "tt_adam_table_sweep": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "tt_adam_table_finish": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, C.POINTER(GradSources), _i64, _vp, _vp, _vp,
                                     _vp, _vp, _i64, _vp]),
+    "tt_stream_create_low_priority": (_int, [C.POINTER(_vp)]),
+    "tt_stream_destroy": (_int, [_vp]),
     "tt_adam_dense": (_int, [C.POINTER(AdamTensor), _i32, _vp, _vp]),
     "tt_hist_embed_pool": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp]),
     "tt_hist_pool_bwd": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),
@@ -141,6 +143,14 @@ def require_device(*tensors: torch.Tensor) -> torch.device:
         elif t.device != dev:
             raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
     return dev
+
+
+def low_priority_stream(device: torch.device) -> torch.cuda.Stream:
+    """Least-priority HIP stream (created by the library), wrapped for torch's event API."""
+    with torch.cuda.device(device):
+        raw = _vp()
+        check(load().tt_stream_create_low_priority(C.byref(raw)), "tt_stream_create_low_priority")
+    return torch.cuda.ExternalStream(raw.value, device=device)
 
 
 # ----------------------------------------------------------------- scratch

@@ -71,7 +71,7 @@ __device__ __forceinline__ const float* source_row(const tt_grad_sources& s, int
 // already have overwritten them in the table).
 template <bool FROM_SIDE>
 __global__ __launch_bounds__(256) void adam_touched_kernel(const float* __restrict__ W, const float* __restrict__ M,
-                                                           const float* __restrict__ V, int64_t dim,
+                                                           const float* __restrict__ V, int64_t n_rows, int64_t dim,
                                                            const double* __restrict__ hyper, const tt_grad_sources src,
                                                            const int32_t* __restrict__ sorted_ids,
                                                            const int32_t* __restrict__ perm,
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void adam_touched_kernel(const float* __restri
   const AdamConst c = load_hyper(hyper);
   const int32_t t0 = seg_begin[u], t1 = seg_begin[u + 1];
   const int64_t row = sorted_ids[t0];
+  if (row >= n_rows) return;  // sentinel run: ids that belong to another rank's block
   float* out = side + u * 3 * dim;
   for (int64_t d = lane; d < dim; d += 64) {
     float g = 0.f;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void adam_touched_kernel(const float* __restri
 }
 
 __global__ __launch_bounds__(256) void adam_stash_kernel(const float* __restrict__ W, const float* __restrict__ M,
-                                                         const float* __restrict__ V, int64_t dim,
+                                                         const float* __restrict__ V, int64_t n_rows, int64_t dim,
                                                          const int32_t* __restrict__ sorted_ids,
                                                          const int32_t* __restrict__ seg_begin,
                                                          const int32_t* __restrict__ n_unique,
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(256) void adam_stash_kernel(const float* __restrict
   if (u >= *n_unique) return;
   const int lane = threadIdx.x & 63;
   const int64_t row = sorted_ids[seg_begin[u]];
+  if (row >= n_rows) return;
   float* out = side + u * 3 * dim;
   for (int64_t d = lane; d < dim; d += 64) {
     out[d] = W[row * dim + d];
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void adam_stash_kernel(const float* __restrict
 }
 
 __global__ __launch_bounds__(256) void adam_writeback_kernel(float* __restrict__ W, float* __restrict__ M,
-                                                             float* __restrict__ V, int64_t dim,
+                                                             float* __restrict__ V, int64_t n_rows, int64_t dim,
                                                              const int32_t* __restrict__ sorted_ids,
                                                              const int32_t* __restrict__ seg_begin,
                                                              const int32_t* __restrict__ n_unique,
@@ -126,6 +128,7 @@ __global__ __launch_bounds__(256) void adam_writeback_kernel(float* __restrict__
   if (u >= *n_unique) return;
   const int lane = threadIdx.x & 63;
   const int64_t row = sorted_ids[seg_begin[u]];
+  if (row >= n_rows) return;
   const float* in = side + u * 3 * dim;
   for (int64_t d = lane; d < dim; d += 64) {
     W[row * dim + d] = in[d];
@@ -188,6 +191,29 @@ __global__ __launch_bounds__(256) void adam_sweep_kernel(float4* __restrict__ W,
     W[i] = p; M[i] = m; V[i] = v;
   }
 }
+// Bounded-work form for the overlapped schedule: each workgroup streams SWEEP_ITERS x 256
+// float4 triples and exits, so wave slots keep freeing up and the dispatcher can slot the
+// (higher-priority) backward kernels in between instead of queueing them behind a
+// persistent grid.
+constexpr int SWEEP_ITERS = 8;
+__global__ __launch_bounds__(256) void adam_sweep_bounded_kernel(float4* __restrict__ W, float4* __restrict__ M,
+                                                                 float4* __restrict__ V, int64_t n4,
+                                                                 const double* __restrict__ hyper) {
+  const AdamConst c = load_hyper(hyper);
+  const int64_t base = (int64_t)blockIdx.x * (256 * SWEEP_ITERS) + threadIdx.x;
+#pragma unroll 2
+  for (int k = 0; k < SWEEP_ITERS; ++k) {
+    const int64_t i = base + (int64_t)k * 256;
+    if (i >= n4) break;
+    float4 p = W[i], m = M[i], v = V[i];
+    adam_elem_zero_grad(p.x, m.x, v.x, c);
+    adam_elem_zero_grad(p.y, m.y, v.y, c);
+    adam_elem_zero_grad(p.z, m.z, v.z, c);
+    adam_elem_zero_grad(p.w, m.w, v.w, c);
+    W[i] = p; M[i] = m; V[i] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void adam_sweep_scalar_kernel(float* __restrict__ W, float* __restrict__ M,
                                                                 float* __restrict__ V, int64_t i0, int64_t n,
                                                                 const double* __restrict__ hyper) {
@@ -217,7 +243,7 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(const AdamBatch ts, con
 }
 
 // dense gradient for torch.optim users: dense[row,:] = sum of that row's gradient rows
-__global__ __launch_bounds__(256) void rowgrad_dense_kernel(const tt_grad_sources src, int64_t dim,
+__global__ __launch_bounds__(256) void rowgrad_dense_kernel(const tt_grad_sources src, int64_t n_rows, int64_t dim,
                                                             const int32_t* __restrict__ sorted_ids,
                                                             const int32_t* __restrict__ perm,
                                                             const int32_t* __restrict__ seg_begin,
@@ -228,6 +254,7 @@ __global__ __launch_bounds__(256) void rowgrad_dense_kernel(const tt_grad_source
   const int lane = threadIdx.x & 63;
   const int32_t t0 = seg_begin[u], t1 = seg_begin[u + 1];
   const int64_t row = sorted_ids[t0];
+  if (row >= n_rows) return;
   for (int64_t d = lane; d < dim; d += 64) {
     float g = 0.f;
     for (int32_t t = t0; t < t1; ++t) g += source_row(src, perm[t])[d];
@@ -243,7 +270,7 @@ static bool check_sources(const tt_grad_sources* s, int64_t n_ids, int64_t dim) 
 }
 
 static int launch_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
-                        hipStream_t st) {
+                        hipStream_t st, bool bounded = false) {
   int rc;
   const int64_t total = n_rows * dim;
   const bool vec = ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(M) | reinterpret_cast<uintptr_t>(V)) & 15) == 0;
@@ -257,6 +284,10 @@ static int launch_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t di
     const int64_t blocks = ceil_div(n4, 256) < cap ? ceil_div(n4, 256) : cap;
     float4 *w4 = reinterpret_cast<float4*>(W), *m4 = reinterpret_cast<float4*>(M), *v4 = reinterpret_cast<float4*>(V);
     ProfScope prof("adam_sweep_kernel", st);
+    static const bool no_bounded = getenv("TT_SWEEP_NO_BOUNDED") != nullptr;
+    if (bounded && !no_bounded) {
+      adam_sweep_bounded_kernel<<<(unsigned)ceil_div(n4, 256 * SWEEP_ITERS), 256, 0, st>>>(w4, m4, v4, n4, hyper);
+    } else
     switch (variant & 3) {
       case 0: adam_sweep_kernel<false, 1><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
       case 1: adam_sweep_kernel<true, 1><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
@@ -301,12 +332,12 @@ extern "C" int tt_adam_table(float* W, float* M, float* V, int64_t n_rows, int64
     if (!sorted_ids || !perm || !seg_begin || !n_unique || !ws) return fail_arg("tt_adam_table: null plan");
     if (!check_sources(src, n_ids, dim)) return fail_arg("tt_adam_table: gradient sources");
     if (ws_bytes < tt_adam_table_workspace_bytes(n_ids, dim)) { set_error("tt_adam_table: workspace"); return TT_E_WORKSPACE; }
-    adam_touched_kernel<false><<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, reinterpret_cast<float*>(ws));
+    adam_touched_kernel<false><<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, reinterpret_cast<float*>(ws));
     if ((rc = check_launch("adam_touched_kernel"))) return rc;
   }
   if ((rc = launch_sweep(W, M, V, n_rows, dim, hyper, st))) return rc;
   if (n_ids > 0) {
-    adam_writeback_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, dim, sorted_ids, seg_begin, n_unique, reinterpret_cast<const float*>(ws));
+    adam_writeback_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, sorted_ids, seg_begin, n_unique, reinterpret_cast<const float*>(ws));
     if ((rc = check_launch("adam_writeback_kernel"))) return rc;
   }
   return 0;
@@ -320,7 +351,7 @@ extern "C" int tt_adam_table_stash(const float* W, const float* M, const float* 
   if (!W || !M || !V || !sorted_ids || !seg_begin || !n_unique || !side) return fail_arg("tt_adam_table_stash: null pointer");
   if (n_rows <= 0 || dim <= 0 || n_ids <= 0) return fail_arg("tt_adam_table_stash: sizes");
   if (side_bytes < tt_adam_table_workspace_bytes(n_ids, dim)) { set_error("tt_adam_table_stash: side buffer"); return TT_E_WORKSPACE; }
-  adam_stash_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, S(stream)>>>(W, M, V, dim, sorted_ids, seg_begin, n_unique, reinterpret_cast<float*>(side));
+  adam_stash_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, S(stream)>>>(W, M, V, n_rows, dim, sorted_ids, seg_begin, n_unique, reinterpret_cast<float*>(side));
   return check_launch("adam_stash_kernel");
 }
 
@@ -328,7 +359,27 @@ extern "C" int tt_adam_table_sweep(float* W, float* M, float* V, int64_t n_rows,
                                    tt_stream_t stream) {
   if (!W || !M || !V || !hyper) return fail_arg("tt_adam_table_sweep: null pointer");
   if (n_rows <= 0 || dim <= 0) return fail_arg("tt_adam_table_sweep: sizes");
-  return launch_sweep(W, M, V, n_rows, dim, hyper, S(stream));
+  return launch_sweep(W, M, V, n_rows, dim, hyper, S(stream), /*bounded=*/true);
+}
+
+// A HIP stream of the device's LEAST priority for the sweep: the backward kernels on the
+// caller's (normal-priority) stream win the dispatcher whenever both have work.
+extern "C" int tt_stream_create_low_priority(void** out) {
+  if (!out) return fail_arg("tt_stream_create_low_priority: null pointer");
+  int least = 0, greatest = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (e != hipSuccess) { set_error("hipDeviceGetStreamPriorityRange: %s", hipGetErrorString(e)); return (int)e; }
+  hipStream_t s;
+  e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least);
+  if (e != hipSuccess) { set_error("hipStreamCreateWithPriority: %s", hipGetErrorString(e)); return (int)e; }
+  *out = reinterpret_cast<void*>(s);
+  return 0;
+}
+extern "C" int tt_stream_destroy(void* stream) {
+  if (!stream) return 0;
+  hipError_t e = hipStreamDestroy(reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) { set_error("hipStreamDestroy: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
 }
 
 extern "C" int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
@@ -342,10 +393,10 @@ extern "C" int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows
   if (side_bytes < tt_adam_table_workspace_bytes(n_ids, dim)) { set_error("tt_adam_table_finish: side buffer"); return TT_E_WORKSPACE; }
   hipStream_t st = S(stream);
   float* sd = reinterpret_cast<float*>(side);
-  adam_touched_kernel<true><<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, sd);
+  adam_touched_kernel<true><<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, sd);
   int rc = check_launch("adam_touched_kernel");
   if (rc) return rc;
-  adam_writeback_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, dim, sorted_ids, seg_begin, n_unique, sd);
+  adam_writeback_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, sorted_ids, seg_begin, n_unique, sd);
   return check_launch("adam_writeback_kernel");
 }
 
@@ -376,6 +427,6 @@ extern "C" int tt_rowgrad_dense(const tt_grad_sources* src, int64_t n_ids, int64
   if (!sorted_ids || !perm || !seg_begin || !n_unique || !dense_grad) return fail_arg("tt_rowgrad_dense: null pointer");
   if (n_ids <= 0 || dim <= 0) return fail_arg("tt_rowgrad_dense: sizes");
   if (!check_sources(src, n_ids, dim)) return fail_arg("tt_rowgrad_dense: gradient sources");
-  rowgrad_dense_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, S(stream)>>>(*src, dim, sorted_ids, perm, seg_begin, n_unique, dense_grad);
+  rowgrad_dense_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, S(stream)>>>(*src, INT64_MAX, dim, sorted_ids, perm, seg_begin, n_unique, dense_grad);
   return check_launch("rowgrad_dense_kernel");
 }

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   if (i >= n_ids) return;
   const int64_t id = ids[i];
   const bool ok = (id >= 0) && (id < n_rows);
-  if (!ok && c == 0) *oob_flag = 1;
+  if (!ok && c == 0 && oob_flag) *oob_flag = 1;
   const V* src = reinterpret_cast<const V*>(table) + (ok ? id : 0) * dimv;
   V* dst = reinterpret_cast<V*>(out) + i * ld_outv;
   for (int64_t k = c; k < dimv; k += LPR) dst[k] = ok ? src[k] : Vec<VEC>::zero();
@@ -138,7 +138,7 @@ using namespace tt;
 extern "C" int tt_gather_rows(const float* table, int64_t n_rows, int64_t dim, const int64_t* ids,
                               int64_t n_ids, float* out, int64_t ld_out, int32_t* oob_flag,
                               tt_stream_t stream) {
-  if (!table || !ids || !out || !oob_flag) return fail_arg("tt_gather_rows: null pointer");
+  if (!table || !ids || !out) return fail_arg("tt_gather_rows: null pointer");
   if (n_rows <= 0 || dim <= 0 || n_ids < 0 || ld_out < dim) return fail_arg("tt_gather_rows: sizes");
   if (n_ids == 0) return 0;
   const bool vec = (dim % 4 == 0) && (ld_out % 4 == 0) && aligned16(table) && aligned16(out);

@@ -85,7 +85,7 @@ class DenseExactAdam(torch.optim.Optimizer):
             st = self.state[p]
             st["exp_avg"] = torch.zeros_like(p)
             st["exp_avg_sq"] = torch.zeros_like(p)
-        self._side_stream = torch.cuda.Stream(device=dev)
+        self._side_stream = N.low_priority_stream(dev)
         self._ready = True
 
     @property

@@ -9,14 +9,22 @@ Partitioning
   * both embedding tables are split into W contiguous row blocks; a rank owns the block and
     its Adam moments, and sweeps only its block (the HBM-bound part scales 1/W, no comms);
   * the batch is split by rank; dense MLP / tower parameters are replicated.
-Exchanges per step
-  1. ids -> owning rank, rows back          all_to_all (variable counts)   2 x [B, D]
-  2. item embeddings                         all_gather                     [B, D] -> [W*B, D]
-  3. max of the value weights, loss          all_reduce (scalars)
-  4. partial dI over the gathered items      reduce_scatter                 [W*B, D] -> [B, D]
-  5. dense-parameter gradients (one flat buffer)  all_reduce                ~0.5 MB
-  6. row gradients -> owning rank            all_to_all                     2 x [B, D]
-Every rank then runs the dense-exact Adam of optim.py on its shard.
+Exchanges per step -- all FIXED size, so the step never synchronises with the host:
+  1. every rank's ids                        all_gather      [B] -> [W*B]          (x2 tables)
+     each owner gathers ITS rows for all W*B ids (zero rows for ids it does not own), then
+     rows to the requesting ranks            reduce_scatter  [W*B, D] -> [B, D]     (x2)
+     (one non-zero contribution per row, so the sum is exact)
+  2. item embeddings                         all_gather      [B, D] -> [W*B, D]
+  3. max of the value weights, loss          all_reduce      scalars
+  4. partial dI over the gathered items      reduce_scatter  [W*B, D] -> [B, D]
+  5. dense-parameter gradients (flat buffer) all_reduce      ~0.5 MB
+  6. embedding-row gradients                 all_gather      [B, D] -> [W*B, D]     (x2)
+     each owner keeps the rows it owns: ids of other ranks' blocks are mapped to a sentinel
+     row that the Adam kernels skip.
+For the base model these blocks are 4 MB per rank (32 MB gathered at W = 8), far below what
+a variable-size all_to_all would save once its host synchronisation is counted.
+Every rank then runs the dense-exact Adam of optim.py on its block, with the zero-gradient
+sweep on a side stream underneath steps 1-6.
 
 The arithmetic is delegated to a `backend` object.  The product backend is `HipBackend`
 (libtt_hotpath.so); it is the default and the only one shipped.  tests/ inject a CPU
@@ -38,19 +46,6 @@ TOWER_KEYS = ("features_arch.0.weight", "features_arch.0.bias", "features_arch.2
 # ----------------------------------------------------------------- collectives
 def _is_gloo() -> bool:
     return dist.get_backend() == "gloo"
-
-
-def all_to_all_rows(send: torch.Tensor, send_counts: Sequence[int], recv_counts: Sequence[int]) -> torch.Tensor:
-    """Variable-count all-to-all of row blocks (dim 0)."""
-    recv = send.new_empty((int(sum(recv_counts)),) + tuple(send.shape[1:]))
-    dist.all_to_all_single(recv, send.contiguous(), list(recv_counts), list(send_counts))
-    return recv
-
-
-def exchange_counts(send_counts: torch.Tensor) -> torch.Tensor:
-    recv = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv, send_counts)
-    return recv
 
 
 def all_gather_rows(x: torch.Tensor) -> torch.Tensor:
@@ -90,29 +85,34 @@ class HipBackend:
     def empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
 
-    def gather(self, table: torch.Tensor, ids: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if out is None:
-            out = self.empty(ids.numel(), table.shape[1])
-        if ids.numel():
-            self.ops.gather_rows_into(table, ids, out)
+    def gather_owned(self, table: torch.Tensor, local: torch.Tensor, n_local: int) -> torch.Tensor:
+        """out[i] = table[local[i]] for local[i] < n_local, a zero row for the sentinel."""
+        out = self.empty(local.numel(), table.shape[1])
+        N = self.N
+        N.check(self.lib.tt_gather_rows(table.data_ptr(), n_local, table.shape[1], local.data_ptr(), local.numel(),
+                                        out.data_ptr(), table.shape[1], None, N.stream()), "tt_gather_rows")
         return out
 
-    def tower_fwd(self, tin: torch.Tensor, feats: torch.Tensor, p: Sequence[torch.Tensor]):
-        """tin[:, :D] already holds the id-embedding rows; fills tin[:, D:] and returns (h, out)."""
+    def tower_fwd(self, emb: torch.Tensor, feats: torch.Tensor, p: Sequence[torch.Tensor]):
+        """out = [emb | MLP(feats)] W3^T + b3 without building the concatenation: two products
+        against the two column blocks of W3, the second accumulating.  Returns (h, f, out)."""
         W1, b1, W2, b2, W3, b3 = p
         ops, N = self.ops, self.N
         B, F = feats.shape
-        D = W2.shape[0]
-        h = self.empty(B, W1.shape[0])
-        ops.gemm(N.TT_GEMM_NT, feats, W1, h, B, W1.shape[0], F, bias=b1, epilogue=N.TT_EPI_RELU)
-        ops.gemm(N.TT_GEMM_NT, h, W2, tin[:, tin.shape[1] - D:], B, D, W1.shape[0], bias=b2)
+        Dm, Hd = W2.shape
+        De = W3.shape[1] - Dm
+        h = self.empty(B, Hd)
+        ops.gemm(N.TT_GEMM_NT, feats, W1, h, B, Hd, F, bias=b1, epilogue=N.TT_EPI_RELU)
+        f = self.empty(B, Dm)
+        ops.gemm(N.TT_GEMM_NT, h, W2, f, B, Dm, Hd, bias=b2)
         out = self.empty(B, W3.shape[0])
-        ops.gemm(N.TT_GEMM_NT, tin, W3, out, B, W3.shape[0], tin.shape[1], bias=b3)
-        return h, out
+        ops.gemm(N.TT_GEMM_NT, emb, W3[:, :De], out, B, W3.shape[0], De, bias=b3)
+        ops.gemm(N.TT_GEMM_NT, f, W3[:, De:], out, B, W3.shape[0], Dm, accumulate=True)
+        return h, f, out
 
-    def tower_bwd(self, d_out, tin, h, feats, p, g):
+    def tower_bwd(self, d_out, emb, h, f, feats, p, g):
         """Writes the six parameter gradients into `g` (views of the flat gradient buffer) and
-        returns the contiguous gradient of the id-embedding rows [B, D_emb]."""
+        returns the gradient of the id-embedding rows [B, D_emb]."""
         W1, b1, W2, b2, W3, b3 = p
         gW1, gb1, gW2, gb2, gW3, gb3 = g
         ops, N = self.ops, self.N
@@ -120,7 +120,8 @@ class HipBackend:
         Dm, Hd = W2.shape
         Do, Din = W3.shape
         De = Din - Dm
-        ops.gemm(N.TT_GEMM_TN, d_out, tin, gW3, Do, Din, B)
+        ops.gemm(N.TT_GEMM_TN, d_out, emb, gW3[:, :De], Do, De, B)
+        ops.gemm(N.TT_GEMM_TN, d_out, f, gW3[:, De:], Do, Dm, B)
         ops.colsum(d_out, gb3)
         d_emb = self.empty(B, De)
         ops.gemm(N.TT_GEMM_NN, d_out, W3[:, :De], d_emb, B, De, Do)
@@ -162,12 +163,12 @@ class HipBackend:
         self.N.check(self.lib.tt_adam_advance(hyper.data_ptr(), self.N.stream()), "tt_adam_advance")
 
     # the table step in three phases (stash -> sweep on a side stream -> finish), see optim.py
-    def adam_table_begin(self, W, M, V, local_ids: torch.Tensor):
-        if local_ids.numel() == 0:
-            return None
+    def adam_table_begin(self, W, M, V, n_local: int, local_ids: torch.Tensor):
+        """`local_ids` may contain the sentinel n_local: the plan sorts it last and the Adam
+        kernels skip its run."""
         ops, N, lib = self.ops, self.N, self.lib
-        n_rows, dim = W.shape
-        plan = ops.RowPlan([local_ids], n_rows, slot=f"plan{W.data_ptr()}")
+        n_rows, dim = n_local, W.shape[1]
+        plan = ops.RowPlan([local_ids], n_rows + 1, slot=f"plan{W.data_ptr()}")
         key = W.data_ptr()
         need = lib.tt_adam_table_workspace_bytes(plan.n, dim)
         side = self._sides.get(key)
@@ -178,19 +179,19 @@ class HipBackend:
                                         plan.sorted_ids.data_ptr(), plan.seg_begin.data_ptr(),
                                         plan.n_unique.data_ptr(), side.data_ptr(), side.numel(), N.stream()),
                 "tt_adam_table_stash")
-        return plan, side
+        return plan, side, n_rows
 
     def sweep_async(self, tables, hyper):
         """Zero-gradient sweep of every (W, M, V) on the side stream, after everything queued so
         far on the main stream (the lookups and the stashes)."""
         N, lib = self.N, self.lib
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
+            self._side_stream = self.N.low_priority_stream(self.device)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
         self._side_stream.wait_event(ready)
-        for W, M, V in tables:
-            N.check(lib.tt_adam_table_sweep(W.data_ptr(), M.data_ptr(), V.data_ptr(), W.shape[0], W.shape[1],
+        for W, M, V, n_local in tables:
+            N.check(lib.tt_adam_table_sweep(W.data_ptr(), M.data_ptr(), V.data_ptr(), n_local, W.shape[1],
                                             hyper.data_ptr(), self._side_stream.cuda_stream), "tt_adam_table_sweep")
         self._sweep_done = torch.cuda.Event()
         self._sweep_done.record(self._side_stream)
@@ -199,12 +200,10 @@ class HipBackend:
         torch.cuda.current_stream().wait_event(self._sweep_done)
 
     def adam_table_finish(self, W, M, V, hyper, state, grad_rows: torch.Tensor):
-        if state is None:
-            return
         N, lib = self.N, self.lib
-        plan, side = state
+        plan, side, n_rows = state
         plan.attach([grad_rows])
-        N.check(lib.tt_adam_table_finish(W.data_ptr(), M.data_ptr(), V.data_ptr(), W.shape[0], W.shape[1],
+        N.check(lib.tt_adam_table_finish(W.data_ptr(), M.data_ptr(), V.data_ptr(), n_rows, W.shape[1],
                                          hyper.data_ptr(), C.byref(plan.sources), plan.n, plan.sorted_ids.data_ptr(),
                                          plan.perm.data_ptr(), plan.seg_begin.data_ptr(), plan.n_unique.data_ptr(),
                                          side.data_ptr(), side.numel(), N.stream()), "tt_adam_table_finish")
@@ -233,23 +232,17 @@ class ShardedTable:
         self.v = torch.zeros_like(self.weight)
 
 
-class Route:
-    """Where each id of a batch lives, and the permutation that groups ids by owner."""
+class Lookup:
+    """Every rank's ids of one lookup, seen from this rank's block: `local` holds the row
+    offset inside the block for ids this rank owns and the sentinel `n_local` (one past the
+    block) for everybody else's."""
 
     def __init__(self, ids: torch.Tensor, table: ShardedTable):
-        W = dist.get_world_size()
-        owner = torch.div(ids, table.rows_per_rank, rounding_mode="floor")
-        if bool(((ids < 0) | (ids >= table.n_rows)).any()):
-            raise IndexError("index out of range in self")
-        self.order = torch.argsort(owner, stable=True)
-        counts = torch.bincount(owner, minlength=W)
-        self.inverse = torch.empty_like(self.order)
-        self.inverse[self.order] = torch.arange(ids.numel(), device=ids.device)
-        recv = exchange_counts(counts)
-        self.send_counts = [int(c) for c in counts.tolist()]  # host sync: variable all_to_all sizes
-        self.recv_counts = [int(c) for c in recv.tolist()]
-        send_local = (ids - owner * table.rows_per_rank)[self.order]
-        self.recv_local_ids = all_to_all_rows(send_local, self.send_counts, self.recv_counts)
+        ids_all = all_gather_rows(ids)
+        local = ids_all - table.lo
+        owned = (local >= 0) & (local < (table.hi - table.lo))
+        self.n_local = table.hi - table.lo
+        self.local = torch.where(owned, local, torch.full_like(local, self.n_local))
 
 
 class ShardedTrainer:
@@ -317,35 +310,29 @@ class ShardedTrainer:
             out.append(tuple(t.to(self.device) for t in b))
         return out
 
-    # ---- lookup / scatter through the owning ranks
-    def _lookup_into(self, table: ShardedTable, ids: torch.Tensor, out: torch.Tensor) -> Route:
-        rt = Route(ids, table)
-        rows_send = self.be.gather(table.weight, rt.recv_local_ids)
-        rows_back = all_to_all_rows(rows_send, rt.recv_counts, rt.send_counts)  # grouped by owner
-        self.be.gather(rows_back, rt.inverse, out)  # undo the grouping, straight into the tower input
-        return rt
-
-    def _return_row_grads(self, rt: Route, d_rows: torch.Tensor) -> torch.Tensor:
-        grouped = self.be.gather(d_rows, rt.order)
-        return all_to_all_rows(grouped, rt.send_counts, rt.recv_counts)  # aligned with rt.recv_local_ids
+    # ---- lookup through the owning ranks (fixed-size collectives, no host sync)
+    def _lookup(self, table: ShardedTable, ids: torch.Tensor) -> Tuple[Lookup, torch.Tensor]:
+        lk = Lookup(ids, table)
+        partial = self.be.gather_owned(table.weight, lk.local, lk.n_local)  # [W*B, D], zeros if not mine
+        rows = reduce_scatter_rows(partial) if self.W > 1 else partial
+        return lk, rows
 
     def step(self, batch) -> torch.Tensor:
         user_id, user_feat, _hist, item_id, item_feat, _pos, labels = batch
         be, W, D, B = self.be, self.W, self.cfg["D"], user_id.shape[0]
-        # 1. towers on the local batch rows
-        u_in, i_in = be.empty(B, 2 * D), be.empty(B, 2 * D)
-        rt_u = self._lookup_into(self.users, user_id, u_in[:, :D])
-        rt_i = self._lookup_into(self.items, item_id, i_in[:, :D])
+        # 1. embedding rows of the local batch, served by the owning ranks
+        lk_u, u_emb = self._lookup(self.users, user_id)
+        lk_i, i_emb = self._lookup(self.items, item_id)
         # the tables' old rows have been read: plan, park the looked-up rows, and start the
         # zero-gradient sweep on the side stream -- it overlaps everything up to step 6
         be.adam_advance(self.hyper)
-        st_u = be.adam_table_begin(self.users.weight, self.users.m, self.users.v, rt_u.recv_local_ids)
-        st_i = be.adam_table_begin(self.items.weight, self.items.m, self.items.v, rt_i.recv_local_ids)
-        be.sweep_async([(self.users.weight, self.users.m, self.users.v),
-                        (self.items.weight, self.items.m, self.items.v)], self.hyper)
+        st_u = be.adam_table_begin(self.users.weight, self.users.m, self.users.v, lk_u.n_local, lk_u.local)
+        st_i = be.adam_table_begin(self.items.weight, self.items.m, self.items.v, lk_i.n_local, lk_i.local)
+        be.sweep_async([(self.users.weight, self.users.m, self.users.v, lk_u.n_local),
+                        (self.items.weight, self.items.m, self.items.v, lk_i.n_local)], self.hyper)
         pu, pi = self._tower_params("user"), self._tower_params("item")
-        u_h, U = be.tower_fwd(u_in, user_feat, pu)
-        i_h, I = be.tower_fwd(i_in, item_feat, pi)
+        u_h, u_f, U = be.tower_fwd(u_emb, user_feat, pu)
+        i_h, i_f, I = be.tower_fwd(i_emb, item_feat, pi)
         # 2. logits against every rank's items
         glob = self.negatives == "global" and W > 1
         I_all = all_gather_rows(I) if glob else I
@@ -366,12 +353,12 @@ class ShardedTrainer:
         dU, dI_all = be.ce_bwd(U, I_all, off, lse, coef)
         dI = reduce_scatter_rows(dI_all) if glob else dI_all
         # 5. towers backward -> dense grads (flat buffer) + embedding-row grads
-        d_urows = be.tower_bwd(dU, u_in, u_h, user_feat, pu, self._tower_grads("user"))
-        d_irows = be.tower_bwd(dI, i_in, i_h, item_feat, pi, self._tower_grads("item"))
+        d_urows = be.tower_bwd(dU, u_emb, u_h, u_f, user_feat, pu, self._tower_grads("user"))
+        d_irows = be.tower_bwd(dI, i_emb, i_h, i_f, item_feat, pi, self._tower_grads("item"))
         if W > 1:
             dist.all_reduce(self.flat_g)
-        g_u = self._return_row_grads(rt_u, d_urows)
-        g_i = self._return_row_grads(rt_i, d_irows)
+        g_u = all_gather_rows(d_urows) if W > 1 else d_urows  # aligned with lk_u.local
+        g_i = all_gather_rows(d_irows) if W > 1 else d_irows
         # 6. dense-exact Adam: the looked-up rows of this rank's blocks, over the swept tables
         be.sweep_wait()
         be.adam_table_finish(self.users.weight, self.users.m, self.users.v, self.hyper, st_u, g_u)
