@@ -185,7 +185,8 @@ def test_adam_table_equals_dense_adam(T, n_rows, D, n1, n2):
 
 
 # ------------------------------------------------------------------ attention
-@pytest.mark.parametrize("B,H,D,heads", [(3, 50, 128, 4), (2, 7, 40, 4), (1, 3, 2, 1), (2, 128, 64, 4), (5, 16, 40, 4)])
+@pytest.mark.parametrize("B,H,D,heads", [(3, 50, 128, 4), (2, 7, 40, 4), (1, 3, 2, 1), (2, 128, 64, 4), (5, 16, 40, 4),
+                                         (4, 64, 64, 4), (2, 33, 128, 2), (3, 1, 128, 4), (9, 50, 64, 2)])
 def test_attention_forward_backward(T, B, H, D, heads):
     ops, N = T
     lib = N.load()

@@ -135,6 +135,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   }
 }
 
+// fast path, attention_mfma.hip
+bool attn_mfma_supported(const void* a, const void* b, int64_t H, int64_t D, int64_t dh);
+int attn_fwd_mfma(const float* qkv, int64_t B, int64_t H, int64_t D, int64_t heads, float* ctx, float* lse, hipStream_t st);
+int attn_bwd_mfma(const float* qkv, const float* lse, const float* d_ctx, int64_t B, int64_t H, int64_t D,
+                  int64_t heads, float* d_qkv, hipStream_t st);
+
 static int pick_dhp(int64_t dh) { return dh <= 4 ? 4 : dh <= 16 ? 16 : dh <= 32 ? 32 : dh <= 64 ? 64 : 0; }
 
 template <typename K>
@@ -156,6 +162,7 @@ extern "C" int tt_attn_fwd(const float* qkv, int64_t B, int64_t H, int64_t D, in
   if (B < 0 || H <= 0 || D <= 0 || heads <= 0 || D % heads != 0) return fail_arg("tt_attn_fwd: sizes");
   if (B == 0) return 0;
   const int64_t dh = D / heads;
+  if (attn_mfma_supported(qkv, ctx, H, D, dh)) return attn_fwd_mfma(qkv, B, H, D, heads, ctx, lse, S(stream));
   const int dhp = pick_dhp(dh);
   if (!dhp) { set_error("tt_attn_fwd: head dim %lld > 64 not implemented", (long long)dh); return TT_E_UNSUPPORTED; }
   const unsigned threads = (unsigned)(H >= 256 ? 256 : round_up(H, 64));
@@ -176,6 +183,8 @@ extern "C" int tt_attn_bwd(const float* qkv, const float* ctx, const float* lse,
   if (B < 0 || H <= 0 || D <= 0 || heads <= 0 || D % heads != 0) return fail_arg("tt_attn_bwd: sizes");
   if (B == 0) return 0;
   const int64_t dh = D / heads;
+  if (attn_mfma_supported(qkv, d_ctx, H, D, dh) && (reinterpret_cast<uintptr_t>(d_qkv) & 15) == 0)
+    return attn_bwd_mfma(qkv, lse, d_ctx, B, H, D, heads, d_qkv, S(stream));
   const int dhp = pick_dhp(dh);
   if (!dhp) { set_error("tt_attn_bwd: head dim %lld > 64 not implemented", (long long)dh); return TT_E_UNSUPPORTED; }
   const unsigned threads = (unsigned)(H >= 256 ? 256 : round_up(H, 64));

@@ -233,9 +233,13 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, GemmArgs g) {
 // ---- column sums -----------------------------------------------------------
 // stage 1: workgroup = 64 columns x 4 row groups over a 64-row chunk (each wave reads one
 // 256-B row segment per instruction); the 4 row-group partials are combined in fixed order.
-constexpr int CS_ROWS = 64;
+static inline int64_t colsum_rows_per_part(int64_t M) {  // 64 rows, more for tall inputs (<= 512 parts)
+  int64_t r = 64;
+  while (ceil_div(M, r) > 512) r *= 2;
+  return r;
+}
 __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ X, int64_t M, int64_t N,
-                                                     int64_t ldx, float* __restrict__ part) {
+                                                     int64_t ldx, float* __restrict__ part, int64_t CS_ROWS) {
   __shared__ float red[4][64];
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int64_t col = (int64_t)blockIdx.x * 64 + c;
@@ -362,7 +366,7 @@ extern "C" int tt_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, const fl
 
 extern "C" int64_t tt_colsum_workspace_bytes(int64_t M, int64_t N) {
   if (M <= 0 || N <= 0) return 0;
-  return round_up(ceil_div(M, CS_ROWS) * N * (int64_t)sizeof(float), 256);
+  return round_up(ceil_div(M, colsum_rows_per_part(M)) * N * (int64_t)sizeof(float), 256);
 }
 
 extern "C" int tt_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out, void* ws,
@@ -370,9 +374,10 @@ extern "C" int tt_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, 
   if (!X || !out) return fail_arg("tt_colsum_f32: null pointer");
   if (M <= 0 || N <= 0 || ldx < N) return fail_arg("tt_colsum_f32: sizes");
   if (!ws || ws_bytes < tt_colsum_workspace_bytes(M, N)) { set_error("tt_colsum_f32: workspace"); return TT_E_WORKSPACE; }
-  const int64_t nparts = ceil_div(M, CS_ROWS);
+  const int64_t rpp = colsum_rows_per_part(M);
+  const int64_t nparts = ceil_div(M, rpp);
   float* part = reinterpret_cast<float*>(ws);
-  colsum_stage1<<<dim3((unsigned)ceil_div(N, 64), (unsigned)nparts), 256, 0, S(stream)>>>(X, M, N, ldx, part);
+  colsum_stage1<<<dim3((unsigned)ceil_div(N, 64), (unsigned)nparts), 256, 0, S(stream)>>>(X, M, N, ldx, part, rpp);
   int rc = check_launch("colsum_stage1");
   if (rc) return rc;
   colsum_stage2<<<(unsigned)ceil_div(N, 64), 256, 0, S(stream)>>>(part, nparts, N, out);

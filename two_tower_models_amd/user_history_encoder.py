@@ -55,7 +55,7 @@ class UserHistoryEncoder(nn.Module):
             # newest item first => row 0 carries the encoding of position H-1 (ref :35-54)
             self.positional_embeddings = self.positional_encoding(
                 seq_len=history_len, d_model=item_id_embedding_dim
-            ).flip([0])
+            ).flip([0]).to(torch.empty(0).device)  # honours an enclosing `with torch.device(...)`
         self.multihead_attn_layers = nn.ModuleList(
             [_AttentionLayerParams(item_id_embedding_dim, num_attention_heads) for _ in range(num_attention_layers)]
         )
@@ -69,7 +69,7 @@ class UserHistoryEncoder(nn.Module):
     def positional_encoding(self, seq_len: int, d_model: int) -> torch.Tensor:
         """The reference's table (ref :69-78): column c holds sin (c even) / cos (c odd) of
         pos / 10000^(2c/d_model), evaluated in Python floats."""
-        table = torch.zeros(seq_len, d_model)
+        table = torch.zeros(seq_len, d_model, device="cpu")  # filled element-wise: keep it on the host
         for pos in range(seq_len):
             for c in range(d_model):
                 angle = pos / (10000 ** ((2 * c) / d_model))
