@@ -1,0 +1,98 @@
+"""The reference's own unit tests (ref:tests/*.py, 10 tests), re-run against the MI355X
+modules: same constructor arguments, same shapes, same assertions.  Only the imports and the
+device differ.  (The seed-42 known-answer tests live in test_gpu_models.py.)"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def A():
+    import two_tower_models_amd as A
+    return A
+
+
+# ---- ref:tests/test_baseline_mips_module.py
+def test_mips_output_shapes_and_values(A):
+    corpus_size, embedding_dim, num_items, batch_size = 100, 50, 10, 32
+    module = A.BaselineMIPSModule(corpus_size, embedding_dim).to(DEV)
+    query = torch.randn(batch_size, embedding_dim, device=DEV)
+    mips_ids, mips_scores, mips_embeddings = module(query, num_items)
+    assert mips_ids.shape == (batch_size, num_items)
+    assert mips_scores.shape == (batch_size, num_items)
+    assert mips_embeddings.shape == (batch_size, num_items, embedding_dim)
+    assert torch.all(mips_ids >= 0) and torch.all(mips_ids < corpus_size)
+    assert mips_ids.dtype == torch.int64
+    assert torch.all(mips_scores[:, :-1] >= mips_scores[:, 1:])  # torch.topk returns sorted scores
+
+
+def _dims():
+    return dict(num_items=10, user_id_hash_size=100, user_id_embedding_dim=50, user_features_size=20,
+                item_id_hash_size=150, item_id_embedding_dim=40, item_features_size=30,
+                user_value_weights=[0.1, 0.2, 0.3])
+
+
+def _inputs(B=32, H=128):
+    return (torch.randint(0, 100, (B,), device=DEV), torch.randn(B, 20, device=DEV),
+            torch.randint(0, 150, (B, H), device=DEV), torch.randint(0, 150, (B,), device=DEV),
+            torch.randn(B, 30, device=DEV), torch.randint(0, 10, (B,), device=DEV),
+            torch.randint(0, 2, (B, 3), device=DEV).float())
+
+
+# ---- ref:tests/test_two_tower_base_retrieval.py
+def test_base_forward_pass_and_train_forward(A):
+    mips = A.BaselineMIPSModule(corpus_size=1001, embedding_dim=40)
+    model = A.TwoTowerBaseRetrieval(mips_module=mips, **_dims()).to(DEV)
+    uid, uf, uh, iid, itf, pos, labels = _inputs()
+    out = model(uid, uf, uh)
+    assert out.shape == (32, 10)
+    assert torch.all(out >= 0) and torch.all(out < mips.corpus_size)
+    loss = model.train_forward(uid, uf, uh, iid, itf, pos, labels)
+    assert isinstance(loss.item(), float)
+
+
+# ---- ref:tests/test_two_tower_user_hist.py
+def test_history_model_forward_pass(A):
+    mips = A.BaselineMIPSModule(corpus_size=1001, embedding_dim=40)
+    model = A.TwoTowerWithUserHistoryEncoder(mips_module=mips, user_history_seqlen=128, **_dims()).to(DEV)
+    uid, uf, uh, *_ = _inputs()
+    out = model(uid, uf, uh)
+    assert out.shape == (32, 10)
+    assert torch.all(out >= 0) and torch.all(out < mips.corpus_size)
+
+
+# ---- ref:tests/test_two_tower_user_hist_position_debias.py (combined debias variant here)
+def test_debias_model_forward_and_train_forward(A):
+    import warnings
+    mips = A.BaselineMIPSModule(corpus_size=1001, embedding_dim=40)
+    model = A.TwoTowerWithDebiasing(mips_module=mips, user_history_seqlen=128, **_dims()).to(DEV)
+    uid, uf, uh, iid, itf, pos, labels = _inputs()
+    out = model(uid, uf, uh)
+    assert out.shape == (32, 10) and torch.all(out >= 0) and torch.all(out < mips.corpus_size)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        loss = model.train_forward(uid, uf, uh, iid, itf, pos, labels)
+    assert isinstance(loss.item(), float)
+    loss.backward()
+    assert all(p.grad is not None for p in model.parameters())
+
+
+# ---- ref:tests/test_user_history_enc.py::test_forward
+def test_encoder_forward_shape(A):
+    model = A.UserHistoryEncoder(item_id_embedding_dim=64, history_len=128, num_attention_heads=4,
+                                 num_attention_layers=12, use_positional_encoding=True).to(DEV)
+    output = model(torch.randn(32, 128, 64, device=DEV))
+    assert output.shape == (32, model.get_output_dim() / 64, 64)
+
+
+# ---- ref:train/train.py: the script runs end to end and the loss goes down
+def test_train_script_default_flags(A, capsys):
+    from two_tower_models_amd import train
+    torch.manual_seed(0)
+    train.main(train.build_parser().parse_args(["--num_epochs", "4"]))
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("Epoch")]
+    assert len(lines) == 4
+    first, last = (float(l.rsplit(" ", 1)[1]) for l in (lines[0], lines[-1]))
+    assert last < first
