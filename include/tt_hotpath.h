@@ -238,6 +238,12 @@ int64_t tt_mips_workspace_bytes(int64_t B, int64_t C, int64_t D, int64_t K, int 
 int tt_mips_topk(const void* query, const void* corpus, int dtype, int64_t B, int64_t C,
                  int64_t D, int64_t K, int64_t* idx_out, float* score_out, void* ws,
                  int64_t ws_bytes, tt_stream_t stream);
+/* Exact merge of per-shard top-K lists (row-sharded corpus): per query, the K best of n_cand
+ * (score, GLOBAL index) candidates under the same (score desc, index asc) order.  idx < 0
+ * marks padding. */
+int64_t tt_mips_merge_workspace_bytes(int64_t B, int64_t n_cand);
+int tt_mips_merge(const float* scores, const int64_t* idx, int64_t B, int64_t n_cand, int64_t K,
+                  int64_t* idx_out, float* score_out, void* ws, int64_t ws_bytes, tt_stream_t stream);
 int tt_f32_to_bf16(const float* in, uint16_t* out, int64_t n, tt_stream_t stream);
 int tt_gather_rows_bf16(const uint16_t* table, int64_t n_rows, int64_t dim, const int64_t* ids,
                         int64_t n_ids, float* out, int64_t ld_out, int32_t* oob_flag,

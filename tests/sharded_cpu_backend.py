@@ -80,5 +80,17 @@ class OracleBackend:
         R.adam_update(W[:n_local], g, M[:n_local], V[:n_local], hyper["step"], hyper["lr"], hyper["b1"],
                       hyper["b2"], hyper["eps"])
 
+    def mips_topk(self, query, corpus, k):
+        idx, sc, _ = R.mips_topk(query, corpus.float(), k)
+        return idx, sc
+
+    def mips_merge(self, scores, idx, k):
+        out_i, out_s = [], []
+        for s, i in zip(scores, idx):
+            order = sorted(range(len(i)), key=lambda t: (i[t].item() < 0, -s[t].item(), i[t].item()))[:k]
+            out_i.append(i[order])
+            out_s.append(s[order])
+        return torch.stack(out_i), torch.stack(out_s)
+
     def adam_dense(self, p, g, m, v, hyper):
         R.adam_update(p, g, m, v, hyper["step"], hyper["lr"], hyper["b1"], hyper["b2"], hyper["eps"])

@@ -50,3 +50,32 @@ def test_world1_hip_backend_matches_oracle(cfg):
             assert torch.allclose(v.cpu(), params[k], atol=6.6e-3 if noise_only else 5e-6), k
     finally:
         dist.destroy_process_group()
+
+
+def test_mips_merge_kernel_and_world1_sharded_mips():
+    """tt_mips_merge on hand-made shard lists (ties across shards, padding) and ShardedMIPS with
+    the product backend at world size 1."""
+    import torch.distributed as dist
+    import fixture_gen as fg
+    from oracle import cpu_ref as R
+    from two_tower_models_amd import ops, sharded
+    dev = torch.device("cuda:0")
+    # 3 "shards" x K=4 candidates for 2 queries; equal scores across shards must order by index
+    sc = torch.tensor([[5., 3., 3., 1., 5., 4., 3., 0., 9., 3., 2., 0.],
+                       [1., 1., 1., 1., 1., 1., 1., 0., 1., 1., 0., 0.]])
+    ix = torch.tensor([[10, 11, 12, 13, 20, 21, 22, -1, 3, 30, 31, -1],
+                       [7, 8, 9, 10, 1, 2, 3, -1, 4, 5, -1, -1]])
+    oi, os_ = ops.mips_merge(sc.to(dev), ix.to(dev), 5)
+    assert oi.cpu().tolist() == [[3, 10, 20, 21, 11], [1, 2, 3, 4, 5]]
+    assert os_.cpu().tolist() == [[9., 5., 5., 4., 3.], [1., 1., 1., 1., 1.]]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                            device_id=dev)
+    try:
+        corpus = torch.from_numpy(fg.exact_mips_corpus(5000, 64))
+        q = torch.from_numpy(fg.exact_mips_queries(9, 64))
+        m = sharded.ShardedMIPS(corpus.to(dev), 0)
+        idx, s = m.search(q.to(dev), 100)
+        want_idx, want_sc, _ = R.mips_topk(q, corpus, 100)
+        assert torch.equal(idx.cpu(), want_idx) and torch.equal(s.cpu(), want_sc)
+    finally:
+        dist.destroy_process_group()

@@ -115,3 +115,41 @@ def test_local_negatives_is_mean_of_per_rank_losses():
     per_rank = [float(R.train_forward(params, res[r]["batches"][0], torch.tensor([0.7]))) for r in range(world)]
     assert abs(res[0]["losses"][0] - sum(per_rank) / world) < 1e-5
     assert res[0]["losses"] == res[1]["losses"]
+
+
+# ---------------------------------------------------------------- sharded MIPS
+def _mips_worker(rank, world, port, outdir, C, K):
+    for p in (ROOT, HERE, os.path.join(HERE, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import fixture_gen as fg
+    from sharded_cpu_backend import OracleBackend
+    from two_tower_models_amd import sharded
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        corpus = torch.from_numpy(fg.exact_mips_corpus(C, 32))
+        lo, hi = sharded.ShardedMIPS.block_range(C, rank, world)
+        m = sharded.ShardedMIPS(corpus[lo:hi].clone(), lo, backend=OracleBackend())
+        q = torch.from_numpy(fg.exact_mips_queries(5 * world, 32))[rank * 5:(rank + 1) * 5]
+        idx, sc = m.search(q, K)
+        torch.save({"idx": idx, "sc": sc}, os.path.join(outdir, f"mips{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,C,K", [(2, 700, 20), (3, 100, 40)])
+def test_sharded_mips_equals_single_device(world, C, K):
+    """Row-sharded corpus (incl. a block smaller than K) == the unsharded exact top-K."""
+    import fixture_gen as fg
+    from oracle import cpu_ref as R
+    outdir = tempfile.mkdtemp()
+    mp.spawn(_mips_worker, args=(world, _free_port(), outdir, C, K), nprocs=world, join=True)
+    corpus = torch.from_numpy(fg.exact_mips_corpus(C, 32))
+    q = torch.from_numpy(fg.exact_mips_queries(5 * world, 32))
+    want_idx, want_sc, _ = R.mips_topk(q, corpus, K)
+    for r in range(world):
+        got = torch.load(os.path.join(outdir, f"mips{r}.pt"))
+        assert torch.equal(got["idx"], want_idx[r * 5:(r + 1) * 5])
+        assert torch.equal(got["sc"], want_sc[r * 5:(r + 1) * 5])

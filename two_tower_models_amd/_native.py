@@ -77,6 +77,8 @@ SIGNATURES = {
     "tt_attn_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "tt_mips_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64, _int]),
     "tt_mips_topk": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "tt_mips_merge_workspace_bytes": (_i64, [_i64, _i64]),
+    "tt_mips_merge": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
     "tt_f32_to_bf16": (_int, [_vp, _vp, _i64, _vp]),
     "tt_gather_rows_bf16": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
 }

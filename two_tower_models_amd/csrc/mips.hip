@@ -393,6 +393,18 @@ __global__ __launch_bounds__(64) void mips_sort_emit_kernel(u64* __restrict__ ca
   }
 }
 
+// merge of per-shard results: keys from (score, global index) pairs, then the same per-query sort
+__global__ void mips_merge_keys_kernel(const float* __restrict__ scores, const int64_t* __restrict__ idx,
+                                       int64_t B, int64_t n_cand, u64* __restrict__ cand, int32_t* __restrict__ count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * n_cand) {
+    const int64_t id = idx[i];
+    // a shard with fewer than K rows pads with index -1: lowest possible key, sorts last
+    cand[i] = (id >= 0) ? make_key(scores[i], (uint32_t)id) : 0ull;
+  }
+  if (i < B) count[i] = (int32_t)n_cand;
+}
+
 __global__ void mips_zero_kernel(u64* tau, int32_t* count, int64_t nq) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nq) { tau[i] = 0; count[i] = 0; }
@@ -520,4 +532,29 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
     if ((rc = check_launch("mips_sort_emit_kernel"))) return rc;
   }
   return 0;
+}
+
+extern "C" int64_t tt_mips_merge_workspace_bytes(int64_t B, int64_t n_cand) {
+  if (B <= 0 || n_cand <= 0) return 256;
+  return 2 * round_up(B * n_cand * 8, 256) + round_up(B * 4, 256) + 256;
+}
+
+extern "C" int tt_mips_merge(const float* scores, const int64_t* idx, int64_t B, int64_t n_cand, int64_t K,
+                             int64_t* idx_out, float* score_out, void* ws, int64_t ws_bytes, tt_stream_t stream) {
+  if (!scores || !idx || !idx_out || !score_out || !ws) return fail_arg("tt_mips_merge: null pointer");
+  if (B <= 0 || n_cand <= 0 || K <= 0 || K > n_cand || n_cand >= ((int64_t)1 << 31)) return fail_arg("tt_mips_merge: sizes");
+  if (ws_bytes < tt_mips_merge_workspace_bytes(B, n_cand)) { set_error("tt_mips_merge: workspace"); return TT_E_WORKSPACE; }
+  hipStream_t st = S(stream);
+  Carver cv(ws);
+  u64* cand = cv.take<u64>(B * n_cand);
+  u64* tmp = cv.take<u64>(B * n_cand);
+  int32_t* count = cv.take<int32_t>(B);
+  int32_t* status = cv.take<int32_t>(1);
+  hipError_t he = hipMemsetAsync(status, 0, 4, st);
+  if (he != hipSuccess) { set_error("tt_mips_merge: memset: %s", hipGetErrorString(he)); return (int)he; }
+  mips_merge_keys_kernel<<<(unsigned)ceil_div(B * n_cand, 256), 256, 0, st>>>(scores, idx, B, n_cand, cand, count);
+  int rc = check_launch("mips_merge_keys_kernel");
+  if (rc) return rc;
+  mips_sort_emit_kernel<<<(unsigned)B, 64, 0, st>>>(cand, tmp, count, n_cand, K, 0, idx_out, score_out, status);
+  return check_launch("mips_sort_emit_kernel");
 }

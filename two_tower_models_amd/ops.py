@@ -519,6 +519,20 @@ def mips_topk(query: torch.Tensor, corpus: torch.Tensor, k: int) -> Tuple[torch.
     return idx, scores
 
 
+def mips_merge(scores: torch.Tensor, idx: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per query, the k best of the [B, n_cand] (score, global index) candidates."""
+    dev = N.require_device(scores, idx)
+    lib = N.load()
+    scores, idx = scores.contiguous(), idx.contiguous()
+    B, n_cand = scores.shape
+    out_idx = torch.empty(B, k, dtype=torch.int64, device=dev)
+    out_sc = torch.empty(B, k, dtype=torch.float32, device=dev)
+    wsp, wsn = _ws(dev, lib.tt_mips_merge_workspace_bytes(B, n_cand), "mips")
+    N.check(lib.tt_mips_merge(scores.data_ptr(), idx.data_ptr(), B, n_cand, k, out_idx.data_ptr(),
+                              out_sc.data_ptr(), wsp, wsn, N.stream()), "tt_mips_merge")
+    return out_idx, out_sc
+
+
 def gather_corpus_rows(corpus: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     """corpus[idx] -> [B, K, D] fp32 (ref:src/baseline_mips_module.py:63-69)."""
     dev = N.require_device(corpus, idx)

@@ -208,6 +208,12 @@ class HipBackend:
                                          plan.perm.data_ptr(), plan.seg_begin.data_ptr(), plan.n_unique.data_ptr(),
                                          side.data_ptr(), side.numel(), N.stream()), "tt_adam_table_finish")
 
+    def mips_topk(self, query, corpus, k):
+        return self.ops.mips_topk(query, corpus, k)
+
+    def mips_merge(self, scores, idx, k):
+        return self.ops.mips_merge(scores, idx, k)
+
     def adam_dense(self, p, g, m, v, hyper):
         N = self.N
         d = (N.AdamTensor * 1)()
@@ -365,3 +371,49 @@ class ShardedTrainer:
         be.adam_table_finish(self.items.weight, self.items.m, self.items.v, self.hyper, st_i, g_i)
         be.adam_dense(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.hyper)
         return loss
+
+
+# ----------------------------------------------------------------- sharded MIPS (BASELINE config 5)
+class ShardedMIPS:
+    """Brute-force MIPS over a corpus whose rows are split into W contiguous blocks
+    (ref:src/baseline_mips_module.py:32-72 on one shard per GPU).  Every rank brings its own
+    B queries; per call:
+        all_gather queries                         [B, D] -> [W*B, D]
+        local exact top-K of ALL queries on this rank's block (tt_mips_topk)
+        all_to_all of the (score, global index) lists   [W, B, K] <-> [W, B, K]   (fixed size)
+        exact merge of the W*K candidates per own query (tt_mips_merge)
+    The global top-K is a subset of the union of the per-block top-Ks and every stage uses
+    the (score desc, index asc) order, so the result equals the single-device answer."""
+
+    def __init__(self, corpus_block: torch.Tensor, row_offset: int, backend=None):
+        if not dist.is_initialized():
+            raise RuntimeError("ShardedMIPS needs torch.distributed to be initialised")
+        self.corpus, self.row_offset = corpus_block, int(row_offset)
+        self.W = dist.get_world_size()
+        self.be = backend if backend is not None else HipBackend(corpus_block.device)
+
+    @staticmethod
+    def block_range(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
+        per = (n_rows + world - 1) // world
+        lo = min(rank * per, n_rows)
+        return lo, min(lo + per, n_rows)
+
+    def search(self, query: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        W, B = self.W, query.shape[0]
+        q_all = all_gather_rows(query) if W > 1 else query
+        n_local = self.corpus.shape[0]
+        k_loc = min(k, n_local)
+        idx, sc = self.be.mips_topk(q_all, self.corpus, k_loc)  # [W*B, k_loc], local row numbers
+        idx = idx + self.row_offset
+        if k_loc < k:  # a block smaller than K: pad with "no candidate"
+            pad = k - k_loc
+            idx = torch.cat([idx, idx.new_full((idx.shape[0], pad), -1)], dim=1)
+            sc = torch.cat([sc, sc.new_zeros((sc.shape[0], pad))], dim=1)
+        if W > 1:
+            ridx, rsc = torch.empty_like(idx), torch.empty_like(sc)
+            dist.all_to_all_single(ridx, idx.contiguous())  # chunk r of the send = rank r's queries
+            dist.all_to_all_single(rsc, sc.contiguous())
+            # received layout [W (source shard), B, k] -> per own query the W*k candidates
+            idx = ridx.view(W, B, k).permute(1, 0, 2).reshape(B, W * k)
+            sc = rsc.view(W, B, k).permute(1, 0, 2).reshape(B, W * k)
+        return self.be.mips_merge(sc, idx, k)
