@@ -60,6 +60,12 @@ def _worker(rank, world, port, outdir, negatives):
         ut, it = _tables(CFG)
         tr.users.weight.copy_(ut[tr.users.lo:tr.users.hi])
         tr.items.weight.copy_(it[tr.items.lo:tr.items.hi])
+        # checkpoint adaptor: a reference-format state_dict round-trips through the shards
+        full = dict(_dense_init(CFG))
+        full["user_id_embedding_arch.weight"], full["item_id_embedding_arch.weight"] = ut, it
+        tr.load_state_dict(full)
+        back = tr.state_dict()
+        assert all(torch.equal(back[k], full[k]) for k in full), "state_dict round trip"
         batches = tr.make_batches(STEPS, seed=99)
         losses = [float(tr.step(b)) for b in batches]
         torch.save({"losses": losses, "users": tr.users.weight.clone(), "items": tr.items.weight.clone(),

@@ -316,6 +316,35 @@ class ShardedTrainer:
             out.append(tuple(t.to(self.device) for t in b))
         return out
 
+    # ---- checkpoint adaptor: sharded blocks <-> the reference's state_dict
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """Full tables assembled on every rank, under the reference's Parameter names, so the
+        result loads into TwoTowerBaseRetrieval (either implementation) unchanged."""
+        out = {k: v.detach().clone() for k, v in self.params.items()}
+        for name, table in (("user_id_embedding_arch.weight", self.users),
+                            ("item_id_embedding_arch.weight", self.items)):
+            per = table.rows_per_rank
+            block = table.weight.new_zeros(per, table.dim)
+            block[: table.hi - table.lo] = table.weight[: table.hi - table.lo]
+            full = all_gather_rows(block) if self.W > 1 else block
+            out[name] = full[: table.n_rows].clone()
+        return out
+
+    def load_state_dict(self, state: Dict[str, torch.Tensor]) -> None:
+        """Scatter a reference-format state_dict into the row blocks / replicated buffer.
+        Adam moments restart from zero (the reference never checkpoints its optimiser)."""
+        with torch.no_grad():
+            for k, v in self.params.items():
+                v.copy_(state[k].to(v.device))
+            for name, table in (("user_id_embedding_arch.weight", self.users),
+                                ("item_id_embedding_arch.weight", self.items)):
+                full = state[name]
+                if full.shape != (table.n_rows, table.dim):
+                    raise ValueError(f"{name}: expected {(table.n_rows, table.dim)}, got {tuple(full.shape)}")
+                table.weight[: table.hi - table.lo].copy_(full[table.lo:table.hi].to(table.weight.device))
+                table.m.zero_()
+                table.v.zero_()
+
     # ---- lookup through the owning ranks (fixed-size collectives, no host sync)
     def _lookup(self, table: ShardedTable, ids: torch.Tensor) -> Tuple[Lookup, torch.Tensor]:
         lk = Lookup(ids, table)
