@@ -229,3 +229,32 @@ def test_hist_embed_pool(T, D, H, B):
     assert torch.allclose(x.cpu().view(B, H, D), emb + pe, atol=1e-7)
     assert torch.allclose(out[:, 1, :].cpu(), emb.mean(1), atol=1e-6)
     assert float(out[:, 0, :].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------ tall-M weights-stationary GEMM
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("M,Nn,K", [(20000, 384, 128), (16389, 130, 100), (16384, 128, 256), (17000, 50, 200),
+                                    (16500, 128, 384), (16390, 70, 300),
+                                    (40000, 128, 32), (16400, 257, 64)])
+def test_gemm_weights_stationary_path(T, layout, M, Nn, K):
+    """M >= 16384 and K <= 256 route NT / NN products to gemm_ws.hip (LDS-DMA when K is 32/64/128/256
+    and rows are aligned, register staging otherwise); epilogues, strides and accumulate included."""
+    ops, N = T
+    A = g((M, K), 201)
+    W = g((Nn, K) if layout == 0 else (K, Nn), 202)
+    bias = g((Nn,), 203)
+    ref = A.double() @ (W.t() if layout == 0 else W).double() + bias.double()
+    Ad, Wd = A.to(DEV), W.to(DEV)
+    big = torch.zeros(M, Nn + 8, device=DEV)
+    out = big[:, 4:4 + Nn]  # strided, 16-B misaligned destination
+    ops.gemm(layout, Ad, Wd, out, M, Nn, K, bias=bias.to(DEV))
+    scale = float(ref.abs().max())
+    assert float((out.cpu().double() - ref).abs().max()) < 3e-6 * math.sqrt(K) * scale
+    assert float(big[:, :4].abs().max()) == 0.0 and float(big[:, 4 + Nn:].abs().max()) == 0.0
+    aux = g((M, Nn), 204).to(DEV)
+    out2 = torch.empty(M, Nn, device=DEV)
+    ops.gemm(layout, Ad, Wd, out2, M, Nn, K, bias=bias.to(DEV), epilogue=N.TT_EPI_RELU_MASK, aux=aux)
+    assert torch.allclose(out2.cpu().double(), ref * (aux.cpu() > 0), atol=3e-6 * math.sqrt(K) * scale)
+    ops.gemm(layout, Ad, Wd, out2, M, Nn, K, epilogue=N.TT_EPI_RELU, accumulate=True)
+    want = ref * (aux.cpu() > 0) + (ref - bias.double()).clamp(min=0)
+    assert torch.allclose(out2.cpu().double(), want, atol=6e-6 * math.sqrt(K) * scale)

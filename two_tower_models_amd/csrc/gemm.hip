@@ -273,7 +273,9 @@ struct GemmPlan {
 static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
   GemmPlan p;
   const int64_t t128 = ceil_div(M, 128) * ceil_div(N, 128);
-  if (t128 >= 192) { p.bm = 128; p.bn = 128; } else { p.bm = 64; p.bn = 64; }
+  // 128^2 tiles when there are enough of them, or when a huge reduction (split-K) supplies the
+  // parallelism instead: the bigger tile halves the operand bytes moved per MFMA
+  if (t128 >= 192 || (K >= 8192 && M >= 128 && N >= 128 && t128 >= 2)) { p.bm = 128; p.bn = 128; } else { p.bm = 64; p.bn = 64; }
   const int64_t tiles = ceil_div(M, p.bm) * ceil_div(N, p.bn);
   const int64_t ktiles = ceil_div(K, BK);
   int64_t splits = 1;
@@ -307,6 +309,11 @@ static int launch_gemm(const GemmArgs& g, hipStream_t st) {
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// tall-M weights-stationary fast path (gemm_ws.hip); -100 = "not applicable"
+int gemm_ws_try(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W,
+                int64_t ldw, float* C, int64_t ldc, const float* bias, int epilogue, const float* aux,
+                int64_t ldaux, int accumulate, hipStream_t st);
+
 }  // namespace tt
 
 using namespace tt;
@@ -330,6 +337,10 @@ extern "C" int tt_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, const fl
   const bool a_kc = layout != TT_GEMM_TN, b_kc = layout == TT_GEMM_NT;
   if (lda < (a_kc ? K : M) || ldb < (b_kc ? K : N)) return fail_arg("tt_gemm_f32: leading dimension");
 
+  {
+    const int rc_ws = gemm_ws_try(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, aux, ldaux, accumulate, S(stream));
+    if (rc_ws != -100) return rc_ws;
+  }
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;

@@ -33,16 +33,9 @@
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "mfma_stream.hpp"
 
 namespace tt {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BI = 128;  // stationary rows per workgroup (32 per wave)
-constexpr int BJ = 64;   // streamed rows per LDS tile
-constexpr float LOG2E = 1.4426950408889634f;
-constexpr float LN2 = 0.6931471805599453f;
-constexpr float NEG_BIG = -3.0e38f;
 
 struct CeArgs {
   const float* X;  // stationary [RX, D]
@@ -63,148 +56,9 @@ struct CeArgs {
   int splits;
 };
 
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-// this wave's 32 stationary rows -> B-operand fragments: xr[g][c] = X[a][8g + 4h + c]
-template <int DP8>
-__device__ __forceinline__ void load_stationary(float (&xr)[DP8][4], const float* __restrict__ X,
-                                                int64_t ld, int64_t row, int64_t nrows, int64_t D,
-                                                int h, bool vec) {
-#pragma unroll
-  for (int g = 0; g < DP8; ++g) {
-    const int64_t k = 8 * g + 4 * h;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < nrows) {
-      const float* p = X + row * ld + k;
-      if (vec && k + 3 < D) {
-        v = *reinterpret_cast<const float4*>(p);
-      } else {
-        if (k + 0 < D) v.x = p[0];
-        if (k + 1 < D) v.y = p[1];
-        if (k + 2 < D) v.z = p[2];
-        if (k + 3 < D) v.w = p[3];
-      }
-    }
-    xr[g][0] = v.x; xr[g][1] = v.y; xr[g][2] = v.z; xr[g][3] = v.w;
-  }
-}
-
-// streamed tile [BJ][DP] : DP8/2 float4 per thread
-template <int DP8>
-__device__ __forceinline__ void tile_fetch(float4 (&st)[(DP8 + 1) / 2], const float* __restrict__ Y,
-                                           int64_t ld, int64_t row0, int64_t nrows, int64_t D, bool vec) {
-  constexpr int C4 = DP8 * 2;  // float4 per row
-#pragma unroll
-  for (int i = 0; i < (DP8 + 1) / 2; ++i) {
-    const int f = threadIdx.x + 256 * i;
-    const int64_t row = row0 + f / C4, k = 4 * (f % C4);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (f < BJ * C4 && row < nrows) {
-      const float* p = Y + row * ld + k;
-      if (vec && k + 3 < D) {
-        v = *reinterpret_cast<const float4*>(p);
-      } else {
-        if (k + 0 < D) v.x = p[0];
-        if (k + 1 < D) v.y = p[1];
-        if (k + 2 < D) v.z = p[2];
-        if (k + 3 < D) v.w = p[3];
-      }
-    }
-    st[i] = v;
-  }
-}
-template <int DP8>
-__device__ __forceinline__ void tile_commit(const float4 (&st)[(DP8 + 1) / 2], float* Ys) {
-  constexpr int C4 = DP8 * 2, LD = DP8 * 8 + 4;
-#pragma unroll
-  for (int i = 0; i < (DP8 + 1) / 2; ++i) {
-    const int f = threadIdx.x + 256 * i;
-    if (f < BJ * C4) *reinterpret_cast<float4*>(Ys + (f / C4) * LD + 4 * (f % C4)) = st[i];
-  }
-}
-
-// ---- LDS image of one streamed tile: addressing for both staging forms
-template <int DP8, bool GLDS>
-struct TileMap {
-  static constexpr int DP = DP8 * 8;
-  static constexpr int LD = GLDS ? DP : DP + 4;          // row stride in floats
-  static constexpr int CPR = DP / 4;                     // 16-B chunks per row
-  static constexpr int SW = (CPR < 16 ? CPR : 16) - 1;   // swizzle mask
-  // float offset of 16-B chunk `c` of row `row`
-  static __device__ __forceinline__ int chunk(int row, int c) {
-    return GLDS ? row * LD + 4 * (c ^ (row & SW)) : row * LD + 4 * c;
-  }
-  // float offset of element (row, col)
-  static __device__ __forceinline__ int elem(int row, int col) {
-    return GLDS ? row * LD + 4 * ((col >> 2) ^ (row & SW)) + (col & 3) : row * LD + col;
-  }
-};
-
-// LDS-DMA of one 64-row tile: each wave instruction lands 1 KiB (= 64/CPR rows); the lane
-// fetches the chunk that belongs at ITS linear LDS position after swizzling.
-template <int DP8>
-__device__ __forceinline__ void tile_dma(const float* __restrict__ Y, int64_t ld, int64_t row0, int64_t nrows,
-                                         float* Ys, int wave, int lane) {
-  using TM = TileMap<DP8, true>;
-  constexpr int RPI = 64 / TM::CPR;        // rows per wave instruction
-  constexpr int NI = BJ / RPI / 4;         // instructions per wave
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int rbase = (wave * NI + i) * RPI;
-    const int row = rbase + lane / TM::CPR;
-    const int c = (lane % TM::CPR) ^ (row & TM::SW);
-    int64_t grow = row0 + row;
-    grow = grow < nrows ? grow : nrows - 1;  // clamp: out-of-range rows are masked by the epilogue
-    const float* src = Y + grow * ld + 4 * c;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(Ys + rbase * TM::DP), 16, 0, 0);
-  }
-}
-
-// St[b][a] for one 32-row sub-tile `jt` of the LDS tile
-template <int DP8, bool GLDS>
-__device__ __forceinline__ f32x16 score_tile(const float* Ys, const float (&xr)[DP8][4], int jt, int r, int h) {
-  using TM = TileMap<DP8, GLDS>;
-  f32x16 acc;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  const int row = jt * 32 + r;
-  // A-operand reads run one k-group ahead of the MFMAs (register double buffer); the
-  // scheduling barrier stops the compiler from hoisting all DP8 reads (64 VGPRs at D=128)
-  float4 y[2];
-  y[0] = *reinterpret_cast<const float4*>(Ys + TM::chunk(row, h));
-#pragma unroll
-  for (int g = 0; g < DP8; ++g) {
-    if (g + 1 < DP8) y[(g + 1) & 1] = *reinterpret_cast<const float4*>(Ys + TM::chunk(row, 2 * (g + 1) + h));
-    const float4 v = y[g & 1];
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, xr[g][0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, xr[g][1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, xr[g][2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, xr[g][3], acc, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  return acc;
-}
-
-__device__ __forceinline__ int brow(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
-
 // ------------------------------------------------------------------ forward
 // Streams tile t+1 while tile t is on the MFMA pipe.  GLDS: DMA issued at the top of the
 // iteration, drained (vmcnt(0)) right before the barrier that ends it.
-template <int DP8, bool GLDS>
-struct Stager {
-  float4 st[GLDS ? 1 : (DP8 + 1) / 2];
-  __device__ __forceinline__ void issue(const float* Y, int64_t ld, int64_t row0, int64_t nrows, int64_t D, bool vec,
-                                        float* dst, int wave, int lane) {
-    if constexpr (GLDS) tile_dma<DP8>(Y, ld, row0, nrows, dst, wave, lane);
-    else tile_fetch<DP8>(st, Y, ld, row0, nrows, D, vec);
-  }
-  __device__ __forceinline__ void land(float* dst) {
-    if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else tile_commit<DP8>(st, dst);
-  }
-};
-
 template <int DP8, bool GLDS>
 __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_kernel(const CeArgs p) {
   using TM = TileMap<DP8, GLDS>;
