@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--workload", default="P", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--negatives", default="global", choices=["global", "local"])
+    ap.add_argument("--overlap", default="zero_grad", choices=["forward", "zero_grad", "off"],
+                    help="when DenseExactAdam starts the table sweep (optim.py); all three are bit-identical")
     ap.add_argument("--sharded", action="store_true", help="use the row-sharded trainer even at --gpus 1")
     args = ap.parse_args()
 
@@ -144,6 +146,7 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     cfg = dict(WORKLOADS[args.workload])
+    args.overlap = {"forward": "forward", "zero_grad": True, "off": False}[args.overlap]
 
     import two_tower_models_amd as A
     from two_tower_models_amd import _native as N
@@ -161,7 +164,7 @@ def main():
         batches = trainer.make_batches(16)
     else:
         model = build_model(cfg, device)
-        opt = A.DenseExactAdam(model.parameters(), lr=1e-3)
+        opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep=args.overlap)
         batches = make_batches(cfg, 16, device)
         total_loss = torch.zeros((), device=device)
 

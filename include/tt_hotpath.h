@@ -93,8 +93,9 @@ int tt_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out,
 
 /* ---------------------------------------------------------------- K5 in-batch softmax CE
  * Forward: S = U I^T is never written to memory.
- *   row_lse[i] = logsumexp_j S[i,j]          (j over the N item rows)
- *   row_ce[i]  = row_lse[i] - S[i, i+diag_offset]
+ *   row_lse[i] = log2 sum_j 2^(S[i,j] log2 e)   (= logsumexp_j S[i,j] / ln 2; opaque to the caller,
+ *                                                 saved for tt_inbatch_ce_bwd which works in base 2)
+ *   row_ce[i]  = logsumexp_j S[i,j] - S[i, i+diag_offset]
  * replaces torch.matmul + F.cross_entropy(reduction="none") at
  * ref:src/two_tower_base_retrieval.py:287,301-312.  U is [M,D], I is [N,D];
  * M == N and diag_offset == 0 for the reference; the sharded trainer passes
@@ -171,7 +172,12 @@ int tt_adam_table(float* W, float* M, float* V, int64_t n_rows, int64_t dim, con
 
 /* The same table step in three phases, for the overlapped schedule: the zero-gradient sweep
  * does not depend on this step's gradients, only on the lookups having finished.
- *   tt_adam_table_stash   park the OLD p,m,v of the looked-up rows in `side` (needs the plan)
+ *   tt_adam_table_stash   park the OLD p,m,v of the looked-up rows in `side` (needs the plan);
+ *                         `side` = three planes [n_ids][dim] (p | m | v).  If slot_of != NULL it
+ *                         receives, per lookup occurrence, its slot in those planes (-1 for a
+ *                         sentinel row): the forward can then gather the old rows from the p
+ *                         plane (tt_gather_rows(side, n_ids, dim, slot_of, ...)) while the sweep
+ *                         is already rewriting the table
  *   tt_adam_table_sweep   every row, gradient = 0 -- run it on a SECOND stream, concurrently
  *                         with the backward pass (HBM-bound vs MFMA/latency-bound)
  *   tt_adam_table_finish  Adam on the looked-up rows from `side` + their summed gradients,
@@ -179,8 +185,9 @@ int tt_adam_table(float* W, float* M, float* V, int64_t n_rows, int64_t dim, con
  * stash -> sweep -> finish leaves bit-identical results to tt_adam_table.  `side` needs
  * tt_adam_table_workspace_bytes(n_ids, dim) and must survive from stash to finish. */
 int tt_adam_table_stash(const float* W, const float* M, const float* V, int64_t n_rows, int64_t dim,
-                        int64_t n_ids, const int32_t* sorted_ids, const int32_t* seg_begin,
-                        const int32_t* n_unique, void* side, int64_t side_bytes, tt_stream_t stream);
+                        int64_t n_ids, const int32_t* sorted_ids, const int32_t* perm,
+                        const int32_t* seg_begin, const int32_t* n_unique, void* side, int64_t side_bytes,
+                        int64_t* slot_of, tt_stream_t stream);
 int tt_adam_table_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
                         tt_stream_t stream);
 int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,

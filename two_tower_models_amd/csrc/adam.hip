@@ -22,6 +22,7 @@ namespace tt {
 
 constexpr int SWEEP_DEFAULT_VARIANT = 0;
 constexpr int SWEEP_DEFAULT_BPC = 8;
+constexpr int SWEEP_DEFAULT_LDS_KB = 0;
 
 struct AdamConst {
   float one_minus_b1, b2, one_minus_b2, eps, neg_step_size, bc2_sqrt;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void adam_touched_kernel(const float* __restri
                                                            const int32_t* __restrict__ perm,
                                                            const int32_t* __restrict__ seg_begin,
                                                            const int32_t* __restrict__ n_unique,
-                                                           float* __restrict__ side) {
+                                                           float* __restrict__ side, int64_t cap) {
   const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (u >= *n_unique) return;
   const int lane = threadIdx.x & 63;
@@ -85,17 +86,20 @@ __global__ __launch_bounds__(256) void adam_touched_kernel(const float* __restri
   const int32_t t0 = seg_begin[u], t1 = seg_begin[u + 1];
   const int64_t row = sorted_ids[t0];
   if (row >= n_rows) return;  // sentinel run: ids that belong to another rank's block
-  float* out = side + u * 3 * dim;
+  // side buffer = three planes [cap][dim]: p | m | v  (the p plane doubles as a gather source)
+  float* sp = side + u * dim;
+  float* sm = sp + cap * dim;
+  float* sv = sm + cap * dim;
   for (int64_t d = lane; d < dim; d += 64) {
     float g = 0.f;
     for (int32_t t = t0; t < t1; ++t) g += source_row(src, perm[t])[d];
     float p, m, v;
-    if constexpr (FROM_SIDE) { p = out[d]; m = out[dim + d]; v = out[2 * dim + d]; }
+    if constexpr (FROM_SIDE) { p = sp[d]; m = sm[d]; v = sv[d]; }
     else { p = W[row * dim + d]; m = M[row * dim + d]; v = V[row * dim + d]; }
     adam_elem(p, m, v, g, c);
-    out[d] = p;
-    out[dim + d] = m;
-    out[2 * dim + d] = v;
+    sp[d] = p;
+    sm[d] = m;
+    sv[d] = v;
   }
 }
 
@@ -103,18 +107,27 @@ __global__ __launch_bounds__(256) void adam_stash_kernel(const float* __restrict
                                                          const float* __restrict__ V, int64_t n_rows, int64_t dim,
                                                          const int32_t* __restrict__ sorted_ids,
                                                          const int32_t* __restrict__ seg_begin,
+                                                         const int32_t* __restrict__ perm,
                                                          const int32_t* __restrict__ n_unique,
-                                                         float* __restrict__ side) {
+                                                         float* __restrict__ side, int64_t cap,
+                                                         int64_t* __restrict__ slot_of) {
   const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (u >= *n_unique) return;
   const int lane = threadIdx.x & 63;
-  const int64_t row = sorted_ids[seg_begin[u]];
+  const int32_t t0 = seg_begin[u], t1 = seg_begin[u + 1];
+  const int64_t row = sorted_ids[t0];
+  // slot_of[i] = stash slot of lookup occurrence i, so the forward can gather the OLD row from
+  // the p plane after the sweep has started rewriting the table (sentinel runs get slot -1)
+  if (slot_of)
+    for (int32_t t = t0 + lane; t < t1; t += 64) slot_of[perm[t]] = (row < n_rows) ? u : -1;
   if (row >= n_rows) return;
-  float* out = side + u * 3 * dim;
+  float* sp = side + u * dim;
+  float* sm = sp + cap * dim;
+  float* sv = sm + cap * dim;
   for (int64_t d = lane; d < dim; d += 64) {
-    out[d] = W[row * dim + d];
-    out[dim + d] = M[row * dim + d];
-    out[2 * dim + d] = V[row * dim + d];
+    sp[d] = W[row * dim + d];
+    sm[d] = M[row * dim + d];
+    sv[d] = V[row * dim + d];
   }
 }
 
@@ -123,17 +136,19 @@ __global__ __launch_bounds__(256) void adam_writeback_kernel(float* __restrict__
                                                              const int32_t* __restrict__ sorted_ids,
                                                              const int32_t* __restrict__ seg_begin,
                                                              const int32_t* __restrict__ n_unique,
-                                                             const float* __restrict__ side) {
+                                                             const float* __restrict__ side, int64_t cap) {
   const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (u >= *n_unique) return;
   const int lane = threadIdx.x & 63;
   const int64_t row = sorted_ids[seg_begin[u]];
   if (row >= n_rows) return;
-  const float* in = side + u * 3 * dim;
+  const float* sp = side + u * dim;
+  const float* sm = sp + cap * dim;
+  const float* sv = sm + cap * dim;
   for (int64_t d = lane; d < dim; d += 64) {
-    W[row * dim + d] = in[d];
-    M[row * dim + d] = in[dim + d];
-    V[row * dim + d] = in[2 * dim + d];
+    W[row * dim + d] = sp[d];
+    M[row * dim + d] = sm[d];
+    V[row * dim + d] = sv[d];
   }
 }
 
@@ -286,7 +301,13 @@ static int launch_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t di
     ProfScope prof("adam_sweep_kernel", st);
     static const bool no_bounded = getenv("TT_SWEEP_NO_BOUNDED") != nullptr;
     if (bounded && !no_bounded) {
-      adam_sweep_bounded_kernel<<<(unsigned)ceil_div(n4, 256 * SWEEP_ITERS), 256, 0, st>>>(w4, m4, v4, n4, hyper);
+      // Static CU partitioning through LDS: the sweep needs no LDS, but reserving some per
+      // workgroup caps how many of them fit on a CU (160 KiB / reservation), which leaves LDS,
+      // wave slots and registers for the backward pass's big workgroups (64 KiB LDS, 256 VGPRs)
+      // that would otherwise never find room between the constantly refilling sweep blocks.
+      // 4 sweep workgroups per CU already saturate HBM (tools/bench_sweep.py).
+      static const int lds_kb = getenv("TT_SWEEP_LDS_KB") ? atoi(getenv("TT_SWEEP_LDS_KB")) : SWEEP_DEFAULT_LDS_KB;
+      adam_sweep_bounded_kernel<<<(unsigned)ceil_div(n4, 256 * SWEEP_ITERS), 256, (size_t)lds_kb * 1024, st>>>(w4, m4, v4, n4, hyper);
     } else
     switch (variant & 3) {
       case 0: adam_sweep_kernel<false, 1><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
@@ -332,12 +353,12 @@ extern "C" int tt_adam_table(float* W, float* M, float* V, int64_t n_rows, int64
     if (!sorted_ids || !perm || !seg_begin || !n_unique || !ws) return fail_arg("tt_adam_table: null plan");
     if (!check_sources(src, n_ids, dim)) return fail_arg("tt_adam_table: gradient sources");
     if (ws_bytes < tt_adam_table_workspace_bytes(n_ids, dim)) { set_error("tt_adam_table: workspace"); return TT_E_WORKSPACE; }
-    adam_touched_kernel<false><<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, reinterpret_cast<float*>(ws));
+    adam_touched_kernel<false><<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, reinterpret_cast<float*>(ws), n_ids);
     if ((rc = check_launch("adam_touched_kernel"))) return rc;
   }
   if ((rc = launch_sweep(W, M, V, n_rows, dim, hyper, st))) return rc;
   if (n_ids > 0) {
-    adam_writeback_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, sorted_ids, seg_begin, n_unique, reinterpret_cast<const float*>(ws));
+    adam_writeback_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, sorted_ids, seg_begin, n_unique, reinterpret_cast<const float*>(ws), n_ids);
     if ((rc = check_launch("adam_writeback_kernel"))) return rc;
   }
   return 0;
@@ -346,12 +367,13 @@ extern "C" int tt_adam_table(float* W, float* M, float* V, int64_t n_rows, int64
 // ---- the same table step in three phases, so the sweep can run on its own stream while
 // the backward pass is still producing the row gradients (DESIGN.md "overlap")
 extern "C" int tt_adam_table_stash(const float* W, const float* M, const float* V, int64_t n_rows, int64_t dim,
-                                   int64_t n_ids, const int32_t* sorted_ids, const int32_t* seg_begin,
-                                   const int32_t* n_unique, void* side, int64_t side_bytes, tt_stream_t stream) {
-  if (!W || !M || !V || !sorted_ids || !seg_begin || !n_unique || !side) return fail_arg("tt_adam_table_stash: null pointer");
+                                   int64_t n_ids, const int32_t* sorted_ids, const int32_t* perm,
+                                   const int32_t* seg_begin, const int32_t* n_unique, void* side,
+                                   int64_t side_bytes, int64_t* slot_of, tt_stream_t stream) {
+  if (!W || !M || !V || !sorted_ids || !perm || !seg_begin || !n_unique || !side) return fail_arg("tt_adam_table_stash: null pointer");
   if (n_rows <= 0 || dim <= 0 || n_ids <= 0) return fail_arg("tt_adam_table_stash: sizes");
   if (side_bytes < tt_adam_table_workspace_bytes(n_ids, dim)) { set_error("tt_adam_table_stash: side buffer"); return TT_E_WORKSPACE; }
-  adam_stash_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, S(stream)>>>(W, M, V, n_rows, dim, sorted_ids, seg_begin, n_unique, reinterpret_cast<float*>(side));
+  adam_stash_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, S(stream)>>>(W, M, V, n_rows, dim, sorted_ids, seg_begin, perm, n_unique, reinterpret_cast<float*>(side), n_ids, slot_of);
   return check_launch("adam_stash_kernel");
 }
 
@@ -393,10 +415,10 @@ extern "C" int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows
   if (side_bytes < tt_adam_table_workspace_bytes(n_ids, dim)) { set_error("tt_adam_table_finish: side buffer"); return TT_E_WORKSPACE; }
   hipStream_t st = S(stream);
   float* sd = reinterpret_cast<float*>(side);
-  adam_touched_kernel<true><<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, sd);
+  adam_touched_kernel<true><<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, sd, n_ids);
   int rc = check_launch("adam_touched_kernel");
   if (rc) return rc;
-  adam_writeback_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, sorted_ids, seg_begin, n_unique, sd);
+  adam_writeback_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, sorted_ids, seg_begin, n_unique, sd, n_ids);
   return check_launch("adam_writeback_kernel");
 }
 

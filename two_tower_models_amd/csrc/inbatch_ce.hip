@@ -49,7 +49,7 @@ struct CeArgs {
   float* part_s;
   float* diag;
   // backward inputs / outputs
-  const float* lse;   // natural-log row LSE, indexed by USER row
+  const float* lse;   // row LSE in the log2 domain (as written by the forward), indexed by USER row
   const float* coef;  // dLoss/d row_ce, indexed by USER row
   float* out;         // [splits][RX][D] slabs (or final [RX, ldo] when splits == 1)
   int64_t ldo;
@@ -102,8 +102,9 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_kern
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int li = jt * 32 + (e & 3) + 8 * (e >> 2);  // tile-local row, minus the 4h lane term
-        if (li == want4) { dg = acc[e]; has_dg = true; }
-        v2[e] = (li < lim4) ? acc[e] * LOG2E : NEG_BIG;
+        const float s2 = acc[e] * LOG2E;  // logits are handled in the log2 domain throughout
+        if (li == want4) { dg = s2; has_dg = true; }
+        v2[e] = (li < lim4) ? s2 : NEG_BIG;
         tmax = fmaxf(tmax, v2[e]);
       }
       const float mn = fmaxf(m, tmax);
@@ -137,9 +138,11 @@ __global__ void ce_fwd_finish_kernel(const float* __restrict__ part_m, const flo
   for (int z = 0; z < splits; ++z) mx = fmaxf(mx, part_m[(int64_t)z * M + i]);
   float s = 0.f;
   for (int z = 0; z < splits; ++z) s += part_s[(int64_t)z * M + i] * exp2f(part_m[(int64_t)z * M + i] - mx);
-  const float lse = (mx + log2f(s)) * LN2;
-  row_lse[i] = lse;
-  row_ce[i] = lse - diag[i];
+  // row_lse stays in the log2 domain (it is only ever consumed by the backward kernels, which work
+  // there too): no ln2 / log2e round trip, and a 1-column row gives exactly p = 1, ce = 0
+  const float lse2 = mx + log2f(s);
+  row_lse[i] = lse2;
+  row_ce[i] = (lse2 - diag[i]) * LN2;
 }
 
 // ------------------------------------------------------------------ backward
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_bwd_kern
   load_stationary<DP8>(xr, p.X, p.ldx, a, p.RX, p.D, h, p.x_vec);
 
   float lse2_a = 0.f, coef_a = 0.f;
-  if (!STREAM_STATS && a < p.RX) { lse2_a = p.lse[a] * LOG2E; coef_a = p.coef[a]; }
+  if (!STREAM_STATS && a < p.RX) { lse2_a = p.lse[a]; coef_a = p.coef[a]; }
 
   const int64_t ntiles_all = (p.RY + BJ - 1) / BJ;
   const int64_t t0 = (int64_t)blockIdx.y * p.tiles_per_split;
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_bwd_kern
     stg.issue(p.Y, p.ldy, t * BJ, p.RY, p.D, p.y_vec, dst, wave, lane);
     if (STREAM_STATS && threadIdx.x < BJ) {
       const int64_t b = t * BJ + threadIdx.x;
-      st_lse = (b < p.RY) ? p.lse[b] * LOG2E : 3.0e38f;
+      st_lse = (b < p.RY) ? p.lse[b] : 3.0e38f;
       st_coef = (b < p.RY) ? p.coef[b] : 0.f;
     }
   };
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_bwd_kern
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int li = jt * 32 + (e & 3) + 8 * (e >> 2);
-          const float pr = fast_exp2(fmaf(acc[e], LOG2E, -lse2_a));
+          const float pr = fast_exp2(mul_rounded(acc[e], LOG2E) - lse2_a);  // same rounded s2 as the forward
           const float gval = coef_a * (pr - ((li == want4) ? 1.f : 0.f));
           gt[e] = (li < lim4) ? gval : 0.f;
         }
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_bwd_kern
           for (int c = 0; c < 4; ++c) {
             const int e = 4 * q + c;
             const int li = jt * 32 + (e & 3) + 8 * (e >> 2);
-            const float pr = fast_exp2(fmaf(acc[e], LOG2E, -lv[c]));
+            const float pr = fast_exp2(mul_rounded(acc[e], LOG2E) - lv[c]);
             gt[e] = cv[c] * (pr - ((li == want4) ? 1.f : 0.f));  // coef 0 beyond RY
           }
         }

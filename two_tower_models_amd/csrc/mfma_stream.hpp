@@ -16,6 +16,13 @@ constexpr float NEG_BIG = -3.0e38f;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// a * b rounded to fp32 on its own: never contracted into a following add (hipcc defaults to
+// -ffp-contract=fast, and __fmul_rn is a plain multiply there)
+__device__ __forceinline__ float mul_rounded(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+
 // this wave's 32 stationary rows -> B-operand fragments: xr[g][c] = X[a][8g + 4h + c]
 template <int DP8>
 __device__ __forceinline__ void load_stationary(float (&xr)[DP8][4], const float* __restrict__ X,

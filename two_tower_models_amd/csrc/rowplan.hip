@@ -120,7 +120,6 @@ __global__ __launch_bounds__(256) void seg_count_kernel(const int32_t* __restric
     const int64_t i = base + k * 256 + threadIdx.x;
     if (i < n) c += (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
   }
-  float dummy = 0.f; (void)dummy;
   int32_t w = c;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);

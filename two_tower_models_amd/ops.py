@@ -154,6 +154,34 @@ def register_lookup(weight: torch.Tensor, ids: torch.Tensor) -> Optional[int]:
     return len(reg) - 1
 
 
+class ActiveStash:
+    """The optimiser's parked copy of the rows a forward is about to look up (old values), plus
+    for every lookup occurrence its slot in that copy.  While it is attached to a table
+    (`weight._tt_active`), lookups gather from here: the zero-gradient sweep may already be
+    rewriting the table itself."""
+
+    def __init__(self, p_plane: torch.Tensor, slots: torch.Tensor, block_sizes: Sequence[int]):
+        self.p_plane, self.slots = p_plane, slots
+        self.offsets = [0]
+        for n in block_sizes:
+            self.offsets.append(self.offsets[-1] + n)
+
+    def slots_for(self, index: int, n: int) -> torch.Tensor:
+        if index + 1 >= len(self.offsets) or self.offsets[index + 1] - self.offsets[index] != n:
+            raise RuntimeError("forward performed a lookup the optimiser was not told about (begin_step mismatch)")
+        return self.slots[self.offsets[index]: self.offsets[index + 1]]
+
+
+def lookup_source(weight: torch.Tensor, ids: torch.Tensor, recording: bool):
+    """-> (rows_table [n, D], row_ids int64 [numel], lookup_index).  Registers the lookup with the
+    table's optimiser when the forward is being recorded."""
+    idx = register_lookup(weight, ids) if recording else None
+    act = getattr(weight, "_tt_active", None)
+    if act is not None and idx is not None:
+        return act.p_plane, act.slots_for(idx, ids.numel()), idx
+    return weight, ids.reshape(-1), idx
+
+
 def dense_grad_from_rows(blocks: Sequence[RowGrad], n_rows: int, dim: int) -> torch.Tensor:
     """The dense [n_rows, dim] embedding gradient torch.optim expects."""
     dev = blocks[0].ids.device
@@ -184,9 +212,9 @@ class EmbeddingLookup(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
         out = torch.empty(ids.numel(), weight.shape[1], dtype=torch.float32, device=weight.device)
-        gather_rows_into(weight, ids.reshape(-1), out)
+        src, row_ids, ctx.lookup_index = lookup_source(weight, ids, ctx.needs_input_grad[0])
+        gather_rows_into(src, row_ids, out)
         ctx.weight = weight
-        ctx.lookup_index = register_lookup(weight, ids) if ctx.needs_input_grad[0] else None
         ctx.save_for_backward(ids)
         return out.view(*ids.shape, weight.shape[1])
 
@@ -278,8 +306,8 @@ class TowerInput(torch.autograd.Function):
         Dm = W2.shape[0]
         Hd = W1.shape[0]
         tin = torch.empty(B, D + Dm, dtype=torch.float32, device=dev)
-        gather_rows_into(weight, ids.reshape(-1), tin[:, :D])
-        ctx.lookup_index = register_lookup(weight, ids) if ctx.needs_input_grad[0] else None
+        src, row_ids, ctx.lookup_index = lookup_source(weight, ids, ctx.needs_input_grad[0])
+        gather_rows_into(src, row_ids, tin[:, :D])
         h = torch.empty(B, Hd, dtype=torch.float32, device=dev)
         gemm(N.TT_GEMM_NT, feats, W1, h, B, Hd, F, bias=b1, epilogue=N.TT_EPI_RELU)
         gemm(N.TT_GEMM_NT, h, W2, tin[:, D:], B, Dm, Hd, bias=b2)
@@ -399,11 +427,14 @@ class HistoryEncoder(torch.autograd.Function):
         dev = N.require_device(source, ids, pe, *layer_params)
         L = len(layer_params) // 4
         lib = N.load()
+        ctx.lookup_index = None
         if ids is not None:
             ids = ids.contiguous()
             B, H = ids.shape
-            n_rows, D = source.shape
-            src = source
+            D = source.shape[1]
+            src, row_ids, ctx.lookup_index = lookup_source(source, ids, ctx.needs_input_grad[0])
+            n_rows = src.shape[0]
+            gather_ids = row_ids.reshape(B, H)
         else:
             src = source.contiguous()
             B, H, D = src.shape
@@ -411,7 +442,8 @@ class HistoryEncoder(torch.autograd.Function):
         out = torch.empty(B, 2, D, dtype=torch.float32, device=dev)
         x = torch.empty(B * H, D, dtype=torch.float32, device=dev)
         pooled = out[:, 1, :]
-        N.check(lib.tt_hist_embed_pool(src.data_ptr(), n_rows, D, N.ptr(ids), B, H, N.ptr(pe), x.data_ptr(),
+        N.check(lib.tt_hist_embed_pool(src.data_ptr(), n_rows, D, N.ptr(gather_ids if ids is not None else None), B, H,
+                                       N.ptr(pe), x.data_ptr(),
                                        pooled.data_ptr(), 2 * D, N.oob.flag(dev).data_ptr(), N.stream()),
                 "tt_hist_embed_pool")
         saved: List[torch.Tensor] = []
@@ -429,7 +461,6 @@ class HistoryEncoder(torch.autograd.Function):
         if L == 0:
             out[:, 0, :].copy_(x.view(B, H, D)[:, 0, :])
         ctx.dims = (B, H, D, L, heads)
-        ctx.lookup_index = register_lookup(source, ids) if (ids is not None and ctx.needs_input_grad[0]) else None
         ctx.table = source if ids is not None else None
         ctx.has_ids = ids is not None
         ctx.save_for_backward(ids, *layer_params, *saved)

@@ -30,11 +30,19 @@ schedule.  Any other call order (zero_grad before forward, no zero_grad at all) 
 takes the serial schedule inside ``step()``.  The one thing the overlapped schedule
 assumes is that a ``zero_grad()`` issued after a forward IS followed by that forward's
 ``backward()`` and ``step()``; pass ``overlap_sweep=False`` if that does not hold.
+
+``overlap_sweep="forward"`` goes one step further: the models' ``train_forward`` announces the
+ids it is about to look up (``begin_step``) BEFORE touching the tables.  The optimiser plans,
+parks the old rows, starts the sweep at once and hands the lookups a view of the parked rows
+(``ops.ActiveStash``), so forward AND backward run under the sweep.  It assumes every
+``train_forward`` executed with autograd enabled is followed by ``backward()`` and ``step()``
+(exactly the reference loop); results are again bit-identical to the serial schedule.
 """
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Iterable, List, Optional
+import weakref
+from typing import Dict, Iterable, List, Optional, Sequence
 
 import torch
 
@@ -45,15 +53,15 @@ from . import ops
 class _TableStep:
     """State of one table between the overlapped begin (in zero_grad) and finish (in step)."""
 
-    __slots__ = ("plan", "side")
+    __slots__ = ("plan", "side", "announced")
 
-    def __init__(self, plan, side):
-        self.plan, self.side = plan, side
+    def __init__(self, plan, side, announced=False):
+        self.plan, self.side, self.announced = plan, side, announced
 
 
 class DenseExactAdam(torch.optim.Optimizer):
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999),
-                 eps: float = 1e-8, overlap_sweep: bool = True) -> None:
+                 eps: float = 1e-8, overlap_sweep=True) -> None:
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
@@ -65,6 +73,10 @@ class DenseExactAdam(torch.optim.Optimizer):
         for p in self._tables:
             p._tt_rowgrads = []  # switches the embedding backward to row form
             p._tt_lookups = []   # the forward's lookups register their ids here
+            p._tt_active = None  # ops.ActiveStash while a "forward"-mode step is under way
+            p._tt_optimizer = weakref.ref(self)
+        if overlap_sweep not in (True, False, "forward"):
+            raise ValueError('overlap_sweep must be True, False or "forward"')
         self.overlap_sweep = overlap_sweep
         self._hyper = None
         self._ready = False
@@ -100,7 +112,10 @@ class DenseExactAdam(torch.optim.Optimizer):
         return buf
 
     # ------------------------------------------------------------------ overlapped begin
-    def _begin_overlapped(self) -> None:
+    def _begin_overlapped(self, announced: Optional[Dict[int, Sequence[torch.Tensor]]] = None) -> None:
+        """Plan + park the old rows on the main stream, then launch the sweep on the side stream.
+        `announced` (forward mode): the id blocks each table WILL be looked up with, in lookup
+        order; otherwise the blocks the forward already registered."""
         lib = N.load()
         if not self._ready:
             self._init_state()
@@ -108,20 +123,25 @@ class DenseExactAdam(torch.optim.Optimizer):
         N.check(lib.tt_adam_advance(hyper, N.stream()), "tt_adam_advance")
         begun: Dict[torch.nn.Parameter, _TableStep] = {}
         for p in self._tables:
-            if not p._tt_lookups:
+            blocks = announced.get(id(p)) if announced is not None else p._tt_lookups
+            if not blocks:
                 continue
             n_rows, dim = p.shape
             st = self.state[p]
-            plan = ops.RowPlan(p._tt_lookups, n_rows, slot=f"plan{id(p)}")
+            plan = ops.RowPlan(blocks, n_rows, slot=f"plan{id(p)}")
             side = self._side(p, lib.tt_adam_table_workspace_bytes(plan.n, dim))
+            slots = torch.empty(plan.n, dtype=torch.int64, device=p.device) if announced is not None else None
             N.check(lib.tt_adam_table_stash(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                            n_rows, dim, plan.n, plan.sorted_ids.data_ptr(),
+                                            n_rows, dim, plan.n, plan.sorted_ids.data_ptr(), plan.perm.data_ptr(),
                                             plan.seg_begin.data_ptr(), plan.n_unique.data_ptr(), side.data_ptr(),
-                                            side.numel(), N.stream()), "tt_adam_table_stash")
-            begun[p] = _TableStep(plan, side)
+                                            side.numel(), N.ptr(slots), N.stream()), "tt_adam_table_stash")
+            begun[p] = _TableStep(plan, side, announced is not None)
+            if announced is not None:
+                p_plane = side[: plan.n * dim * 4].view(torch.float32).view(plan.n, dim)
+                p._tt_active = ops.ActiveStash(p_plane, slots, plan.block_sizes)
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
-        ready.record(main)  # lookups + stashes are complete at this point of the main stream
+        ready.record(main)  # lookups (or none yet, forward mode) + stashes are complete here
         self._side_stream.wait_event(ready)
         for p in begun:
             st = self.state[p]
@@ -131,6 +151,23 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._sweep_done = torch.cuda.Event()
         self._sweep_done.record(self._side_stream)
         self._begun = begun
+
+    def begin_step(self, lookups: Dict[torch.nn.Parameter, Sequence[torch.Tensor]]) -> bool:
+        """Forward-mode entry (called by the models' train_forward before any lookup): announce
+        the id blocks per table, in the order the forward will look them up.  Returns False
+        (and does nothing) unless ``overlap_sweep == "forward"`` applies."""
+        if self.overlap_sweep != "forward" or not torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
+            return False
+        if self._begun is not None:
+            raise RuntimeError('overlap_sweep="forward" supports one train_forward per optimiser step')
+        if not all(p.is_cuda for p in self._tables):
+            return False
+        for p in self._tables:
+            p._tt_lookups.clear()
+            p._tt_rowgrads.clear()
+        mine = {id(p) for p in self._tables}
+        self._begin_overlapped({id(p): [b.reshape(-1) for b in blocks] for p, blocks in lookups.items() if id(p) in mine})
+        return True
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         for p in self._tables:
@@ -196,6 +233,7 @@ class DenseExactAdam(torch.optim.Optimizer):
         for p in self._tables:
             p._tt_lookups.clear()
             p._tt_rowgrads.clear()
+            p._tt_active = None
 
         live = [p for p in self._dense if p.grad is not None]
         if live:

@@ -176,8 +176,8 @@ class HipBackend:
             side = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.device)
             self._sides[key] = side
         N.check(lib.tt_adam_table_stash(W.data_ptr(), M.data_ptr(), V.data_ptr(), n_rows, dim, plan.n,
-                                        plan.sorted_ids.data_ptr(), plan.seg_begin.data_ptr(),
-                                        plan.n_unique.data_ptr(), side.data_ptr(), side.numel(), N.stream()),
+                                        plan.sorted_ids.data_ptr(), plan.perm.data_ptr(), plan.seg_begin.data_ptr(),
+                                        plan.n_unique.data_ptr(), side.data_ptr(), side.numel(), None, N.stream()),
                 "tt_adam_table_stash")
         return plan, side, n_rows
 

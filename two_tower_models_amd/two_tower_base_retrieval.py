@@ -152,6 +152,18 @@ class TwoTowerBaseRetrieval(nn.Module):
         net_user_value = net_user_value / torch.max(net_user_value)
         return torch.mean(row_ce * net_user_value) + additional_loss
 
+    def _lookup_plan(self, user_id, user_history, item_id):
+        """{table: [id blocks in the order this model's forward looks them up]}."""
+        return {self.user_id_embedding_arch.weight: [user_id], self.item_id_embedding_arch.weight: [item_id]}
+
+    def _announce_lookups(self, user_id, user_history, item_id) -> None:
+        """DenseExactAdam(overlap_sweep="forward"): tell the optimiser which rows this step reads
+        so its table sweep can start before the forward's gathers (optim.py)."""
+        ref = getattr(self.item_id_embedding_arch.weight, "_tt_optimizer", None)
+        opt = ref() if ref is not None else None
+        if opt is not None and user_id.is_cuda:
+            opt.begin_step(self._lookup_plan(user_id, user_history, item_id))
+
     def train_forward(
         self,
         user_id: torch.Tensor,  # [B]
@@ -163,6 +175,7 @@ class TwoTowerBaseRetrieval(nn.Module):
         labels: torch.Tensor,  # [B, T]
     ) -> torch.Tensor:
         """Scalar training loss with an autograd graph (ref :349-394)."""
+        self._announce_lookups(user_id, user_history, item_id)
         user_embedding = self.compute_user_embedding(user_id, user_features, user_history)
         item_embeddings = self.compute_item_embeddings(item_id, item_features)
         return self.compute_training_loss(

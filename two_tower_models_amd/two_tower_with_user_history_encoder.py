@@ -63,3 +63,8 @@ class TwoTowerWithUserHistoryEncoder(TwoTowerBaseRetrieval):
         summary = summary.view(summary.shape[0], -1)
         base = super().process_user_features(user_id=user_id, user_features=user_features, user_history=user_history)
         return torch.cat([base, summary], dim=1)
+
+    def _lookup_plan(self, user_id, user_history, item_id):
+        # forward order: history rows (encoder), then the user row, then the item row
+        return {self.user_id_embedding_arch.weight: [user_id],
+                self.item_id_embedding_arch.weight: [user_history, item_id]}
