@@ -143,7 +143,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    device = torch.device(f"cuda:{local_rank}")
+    # TT_BENCH_DIST_BACKEND=gloo: test hook -- all ranks share cuda:0 and exchange through gloo (RCCL
+    # refuses two ranks on one device), so the N > 1 code path can be exercised on a 1-GPU box.
+    dist_backend = os.environ.get("TT_BENCH_DIST_BACKEND", "nccl")
+    device = torch.device(f"cuda:{local_rank if dist_backend == 'nccl' else 0}")
     torch.cuda.set_device(device)
     cfg = dict(WORKLOADS[args.workload])
     args.overlap = {"forward": "forward", "zero_grad": True, "off": False}[args.overlap]
@@ -158,7 +161,10 @@ def main():
         from two_tower_models_amd import sharded
         if "MASTER_ADDR" not in os.environ:  # plain `python bench.py --sharded`
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=device)
+        if dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(dist_backend)
         trainer = sharded.ShardedTrainer(cfg, device, negatives=args.negatives)
         step = trainer.step
         batches = trainer.make_batches(16)
@@ -191,7 +197,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        sharded.all_reduce_(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
 
     import ctypes as C
@@ -227,7 +233,8 @@ def main():
                                    + (f", H={cfg['H']} history encoder" if cfg['model'] == 'hist' else ""),
                        "global_batch": B * world,
                        "parallelism": "single GPU" if not use_sharded else
-                       f"row-sharded tables x{world}, {args.negatives} in-batch negatives, RCCL"},
+                       f"row-sharded tables x{world}, {args.negatives} in-batch negatives, "
+                       + ("RCCL" if dist_backend == "nccl" else dist_backend)},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

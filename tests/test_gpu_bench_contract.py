@@ -1,0 +1,59 @@
+"""bench.py's output contract, at a tiny workload: ONE JSON line, last on stdout, carrying the
+driver's keys plus `roofline` and `cpu_baseline`; and the N > 1 launch path
+(`python -m torch.distributed.run ... bench.py --gpus N`) end to end.  The 2-rank run shares
+the single GPU of the test box through bench.py's gloo test hook; under RCCL on an N-GPU node the
+same code runs with one rank per device."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _last_json(stdout: str):
+    lines = [l for l in stdout.strip().splitlines() if l.strip()]
+    return json.loads(lines[-1])  # the contract: the JSON line is the LAST line
+
+
+def test_single_gpu_line():
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "tiny", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                       stdin=subprocess.DEVNULL)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _last_json(r.stdout)
+    assert KEYS <= set(out), KEYS - set(out)
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1 and out["vs_baseline"] is None
+    assert out["value"] > 0 and abs(out["value"] - 128 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    roof = out["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["launches"] == 2 * 3
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert "workload" in out["config"] and "model" not in out["config"]
+
+
+def test_two_rank_launch_line():
+    env = dict(os.environ, TT_BENCH_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2",
+                        "--workload", "tiny", "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900, stdin=subprocess.DEVNULL)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json(r.stdout)
+    assert KEYS <= set(out)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 256 and out["scaling"] == "weak"
+    assert out["cpu_baseline"] is None  # rank 0 at N = 1 only
+    assert out["value"] > 0 and out["roofline"]["launches"] == 2 * 3

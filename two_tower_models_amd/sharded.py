@@ -48,22 +48,62 @@ def _is_gloo() -> bool:
     return dist.get_backend() == "gloo"
 
 
+def _host_staged(x: torch.Tensor) -> bool:
+    """gloo moves host memory only.  Device tensors under gloo (several ranks sharing ONE GPU, used
+    by tests/test_gpu_sharded.py to run the HIP backend at world size > 1 on a 1-GPU box) are
+    staged through the host; under RCCL nothing is staged."""
+    return _is_gloo() and x.device.type != "cpu"
+
+
 def all_gather_rows(x: torch.Tensor) -> torch.Tensor:
+    if _host_staged(x):
+        return all_gather_rows(x.cpu()).to(x.device)
     out = x.new_empty((dist.get_world_size() * x.shape[0],) + tuple(x.shape[1:]))
     dist.all_gather_into_tensor(out, x.contiguous())
     return out
 
 
 def reduce_scatter_rows(x: torch.Tensor) -> torch.Tensor:
+    if _host_staged(x):
+        return reduce_scatter_rows(x.cpu()).to(x.device)
     W = dist.get_world_size()
     out = x.new_empty((x.shape[0] // W,) + tuple(x.shape[1:]))
-    if _is_gloo():  # gloo has no reduce_scatter: all_reduce + slice (CPU tests only)
+    if _is_gloo():  # gloo has no reduce_scatter: all_reduce + slice (tests only)
         y = x.clone()
         dist.all_reduce(y)
         r = dist.get_rank()
         out.copy_(y[r * out.shape[0]:(r + 1) * out.shape[0]])
     else:
         dist.reduce_scatter_tensor(out, x.contiguous())
+    return out
+
+
+def all_reduce_(x: torch.Tensor, op=dist.ReduceOp.SUM) -> torch.Tensor:
+    if _host_staged(x):
+        h = x.cpu()
+        dist.all_reduce(h, op=op)
+        x.copy_(h)
+    else:
+        dist.all_reduce(x, op=op)
+    return x
+
+
+def broadcast_(x: torch.Tensor, src: int) -> torch.Tensor:
+    if _host_staged(x):
+        h = x.cpu()
+        dist.broadcast(h, src=src)
+        x.copy_(h)
+    else:
+        dist.broadcast(x, src=src)
+    return x
+
+
+def all_to_all_rows(x: torch.Tensor) -> torch.Tensor:
+    """Chunk r of `x` (equal chunks along dim 0) goes to rank r."""
+    if _host_staged(x):
+        return all_to_all_rows(x.cpu()).to(x.device)
+    out = torch.empty_like(x)
+    dist.all_to_all_single(out, x.contiguous())
     return out
 
 
@@ -292,7 +332,7 @@ class ShardedTrainer:
                 bound = 1.0 / math.sqrt(shape[1])
                 self.params[name].copy_(((torch.rand(shape, generator=gen) * 2 - 1) * bound).to(device))
             off += n
-        dist.broadcast(self.flat_p, src=0)  # replicas must start bit-identical
+        broadcast_(self.flat_p, src=0)  # replicas must start bit-identical
         self.hyper = self.be.new_hyper(lr, betas, eps)
         self.last_loss = torch.zeros((), dtype=torch.float32, device=device)
 
@@ -377,12 +417,12 @@ class ShardedTrainer:
         nuv = torch.clamp(torch.sum(labels * self.uvw, dim=-1), min=0.000001)
         nmax = nuv.max()
         if glob:
-            dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
+            all_reduce_(nmax, op=dist.ReduceOp.MAX)
         w = nuv / nmax
         denom = float(B * W)  # global negatives: mean over W*B rows; local: mean of W per-rank means
         coef = (w / denom).contiguous()
         loss = (ce * w).sum() / denom
-        dist.all_reduce(loss)
+        all_reduce_(loss)
         self.last_loss = loss
         # 4. backward through the loss
         dU, dI_all = be.ce_bwd(U, I_all, off, lse, coef)
@@ -391,7 +431,7 @@ class ShardedTrainer:
         d_urows = be.tower_bwd(dU, u_emb, u_h, u_f, user_feat, pu, self._tower_grads("user"))
         d_irows = be.tower_bwd(dI, i_emb, i_h, i_f, item_feat, pi, self._tower_grads("item"))
         if W > 1:
-            dist.all_reduce(self.flat_g)
+            all_reduce_(self.flat_g)
         g_u = all_gather_rows(d_urows) if W > 1 else d_urows  # aligned with lk_u.local
         g_i = all_gather_rows(d_irows) if W > 1 else d_irows
         # 6. dense-exact Adam: the looked-up rows of this rank's blocks, over the swept tables
@@ -439,9 +479,7 @@ class ShardedMIPS:
             idx = torch.cat([idx, idx.new_full((idx.shape[0], pad), -1)], dim=1)
             sc = torch.cat([sc, sc.new_zeros((sc.shape[0], pad))], dim=1)
         if W > 1:
-            ridx, rsc = torch.empty_like(idx), torch.empty_like(sc)
-            dist.all_to_all_single(ridx, idx.contiguous())  # chunk r of the send = rank r's queries
-            dist.all_to_all_single(rsc, sc.contiguous())
+            ridx, rsc = all_to_all_rows(idx), all_to_all_rows(sc)  # chunk r of the send = rank r's queries
             # received layout [W (source shard), B, k] -> per own query the W*k candidates
             idx = ridx.view(W, B, k).permute(1, 0, 2).reshape(B, W * k)
             sc = rsc.view(W, B, k).permute(1, 0, 2).reshape(B, W * k)
