@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--workload", default="P", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--negatives", default="global", choices=["global", "local"])
-    ap.add_argument("--overlap", default="zero_grad", choices=["forward", "zero_grad", "off"],
+    ap.add_argument("--overlap", default="forward", choices=["forward", "zero_grad", "off"],
                     help="when DenseExactAdam starts the table sweep (optim.py); all three are bit-identical")
     ap.add_argument("--sharded", action="store_true", help="use the row-sharded trainer even at --gpus 1")
     args = ap.parse_args()

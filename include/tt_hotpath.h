@@ -160,8 +160,8 @@ int tt_rowgrad_dense(const tt_grad_sources* src /*host*/, int64_t n_ids, int64_t
 /* Adam hyper-parameters + step live in DEVICE memory (8 doubles) so that a
  * captured hipGraph replays with a moving step count:
  *   [0] lr [1] beta1 [2] beta2 [3] eps [4] step [5] lr/(1-beta1^step)
- *   [6] sqrt(1-beta2^step) [7] reserved.   tt_adam_advance bumps [4] and
- * recomputes [5],[6] in double, as torch.optim.Adam does on the host. */
+ *   [6] sqrt(1-beta2^step) [7] library scratch (the sweep's chunk counters; initialise to 0).
+ * tt_adam_advance bumps [4] and recomputes [5],[6] in double, as torch.optim.Adam does on the host. */
 int tt_adam_advance(double* hyper, tt_stream_t stream);
 
 int64_t tt_adam_table_workspace_bytes(int64_t n_ids, int64_t dim);
@@ -172,12 +172,14 @@ int tt_adam_table(float* W, float* M, float* V, int64_t n_rows, int64_t dim, con
 
 /* The same table step in three phases, for the overlapped schedule: the zero-gradient sweep
  * does not depend on this step's gradients, only on the lookups having finished.
- *   tt_adam_table_stash   park the OLD p,m,v of the looked-up rows in `side` (needs the plan);
- *                         `side` = three planes [n_ids][dim] (p | m | v).  If slot_of != NULL it
- *                         receives, per lookup occurrence, its slot in those planes (-1 for a
- *                         sentinel row): the forward can then gather the old rows from the p
- *                         plane (tt_gather_rows(side, n_ids, dim, slot_of, ...)) while the sweep
- *                         is already rewriting the table
+ *   tt_adam_table_stash   park the OLD p,m,v of the looked-up rows in `side` (needs the plan; one
+ *                         copy per unique row).  `side` = three planes [n_ids][dim] (p | m | v);
+ *                         a row's slot is the position of its FIRST occurrence in the id list
+ *   tt_adam_table_stash_ids  the same from the raw id list, no plan needed: occurrence i parks
+ *                         row ids[i] in slot i (ids outside [0, n_rows) park zeros).  The sweep
+ *                         can then start before the ids are sorted, and the p plane IS the
+ *                         lookup result of the step's forward (rows in id-list order), which
+ *                         must read it instead of the table the sweep is rewriting
  *   tt_adam_table_sweep   every row, gradient = 0 -- run it on a SECOND stream, concurrently
  *                         with the backward pass (HBM-bound vs MFMA/latency-bound)
  *   tt_adam_table_finish  Adam on the looked-up rows from `side` + their summed gradients,
@@ -187,7 +189,10 @@ int tt_adam_table(float* W, float* M, float* V, int64_t n_rows, int64_t dim, con
 int tt_adam_table_stash(const float* W, const float* M, const float* V, int64_t n_rows, int64_t dim,
                         int64_t n_ids, const int32_t* sorted_ids, const int32_t* perm,
                         const int32_t* seg_begin, const int32_t* n_unique, void* side, int64_t side_bytes,
-                        int64_t* slot_of, tt_stream_t stream);
+                        tt_stream_t stream);
+int tt_adam_table_stash_ids(const float* W, const float* M, const float* V, int64_t n_rows, int64_t dim,
+                            const int64_t* ids, int64_t n_ids, void* side, int64_t side_bytes,
+                            tt_stream_t stream);
 int tt_adam_table_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
                         tt_stream_t stream);
 int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,

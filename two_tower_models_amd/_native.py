@@ -64,7 +64,8 @@ SIGNATURES = {
     "tt_adam_table_workspace_bytes": (_i64, [_i64, _i64]),
     "tt_adam_table": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, C.POINTER(GradSources), _i64, _vp, _vp, _vp,
                              _vp, _vp, _i64, _vp]),
-    "tt_adam_table_stash": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "tt_adam_table_stash": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "tt_adam_table_stash_ids": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "tt_adam_table_sweep": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "tt_adam_table_finish": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, C.POINTER(GradSources), _i64, _vp, _vp, _vp,
                                     _vp, _vp, _i64, _vp]),

@@ -22,7 +22,7 @@ namespace tt {
 
 constexpr int SWEEP_DEFAULT_VARIANT = 0;
 constexpr int SWEEP_DEFAULT_BPC = 8;
-constexpr int SWEEP_DEFAULT_LDS_KB = 0;
+constexpr int SWEEP_DEFAULT_PERSIST = 3;
 
 struct AdamConst {
   float one_minus_b1, b2, one_minus_b2, eps, neg_step_size, bc2_sqrt;
@@ -67,9 +67,15 @@ __device__ __forceinline__ const float* source_row(const tt_grad_sources& s, int
   return s.rows[k] + (pos - s.first[k]) * s.ld[k];
 }
 
+// Side buffer = three planes [cap][dim]: p | m | v, cap = n_ids.  A looked-up row lives in the slot
+// numbered by its FIRST occurrence among the step's ids (perm[seg_begin[u]]: the sort is stable),
+// so the buffer can be filled either from the plan (adam_stash_kernel: unique rows only) or
+// straight from the id list before any plan exists (adam_stash_ids_kernel: every occurrence;
+// the p plane is then also the forward's lookup result).
+//
 // one wavefront per unique row; 4 rows per workgroup.  FROM_SIDE: the row's OLD p,m,v were
-// parked in the side buffer by adam_stash_kernel (overlapped schedule: by now the sweep may
-// already have overwritten them in the table).
+// parked in the side buffer (overlapped schedule: by now the sweep may already have
+// overwritten them in the table).
 template <bool FROM_SIDE>
 __global__ __launch_bounds__(256) void adam_touched_kernel(const float* __restrict__ W, const float* __restrict__ M,
                                                            const float* __restrict__ V, int64_t n_rows, int64_t dim,
@@ -86,8 +92,7 @@ __global__ __launch_bounds__(256) void adam_touched_kernel(const float* __restri
   const int32_t t0 = seg_begin[u], t1 = seg_begin[u + 1];
   const int64_t row = sorted_ids[t0];
   if (row >= n_rows) return;  // sentinel run: ids that belong to another rank's block
-  // side buffer = three planes [cap][dim]: p | m | v  (the p plane doubles as a gather source)
-  float* sp = side + u * dim;
+  float* sp = side + (int64_t)perm[t0] * dim;
   float* sm = sp + cap * dim;
   float* sv = sm + cap * dim;
   for (int64_t d = lane; d < dim; d += 64) {
@@ -109,19 +114,14 @@ __global__ __launch_bounds__(256) void adam_stash_kernel(const float* __restrict
                                                          const int32_t* __restrict__ seg_begin,
                                                          const int32_t* __restrict__ perm,
                                                          const int32_t* __restrict__ n_unique,
-                                                         float* __restrict__ side, int64_t cap,
-                                                         int64_t* __restrict__ slot_of) {
+                                                         float* __restrict__ side, int64_t cap) {
   const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (u >= *n_unique) return;
   const int lane = threadIdx.x & 63;
-  const int32_t t0 = seg_begin[u], t1 = seg_begin[u + 1];
+  const int32_t t0 = seg_begin[u];
   const int64_t row = sorted_ids[t0];
-  // slot_of[i] = stash slot of lookup occurrence i, so the forward can gather the OLD row from
-  // the p plane after the sweep has started rewriting the table (sentinel runs get slot -1)
-  if (slot_of)
-    for (int32_t t = t0 + lane; t < t1; t += 64) slot_of[perm[t]] = (row < n_rows) ? u : -1;
   if (row >= n_rows) return;
-  float* sp = side + u * dim;
+  float* sp = side + (int64_t)perm[t0] * dim;
   float* sm = sp + cap * dim;
   float* sv = sm + cap * dim;
   for (int64_t d = lane; d < dim; d += 64) {
@@ -131,18 +131,53 @@ __global__ __launch_bounds__(256) void adam_stash_kernel(const float* __restrict
   }
 }
 
+// Plan-free stash: occurrence i of the step's id list parks row ids[i] in slot i (duplicates park
+// the same values several times; the finish uses the first).  Needs nothing but the ids, so the
+// sweep can start a few microseconds into the step while the sort runs underneath it.  Ids
+// outside [0, n_rows) (another rank's rows, or invalid input that the plan will flag) park zeros.
+__global__ __launch_bounds__(256) void adam_stash_ids_kernel(const float* __restrict__ W, const float* __restrict__ M,
+                                                             const float* __restrict__ V, int64_t n_rows, int64_t dim,
+                                                             const int64_t* __restrict__ ids, int64_t n_ids,
+                                                             float* __restrict__ side) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_ids) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = ids[i];
+  const bool ok = row >= 0 && row < n_rows;
+  float* sp = side + i * dim;
+  float* sm = sp + n_ids * dim;
+  float* sv = sm + n_ids * dim;
+  if (((dim & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(M) |
+                            reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(side)) & 15) == 0) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t d = 4 * lane; d < dim; d += 256) {
+      *reinterpret_cast<float4*>(sp + d) = ok ? *reinterpret_cast<const float4*>(W + row * dim + d) : z;
+      *reinterpret_cast<float4*>(sm + d) = ok ? *reinterpret_cast<const float4*>(M + row * dim + d) : z;
+      *reinterpret_cast<float4*>(sv + d) = ok ? *reinterpret_cast<const float4*>(V + row * dim + d) : z;
+    }
+  } else {
+    for (int64_t d = lane; d < dim; d += 64) {
+      sp[d] = ok ? W[row * dim + d] : 0.f;
+      sm[d] = ok ? M[row * dim + d] : 0.f;
+      sv[d] = ok ? V[row * dim + d] : 0.f;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void adam_writeback_kernel(float* __restrict__ W, float* __restrict__ M,
                                                              float* __restrict__ V, int64_t n_rows, int64_t dim,
                                                              const int32_t* __restrict__ sorted_ids,
                                                              const int32_t* __restrict__ seg_begin,
+                                                             const int32_t* __restrict__ perm,
                                                              const int32_t* __restrict__ n_unique,
                                                              const float* __restrict__ side, int64_t cap) {
   const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (u >= *n_unique) return;
   const int lane = threadIdx.x & 63;
-  const int64_t row = sorted_ids[seg_begin[u]];
+  const int32_t t0 = seg_begin[u];
+  const int64_t row = sorted_ids[t0];
   if (row >= n_rows) return;
-  const float* sp = side + u * dim;
+  const float* sp = side + (int64_t)perm[t0] * dim;
   const float* sm = sp + cap * dim;
   const float* sv = sm + cap * dim;
   for (int64_t d = lane; d < dim; d += 64) {
@@ -206,10 +241,10 @@ __global__ __launch_bounds__(256) void adam_sweep_kernel(float4* __restrict__ W,
     W[i] = p; M[i] = m; V[i] = v;
   }
 }
-// Bounded-work form for the overlapped schedule: each workgroup streams SWEEP_ITERS x 256
-// float4 triples and exits, so wave slots keep freeing up and the dispatcher can slot the
-// (higher-priority) backward kernels in between instead of queueing them behind a
-// persistent grid.
+// One-shot bounded-work form (TT_SWEEP_PERSIST=0): each workgroup streams SWEEP_ITERS x 256
+// float4 triples and exits.  Kept as the A/B partner of the persistent kernel below: the
+// dispatcher refills every freed slot with another of these small workgroups, so the big
+// forward / backward workgroups starve until the grid is exhausted (sweep + compute in series).
 constexpr int SWEEP_ITERS = 8;
 __global__ __launch_bounds__(256) void adam_sweep_bounded_kernel(float4* __restrict__ W, float4* __restrict__ M,
                                                                  float4* __restrict__ V, int64_t n4,
@@ -226,6 +261,63 @@ __global__ __launch_bounds__(256) void adam_sweep_bounded_kernel(float4* __restr
     adam_elem_zero_grad(p.z, m.z, v.z, c);
     adam_elem_zero_grad(p.w, m.w, v.w, c);
     W[i] = p; M[i] = m; V[i] = v;
+  }
+}
+
+// Persistent form of the same chunking: gridDim.x = (#CUs x workgroups-per-CU) workgroups take
+// 256 x ITERS-float4 chunks in order, so neighbouring workgroups stream neighbouring chunks
+// (the DRAM page pattern of the bounded kernel) while the sweep's footprint on every CU stays
+// FIXED: a few light waves per SIMD, no LDS.  That leaves registers, LDS and wave slots for
+// the forward / backward kernels' big workgroups for the whole 5 ms the sweep lasts -- with the
+// one-shot grid above the dispatcher refills every freed slot with another small sweep
+// workgroup and a 256-VGPR / 64-KiB workgroup never finds a whole CU's worth of room.
+template <bool DYNAMIC, int ITERS, int UNR>
+__global__ __launch_bounds__(256) void adam_sweep_persistent_kernel(float4* __restrict__ W, float4* __restrict__ M,
+                                                                    float4* __restrict__ V, int64_t n4,
+                                                                    const double* __restrict__ hyper,
+                                                                    unsigned* __restrict__ ctr) {
+  const AdamConst c = load_hyper(hyper);
+  const unsigned n_chunks = (unsigned)((n4 + 256 * ITERS - 1) / (256 * ITERS));
+  __shared__ unsigned s_next[2];
+  // DYNAMIC: chunks are handed out through a device counter (ctr[0]), one fetch ahead of the
+  // chunk being streamed, so workgroups that share a CU with a heavy kernel simply take fewer
+  // chunks.  The last workgroup out (ctr[1]) re-arms both counters for the next launch; launches
+  // sharing `ctr` must be stream-ordered, which they are (one optimiser = one sweep stream).
+  unsigned ch = blockIdx.x;
+  if (DYNAMIC) {
+    if (threadIdx.x == 0) s_next[0] = atomicAdd(&ctr[0], 1u);
+    __syncthreads();
+    ch = s_next[0];
+  }
+  int par = 0;
+  while (ch < n_chunks) {
+    if (DYNAMIC && threadIdx.x == 0) s_next[par ^ 1] = atomicAdd(&ctr[0], 1u);
+    const int64_t base = (int64_t)ch * (256 * ITERS) + threadIdx.x;
+#pragma unroll UNR
+    for (int k = 0; k < ITERS; ++k) {
+      const int64_t i = base + (int64_t)k * 256;
+      if (i >= n4) break;
+      float4 p = W[i], m = M[i], v = V[i];
+      adam_elem_zero_grad(p.x, m.x, v.x, c);
+      adam_elem_zero_grad(p.y, m.y, v.y, c);
+      adam_elem_zero_grad(p.z, m.z, v.z, c);
+      adam_elem_zero_grad(p.w, m.w, v.w, c);
+      W[i] = p; M[i] = m; V[i] = v;
+    }
+    if (DYNAMIC) {
+      __syncthreads();
+      par ^= 1;
+      ch = s_next[par];
+    } else {
+      ch += gridDim.x;
+    }
+  }
+  if (DYNAMIC && threadIdx.x == 0) {
+    if (atomicAdd(&ctr[1], 1u) == gridDim.x - 1) {
+      ctr[0] = 0;
+      ctr[1] = 0;
+      __threadfence();
+    }
   }
 }
 
@@ -284,6 +376,18 @@ static bool check_sources(const tt_grad_sources* s, int64_t n_ids, int64_t dim) 
   return s->first[s->n_sources] == n_ids;
 }
 
+// CUs of the current device (256 on MI355X), queried once per device
+static int device_cu_count() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cached[dev];
+}
+
 static int launch_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
                         hipStream_t st, bool bounded = false) {
   int rc;
@@ -299,15 +403,22 @@ static int launch_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t di
     const int64_t blocks = ceil_div(n4, 256) < cap ? ceil_div(n4, 256) : cap;
     float4 *w4 = reinterpret_cast<float4*>(W), *m4 = reinterpret_cast<float4*>(M), *v4 = reinterpret_cast<float4*>(V);
     ProfScope prof("adam_sweep_kernel", st);
-    static const bool no_bounded = getenv("TT_SWEEP_NO_BOUNDED") != nullptr;
-    if (bounded && !no_bounded) {
-      // Static CU partitioning through LDS: the sweep needs no LDS, but reserving some per
-      // workgroup caps how many of them fit on a CU (160 KiB / reservation), which leaves LDS,
-      // wave slots and registers for the backward pass's big workgroups (64 KiB LDS, 256 VGPRs)
-      // that would otherwise never find room between the constantly refilling sweep blocks.
-      // 4 sweep workgroups per CU already saturate HBM (tools/bench_sweep.py).
-      static const int lds_kb = getenv("TT_SWEEP_LDS_KB") ? atoi(getenv("TT_SWEEP_LDS_KB")) : SWEEP_DEFAULT_LDS_KB;
-      adam_sweep_bounded_kernel<<<(unsigned)ceil_div(n4, 256 * SWEEP_ITERS), 256, (size_t)lds_kb * 1024, st>>>(w4, m4, v4, n4, hyper);
+    // Overlapped schedule (tt_adam_table_sweep): persistent, dynamically chunked sweep with
+    // TT_SWEEP_PERSIST workgroups per CU (default 3 = 3 waves per SIMD, ~12 16-byte loads in
+    // flight per lane: HBM-saturating on its own and small enough that a 256-VGPR / 64-KiB
+    // backward workgroup still fits next to it; from 5 per CU upwards it no longer does and the
+    // step degrades to sweep + compute in series -- measured, profiles/README.md).
+    // TT_SWEEP_PERSIST=0 selects the one-shot bounded grid instead.
+    static const int persist = getenv("TT_SWEEP_PERSIST") ? atoi(getenv("TT_SWEEP_PERSIST")) : SWEEP_DEFAULT_PERSIST;
+    if (bounded && persist > 0) {
+      static const bool dyn = getenv("TT_SWEEP_STATIC") == nullptr;
+      // hyper[7] is the library's scratch slot: two 32-bit chunk counters, zero between launches
+      unsigned* ctr = reinterpret_cast<unsigned*>(const_cast<double*>(hyper) + 7);
+      const unsigned grid = (unsigned)(device_cu_count() * persist);
+      if (dyn) adam_sweep_persistent_kernel<true, 4, 4><<<grid, 256, 0, st>>>(w4, m4, v4, n4, hyper, ctr);
+      else adam_sweep_persistent_kernel<false, 4, 4><<<grid, 256, 0, st>>>(w4, m4, v4, n4, hyper, ctr);
+    } else if (bounded) {
+      adam_sweep_bounded_kernel<<<(unsigned)ceil_div(n4, 256 * SWEEP_ITERS), 256, 0, st>>>(w4, m4, v4, n4, hyper);
     } else
     switch (variant & 3) {
       case 0: adam_sweep_kernel<false, 1><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
@@ -358,7 +469,7 @@ extern "C" int tt_adam_table(float* W, float* M, float* V, int64_t n_rows, int64
   }
   if ((rc = launch_sweep(W, M, V, n_rows, dim, hyper, st))) return rc;
   if (n_ids > 0) {
-    adam_writeback_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, sorted_ids, seg_begin, n_unique, reinterpret_cast<const float*>(ws), n_ids);
+    adam_writeback_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, sorted_ids, seg_begin, perm, n_unique, reinterpret_cast<const float*>(ws), n_ids);
     if ((rc = check_launch("adam_writeback_kernel"))) return rc;
   }
   return 0;
@@ -369,12 +480,22 @@ extern "C" int tt_adam_table(float* W, float* M, float* V, int64_t n_rows, int64
 extern "C" int tt_adam_table_stash(const float* W, const float* M, const float* V, int64_t n_rows, int64_t dim,
                                    int64_t n_ids, const int32_t* sorted_ids, const int32_t* perm,
                                    const int32_t* seg_begin, const int32_t* n_unique, void* side,
-                                   int64_t side_bytes, int64_t* slot_of, tt_stream_t stream) {
+                                   int64_t side_bytes, tt_stream_t stream) {
   if (!W || !M || !V || !sorted_ids || !perm || !seg_begin || !n_unique || !side) return fail_arg("tt_adam_table_stash: null pointer");
   if (n_rows <= 0 || dim <= 0 || n_ids <= 0) return fail_arg("tt_adam_table_stash: sizes");
   if (side_bytes < tt_adam_table_workspace_bytes(n_ids, dim)) { set_error("tt_adam_table_stash: side buffer"); return TT_E_WORKSPACE; }
-  adam_stash_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, S(stream)>>>(W, M, V, n_rows, dim, sorted_ids, seg_begin, perm, n_unique, reinterpret_cast<float*>(side), n_ids, slot_of);
+  adam_stash_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, S(stream)>>>(W, M, V, n_rows, dim, sorted_ids, seg_begin, perm, n_unique, reinterpret_cast<float*>(side), n_ids);
   return check_launch("adam_stash_kernel");
+}
+
+extern "C" int tt_adam_table_stash_ids(const float* W, const float* M, const float* V, int64_t n_rows, int64_t dim,
+                                       const int64_t* ids, int64_t n_ids, void* side, int64_t side_bytes,
+                                       tt_stream_t stream) {
+  if (!W || !M || !V || !ids || !side) return fail_arg("tt_adam_table_stash_ids: null pointer");
+  if (n_rows <= 0 || dim <= 0 || n_ids <= 0) return fail_arg("tt_adam_table_stash_ids: sizes");
+  if (side_bytes < tt_adam_table_workspace_bytes(n_ids, dim)) { set_error("tt_adam_table_stash_ids: side buffer"); return TT_E_WORKSPACE; }
+  adam_stash_ids_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, S(stream)>>>(W, M, V, n_rows, dim, ids, n_ids, reinterpret_cast<float*>(side));
+  return check_launch("adam_stash_ids_kernel");
 }
 
 extern "C" int tt_adam_table_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
@@ -418,7 +539,7 @@ extern "C" int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows
   adam_touched_kernel<true><<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, sd, n_ids);
   int rc = check_launch("adam_touched_kernel");
   if (rc) return rc;
-  adam_writeback_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, sorted_ids, seg_begin, n_unique, sd, n_ids);
+  adam_writeback_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, sorted_ids, seg_begin, perm, n_unique, sd, n_ids);
   return check_launch("adam_writeback_kernel");
 }
 

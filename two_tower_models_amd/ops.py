@@ -97,26 +97,34 @@ class RowPlan:
     """Device-side run structure of the ids looked up in a step (tt_rowgrad_plan).  Built from
     the ids alone (they are known at forward time); the gradient blocks are attached later."""
 
-    def __init__(self, id_blocks: Sequence[torch.Tensor], n_rows: int, slot: str = "plan"):
+    def __init__(self, id_blocks: Sequence[torch.Tensor], n_rows: int, slot: str = "plan", defer: bool = False):
+        """`defer`: only concatenate the ids (`self.ids`); the sort is launched by `build()`."""
         if len(id_blocks) > N.TT_MAX_GRAD_SOURCES:
             raise RuntimeError(f"more than {N.TT_MAX_GRAD_SOURCES} lookups of one table in a step")
         id_blocks = [b.reshape(-1) for b in id_blocks]
         dev = id_blocks[0].device
         lib = N.load()
         ids = id_blocks[0] if len(id_blocks) == 1 else torch.cat(id_blocks)
+        if ids.dtype != torch.int64 or not ids.is_contiguous():
+            ids = ids.to(torch.int64).contiguous()
         n = ids.numel()
-        self.n = n
+        self.n, self.ids, self.n_rows, self._slot = n, ids, n_rows, slot
         self.block_sizes = [b.numel() for b in id_blocks]
         self.sorted_ids = torch.empty(n, dtype=torch.int32, device=dev)
         self.perm = torch.empty(n, dtype=torch.int32, device=dev)
         self.seg_begin = torch.empty(n + 1, dtype=torch.int32, device=dev)
         self.n_unique = torch.empty(1, dtype=torch.int32, device=dev)
-        wsp, wsn = _ws(dev, lib.tt_rowgrad_workspace_bytes(n), slot)
-        N.check(lib.tt_rowgrad_plan(ids.data_ptr(), n, n_rows, self.sorted_ids.data_ptr(), self.perm.data_ptr(),
-                                    self.seg_begin.data_ptr(), self.n_unique.data_ptr(),
-                                    N.oob.flag(dev).data_ptr(), wsp, wsn, N.stream()), "tt_rowgrad_plan")
         self.sources = None
         self._keep = None
+        if not defer:
+            self.build()
+
+    def build(self) -> None:
+        lib, dev = N.load(), self.ids.device
+        wsp, wsn = _ws(dev, lib.tt_rowgrad_workspace_bytes(self.n), self._slot)
+        N.check(lib.tt_rowgrad_plan(self.ids.data_ptr(), self.n, self.n_rows, self.sorted_ids.data_ptr(),
+                                    self.perm.data_ptr(), self.seg_begin.data_ptr(), self.n_unique.data_ptr(),
+                                    N.oob.flag(dev).data_ptr(), wsp, wsn, N.stream()), "tt_rowgrad_plan")
 
     @classmethod
     def from_grads(cls, blocks: Sequence[RowGrad], n_rows: int) -> "RowPlan":
@@ -155,13 +163,14 @@ def register_lookup(weight: torch.Tensor, ids: torch.Tensor) -> Optional[int]:
 
 
 class ActiveStash:
-    """The optimiser's parked copy of the rows a forward is about to look up (old values), plus
-    for every lookup occurrence its slot in that copy.  While it is attached to a table
-    (`weight._tt_active`), lookups gather from here: the zero-gradient sweep may already be
-    rewriting the table itself."""
+    """The optimiser's parked copy of the rows a forward is about to look up (old values): the p
+    plane of the Adam side buffer, one row per lookup occurrence in announcement order
+    (tt_adam_table_stash_ids).  While it is attached to a table (`weight._tt_active`), lookups
+    read from here: the zero-gradient sweep may already be rewriting the table itself."""
 
-    def __init__(self, p_plane: torch.Tensor, slots: torch.Tensor, block_sizes: Sequence[int]):
-        self.p_plane, self.slots = p_plane, slots
+    def __init__(self, p_plane: torch.Tensor, block_sizes: Sequence[int]):
+        self.p_plane = p_plane
+        self.positions = torch.arange(p_plane.shape[0], dtype=torch.int64, device=p_plane.device)
         self.offsets = [0]
         for n in block_sizes:
             self.offsets.append(self.offsets[-1] + n)
@@ -169,7 +178,7 @@ class ActiveStash:
     def slots_for(self, index: int, n: int) -> torch.Tensor:
         if index + 1 >= len(self.offsets) or self.offsets[index + 1] - self.offsets[index] != n:
             raise RuntimeError("forward performed a lookup the optimiser was not told about (begin_step mismatch)")
-        return self.slots[self.offsets[index]: self.offsets[index + 1]]
+        return self.positions[self.offsets[index]: self.offsets[index + 1]]
 
 
 def lookup_source(weight: torch.Tensor, ids: torch.Tensor, recording: bool):

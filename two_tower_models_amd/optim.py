@@ -33,8 +33,9 @@ assumes is that a ``zero_grad()`` issued after a forward IS followed by that for
 
 ``overlap_sweep="forward"`` goes one step further: the models' ``train_forward`` announces the
 ids it is about to look up (``begin_step``) BEFORE touching the tables.  The optimiser plans,
-parks the old rows, starts the sweep at once and hands the lookups a view of the parked rows
-(``ops.ActiveStash``), so forward AND backward run under the sweep.  It assumes every
+parks the old rows straight from the id lists (no sort needed yet), starts the sweep at once and
+hands the lookups a view of the parked rows (``ops.ActiveStash``), so the id sort, forward AND
+backward all run under the sweep.  It assumes every
 ``train_forward`` executed with autograd enabled is followed by ``backward()`` and ``step()``
 (exactly the reference loop); results are again bit-identical to the serial schedule.
 """
@@ -128,17 +129,22 @@ class DenseExactAdam(torch.optim.Optimizer):
                 continue
             n_rows, dim = p.shape
             st = self.state[p]
-            plan = ops.RowPlan(blocks, n_rows, slot=f"plan{id(p)}")
+            # forward mode: the ids alone are enough to park the rows (slot = occurrence), so the
+            # sort is deferred until the sweep is running
+            plan = ops.RowPlan(blocks, n_rows, slot=f"plan{id(p)}", defer=announced is not None)
             side = self._side(p, lib.tt_adam_table_workspace_bytes(plan.n, dim))
-            slots = torch.empty(plan.n, dtype=torch.int64, device=p.device) if announced is not None else None
-            N.check(lib.tt_adam_table_stash(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                            n_rows, dim, plan.n, plan.sorted_ids.data_ptr(), plan.perm.data_ptr(),
-                                            plan.seg_begin.data_ptr(), plan.n_unique.data_ptr(), side.data_ptr(),
-                                            side.numel(), N.ptr(slots), N.stream()), "tt_adam_table_stash")
-            begun[p] = _TableStep(plan, side, announced is not None)
             if announced is not None:
+                N.check(lib.tt_adam_table_stash_ids(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                                    n_rows, dim, plan.ids.data_ptr(), plan.n, side.data_ptr(),
+                                                    side.numel(), N.stream()), "tt_adam_table_stash_ids")
                 p_plane = side[: plan.n * dim * 4].view(torch.float32).view(plan.n, dim)
-                p._tt_active = ops.ActiveStash(p_plane, slots, plan.block_sizes)
+                p._tt_active = ops.ActiveStash(p_plane, plan.block_sizes)
+            else:
+                N.check(lib.tt_adam_table_stash(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                                n_rows, dim, plan.n, plan.sorted_ids.data_ptr(), plan.perm.data_ptr(),
+                                                plan.seg_begin.data_ptr(), plan.n_unique.data_ptr(), side.data_ptr(),
+                                                side.numel(), N.stream()), "tt_adam_table_stash")
+            begun[p] = _TableStep(plan, side, announced is not None)
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(main)  # lookups (or none yet, forward mode) + stashes are complete here
@@ -148,6 +154,9 @@ class DenseExactAdam(torch.optim.Optimizer):
             N.check(lib.tt_adam_table_sweep(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                             p.shape[0], p.shape[1], hyper, self._side_stream.cuda_stream),
                     "tt_adam_table_sweep")
+        if announced is not None:
+            for ts in begun.values():
+                ts.plan.build()  # main stream, underneath the sweep
         self._sweep_done = torch.cuda.Event()
         self._sweep_done.record(self._side_stream)
         self._begun = begun

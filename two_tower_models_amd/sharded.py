@@ -217,7 +217,7 @@ class HipBackend:
             self._sides[key] = side
         N.check(lib.tt_adam_table_stash(W.data_ptr(), M.data_ptr(), V.data_ptr(), n_rows, dim, plan.n,
                                         plan.sorted_ids.data_ptr(), plan.perm.data_ptr(), plan.seg_begin.data_ptr(),
-                                        plan.n_unique.data_ptr(), side.data_ptr(), side.numel(), None, N.stream()),
+                                        plan.n_unique.data_ptr(), side.data_ptr(), side.numel(), N.stream()),
                 "tt_adam_table_stash")
         return plan, side, n_rows
 

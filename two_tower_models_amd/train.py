@@ -101,7 +101,9 @@ def main(args):
     dataset = DummyRecDataset(num_samples=args.num_samples, num_users=args.num_users, num_items=args.num_items,
                               feature_dim=args.feature_dim, user_history_seqlen=args.user_history_seqlen, device=device)
     dataloader = DeviceBatches(dataset, batch_size=args.batch_size, shuffle=True)
-    optimizer = DenseExactAdam(model.parameters(), lr=args.learning_rate)
+    # the loop below is exactly train_forward -> zero_grad -> backward -> step, which is what the
+    # forward-announced sweep start assumes (optim.py)
+    optimizer = DenseExactAdam(model.parameters(), lr=args.learning_rate, overlap_sweep="forward")
     for epoch in range(args.num_epochs):
         avg_loss = train_one_epoch(model, dataloader, optimizer, device)
         print(f"Epoch [{epoch + 1}/{args.num_epochs}] - Loss: {avg_loss:.4f}")
