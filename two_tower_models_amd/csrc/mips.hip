@@ -2,22 +2,31 @@
 // whose [B, C] score matrix never reaches HBM, exact under the total order
 // (score desc, index asc).
 //
-// Every score is mapped to a 64-bit key  (orderable(score) << 32) | ~index : larger key =
-// better item, all keys of one query are distinct.  Three stages per batch of queries:
-//   pass 1   score GEMM; each lane reduces the keys of a fixed group of 64 corpus rows to
-//            their max and stores it:  gmax[group][query]                (MFMA-bound)
-//   select   tau[q] = K-th largest group max of query q (MSD radix select).  At least K
-//            items have key >= tau, and every item with key >= tau lies in one of exactly K
-//            groups, so at most 64*K items qualify (typically ~1.01 K on random data).
-//   pass 2   the SAME score GEMM (bit-identical arithmetic); items with key >= tau[q] are
-//            appended to the query's candidate list                       (MFMA-bound)
+// The corpus is cut into GROUPS of 64 consecutive rows.  Per batch of <= 1024 queries:
+//   pass 1   dense score GEMM; each lane reduces the scores of one group to their max and
+//            stores it:  gmax[group][query] (4 B, order-preserving integer)      (MFMA-bound)
+//   select   the K best groups of every query under (max score desc, group asc): MSD radix
+//            select of the K-th largest 64-bit group key (ord(max) << 32 | ~group) -> tau[q].
+//            Groups are contiguous row ranges, so this is the order of their best items, and
+//            every item of the true top-K lies in one of these exactly-K groups.
+//   list     glist[q][0..K) = the groups with key >= tau[q].
+//   pass 2   SPARSE: only the K selected groups of each query are scored again (64 K rows per
+//            query instead of C), one wavefront per (query, group), with the same MFMA
+//            instruction sequence as pass 1 (bit-identical scores; the query simply occupies
+//            all 32 B-operand columns).  Items whose (ord(score), ~group) >= tau[q] become
+//            candidates (64-bit keys ord(score) << 32 | ~row): at most 64*K, typically ~1.01 K.
+//            The corpus rows are read straight from HBM (contiguous 16-32 KiB per group).
+//            Ragged / unaligned D and corpora with fewer than K groups take the dense pass 2
+//            (the pass-1 kernel with the candidate epilogue) instead.
 //   sort     one wavefront per query: stable LSD radix sort of the candidates, emit top K.
 //
 // GEMM structure = the in-batch-softmax kernel's: each wave keeps 32 queries in registers
 // as MFMA B-operand fragments, corpus rows stream through double-buffered LDS as the A
 // operand, so the C/D layout gives ONE query per lane and 16 corpus rows per tile in that
-// lane's registers -- the group max needs no cross-lane traffic.
-//   fp32 : v_mfma_f32_32x32x2_f32   (exact fp32 fmaf chain)
+// lane's registers.  Which corpus row feeds which A-operand row is free, and it is chosen so
+// that over a 128-row chunk (4 tiles) lane-half h sees exactly the 64 CONSECUTIVE rows
+// 64h .. 64h+63, in increasing order: the group max needs no cross-lane traffic.
+//   fp32 : v_mfma_f32_32x32x2_f32   (fp32 products and accumulate)
 //   bf16 : v_mfma_f32_32x32x16_bf16 (exact products, fp32 accumulate)
 #include "common.hpp"
 
@@ -43,6 +52,18 @@ __device__ __forceinline__ float ord2f(uint32_t o) {
 __device__ __forceinline__ u64 make_key(float score, uint32_t idx) {
   return ((u64)f2ord(score) << 32) | (u64)(0xFFFFFFFFu - idx);
 }
+// order-preserving integer of a score, -0.0 canonicalised to +0.0 (they tie, like in torch)
+__device__ __forceinline__ uint32_t score_ord(float s) { return f2ord(s + 0.0f); }
+__device__ __forceinline__ u64 ord_key(uint32_t ord, uint32_t idx) {
+  return ((u64)ord << 32) | (u64)(0xFFFFFFFFu - idx);
+}
+// LDS row L (0..63) of the t2-th (0/1) 64-row tile of a chunk -> row offset inside the chunk.
+// MFMA tile T = 2*t2 + L/32, A-operand row a = L%32 lands in lane-half (a>>2)&1, element
+// e = 4*(a>>3) + (a&3) of the accumulator; it is fed chunk row 64*half + 16*T + e.
+__device__ __forceinline__ int chunk_row(int t2, int L) {
+  const int a = L & 31, T = 2 * t2 + (L >> 5);
+  return 64 * ((a >> 2) & 1) + 16 * T + 4 * (a >> 3) + (a & 3);
+}
 
 struct MipsArgs {
   const void* Q;       // [B, D] queries (fp32 or bf16)
@@ -50,11 +71,14 @@ struct MipsArgs {
   int64_t B, C, D;
   int64_t q0, nq;      // this batch: queries q0 .. q0+nq
   int64_t chunks_per_split, n_chunks;
-  u64* gmax;           // [2*n_chunks][nq]
-  const u64* tau;      // [nq]
+  uint32_t* gmax;      // [n_groups][nq] score_ord of the group max (0 = empty group)
+  const u64* tau;      // [nq] K-th largest group key
   u64* cand;           // [nq][cap]
   int32_t* count;      // [nq]
   int64_t cap;
+  const int32_t* glist;  // [nq][K] selected groups (sparse pass 2)
+  const int32_t* lcount; // [nq]
+  int64_t K;
   int vec_ok;
 };
 
@@ -88,13 +112,13 @@ struct Op<TT_F32, DPX> {
       f.v[g][0] = v.x; f.v[g][1] = v.y; f.v[g][2] = v.z; f.v[g][3] = v.w;
     }
   }
-  static __device__ __forceinline__ void fetch(uint4 (&st)[NLOAD], const void* Cm, int64_t row0, int64_t nrows, int64_t D, bool vec) {
+  static __device__ __forceinline__ void fetch(uint4 (&st)[NLOAD], const void* Cm, int64_t t, int64_t nrows, int64_t D, bool vec) {
     constexpr int C4 = DP / 4;
     const float* Y = reinterpret_cast<const float*>(Cm);
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
       const int f = threadIdx.x + 256 * i;
-      const int64_t row = row0 + f / C4, k = 4 * (f % C4);
+      const int64_t row = (t >> 1) * CHUNK + chunk_row((int)(t & 1), (f / C4) & (CT - 1)), k = 4 * (f % C4);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (f < CT * C4 && row < nrows) {
         const float* p = Y + row * D + k;
@@ -117,11 +141,12 @@ struct Op<TT_F32, DPX> {
       if (f < CT * C4) *reinterpret_cast<uint4*>(Ys + (f / C4) * LDB + 16 * (f % C4)) = st[i];
     }
   }
-  static __device__ __forceinline__ f32x16 tile(const char* Ys, const Frag& q, int jt, int r, int h) {
+  static constexpr int ESZ = 4;
+  // yrow -> this lane's A-operand row (LDS or global), already advanced by 16*h bytes
+  static __device__ __forceinline__ f32x16 tile_at(const char* yrow, const Frag& q) {
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const char* yrow = Ys + (jt * 32 + r) * LDB + 16 * h;
 #pragma unroll
     for (int g = 0; g < DPX; ++g) {
       const float4 y = *reinterpret_cast<const float4*>(yrow + 32 * g);
@@ -131,6 +156,9 @@ struct Op<TT_F32, DPX> {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.w, q.v[g][3], acc, 0, 0, 0);
     }
     return acc;
+  }
+  static __device__ __forceinline__ f32x16 tile(const char* Ys, const Frag& q, int jt, int r, int h) {
+    return tile_at(Ys + (jt * 32 + r) * LDB + 16 * h, q);
   }
 };
 
@@ -154,13 +182,13 @@ struct Op<TT_BF16, DPX> {
     for (int g = 0; g < DPX; ++g)
       f.v[g] = (row < nrows) ? load8(X, row, 16 * g + 8 * h, D, vec) : make_uint4(0, 0, 0, 0);
   }
-  static __device__ __forceinline__ void fetch(uint4 (&st)[NLOAD], const void* Cm, int64_t row0, int64_t nrows, int64_t D, bool vec) {
+  static __device__ __forceinline__ void fetch(uint4 (&st)[NLOAD], const void* Cm, int64_t t, int64_t nrows, int64_t D, bool vec) {
     constexpr int C8 = DP / 8;
     const uint16_t* Y = reinterpret_cast<const uint16_t*>(Cm);
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
       const int f = threadIdx.x + 256 * i;
-      const int64_t row = row0 + f / C8, k = 8 * (f % C8);
+      const int64_t row = (t >> 1) * CHUNK + chunk_row((int)(t & 1), (f / C8) & (CT - 1)), k = 8 * (f % C8);
       st[i] = (f < CT * C8 && row < nrows) ? load8(Y, row, k, D, vec) : make_uint4(0, 0, 0, 0);
     }
   }
@@ -172,11 +200,11 @@ struct Op<TT_BF16, DPX> {
       if (f < CT * C8) *reinterpret_cast<uint4*>(Ys + (f / C8) * LDB + 16 * (f % C8)) = st[i];
     }
   }
-  static __device__ __forceinline__ f32x16 tile(const char* Ys, const Frag& q, int jt, int r, int h) {
+  static constexpr int ESZ = 2;
+  static __device__ __forceinline__ f32x16 tile_at(const char* yrow, const Frag& q) {
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const char* yrow = Ys + (jt * 32 + r) * LDB + 16 * h;
 #pragma unroll
     for (int g = 0; g < DPX; ++g) {
       const uint4 y = *reinterpret_cast<const uint4*>(yrow + 32 * g);
@@ -184,9 +212,13 @@ struct Op<TT_BF16, DPX> {
     }
     return acc;
   }
+  static __device__ __forceinline__ f32x16 tile(const char* Ys, const Frag& q, int jt, int r, int h) {
+    return tile_at(Ys + (jt * 32 + r) * LDB + 16 * h, q);
+  }
 };
 
-// ---------------------------------------------------------------- the two GEMM passes
+// ---------------------------------------------------------------- the dense GEMM pass
+// PASS 1: group maxima.  PASS 2 (fallback for ragged D / tiny corpora): candidates.
 template <int DT, int DPX, int PASS>
 __global__ __launch_bounds__(256) void mips_score_kernel(const MipsArgs p) {
   using O = Op<DT, DPX>;
@@ -208,47 +240,97 @@ __global__ __launch_bounds__(256) void mips_score_kernel(const MipsArgs p) {
 
   uint4 st[O::NLOAD];
   if (t0 < t1) {
-    O::fetch(st, p.Cm, t0 * CT, p.C, p.D, p.vec_ok);
+    O::fetch(st, p.Cm, t0, p.C, p.D, p.vec_ok);
     O::commit(st, smem_raw);
   }
   __syncthreads();
   float best = 0.f;
-  uint32_t best_idx = 0;
   bool have = false;
   for (int64_t t = t0; t < t1; ++t) {
     const int cur = (int)((t - t0) & 1);
-    if (t + 1 < t1) O::fetch(st, p.Cm, (t + 1) * CT, p.C, p.D, p.vec_ok);
+    if (t + 1 < t1) O::fetch(st, p.Cm, t + 1, p.C, p.D, p.vec_ok);
     const char* ys = smem_raw + cur * TILE_BYTES;
+    const int64_t chunk = t >> 1;
+    const bool full = (chunk + 1) * CHUNK <= p.C;  // no row of this chunk is past the corpus end
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
       const f32x16 acc = O::tile(ys, qf, jt, r, h);
-      const int64_t b0 = t * CT + jt * 32 + 4 * h;
+      // this lane's 16 scores are chunk rows 64h + 16T + e, T = 2*(t&1) + jt (see chunk_row)
+      const int64_t b0 = chunk * CHUNK + 64 * h + 16 * (2 * (int)(t & 1) + jt);
+      if (PASS == 1) {
+        if (full) {
+          float m = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t row = b0 + (e & 3) + 8 * (e >> 2);
-        const float s = acc[e];
-        if (row < p.C) {
-          if (PASS == 1) {
-            // rows are visited in increasing index order inside a lane: strict > keeps the
-            // smaller index on equal scores == max of the composite key
-            if (!have || s > best) { best = s; best_idx = (uint32_t)row; have = true; }
-          } else if (q_ok) {
-            const u64 key = make_key(s, (uint32_t)row);
-            if (key >= tau) {
-              const int pos = atomicAdd(&p.count[ql], 1);
-              if (pos < p.cap) p.cand[ql * p.cap + pos] = key;
-            }
+          for (int e = 4; e < 16; e += 4) m = fmaxf(m, fmaxf(fmaxf(acc[e], acc[e + 1]), fmaxf(acc[e + 2], acc[e + 3])));
+          best = have ? fmaxf(best, m) : m;
+          have = true;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (b0 + e < p.C) { best = have ? fmaxf(best, acc[e]) : acc[e]; have = true; }
+        }
+      } else if (q_ok) {
+        const uint32_t grp = (uint32_t)(2 * chunk + h);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t row = b0 + e;
+          const uint32_t ord = score_ord(acc[e]);
+          if (row < p.C && ord_key(ord, grp) >= tau) {
+            const int pos = atomicAdd(&p.count[ql], 1);
+            if (pos < p.cap) p.cand[ql * p.cap + pos] = ord_key(ord, (uint32_t)row);
           }
         }
       }
     }
-    if (PASS == 1 && ((t + 1) % (CHUNK / CT)) == 0) {  // a 128-row chunk is complete
-      const int64_t chunk = t / (CHUNK / CT);
-      if (q_ok) p.gmax[(2 * chunk + h) * p.nq + ql] = have ? make_key(best, best_idx) : 0ull;
+    if (PASS == 1 && (t & 1)) {  // a 128-row chunk is complete: lane-half h holds group 2*chunk + h
+      if (q_ok) p.gmax[(2 * chunk + h) * p.nq + ql] = have ? score_ord(best) : 0u;
       have = false;
     }
     if (t + 1 < t1) O::commit(st, smem_raw + (cur ^ 1) * TILE_BYTES);
     __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- sparse pass 2
+// One wavefront per (query, selected group): the group's 64 rows come straight from global
+// memory as the A operand (row a of the MFMA tile = row a of the 32-row half group), the query
+// fills all 32 B-operand columns, so lanes 0 and 32 hold the 2 x 16 scores of column 0.  The
+// per-element arithmetic is the MFMA's own and does not depend on the operand row / column
+// an element sits in, so these scores are bit-identical to pass 1's.
+template <int DT, int DPX>
+__global__ __launch_bounds__(256) void mips_sparse_kernel(const MipsArgs p) {
+  using O = Op<DT, DPX>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t ql = blockIdx.x;
+  typename O::Frag qf;
+  O::load_queries(qf, p.Q, p.q0 + ql, p.q0 + p.nq, p.D, h, true);
+  const u64 tau = p.tau[ql];
+  int32_t n_sel = p.lcount[ql];
+  if (n_sel > p.K) n_sel = (int32_t)p.K;
+  const int32_t* gl = p.glist + ql * p.K;
+  const char* base = reinterpret_cast<const char*>(p.Cm);
+  const int64_t row_bytes = p.D * O::ESZ;
+  const int nslots = gridDim.y * 4;
+  for (int gi = blockIdx.y * 4 + wave; gi < n_sel; gi += nslots) {
+    const uint32_t grp = (uint32_t)gl[gi];
+    const int64_t row0 = (int64_t)grp * GROUP;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      int64_t arow = row0 + 32 * jt + r;
+      if (arow >= p.C) arow = p.C - 1;  // past the end: any valid row, its scores are ignored
+      const f32x16 acc = O::tile_at(base + arow * row_bytes + 16 * h, qf);
+      if (r == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t row = row0 + 32 * jt + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const uint32_t ord = score_ord(acc[e]);
+          if (row < p.C && ord_key(ord, grp) >= tau) {
+            const int pos = atomicAdd(&p.count[ql], 1);
+            if (pos < p.cap) p.cand[ql * p.cap + pos] = ord_key(ord, (uint32_t)row);
+          }
+        }
+      }
+    }
   }
 }
 
@@ -262,7 +344,7 @@ __global__ __launch_bounds__(256) void mips_score_kernel(const MipsArgs p) {
 //         are still wanted (then the prefix itself is an exact threshold).
 // `tau` doubles as the prefix being built.
 constexpr int SEL_Q = 32;
-__global__ __launch_bounds__(256) void mips_select_hist_kernel(const u64* __restrict__ gmax, int64_t n_groups,
+__global__ __launch_bounds__(256) void mips_select_hist_kernel(const uint32_t* __restrict__ gmax, int64_t n_groups,
                                                                int64_t nq, int pass, const u64* __restrict__ tau,
                                                                const int32_t* __restrict__ done,
                                                                int32_t* __restrict__ ghist) {
@@ -285,7 +367,7 @@ __global__ __launch_bounds__(256) void mips_select_hist_kernel(const u64* __rest
   const int64_t g1 = (g0 + per < n_groups) ? g0 + per : n_groups;
   if (live) {
     for (int64_t g = g0 + lane8; g < g1; g += 8) {
-      const u64 key = gmax[g * nq + q];
+      const u64 key = ord_key(gmax[g * nq + q], (uint32_t)g);
       if ((key & himask) == prefix) atomicAdd(&hist[ql][(int)((key >> shift) & 255)], 1);
     }
   }
@@ -323,6 +405,25 @@ __global__ void mips_select_init_kernel(int32_t* __restrict__ ghist, int32_t* __
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nq * 256) ghist[i] = 0;
   if (i < nq) { want[i] = K; done[i] = 0; }
+}
+
+// the groups of every query whose key reaches tau: exactly K of them (keys are distinct)
+__global__ __launch_bounds__(256) void mips_group_list_kernel(const uint32_t* __restrict__ gmax, int64_t n_groups,
+                                                              int64_t nq, const u64* __restrict__ tau, int64_t K,
+                                                              int32_t* __restrict__ glist, int32_t* __restrict__ lcount) {
+  const int ql = threadIdx.x & 31, lane8 = threadIdx.x >> 5;
+  const int64_t q = (int64_t)blockIdx.x * SEL_Q + ql;
+  if (q >= nq) return;
+  const u64 t = tau[q];
+  const int64_t per = (n_groups + gridDim.y - 1) / gridDim.y;
+  const int64_t g0 = (int64_t)blockIdx.y * per;
+  const int64_t g1 = (g0 + per < n_groups) ? g0 + per : n_groups;
+  for (int64_t g = g0 + lane8; g < g1; g += 8) {
+    if (ord_key(gmax[g * nq + q], (uint32_t)g) >= t) {
+      const int pos = atomicAdd(&lcount[q], 1);
+      if (pos < K) glist[q * K + pos] = (int32_t)g;
+    }
+  }
 }
 
 // ---------------------------------------------------------------- per-query candidate sort
@@ -405,9 +506,9 @@ __global__ void mips_merge_keys_kernel(const float* __restrict__ scores, const i
   if (i < B) count[i] = (int32_t)n_cand;
 }
 
-__global__ void mips_zero_kernel(u64* tau, int32_t* count, int64_t nq) {
+__global__ void mips_zero_kernel(u64* tau, int32_t* count, int32_t* lcount, int64_t nq) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nq) { tau[i] = 0; count[i] = 0; }
+  if (i < nq) { tau[i] = 0; count[i] = 0; lcount[i] = 0; }
 }
 
 constexpr int64_t MIPS_QBATCH = 1024;
@@ -462,6 +563,23 @@ static int dispatch_score(int dtype, int dpx, const MipsArgs& a, dim3 grid, hipS
   return launch_score<TT_BF16, 8, PASS>(a, grid, st);
 }
 
+template <int DT, int DPX>
+static int launch_sparse(const MipsArgs& a, dim3 grid, hipStream_t st) {
+  ProfScope prof("mips_sparse_kernel", st);
+  mips_sparse_kernel<DT, DPX><<<grid, 256, 0, st>>>(a);
+  return check_launch("mips_sparse_kernel");
+}
+static int dispatch_sparse(int dtype, int dpx, const MipsArgs& a, dim3 grid, hipStream_t st) {
+  if (dtype == TT_F32) {
+    if (dpx == 4) return launch_sparse<TT_F32, 4>(a, grid, st);
+    if (dpx == 8) return launch_sparse<TT_F32, 8>(a, grid, st);
+    return launch_sparse<TT_F32, 16>(a, grid, st);
+  }
+  if (dpx == 2) return launch_sparse<TT_BF16, 2>(a, grid, st);
+  if (dpx == 4) return launch_sparse<TT_BF16, 4>(a, grid, st);
+  return launch_sparse<TT_BF16, 8>(a, grid, st);
+}
+
 }  // namespace tt
 
 using namespace tt;
@@ -469,7 +587,9 @@ using namespace tt;
 extern "C" int64_t tt_mips_workspace_bytes(int64_t B, int64_t C, int64_t D, int64_t K, int dtype) {
   MipsPlan pl;
   if (B <= 0 || C <= 0 || D <= 0 || K <= 0 || K > C || !plan_mips(B, C, D, K, dtype, pl)) return 256;
-  return round_up(pl.n_groups * pl.qb * 8, 256)  // gmax
+  return round_up(pl.n_groups * pl.qb * 4, 256)  // gmax
+         + round_up(pl.qb * K * 4, 256)          // selected groups
+         + round_up(pl.qb * 4, 256)              // their count
          + round_up(pl.qb * 256 * 4, 256)        // select histograms
          + 2 * round_up(pl.qb * 4, 256)          // select want / done
          + round_up(pl.qb * 8, 256)              // tau
@@ -488,7 +608,9 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
   if (ws_bytes < tt_mips_workspace_bytes(B, C, D, K, dtype)) { set_error("tt_mips_topk: workspace"); return TT_E_WORKSPACE; }
   hipStream_t st = S(stream);
   Carver cv(ws);
-  u64* gmax = cv.take<u64>(pl.n_groups * pl.qb);
+  uint32_t* gmax = cv.take<uint32_t>(pl.n_groups * pl.qb);
+  int32_t* glist = cv.take<int32_t>(pl.qb * K);
+  int32_t* lcount = cv.take<int32_t>(pl.qb);
   int32_t* ghist = cv.take<int32_t>(pl.qb * 256);
   int32_t* want = cv.take<int32_t>(pl.qb);
   int32_t* done = cv.take<int32_t>(pl.qb);
@@ -509,9 +631,14 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
     a.Q = query; a.Cm = corpus; a.B = B; a.C = C; a.D = D; a.q0 = q0; a.nq = nq;
     a.chunks_per_split = pl.chunks_per_split; a.n_chunks = pl.n_chunks;
     a.gmax = gmax; a.tau = tau; a.cand = cand; a.count = count; a.cap = pl.cap; a.vec_ok = vec ? 1 : 0;
+    a.glist = glist; a.lcount = lcount; a.K = K;
     dim3 grid((unsigned)ceil_div(nq, QB_WG), (unsigned)pl.splits);
-    mips_zero_kernel<<<(unsigned)ceil_div(nq, 256), 256, 0, st>>>(tau, count, nq);
+    mips_zero_kernel<<<(unsigned)ceil_div(nq, 256), 256, 0, st>>>(tau, count, lcount, nq);
     if ((rc = check_launch("mips_zero_kernel"))) return rc;
+    // sparse pass 2 reads the corpus rows as MFMA fragments straight from global memory
+    static const bool no_sparse = getenv("TT_MIPS_NO_SPARSE") != nullptr;
+    const int dp = pl.dpx * (dtype == TT_F32 ? 8 : 16);
+    const bool sparse = pl.n_groups > K && vec && D == dp && !no_sparse;
     if (pl.n_groups > K) {  // otherwise tau = 0: every item is a candidate (cap == n_groups*64 >= C)
       if ((rc = dispatch_score<1>(dtype, pl.dpx, a, grid, st))) return rc;
       mips_select_init_kernel<<<(unsigned)ceil_div(nq * 256, 256), 256, 0, st>>>(ghist, want, done, nq, (int32_t)K);
@@ -527,7 +654,20 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
         if ((rc = check_launch("mips_select_pick_kernel"))) return rc;
       }
     }
-    if ((rc = dispatch_score<2>(dtype, pl.dpx, a, grid, st))) return rc;
+    if (sparse) {
+      const int64_t qblocks = ceil_div(nq, SEL_Q);
+      int64_t slices = ceil_div(2048, qblocks);
+      if (slices > ceil_div(pl.n_groups, 64)) slices = ceil_div(pl.n_groups, 64);
+      if (slices < 1) slices = 1;
+      mips_group_list_kernel<<<dim3((unsigned)qblocks, (unsigned)slices), 256, 0, st>>>(gmax, pl.n_groups, nq, tau, K, glist, lcount);
+      if ((rc = check_launch("mips_group_list_kernel"))) return rc;
+      int64_t gsplit = ceil_div(8192, nq);  // ~8 K workgroups in flight whatever the batch size
+      if (gsplit > ceil_div(K, 4)) gsplit = ceil_div(K, 4);
+      if (gsplit < 1) gsplit = 1;
+      if ((rc = dispatch_sparse(dtype, pl.dpx, a, dim3((unsigned)nq, (unsigned)gsplit), st))) return rc;
+    } else {
+      if ((rc = dispatch_score<2>(dtype, pl.dpx, a, grid, st))) return rc;
+    }
     mips_sort_emit_kernel<<<(unsigned)nq, 64, 0, st>>>(cand, tmp, count, pl.cap, K, q0, idx_out, score_out, status);
     if ((rc = check_launch("mips_sort_emit_kernel"))) return rc;
   }
