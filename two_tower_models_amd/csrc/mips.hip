@@ -407,21 +407,88 @@ __global__ void mips_select_init_kernel(int32_t* __restrict__ ghist, int32_t* __
   if (i < nq) { want[i] = K; done[i] = 0; }
 }
 
-// the groups of every query whose key reaches tau: exactly K of them (keys are distinct)
-__global__ __launch_bounds__(256) void mips_group_list_kernel(const uint32_t* __restrict__ gmax, int64_t n_groups,
-                                                              int64_t nq, const u64* __restrict__ tau, int64_t K,
-                                                              int32_t* __restrict__ glist, int32_t* __restrict__ lcount) {
+// After the first two digit passes (full scans of gmax) tau's top 16 bits are fixed and only a
+// per-cent or so of the groups still share them.  ONE more full scan splits every query's groups:
+//   key prefix above tau's (or query already decided and key >= tau)  -> glist, selected for sure
+//   same 16-bit prefix, still undecided                               -> surv[q][..] (the keys)
+// and the remaining six digit passes run on the short survivor lists, one workgroup per query
+// (mips_select_finish_kernel), which also appends the survivors that make it to glist.
+__global__ __launch_bounds__(256) void mips_select_split_kernel(const uint32_t* __restrict__ gmax, int64_t n_groups,
+                                                                int64_t nq, const u64* __restrict__ tau,
+                                                                const int32_t* __restrict__ done, int64_t K,
+                                                                int32_t* __restrict__ glist, int32_t* __restrict__ lcount,
+                                                                u64* __restrict__ surv, int32_t* __restrict__ scount) {
   const int ql = threadIdx.x & 31, lane8 = threadIdx.x >> 5;
   const int64_t q = (int64_t)blockIdx.x * SEL_Q + ql;
   if (q >= nq) return;
   const u64 t = tau[q];
+  const bool decided = done[q] != 0;
+  if (decided && !glist) return;
   const int64_t per = (n_groups + gridDim.y - 1) / gridDim.y;
   const int64_t g0 = (int64_t)blockIdx.y * per;
   const int64_t g1 = (g0 + per < n_groups) ? g0 + per : n_groups;
   for (int64_t g = g0 + lane8; g < g1; g += 8) {
-    if (ord_key(gmax[g * nq + q], (uint32_t)g) >= t) {
-      const int pos = atomicAdd(&lcount[q], 1);
-      if (pos < K) glist[q * K + pos] = (int32_t)g;
+    const u64 key = ord_key(gmax[g * nq + q], (uint32_t)g);
+    const bool sure = decided ? key >= t : (key >> 48) > (t >> 48);
+    if (sure) {
+      if (glist) {
+        const int pos = atomicAdd(&lcount[q], 1);
+        if (pos < K) glist[q * K + pos] = (int32_t)g;
+      }
+    } else if (!decided && (key >> 48) == (t >> 48)) {
+      surv[q * n_groups + atomicAdd(&scount[q], 1)] = key;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mips_select_finish_kernel(const u64* __restrict__ surv,
+                                                                 const int32_t* __restrict__ scount, int64_t n_groups,
+                                                                 u64* __restrict__ tau, const int32_t* __restrict__ want,
+                                                                 const int32_t* __restrict__ done, int64_t K,
+                                                                 int32_t* __restrict__ glist, int32_t* __restrict__ lcount) {
+  __shared__ int32_t hist[256];
+  __shared__ u64 s_tau;
+  __shared__ int32_t s_want, s_done;
+  const int64_t q = blockIdx.x;
+  if (done[q]) return;  // decided after two digits: the split kernel already listed its groups
+  const int32_t n = scount[q];
+  const u64* keys = surv + q * n_groups;
+  if (threadIdx.x == 0) { s_tau = tau[q]; s_want = want[q]; s_done = 0; }
+  __syncthreads();
+  for (int pass = 2; pass < 8; ++pass) {
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int shift = 56 - 8 * pass;
+    const u64 himask = ~0ull << (shift + 8), prefix = s_tau;
+    for (int32_t i = threadIdx.x; i < n; i += 256) {
+      const u64 key = keys[i];
+      if ((key & himask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255)], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // same walk as mips_select_pick_kernel
+      const int32_t w = s_want;
+      int32_t acc = 0;
+      int d = 255;
+      for (; d > 0; --d) {
+        if (acc + hist[d] >= w) break;
+        acc += hist[d];
+      }
+      s_tau = prefix | ((u64)d << shift);
+      s_want = w - acc;
+      if (hist[d] == w - acc || pass == 7) s_done = 1;
+    }
+    __syncthreads();
+    if (s_done) break;
+  }
+  const u64 t = s_tau;
+  if (threadIdx.x == 0) tau[q] = t;
+  if (glist) {
+    for (int32_t i = threadIdx.x; i < n; i += 256) {
+      const u64 key = keys[i];
+      if (key >= t) {
+        const int pos = atomicAdd(&lcount[q], 1);
+        if (pos < K) glist[q * K + pos] = (int32_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+      }
     }
   }
 }
@@ -506,9 +573,9 @@ __global__ void mips_merge_keys_kernel(const float* __restrict__ scores, const i
   if (i < B) count[i] = (int32_t)n_cand;
 }
 
-__global__ void mips_zero_kernel(u64* tau, int32_t* count, int32_t* lcount, int64_t nq) {
+__global__ void mips_zero_kernel(u64* tau, int32_t* count, int32_t* lcount, int32_t* scount, int64_t nq) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nq) { tau[i] = 0; count[i] = 0; lcount[i] = 0; }
+  if (i < nq) { tau[i] = 0; count[i] = 0; lcount[i] = 0; scount[i] = 0; }
 }
 
 constexpr int64_t MIPS_QBATCH = 1024;
@@ -590,6 +657,8 @@ extern "C" int64_t tt_mips_workspace_bytes(int64_t B, int64_t C, int64_t D, int6
   return round_up(pl.n_groups * pl.qb * 4, 256)  // gmax
          + round_up(pl.qb * K * 4, 256)          // selected groups
          + round_up(pl.qb * 4, 256)              // their count
+         + round_up(pl.n_groups * pl.qb * 8, 256) // select survivors (keys)
+         + round_up(pl.qb * 4, 256)              // their count
          + round_up(pl.qb * 256 * 4, 256)        // select histograms
          + 2 * round_up(pl.qb * 4, 256)          // select want / done
          + round_up(pl.qb * 8, 256)              // tau
@@ -611,6 +680,8 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
   uint32_t* gmax = cv.take<uint32_t>(pl.n_groups * pl.qb);
   int32_t* glist = cv.take<int32_t>(pl.qb * K);
   int32_t* lcount = cv.take<int32_t>(pl.qb);
+  u64* surv = cv.take<u64>(pl.n_groups * pl.qb);
+  int32_t* scount = cv.take<int32_t>(pl.qb);
   int32_t* ghist = cv.take<int32_t>(pl.qb * 256);
   int32_t* want = cv.take<int32_t>(pl.qb);
   int32_t* done = cv.take<int32_t>(pl.qb);
@@ -633,7 +704,7 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
     a.gmax = gmax; a.tau = tau; a.cand = cand; a.count = count; a.cap = pl.cap; a.vec_ok = vec ? 1 : 0;
     a.glist = glist; a.lcount = lcount; a.K = K;
     dim3 grid((unsigned)ceil_div(nq, QB_WG), (unsigned)pl.splits);
-    mips_zero_kernel<<<(unsigned)ceil_div(nq, 256), 256, 0, st>>>(tau, count, lcount, nq);
+    mips_zero_kernel<<<(unsigned)ceil_div(nq, 256), 256, 0, st>>>(tau, count, lcount, scount, nq);
     if ((rc = check_launch("mips_zero_kernel"))) return rc;
     // sparse pass 2 reads the corpus rows as MFMA fragments straight from global memory
     static const bool no_sparse = getenv("TT_MIPS_NO_SPARSE") != nullptr;
@@ -647,20 +718,19 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
       int64_t slices = ceil_div(2048, qblocks);
       if (slices > ceil_div(pl.n_groups, 64)) slices = ceil_div(pl.n_groups, 64);
       if (slices < 1) slices = 1;
-      for (int pass = 0; pass < 8; ++pass) {  // queries that finish early skip the later passes
+      for (int pass = 0; pass < 2; ++pass) {
         mips_select_hist_kernel<<<dim3((unsigned)qblocks, (unsigned)slices), 256, 0, st>>>(gmax, pl.n_groups, nq, pass, tau, done, ghist);
         if ((rc = check_launch("mips_select_hist_kernel"))) return rc;
         mips_select_pick_kernel<<<(unsigned)ceil_div(nq, 64), 64, 0, st>>>(ghist, nq, pass, tau, want, done);
         if ((rc = check_launch("mips_select_pick_kernel"))) return rc;
       }
+      int32_t* gl = sparse ? glist : nullptr;
+      mips_select_split_kernel<<<dim3((unsigned)qblocks, (unsigned)slices), 256, 0, st>>>(gmax, pl.n_groups, nq, tau, done, K, gl, lcount, surv, scount);
+      if ((rc = check_launch("mips_select_split_kernel"))) return rc;
+      mips_select_finish_kernel<<<(unsigned)nq, 256, 0, st>>>(surv, scount, pl.n_groups, tau, want, done, K, gl, lcount);
+      if ((rc = check_launch("mips_select_finish_kernel"))) return rc;
     }
     if (sparse) {
-      const int64_t qblocks = ceil_div(nq, SEL_Q);
-      int64_t slices = ceil_div(2048, qblocks);
-      if (slices > ceil_div(pl.n_groups, 64)) slices = ceil_div(pl.n_groups, 64);
-      if (slices < 1) slices = 1;
-      mips_group_list_kernel<<<dim3((unsigned)qblocks, (unsigned)slices), 256, 0, st>>>(gmax, pl.n_groups, nq, tau, K, glist, lcount);
-      if ((rc = check_launch("mips_group_list_kernel"))) return rc;
       int64_t gsplit = ceil_div(8192, nq);  // ~8 K workgroups in flight whatever the batch size
       if (gsplit > ceil_div(K, 4)) gsplit = ceil_div(K, 4);
       if (gsplit < 1) gsplit = 1;
