@@ -29,10 +29,10 @@
 //   fp32 : v_mfma_f32_32x32x2_f32   (fp32 products and accumulate)
 //   bf16 : v_mfma_f32_32x32x16_bf16 (exact products, fp32 accumulate)
 #include "common.hpp"
+#include "mfma_stream.hpp"
 
 namespace tt {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned long long u64;
 
@@ -79,6 +79,7 @@ struct MipsArgs {
   const int32_t* glist;  // [nq][K] selected groups (sparse pass 2)
   const int32_t* lcount; // [nq]
   int64_t K;
+  int64_t xblocks, splits;  // DMA pass 1: 1-D grid decomposition
   int vec_ok;
 };
 
@@ -287,6 +288,129 @@ __global__ __launch_bounds__(256) void mips_score_kernel(const MipsArgs p) {
       have = false;
     }
     if (t + 1 < t1) O::commit(st, smem_raw + (cur ^ 1) * TILE_BYTES);
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- pass 1, LDS-DMA form
+// Same computation as mips_score_kernel<.., 1> for the common case (16-B aligned rows, D a
+// multiple of 32 B/row-chunk sizes: D == DP, >= 8 chunks of 16 B per row):
+//   * the corpus tile goes global -> LDS by DMA (no staging registers), unpadded rows with the
+//     XOR chunk swizzle of mfma_stream.hpp; the chunk_row permutation is applied to the SOURCE
+//     row of each DMA lane;
+//   * 2 workgroups per CU, so one wave's max-epilogue overlaps another's MFMAs;
+//   * NQ = 2 (bf16): every A fragment read from LDS feeds TWO MFMAs (64 queries per wave) -- at
+//     one 1-KiB LDS read per 32-cycle bf16 MFMA the LDS port, not the matrix core, is the limit.
+template <int DP8>
+__device__ __forceinline__ void corpus_tile_dma(const char* __restrict__ Cm, int64_t row_bytes, int64_t t, int64_t C,
+                                                float* Ys, int wave, int lane) {
+  using TM = TileMap<DP8, true>;
+  constexpr int RPI = 64 / TM::CPR;  // rows per wave instruction (1 KiB)
+  constexpr int NI = CT / RPI / 4;   // instructions per wave
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int rbase = (wave * NI + i) * RPI;
+    const int row = rbase + lane / TM::CPR;
+    const int c = (lane % TM::CPR) ^ (row & TM::SW);
+    int64_t grow = (t >> 1) * CHUNK + chunk_row((int)(t & 1), row);
+    grow = grow < C ? grow : C - 1;  // rows past the end are masked by the epilogue
+    const char* src = Cm + grow * row_bytes + 16 * c;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(Ys + rbase * TM::DP), 16, 0, 0);
+  }
+}
+
+template <int DT, int DPX, int NQ>
+__global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p) {
+  using O = Op<DT, DPX>;
+  using TM = TileMap<DPX, true>;  // row bytes = 32 * DPX for both dtypes
+  static_assert(DT == TT_BF16 || NQ == 1, "two query fragments only for bf16");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* const smem = reinterpret_cast<float*>(smem_raw);
+  constexpr int TILE_FLOATS = CT * TM::DP;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  // XCD-aware decomposition of the 1-D grid (workgroup L runs on XCD L % 8, each XCD has its own
+  // L2): the `xblocks` query blocks that stream the SAME corpus split get consecutive slots on
+  // ONE XCD, so the split is fetched from HBM once and hit in that L2 by the others.
+  const int64_t total = p.xblocks * p.splits, per_xcd = (total + 7) / 8;
+  const int64_t w = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (w >= total) return;
+  const int64_t bx = w % p.xblocks, by = w / p.xblocks;
+  const int64_t qbase = bx * (QB_WG * NQ) + wave * (32 * NQ) + r;
+
+  typename O::Frag qf[NQ];
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) O::load_queries(qf[n], p.Q, p.q0 + qbase + 32 * n, p.q0 + p.nq, p.D, h, true);
+
+  const int64_t c0 = by * p.chunks_per_split;
+  const int64_t c1 = (c0 + p.chunks_per_split < p.n_chunks) ? c0 + p.chunks_per_split : p.n_chunks;
+  const int64_t t0 = c0 * (CHUNK / CT), t1 = c1 * (CHUNK / CT);
+  const char* Cm = reinterpret_cast<const char*>(p.Cm);
+  const int64_t row_bytes = p.D * O::ESZ;
+
+  if (t0 < t1) {
+    corpus_tile_dma<DPX>(Cm, row_bytes, t0, p.C, smem, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  float best[NQ];
+  bool have = false;
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) best[n] = 0.f;
+  for (int64_t t = t0; t < t1; ++t) {
+    const int cur = (int)((t - t0) & 1);
+    float* nxt = smem + (cur ^ 1) * TILE_FLOATS;
+    if (t + 1 < t1) corpus_tile_dma<DPX>(Cm, row_bytes, t + 1, p.C, nxt, wave, lane);
+    const float* ys = smem + cur * TILE_FLOATS;
+    const int64_t chunk = t >> 1;
+    const bool full = (chunk + 1) * CHUNK <= p.C;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      f32x16 acc[NQ];
+      if constexpr (DT == TT_F32) {
+        acc[0] = score_tile<DPX, true>(ys, qf[0].v, jt, r, h);
+      } else {
+#pragma unroll
+        for (int n = 0; n < NQ; ++n)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
+        const int row = jt * 32 + r;
+#pragma unroll
+        for (int g = 0; g < DPX; ++g) {
+          const uint4 y = *reinterpret_cast<const uint4*>(ys + TM::chunk(row, 2 * g + h));
+#pragma unroll
+          for (int n = 0; n < NQ; ++n)
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, y), __builtin_bit_cast(bf16x8, qf[n].v[g]), acc[n], 0, 0, 0);
+        }
+      }
+      const int64_t b0 = chunk * CHUNK + 64 * h + 16 * (2 * (int)(t & 1) + jt);
+#pragma unroll
+      for (int n = 0; n < NQ; ++n) {
+        if (full) {
+          float m = fmaxf(fmaxf(acc[n][0], acc[n][1]), fmaxf(acc[n][2], acc[n][3]));
+#pragma unroll
+          for (int e = 4; e < 16; e += 4)
+            m = fmaxf(m, fmaxf(fmaxf(acc[n][e], acc[n][e + 1]), fmaxf(acc[n][e + 2], acc[n][e + 3])));
+          best[n] = have ? fmaxf(best[n], m) : m;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (b0 + e < p.C) best[n] = (have || e > 0) ? fmaxf(best[n], acc[n][e]) : acc[n][e];
+        }
+      }
+      // rows of one lane ascend with (tile, e): once the first row of this tile is in range
+      // (b0 < C) the lane holds a real score
+      have = have || full || b0 < p.C;
+    }
+    if (t & 1) {  // chunk complete: lane-half h holds group 2*chunk + h
+#pragma unroll
+      for (int n = 0; n < NQ; ++n) {
+        const int64_t ql = qbase + 32 * n;
+        if (ql < p.nq) p.gmax[(2 * chunk + h) * p.nq + ql] = have ? score_ord(best[n]) : 0u;
+      }
+      have = false;
+    }
+    if (t + 1 < t1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 }
@@ -630,6 +754,38 @@ static int dispatch_score(int dtype, int dpx, const MipsArgs& a, dim3 grid, hipS
   return launch_score<TT_BF16, 8, PASS>(a, grid, st);
 }
 
+template <int DT, int DPX, int NQ>
+static int launch_pass1_dma(MipsArgs a, int64_t, hipStream_t st) {
+  const size_t lds = 2 * (size_t)CT * 32 * DPX;
+  // 2 workgroups per CU are resident; aim at ~4 rounds of them
+  const int64_t xblocks = ceil_div(a.nq, QB_WG * NQ);
+  int64_t splits = ceil_div(2048, xblocks);
+  if (splits > a.n_chunks) splits = a.n_chunks;
+  a.chunks_per_split = ceil_div(a.n_chunks, splits);
+  splits = ceil_div(a.n_chunks, a.chunks_per_split);
+  a.xblocks = xblocks;
+  a.splits = splits;
+  const int64_t grid = 8 * ceil_div(xblocks * splits, 8);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mips_pass1_dma_kernel<DT, DPX, NQ>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { set_error("mips_pass1_dma_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+  ProfScope prof("mips_score_kernel", st);
+  mips_pass1_dma_kernel<DT, DPX, NQ><<<(unsigned)grid, 256, lds, st>>>(a);
+  return check_launch("mips_pass1_dma_kernel");
+}
+// -1: shape not covered by the DMA form
+static int dispatch_pass1_dma(int dtype, int dpx, const MipsArgs& a, int64_t splits, hipStream_t st) {
+  if (dtype == TT_F32) {
+    if (dpx == 4) return launch_pass1_dma<TT_F32, 4, 1>(a, splits, st);
+    if (dpx == 8) return launch_pass1_dma<TT_F32, 8, 1>(a, splits, st);
+    return launch_pass1_dma<TT_F32, 16, 1>(a, splits, st);
+  }
+  const bool two = a.nq > QB_WG;
+  if (dpx == 4) return two ? launch_pass1_dma<TT_BF16, 4, 2>(a, splits, st) : launch_pass1_dma<TT_BF16, 4, 1>(a, splits, st);
+  if (dpx == 8) return two ? launch_pass1_dma<TT_BF16, 8, 2>(a, splits, st) : launch_pass1_dma<TT_BF16, 8, 1>(a, splits, st);
+  return -1;  // bf16 D = 32: 4 chunks per row, below the swizzle's width
+}
+
 template <int DT, int DPX>
 static int launch_sparse(const MipsArgs& a, dim3 grid, hipStream_t st) {
   ProfScope prof("mips_sparse_kernel", st);
@@ -711,7 +867,10 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
     const int dp = pl.dpx * (dtype == TT_F32 ? 8 : 16);
     const bool sparse = pl.n_groups > K && vec && D == dp && !no_sparse;
     if (pl.n_groups > K) {  // otherwise tau = 0: every item is a candidate (cap == n_groups*64 >= C)
-      if ((rc = dispatch_score<1>(dtype, pl.dpx, a, grid, st))) return rc;
+      static const bool no_dma = getenv("TT_MIPS_NO_DMA") != nullptr;
+      rc = (vec && D == dp && !no_dma) ? dispatch_pass1_dma(dtype, pl.dpx, a, pl.splits, st) : -1;
+      if (rc == -1) rc = dispatch_score<1>(dtype, pl.dpx, a, grid, st);
+      if (rc) return rc;
       mips_select_init_kernel<<<(unsigned)ceil_div(nq * 256, 256), 256, 0, st>>>(ghist, want, done, nq, (int32_t)K);
       if ((rc = check_launch("mips_select_init_kernel"))) return rc;
       const int64_t qblocks = ceil_div(nq, SEL_Q);
