@@ -72,6 +72,8 @@ struct MipsArgs {
   int64_t q0, nq;      // this batch: queries q0 .. q0+nq
   int64_t chunks_per_split, n_chunks;
   uint32_t* gmax;      // [n_groups][nq] score_ord of the group max (0 = empty group)
+  uint32_t* gm2;       // [n_groups][nq] score_ord of the group's SECOND best score, or NULL
+  uint8_t* garg;       // [n_groups][nq] row offset (0..63) of the group's best item (first max)
   const u64* tau;      // [nq] K-th largest group key
   u64* cand;           // [nq][cap]
   int32_t* count;      // [nq]
@@ -320,7 +322,13 @@ __device__ __forceinline__ void corpus_tile_dma(const char* __restrict__ Cm, int
   }
 }
 
-template <int DT, int DPX, int NQ>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// STAGES: depth of the LDS tile ring.  A bf16 tile is 1024 MFMA cycles (0.4 us) of work per wave,
+// less than the global-memory latency, so one tile of prefetch (STAGES = 2) leaves the matrix
+// cores waiting for the DMA every iteration; fp32 tiles are 8x longer and 2 stages suffice.
+template <int DT, int DPX, int NQ, int STAGES>
 __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p) {
   using O = Op<DT, DPX>;
   using TM = TileMap<DPX, true>;  // row bytes = 32 * DPX for both dtypes
@@ -348,19 +356,25 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
   const char* Cm = reinterpret_cast<const char*>(p.Cm);
   const int64_t row_bytes = p.D * O::ESZ;
 
-  if (t0 < t1) {
-    corpus_tile_dma<DPX>(Cm, row_bytes, t0, p.C, smem, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
-  float best[NQ];
-  bool have = false;
+  constexpr int NI = CT / (64 / TM::CPR) / 4;  // DMA instructions per wave per tile
 #pragma unroll
-  for (int n = 0; n < NQ; ++n) best[n] = 0.f;
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (t0 + s < t1) corpus_tile_dma<DPX>(Cm, row_bytes, t0 + s, p.C, smem + s * TILE_FLOATS, wave, lane);
+  if (t0 + STAGES - 1 <= t1) wait_vmcnt<(STAGES - 2) * NI>();  // tile t0 has landed
+  else wait_vmcnt<0>();
+  __syncthreads();
+  // per group (= this lane-half's 64 rows of the chunk): best score, second best, offset of the
+  // first best.  med3(m1, m2, x) with m1 >= m2 is the new second best in one instruction.
+  constexpr float NEG_INF = -__builtin_huge_valf();
+  float m1[NQ], m2[NQ];
+  int arg[NQ];
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) { m1[n] = NEG_INF; m2[n] = NEG_INF; arg[n] = 0; }
   for (int64_t t = t0; t < t1; ++t) {
-    const int cur = (int)((t - t0) & 1);
-    float* nxt = smem + (cur ^ 1) * TILE_FLOATS;
-    if (t + 1 < t1) corpus_tile_dma<DPX>(Cm, row_bytes, t + 1, p.C, nxt, wave, lane);
+    const int cur = (int)((t - t0) % STAGES);
+    // the buffer of tile t-1 is free since the barrier that ended the previous iteration
+    const bool more = t + STAGES - 1 < t1;
+    if (more) corpus_tile_dma<DPX>(Cm, row_bytes, t + STAGES - 1, p.C, smem + ((cur + STAGES - 1) % STAGES) * TILE_FLOATS, wave, lane);
     const float* ys = smem + cur * TILE_FLOATS;
     const int64_t chunk = t >> 1;
     const bool full = (chunk + 1) * CHUNK <= p.C;
@@ -383,34 +397,38 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, y), __builtin_bit_cast(bf16x8, qf[n].v[g]), acc[n], 0, 0, 0);
         }
       }
-      const int64_t b0 = chunk * CHUNK + 64 * h + 16 * (2 * (int)(t & 1) + jt);
+      const int off0 = 16 * (2 * (int)(t & 1) + jt);  // group-relative row of element 0
+      const int64_t b0 = chunk * CHUNK + 64 * h + off0;
 #pragma unroll
       for (int n = 0; n < NQ; ++n) {
-        if (full) {
-          float m = fmaxf(fmaxf(acc[n][0], acc[n][1]), fmaxf(acc[n][2], acc[n][3]));
 #pragma unroll
-          for (int e = 4; e < 16; e += 4)
-            m = fmaxf(m, fmaxf(fmaxf(acc[n][e], acc[n][e + 1]), fmaxf(acc[n][e + 2], acc[n][e + 3])));
-          best[n] = have ? fmaxf(best[n], m) : m;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 16; ++e)
-            if (b0 + e < p.C) best[n] = (have || e > 0) ? fmaxf(best[n], acc[n][e]) : acc[n][e];
+        for (int e = 0; e < 16; ++e) {
+          float x = acc[n][e];
+          if (!full) x = (b0 + e < p.C) ? x : NEG_INF;
+          const bool gt = x > m1[n];  // strict: equal scores keep the earlier (smaller) row
+          m2[n] = __builtin_amdgcn_fmed3f(m1[n], m2[n], x);
+          m1[n] = fmaxf(m1[n], x);
+          arg[n] = gt ? off0 + e : arg[n];
         }
       }
-      // rows of one lane ascend with (tile, e): once the first row of this tile is in range
-      // (b0 < C) the lane holds a real score
-      have = have || full || b0 < p.C;
     }
     if (t & 1) {  // chunk complete: lane-half h holds group 2*chunk + h
+      const int64_t grp = 2 * chunk + h;
+      const bool nonempty = grp * GROUP < p.C;
 #pragma unroll
       for (int n = 0; n < NQ; ++n) {
         const int64_t ql = qbase + 32 * n;
-        if (ql < p.nq) p.gmax[(2 * chunk + h) * p.nq + ql] = have ? score_ord(best[n]) : 0u;
+        if (ql < p.nq) {
+          p.gmax[grp * p.nq + ql] = nonempty ? score_ord(m1[n]) : 0u;
+          p.gm2[grp * p.nq + ql] = nonempty ? score_ord(m2[n]) : 0u;
+          p.garg[grp * p.nq + ql] = (uint8_t)arg[n];
+        }
+        m1[n] = NEG_INF; m2[n] = NEG_INF; arg[n] = 0;
       }
-      have = false;
     }
-    if (t + 1 < t1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // tile t+1 must have landed; tiles t+2 .. t+STAGES-1 may still be in flight
+    if (more) wait_vmcnt<(STAGES - 2) * NI>();
+    else wait_vmcnt<0>();
     __syncthreads();
   }
 }
@@ -438,6 +456,18 @@ __global__ __launch_bounds__(256) void mips_sparse_kernel(const MipsArgs p) {
   for (int gi = blockIdx.y * 4 + wave; gi < n_sel; gi += nslots) {
     const uint32_t grp = (uint32_t)gl[gi];
     const int64_t row0 = (int64_t)grp * GROUP;
+    if (p.gm2) {
+      // pass 1 kept the group's two best scores: when the second best cannot qualify, the best
+      // item (score and row known) is the group's only candidate and nothing is re-scored
+      const int64_t at = (int64_t)grp * p.nq + ql;
+      if (ord_key(p.gm2[at], grp) < tau) {
+        if (lane == 0) {
+          const int pos = atomicAdd(&p.count[ql], 1);
+          if (pos < p.cap) p.cand[ql * p.cap + pos] = ord_key(p.gmax[at], (uint32_t)(row0 + p.garg[at]));
+        }
+        continue;
+      }
+    }
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
       int64_t arow = row0 + 32 * jt + r;
@@ -756,7 +786,8 @@ static int dispatch_score(int dtype, int dpx, const MipsArgs& a, dim3 grid, hipS
 
 template <int DT, int DPX, int NQ>
 static int launch_pass1_dma(MipsArgs a, int64_t, hipStream_t st) {
-  const size_t lds = 2 * (size_t)CT * 32 * DPX;
+  constexpr int STAGES = (DT == TT_BF16) ? 4 : 2;
+  const size_t lds = STAGES * (size_t)CT * 32 * DPX;
   // 2 workgroups per CU are resident; aim at ~4 rounds of them
   const int64_t xblocks = ceil_div(a.nq, QB_WG * NQ);
   int64_t splits = ceil_div(2048, xblocks);
@@ -766,11 +797,11 @@ static int launch_pass1_dma(MipsArgs a, int64_t, hipStream_t st) {
   a.xblocks = xblocks;
   a.splits = splits;
   const int64_t grid = 8 * ceil_div(xblocks * splits, 8);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mips_pass1_dma_kernel<DT, DPX, NQ>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mips_pass1_dma_kernel<DT, DPX, NQ, STAGES>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("mips_pass1_dma_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
   ProfScope prof("mips_score_kernel", st);
-  mips_pass1_dma_kernel<DT, DPX, NQ><<<(unsigned)grid, 256, lds, st>>>(a);
+  mips_pass1_dma_kernel<DT, DPX, NQ, STAGES><<<(unsigned)grid, 256, lds, st>>>(a);
   return check_launch("mips_pass1_dma_kernel");
 }
 // -1: shape not covered by the DMA form
@@ -780,9 +811,16 @@ static int dispatch_pass1_dma(int dtype, int dpx, const MipsArgs& a, int64_t spl
     if (dpx == 8) return launch_pass1_dma<TT_F32, 8, 1>(a, splits, st);
     return launch_pass1_dma<TT_F32, 16, 1>(a, splits, st);
   }
-  const bool two = a.nq > QB_WG;
-  if (dpx == 4) return two ? launch_pass1_dma<TT_BF16, 4, 2>(a, splits, st) : launch_pass1_dma<TT_BF16, 4, 1>(a, splits, st);
-  if (dpx == 8) return two ? launch_pass1_dma<TT_BF16, 8, 2>(a, splits, st) : launch_pass1_dma<TT_BF16, 8, 1>(a, splits, st);
+  static const int force_nq = getenv("TT_MIPS_NQ") ? atoi(getenv("TT_MIPS_NQ")) : 0;
+  const int nqf = force_nq ? force_nq : (a.nq > 2 * QB_WG ? 4 : a.nq > QB_WG ? 2 : 1);
+  if (dpx == 4) {
+    if (nqf == 4) return launch_pass1_dma<TT_BF16, 4, 4>(a, splits, st);
+    return nqf == 2 ? launch_pass1_dma<TT_BF16, 4, 2>(a, splits, st) : launch_pass1_dma<TT_BF16, 4, 1>(a, splits, st);
+  }
+  if (dpx == 8) {
+    if (nqf == 4) return launch_pass1_dma<TT_BF16, 8, 4>(a, splits, st);
+    return nqf == 2 ? launch_pass1_dma<TT_BF16, 8, 2>(a, splits, st) : launch_pass1_dma<TT_BF16, 8, 1>(a, splits, st);
+  }
   return -1;  // bf16 D = 32: 4 chunks per row, below the swizzle's width
 }
 
@@ -811,6 +849,8 @@ extern "C" int64_t tt_mips_workspace_bytes(int64_t B, int64_t C, int64_t D, int6
   MipsPlan pl;
   if (B <= 0 || C <= 0 || D <= 0 || K <= 0 || K > C || !plan_mips(B, C, D, K, dtype, pl)) return 256;
   return round_up(pl.n_groups * pl.qb * 4, 256)  // gmax
+         + round_up(pl.n_groups * pl.qb * 4, 256)  // second best per group
+         + round_up(pl.n_groups * pl.qb, 256)      // offset of the best per group
          + round_up(pl.qb * K * 4, 256)          // selected groups
          + round_up(pl.qb * 4, 256)              // their count
          + round_up(pl.n_groups * pl.qb * 8, 256) // select survivors (keys)
@@ -834,6 +874,8 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
   hipStream_t st = S(stream);
   Carver cv(ws);
   uint32_t* gmax = cv.take<uint32_t>(pl.n_groups * pl.qb);
+  uint32_t* gm2 = cv.take<uint32_t>(pl.n_groups * pl.qb);
+  uint8_t* garg = cv.take<uint8_t>(pl.n_groups * pl.qb);
   int32_t* glist = cv.take<int32_t>(pl.qb * K);
   int32_t* lcount = cv.take<int32_t>(pl.qb);
   u64* surv = cv.take<u64>(pl.n_groups * pl.qb);
@@ -859,6 +901,7 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
     a.chunks_per_split = pl.chunks_per_split; a.n_chunks = pl.n_chunks;
     a.gmax = gmax; a.tau = tau; a.cand = cand; a.count = count; a.cap = pl.cap; a.vec_ok = vec ? 1 : 0;
     a.glist = glist; a.lcount = lcount; a.K = K;
+    a.gm2 = gm2; a.garg = garg;
     dim3 grid((unsigned)ceil_div(nq, QB_WG), (unsigned)pl.splits);
     mips_zero_kernel<<<(unsigned)ceil_div(nq, 256), 256, 0, st>>>(tau, count, lcount, scount, nq);
     if ((rc = check_launch("mips_zero_kernel"))) return rc;
@@ -869,8 +912,13 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
     if (pl.n_groups > K) {  // otherwise tau = 0: every item is a candidate (cap == n_groups*64 >= C)
       static const bool no_dma = getenv("TT_MIPS_NO_DMA") != nullptr;
       rc = (vec && D == dp && !no_dma) ? dispatch_pass1_dma(dtype, pl.dpx, a, pl.splits, st) : -1;
-      if (rc == -1) rc = dispatch_score<1>(dtype, pl.dpx, a, grid, st);
+      if (rc == -1) {  // generic pass 1 keeps the group maxima only
+        a.gm2 = nullptr;
+        rc = dispatch_score<1>(dtype, pl.dpx, a, grid, st);
+      }
       if (rc) return rc;
+      static const bool no_top2 = getenv("TT_MIPS_NO_TOP2") != nullptr;  // A/B: re-score every selected group
+      if (no_top2) a.gm2 = nullptr;
       mips_select_init_kernel<<<(unsigned)ceil_div(nq * 256, 256), 256, 0, st>>>(ghist, want, done, nq, (int32_t)K);
       if ((rc = check_launch("mips_select_init_kernel"))) return rc;
       const int64_t qblocks = ceil_div(nq, SEL_Q);
