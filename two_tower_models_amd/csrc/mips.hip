@@ -453,34 +453,50 @@ __global__ __launch_bounds__(256) void mips_sparse_kernel(const MipsArgs p) {
   const char* base = reinterpret_cast<const char*>(p.Cm);
   const int64_t row_bytes = p.D * O::ESZ;
   const int nslots = gridDim.y * 4;
-  for (int gi = blockIdx.y * 4 + wave; gi < n_sel; gi += nslots) {
-    const uint32_t grp = (uint32_t)gl[gi];
-    const int64_t row0 = (int64_t)grp * GROUP;
-    if (p.gm2) {
-      // pass 1 kept the group's two best scores: when the second best cannot qualify, the best
-      // item (score and row known) is the group's only candidate and nothing is re-scored
-      const int64_t at = (int64_t)grp * p.nq + ql;
-      if (ord_key(p.gm2[at], grp) < tau) {
-        if (lane == 0) {
-          const int pos = atomicAdd(&p.count[ql], 1);
-          if (pos < p.cap) p.cand[ql * p.cap + pos] = ord_key(p.gmax[at], (uint32_t)(row0 + p.garg[at]));
-        }
-        continue;
+  const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // 64 selected groups per wave step, one per lane: the single-candidate groups (the usual case
+  // when pass 1 kept the runner-up scores) are emitted with one atomic per wave; the others are
+  // re-scored one after the other by the whole wave
+  for (int gbase = (blockIdx.y * 4 + wave) * 64; gbase < n_sel; gbase += nslots * 64) {
+    const int gi = gbase + lane;
+    const bool valid = gi < n_sel;
+    const uint32_t my_grp = valid ? (uint32_t)gl[gi] : 0u;
+    bool single = false;
+    int64_t at = 0;
+    if (p.gm2 && valid) {
+      at = (int64_t)my_grp * p.nq + ql;
+      single = ord_key(p.gm2[at], my_grp) < tau;  // the runner-up cannot qualify
+    }
+    const u64 smask = __ballot(single);
+    if (smask) {
+      int pos0 = 0;
+      if (lane == 0) pos0 = atomicAdd(&p.count[ql], __popcll(smask));
+      pos0 = __shfl(pos0, 0, 64);
+      if (single) {
+        const int pos = pos0 + __popcll(smask & lt_mask);
+        if (pos < p.cap) p.cand[ql * p.cap + pos] = ord_key(p.gmax[at], (uint32_t)((int64_t)my_grp * GROUP + p.garg[at]));
       }
     }
+    u64 todo = __ballot(valid && !single);
+    while (todo) {
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const uint32_t grp = (uint32_t)__shfl((int)my_grp, src, 64);
+      const int64_t row0 = (int64_t)grp * GROUP;
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-      int64_t arow = row0 + 32 * jt + r;
-      if (arow >= p.C) arow = p.C - 1;  // past the end: any valid row, its scores are ignored
-      const f32x16 acc = O::tile_at(base + arow * row_bytes + 16 * h, qf);
-      if (r == 0) {
+      for (int jt = 0; jt < 2; ++jt) {
+        int64_t arow = row0 + 32 * jt + r;
+        if (arow >= p.C) arow = p.C - 1;  // past the end: any valid row, its scores are ignored
+        const f32x16 acc = O::tile_at(base + arow * row_bytes + 16 * h, qf);
+        if (r == 0) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int64_t row = row0 + 32 * jt + (e & 3) + 8 * (e >> 2) + 4 * h;
-          const uint32_t ord = score_ord(acc[e]);
-          if (row < p.C && ord_key(ord, grp) >= tau) {
-            const int pos = atomicAdd(&p.count[ql], 1);
-            if (pos < p.cap) p.cand[ql * p.cap + pos] = ord_key(ord, (uint32_t)row);
+          for (int e = 0; e < 16; ++e) {
+            const int64_t row = row0 + 32 * jt + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const uint32_t ord = score_ord(acc[e]);
+            if (row < p.C && ord_key(ord, grp) >= tau) {
+              const int pos = atomicAdd(&p.count[ql], 1);
+              if (pos < p.cap) p.cand[ql * p.cap + pos] = ord_key(ord, (uint32_t)row);
+            }
           }
         }
       }
@@ -939,7 +955,8 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
     }
     if (sparse) {
       int64_t gsplit = ceil_div(8192, nq);  // ~8 K workgroups in flight whatever the batch size
-      if (gsplit > ceil_div(K, 4)) gsplit = ceil_div(K, 4);
+      const int64_t max_split = a.gm2 ? ceil_div(K, 4 * 64) : ceil_div(K, 4);  // a wave takes 64 groups per step
+      if (gsplit > max_split) gsplit = max_split;
       if (gsplit < 1) gsplit = 1;
       if ((rc = dispatch_sparse(dtype, pl.dpx, a, dim3((unsigned)nq, (unsigned)gsplit), st))) return rc;
     } else {
