@@ -3,9 +3,14 @@
 // VALU kernels for everything else.
 //
 // One WAVEFRONT owns one (sample, head); nothing is shared between waves, so the kernels
-// contain no workgroup barrier.  Q*scale, K, V (and dO in the backward) sit in the wave's own
-// LDS slice as row-major [64][dh+4] images (rows >= H are zero) and serve both operand forms
-// of the 32x32x2 fp32 MFMA:
+// contain no workgroup barrier.  The matrices that act as the MFMA A operand (and as the
+// element-wise Y of the PY product) sit in the wave's own LDS slice as row-major [64][dh+4]
+// images (rows >= H are zero); the matrix on the B side of an NT product is held in REGISTERS
+// as fragments loaded straight from global memory.  Only TWO images are resident per wave
+// (forward: K, V; backward: K, V in orientation 1, then Q*scale, dO in orientation 2 reuse the
+// same slice), 18 KiB at dh = 32, so 8 waves fit on a CU (2 per SIMD) -- with all operands in
+// LDS it was 4, every load and MFMA dependency exposed.  Both operand forms of the 32x32x2
+// fp32 MFMA:
 //   * "NT" product  D[x][y] = sum_d A[x][d] B[y][d]  (A-rows / B-rows fetched with
 //     ds_read_b128, four consecutive k per read, the k->(step, lane-half) permutation of
 //     gemm.hip) -- result layout: lane = y, registers = 16 values of x;
@@ -75,6 +80,40 @@ __device__ __forceinline__ f32x16 nt_tile(const float* A, int a0, const float* B
   return acc;
 }
 
+// B-side fragments of an NT product, straight from global memory: lane (r, h) holds row
+// `row` of the matrix, elements k = 8g + 4h + c (the k-permutation of nt_tile).  Rows >= H are 0.
+template <int DH>
+__device__ __forceinline__ void load_bfrag(float4 (&bf)[DH / 8], const float* __restrict__ src, int64_t ld, int row,
+                                           int H, float scale, int h) {
+#pragma unroll
+  for (int g = 0; g < DH / 8; ++g) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < H) {
+      v = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + 8 * g + 4 * h);
+      v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+    }
+    bf[g] = v;
+  }
+}
+// nt_tile with the B rows in registers (load_bfrag of rows b0 + r)
+template <int DH>
+__device__ __forceinline__ f32x16 nt_tile_rb(const float* A, int a0, const float4 (&bf)[DH / 8], int r, int h) {
+  constexpr int LD = DH + 4;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const float* ap = A + (a0 + r) * LD + 4 * h;
+#pragma unroll
+  for (int g = 0; g < DH / 8; ++g) {
+    const float4 a = *reinterpret_cast<const float4*>(ap + 8 * g);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bf[g].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bf[g].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bf[g].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bf[g].w, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
 // out[dt][x][d] += sum over the 32 y of this tile: G[x][y0 + y] * Y[y0 + y][32*dt + d]
 // G: an NT result (lane = x, registers = y).  out layout: lane&31 = d, registers = x rows.
 template <int DH>
@@ -121,13 +160,11 @@ __global__ __launch_bounds__(64 * WAVES) void attn_fwd_mfma_kernel(const float* 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int64_t pair = (int64_t)blockIdx.x * WAVES + wave;
   if (pair >= n_pairs) return;
-  float* Qs = reinterpret_cast<float*>(smem_raw) + wave * 3 * L::MAT;
-  float* Ks = Qs + L::MAT;
+  float* Ks = reinterpret_cast<float*>(smem_raw) + wave * 2 * L::MAT;
   float* Vs = Ks + L::MAT;
   const int64_t b = pair / heads, hd = pair % heads;
   const float* base = qkv + b * H * 3 * (int64_t)D + hd * DH;
   const float scale = 1.0f / sqrtf((float)DH);
-  stage<DH>(Qs, base, 3 * D, H, scale, lane);
   stage<DH>(Ks, base + D, 3 * D, H, 1.f, lane);
   stage<DH>(Vs, base + 2 * D, 3 * D, H, 1.f, lane);
   __builtin_amdgcn_wave_barrier();
@@ -135,11 +172,13 @@ __global__ __launch_bounds__(64 * WAVES) void attn_fwd_mfma_kernel(const float* 
   float* out = ctx + b * H * (int64_t)D + hd * DH;
 #pragma unroll
   for (int it = 0; it < 2; ++it) {  // 32 queries at a time: lane r <-> query it*32 + r
+    float4 qf[DH / 8];
+    load_bfrag<DH>(qf, base, 3 * D, it * 32 + r, H, scale, h);
     f32x16 st[2];
     float mx = -3.0e38f;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
-      st[jt] = nt_tile<DH>(Ks, jt * 32, Qs, it * 32, r, h);
+      st[jt] = nt_tile_rb<DH>(Ks, jt * 32, qf, r, h);
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const bool valid = jt * 32 + arow(e, h) < H;
@@ -184,24 +223,23 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_mfma_kernel(const float* 
                                                                    float* __restrict__ d_qkv) {
   using L = AttnLds<DH>;
   constexpr int TD = (DH + 31) / 32;
-  constexpr int PER_WAVE = 4 * L::MAT + 2 * HP;  // Qs, K, V, dO images + lse[64] + delta[64]
+  constexpr int PER_WAVE = 2 * L::MAT + 2 * HP;  // two images (K, V then Qs, dO) + lse[64] + delta[64]
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int64_t pair = (int64_t)blockIdx.x * WAVES + wave;
   if (pair >= n_pairs) return;
-  float* Qs = reinterpret_cast<float*>(smem_raw) + wave * PER_WAVE;
-  float* Ks = Qs + L::MAT;
-  float* Vs = Ks + L::MAT;
-  float* Gs = Vs + L::MAT;   // dO
-  float* Ls = Gs + L::MAT;   // lse per query row (+huge for padding rows -> P = 0)
+  float* M0 = reinterpret_cast<float*>(smem_raw) + wave * PER_WAVE;
+  float* M1 = M0 + L::MAT;
+  float* Ls = M1 + L::MAT;   // lse per query row (+huge for padding rows -> P = 0)
   float* Ds = Ls + HP;       // delta per query row
   const int64_t b = pair / heads, hd = pair % heads;
   const float* base = qkv + b * H * 3 * (int64_t)D + hd * DH;
+  const float* gbase = d_ctx + b * H * (int64_t)D + hd * DH;
   const float scale = 1.0f / sqrtf((float)DH);
-  stage<DH>(Qs, base, 3 * D, H, scale, lane);
+  float* Ks = M0;
+  float* Vs = M1;
   stage<DH>(Ks, base + D, 3 * D, H, 1.f, lane);
   stage<DH>(Vs, base + 2 * D, 3 * D, H, 1.f, lane);
-  stage<DH>(Gs, d_ctx + b * H * (int64_t)D + hd * DH, D, H, 1.f, lane);
   Ls[lane] = (lane < H) ? lse[(b * heads + hd) * H + lane] : 3.0e38f;
   __builtin_amdgcn_wave_barrier();
   float* obase = d_qkv + b * H * 3 * (int64_t)D + hd * DH;
@@ -211,12 +249,15 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_mfma_kernel(const float* 
   for (int it = 0; it < 2; ++it) {
     const int i = it * 32 + r;
     const float li = Ls[i];
+    float4 qf[DH / 8], gf[DH / 8];
+    load_bfrag<DH>(qf, base, 3 * D, i, H, scale, h);
+    load_bfrag<DH>(gf, gbase, D, i, H, 1.f, h);
     f32x16 pt[2], dpt[2];
     float dl = 0.f;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
-      pt[jt] = nt_tile<DH>(Ks, jt * 32, Qs, it * 32, r, h);   // St[j][i]
-      dpt[jt] = nt_tile<DH>(Vs, jt * 32, Gs, it * 32, r, h);  // dPt[j][i] = V_j . dO_i
+      pt[jt] = nt_tile_rb<DH>(Ks, jt * 32, qf, r, h);   // St[j][i]
+      dpt[jt] = nt_tile_rb<DH>(Vs, jt * 32, gf, r, h);  // dPt[j][i] = V_j . dO_i
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const bool valid = jt * 32 + arow(e, h) < H;
@@ -241,10 +282,19 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_mfma_kernel(const float* 
   }
   __builtin_amdgcn_wave_barrier();
 
-  // ---- orientation 2: lane = key j.  dV and dK (reductions over the queries i).
+  // ---- orientation 2: lane = key j.  dV and dK (reductions over the queries i).  The slice now
+  // holds Q*scale and dO (A operands and PY sources); K and V move to registers.
+  float* Qs = M0;
+  float* Gs = M1;
+  stage<DH>(Qs, base, 3 * D, H, scale, lane);
+  stage<DH>(Gs, gbase, D, H, 1.f, lane);
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int jt = 0; jt < 2; ++jt) {
     const bool jvalid = jt * 32 + r < H;
+    float4 kf[DH / 8], vf[DH / 8];
+    load_bfrag<DH>(kf, base + D, 3 * D, jt * 32 + r, H, 1.f, h);
+    load_bfrag<DH>(vf, base + 2 * D, 3 * D, jt * 32 + r, H, 1.f, h);
     f32x16 dv[TD], dk[TD];
 #pragma unroll
     for (int d = 0; d < TD; ++d)
@@ -252,8 +302,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_mfma_kernel(const float* 
       for (int e = 0; e < 16; ++e) { dv[d][e] = 0.f; dk[d][e] = 0.f; }
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      f32x16 p = nt_tile<DH>(Qs, it * 32, Ks, jt * 32, r, h);    // S[i][j]
-      f32x16 dp = nt_tile<DH>(Gs, it * 32, Vs, jt * 32, r, h);   // dP[i][j] = dO_i . V_j
+      f32x16 p = nt_tile_rb<DH>(Qs, it * 32, kf, r, h);    // S[i][j]
+      f32x16 dp = nt_tile_rb<DH>(Gs, it * 32, vf, r, h);   // dP[i][j] = dO_i . V_j
       const float* lrow = Ls + it * 32 + 4 * h;
       const float* drow = Ds + it * 32 + 4 * h;
 #pragma unroll
@@ -287,8 +337,8 @@ static int lds_opt_in(K kernel, size_t lds, const char* name) {
 
 template <int DH>
 static int launch_fwd(const float* qkv, int64_t n_pairs, int H, int D, int heads, float* ctx, float* lse, hipStream_t st) {
-  constexpr int WAVES = (DH <= 32) ? 4 : 2;
-  const size_t lds = (size_t)WAVES * 3 * AttnLds<DH>::MAT * sizeof(float);
+  constexpr int WAVES = 4;
+  const size_t lds = (size_t)WAVES * 2 * AttnLds<DH>::MAT * sizeof(float);
   int rc = lds_opt_in(attn_fwd_mfma_kernel<DH, WAVES>, lds, "attn_fwd_mfma_kernel");
   if (rc) return rc;
   ProfScope prof("attn_fwd_mfma_kernel", st);
@@ -298,8 +348,8 @@ static int launch_fwd(const float* qkv, int64_t n_pairs, int H, int D, int heads
 template <int DH>
 static int launch_bwd(const float* qkv, const float* lse, const float* d_ctx, int64_t n_pairs, int H, int D, int heads,
                       float* d_qkv, hipStream_t st) {
-  constexpr int WAVES = (DH <= 32) ? 2 : 1;
-  const size_t lds = (size_t)WAVES * (4 * AttnLds<DH>::MAT + 2 * HP) * sizeof(float);
+  constexpr int WAVES = (DH <= 32) ? 4 : 2;
+  const size_t lds = (size_t)WAVES * (2 * AttnLds<DH>::MAT + 2 * HP) * sizeof(float);
   int rc = lds_opt_in(attn_bwd_mfma_kernel<DH, WAVES>, lds, "attn_bwd_mfma_kernel");
   if (rc) return rc;
   ProfScope prof("attn_bwd_mfma_kernel", st);
