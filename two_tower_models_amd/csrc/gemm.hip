@@ -280,7 +280,10 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
   const int64_t ktiles = ceil_div(K, BK);
   int64_t splits = 1;
   if (tiles < 256 && ktiles >= 16) {
-    splits = ceil_div(512, tiles);
+    // 2 workgroups of the 128^2 kernel are resident per CU: tiles * splits must not EXCEED the
+    // 512 slots, or one straggler workgroup runs a second round on an otherwise idle GPU
+    // (3 tiles x 171 splits = 513 cost 2x; measured on the 384x128x204800 dW GEMM)
+    splits = 512 / tiles;
     if (splits > ktiles / 4) splits = ktiles / 4;  // at least 4 K-tiles per split
     if (splits > 256) splits = 256;
     if (splits < 1) splits = 1;
