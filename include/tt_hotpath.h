@@ -85,6 +85,12 @@ int tt_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, const float* A, int
                 const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
                 int epilogue, const float* aux, int64_t ldaux, int accumulate, void* ws,
                 int64_t ws_bytes, tt_stream_t stream);
+/* The weight-gradient GEMM with the bias gradient for free: C = A^T B (TT_GEMM_TN, A = dy [K,M],
+ * B = x [K,N]) and a_colsum[m] = sum_k A[k,m] (= db) from the same pass over A.  Same workspace
+ * as tt_gemm_f32 (tt_gemm_workspace_bytes(TT_GEMM_TN, M, N, K)); deterministic. */
+int tt_gemm_tn_colsum_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                          int64_t ldb, float* C, int64_t ldc, int accumulate, float* a_colsum, void* ws,
+                          int64_t ws_bytes, tt_stream_t stream);
 
 /* out[n] = sum_m X[m,n]  (bias gradients), deterministic two-stage reduction */
 int64_t tt_colsum_workspace_bytes(int64_t M, int64_t N);

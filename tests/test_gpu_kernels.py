@@ -62,6 +62,28 @@ def test_gemm_epilogues_strided_and_accumulate(T):
     assert torch.allclose(out2.cpu().double(), ref * (aux > 0) + ref, atol=2e-4)
 
 
+@pytest.mark.parametrize("rows,n_out,k_in", [(5000, 96, 40), (70000, 384, 128), (300, 130, 64), (33, 7, 5)])
+def test_gemm_tn_with_fused_column_sum(T, rows, n_out, k_in):
+    """tt_gemm_tn_colsum_f32: dW = dy^T x and db = column sums of dy from one pass (split-K and
+    single-pass shapes, 64^2 and 128^2 tiles, ragged edges, strided operands)."""
+    ops, N = T
+    dy_full, x = g((rows, n_out + 4), 301), g((rows, k_in), 302)
+    dy = dy_full[:, 4:]
+    dW = torch.empty(n_out, k_in, device=DEV)
+    dyd = dy_full.to(DEV)[:, 4:]
+    _, db = ops.gemm_tn_colsum(dyd, x.to(DEV), dW)
+    ref_w = dy.double().t() @ x.double()
+    ref_b = dy.double().sum(0)
+    assert float((dW.cpu().double() - ref_w).abs().max()) < 3e-6 * math.sqrt(rows) * max(1.0, float(ref_w.abs().max()))
+    assert float((db.cpu().double() - ref_b).abs().max()) < 3e-6 * math.sqrt(rows) * max(1.0, float(ref_b.abs().max()))
+    # the fused product equals the plain TN GEMM bit for bit, and the sum is deterministic
+    plain = torch.empty(n_out, k_in, device=DEV)
+    ops.gemm(N.TT_GEMM_TN, dyd, x.to(DEV), plain, n_out, k_in, rows)
+    assert torch.equal(plain, dW)
+    _, db2 = ops.gemm_tn_colsum(dyd, x.to(DEV), torch.empty_like(dW))
+    assert torch.equal(db, db2)
+
+
 def test_colsum(T):
     ops, N = T
     X = g((1000, 300), 9)

@@ -50,6 +50,7 @@ SIGNATURES = {
     "tt_gemm_workspace_bytes": (_i64, [_int, _i64, _i64, _i64]),
     "tt_gemm_f32": (_int, [_int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _int, _vp,
                            _i64, _int, _vp, _i64, _vp]),
+    "tt_gemm_tn_colsum_f32": (_int, [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _vp, _i64, _vp]),
     "tt_colsum_workspace_bytes": (_i64, [_i64, _i64]),
     "tt_colsum_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp]),
     "tt_inbatch_ce_workspace_bytes": (_i64, [_i64, _i64, _i64]),

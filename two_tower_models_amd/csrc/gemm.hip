@@ -35,6 +35,7 @@ struct GemmArgs {
   int64_t M, N, K, lda, ldb, ldc, ldaux;
   int64_t k_per_split;  // multiple of BK
   int epilogue, accumulate, a_vec, b_vec, splits;
+  float* a_colsum;      // TN only, optional: [splits][M] partial column sums of A (sum over k)
 };
 
 // ---- global -> register staging -------------------------------------------
@@ -141,6 +142,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     if constexpr (B_KC) store_kc<BN>(sb, b_d); else store_rc<BN>(sb, b_d);
   };
 
+  // TN with a_colsum: the workgroups of the first column block also sum the A tile over k
+  // (A = dY in a weight-gradient GEMM, so this is the bias gradient -- dY is read once)
+  const bool do_colsum = !A_KC && g.a_colsum != nullptr && blockIdx.x == 0;
+  float csum = 0.f;
+
   const int64_t ntiles = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
   if (ntiles > 0) {
     fetch(kbeg);
@@ -152,6 +158,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     if (t + 1 < ntiles) fetch(kbeg + (t + 1) * BK);
     const float* a_s = smem + cur * STAGE_FLOATS;
     const float* b_s = a_s + A_FLOATS;
+    if constexpr (!A_KC) {
+      if (do_colsum) {  // thread -> column t % BM, k rows t / BM, + 256/BM, ... (zero padded)
+#pragma unroll
+        for (int q = 0; q < BK * BM / 256; ++q) csum += a_s[(q * (256 / BM) + threadIdx.x / BM) * BM + threadIdx.x % BM];
+      }
+    }
 #pragma unroll
     for (int grp = 0; grp < BK / 8; ++grp) {
       float av[TM][4], bv[TN][4];
@@ -185,6 +197,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     }
     if (t + 1 < ntiles) commit(cur ^ 1);
     __syncthreads();
+  }
+
+  if constexpr (!A_KC) {
+    if (do_colsum) {  // combine the 256/BM k-groups in a fixed order (the LDS tiles are dead now)
+      smem[threadIdx.x] = csum;
+      __syncthreads();
+      if (threadIdx.x < BM && m0 + threadIdx.x < g.M) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 256 / BM; ++q) v += smem[q * BM + threadIdx.x];
+        g.a_colsum[(int64_t)blockIdx.z * g.M + m0 + threadIdx.x] = v;
+      }
+    }
   }
 
   // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -325,13 +350,14 @@ extern "C" int64_t tt_gemm_workspace_bytes(int layout, int64_t M, int64_t N, int
   (void)layout;
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const GemmPlan p = plan_gemm(M, N, K);
-  return p.splits > 1 ? round_up((int64_t)p.splits * M * N * (int64_t)sizeof(float), 256) : 0;
+  // split-K slabs + (tt_gemm_tn_colsum_f32) one row of column-sum partials per split
+  return p.splits > 1 ? round_up((int64_t)p.splits * M * (N + 1) * (int64_t)sizeof(float), 256) : 0;
 }
 
-extern "C" int tt_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
-                           const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
-                           int epilogue, const float* aux, int64_t ldaux, int accumulate, void* ws,
-                           int64_t ws_bytes, tt_stream_t stream) {
+static int gemm_impl(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                     const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                     int epilogue, const float* aux, int64_t ldaux, int accumulate, float* a_colsum, void* ws,
+                     int64_t ws_bytes, tt_stream_t stream) {
   if (!A || !B || !C) return fail_arg("tt_gemm_f32: null pointer");
   if (M < 0 || N < 0 || K < 0 || ldc < N) return fail_arg("tt_gemm_f32: sizes");
   if (layout < TT_GEMM_NT || layout > TT_GEMM_TN) return fail_arg("tt_gemm_f32: layout");
@@ -340,11 +366,12 @@ extern "C" int tt_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, const fl
   const bool a_kc = layout != TT_GEMM_TN, b_kc = layout == TT_GEMM_NT;
   if (lda < (a_kc ? K : M) || ldb < (b_kc ? K : N)) return fail_arg("tt_gemm_f32: leading dimension");
 
-  {
+  if (!a_colsum) {
     const int rc_ws = gemm_ws_try(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, aux, ldaux, accumulate, S(stream));
     if (rc_ws != -100) return rc_ws;
   }
   GemmArgs g;
+  g.a_colsum = nullptr;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
   g.epilogue = epilogue; g.accumulate = accumulate;
@@ -356,11 +383,14 @@ extern "C" int tt_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, const fl
   hipStream_t st = S(stream);
 
   GemmArgs gk = g;
+  float* cs_part = nullptr;
   if (g.splits > 1) {
-    const int64_t need = round_up((int64_t)g.splits * M * N * (int64_t)sizeof(float), 256);
+    const int64_t need = round_up((int64_t)g.splits * M * (N + 1) * (int64_t)sizeof(float), 256);
     if (!ws || ws_bytes < need) { set_error("tt_gemm_f32: workspace %lld < %lld", (long long)ws_bytes, (long long)need); return TT_E_WORKSPACE; }
     gk.C = reinterpret_cast<float*>(ws);
+    cs_part = reinterpret_cast<float*>(ws) + (int64_t)g.splits * M * N;
   }
+  if (a_colsum) gk.a_colsum = g.splits > 1 ? cs_part : a_colsum;
   int rc;
 #define TT_DISPATCH(BMv, BNv)                                                        \
   (layout == TT_GEMM_NT   ? launch_gemm<BMv, BNv, true, true>(gk, st)                \
@@ -373,9 +403,30 @@ extern "C" int tt_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, const fl
     const int64_t total = M * N;
     const int64_t blocks = ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048;
     splitk_reduce_kernel<<<blocks, 256, 0, st>>>(reinterpret_cast<const float*>(ws), g);
-    return check_launch("splitk_reduce_kernel");
+    if ((rc = check_launch("splitk_reduce_kernel"))) return rc;
+    if (a_colsum) {  // per-split partials -> column sums, in split order
+      colsum_stage2<<<(unsigned)ceil_div(M, 64), 256, 0, st>>>(cs_part, g.splits, M, a_colsum);
+      return check_launch("colsum_stage2");
+    }
   }
   return 0;
+}
+
+extern "C" int tt_gemm_f32(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                           const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                           int epilogue, const float* aux, int64_t ldaux, int accumulate, void* ws,
+                           int64_t ws_bytes, tt_stream_t stream) {
+  return gemm_impl(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, aux, ldaux, accumulate, nullptr, ws,
+                   ws_bytes, stream);
+}
+
+extern "C" int tt_gemm_tn_colsum_f32(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                                     int64_t ldb, float* C, int64_t ldc, int accumulate, float* a_colsum, void* ws,
+                                     int64_t ws_bytes, tt_stream_t stream) {
+  if (!a_colsum) return fail_arg("tt_gemm_tn_colsum_f32: null pointer");
+  if (K <= 0) return fail_arg("tt_gemm_tn_colsum_f32: sizes");
+  return gemm_impl(TT_GEMM_TN, M, N, K, A, lda, B, ldb, C, ldc, nullptr, TT_EPI_NONE, nullptr, 0, accumulate,
+                   a_colsum, ws, ws_bytes, stream);
 }
 
 extern "C" int64_t tt_colsum_workspace_bytes(int64_t M, int64_t N) {

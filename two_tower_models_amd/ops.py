@@ -55,6 +55,23 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, M: in
     return out
 
 
+def gemm_tn_colsum(dy: torch.Tensor, x: torch.Tensor, dW: torch.Tensor, accumulate: bool = False,
+                   db: Optional[torch.Tensor] = None):
+    """Weight gradient and bias gradient of y = x W^T + b in one pass over dy:
+    dW[N_out, K_in] (+)= dy^T x,  db[N_out] = sum over rows of dy  (tt_gemm_tn_colsum_f32)."""
+    dev = N.require_device(dy, x, dW)
+    lib = N.load()
+    pa, Mrows, Nout, lda = _f32_2d(dy, "dy")
+    pb, _, Kin, ldb = _f32_2d(x, "x")
+    pc, _, _, ldc = _f32_2d(dW, "dW")
+    if db is None:
+        db = torch.empty(Nout, dtype=torch.float32, device=dev)
+    wsp, wsn = _ws(dev, lib.tt_gemm_workspace_bytes(N.TT_GEMM_TN, Nout, Kin, Mrows))
+    N.check(lib.tt_gemm_tn_colsum_f32(Nout, Kin, Mrows, pa, lda, pb, ldb, pc, ldc, 1 if accumulate else 0,
+                                      db.data_ptr(), wsp, wsn, N.stream()), "tt_gemm_tn_colsum_f32")
+    return dW, db
+
+
 def colsum(X: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     dev = N.require_device(X)
     lib = N.load()
@@ -258,8 +275,7 @@ class Linear(torch.autograd.Function):
             dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
             gemm(N.TT_GEMM_NN, dy, W, dx, M, K, Nn)
         dW = torch.empty(Nn, K, dtype=torch.float32, device=dy.device)
-        gemm(N.TT_GEMM_TN, dy, x, dW, Nn, K, M)
-        db = colsum(dy)
+        _, db = gemm_tn_colsum(dy, x, dW)
         return dx, dW, db
 
 
@@ -287,13 +303,11 @@ class FeatureMLP(torch.autograd.Function):
         B, F = feats.shape
         Dm, Hd = W2.shape
         dW2 = torch.empty(Dm, Hd, dtype=torch.float32, device=dev)
-        gemm(N.TT_GEMM_TN, dy, h, dW2, Dm, Hd, B)
-        db2 = colsum(dy)
+        _, db2 = gemm_tn_colsum(dy, h, dW2)
         dh = torch.empty(B, Hd, dtype=torch.float32, device=dev)
         gemm(N.TT_GEMM_NN, dy, W2, dh, B, Hd, Dm, epilogue=N.TT_EPI_RELU_MASK, aux=h)
         dW1 = torch.empty(Hd, F, dtype=torch.float32, device=dev)
-        gemm(N.TT_GEMM_TN, dh, feats, dW1, Hd, F, B)
-        db1 = colsum(dh)
+        _, db1 = gemm_tn_colsum(dh, feats, dW1)
         dfe = None
         if ctx.needs_input_grad[0]:
             dfe = torch.empty(B, F, dtype=torch.float32, device=dev)
@@ -335,13 +349,11 @@ class TowerInput(torch.autograd.Function):
         Dm, Hd = W2.shape
         d_f = d_tin[:, D:]
         dW2 = torch.empty(Dm, Hd, dtype=torch.float32, device=dev)
-        gemm(N.TT_GEMM_TN, d_f, h, dW2, Dm, Hd, B)
-        db2 = colsum(d_f)
+        _, db2 = gemm_tn_colsum(d_f, h, dW2)
         dh = torch.empty(B, Hd, dtype=torch.float32, device=dev)
         gemm(N.TT_GEMM_NN, d_f, W2, dh, B, Hd, Dm, epilogue=N.TT_EPI_RELU_MASK, aux=h)
         dW1 = torch.empty(Hd, F, dtype=torch.float32, device=dev)
-        gemm(N.TT_GEMM_TN, dh, feats, dW1, Hd, F, B)
-        db1 = colsum(dh)
+        _, db1 = gemm_tn_colsum(dh, feats, dW1)
         dweight = None
         if ctx.needs_input_grad[0]:
             dweight = _route_table_grad(w, ids.reshape(-1), d_tin[:, :D], ctx.lookup_index)
@@ -494,21 +506,18 @@ class HistoryEncoder(torch.autograd.Function):
             dW_out = torch.empty(D, D, dtype=torch.float32, device=dev)
             if l == L - 1:
                 rows0 = ctx_t.view(B, H * D)[:, :D]
-                gemm(N.TT_GEMM_TN, d_recent, rows0, dW_out, D, D, B)
-                db_out = colsum(d_recent)
+                _, db_out = gemm_tn_colsum(d_recent, rows0, dW_out)
                 d_ctx = torch.zeros(B * H, D, dtype=torch.float32, device=dev)
                 gemm(N.TT_GEMM_NN, d_recent, w_out, d_ctx.view(B, H * D)[:, :D], B, D, D)
             else:
-                gemm(N.TT_GEMM_TN, dx, ctx_t, dW_out, D, D, B * H)
-                db_out = colsum(dx)
+                _, db_out = gemm_tn_colsum(dx, ctx_t, dW_out)
                 d_ctx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
                 gemm(N.TT_GEMM_NN, dx, w_out, d_ctx, B * H, D, D)
             d_qkv = torch.empty(B * H, 3 * D, dtype=torch.float32, device=dev)
             N.check(lib.tt_attn_bwd(qkv.data_ptr(), ctx_t.data_ptr(), lse.data_ptr(), d_ctx.data_ptr(), B, H, D,
                                     heads, d_qkv.data_ptr(), N.stream()), "tt_attn_bwd")
             dW_in = torch.empty(3 * D, D, dtype=torch.float32, device=dev)
-            gemm(N.TT_GEMM_TN, d_qkv, x, dW_in, 3 * D, D, B * H)
-            db_in = colsum(d_qkv)
+            _, db_in = gemm_tn_colsum(d_qkv, x, dW_in)
             dx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
             gemm(N.TT_GEMM_NN, d_qkv, w_in, dx, B * H, D, 3 * D)
             grads[4 * l: 4 * l + 4] = [dW_in, db_in, dW_out, db_out]

@@ -160,19 +160,16 @@ class HipBackend:
         Dm, Hd = W2.shape
         Do, Din = W3.shape
         De = Din - Dm
-        ops.gemm(N.TT_GEMM_TN, d_out, emb, gW3[:, :De], Do, De, B)
+        ops.gemm_tn_colsum(d_out, emb, gW3[:, :De], db=gb3)
         ops.gemm(N.TT_GEMM_TN, d_out, f, gW3[:, De:], Do, Dm, B)
-        ops.colsum(d_out, gb3)
         d_emb = self.empty(B, De)
         ops.gemm(N.TT_GEMM_NN, d_out, W3[:, :De], d_emb, B, De, Do)
         d_f = self.empty(B, Dm)
         ops.gemm(N.TT_GEMM_NN, d_out, W3[:, De:], d_f, B, Dm, Do)
-        ops.gemm(N.TT_GEMM_TN, d_f, h, gW2, Dm, Hd, B)
-        ops.colsum(d_f, gb2)
+        ops.gemm_tn_colsum(d_f, h, gW2, db=gb2)
         dh = self.empty(B, Hd)
         ops.gemm(N.TT_GEMM_NN, d_f, W2, dh, B, Hd, Dm, epilogue=N.TT_EPI_RELU_MASK, aux=h)
-        ops.gemm(N.TT_GEMM_TN, dh, feats, gW1, Hd, F, B)
-        ops.colsum(dh, gb1)
+        ops.gemm_tn_colsum(dh, feats, gW1, db=gb1)
         return d_emb
 
     def ce_fwd(self, U, I_all, off):
