@@ -17,6 +17,8 @@
 //     slots (odd) makes the b128 reads bank-conflict free.
 //   row-contiguous operand ([K][rows] in memory): [32][rows] floats, lanes read
 //     consecutive rows with ds_read_b32 (conflict free by construction).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace tt {
@@ -40,7 +42,10 @@ struct GemmArgs {
 
 // ---- global -> register staging -------------------------------------------
 // k-contiguous operand: element (row, k) at X[row*ld + k]
-template <int ROWS>
+// FULL: the tile lies inside the operand and rows are 16-B aligned -> plain vector loads.  The
+// general form guards every element, and hipcc then waits for each load before the next guard
+// (one fully exposed memory round trip per load), so interior tiles must not take it.
+template <int ROWS, bool FULL>
 __device__ __forceinline__ void load_kc(float4 (&st)[ROWS * 8 / 256], const float* __restrict__ X,
                                         int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
                                         int64_t kend, bool vec) {
@@ -48,19 +53,24 @@ __device__ __forceinline__ void load_kc(float4 (&st)[ROWS * 8 / 256], const floa
   for (int i = 0; i < ROWS * 8 / 256; ++i) {
     const int f = threadIdx.x + 256 * i;
     const int64_t row = row0 + f / 8, k = k0 + 4 * (f % 8);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < nrows) {
+    if constexpr (FULL) {
       const float* p = X + row * ld + k;
-      if (vec && k + 3 < kend) {
-        v = *reinterpret_cast<const float4*>(p);
-      } else {
-        if (k + 0 < kend) v.x = p[0];
-        if (k + 1 < kend) v.y = p[1];
-        if (k + 2 < kend) v.z = p[2];
-        if (k + 3 < kend) v.w = p[3];
+      st[i] = make_float4(p[0], p[1], p[2], p[3]);  // one global_load_dwordx4 (16-B aligned by contract)
+    } else {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < nrows) {
+        const float* p = X + row * ld + k;
+        if (vec && k + 3 < kend) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (k + 0 < kend) v.x = p[0];
+          if (k + 1 < kend) v.y = p[1];
+          if (k + 2 < kend) v.z = p[2];
+          if (k + 3 < kend) v.w = p[3];
+        }
       }
+      st[i] = v;
     }
-    st[i] = v;
   }
 }
 template <int ROWS>
@@ -72,7 +82,7 @@ __device__ __forceinline__ void store_kc(const float4 (&st)[ROWS * 8 / 256], flo
   }
 }
 // row-contiguous operand: element (row, k) at X[k*ld + row]
-template <int ROWS>
+template <int ROWS, bool FULL>
 __device__ __forceinline__ void load_rc(float4 (&st)[ROWS * 8 / 256], const float* __restrict__ X,
                                         int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
                                         int64_t kend, bool vec) {
@@ -80,19 +90,24 @@ __device__ __forceinline__ void load_rc(float4 (&st)[ROWS * 8 / 256], const floa
   for (int i = 0; i < ROWS * 8 / 256; ++i) {
     const int f = threadIdx.x + 256 * i;
     const int64_t k = k0 + f / (ROWS / 4), row = row0 + 4 * (f % (ROWS / 4));
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k < kend) {
+    if constexpr (FULL) {
       const float* p = X + k * ld + row;
-      if (vec && row + 3 < nrows) {
-        v = *reinterpret_cast<const float4*>(p);
-      } else {
-        if (row + 0 < nrows) v.x = p[0];
-        if (row + 1 < nrows) v.y = p[1];
-        if (row + 2 < nrows) v.z = p[2];
-        if (row + 3 < nrows) v.w = p[3];
+      st[i] = make_float4(p[0], p[1], p[2], p[3]);
+    } else {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < kend) {
+        const float* p = X + k * ld + row;
+        if (vec && row + 3 < nrows) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (row + 0 < nrows) v.x = p[0];
+          if (row + 1 < nrows) v.y = p[1];
+          if (row + 2 < nrows) v.z = p[2];
+          if (row + 3 < nrows) v.w = p[3];
+        }
       }
+      st[i] = v;
     }
-    st[i] = v;
   }
 }
 template <int ROWS>
@@ -104,7 +119,7 @@ __device__ __forceinline__ void store_rc(const float4 (&st)[ROWS * 8 / 256], flo
   }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC>
+template <int BM, int BN, bool A_KC, bool B_KC, bool FULL>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave along m / n
   constexpr int A_FLOATS = A_KC ? BM * LDK : BK * BM;
@@ -129,18 +144,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   float4 sa[BM * 8 / 256], sb[BN * 8 / 256];
-  auto fetch = [&](int64_t k0) {
-    if constexpr (A_KC) load_kc<BM>(sa, g.A, g.lda, m0, g.M, k0, kend, g.a_vec);
-    else load_rc<BM>(sa, g.A, g.lda, m0, g.M, k0, kend, g.a_vec);
-    if constexpr (B_KC) load_kc<BN>(sb, g.B, g.ldb, n0, g.N, k0, kend, g.b_vec);
-    else load_rc<BN>(sb, g.B, g.ldb, n0, g.N, k0, kend, g.b_vec);
-  };
-  auto commit = [&](int buf) {
-    float* a_d = smem + buf * STAGE_FLOATS;
-    float* b_d = a_d + A_FLOATS;
-    if constexpr (A_KC) store_kc<BM>(sa, a_d); else store_rc<BM>(sa, a_d);
-    if constexpr (B_KC) store_kc<BN>(sb, b_d); else store_rc<BN>(sb, b_d);
-  };
+#define TT_FETCH(k0)                                                                              \
+  do {                                                                                            \
+    if constexpr (A_KC) load_kc<BM, FULL>(sa, g.A, g.lda, m0, g.M, (k0), kend, g.a_vec);          \
+    else load_rc<BM, FULL>(sa, g.A, g.lda, m0, g.M, (k0), kend, g.a_vec);                         \
+    if constexpr (B_KC) load_kc<BN, FULL>(sb, g.B, g.ldb, n0, g.N, (k0), kend, g.b_vec);          \
+    else load_rc<BN, FULL>(sb, g.B, g.ldb, n0, g.N, (k0), kend, g.b_vec);                         \
+  } while (0)
+#define TT_COMMIT(buf)                                                                            \
+  do {                                                                                            \
+    float* a_d = smem + (buf) * STAGE_FLOATS;                                                     \
+    float* b_d = a_d + A_FLOATS;                                                                  \
+    if constexpr (A_KC) store_kc<BM>(sa, a_d); else store_rc<BM>(sa, a_d);                        \
+    if constexpr (B_KC) store_kc<BN>(sb, b_d); else store_rc<BN>(sb, b_d);                        \
+  } while (0)
 
   // TN with a_colsum: the workgroups of the first column block also sum the A tile over k
   // (A = dY in a weight-gradient GEMM, so this is the bias gradient -- dY is read once)
@@ -149,13 +166,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 
   const int64_t ntiles = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
   if (ntiles > 0) {
-    fetch(kbeg);
-    commit(0);
+    TT_FETCH(kbeg);
+    TT_COMMIT(0);
   }
   __syncthreads();
   for (int64_t t = 0; t < ntiles; ++t) {
     const int cur = (int)(t & 1);
-    if (t + 1 < ntiles) fetch(kbeg + (t + 1) * BK);
+    if (t + 1 < ntiles) TT_FETCH(kbeg + (t + 1) * BK);
     const float* a_s = smem + cur * STAGE_FLOATS;
     const float* b_s = a_s + A_FLOATS;
     if constexpr (!A_KC) {
@@ -195,9 +212,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][c], bv[j][c], acc[i][j], 0, 0, 0);
     }
-    if (t + 1 < ntiles) commit(cur ^ 1);
+    if (t + 1 < ntiles) TT_COMMIT(cur ^ 1);
     __syncthreads();
   }
+#undef TT_FETCH
+#undef TT_COMMIT
 
   if constexpr (!A_KC) {
     if (do_colsum) {  // combine the 256/BM k-groups in a fixed order (the LDS tiles are dead now)
@@ -313,26 +332,37 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
     if (splits > 256) splits = 256;
     if (splits < 1) splits = 1;
   }
+  if (const char* e = getenv("TT_GEMM_SPLITS")) {  // tuning hook
+    splits = atoi(e);
+    if (splits < 1) splits = 1;
+    if (splits > ktiles) splits = ktiles;
+  }
   p.k_per_split = ceil_div(ktiles, splits) * BK;
   p.splits = (int)ceil_div(K, p.k_per_split);
   return p;
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC>
-static int launch_gemm(const GemmArgs& g, hipStream_t st) {
+template <int BM, int BN, bool A_KC, bool B_KC, bool FULL>
+static int launch_gemm_v(const GemmArgs& g, hipStream_t st) {
   constexpr int A_FLOATS = A_KC ? BM * LDK : BK * BM;
   constexpr int B_FLOATS = B_KC ? BN * LDK : BK * BN;
   const size_t lds = 2 * (A_FLOATS + B_FLOATS) * sizeof(float);
   dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)g.splits);
   static bool lds_opt_in = false;  // >64 KiB of dynamic LDS needs an explicit opt-in, once per kernel
   if (!lds_opt_in && lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<BM, BN, A_KC, B_KC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<BM, BN, A_KC, B_KC, FULL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("gemm_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     lds_opt_in = true;
   }
-  gemm_kernel<BM, BN, A_KC, B_KC><<<grid, 256, lds, st>>>(g);
+  gemm_kernel<BM, BN, A_KC, B_KC, FULL><<<grid, 256, lds, st>>>(g);
   return check_launch("gemm_kernel");
+}
+template <int BM, int BN, bool A_KC, bool B_KC>
+static int launch_gemm(const GemmArgs& g, hipStream_t st) {
+  // every tile interior, every row 16-B aligned, every split a whole number of K-tiles
+  const bool full = g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0 && g.a_vec && g.b_vec;
+  return full ? launch_gemm_v<BM, BN, A_KC, B_KC, true>(g, st) : launch_gemm_v<BM, BN, A_KC, B_KC, false>(g, st);
 }
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
