@@ -50,11 +50,12 @@ __device__ __forceinline__ void stage(float* dst, const float* __restrict__ src,
   for (int it = 0; it < HP * C4 / 64; ++it) {
     const int f = it * 64 + lane;
     const int row = f / C4, c4 = f % C4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < H) {
-      v = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + 4 * c4);
-      v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
-    }
+    // unconditional load from a clamped row, masked afterwards: a guarded load makes hipcc wait
+    // for each one before evaluating the next guard (one exposed round trip per load)
+    const bool ok = row < H;
+    const float* p = src + (int64_t)(ok ? row : H - 1) * ld + 4 * c4;
+    const float x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3];
+    const float4 v = make_float4(ok ? x0 * scale : 0.f, ok ? x1 * scale : 0.f, ok ? x2 * scale : 0.f, ok ? x3 * scale : 0.f);
     *reinterpret_cast<float4*>(dst + row * LD + 4 * c4) = v;
   }
 }
@@ -85,14 +86,12 @@ __device__ __forceinline__ f32x16 nt_tile(const float* A, int a0, const float* B
 template <int DH>
 __device__ __forceinline__ void load_bfrag(float4 (&bf)[DH / 8], const float* __restrict__ src, int64_t ld, int row,
                                            int H, float scale, int h) {
+  const bool ok = row < H;
+  const float* p = src + (int64_t)(ok ? row : H - 1) * ld + 4 * h;  // clamped row, masked below
 #pragma unroll
   for (int g = 0; g < DH / 8; ++g) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < H) {
-      v = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + 8 * g + 4 * h);
-      v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
-    }
-    bf[g] = v;
+    const float x0 = p[8 * g], x1 = p[8 * g + 1], x2 = p[8 * g + 2], x3 = p[8 * g + 3];
+    bf[g] = make_float4(ok ? x0 * scale : 0.f, ok ? x1 * scale : 0.f, ok ? x2 * scale : 0.f, ok ? x3 * scale : 0.f);
   }
 }
 // nt_tile with the B rows in registers (load_bfrag of rows b0 + r)
