@@ -89,20 +89,36 @@ __global__ __launch_bounds__(256) void hist_embed_pool_kernel(
   const int64_t b = blockIdx.x;
   const V* pev = reinterpret_cast<const V*>(pe);
   V* xb = reinterpret_cast<V*>(x) + b * H * dimv;
+  // U history positions per round: first all ids, then all rows (unconditional loads from clamped
+  // indices, masked afterwards) -- two memory round trips per round instead of two per position
+  constexpr int U = 8;
   for (int64_t k = c; k < dimv; k += LPR) {
     V acc = Vec<VEC>::zero();
-    for (int64_t h = g; h < H; h += G) {
-      V v;
-      if (ids) {
-        const int64_t id = ids[b * H + h];
-        const bool ok = (id >= 0) && (id < n_rows);
-        if (!ok) *oob_flag = 1;
-        v = ok ? reinterpret_cast<const V*>(table)[id * dimv + k] : Vec<VEC>::zero();
-      } else {
-        v = reinterpret_cast<const V*>(table)[(b * H + h) * dimv + k];
+    for (int64_t h0 = g; h0 < H; h0 += (int64_t)G * U) {
+      int64_t id[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t h = h0 + (int64_t)u * G;
+        const int64_t hc = h < H ? h : H - 1;
+        id[u] = ids ? ids[b * H + hc] : b * H + hc;
       }
-      acc = Vec<VEC>::add(acc, v);
-      xb[h * dimv + k] = pe ? Vec<VEC>::add(v, pev[h * dimv + k]) : v;
+      V v[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        ok[u] = !ids || ((id[u] >= 0) && (id[u] < n_rows));
+        v[u] = reinterpret_cast<const V*>(table)[(ok[u] ? id[u] : 0) * dimv + k];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t h = h0 + (int64_t)u * G;
+        if (h < H) {
+          if (!ok[u]) *oob_flag = 1;
+          const V x_in = ok[u] ? v[u] : Vec<VEC>::zero();
+          acc = Vec<VEC>::add(acc, x_in);
+          xb[h * dimv + k] = pe ? Vec<VEC>::add(x_in, pev[h * dimv + k]) : x_in;
+        }
+      }
     }
     part[g * dimv + k] = acc;
   }
