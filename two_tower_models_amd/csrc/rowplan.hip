@@ -31,9 +31,18 @@ __global__ __launch_bounds__(64) void radix_hist_kernel(const int32_t* __restric
   for (int d = lane; d < 256; d += 64) h[d] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * TILE;
+  // all 16 keys of this lane first (unconditional loads from clamped indices: one memory round
+  // trip for the tile instead of one per round), then the LDS histogram
+  int32_t k[TILE / 64];
+#pragma unroll
   for (int rnd = 0; rnd < TILE / 64; ++rnd) {
     const int64_t i = base + rnd * 64 + lane;
-    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255], 1);
+    k[rnd] = keys[i < n ? i : n - 1];
+  }
+#pragma unroll
+  for (int rnd = 0; rnd < TILE / 64; ++rnd) {
+    const int64_t i = base + rnd * 64 + lane;
+    if (i < n) atomicAdd(&h[(k[rnd] >> shift) & 255], 1);
   }
   __syncthreads();
   for (int d = lane; d < 256; d += 64) hist[(int64_t)d * nblk + blockIdx.x] = h[d];
@@ -86,11 +95,20 @@ __global__ __launch_bounds__(64) void radix_scatter_kernel(const int32_t* __rest
   __syncthreads();
   const int64_t tile0 = (int64_t)blockIdx.x * TILE;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int32_t kreg[TILE / 64], vreg[TILE / 64];  // the whole tile up front: see radix_hist_kernel
+#pragma unroll
+  for (int rnd = 0; rnd < TILE / 64; ++rnd) {
+    const int64_t i = tile0 + rnd * 64 + lane;
+    const int64_t ic = i < n ? i : n - 1;
+    kreg[rnd] = keys_in[ic];
+    vreg[rnd] = vals_in[ic];
+  }
+#pragma unroll
   for (int rnd = 0; rnd < TILE / 64; ++rnd) {
     const int64_t i = tile0 + rnd * 64 + lane;
     const bool active = i < n;
-    const int32_t key = active ? keys_in[i] : 0;
-    const int32_t val = active ? vals_in[i] : 0;
+    const int32_t key = kreg[rnd];
+    const int32_t val = vreg[rnd];
     const int d = (key >> shift) & 255;
     unsigned long long mask = __ballot(active);
 #pragma unroll
