@@ -20,8 +20,6 @@
 
 namespace tt {
 
-constexpr int SWEEP_DEFAULT_VARIANT = 0;
-constexpr int SWEEP_DEFAULT_BPC = 8;
 constexpr int SWEEP_DEFAULT_PERSIST = 3;
 
 struct AdamConst {
@@ -187,60 +185,9 @@ __global__ __launch_bounds__(256) void adam_writeback_kernel(float* __restrict__
   }
 }
 
-// the roofline kernel: 3 x 16-B loads + 3 x 16-B stores per lane per float4.
-// NT  : non-temporal (streaming) loads/stores -- every byte is touched exactly once per step
-// UNR : float4 triples in flight per lane per loop iteration
-template <bool NT>
-__device__ __forceinline__ float4 ld4(const float4* p) {
-  if constexpr (NT) {
-    float4 v;
-    v.x = __builtin_nontemporal_load(&p->x); v.y = __builtin_nontemporal_load(&p->y);
-    v.z = __builtin_nontemporal_load(&p->z); v.w = __builtin_nontemporal_load(&p->w);
-    return v;
-  } else {
-    return *p;
-  }
-}
-template <bool NT>
-__device__ __forceinline__ void st4(float4* p, const float4& v) {
-  if constexpr (NT) {
-    __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
-    __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
-  } else {
-    *p = v;
-  }
-}
-template <bool NT, int UNR>
-__global__ __launch_bounds__(256) void adam_sweep_kernel(float4* __restrict__ W, float4* __restrict__ M,
-                                                         float4* __restrict__ V, int64_t n4,
-                                                         const double* __restrict__ hyper) {
-  const AdamConst c = load_hyper(hyper);
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + (UNR - 1) * stride < n4; i += UNR * stride) {
-    float4 p[UNR], m[UNR], v[UNR];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      p[u] = ld4<NT>(W + i + u * stride); m[u] = ld4<NT>(M + i + u * stride); v[u] = ld4<NT>(V + i + u * stride);
-    }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      adam_elem_zero_grad(p[u].x, m[u].x, v[u].x, c);
-      adam_elem_zero_grad(p[u].y, m[u].y, v[u].y, c);
-      adam_elem_zero_grad(p[u].z, m[u].z, v[u].z, c);
-      adam_elem_zero_grad(p[u].w, m[u].w, v[u].w, c);
-      st4<NT>(W + i + u * stride, p[u]); st4<NT>(M + i + u * stride, m[u]); st4<NT>(V + i + u * stride, v[u]);
-    }
-  }
-  for (; i < n4; i += stride) {
-    float4 p = W[i], m = M[i], v = V[i];
-    adam_elem_zero_grad(p.x, m.x, v.x, c);
-    adam_elem_zero_grad(p.y, m.y, v.y, c);
-    adam_elem_zero_grad(p.z, m.z, v.z, c);
-    adam_elem_zero_grad(p.w, m.w, v.w, c);
-    W[i] = p; M[i] = m; V[i] = v;
-  }
-}
+// The roofline kernel: 3 x 16-B loads + 3 x 16-B stores per lane per float4, nothing else.
+// (Non-temporal loads/stores and a plain grid-stride loop were A/B'd on hardware and lose 3-5 %;
+// see DESIGN.md.)
 // One-shot bounded-work form (TT_SWEEP_PERSIST=0): each workgroup streams SWEEP_ITERS x 256
 // float4 triples and exits.  Kept as the A/B partner of the persistent kernel below: the
 // dispatcher refills every freed slot with another of these small workgroups, so the big
@@ -271,7 +218,7 @@ __global__ __launch_bounds__(256) void adam_sweep_bounded_kernel(float4* __restr
 // the forward / backward kernels' big workgroups for the whole 5 ms the sweep lasts -- with the
 // one-shot grid above the dispatcher refills every freed slot with another small sweep
 // workgroup and a 256-VGPR / 64-KiB workgroup never finds a whole CU's worth of room.
-template <bool DYNAMIC, int ITERS, int UNR>
+template <int ITERS, int UNR>
 __global__ __launch_bounds__(256) void adam_sweep_persistent_kernel(float4* __restrict__ W, float4* __restrict__ M,
                                                                     float4* __restrict__ V, int64_t n4,
                                                                     const double* __restrict__ hyper,
@@ -279,19 +226,17 @@ __global__ __launch_bounds__(256) void adam_sweep_persistent_kernel(float4* __re
   const AdamConst c = load_hyper(hyper);
   const unsigned n_chunks = (unsigned)((n4 + 256 * ITERS - 1) / (256 * ITERS));
   __shared__ unsigned s_next[2];
-  // DYNAMIC: chunks are handed out through a device counter (ctr[0]), one fetch ahead of the
-  // chunk being streamed, so workgroups that share a CU with a heavy kernel simply take fewer
-  // chunks.  The last workgroup out (ctr[1]) re-arms both counters for the next launch; launches
-  // sharing `ctr` must be stream-ordered, which they are (one optimiser = one sweep stream).
-  unsigned ch = blockIdx.x;
-  if (DYNAMIC) {
-    if (threadIdx.x == 0) s_next[0] = atomicAdd(&ctr[0], 1u);
-    __syncthreads();
-    ch = s_next[0];
-  }
+  // Chunks are handed out through a device counter (ctr[0]), one fetch ahead of the chunk being
+  // streamed, so workgroups that share a CU with a heavy kernel simply take fewer chunks (with a
+  // static round-robin assignment the step time was bimodal).  The last workgroup out (ctr[1])
+  // re-arms both counters for the next launch; launches sharing `ctr` must be stream-ordered,
+  // which they are (one optimiser = one hyper buffer = one sweep stream).
+  if (threadIdx.x == 0) s_next[0] = atomicAdd(&ctr[0], 1u);
+  __syncthreads();
+  unsigned ch = s_next[0];
   int par = 0;
   while (ch < n_chunks) {
-    if (DYNAMIC && threadIdx.x == 0) s_next[par ^ 1] = atomicAdd(&ctr[0], 1u);
+    if (threadIdx.x == 0) s_next[par ^ 1] = atomicAdd(&ctr[0], 1u);
     const int64_t base = (int64_t)ch * (256 * ITERS) + threadIdx.x;
 #pragma unroll UNR
     for (int k = 0; k < ITERS; ++k) {
@@ -304,15 +249,11 @@ __global__ __launch_bounds__(256) void adam_sweep_persistent_kernel(float4* __re
       adam_elem_zero_grad(p.w, m.w, v.w, c);
       W[i] = p; M[i] = m; V[i] = v;
     }
-    if (DYNAMIC) {
-      __syncthreads();
-      par ^= 1;
-      ch = s_next[par];
-    } else {
-      ch += gridDim.x;
-    }
+    __syncthreads();
+    par ^= 1;
+    ch = s_next[par];
   }
-  if (DYNAMIC && threadIdx.x == 0) {
+  if (threadIdx.x == 0) {
     if (atomicAdd(&ctr[1], 1u) == gridDim.x - 1) {
       ctr[0] = 0;
       ctr[1] = 0;
@@ -389,42 +330,28 @@ static int device_cu_count() {
 }
 
 static int launch_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
-                        hipStream_t st, bool bounded = false) {
+                        hipStream_t st) {
   int rc;
   const int64_t total = n_rows * dim;
   const bool vec = ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(M) | reinterpret_cast<uintptr_t>(V)) & 15) == 0;
   const int64_t n4 = vec ? total / 4 : 0;
   if (n4 > 0) {
-    // tuning knobs (A/B'd on hardware, see profiles/): TT_SWEEP_VARIANT bit0 = non-temporal,
-    // bit1 = 2x unroll; TT_SWEEP_BLOCKS_PER_CU = workgroups per CU
-    static const int variant = getenv("TT_SWEEP_VARIANT") ? atoi(getenv("TT_SWEEP_VARIANT")) : SWEEP_DEFAULT_VARIANT;
-    static const int bpc = getenv("TT_SWEEP_BLOCKS_PER_CU") ? atoi(getenv("TT_SWEEP_BLOCKS_PER_CU")) : SWEEP_DEFAULT_BPC;
-    const int64_t cap = (int64_t)256 * (bpc > 0 ? bpc : 8);
-    const int64_t blocks = ceil_div(n4, 256) < cap ? ceil_div(n4, 256) : cap;
     float4 *w4 = reinterpret_cast<float4*>(W), *m4 = reinterpret_cast<float4*>(M), *v4 = reinterpret_cast<float4*>(V);
     ProfScope prof("adam_sweep_kernel", st);
-    // Overlapped schedule (tt_adam_table_sweep): persistent, dynamically chunked sweep with
-    // TT_SWEEP_PERSIST workgroups per CU (default 3 = 3 waves per SIMD, ~12 16-byte loads in
-    // flight per lane: HBM-saturating on its own and small enough that a 256-VGPR / 64-KiB
-    // backward workgroup still fits next to it; from 5 per CU upwards it no longer does and the
-    // step degrades to sweep + compute in series -- measured, profiles/README.md).
-    // TT_SWEEP_PERSIST=0 selects the one-shot bounded grid instead.
+    // Persistent, dynamically chunked sweep with TT_SWEEP_PERSIST workgroups per CU (default 3 =
+    // 3 waves per SIMD, ~12 16-byte loads in flight per lane: HBM-saturating on its own and small
+    // enough that a 256-VGPR / 64-KiB forward / backward workgroup still fits next to it; from 5
+    // per CU upwards it no longer does and the overlapped step degrades to sweep + compute in
+    // series -- measured, profiles/README.md).  TT_SWEEP_PERSIST=0 selects the one-shot bounded
+    // grid instead (the A/B partner).
     static const int persist = getenv("TT_SWEEP_PERSIST") ? atoi(getenv("TT_SWEEP_PERSIST")) : SWEEP_DEFAULT_PERSIST;
-    if (bounded && persist > 0) {
-      static const bool dyn = getenv("TT_SWEEP_STATIC") == nullptr;
+    if (persist > 0) {
       // hyper[7] is the library's scratch slot: two 32-bit chunk counters, zero between launches
       unsigned* ctr = reinterpret_cast<unsigned*>(const_cast<double*>(hyper) + 7);
       const unsigned grid = (unsigned)(device_cu_count() * persist);
-      if (dyn) adam_sweep_persistent_kernel<true, 4, 4><<<grid, 256, 0, st>>>(w4, m4, v4, n4, hyper, ctr);
-      else adam_sweep_persistent_kernel<false, 4, 4><<<grid, 256, 0, st>>>(w4, m4, v4, n4, hyper, ctr);
-    } else if (bounded) {
+      adam_sweep_persistent_kernel<4, 4><<<grid, 256, 0, st>>>(w4, m4, v4, n4, hyper, ctr);
+    } else {
       adam_sweep_bounded_kernel<<<(unsigned)ceil_div(n4, 256 * SWEEP_ITERS), 256, 0, st>>>(w4, m4, v4, n4, hyper);
-    } else
-    switch (variant & 3) {
-      case 0: adam_sweep_kernel<false, 1><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
-      case 1: adam_sweep_kernel<true, 1><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
-      case 2: adam_sweep_kernel<false, 2><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
-      default: adam_sweep_kernel<true, 2><<<(unsigned)blocks, 256, 0, st>>>(w4, m4, v4, n4, hyper); break;
     }
     if ((rc = check_launch("adam_sweep_kernel"))) return rc;
   }
@@ -502,7 +429,7 @@ extern "C" int tt_adam_table_sweep(float* W, float* M, float* V, int64_t n_rows,
                                    tt_stream_t stream) {
   if (!W || !M || !V || !hyper) return fail_arg("tt_adam_table_sweep: null pointer");
   if (n_rows <= 0 || dim <= 0) return fail_arg("tt_adam_table_sweep: sizes");
-  return launch_sweep(W, M, V, n_rows, dim, hyper, S(stream), /*bounded=*/true);
+  return launch_sweep(W, M, V, n_rows, dim, hyper, S(stream));
 }
 
 // A HIP stream of the device's LEAST priority for the sweep: the backward kernels on the

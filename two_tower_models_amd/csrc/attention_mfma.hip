@@ -60,29 +60,8 @@ __device__ __forceinline__ void stage(float* dst, const float* __restrict__ src,
   }
 }
 
-// D[x][y] = sum_d A[a0 + x][d] * B[b0 + y][d]; result: lane&31 = y, registers = x rows arow(e,h)
-template <int DH>
-__device__ __forceinline__ f32x16 nt_tile(const float* A, int a0, const float* B, int b0, int r, int h) {
-  constexpr int LD = DH + 4;
-  f32x16 acc;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  const float* ap = A + (a0 + r) * LD + 4 * h;
-  const float* bp = B + (b0 + r) * LD + 4 * h;
-#pragma unroll
-  for (int g = 0; g < DH / 8; ++g) {
-    const float4 a = *reinterpret_cast<const float4*>(ap + 8 * g);
-    const float4 b = *reinterpret_cast<const float4*>(bp + 8 * g);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-  }
-  return acc;
-}
-
 // B-side fragments of an NT product, straight from global memory: lane (r, h) holds row
-// `row` of the matrix, elements k = 8g + 4h + c (the k-permutation of nt_tile).  Rows >= H are 0.
+// `row` of the matrix, elements k = 8g + 4h + c (the k-permutation of gemm.hip).  Rows >= H are 0.
 template <int DH>
 __device__ __forceinline__ void load_bfrag(float4 (&bf)[DH / 8], const float* __restrict__ src, int64_t ld, int row,
                                            int H, float scale, int h) {
@@ -94,7 +73,8 @@ __device__ __forceinline__ void load_bfrag(float4 (&bf)[DH / 8], const float* __
     bf[g] = make_float4(ok ? x0 * scale : 0.f, ok ? x1 * scale : 0.f, ok ? x2 * scale : 0.f, ok ? x3 * scale : 0.f);
   }
 }
-// nt_tile with the B rows in registers (load_bfrag of rows b0 + r)
+// D[x][y] = sum_d A[a0 + x][d] * B[b0 + y][d] with the B rows in registers (load_bfrag of rows
+// b0 + r); result: lane&31 = y, registers = x rows arow(e,h)
 template <int DH>
 __device__ __forceinline__ f32x16 nt_tile_rb(const float* A, int a0, const float4 (&bf)[DH / 8], int r, int h) {
   constexpr int LD = DH + 4;
