@@ -211,6 +211,32 @@ int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows, int64_t d
 int tt_stream_create_low_priority(void** out_stream);
 int tt_stream_destroy(void* stream);
 
+/* Deferred ("lazy") schedule of the SAME dense Adam -- value-exact, reported separately from the
+ * dense-sweep figure.  A row that receives no gradient evolves by a recurrence that
+ * needs only the row and the per-step constants, so its zero-gradient steps are replayed in
+ * registers (same fp32 operations, same order) when the row is next needed instead of being
+ * applied by a sweep every step; results are bit-identical to tt_adam_table.
+ *   last_step[n_rows] (int32, zero-initialised): the step each row is current for.
+ *   tab[2*tab_steps] (float): per-step constants, maintained by tt_adam_advance_tab (use it
+ *     instead of tt_adam_advance); steps beyond the table are recomputed in double in-kernel.
+ *   tt_adam_rows_catchup  rows ids[0..n) (duplicates allowed) -> current step.  Call before any
+ *                         lookup reads them.
+ *   tt_adam_table_lazy    this step's gradient update on the planned rows only (after
+ *                         tt_adam_advance_tab), rows first brought to the previous step.
+ *   tt_adam_table_flush   every row -> current step: before anything reads the table as a whole
+ *                         (checkpoint, export).  */
+int tt_adam_advance_tab(double* hyper, float* tab, int64_t tab_steps, tt_stream_t stream);
+int tt_adam_rows_catchup(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const int64_t* ids,
+                         int64_t n_ids, int32_t* last_step, const double* hyper, const float* tab,
+                         int64_t tab_steps, tt_stream_t stream);
+int tt_adam_table_lazy(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
+                       const tt_grad_sources* src /*host*/, int64_t n_ids, const int32_t* sorted_ids,
+                       const int32_t* perm, const int32_t* seg_begin, const int32_t* n_unique, void* ws,
+                       int64_t ws_bytes, int32_t* last_step, const float* tab, int64_t tab_steps,
+                       tt_stream_t stream);
+int tt_adam_table_flush(float* W, float* M, float* V, int64_t n_rows, int64_t dim, int32_t* last_step,
+                        const double* hyper, const float* tab, int64_t tab_steps, tt_stream_t stream);
+
 /* dense parameters: `tensors` is a HOST array of n_tensors {p,g,m,v,n} descriptors
  * (device pointers inside); they are passed to the kernel by value, 64 per launch. */
 typedef struct {

@@ -238,6 +238,54 @@ def test_overlapped_sweep_is_bit_identical_to_serial(golden, kind, name):
     assert opt._begun is None
 
 
+@pytest.mark.parametrize("kind,name", [("base", "g2_base_aligned"), ("hist", "g4_hist_d128")])
+def test_lazy_adam_is_bit_identical_to_dense(golden, kind, name):
+    """DenseExactAdam(lazy=True) replays the zero-gradient steps of a row when the row is next
+    needed instead of sweeping the table every step.  After flush() every table row, both Adam
+    moments and every dense parameter must carry EXACTLY the bits of the dense schedule -- rows
+    touched every step, rows touched after gaps of several steps, and rows never touched."""
+    import two_tower_models_amd as A
+    g = golden(name)
+    n_users, n_items = int(g["cfg"][0]), int(g["cfg"][3])
+    base = batch_of(g)
+    Bsz = base[0].shape[0]
+    gen = torch.Generator().manual_seed(77)
+    steps = []
+    for s in range(7):  # ids from a sliding window: rows recur after 1..6 idle steps
+        b = [t.clone() for t in base]
+        b[0] = ((torch.randint(0, 40, (Bsz,), generator=gen) + 13 * s) % n_users).to(DEV)
+        b[3] = ((torch.randint(0, 50, (Bsz,), generator=gen) + 17 * s) % n_items).to(DEV)
+        if kind == "hist":
+            b[2] = ((torch.randint(0, 60, tuple(base[2].shape), generator=gen) + 11 * s) % n_items).to(DEV)
+        steps.append(b)
+    finals, moments = [], []
+    for lazy in (False, True):
+        model = make_model(kind, g)
+        opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep=False, lazy=lazy)
+        for s, b in enumerate(steps):
+            loss = model.train_forward(*b)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            if s == 3:  # inference between steps: its lookups must see up-to-date rows as well
+                with torch.no_grad():
+                    probe = model.train_forward(*steps[0])
+                finals.append(probe.clone())
+        if lazy:
+            stale = model.item_id_embedding_arch.weight.detach().clone()
+            opt.flush()
+            assert not torch.equal(stale, model.item_id_embedding_arch.weight)  # something WAS deferred
+        torch.cuda.synchronize()
+        finals.append({k: v.clone() for k, v in model.state_dict().items()})
+        moments.append([(opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()) for p in opt._tables])
+        assert opt.step_count == len(steps)
+    assert torch.equal(finals[0], finals[2])  # the mid-run no_grad loss
+    for k in finals[1]:
+        assert torch.equal(finals[1][k], finals[3][k]), k
+    for (m0, v0), (m1, v1) in zip(*moments):
+        assert torch.equal(m0, m1) and torch.equal(v0, v1)
+
+
 def test_zero_grad_before_forward_takes_serial_schedule(golden):
     import two_tower_models_amd as A
     g = golden("g2_base_aligned")

@@ -70,6 +70,11 @@ SIGNATURES = {
     "tt_adam_table_sweep": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "tt_adam_table_finish": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, C.POINTER(GradSources), _i64, _vp, _vp, _vp,
                                     _vp, _vp, _i64, _vp]),
+    "tt_adam_advance_tab": (_int, [_vp, _vp, _i64, _vp]),
+    "tt_adam_rows_catchup": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "tt_adam_table_lazy": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, C.POINTER(GradSources), _i64, _vp, _vp, _vp, _vp,
+                                  _vp, _i64, _vp, _vp, _i64, _vp]),
+    "tt_adam_table_flush": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
     "tt_stream_create_low_priority": (_int, [C.POINTER(_vp)]),
     "tt_stream_destroy": (_int, [_vp]),
     "tt_adam_dense": (_int, [C.POINTER(AdamTensor), _i32, _vp, _vp]),

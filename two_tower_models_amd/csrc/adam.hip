@@ -50,11 +50,23 @@ __device__ __forceinline__ void adam_elem_zero_grad(float& p, float& m, float& v
   p = p + c.neg_step_size * (m / denom);
 }
 
-__global__ void adam_advance_kernel(double* h) {
+// step-dependent constants exactly as load_hyper() hands them to the kernels
+__device__ __forceinline__ void step_consts_from_doubles(double lr, double b1, double b2, double step,
+                                                         double& h5, double& h6) {
+  h5 = lr / (1.0 - pow(b1, step));
+  h6 = sqrt(1.0 - pow(b2, step));
+}
+// tab (optional): per-step constants for the deferred schedule, tab[2j] = (float)(-h5_j),
+// tab[2j+1] = (float)h6_j -- the values every dense kernel of step j saw
+__global__ void adam_advance_kernel(double* h, float* tab, int64_t tab_cap) {
   const double step = h[4] + 1.0;
   h[4] = step;
-  h[5] = h[0] / (1.0 - pow(h[1], step));
-  h[6] = sqrt(1.0 - pow(h[2], step));
+  step_consts_from_doubles(h[0], h[1], h[2], step, h[5], h[6]);
+  const int64_t j = (int64_t)step;
+  if (tab && j < tab_cap) {
+    tab[2 * j] = (float)(-h[5]);
+    tab[2 * j + 1] = (float)h[6];
+  }
 }
 
 __device__ __forceinline__ const float* source_row(const tt_grad_sources& s, int64_t pos) {
@@ -274,6 +286,114 @@ __global__ __launch_bounds__(256) void adam_sweep_scalar_kernel(float* __restric
   }
 }
 
+// ------------------------------------------------------------------ deferred ("lazy") schedule
+// Dense Adam moves an untouched row by a recurrence that needs nothing but the row itself and
+// the step-dependent constants, so the zero-gradient steps of a row can be REPLAYED, in
+// registers, the next time the row is needed (looked up, updated, or flushed), with the very
+// same fp32 operations in the same order: bit-identical to sweeping the table every step, but
+// the table is only touched where it is used.  last_step[row] = the step the row is current for.
+__device__ __forceinline__ void replay_consts(AdamConst& c, const double* __restrict__ h, const float* __restrict__ tab,
+                                              int64_t cap, int64_t j) {
+  if (j < cap) {
+    c.neg_step_size = tab[2 * j];
+    c.bc2_sqrt = tab[2 * j + 1];
+  } else {  // beyond the table: the same double arithmetic adam_advance_kernel performs
+    double h5, h6;
+    step_consts_from_doubles(h[0], h[1], h[2], (double)j, h5, h6);
+    c.neg_step_size = (float)(-h5);
+    c.bc2_sqrt = (float)h6;
+  }
+}
+
+// one wavefront replays steps from+1 .. to of one row (zero gradient)
+__device__ __forceinline__ void replay_row(float* __restrict__ W, float* __restrict__ M, float* __restrict__ V,
+                                           int64_t row, int64_t dim, int32_t from, int32_t to,
+                                           const double* __restrict__ hyper, const float* __restrict__ tab,
+                                           int64_t cap, int lane) {
+  AdamConst c = load_hyper(hyper);
+  for (int64_t d0 = 0; d0 < dim; d0 += 256) {
+    float p[4], m[4], v[4];
+    bool live = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t d = d0 + lane + 64 * q;
+      const int64_t at = row * dim + (d < dim ? d : dim - 1);
+      p[q] = W[at]; m[q] = M[at]; v[q] = V[at];
+      live = live || (d < dim && (m[q] != 0.f || v[q] != 0.f));
+    }
+    // m = v = 0 (a row no gradient ever reached): the update is exactly p += -s * (0 / eps) = p
+    if (!__any(live)) continue;
+    for (int32_t j = from + 1; j <= to; ++j) {
+      replay_consts(c, hyper, tab, cap, j);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) adam_elem_zero_grad(p[q], m[q], v[q], c);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t d = d0 + lane + 64 * q;
+      if (d < dim) { W[row * dim + d] = p[q]; M[row * dim + d] = m[q]; V[row * dim + d] = v[q]; }
+    }
+  }
+}
+
+// rows about to be read or updated: bring ids[i] up to step (current + offset).  Duplicate ids are
+// resolved by an atomic claim on last_step (the first wave replays, the others find it current).
+__global__ __launch_bounds__(256) void adam_catchup_ids_kernel(float* __restrict__ W, float* __restrict__ M,
+                                                               float* __restrict__ V, int64_t n_rows, int64_t dim,
+                                                               const int64_t* __restrict__ ids, int64_t n_ids,
+                                                               int32_t* __restrict__ last_step,
+                                                               const double* __restrict__ hyper, int offset,
+                                                               const float* __restrict__ tab, int64_t cap) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_ids) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = ids[i];
+  if (row < 0 || row >= n_rows) return;  // reported by the lookup / plan that follows
+  const int32_t target = (int32_t)hyper[4] + offset;
+  int32_t prev = 0;
+  if (lane == 0) prev = atomicMax(&last_step[row], target);
+  prev = __shfl(prev, 0, 64);
+  if (prev >= target) return;
+  replay_row(W, M, V, row, dim, prev, target, hyper, tab, cap, lane);
+}
+
+// the same for the unique rows of a plan (no duplicates: no claim needed)
+__global__ __launch_bounds__(256) void adam_catchup_plan_kernel(float* __restrict__ W, float* __restrict__ M,
+                                                                float* __restrict__ V, int64_t n_rows, int64_t dim,
+                                                                const int32_t* __restrict__ sorted_ids,
+                                                                const int32_t* __restrict__ seg_begin,
+                                                                const int32_t* __restrict__ n_unique,
+                                                                int32_t* __restrict__ last_step,
+                                                                const double* __restrict__ hyper, int offset, int mark,
+                                                                const float* __restrict__ tab, int64_t cap) {
+  const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= *n_unique) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = sorted_ids[seg_begin[u]];
+  if (row >= n_rows) return;
+  const int32_t target = (int32_t)hyper[4] + offset;
+  const int32_t prev = last_step[row];
+  if (prev < target) replay_row(W, M, V, row, dim, prev, target, hyper, tab, cap, lane);
+  if (lane == 0) last_step[row] = target + mark;  // mark = 1: the gradient step that follows
+}
+
+// every row up to the current step (before anything reads the table as a whole)
+__global__ __launch_bounds__(256) void adam_flush_kernel(float* __restrict__ W, float* __restrict__ M,
+                                                         float* __restrict__ V, int64_t n_rows, int64_t dim,
+                                                         int32_t* __restrict__ last_step,
+                                                         const double* __restrict__ hyper,
+                                                         const float* __restrict__ tab, int64_t cap) {
+  const int lane = threadIdx.x & 63;
+  const int32_t target = (int32_t)hyper[4];
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += stride) {
+    const int32_t prev = last_step[row];
+    if (prev >= target) continue;
+    replay_row(W, M, V, row, dim, prev, target, hyper, tab, cap, lane);
+    if (lane == 0) last_step[row] = target;
+  }
+}
+
 // dense parameters: blockIdx.y = tensor, blockIdx.x = 1024-element chunk.  The descriptors
 // travel in the kernel arguments (by value), so there is no host->device copy to race with
 // and a captured graph keeps its own copy.
@@ -370,7 +490,7 @@ using namespace tt;
 
 extern "C" int tt_adam_advance(double* hyper, tt_stream_t stream) {
   if (!hyper) return fail_arg("tt_adam_advance: null pointer");
-  adam_advance_kernel<<<1, 1, 0, S(stream)>>>(hyper);
+  adam_advance_kernel<<<1, 1, 0, S(stream)>>>(hyper, nullptr, 0);
   return check_launch("adam_advance_kernel");
 }
 
@@ -468,6 +588,57 @@ extern "C" int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows
   if (rc) return rc;
   adam_writeback_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, sorted_ids, seg_begin, perm, n_unique, sd, n_ids);
   return check_launch("adam_writeback_kernel");
+}
+
+// ---- deferred ("lazy") schedule: see the kernels above
+extern "C" int tt_adam_advance_tab(double* hyper, float* tab, int64_t tab_steps, tt_stream_t stream) {
+  if (!hyper || !tab) return fail_arg("tt_adam_advance_tab: null pointer");
+  if (tab_steps <= 0) return fail_arg("tt_adam_advance_tab: sizes");
+  adam_advance_kernel<<<1, 1, 0, S(stream)>>>(hyper, tab, tab_steps);
+  return check_launch("adam_advance_kernel");
+}
+
+extern "C" int tt_adam_rows_catchup(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const int64_t* ids,
+                                    int64_t n_ids, int32_t* last_step, const double* hyper, const float* tab,
+                                    int64_t tab_steps, tt_stream_t stream) {
+  if (!W || !M || !V || !ids || !last_step || !hyper || !tab) return fail_arg("tt_adam_rows_catchup: null pointer");
+  if (n_rows <= 0 || dim <= 0 || n_ids <= 0) return fail_arg("tt_adam_rows_catchup: sizes");
+  adam_catchup_ids_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, S(stream)>>>(W, M, V, n_rows, dim, ids, n_ids, last_step, hyper, 0, tab, tab_steps);
+  return check_launch("adam_catchup_ids_kernel");
+}
+
+extern "C" int tt_adam_table_lazy(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
+                                  const tt_grad_sources* src, int64_t n_ids, const int32_t* sorted_ids,
+                                  const int32_t* perm, const int32_t* seg_begin, const int32_t* n_unique,
+                                  void* ws, int64_t ws_bytes, int32_t* last_step, const float* tab,
+                                  int64_t tab_steps, tt_stream_t stream) {
+  if (!W || !M || !V || !hyper || !sorted_ids || !perm || !seg_begin || !n_unique || !ws || !last_step || !tab)
+    return fail_arg("tt_adam_table_lazy: null pointer");
+  if (n_rows <= 0 || dim <= 0 || n_ids <= 0) return fail_arg("tt_adam_table_lazy: sizes");
+  if (!check_sources(src, n_ids, dim)) return fail_arg("tt_adam_table_lazy: gradient sources");
+  if (ws_bytes < tt_adam_table_workspace_bytes(n_ids, dim)) { set_error("tt_adam_table_lazy: workspace"); return TT_E_WORKSPACE; }
+  hipStream_t st = S(stream);
+  const unsigned blocks = (unsigned)ceil_div(n_ids, 4);
+  // rows to the step before this one (a no-op for rows the forward's lookups already brought
+  // up to date), stamped with this step; then this step's gradient update on them alone
+  adam_catchup_plan_kernel<<<blocks, 256, 0, st>>>(W, M, V, n_rows, dim, sorted_ids, seg_begin, n_unique, last_step, hyper, -1, 1, tab, tab_steps);
+  int rc = check_launch("adam_catchup_plan_kernel");
+  if (rc) return rc;
+  adam_touched_kernel<false><<<blocks, 256, 0, st>>>(W, M, V, n_rows, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, reinterpret_cast<float*>(ws), n_ids);
+  if ((rc = check_launch("adam_touched_kernel"))) return rc;
+  adam_writeback_kernel<<<blocks, 256, 0, st>>>(W, M, V, n_rows, dim, sorted_ids, seg_begin, perm, n_unique, reinterpret_cast<const float*>(ws), n_ids);
+  return check_launch("adam_writeback_kernel");
+}
+
+extern "C" int tt_adam_table_flush(float* W, float* M, float* V, int64_t n_rows, int64_t dim, int32_t* last_step,
+                                   const double* hyper, const float* tab, int64_t tab_steps, tt_stream_t stream) {
+  if (!W || !M || !V || !last_step || !hyper || !tab) return fail_arg("tt_adam_table_flush: null pointer");
+  if (n_rows <= 0 || dim <= 0) return fail_arg("tt_adam_table_flush: sizes");
+  const int64_t want = ceil_div(n_rows, 4);
+  const int64_t cap = (int64_t)device_cu_count() * 32;
+  ProfScope prof("adam_flush_kernel", S(stream));
+  adam_flush_kernel<<<(unsigned)(want < cap ? want : cap), 256, 0, S(stream)>>>(W, M, V, n_rows, dim, last_step, hyper, tab, tab_steps);
+  return check_launch("adam_flush_kernel");
 }
 
 extern "C" int tt_adam_dense(const tt_adam_tensor* tensors, int32_t n_tensors, const double* hyper,

@@ -201,6 +201,9 @@ class ActiveStash:
 def lookup_source(weight: torch.Tensor, ids: torch.Tensor, recording: bool):
     """-> (rows_table [n, D], row_ids int64 [numel], lookup_index).  Registers the lookup with the
     table's optimiser when the forward is being recorded."""
+    lazy = getattr(weight, "_tt_lazy", None)
+    if lazy is not None:  # deferred Adam: the rows must be current before anyone reads them
+        lazy.catch_up(ids)
     idx = register_lookup(weight, ids) if recording else None
     act = getattr(weight, "_tt_active", None)
     if act is not None and idx is not None:

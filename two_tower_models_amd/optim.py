@@ -38,6 +38,15 @@ hands the lookups a view of the parked rows (``ops.ActiveStash``), so the id sor
 backward all run under the sweep.  It assumes every
 ``train_forward`` executed with autograd enabled is followed by ``backward()`` and ``step()``
 (exactly the reference loop); results are again bit-identical to the serial schedule.
+
+Deferred schedule (``lazy=True``; SURVEY 8f-3, reported separately from the dense figure).  The
+zero-gradient steps of an untouched row are a recurrence on the row alone, so instead of sweeping
+the table every step the optimiser REPLAYS them, in registers and with the same fp32 operations
+in the same order, when a row is next looked up, updated or flushed.  Tables end up bit-identical
+to the dense schedule (``tests/test_gpu_models.py::test_lazy_adam_is_bit_identical_to_dense``);
+the step no longer streams 24 B per table element.  Lookups through this package's modules catch
+their rows up automatically; anything else that reads a table as a whole (``model.state_dict()``,
+exporting a corpus) must call ``optimizer.flush()`` first (``optimizer.state_dict()`` does).
 """
 from __future__ import annotations
 
@@ -60,9 +69,23 @@ class _TableStep:
         self.plan, self.side, self.announced = plan, side, announced
 
 
+class _LazyRows:
+    """Attached to a table as ``weight._tt_lazy``: lets a lookup bring its rows up to date."""
+
+    __slots__ = ("opt", "param")
+
+    def __init__(self, opt: "DenseExactAdam", param: torch.nn.Parameter):
+        self.opt, self.param = weakref.ref(opt), param
+
+    def catch_up(self, ids: torch.Tensor) -> None:
+        opt = self.opt()
+        if opt is not None:
+            opt._catch_up(self.param, ids)
+
+
 class DenseExactAdam(torch.optim.Optimizer):
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999),
-                 eps: float = 1e-8, overlap_sweep=True) -> None:
+                 eps: float = 1e-8, overlap_sweep=True, lazy: bool = False) -> None:
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
@@ -78,7 +101,15 @@ class DenseExactAdam(torch.optim.Optimizer):
             p._tt_optimizer = weakref.ref(self)
         if overlap_sweep not in (True, False, "forward"):
             raise ValueError('overlap_sweep must be True, False or "forward"')
-        self.overlap_sweep = overlap_sweep
+        self.lazy = bool(lazy)
+        self.overlap_sweep = False if self.lazy else overlap_sweep  # no sweep to overlap
+        self._last_step: Dict[int, torch.Tensor] = {}
+        self._tab: Optional[torch.Tensor] = None
+        self._tab_steps = 0
+        self._host_steps = 0  # steps taken, counted on the host (no device sync)
+        if self.lazy:
+            for p in self._tables:
+                p._tt_lazy = _LazyRows(self, p)
         self._hyper = None
         self._ready = False
         self._side_stream: Optional[torch.cuda.Stream] = None
@@ -99,7 +130,54 @@ class DenseExactAdam(torch.optim.Optimizer):
             st["exp_avg"] = torch.zeros_like(p)
             st["exp_avg_sq"] = torch.zeros_like(p)
         self._side_stream = N.low_priority_stream(dev)
+        if self.lazy:
+            for p in self._tables:
+                self._last_step[id(p)] = torch.zeros(p.shape[0], dtype=torch.int32, device=dev)
+            self._tab_steps = 1 << 16
+            self._tab = torch.zeros(2 * self._tab_steps, dtype=torch.float32, device=dev)
         self._ready = True
+
+    # ------------------------------------------------------------------ deferred schedule
+    def _catch_up(self, p: torch.nn.Parameter, ids: torch.Tensor) -> None:
+        """Rows `ids` of table `p` -> current step (called by the lookups before they read)."""
+        if self._host_steps == 0 or not p.is_cuda or ids.numel() == 0:
+            return
+        ids = ids.reshape(-1)
+        if ids.dtype != torch.int64 or not ids.is_contiguous():
+            ids = ids.to(torch.int64).contiguous()
+        st = self.state[p]
+        N.check(N.load().tt_adam_rows_catchup(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                              p.shape[0], p.shape[1], ids.data_ptr(), ids.numel(),
+                                              self._last_step[id(p)].data_ptr(), self._hyper.data_ptr(),
+                                              self._tab.data_ptr(), self._tab_steps, N.stream()),
+                "tt_adam_rows_catchup")
+
+    @torch.no_grad()
+    def flush(self) -> None:
+        """Deferred schedule: bring EVERY table row up to the current step.  Needed before the
+        tables are read other than through this package's lookups (checkpoint, corpus export)."""
+        if not self.lazy or not self._ready or self._host_steps == 0:
+            return
+        lib = N.load()
+        for p in self._tables:
+            st = self.state[p]
+            N.check(lib.tt_adam_table_flush(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                            p.shape[0], p.shape[1], self._last_step[id(p)].data_ptr(),
+                                            self._hyper.data_ptr(), self._tab.data_ptr(), self._tab_steps,
+                                            N.stream()), "tt_adam_table_flush")
+
+    def state_dict(self):
+        self.flush()
+        return super().state_dict()
+
+    def _advance_lazy(self) -> None:
+        if self._host_steps + 2 >= self._tab_steps:  # grow the per-step constant table (x2)
+            bigger = torch.zeros(4 * self._tab_steps, dtype=torch.float32, device=self._tab.device)
+            bigger[: 2 * self._tab_steps].copy_(self._tab)
+            self._tab, self._tab_steps = bigger, 2 * self._tab_steps
+        N.check(N.load().tt_adam_advance_tab(self._hyper.data_ptr(), self._tab.data_ptr(), self._tab_steps,
+                                             N.stream()), "tt_adam_advance_tab")
+        self._host_steps += 1
 
     @property
     def step_count(self) -> int:
@@ -122,6 +200,7 @@ class DenseExactAdam(torch.optim.Optimizer):
             self._init_state()
         hyper = self._hyper.data_ptr()
         N.check(lib.tt_adam_advance(hyper, N.stream()), "tt_adam_advance")
+        self._host_steps += 1
         begun: Dict[torch.nn.Parameter, _TableStep] = {}
         for p in self._tables:
             blocks = announced.get(id(p)) if announced is not None else p._tt_lookups
@@ -218,8 +297,29 @@ class DenseExactAdam(torch.optim.Optimizer):
                                                  ts.side.data_ptr(), ts.side.numel(), N.stream()),
                         "tt_adam_table_finish")
             self._begun = None
+        elif self.lazy:
+            self._advance_lazy()
+            for p in self._tables:
+                blocks = p._tt_rowgrads
+                if p.grad is not None:
+                    raise RuntimeError("embedding table received a dense gradient while in row-gradient mode")
+                if not blocks:
+                    continue
+                if all(b.index is not None for b in blocks):
+                    blocks = sorted(blocks, key=lambda b: b.index)
+                st = self.state[p]
+                n_rows, dim = p.shape
+                plan = ops.RowPlan.from_grads(blocks, n_rows)
+                wsp, wsn = ops._ws(p.device, lib.tt_adam_table_workspace_bytes(plan.n, dim), "adam_side")
+                N.check(lib.tt_adam_table_lazy(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                               n_rows, dim, hyper, C.byref(plan.sources), plan.n,
+                                               plan.sorted_ids.data_ptr(), plan.perm.data_ptr(),
+                                               plan.seg_begin.data_ptr(), plan.n_unique.data_ptr(), wsp, wsn,
+                                               self._last_step[id(p)].data_ptr(), self._tab.data_ptr(),
+                                               self._tab_steps, N.stream()), "tt_adam_table_lazy")
         else:
             N.check(lib.tt_adam_advance(hyper, N.stream()), "tt_adam_advance")
+            self._host_steps += 1
             for p in self._tables:
                 blocks = p._tt_rowgrads
                 st = self.state[p]

@@ -103,10 +103,12 @@ def main(args):
     dataloader = DeviceBatches(dataset, batch_size=args.batch_size, shuffle=True)
     # the loop below is exactly train_forward -> zero_grad -> backward -> step, which is what the
     # forward-announced sweep start assumes (optim.py)
-    optimizer = DenseExactAdam(model.parameters(), lr=args.learning_rate, overlap_sweep="forward")
+    optimizer = DenseExactAdam(model.parameters(), lr=args.learning_rate, overlap_sweep="forward",
+                               lazy=getattr(args, "lazy_adam", False))
     for epoch in range(args.num_epochs):
         avg_loss = train_one_epoch(model, dataloader, optimizer, device)
         print(f"Epoch [{epoch + 1}/{args.num_epochs}] - Loss: {avg_loss:.4f}")
+    optimizer.flush()  # deferred schedule: the tables are complete again from here on
 
 
 def build_parser() -> argparse.ArgumentParser:
@@ -127,6 +129,8 @@ def build_parser() -> argparse.ArgumentParser:
     ):
         p.add_argument(flag, type=typ, default=default, help=hlp)
     p.add_argument("--model", choices=sorted(MODELS), default="base", help="model variant (upstream: base only)")
+    p.add_argument("--lazy_adam", action="store_true",
+                   help="value-exact deferred Adam: replay a row's zero-gradient steps when it is next needed")
     return p
 
 
