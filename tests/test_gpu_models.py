@@ -286,6 +286,51 @@ def test_lazy_adam_is_bit_identical_to_dense(golden, kind, name):
         assert torch.equal(m0, m1) and torch.equal(v0, v1)
 
 
+@pytest.mark.parametrize("lazy", [False, True])
+def test_checkpoint_resume_is_bit_identical(golden, lazy):
+    """model.state_dict() + optimizer.state_dict() after 3 steps, loaded into fresh objects, then 2
+    more steps == 5 uninterrupted steps (tables, dense parameters, moments); the optimiser state
+    uses torch.optim.Adam's keys (step, exp_avg, exp_avg_sq)."""
+    import io
+    import two_tower_models_amd as A
+    g = golden("g2_base_aligned")
+    batches = [batch_of(g, prefix=f"step{s}.in.") for s in range(3)]
+    batches = batches + batches[:2]
+
+    def run(model, opt, bs):
+        for b in bs:
+            loss = model.train_forward(*b)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+
+    ref_model = make_model("base", g)
+    ref_opt = A.DenseExactAdam(ref_model.parameters(), lr=1e-3, lazy=lazy)
+    run(ref_model, ref_opt, batches)
+    ref_opt.flush()
+
+    m1 = make_model("base", g)
+    o1 = A.DenseExactAdam(m1.parameters(), lr=1e-3, lazy=lazy)
+    run(m1, o1, batches[:3])
+    buf = io.BytesIO()
+    torch.save({"opt": o1.state_dict(), "model": m1.state_dict()}, buf)  # optimiser first: it flushes
+    ck = torch.load(io.BytesIO(buf.getvalue()))
+    any_state = next(iter(ck["opt"]["state"].values()))
+    assert set(any_state) == {"step", "exp_avg", "exp_avg_sq"} and float(any_state["step"]) == 3.0
+    m2 = make_model("base", g)
+    m2.load_state_dict(ck["model"])
+    o2 = A.DenseExactAdam(m2.parameters(), lr=1e-3, lazy=lazy)
+    o2.load_state_dict(ck["opt"])
+    run(m2, o2, batches[3:])
+    o2.flush()
+    assert o2.step_count == 5
+    for (k, a), (_, b) in zip(ref_model.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    for pa, pb in zip(ref_opt._params, o2._params):
+        assert torch.equal(ref_opt.state[pa]["exp_avg"], o2.state[pb]["exp_avg"])
+        assert torch.equal(ref_opt.state[pa]["exp_avg_sq"], o2.state[pb]["exp_avg_sq"])
+
+
 def test_zero_grad_before_forward_takes_serial_schedule(golden):
     import two_tower_models_amd as A
     g = golden("g2_base_aligned")

@@ -107,6 +107,7 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._tab: Optional[torch.Tensor] = None
         self._tab_steps = 0
         self._host_steps = 0  # steps taken, counted on the host (no device sync)
+        self._resume_step = 0  # step count adopted from a loaded checkpoint
         if self.lazy:
             for p in self._tables:
                 p._tt_lazy = _LazyRows(self, p)
@@ -127,21 +128,26 @@ class DenseExactAdam(torch.optim.Optimizer):
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise TypeError("DenseExactAdam needs contiguous fp32 parameters")
             st = self.state[p]
-            st["exp_avg"] = torch.zeros_like(p)
-            st["exp_avg_sq"] = torch.zeros_like(p)
+            for key in ("exp_avg", "exp_avg_sq"):  # a loaded checkpoint already supplied them
+                if key not in st or st[key].shape != p.shape or st[key].device != p.device:
+                    st[key] = torch.zeros_like(p) if key not in st else st[key].to(p.device, torch.float32).contiguous()
         self._side_stream = N.low_priority_stream(dev)
+        start = int(self._resume_step)
+        self._hyper[4] = float(start)  # [5], [6] are recomputed from the step by every advance
+        self._host_steps = start
         if self.lazy:
+            # a checkpoint holds flushed tables: every row is current for the step it was taken at
             for p in self._tables:
-                self._last_step[id(p)] = torch.zeros(p.shape[0], dtype=torch.int32, device=dev)
-            self._tab_steps = 1 << 16
+                self._last_step[id(p)] = torch.full((p.shape[0],), start, dtype=torch.int32, device=dev)
+            self._tab_steps = max(1 << 16, 2 * (start + 2))
             self._tab = torch.zeros(2 * self._tab_steps, dtype=torch.float32, device=dev)
         self._ready = True
 
     # ------------------------------------------------------------------ deferred schedule
     def _catch_up(self, p: torch.nn.Parameter, ids: torch.Tensor) -> None:
         """Rows `ids` of table `p` -> current step (called by the lookups before they read)."""
-        if self._host_steps == 0 or not p.is_cuda or ids.numel() == 0:
-            return
+        if not self._ready or self._host_steps == 0 or not p.is_cuda or ids.numel() == 0:
+            return  # nothing has been deferred yet (fresh, or just loaded from a flushed checkpoint)
         ids = ids.reshape(-1)
         if ids.dtype != torch.int64 or not ids.is_contiguous():
             ids = ids.to(torch.int64).contiguous()
@@ -167,8 +173,24 @@ class DenseExactAdam(torch.optim.Optimizer):
                                             N.stream()), "tt_adam_table_flush")
 
     def state_dict(self):
+        """torch.optim.Adam's layout (per parameter: step, exp_avg, exp_avg_sq), tables flushed."""
         self.flush()
-        return super().state_dict()
+        sd = super().state_dict()
+        step = torch.tensor(float(self.step_count))
+        for st in sd["state"].values():
+            st["step"] = step.clone()
+        return sd
+
+    def load_state_dict(self, state_dict) -> None:
+        """Accepts this class's or torch.optim.Adam's state (same keys).  Takes effect at the next
+        step: the moments are adopted as they are, the step count restarts from the stored one."""
+        super().load_state_dict(state_dict)
+        steps = {int(float(st["step"])) for st in self.state.values() if "step" in st}
+        if len(steps) > 1:
+            raise ValueError("DenseExactAdam needs one common step count for all parameters")
+        self._resume_step = steps.pop() if steps else 0
+        self._begun = None
+        self._ready = False  # device-side state is rebuilt around the loaded moments
 
     def _advance_lazy(self) -> None:
         if self._host_steps + 2 >= self._tab_steps:  # grow the per-step constant table (x2)
