@@ -96,3 +96,24 @@ def test_train_script_default_flags(A, capsys):
     assert len(lines) == 4
     first, last = (float(l.rsplit(" ", 1)[1]) for l in (lines[0], lines[-1]))
     assert last < first
+
+
+def test_index_corpus_serves_the_item_tower(A):
+    """index_corpus installs item-tower outputs as the MIPS corpus: forward() then returns, for every
+    user, the ids whose item embeddings have the largest inner products with the user embedding."""
+    torch.manual_seed(5)
+    mips = A.BaselineMIPSModule(corpus_size=8, embedding_dim=32)
+    model = A.TwoTowerBaseRetrieval(num_items=7, user_id_hash_size=50, user_id_embedding_dim=32, user_features_size=6,
+                                    item_id_hash_size=300, item_id_embedding_dim=32, item_features_size=5,
+                                    user_value_weights=[1.0], mips_module=mips).to(DEV)
+    C = 300
+    item_id = torch.arange(C, device=DEV)
+    item_features = torch.randn(C, 5, device=DEV)
+    model.index_corpus(item_id, item_features, chunk=128)
+    assert mips.corpus_size == C and tuple(mips.corpus.shape) == (C, 32)
+    uid, uf = torch.randint(0, 50, (9,), device=DEV), torch.randn(9, 6, device=DEV)
+    got = model(uid, uf, torch.zeros(9, 3, dtype=torch.long, device=DEV))
+    with torch.no_grad():
+        u = model.compute_user_embedding(uid, uf, torch.zeros(9, 3, dtype=torch.long, device=DEV))
+        want = torch.topk(u.cpu().double() @ mips.corpus.cpu().double().t(), 7, dim=1).indices
+    assert torch.equal(got.cpu().sort(dim=1).values, want.sort(dim=1).values)

@@ -40,6 +40,14 @@ class BaselineMIPSModule(nn.Module):
         self.corpus = self.corpus.to(torch.bfloat16)
         return self
 
+    def set_corpus(self, embeddings: torch.Tensor, bf16: bool = False) -> "BaselineMIPSModule":
+        """Replace the random corpus (ref :29-30) by real item embeddings [C, DI]."""
+        if embeddings.dim() != 2 or embeddings.shape[1] != self.embedding_dim:
+            raise ValueError(f"corpus must be [C, {self.embedding_dim}]")
+        self.corpus = embeddings.detach().to(torch.bfloat16 if bf16 else torch.float32).contiguous()
+        self.corpus_size = self.corpus.shape[0]
+        return self
+
     def search(self, query_embedding: torch.Tensor, num_items: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """(indices int64 [B, K], scores fp32 [B, K]) without gathering the rows."""
         return ops.mips_topk(query_embedding, self.corpus, num_items)

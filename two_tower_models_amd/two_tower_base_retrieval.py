@@ -122,6 +122,19 @@ class TwoTowerBaseRetrieval(nn.Module):
         return top_items
 
     # ------------------------------------------------------------------ loss
+    @torch.no_grad()
+    def index_corpus(self, item_id: torch.Tensor, item_features: torch.Tensor, chunk: int = 262144,
+                     bf16: bool = False) -> None:
+        """Serve what was trained (upstream searches a random corpus): run the item
+        tower over the catalogue (item_id [C], item_features [C, II]) in chunks and install the
+        embeddings as the MIPS corpus -- corpus row r is item item_id[r]."""
+        out = torch.empty(item_id.shape[0], self.item_id_embedding_arch.weight.shape[1], dtype=torch.float32,
+                          device=item_id.device)
+        for lo in range(0, item_id.shape[0], chunk):
+            hi = min(lo + chunk, item_id.shape[0])
+            out[lo:hi] = self.compute_item_embeddings(item_id[lo:hi], item_features[lo:hi])
+        self.mips_module.set_corpus(out, bf16=bf16)
+
     def debias_net_user_value(
         self, net_user_value: torch.Tensor, position: torch.Tensor, user_embedding: torch.Tensor
     ) -> Tuple[torch.Tensor, torch.Tensor]:
