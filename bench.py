@@ -117,8 +117,14 @@ def cpu_baseline(cfg, seconds_budget=25.0):
         if time.perf_counter() - t0 > seconds_budget * 0.6 or steps >= 8:
             break
     dt = time.perf_counter() - t0
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
+    except OSError:
+        pass
     return {
-        "value": B * steps / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+        "value": B * steps / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
         "sample": f"{steps} train steps of oracle/cpu_ref.py (torch CPU, {cores} threads), B={B}, D={D}, "
                   f"N_u={n_users}, N_i={n_items}" + ("" if n_items == cfg["n_items"] else " (shrunk to fit host RAM)")
                   + f", {dt / steps * 1e3:.0f} ms/step",
@@ -136,6 +142,9 @@ def main():
     ap.add_argument("--overlap", default="forward", choices=["forward", "zero_grad", "off"],
                     help="when DenseExactAdam starts the table sweep (optim.py); all three are bit-identical")
     ap.add_argument("--sharded", action="store_true", help="use the row-sharded trainer even at --gpus 1")
+    ap.add_argument("--phase", default="step", choices=["step", "fwd", "fwdbwd"],
+                    help="step: the metric (fwd + zero_grad + bwd + Adam).  fwd / fwdbwd: SURVEY 8d's secondary "
+                         "figures -- forward only, or forward + backward without the optimiser step")
     ap.add_argument("--adam", default="dense", choices=["dense", "lazy"],
                     help="dense: the table sweep every step (the headline figure).  lazy: the value-exact deferred "
                          "schedule (SURVEY 8f-3, reported separately): K steps + a final flush inside the timed "
@@ -178,11 +187,22 @@ def main():
         batches = make_batches(cfg, 16, device)
         total_loss = torch.zeros((), device=device)
 
+        if args.phase != "step":  # no optimiser step: nothing may start a sweep
+            opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep=False)
+
         def step(batch):
+            if args.phase == "fwd":
+                with torch.no_grad():
+                    total_loss.add_(model.train_forward(*batch))
+                return
             loss = model.train_forward(*batch)
             opt.zero_grad()
             loss.backward()
-            opt.step()
+            if args.phase == "step":
+                opt.step()
+            else:
+                for p in opt._tables:  # step() would have consumed these
+                    p._tt_lookups.clear()
             total_loss.add_(loss.detach())  # the loop's loss accumulation, without the host sync
 
     def barrier():
@@ -239,7 +259,8 @@ def main():
                     "avg_launch_ms": round(ms.value / cnt.value, 4),
                     "algorithmic_bytes_per_launch": sweep_bytes_step * args.steps / cnt.value}
         out = {
-            "metric": "user-item pairs/sec (in-batch softmax train step: fwd + zero_grad + bwd + dense-exact Adam)"
+            "metric": ("user-item pairs/sec (in-batch softmax train step: fwd + zero_grad + bwd + dense-exact Adam)"
+                       if args.phase == "step" else f"user-item pairs/sec, {args.phase} only (secondary figure, SURVEY 8d)")
                       + (" [value-exact DEFERRED Adam: K steps + flush; not the headline schedule]" if args.adam == "lazy" else ""),
             "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
