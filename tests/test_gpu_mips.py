@@ -116,6 +116,22 @@ def test_large_random_against_oracle_sets(A):
         assert exact_rows >= B // 2
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_many_query_batches_reuse_the_workspace(A, bf16):
+    """B = 2500 queries = three internal batches of <= 1024 sharing one workspace (group maxima,
+    selected-group lists, select survivors, candidates): every batch must start from clean counters.
+    Exact-arithmetic corpus -> indices and scores bit-exact against the oracle order."""
+    C, D, B, K = 20_000, 64, 2500, 50
+    corpus = T(fg.exact_mips_corpus(C, D))
+    q = T(fg.exact_mips_queries(B, D))
+    m = module_with(A, corpus, bf16)
+    idx, sc = m.search(q.to(DEV), K)
+    want_idx, want_sc, _ = R.mips_topk(q, corpus, K)
+    assert torch.equal(idx.cpu(), want_idx) and torch.equal(sc.cpu(), want_sc)
+    idx2, sc2 = m.search(q.to(DEV), K)  # and the next call as well
+    assert torch.equal(idx2, idx) and torch.equal(sc2, sc)
+
+
 def test_debias_model_forward_topk_vs_reference(A, golden):
     """BASELINE config 5's model: TwoTowerWithDebiasing.forward -> MIPS ids."""
     from test_gpu_models import make_model, batch_of
