@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--overlap", default="forward", choices=["forward", "zero_grad", "off"],
                     help="when DenseExactAdam starts the table sweep (optim.py); all three are bit-identical")
     ap.add_argument("--sharded", action="store_true", help="use the row-sharded trainer even at --gpus 1")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole step as one hipGraph (GraphedTrainStep; single-stream optimiser schedules)")
     ap.add_argument("--phase", default="step", choices=["step", "fwd", "fwdbwd"],
                     help="step: the metric (fwd + zero_grad + bwd + Adam).  fwd / fwdbwd: SURVEY 8d's secondary "
                          "figures -- forward only, or forward + backward without the optimiser step")
@@ -207,6 +209,14 @@ def main():
                 for p in opt._tables:  # step() would have consumed these
                     p._tt_lookups.clear()
             total_loss.add_(loss.detach())  # the loop's loss accumulation, without the host sync
+
+    if args.graph:
+        if use_sharded or args.phase != "step":
+            raise SystemExit("--graph applies to the single-GPU train step")
+        graphed = A.GraphedTrainStep(model, opt, batches[0], warmup=2)
+
+        def step(batch):  # noqa: F811 -- replaces the eager step
+            total_loss.add_(graphed(*batch))
 
     def barrier():
         if world > 1:
@@ -272,7 +282,7 @@ def main():
                                    f"N_i={cfg['n_items']}, D={cfg['D']}, F={cfg['F']}, B={B}/GPU"
                                    + (f", H={cfg['H']} history encoder" if cfg['model'] == 'hist' else ""),
                        "global_batch": B * world,
-                       "parallelism": "single GPU" if not use_sharded else
+                       "parallelism": ("single GPU" + (", whole-step hipGraph" if args.graph else "")) if not use_sharded else
                        f"row-sharded tables x{world}, {args.negatives} in-batch negatives, "
                        + ("RCCL" if dist_backend == "nccl" else dist_backend)},
             "roofline": roof,

@@ -331,6 +331,52 @@ def test_checkpoint_resume_is_bit_identical(golden, lazy):
         assert torch.equal(ref_opt.state[pa]["exp_avg_sq"], o2.state[pb]["exp_avg_sq"])
 
 
+@pytest.mark.parametrize("kind,name,lazy", [("base", "g2_base_aligned", True), ("base", "g2_base_aligned", False),
+                                            ("hist", "g4_hist_d128", True)])
+def test_graphed_train_step_is_bit_identical_to_eager(golden, kind, name, lazy):
+    """GraphedTrainStep (whole-step hipGraph: forward, zero_grad, backward, optimiser) replayed N
+    times == N eager steps: the step count and bias corrections advance on the device, row plans
+    are sized on the device, so nothing is baked into the captured graph but the shapes."""
+    import two_tower_models_amd as A
+    g = golden(name)
+    base = batch_of(g)
+    n_users, n_items = int(g["cfg"][0]), int(g["cfg"][3])
+    gen = torch.Generator().manual_seed(5)
+    bs = []
+    for s in range(8):
+        b = [t.clone() for t in base]
+        b[0] = torch.randint(0, n_users, tuple(base[0].shape), generator=gen).to(DEV)
+        b[3] = torch.randint(0, n_items, tuple(base[3].shape), generator=gen).to(DEV)
+        bs.append(b)
+    W = 2  # GraphedTrainStep's warm-up = W real steps on the example batch
+    order = [bs[0]] * W + bs[1:]
+    eager = make_model(kind, g)
+    eopt = A.DenseExactAdam(eager.parameters(), lr=1e-3, overlap_sweep=False, lazy=lazy)
+    elosses = []
+    side = torch.cuda.Stream()  # eager reference on a side stream as well (same autograd stream rules)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for b in order:
+            loss = eager.train_forward(*b)
+            eopt.zero_grad()
+            loss.backward()
+            eopt.step()
+            elosses.append(loss.item())
+        eopt.flush()
+    torch.cuda.current_stream().wait_stream(side)
+    del loss
+    model = make_model(kind, g)
+    opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep=False, lazy=lazy)
+    step = A.GraphedTrainStep(model, opt, bs[0], warmup=W)
+    glosses = [step(*b).item() for b in bs[1:]]
+    opt.flush()
+    torch.cuda.synchronize()
+    assert opt.step_count == len(order)
+    assert glosses == elosses[W:]
+    for (k, a), (_, b) in zip(eager.state_dict().items(), model.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
 def test_zero_grad_before_forward_takes_serial_schedule(golden):
     import two_tower_models_amd as A
     g = golden("g2_base_aligned")

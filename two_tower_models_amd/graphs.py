@@ -1,0 +1,64 @@
+"""Whole-step hipGraph capture: forward + zero_grad + backward + optimiser step replayed as ONE
+graph launch.  The step is capturable because nothing in it depends on host-side state: sizes
+come from device-side counts (row plans), the Adam step count and bias corrections live in
+device memory (`tt_adam_advance`), out-of-range ids raise through a device flag, and the
+workspaces are torch tensors (allocated from the graph's private pool during capture).
+
+What it buys: the ~85 (base model) to ~200 (history model) kernel launches of a step cost
+5-10 us of host time each; once the HBM-bound table sweep is out of the way (deferred Adam, or
+small tables) the step is launch-bound -- C2 with the deferred schedule: 1.08 -> 0.65 ms/step.
+Under capture the optimiser takes its single-stream schedules (serial sweep, or deferred), so for
+the dense schedule at large tables the eager overlapped step remains the faster one.
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+
+
+class GraphedTrainStep:
+    """``step = GraphedTrainStep(model, optimizer, example_batch); loss = step(*batch)``.
+
+    `example_batch` fixes the shapes; every later batch is copied into the captured input
+    buffers.  The returned loss tensor is the graph's static output (clone it to keep a value).
+    Mirrors the body of ref:train/train.py:112-125.  The `warmup` eager steps are REAL optimiser
+    steps on the example batch.  Build it before running eager backward passes on the default
+    stream (torch's usual whole-network-capture rule: autograd nodes remember their stream)."""
+
+    def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, example_batch: Sequence[torch.Tensor],
+                 warmup: int = 3) -> None:
+        self.model, self.optimizer = model, optimizer
+        if getattr(optimizer, "overlap_sweep", False):
+            # the captured step uses the single-stream schedule; warm up (and stay) on that one so its
+            # workspaces exist before capture
+            optimizer.overlap_sweep = False
+        self.static_inputs = [t.clone() for t in example_batch]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # eager warm-up on a side stream: lazy state, workspaces, kernel attributes
+            for _ in range(max(1, warmup)):
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.warmup_steps = max(1, warmup)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._body()
+
+    def _body(self) -> torch.Tensor:
+        loss = self.model.train_forward(*self.static_inputs)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self.optimizer.step()
+        return loss
+
+    def __call__(self, *batch: torch.Tensor) -> torch.Tensor:
+        if len(batch) != len(self.static_inputs):
+            raise ValueError(f"expected {len(self.static_inputs)} input tensors")
+        for dst, src in zip(self.static_inputs, batch):
+            if dst.shape != src.shape or dst.dtype != src.dtype:
+                raise ValueError("batch shape / dtype differs from the captured example batch")
+            dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.loss
