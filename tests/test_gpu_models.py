@@ -238,7 +238,7 @@ def test_overlapped_sweep_is_bit_identical_to_serial(golden, kind, name):
     assert opt._begun is None
 
 
-@pytest.mark.parametrize("kind,name", [("base", "g2_base_aligned"), ("hist", "g4_hist_d128")])
+@pytest.mark.parametrize("kind,name", [("base", "g2_base_aligned"), ("hist", "g4_hist_d128"), ("base", "g1_base_tiny")])
 def test_lazy_adam_is_bit_identical_to_dense(golden, kind, name):
     """DenseExactAdam(lazy=True) replays the zero-gradient steps of a row when the row is next
     needed instead of sweeping the table every step.  After flush() every table row, both Adam
