@@ -28,6 +28,18 @@ template <int DP8>
 __device__ __forceinline__ void load_stationary(float (&xr)[DP8][4], const float* __restrict__ X,
                                                 int64_t ld, int64_t row, int64_t nrows, int64_t D,
                                                 int h, bool vec) {
+  if (vec && D == 8 * DP8) {
+    // full-width aligned rows: unconditional loads from a clamped row, masked afterwards (guarded
+    // loads make hipcc wait for each load before the next guard: DP8 exposed round trips per wave)
+    const bool ok = row < nrows;
+    const float* p = X + (ok ? row : nrows - 1) * ld + 4 * h;
+#pragma unroll
+    for (int g = 0; g < DP8; ++g) {
+      const float x0 = p[8 * g], x1 = p[8 * g + 1], x2 = p[8 * g + 2], x3 = p[8 * g + 3];
+      xr[g][0] = ok ? x0 : 0.f; xr[g][1] = ok ? x1 : 0.f; xr[g][2] = ok ? x2 : 0.f; xr[g][3] = ok ? x3 : 0.f;
+    }
+    return;
+  }
 #pragma unroll
   for (int g = 0; g < DP8; ++g) {
     const int64_t k = 8 * g + 4 * h;
