@@ -12,7 +12,7 @@
 
 namespace tt {
 
-constexpr int TILE = 1024;  // keys per workgroup per pass (one wavefront, 16 rounds)
+constexpr int TILE = 256;  // keys per workgroup per pass (one wavefront, 4 rounds): 209 K ids -> 816 waves
 
 __global__ void plan_init_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t n_rows,
                                  int32_t* __restrict__ keys, int32_t* __restrict__ vals, int32_t* oob_flag) {
