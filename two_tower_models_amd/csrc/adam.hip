@@ -305,17 +305,20 @@ __device__ __forceinline__ void replay_consts(AdamConst& c, const double* __rest
   }
 }
 
-// one wavefront replays steps from+1 .. to of one row (zero gradient)
-__device__ __forceinline__ void replay_row(float* __restrict__ W, float* __restrict__ M, float* __restrict__ V,
-                                           int64_t row, int64_t dim, int32_t from, int32_t to,
-                                           const double* __restrict__ hyper, const float* __restrict__ tab,
-                                           int64_t cap, int lane) {
+// one wavefront replays steps from+1 .. to of one row (zero gradient), Q elements per lane and
+// chunk of 64*Q columns.  The replay is pure VALU work (IEEE sqrt and two divisions per element
+// and step), so Q is matched to the row width -- no lane computes padding.
+template <int Q>
+__device__ __forceinline__ void replay_row_q(float* __restrict__ W, float* __restrict__ M, float* __restrict__ V,
+                                             int64_t row, int64_t dim, int32_t from, int32_t to,
+                                             const double* __restrict__ hyper, const float* __restrict__ tab,
+                                             int64_t cap, int lane) {
   AdamConst c = load_hyper(hyper);
-  for (int64_t d0 = 0; d0 < dim; d0 += 256) {
-    float p[4], m[4], v[4];
+  for (int64_t d0 = 0; d0 < dim; d0 += 64 * Q) {
+    float p[Q], m[Q], v[Q];
     bool live = false;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < Q; ++q) {
       const int64_t d = d0 + lane + 64 * q;
       const int64_t at = row * dim + (d < dim ? d : dim - 1);
       p[q] = W[at]; m[q] = M[at]; v[q] = V[at];
@@ -323,17 +326,27 @@ __device__ __forceinline__ void replay_row(float* __restrict__ W, float* __restr
     }
     // m = v = 0 (a row no gradient ever reached): the update is exactly p += -s * (0 / eps) = p
     if (!__any(live)) continue;
-    for (int32_t j = from + 1; j <= to; ++j) {
+    for (int32_t j = from + 1; j <= to; ++j) {  // from / to are wave-uniform: scalar loop, scalar loads
       replay_consts(c, hyper, tab, cap, j);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) adam_elem_zero_grad(p[q], m[q], v[q], c);
+      for (int q = 0; q < Q; ++q) adam_elem_zero_grad(p[q], m[q], v[q], c);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < Q; ++q) {
       const int64_t d = d0 + lane + 64 * q;
       if (d < dim) { W[row * dim + d] = p[q]; M[row * dim + d] = m[q]; V[row * dim + d] = v[q]; }
     }
   }
+}
+__device__ __forceinline__ void replay_row(float* __restrict__ W, float* __restrict__ M, float* __restrict__ V,
+                                           int64_t row, int64_t dim, int32_t from, int32_t to,
+                                           const double* __restrict__ hyper, const float* __restrict__ tab,
+                                           int64_t cap, int lane) {
+  from = __builtin_amdgcn_readfirstlane(from);
+  to = __builtin_amdgcn_readfirstlane(to);
+  if (dim <= 64) replay_row_q<1>(W, M, V, row, dim, from, to, hyper, tab, cap, lane);
+  else if (dim <= 128) replay_row_q<2>(W, M, V, row, dim, from, to, hyper, tab, cap, lane);
+  else replay_row_q<4>(W, M, V, row, dim, from, to, hyper, tab, cap, lane);
 }
 
 // rows about to be read or updated: bring ids[i] up to step (current + offset).  Duplicate ids are
