@@ -145,6 +145,9 @@ def main():
     ap.add_argument("--overlap", default="forward", choices=["forward", "zero_grad", "off"],
                     help="when DenseExactAdam starts the table sweep (optim.py); all three are bit-identical")
     ap.add_argument("--sharded", action="store_true", help="use the row-sharded trainer even at --gpus 1")
+    ap.add_argument("--fresh-ids", action="store_true",
+                    help="draw new uniform user / item ids on the device every step instead of cycling 16 batches "
+                         "(the deferred schedule's steady state: every lookup hits rows that idled for ~N/B steps)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole step as one hipGraph (GraphedTrainStep; single-stream optimiser schedules)")
     ap.add_argument("--phase", default="step", choices=["step", "fwd", "fwdbwd"],
@@ -195,12 +198,30 @@ def main():
         if args.phase != "step":  # no optimiser step: nothing may start a sweep
             opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep=False)
 
-        def step(batch):
+        id_gen = torch.Generator(device=device).manual_seed(4321)
+
+        def refresh(batch):  # --fresh-ids: same features / labels, new uniform ids
+            b = list(batch)
+            b[0] = torch.randint(0, cfg["n_users"], tuple(b[0].shape), device=device, generator=id_gen)
+            b[3] = torch.randint(0, cfg["n_items"], tuple(b[3].shape), device=device, generator=id_gen)
+            if cfg["model"] == "hist":
+                b[2] = torch.randint(0, cfg["n_items"], tuple(b[2].shape), device=device, generator=id_gen)
+            return b
+
+        pending = {}
+
+        def step(batch, nxt=None):
+            if args.fresh_ids:
+                batch = pending.pop("next", None) or refresh(batch)
+                if nxt is not None:
+                    nxt = pending["next"] = refresh(nxt)
             if args.phase == "fwd":
                 with torch.no_grad():
                     total_loss.add_(model.train_forward(*batch))
                 return
             loss = model.train_forward(*batch)
+            if args.adam == "lazy" and nxt is not None:  # replay the next batch's rows underneath this step
+                opt.prefetch_rows(model._lookup_plan(nxt[0], nxt[2], nxt[3]))
             opt.zero_grad()
             loss.backward()
             if args.phase == "step":
@@ -223,13 +244,21 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    single = not use_sharded and not args.graph
+
+    def run(i):
+        if single:
+            step(batches[i % len(batches)], batches[(i + 1) % len(batches)])
+        else:
+            step(batches[i % len(batches)])
+
     for i in range(args.warmup):
-        step(batches[i % len(batches)])
+        run(i)
     barrier()
     lib.tt_profile_enable(1)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(batches[i % len(batches)])
+        run(args.warmup + i)
     if args.adam == "lazy" and not use_sharded:
         opt.flush()  # every deferred row update is paid for inside the timed region
     barrier()

@@ -108,6 +108,8 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._tab_steps = 0
         self._host_steps = 0  # steps taken, counted on the host (no device sync)
         self._resume_step = 0  # step count adopted from a loaded checkpoint
+        self._prefetch_done: Optional[torch.cuda.Event] = None
+        self._prefetch_keep = None
         if self.lazy:
             for p in self._tables:
                 p._tt_lazy = _LazyRows(self, p)
@@ -148,6 +150,9 @@ class DenseExactAdam(torch.optim.Optimizer):
         """Rows `ids` of table `p` -> current step (called by the lookups before they read)."""
         if not self._ready or self._host_steps == 0 or not p.is_cuda or ids.numel() == 0:
             return  # nothing has been deferred yet (fresh, or just loaded from a flushed checkpoint)
+        if self._prefetch_done is not None:  # never replay a row on two streams at once
+            torch.cuda.current_stream().wait_event(self._prefetch_done)
+            self._prefetch_done, self._prefetch_keep = None, None
         ids = ids.reshape(-1)
         if ids.dtype != torch.int64 or not ids.is_contiguous():
             ids = ids.to(torch.int64).contiguous()
@@ -159,11 +164,51 @@ class DenseExactAdam(torch.optim.Optimizer):
                 "tt_adam_rows_catchup")
 
     @torch.no_grad()
+    def prefetch_rows(self, lookups: Dict[torch.nn.Parameter, Sequence[torch.Tensor]]) -> None:
+        """Deferred schedule: replay the idle steps of the rows a LATER batch will look up, on the
+        low-priority side stream, underneath the current step's forward / backward (the replay is
+        VALU work, the step is MFMA work).  Call it after the current step's ``train_forward`` --
+        rows the current step reads are then already current and are left alone -- with
+        ``model._lookup_plan(user_id, user_history, item_id)`` of the next batch.  ``step()`` waits
+        for it.  Purely a scheduling hint: results are bit-identical with or without it."""
+        if not self.lazy or not self._ready or self._host_steps == 0:
+            return
+        mine = {id(p): p for p in self._tables}
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)  # the current step's own catch-ups and gathers are enqueued before this point
+        self._side_stream.wait_event(ready)
+        lib = N.load()
+        keep = []
+        for p, blocks in lookups.items():
+            if id(p) not in mine or not p.is_cuda:
+                continue
+            st = self.state[p]
+            for ids in blocks:
+                ids = ids.reshape(-1)
+                if ids.dtype != torch.int64 or not ids.is_contiguous():
+                    ids = ids.to(torch.int64).contiguous()
+                if ids.numel() == 0:
+                    continue
+                keep.append(ids)
+                N.check(lib.tt_adam_rows_catchup(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                                 p.shape[0], p.shape[1], ids.data_ptr(), ids.numel(),
+                                                 self._last_step[id(p)].data_ptr(), self._hyper.data_ptr(),
+                                                 self._tab.data_ptr(), self._tab_steps,
+                                                 self._side_stream.cuda_stream), "tt_adam_rows_catchup")
+        self._prefetch_done = torch.cuda.Event()
+        self._prefetch_done.record(self._side_stream)
+        self._prefetch_keep = keep  # the id tensors must outlive the side-stream kernels
+
+    @torch.no_grad()
     def flush(self) -> None:
         """Deferred schedule: bring EVERY table row up to the current step.  Needed before the
         tables are read other than through this package's lookups (checkpoint, corpus export)."""
         if not self.lazy or not self._ready or self._host_steps == 0:
             return
+        if self._prefetch_done is not None:
+            torch.cuda.current_stream().wait_event(self._prefetch_done)
+            self._prefetch_done, self._prefetch_keep = None, None
         lib = N.load()
         for p in self._tables:
             st = self.state[p]
@@ -320,6 +365,9 @@ class DenseExactAdam(torch.optim.Optimizer):
                         "tt_adam_table_finish")
             self._begun = None
         elif self.lazy:
+            if self._prefetch_done is not None:  # rows being replayed for a later batch: finish first
+                torch.cuda.current_stream().wait_event(self._prefetch_done)
+                self._prefetch_done, self._prefetch_keep = None, None
             self._advance_lazy()
             for p in self._tables:
                 blocks = p._tt_rowgrads
