@@ -177,6 +177,8 @@ def main():
     lib = N.load()
 
     use_sharded = world > 1 or args.sharded
+    if use_sharded and (args.adam != "dense" or args.fresh_ids or args.phase != "step"):
+        raise SystemExit("--adam lazy / --fresh-ids / --phase apply to the single-GPU module path")
     if use_sharded:
         import torch.distributed as dist
         from two_tower_models_amd import sharded
