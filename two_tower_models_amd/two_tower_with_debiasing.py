@@ -18,40 +18,24 @@ from .two_tower_with_user_history_encoder import TwoTowerWithUserHistoryEncoder
 
 
 class TwoTowerWithDebiasing(TwoTowerWithUserHistoryEncoder):
-    def __init__(
-        self,
-        num_items: int,
-        user_id_hash_size: int,
-        user_id_embedding_dim: int,
-        user_features_size: int,
-        user_history_seqlen: int,
-        item_id_hash_size: int,
-        item_id_embedding_dim: int,
-        item_features_size: int,
-        user_value_weights: List[float],
-        mips_module: nn.Module,
-    ) -> None:
-        super().__init__(
-            num_items=num_items,
-            user_id_hash_size=user_id_hash_size,
-            user_id_embedding_dim=user_id_embedding_dim,
-            user_features_size=user_features_size,
-            user_history_seqlen=user_history_seqlen,
-            item_id_hash_size=item_id_hash_size,
-            item_id_embedding_dim=item_id_embedding_dim,
-            item_features_size=item_features_size,
-            user_value_weights=user_value_weights,
-            mips_module=mips_module,
-        )
-        self.position_bias_net_user_value = nn.Embedding(num_embeddings=100, embedding_dim=1)
+    # constructor keywords = ref :18-30
+    def __init__(self, num_items: int, user_id_hash_size: int, user_id_embedding_dim: int, user_features_size: int,
+                 user_history_seqlen: int, item_id_hash_size: int, item_id_embedding_dim: int,
+                 item_features_size: int, user_value_weights: List[float], mips_module: nn.Module) -> None:
+        super().__init__(num_items, user_id_hash_size, user_id_embedding_dim, user_features_size,
+                         user_history_seqlen, item_id_hash_size, item_id_embedding_dim, item_features_size,
+                         user_value_weights, mips_module)
+        # position prior: one scalar per position bucket; user prior: Linear([user emb | position prior]) -> 1
+        self.position_bias_net_user_value = nn.Embedding(100, 1)
         self.user_debias_net_user_value = nn.Sequential(nn.Linear(item_id_embedding_dim + 1, 1))
 
-    def debias_net_user_value(
-        self, net_user_value: torch.Tensor, position: torch.Tensor, user_embedding: torch.Tensor
-    ) -> Tuple[torch.Tensor, torch.Tensor]:
-        e_position = self.position_bias_net_user_value(position)  # [B, 1]
-        e_user = self.user_debias_net_user_value(torch.cat([user_embedding, e_position], dim=-1)).squeeze(1)
-        position_loss = F.mse_loss(input=e_position, target=net_user_value, reduction="sum")
-        user_loss = F.mse_loss(input=e_user, target=net_user_value, reduction="sum")
-        e_user = torch.clamp(e_user, min=1e-3)
-        return net_user_value / e_user, user_loss + position_loss
+    def debias_net_user_value(self, net_user_value: torch.Tensor, position: torch.Tensor,
+                              user_embedding: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(net_user_value / clamp(user prior), sum-MSE of both priors) -- ref :77-129, including
+        upstream's [B,1]-vs-[B] broadcast inside the position loss."""
+        pos_prior = self.position_bias_net_user_value(position)  # [B, 1]
+        head_in = torch.cat([user_embedding, pos_prior], dim=-1)  # [B, DI + 1]
+        user_prior = self.user_debias_net_user_value(head_in).squeeze(1)  # [B]
+        aux = F.mse_loss(user_prior, net_user_value, reduction="sum") \
+            + F.mse_loss(pos_prior, net_user_value, reduction="sum")
+        return net_user_value / torch.clamp(user_prior, min=1e-3), aux

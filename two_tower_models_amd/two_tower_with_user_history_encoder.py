@@ -14,42 +14,22 @@ from .user_history_encoder import UserHistoryEncoder
 
 
 class TwoTowerWithUserHistoryEncoder(TwoTowerBaseRetrieval):
-    def __init__(
-        self,
-        num_items: int,
-        user_id_hash_size: int,
-        user_id_embedding_dim: int,
-        user_features_size: int,
-        user_history_seqlen: int,
-        item_id_hash_size: int,
-        item_id_embedding_dim: int,
-        item_features_size: int,
-        user_value_weights: List[float],
-        mips_module: nn.Module,
-    ) -> None:
-        super().__init__(
-            num_items=num_items,
-            user_id_hash_size=user_id_hash_size,
-            user_id_embedding_dim=user_id_embedding_dim,
-            user_features_size=user_features_size,
-            item_id_hash_size=item_id_hash_size,
-            item_id_embedding_dim=item_id_embedding_dim,
-            item_features_size=item_features_size,
-            user_value_weights=user_value_weights,
-            mips_module=mips_module,
-        )
-        # 4 heads x 3 layers with positional encoding are hard-coded upstream (ref :64-70)
-        self.user_history_encoder = UserHistoryEncoder(
-            item_id_embedding_dim=item_id_embedding_dim,
-            history_len=user_history_seqlen,
-            num_attention_heads=4,
-            num_attention_layers=3,
-            use_positional_encoding=True,
-        )
-        # replaces the base tower: input = 2*DU + 2*DI (ref :81-83)
-        self.user_tower_arch = nn.Linear(
-            2 * user_id_embedding_dim + self.user_history_encoder.get_output_dim(), item_id_embedding_dim
-        )
+    # constructor keywords = ref :19-31 (callers pass them by name)
+    def __init__(self, num_items: int, user_id_hash_size: int, user_id_embedding_dim: int, user_features_size: int,
+                 user_history_seqlen: int, item_id_hash_size: int, item_id_embedding_dim: int,
+                 item_features_size: int, user_value_weights: List[float], mips_module: nn.Module) -> None:
+        base_kw = dict(num_items=num_items, user_id_hash_size=user_id_hash_size,
+                       user_id_embedding_dim=user_id_embedding_dim, user_features_size=user_features_size,
+                       item_id_hash_size=item_id_hash_size, item_id_embedding_dim=item_id_embedding_dim,
+                       item_features_size=item_features_size, user_value_weights=user_value_weights,
+                       mips_module=mips_module)
+        super().__init__(**base_kw)
+        DU, DI = user_id_embedding_dim, item_id_embedding_dim
+        # upstream hard-codes 4 heads x 3 layers with positional encoding (ref :64-70)
+        self.user_history_encoder = UserHistoryEncoder(DI, user_history_seqlen, num_attention_heads=4,
+                                                       num_attention_layers=3, use_positional_encoding=True)
+        # replaces the base tower: its input is now 2*DU + 2*DI wide (ref :81-83)
+        self.user_tower_arch = nn.Linear(2 * DU + self.user_history_encoder.get_output_dim(), DI)
 
     def process_user_features(
         self, user_id: torch.Tensor, user_features: torch.Tensor, user_history: torch.Tensor
