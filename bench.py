@@ -188,7 +188,7 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(dist_backend)
-        trainer = sharded.ShardedTrainer(cfg, device, negatives=args.negatives)
+        trainer = sharded.ShardedTrainer(cfg, device, negatives=args.negatives)  # cfg['model'] selects base / hist
         step = trainer.step
         batches = trainer.make_batches(16)
     else:

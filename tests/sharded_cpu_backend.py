@@ -22,26 +22,43 @@ class OracleBackend:
         out[mine] = table[local[mine]]
         return out
 
-    def tower_fwd(self, emb, feats, p):
+    def tower_fwd(self, emb, feats, p, extra=None):
         W1, b1, W2, b2, W3, b3 = p
         h = torch.clamp(feats @ W1.t() + b1, min=0.0)
         f = h @ W2.t() + b2
-        return h, f, torch.cat([emb, f], dim=1) @ W3.t() + b3
+        pieces = [emb, f] + ([extra] if extra is not None else [])
+        return h, f, torch.cat(pieces, dim=1) @ W3.t() + b3
 
-    def tower_bwd(self, d_out, emb, h, f, feats, p, g):
+    def tower_bwd(self, d_out, emb, h, f, feats, p, g, extra=None):
         W1, b1, W2, b2, W3, b3 = p
         gW1, gb1, gW2, gb2, gW3, gb3 = g
-        De = emb.shape[1]
-        gW3.copy_(d_out.t() @ torch.cat([emb, f], dim=1))
+        De, Dm = emb.shape[1], f.shape[1]
+        pieces = [emb, f] + ([extra] if extra is not None else [])
+        gW3.copy_(d_out.t() @ torch.cat(pieces, dim=1))
         gb3.copy_(d_out.sum(0))
         d_tin = d_out @ W3
-        d_f = d_tin[:, De:]
+        d_f = d_tin[:, De:De + Dm]
         gW2.copy_(d_f.t() @ h)
         gb2.copy_(d_f.sum(0))
         dh = (d_f @ W2) * (h > 0)
         gW1.copy_(dh.t() @ feats)
         gb1.copy_(dh.sum(0))
-        return d_tin[:, :De].contiguous()
+        return d_tin[:, :De].contiguous(), (d_tin[:, De + Dm:].contiguous() if extra is not None else None)
+
+    def encoder_fwd(self, x, pe, heads, layer_params):
+        xin = x.detach().clone().requires_grad_(True)
+        ps = [t.detach().clone().requires_grad_(True) for t in layer_params]
+        layers = [tuple(ps[4 * l: 4 * l + 4]) for l in range(len(ps) // 4)]
+        with torch.enable_grad():
+            out = R.history_encoder_forward(xin, layers, heads, pe)
+        return out.detach(), (out, xin, ps)
+
+    def encoder_bwd(self, saved, d_summary, grad_views):
+        out, xin, ps = saved
+        grads = torch.autograd.grad(out, [xin] + ps, d_summary)
+        for view, gr in zip(grad_views, grads[1:]):
+            view.copy_(gr)
+        return grads[0].reshape(-1, xin.shape[-1])
 
     def ce_fwd(self, U, I_all, off):
         s = R.inbatch_logits(U, I_all)

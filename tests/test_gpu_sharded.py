@@ -88,7 +88,9 @@ def test_mips_merge_kernel_and_world1_sharded_mips():
 # diag_offset, zero rows for ids another rank owns, sentinel rows in the Adam plan, the side-stream
 # sweep, mips_merge over W candidate lists.
 MULTI_CFGS = {"d128": dict(n_users=300, n_items=500, D=128, F=8, B=128, H=2),
-              "ragged": dict(n_users=53, n_items=71, D=40, F=20, B=24, H=2)}
+              "ragged": dict(n_users=53, n_items=71, D=40, F=20, B=24, H=2),
+              # TwoTowerWithUserHistoryEncoder: 4 heads x dh 32 (MFMA attention), B*H = 240 history rows per rank
+              "hist": dict(n_users=211, n_items=307, D=128, F=8, B=40, H=6, model="hist")}
 MULTI_STEPS = 3
 
 
@@ -96,8 +98,12 @@ def _multi_init(cfg):
     """Dense init with small tower weights + 0.5-scaled tables: logits O(1), loss ~ 3.  (With O(100)
     logits most rows are saturated, p - 1 cancels catastrophically and whole rows carry a 1e-2
     relative gradient error in ANY fp32 implementation.)"""
-    from test_sharded_cpu import _dense_init
-    dense = {k: (0.15 * v if k.endswith("tower_arch.weight") else v) for k, v in _dense_init(cfg).items()}
+    from test_sharded_cpu import _dense_init, _hist_dense_init
+    init = _hist_dense_init if cfg.get("model") == "hist" else _dense_init
+    hist = cfg.get("model") == "hist"
+    dense = {k: ((0.05 if hist else 0.15) * v if k.endswith("tower_arch.weight") else v) for k, v in init(cfg).items()}
+    if hist:  # D = 128: keep the attention logits and the summary O(1) as well
+        dense = {k: (0.3 * v if ("in_proj_weight" in k or "out_proj.weight" in k) else v) for k, v in dense.items()}
     g = torch.Generator().manual_seed(6)
     ut = 0.5 * torch.randn(cfg["n_users"], cfg["D"], generator=g)
     it = 0.5 * torch.randn(cfg["n_items"], cfg["D"], generator=g)
@@ -136,7 +142,7 @@ def _multi_worker(rank, world, port, outdir, cfg_name, negatives):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,cfg_name", [(2, "d128"), (3, "ragged")])
+@pytest.mark.parametrize("world,cfg_name", [(2, "d128"), (3, "ragged"), (2, "hist")])
 def test_multi_rank_hip_backend_equals_reference_on_concatenated_batch(world, cfg_name):
     import os
     import tempfile
@@ -152,9 +158,12 @@ def test_multi_rank_hip_backend_equals_reference_on_concatenated_batch(world, cf
     params["item_id_embedding_arch.weight"] = it.clone()
     state = R.AdamState(params)
     want = []
+    kw = {}
+    if cfg.get("model") == "hist":
+        kw = dict(with_history=True, heads=4, pos_table=R.positional_table(cfg["H"], cfg["D"]))
     for s in range(MULTI_STEPS):
         cat = [torch.cat([res[r]["batches"][s][k] for r in range(world)]) for k in range(7)]
-        want.append(R.train_step(params, state, cat, torch.tensor([0.7])))
+        want.append(R.train_step(params, state, cat, torch.tensor([0.7]), **kw))
     for r in range(world):
         assert np.allclose(res[r]["losses"], want, atol=1e-4), (res[r]["losses"], want)
         ulo, uhi, ilo, ihi = res[r]["lo_hi"]
@@ -169,7 +178,9 @@ def test_multi_rank_hip_backend_equals_reference_on_concatenated_batch(world, cf
         for name, got, ref in named:
             err = (got - ref).abs()
             assert float(err.max()) <= 2.2e-3 * MULTI_STEPS, (name, r, float(err.max()))
-            if name not in ("item_tower_arch.bias", "item_features_arch.2.bias"):  # zero true gradient: noise only
+            # zero true gradient, noise only: the item-side biases and the key third of every in_proj_bias
+            noise_only = name in ("item_tower_arch.bias", "item_features_arch.2.bias") or name.endswith("in_proj_bias")
+            if not noise_only:
                 assert float((err > 5e-6).float().mean()) <= 2e-3, (name, r, float((err > 5e-6).float().mean()))
         # replicas stay bit-identical
         assert all(torch.equal(v, res[0]["dense"][k]) for k, v in res[r]["dense"].items())

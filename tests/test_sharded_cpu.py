@@ -123,6 +123,84 @@ def test_local_negatives_is_mean_of_per_rank_losses():
     assert res[0]["losses"] == res[1]["losses"]
 
 
+# ---------------------------------------------------------------- history model
+HCFG = dict(n_users=37, n_items=61, D=16, F=4, B=6, H=5, model="hist")
+
+
+def _hist_dense_init(cfg):
+    g = torch.Generator().manual_seed(15)
+    D = cfg["D"]
+    out = {k: v for k, v in _dense_init(cfg).items() if k != "user_tower_arch.weight"}
+    out["user_tower_arch.weight"] = torch.randn(D, 4 * D, generator=g) * 0.15
+    for l in range(3):
+        base = f"user_history_encoder.multihead_attn_layers.{l}."
+        out[base + "in_proj_weight"] = torch.randn(3 * D, D, generator=g) * 0.2
+        out[base + "in_proj_bias"] = torch.randn(3 * D, generator=g) * 0.05
+        out[base + "out_proj.weight"] = torch.randn(D, D, generator=g) * 0.2
+        out[base + "out_proj.bias"] = torch.randn(D, generator=g) * 0.05
+    return out
+
+
+def _hist_worker(rank, world, port, outdir):
+    for p in (ROOT, HERE, os.path.join(HERE, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from sharded_cpu_backend import OracleBackend
+    from two_tower_models_amd import sharded
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        tr = sharded.ShardedTrainer(HCFG, torch.device("cpu"), backend=OracleBackend(), user_value_weights=(0.7,),
+                                    dense_init=_hist_dense_init(HCFG))
+        ut, it = _tables(HCFG)
+        tr.users.weight[: tr.users.hi - tr.users.lo].copy_(0.5 * ut[tr.users.lo:tr.users.hi])
+        tr.items.weight[: tr.items.hi - tr.items.lo].copy_(0.5 * it[tr.items.lo:tr.items.hi])
+        batches = tr.make_batches(STEPS, seed=41)
+        losses = [float(tr.step(b)) for b in batches]
+        torch.save({"losses": losses, "users": tr.users.weight.clone(), "items": tr.items.weight.clone(),
+                    "lo_hi": (tr.users.lo, tr.users.hi, tr.items.lo, tr.items.hi),
+                    "dense": {k: v.clone() for k, v in tr.params.items()},
+                    "batches": [tuple(t.clone() for t in b) for b in batches]},
+                   os.path.join(outdir, f"hist{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_history_model_equals_reference_on_concatenated_batch():
+    """TwoTowerWithUserHistoryEncoder on 2 ranks: B*H history rows fetched from the sharded item table,
+    encoder replicated, item-table gradients from both the id and the history lookups."""
+    from oracle import cpu_ref as R
+    world = 2
+    outdir = tempfile.mkdtemp()
+    mp.spawn(_hist_worker, args=(world, _free_port(), outdir), nprocs=world, join=True)
+    res = [torch.load(os.path.join(outdir, f"hist{r}.pt")) for r in range(world)]
+    ut, it = _tables(HCFG)
+    params = dict(_hist_dense_init(HCFG))
+    params["user_id_embedding_arch.weight"] = 0.5 * ut
+    params["item_id_embedding_arch.weight"] = 0.5 * it
+    state = R.AdamState(params)
+    pe = R.positional_table(HCFG["H"], HCFG["D"])
+    want = []
+    for s in range(STEPS):
+        cat = [torch.cat([res[r]["batches"][s][k] for r in range(world)]) for k in range(7)]
+        want.append(R.train_step(params, state, cat, torch.tensor([0.7]), with_history=True, heads=4, pos_table=pe))
+    for r in range(world):
+        assert np.allclose(res[r]["losses"], want, atol=1e-5), (res[r]["losses"], want)
+        ulo, uhi, ilo, ihi = res[r]["lo_hi"]
+        named = [("users", res[r]["users"][: uhi - ulo], params["user_id_embedding_arch.weight"][ulo:uhi]),
+                 ("items", res[r]["items"][: ihi - ilo], params["item_id_embedding_arch.weight"][ilo:ihi])]
+        named += [(k, v, params[k]) for k, v in res[r]["dense"].items()]
+        for name, got, ref in named:
+            err = (got - ref).abs()
+            assert float(err.max()) <= 2.2e-3 * STEPS, (name, float(err.max()))
+            # zero true gradient (Adam only sees rounding noise): the two item-side biases, and the K third
+            # of every in_proj_bias (a key bias shifts all scores of a query equally: softmax-invariant)
+            noise_only = name in ("item_tower_arch.bias", "item_features_arch.2.bias") or name.endswith("in_proj_bias")
+            if not noise_only:
+                assert float((err > 5e-6).float().mean()) <= 5e-3, (name, float((err > 5e-6).float().mean()))
+
+
 # ---------------------------------------------------------------- sharded MIPS
 def _mips_worker(rank, world, port, outdir, C, K):
     for p in (ROOT, HERE, os.path.join(HERE, "golden")):

@@ -133,44 +133,73 @@ class HipBackend:
                                         out.data_ptr(), table.shape[1], None, N.stream()), "tt_gather_rows")
         return out
 
-    def tower_fwd(self, emb: torch.Tensor, feats: torch.Tensor, p: Sequence[torch.Tensor]):
-        """out = [emb | MLP(feats)] W3^T + b3 without building the concatenation: two products
-        against the two column blocks of W3, the second accumulating.  Returns (h, f, out)."""
+    def tower_fwd(self, emb: torch.Tensor, feats: torch.Tensor, p: Sequence[torch.Tensor],
+                  extra: Optional[torch.Tensor] = None):
+        """out = [emb | MLP(feats) (| extra)] W3^T + b3 without building the concatenation: one
+        product per column block of W3, accumulating.  `extra` [B, E] is the history summary of the
+        history model's user tower (ref:src/two_tower_with_user_history_encoder.py:110-121).
+        Returns (h, f, out)."""
         W1, b1, W2, b2, W3, b3 = p
         ops, N = self.ops, self.N
         B, F = feats.shape
         Dm, Hd = W2.shape
-        De = W3.shape[1] - Dm
+        E = 0 if extra is None else extra.shape[1]
+        De = W3.shape[1] - Dm - E
         h = self.empty(B, Hd)
         ops.gemm(N.TT_GEMM_NT, feats, W1, h, B, Hd, F, bias=b1, epilogue=N.TT_EPI_RELU)
         f = self.empty(B, Dm)
         ops.gemm(N.TT_GEMM_NT, h, W2, f, B, Dm, Hd, bias=b2)
         out = self.empty(B, W3.shape[0])
         ops.gemm(N.TT_GEMM_NT, emb, W3[:, :De], out, B, W3.shape[0], De, bias=b3)
-        ops.gemm(N.TT_GEMM_NT, f, W3[:, De:], out, B, W3.shape[0], Dm, accumulate=True)
+        ops.gemm(N.TT_GEMM_NT, f, W3[:, De:De + Dm], out, B, W3.shape[0], Dm, accumulate=True)
+        if extra is not None:
+            ops.gemm(N.TT_GEMM_NT, extra, W3[:, De + Dm:], out, B, W3.shape[0], E, accumulate=True)
         return h, f, out
 
-    def tower_bwd(self, d_out, emb, h, f, feats, p, g):
+    def tower_bwd(self, d_out, emb, h, f, feats, p, g, extra: Optional[torch.Tensor] = None):
         """Writes the six parameter gradients into `g` (views of the flat gradient buffer) and
-        returns the gradient of the id-embedding rows [B, D_emb]."""
+        returns (gradient of the id-embedding rows [B, D_emb], gradient of `extra` or None)."""
         W1, b1, W2, b2, W3, b3 = p
         gW1, gb1, gW2, gb2, gW3, gb3 = g
         ops, N = self.ops, self.N
         B, F = feats.shape
         Dm, Hd = W2.shape
         Do, Din = W3.shape
-        De = Din - Dm
+        E = 0 if extra is None else extra.shape[1]
+        De = Din - Dm - E
         ops.gemm_tn_colsum(d_out, emb, gW3[:, :De], db=gb3)
-        ops.gemm(N.TT_GEMM_TN, d_out, f, gW3[:, De:], Do, Dm, B)
+        ops.gemm(N.TT_GEMM_TN, d_out, f, gW3[:, De:De + Dm], Do, Dm, B)
         d_emb = self.empty(B, De)
         ops.gemm(N.TT_GEMM_NN, d_out, W3[:, :De], d_emb, B, De, Do)
         d_f = self.empty(B, Dm)
-        ops.gemm(N.TT_GEMM_NN, d_out, W3[:, De:], d_f, B, Dm, Do)
+        ops.gemm(N.TT_GEMM_NN, d_out, W3[:, De:De + Dm], d_f, B, Dm, Do)
+        d_extra = None
+        if extra is not None:
+            ops.gemm(N.TT_GEMM_TN, d_out, extra, gW3[:, De + Dm:], Do, E, B)
+            d_extra = self.empty(B, E)
+            ops.gemm(N.TT_GEMM_NN, d_out, W3[:, De + Dm:], d_extra, B, E, Do)
         ops.gemm_tn_colsum(d_f, h, gW2, db=gb2)
         dh = self.empty(B, Hd)
         ops.gemm(N.TT_GEMM_NN, d_f, W2, dh, B, Hd, Dm, epilogue=N.TT_EPI_RELU_MASK, aux=h)
         ops.gemm_tn_colsum(dh, feats, gW1, db=gb1)
-        return d_emb
+        return d_emb, d_extra
+
+    # history encoder (ref:src/user_history_encoder.py:80-121) through the product's autograd function
+    def encoder_fwd(self, x: torch.Tensor, pe: Optional[torch.Tensor], heads: int, layer_params: Sequence[torch.Tensor]):
+        """x [B, H, D] embedded history -> (summary [B, 2, D], saved state for encoder_bwd)."""
+        xin = x.detach().requires_grad_(True)
+        ps = [t.detach().requires_grad_(True) for t in layer_params]
+        with torch.enable_grad():
+            out = self.ops.HistoryEncoder.apply(xin, None, pe, heads, *ps)
+        return out.detach(), (out, xin, ps)
+
+    def encoder_bwd(self, saved, d_summary: torch.Tensor, grad_views: Sequence[torch.Tensor]) -> torch.Tensor:
+        """-> d_x [B*H, D]; the layer-parameter gradients are written into `grad_views`."""
+        out, xin, ps = saved
+        grads = torch.autograd.grad(out, [xin] + ps, d_summary.contiguous())
+        for view, gr in zip(grad_views, grads[1:]):
+            view.copy_(gr)
+        return grads[0].reshape(-1, xin.shape[-1])
 
     def ce_fwd(self, U, I_all, off):
         ops, N, lib = self.ops, self.N, self.lib
@@ -290,7 +319,10 @@ class Lookup:
 
 class ShardedTrainer:
     """TwoTowerBaseRetrieval train step (ref:src/two_tower_base_retrieval.py:349-394 +
-    ref:train/train.py:112-125) on W row-sharded ranks.  `cfg`: n_users, n_items, D, F, B."""
+    ref:train/train.py:112-125) on W row-sharded ranks.  `cfg`: n_users, n_items, D, F, B; with
+    `model="hist"` and `H` the TwoTowerWithUserHistoryEncoder step
+    (ref:src/two_tower_with_user_history_encoder.py:85-122): the B*H history rows travel through
+    the same owner-gather / reduce-scatter exchange as the id rows, the encoder is replicated."""
 
     def __init__(self, cfg: Dict, device: torch.device, negatives: str = "global", backend=None,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, user_value_weights=(1.0,), seed: int = 0,
@@ -301,15 +333,28 @@ class ShardedTrainer:
         self.W, self.rank = dist.get_world_size(), dist.get_rank()
         self.be = backend if backend is not None else HipBackend(device)
         D, F = cfg["D"], cfg["F"]
+        # history model (ref:src/two_tower_with_user_history_encoder.py): the encoder is replicated,
+        # its input rows come out of the sharded ITEM table like every other lookup
+        self.hist = cfg.get("model", "base") == "hist"
+        self.heads, self.layers = 4, 3  # hard-coded upstream (ref :64-70)
         self.users = ShardedTable(cfg["n_users"], D, device, seed + 1)
         self.items = ShardedTable(cfg["n_items"], D, device, seed + 2)
         self.uvw = torch.tensor(list(user_value_weights), dtype=torch.float32, device=device)
         # replicated dense parameters live in ONE flat buffer (one all_reduce, one Adam launch)
         shapes = []
         for side in ("user", "item"):
+            tower_in = 4 * D if (self.hist and side == "user") else 2 * D
             shapes += [(f"{side}_features_arch.0.weight", (256, F)), (f"{side}_features_arch.0.bias", (256,)),
                        (f"{side}_features_arch.2.weight", (D, 256)), (f"{side}_features_arch.2.bias", (D,)),
-                       (f"{side}_tower_arch.weight", (D, 2 * D)), (f"{side}_tower_arch.bias", (D,))]
+                       (f"{side}_tower_arch.weight", (D, tower_in)), (f"{side}_tower_arch.bias", (D,))]
+        self.encoder_keys: List[str] = []
+        if self.hist:
+            for l in range(self.layers):
+                base = f"user_history_encoder.multihead_attn_layers.{l}."
+                layer = [(base + "in_proj_weight", (3 * D, D)), (base + "in_proj_bias", (3 * D,)),
+                         (base + "out_proj.weight", (D, D)), (base + "out_proj.bias", (D,))]
+                shapes += layer
+                self.encoder_keys += [k for k, _ in layer]
         total = sum(math.prod(s) for _, s in shapes)
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=device)
         self.flat_g = torch.zeros_like(self.flat_p)
@@ -325,11 +370,23 @@ class ShardedTrainer:
             self.grads[name] = self.flat_g[off:off + n].view(shape)
             if dense_init is not None:
                 self.params[name].copy_(dense_init[name].to(device))
-            elif len(shape) == 2:  # nn.Linear default: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
-                bound = 1.0 / math.sqrt(shape[1])
+            elif len(shape) == 2:
+                # nn.Linear default: U(-1/sqrt(fan_in), 1/sqrt(fan_in)); MultiheadAttention's packed
+                # in-projection: xavier-uniform.  Biases of the attention layers start at zero.
+                bound = (math.sqrt(6.0 / (shape[0] + shape[1])) if name.endswith("in_proj_weight")
+                         else 1.0 / math.sqrt(shape[1]))
                 self.params[name].copy_(((torch.rand(shape, generator=gen) * 2 - 1) * bound).to(device))
             off += n
         broadcast_(self.flat_p, src=0)  # replicas must start bit-identical
+        self.pe = None
+        if self.hist:  # the reference's table, newest item first (ref:src/user_history_encoder.py:35-78)
+            H = cfg["H"]
+            table = torch.zeros(H, D)
+            for pos in range(H):
+                for c in range(D):
+                    angle = pos / (10000 ** ((2 * c) / D))
+                    table[pos, c] = math.sin(angle) if c % 2 == 0 else math.cos(angle)
+            self.pe = table.flip([0]).contiguous().to(device)
         self.hyper = self.be.new_hyper(lr, betas, eps)
         self.last_loss = torch.zeros((), dtype=torch.float32, device=device)
 
@@ -390,20 +447,28 @@ class ShardedTrainer:
         return lk, rows
 
     def step(self, batch) -> torch.Tensor:
-        user_id, user_feat, _hist, item_id, item_feat, _pos, labels = batch
+        user_id, user_feat, hist_ids, item_id, item_feat, _pos, labels = batch
         be, W, D, B = self.be, self.W, self.cfg["D"], user_id.shape[0]
         # 1. embedding rows of the local batch, served by the owning ranks
         lk_u, u_emb = self._lookup(self.users, user_id)
+        if self.hist:  # history rows first: the reference's lookup order on the item table
+            lk_h, h_rows = self._lookup(self.items, hist_ids.reshape(-1))
         lk_i, i_emb = self._lookup(self.items, item_id)
+        item_local = torch.cat([lk_h.local, lk_i.local]) if self.hist else lk_i.local
         # the tables' old rows have been read: plan, park the looked-up rows, and start the
         # zero-gradient sweep on the side stream -- it overlaps everything up to step 6
         be.adam_advance(self.hyper)
         st_u = be.adam_table_begin(self.users.weight, self.users.m, self.users.v, lk_u.n_local, lk_u.local)
-        st_i = be.adam_table_begin(self.items.weight, self.items.m, self.items.v, lk_i.n_local, lk_i.local)
+        st_i = be.adam_table_begin(self.items.weight, self.items.m, self.items.v, lk_i.n_local, item_local)
         be.sweep_async([(self.users.weight, self.users.m, self.users.v, lk_u.n_local),
                         (self.items.weight, self.items.m, self.items.v, lk_i.n_local)], self.hyper)
         pu, pi = self._tower_params("user"), self._tower_params("item")
-        u_h, u_f, U = be.tower_fwd(u_emb, user_feat, pu)
+        summary, enc_saved = None, None
+        if self.hist:
+            enc_params = [self.params[k] for k in self.encoder_keys]
+            summary3, enc_saved = be.encoder_fwd(h_rows.view(B, -1, D), self.pe, self.heads, enc_params)
+            summary = summary3.reshape(B, 2 * D)
+        u_h, u_f, U = be.tower_fwd(u_emb, user_feat, pu, extra=summary)
         i_h, i_f, I = be.tower_fwd(i_emb, item_feat, pi)
         # 2. logits against every rank's items
         glob = self.negatives == "global" and W > 1
@@ -425,12 +490,16 @@ class ShardedTrainer:
         dU, dI_all = be.ce_bwd(U, I_all, off, lse, coef)
         dI = reduce_scatter_rows(dI_all) if glob else dI_all
         # 5. towers backward -> dense grads (flat buffer) + embedding-row grads
-        d_urows = be.tower_bwd(dU, u_emb, u_h, u_f, user_feat, pu, self._tower_grads("user"))
-        d_irows = be.tower_bwd(dI, i_emb, i_h, i_f, item_feat, pi, self._tower_grads("item"))
+        d_urows, d_summary = be.tower_bwd(dU, u_emb, u_h, u_f, user_feat, pu, self._tower_grads("user"), extra=summary)
+        d_irows, _ = be.tower_bwd(dI, i_emb, i_h, i_f, item_feat, pi, self._tower_grads("item"))
+        if self.hist:
+            d_hrows = be.encoder_bwd(enc_saved, d_summary.view(B, 2, D), [self.grads[k] for k in self.encoder_keys])
         if W > 1:
             all_reduce_(self.flat_g)
         g_u = all_gather_rows(d_urows) if W > 1 else d_urows  # aligned with lk_u.local
         g_i = all_gather_rows(d_irows) if W > 1 else d_irows
+        if self.hist:  # aligned with item_local = [history ids | item ids]
+            g_i = torch.cat([all_gather_rows(d_hrows) if W > 1 else d_hrows, g_i])
         # 6. dense-exact Adam: the looked-up rows of this rank's blocks, over the swept tables
         be.sweep_wait()
         be.adam_table_finish(self.users.weight, self.users.m, self.users.v, self.hyper, st_u, g_u)
