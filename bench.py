@@ -40,6 +40,8 @@ WORKLOADS = {
     # BASELINE config 4: 100 M items (row-sharded x8 in the reference plan; 155 GB of p, m, v also fits ONE
     # MI355X's 288 GB, which is what `--workload C4 --gpus 1` runs)
     "C4": dict(n_users=1_000_000, n_items=100_000_000, D=128, F=8, B=8192, H=4, model="base"),
+    # logits-bound shape (what every rank sees once the tables are sharded thin): small tables, full batch
+    "CE": dict(n_users=100_000, n_items=100_000, D=128, F=8, B=8192, H=4, model="base"),
     "tiny": dict(n_users=1024, n_items=10_000, D=32, F=8, B=128, H=4, model="base"),
 }
 
