@@ -25,7 +25,7 @@ struct WsArgs {
   const float* aux;
   int64_t M, N, K, lda, ldw, ldc, ldaux;
   int colblocks, rowgroups;  // grid = colblocks * rowgroups workgroups, 1-D
-  int a_vec, w_vec, c_vec, epilogue, accumulate, epi_after_acc, dbg_nostore;
+  int a_vec, w_vec, c_vec, epilogue, accumulate, epi_after_acc;
 };
 
 // stationary fragments from a [K][N] (row = reduction index) weight: xr[g][c] = W[8g+4h+c][n]
@@ -140,10 +140,7 @@ __global__ __launch_bounds__(256, ((GLDS && DP8 <= 16) ? 2 : 1)) void gemm_ws_ke
         }
       }
     } else {
-      if (p.dbg_nostore) {  // ablation: keep the accumulators live, write nothing
-#pragma unroll
-        for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[e]));
-      } else if (m < p.M) {
+      if (m < p.M) {
         // 32-bit element offsets (the host guarantees M*ldc < 2^31)
         const int coff = (int)m * (int)p.ldc + (int)nw + 4 * h;
         const int aoff = (int)m * (int)p.ldaux + (int)nw + 4 * h;
@@ -238,7 +235,6 @@ static int ws_launch_one(int layout, int64_t M, int64_t N, int64_t K, const floa
   a.A = A; a.W = W; a.C = C; a.bias = bias; a.aux = aux;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldaux = ldaux;
   a.epilogue = epilogue; a.accumulate = accumulate; a.epi_after_acc = epi_after_acc;
-  a.dbg_nostore = getenv("TT_WS_NOSTORE") != nullptr;
   a.a_vec = (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   a.w_vec = (ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
   a.c_vec = (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
@@ -255,7 +251,7 @@ static int ws_launch_one(int layout, int64_t M, int64_t N, int64_t K, const floa
   dim3 grid((unsigned)(colblocks * rowgroups));
   const bool wt = layout == TT_GEMM_NN;
   int mode = WS_GENERIC;
-  if (a.c_vec && N % 32 == 0 && epilogue == TT_EPI_NONE && !a.dbg_nostore) mode = accumulate ? WS_ACC : WS_PLAIN;
+  if (a.c_vec && N % 32 == 0 && epilogue == TT_EPI_NONE) mode = accumulate ? WS_ACC : WS_PLAIN;
   if (dma) return wt ? dispatch_mode<true, true>(mode, dp8, a, grid, st) : dispatch_mode<true, false>(mode, dp8, a, grid, st);
   return wt ? dispatch_mode<false, true>(mode, dp8, a, grid, st) : dispatch_mode<false, false>(mode, dp8, a, grid, st);
 }
