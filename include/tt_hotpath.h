@@ -116,8 +116,17 @@ int tt_inbatch_ce_fwd(const float* U, int64_t ldu, const float* I, int64_t ldi, 
                       void* ws, int64_t ws_bytes, tt_stream_t stream);
 int tt_inbatch_ce_bwd(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M,
                       int64_t N, int64_t D, int64_t diag_offset, const float* row_lse,
-                      const float* coef, float* dU, int64_t lddu, float* dI, int64_t lddi,
+                      const float* coef, float* dU /* may be NULL */, int64_t lddu, float* dI, int64_t lddi,
                       void* ws, int64_t ws_bytes, tt_stream_t stream);
+
+/* Forward fused with the user-side gradient: additionally returns
+ *   du_unit[i,:] = sum_j softmax(S)[i,j] I[j,:] - I[i + diag_offset,:]
+ * so that dU[i,:] = dLoss/drow_ce[i] * du_unit[i,:] is an elementwise step and tt_inbatch_ce_bwd can
+ * be called with dU == NULL (item side only): 4 instead of 5 logit-sized products per training
+ * step.  Same workspace query as the other two. */
+int tt_inbatch_ce_fwd_du(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N,
+                         int64_t D, int64_t diag_offset, float* row_lse, float* row_ce, float* du_unit,
+                         int64_t ld_du, void* ws, int64_t ws_bytes, tt_stream_t stream);
 
 /* net_user_value weights, ref:...base_retrieval.py:322,334-339 for 2-D labels:
  *   nuv[i] = sum_t labels[i,t]*uvw[t];  w = clamp(nuv,1e-6);  w /= max_i w

@@ -139,6 +139,44 @@ def test_inbatch_ce_large_logits_stable(T):
     assert torch.allclose(ce.cpu().double(), ref, atol=1e-3, rtol=1e-5)
 
 
+@pytest.mark.parametrize("M,Nn,D,off,scale", [(300, 300, 128, 0, 0.5), (130, 700, 128, 400, 0.5), (96, 96, 128, 0, 3.0),
+                                               (77, 200, 40, 50, 1.0), (8192, 8192, 128, 0, 0.3)])
+def test_inbatch_ce_fused_forward_gives_the_user_gradient(T, M, Nn, D, off, scale):
+    """tt_inbatch_ce_fwd_du: row statistics identical in meaning to tt_inbatch_ce_fwd, and
+    coef * du_unit == the dU of tt_inbatch_ce_bwd (whose dU kernel it replaces), including rows
+    whose softmax is saturated (logits ~ +-100 at scale 3) and the split / ragged shapes;
+    tt_inbatch_ce_bwd with dU == NULL still returns the same dI."""
+    ops, N = T
+    lib = N.load()
+    U = (g((M, D), 61) * scale).to(DEV)
+    I = (g((Nn, D), 62) * scale).to(DEV)
+    coef = (g((M,), 63).abs() / M).to(DEV)
+    wsp, wsn = ops._ws(torch.device(DEV), lib.tt_inbatch_ce_workspace_bytes(M, Nn, D), "ce_test")
+    e = lambda *shape: torch.empty(*shape, device=DEV)
+    lse1, ce1, lse2, ce2, du_unit = e(M), e(M), e(M), e(M), e(M, D)
+    N.check(lib.tt_inbatch_ce_fwd(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, off, lse1.data_ptr(), ce1.data_ptr(),
+                                  wsp, wsn, N.stream()), "fwd")
+    dU, dI = e(M, D), e(Nn, D)
+    N.check(lib.tt_inbatch_ce_bwd(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, off, lse1.data_ptr(), coef.data_ptr(),
+                                  dU.data_ptr(), D, dI.data_ptr(), D, wsp, wsn, N.stream()), "bwd")
+    N.check(lib.tt_inbatch_ce_fwd_du(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, off, lse2.data_ptr(), ce2.data_ptr(),
+                                     du_unit.data_ptr(), D, wsp, wsn, N.stream()), "fwd_du")
+    dI2 = e(Nn, D)
+    N.check(lib.tt_inbatch_ce_bwd(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, off, lse2.data_ptr(), coef.data_ptr(),
+                                  None, D, dI2.data_ptr(), D, wsp, wsn, N.stream()), "bwd items")
+    assert torch.allclose(ce2, ce1, atol=2e-5 * max(1.0, scale * scale * 10), rtol=1e-5)
+    dU2 = du_unit * coef.unsqueeze(1)
+    # fp64 reference for the user-side gradient
+    Ud, Id = U.cpu().double(), I.cpu().double()
+    P = torch.softmax(Ud @ Id.t(), dim=1)
+    P[torch.arange(M), torch.arange(M) + off] -= 1.0
+    ref = (P * coef.cpu().double().unsqueeze(1)) @ Id
+    tol = 2e-5 * float(ref.abs().max()) + 1e-12
+    assert float((dU2.cpu().double() - ref).abs().max()) <= tol
+    assert float((dU.cpu().double() - ref).abs().max()) <= tol
+    assert torch.allclose(dI2, dI, atol=1e-6 * float(dI.abs().max()) + 1e-12, rtol=1e-5)
+
+
 def test_weighted_mean_loss(T):
     ops, N = T
     B, Tn = 777, 3

@@ -30,7 +30,18 @@ for M, Nn in shapes:
         N.check(lib.tt_inbatch_ce_bwd(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, 0, lse.data_ptr(), coef.data_ptr(),
                                       dU.data_ptr(), D, dI.data_ptr(), D, ws.data_ptr(), wsn, N.stream()), "bwd")
 
-    for name, fn, flops in (("fwd", fwd, 2.0 * M * Nn * D), ("bwd", bwd, 8.0 * M * Nn * D)):
+    du_unit = torch.empty(M, D, device=dev)
+
+    def fwd_du():  # forward + expected item embedding (the user-side gradient up to the row factor)
+        N.check(lib.tt_inbatch_ce_fwd_du(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, 0, lse.data_ptr(), ce.data_ptr(),
+                                         du_unit.data_ptr(), D, ws.data_ptr(), wsn, N.stream()), "fwd_du")
+
+    def bwd_items():  # item-side gradient only (dU == NULL)
+        N.check(lib.tt_inbatch_ce_bwd(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, 0, lse.data_ptr(), coef.data_ptr(),
+                                      None, D, dI.data_ptr(), D, ws.data_ptr(), wsn, N.stream()), "bwd_items")
+
+    for name, fn, flops in (("fwd", fwd, 2.0 * M * Nn * D), ("bwd", bwd, 8.0 * M * Nn * D),
+                            ("fwd_du", fwd_du, 4.0 * M * Nn * D), ("bwd_items", bwd_items, 4.0 * M * Nn * D)):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()

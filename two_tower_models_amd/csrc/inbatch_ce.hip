@@ -281,6 +281,174 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_bwd_kern
   }
 }
 
+// ------------------------------------------------------------------ forward fused with dU
+// Forward that also returns E[a][:] = sum_b softmax(S)[a][b] * Y[b][:], the expected item embedding
+// of every user -- from which dU[a] = dLoss/dce[a] * (E[a] - Y[a + diag_offset]) is an elementwise
+// step, so the backward needs no dU kernel and its recomputation of the logits (5 -> 4 logit-sized
+// products per training step; at 8 GPUs with global negatives the logits ARE the step).
+// It is the dU kernel above with the online-softmax state of the forward: probabilities are formed
+// against the RUNNING maximum, and whenever that moves the accumulated rows are rescaled.  The
+// accumulator tile has one output column per lane and 16 USER rows in the registers, so the 32
+// per-user factors of a wave travel through 128 B of LDS (written by the lane that owns the user,
+// read as four float4 by everybody).  Both lane halves of a user share one running maximum (one
+// cross-half exchange per sub-tile), because their probabilities are summed by the same MFMA.
+template <int DP8, bool GLDS>
+__global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_du_kernel(const CeArgs p) {
+  using TM = TileMap<DP8, GLDS>;
+  constexpr int TD = (DP8 + 3) / 4;
+  constexpr int TILE_FLOATS = BJ * TM::LD;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* const smem = reinterpret_cast<float*>(smem_raw);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t a = (int64_t)blockIdx.x * BI + wave * 32 + r;
+  float* const fbuf = smem + 2 * TILE_FLOATS + wave * 32;  // this wave's 32 rescale factors
+
+  float xr[DP8][4];
+  load_stationary<DP8>(xr, p.X, p.ldx, a, p.RX, p.D, h, p.x_vec);
+
+  const int64_t ntiles_all = (p.RY + BJ - 1) / BJ;
+  const int64_t t0 = (int64_t)blockIdx.y * p.tiles_per_split;
+  const int64_t t1 = (t0 + p.tiles_per_split < ntiles_all) ? t0 + p.tiles_per_split : ntiles_all;
+
+  f32x16 dacc[TD];
+#pragma unroll
+  for (int d = 0; d < TD; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dacc[d][e] = 0.f;
+  int ybase[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    ybase[q] = GLDS ? 4 * h * TM::LD + 4 * ((((r >> 2) ^ (4 * h)) & TM::SW) ^ q) + (r & 3) : 4 * h * TM::LD + r;
+
+  float m = NEG_BIG, s = 0.f, dg = 0.f;
+  bool has_dg = false;
+  const int64_t want = a + p.diag_offset;
+
+  Stager<DP8, GLDS> stg;
+  if (t0 < t1) {
+    stg.issue(p.Y, p.ldy, t0 * BJ, p.RY, p.D, p.y_vec, smem, wave, lane);
+    stg.land(smem);
+  }
+  __syncthreads();
+  for (int64_t t = t0; t < t1; ++t) {
+    const int cur = (int)((t - t0) & 1);
+    float* nxt = smem + (cur ^ 1) * TILE_FLOATS;
+    if (t + 1 < t1) stg.issue(p.Y, p.ldy, (t + 1) * BJ, p.RY, p.D, p.y_vec, nxt, wave, lane);
+    const float* ys = smem + cur * TILE_FLOATS;
+    const int64_t wrel = want - t * BJ, lrel = p.RY - t * BJ;
+    const int want4 = (wrel >= 0 && wrel < BJ) ? (int)wrel - 4 * h : -1000;
+    const int lim4 = (lrel < BJ ? (int)lrel : BJ) - 4 * h;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      const f32x16 acc = score_tile<DP8, GLDS>(ys, xr, jt, r, h);
+      float v2[16];
+      float tmax = NEG_BIG;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int li = jt * 32 + (e & 3) + 8 * (e >> 2);
+        const float s2 = acc[e] * LOG2E;
+        if (li == want4) { dg = s2; has_dg = true; }
+        v2[e] = (li < lim4) ? s2 : NEG_BIG;
+        tmax = fmaxf(tmax, v2[e]);
+      }
+      float mn = fmaxf(m, tmax);
+      mn = fmaxf(mn, __shfl_xor(mn, 32, 64));  // one reference per USER: both lane halves feed the same MFMA
+      const float f = fast_exp2(m - mn);       // m is identical in both halves by construction
+      float add = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        v2[e] = fast_exp2(v2[e] - mn);  // in place: v2 now holds the probabilities (rows past the end: 0)
+        add += v2[e];
+      }
+      s = s * f + add;
+      m = mn;
+      // rescale the accumulated rows: register e of dacc is user row brow(e, h) of this wave
+      if (h == 0) fbuf[r] = f;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 f4 = *reinterpret_cast<const float4*>(fbuf + 8 * q + 4 * h);
+#pragma unroll
+        for (int d = 0; d < TD; ++d) {
+          dacc[d][4 * q] *= f4.x; dacc[d][4 * q + 1] *= f4.y; dacc[d][4 * q + 2] *= f4.z; dacc[d][4 * q + 3] *= f4.w;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // O[a][d] += sum_b p[a][b] * Y[b][d]  (the dU kernel's second product, same operand addressing)
+      float yv[2][TD];
+      auto yread = [&](int e, float (&dst)[TD]) {
+        const int E = (e & 3) + 8 * (e >> 2);
+        const int hi = (GLDS && TM::SW >= 8) ? ((e >> 2) & 1) : 0;
+#pragma unroll
+        for (int d = 0; d < TD; ++d) dst[d] = ys[(jt * 32 + E) * TM::LD + 32 * (d ^ hi) + ybase[e & 3]];
+      };
+      yread(0, yv[0]);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if (e + 1 < 16) yread(e + 1, yv[(e + 1) & 1]);
+#pragma unroll
+        for (int d = 0; d < TD; ++d)
+          dacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2[e], yv[e & 1][d], dacc[d], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (t + 1 < t1) stg.land(nxt);
+    __syncthreads();
+  }
+  // the two lane halves hold the same m and disjoint parts of the sum
+  const float so = __shfl_xor(s, 32, 64), dgo = __shfl_xor(dg, 32, 64);
+  const bool has_o = __shfl_xor((int)has_dg, 32, 64) != 0;
+  if (h == 0 && a < p.RX) {
+    p.part_m[(int64_t)blockIdx.y * p.RX + a] = m;
+    p.part_s[(int64_t)blockIdx.y * p.RX + a] = s + so;
+    if (has_dg || has_o) p.diag[a] = has_dg ? dg : dgo;
+  }
+  float* out = p.out + (int64_t)blockIdx.y * p.RX * p.D;  // unnormalised, relative to 2^m of this split
+  const int64_t abase = (int64_t)blockIdx.x * BI + wave * 32;
+#pragma unroll
+  for (int d = 0; d < TD; ++d) {
+    const int64_t col = 32 * d + r;
+    if (col >= p.D) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t row = abase + brow(e, h);
+      if (row < p.RX) out[row * p.D + col] = dacc[d][e];
+    }
+  }
+}
+
+// merge the splits: row statistics as ce_fwd_finish_kernel, E = sum_z O_z 2^(m_z - M) / S, and
+// du_unit[a] = E[a] - Y[a + diag_offset]  (dU[a] = dLoss/dce[a] * du_unit[a])
+__global__ __launch_bounds__(256) void ce_fwd_du_finish_kernel(const float* __restrict__ part_m,
+                                                               const float* __restrict__ part_s,
+                                                               const float* __restrict__ diag,
+                                                               const float* __restrict__ slabs, int splits, int64_t M,
+                                                               int64_t D, const float* __restrict__ Y, int64_t ldy,
+                                                               int64_t diag_offset, float* __restrict__ row_lse,
+                                                               float* __restrict__ row_ce, float* __restrict__ du_unit,
+                                                               int64_t ld_du) {
+  // one wavefront per user row
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  float mx = NEG_BIG;
+  for (int z = 0; z < splits; ++z) mx = fmaxf(mx, part_m[(int64_t)z * M + row]);
+  float S = 0.f;
+  for (int z = 0; z < splits; ++z) S += part_s[(int64_t)z * M + row] * exp2f(part_m[(int64_t)z * M + row] - mx);
+  const float inv = 1.0f / S;
+  for (int64_t col = lane; col < D; col += 64) {
+    float e = 0.f;
+    for (int z = 0; z < splits; ++z)
+      e += slabs[((int64_t)z * M + row) * D + col] * exp2f(part_m[(int64_t)z * M + row] - mx);
+    du_unit[row * ld_du + col] = e * inv - Y[(row + diag_offset) * ldy + col];
+  }
+  if (lane == 0) {
+    const float lse2 = mx + log2f(S);
+    row_lse[row] = lse2;
+    row_ce[row] = (lse2 - diag[row]) * LN2;
+  }
+}
+
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int splits, int64_t rows, int64_t D,
                                    float* __restrict__ out, int64_t ldo) {
   const int64_t total = rows * D;
@@ -392,6 +560,19 @@ static int dispatch_fwd(int dp8, bool dma, const CeArgs& a, dim3 grid, hipStream
   if (dma) return dp8 == 4 ? launch_fwd<4, true>(a, grid, st) : dp8 == 8 ? launch_fwd<8, true>(a, grid, st) : launch_fwd<16, true>(a, grid, st);
   return dp8 == 4 ? launch_fwd<4, false>(a, grid, st) : dp8 == 8 ? launch_fwd<8, false>(a, grid, st) : launch_fwd<16, false>(a, grid, st);
 }
+template <int DP8, bool GLDS>
+static int launch_fwd_du(const CeArgs& a, dim3 grid, hipStream_t st) {
+  const size_t lds = (2 * BJ * TileMap<DP8, GLDS>::LD + 4 * 32) * sizeof(float);
+  int rc = opt_in_lds(ce_fwd_du_kernel<DP8, GLDS>, lds, "ce_fwd_du_kernel");
+  if (rc) return rc;
+  ProfScope prof("ce_fwd_kernel", st);
+  ce_fwd_du_kernel<DP8, GLDS><<<grid, 256, lds, st>>>(a);
+  return check_launch("ce_fwd_du_kernel");
+}
+static int dispatch_fwd_du(int dp8, bool dma, const CeArgs& a, dim3 grid, hipStream_t st) {
+  if (dma) return dp8 == 4 ? launch_fwd_du<4, true>(a, grid, st) : dp8 == 8 ? launch_fwd_du<8, true>(a, grid, st) : launch_fwd_du<16, true>(a, grid, st);
+  return dp8 == 4 ? launch_fwd_du<4, false>(a, grid, st) : dp8 == 8 ? launch_fwd_du<8, false>(a, grid, st) : launch_fwd_du<16, false>(a, grid, st);
+}
 template <bool SS>
 static int dispatch_bwd(int dp8, bool dma, const CeArgs& a, dim3 grid, hipStream_t st) {
   if (dma) return dp8 == 4 ? launch_bwd<4, SS, true>(a, grid, st) : dp8 == 8 ? launch_bwd<8, SS, true>(a, grid, st) : launch_bwd<16, SS, true>(a, grid, st);
@@ -410,7 +591,10 @@ extern "C" int64_t tt_inbatch_ce_workspace_bytes(int64_t M, int64_t N, int64_t D
   const int64_t du = pu.splits > 1 ? round_up((int64_t)pu.splits * M * D * 4, 256) : 0;
   const int64_t di = pi.splits > 1 ? round_up((int64_t)pi.splits * N * D * 4, 256) : 0;
   const int64_t bwd = du + di;
-  return fwd > bwd ? fwd : bwd;
+  // tt_inbatch_ce_fwd_du keeps the statistics and ALWAYS writes its per-split slabs
+  const int64_t fwd_du = fwd + round_up((int64_t)pu.splits * M * D * 4, 256);
+  const int64_t most = fwd > bwd ? fwd : bwd;
+  return most > fwd_du ? most : fwd_du;
 }
 
 extern "C" int tt_inbatch_ce_fwd(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M,
@@ -436,12 +620,37 @@ extern "C" int tt_inbatch_ce_fwd(const float* U, int64_t ldu, const float* I, in
   return check_launch("ce_fwd_finish_kernel");
 }
 
+extern "C" int tt_inbatch_ce_fwd_du(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N,
+                                    int64_t D, int64_t diag_offset, float* row_lse, float* row_ce, float* du_unit,
+                                    int64_t ld_du, void* ws, int64_t ws_bytes, tt_stream_t stream) {
+  if (!U || !I || !row_lse || !row_ce || !du_unit || !ws) return fail_arg("tt_inbatch_ce_fwd_du: null pointer");
+  if (M <= 0 || N <= 0 || D <= 0 || ldu < D || ldi < D || ld_du < D) return fail_arg("tt_inbatch_ce_fwd_du: sizes");
+  if (diag_offset < 0 || diag_offset + M > N) return fail_arg("tt_inbatch_ce_fwd_du: diagonal outside the item block");
+  CePlan pl;
+  if (!plan_ce(M, N, D, pl)) { set_error("tt_inbatch_ce: D=%lld > 128 not implemented", (long long)D); return TT_E_UNSUPPORTED; }
+  if (ws_bytes < tt_inbatch_ce_workspace_bytes(M, N, D)) { set_error("tt_inbatch_ce_fwd_du: workspace"); return TT_E_WORKSPACE; }
+  float* w = reinterpret_cast<float*>(ws);
+  CeArgs a{};
+  a.X = U; a.Y = I; a.ldx = ldu; a.ldy = ldi; a.RX = M; a.RY = N; a.D = D;
+  a.diag_offset = diag_offset; a.tiles_per_split = pl.tiles_per_split; a.splits = pl.splits;
+  a.x_vec = (ldu % 4 == 0) && al16(U); a.y_vec = (ldi % 4 == 0) && al16(I);
+  a.part_m = w; a.part_s = w + (int64_t)pl.splits * M; a.diag = w + 2 * (int64_t)pl.splits * M;
+  a.out = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + round_up((2 * (int64_t)pl.splits * M + M) * 4, 256));
+  dim3 grid((unsigned)ceil_div(M, BI), (unsigned)pl.splits);
+  hipStream_t st = S(stream);
+  int rc = dispatch_fwd_du(pl.dp8, can_dma(I, ldi, D, pl.dp8), a, grid, st);
+  if (rc) return rc;
+  ce_fwd_du_finish_kernel<<<(unsigned)ceil_div(M, 4), 256, 0, st>>>(a.part_m, a.part_s, a.diag, a.out, pl.splits, M, D, I,
+                                                                     ldi, diag_offset, row_lse, row_ce, du_unit, ld_du);
+  return check_launch("ce_fwd_du_finish_kernel");
+}
+
 extern "C" int tt_inbatch_ce_bwd(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M,
                                  int64_t N, int64_t D, int64_t diag_offset, const float* row_lse,
                                  const float* coef, float* dU, int64_t lddu, float* dI, int64_t lddi,
                                  void* ws, int64_t ws_bytes, tt_stream_t stream) {
-  if (!U || !I || !row_lse || !coef || !dU || !dI || !ws) return fail_arg("tt_inbatch_ce_bwd: null pointer");
-  if (M <= 0 || N <= 0 || D <= 0 || ldu < D || ldi < D || lddu < D || lddi < D) return fail_arg("tt_inbatch_ce_bwd: sizes");
+  if (!U || !I || !row_lse || !coef || !dI || !ws) return fail_arg("tt_inbatch_ce_bwd: null pointer");
+  if (M <= 0 || N <= 0 || D <= 0 || ldu < D || ldi < D || (dU && lddu < D) || lddi < D) return fail_arg("tt_inbatch_ce_bwd: sizes");
   CePlan pu, pi;
   if (!plan_ce(M, N, D, pu) || !plan_ce(N, M, D, pi)) { set_error("tt_inbatch_ce: D=%lld > 128 not implemented", (long long)D); return TT_E_UNSUPPORTED; }
   if (ws_bytes < tt_inbatch_ce_workspace_bytes(M, N, D)) { set_error("tt_inbatch_ce_bwd: workspace"); return TT_E_WORKSPACE; }
@@ -450,7 +659,7 @@ extern "C" int tt_inbatch_ce_bwd(const float* U, int64_t ldu, const float* I, in
   float* slab_u = reinterpret_cast<float*>(wsb);
   float* slab_i = reinterpret_cast<float*>(wsb + (pu.splits > 1 ? round_up((int64_t)pu.splits * M * D * 4, 256) : 0));
   int rc;
-  {  // dU: stationary users, streamed items
+  if (dU) {  // dU: stationary users, streamed items (skipped when the forward already produced it)
     CeArgs a{};
     a.X = U; a.Y = I; a.ldx = ldu; a.ldy = ldi; a.RX = M; a.RY = N; a.D = D; a.diag_offset = diag_offset;
     a.tiles_per_split = pu.tiles_per_split; a.splits = pu.splits;

@@ -8,6 +8,7 @@ allocator, the autograd tape and the stream.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -363,6 +364,9 @@ class TowerInput(torch.autograd.Function):
         return dweight, None, None, dW1, db1, dW2, db2
 
 
+_FUSED_DU = os.environ.get("TT_CE_NO_FUSED_DU") is None  # A/B switch
+
+
 class InBatchSoftmaxCE(torch.autograd.Function):
     """row_ce[i] = logsumexp_j (U I^T)[i, j] - (U I^T)[i, i + diag_offset]
     (torch.matmul + F.cross_entropy(reduction="none"), ref:...base_retrieval.py:287-312)."""
@@ -379,28 +383,38 @@ class InBatchSoftmaxCE(torch.autograd.Function):
         wsp, wsn = _ws(dev, lib.tt_inbatch_ce_workspace_bytes(M, Nn, D))
         pu, _, _, ldu = _f32_2d(U, "U")
         pi, _, _, ldi = _f32_2d(I, "I")
+        ctx.diag_offset = diag_offset
+        if ctx.needs_input_grad[0] and _FUSED_DU:
+            # training: the forward also accumulates E[i] = sum_j p_ij I_j, which IS the user-side
+            # gradient up to the row factor -- the backward then only runs the item-side kernel
+            du_unit = torch.empty(M, D, dtype=torch.float32, device=dev)
+            N.check(lib.tt_inbatch_ce_fwd_du(pu, ldu, pi, ldi, M, Nn, D, diag_offset, lse.data_ptr(), ce.data_ptr(),
+                                             du_unit.data_ptr(), D, wsp, wsn, N.stream()), "tt_inbatch_ce_fwd_du")
+            ctx.save_for_backward(U, I, lse, du_unit)
+            return ce
         N.check(lib.tt_inbatch_ce_fwd(pu, ldu, pi, ldi, M, Nn, D, diag_offset, lse.data_ptr(), ce.data_ptr(),
                                       wsp, wsn, N.stream()), "tt_inbatch_ce_fwd")
-        ctx.diag_offset = diag_offset
         ctx.save_for_backward(U, I, lse)
         return ce
 
     @staticmethod
     def backward(ctx, d_ce):
-        U, I, lse = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        U, I, lse = saved[:3]
+        du_unit = saved[3] if len(saved) > 3 else None
         dev = U.device
         M, D = U.shape
         Nn = I.shape[0]
         lib = N.load()
         coef = d_ce.contiguous()
-        dU = torch.empty(M, D, dtype=torch.float32, device=dev)
+        dU = du_unit * coef.unsqueeze(1) if du_unit is not None else torch.empty(M, D, dtype=torch.float32, device=dev)
         dI = torch.empty(Nn, D, dtype=torch.float32, device=dev)
         wsp, wsn = _ws(dev, lib.tt_inbatch_ce_workspace_bytes(M, Nn, D))
         pu, _, _, ldu = _f32_2d(U, "U")
         pi, _, _, ldi = _f32_2d(I, "I")
         N.check(lib.tt_inbatch_ce_bwd(pu, ldu, pi, ldi, M, Nn, D, ctx.diag_offset, lse.data_ptr(),
-                                      coef.data_ptr(), dU.data_ptr(), D, dI.data_ptr(), D, wsp, wsn,
-                                      N.stream()), "tt_inbatch_ce_bwd")
+                                      coef.data_ptr(), None if du_unit is not None else dU.data_ptr(), D,
+                                      dI.data_ptr(), D, wsp, wsn, N.stream()), "tt_inbatch_ce_bwd")
         return dU, dI, None
 
 

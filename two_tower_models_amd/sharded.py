@@ -119,6 +119,7 @@ class HipBackend:
         self.lib = _native.load()
         self.device = device
         self._sides = {}
+        self._du_unit = None
         self._side_stream = None
         self._sweep_done = None
 
@@ -207,18 +208,23 @@ class HipBackend:
         Nn = I_all.shape[0]
         lse, ce = self.empty(M), self.empty(M)
         wsp, wsn = ops._ws(self.device, lib.tt_inbatch_ce_workspace_bytes(M, Nn, D))
-        N.check(lib.tt_inbatch_ce_fwd(U.data_ptr(), D, I_all.data_ptr(), D, M, Nn, D, off, lse.data_ptr(),
-                                      ce.data_ptr(), wsp, wsn, N.stream()), "tt_inbatch_ce_fwd")
+        # forward fused with the user-side gradient (kept for ce_bwd): with global negatives the
+        # logits are the step at 8 GPUs, and this removes one of their five passes
+        self._du_unit = self.empty(M, D)
+        N.check(lib.tt_inbatch_ce_fwd_du(U.data_ptr(), D, I_all.data_ptr(), D, M, Nn, D, off, lse.data_ptr(),
+                                         ce.data_ptr(), self._du_unit.data_ptr(), D, wsp, wsn, N.stream()),
+                "tt_inbatch_ce_fwd_du")
         return ce, lse
 
     def ce_bwd(self, U, I_all, off, lse, coef):
         ops, N, lib = self.ops, self.N, self.lib
         M, D = U.shape
         Nn = I_all.shape[0]
-        dU, dI = self.empty(M, D), self.empty(Nn, D)
+        dU, dI = self._du_unit * coef.unsqueeze(1), self.empty(Nn, D)
+        self._du_unit = None
         wsp, wsn = ops._ws(self.device, lib.tt_inbatch_ce_workspace_bytes(M, Nn, D))
         N.check(lib.tt_inbatch_ce_bwd(U.data_ptr(), D, I_all.data_ptr(), D, M, Nn, D, off, lse.data_ptr(),
-                                      coef.data_ptr(), dU.data_ptr(), D, dI.data_ptr(), D, wsp, wsn, N.stream()),
+                                      coef.data_ptr(), None, D, dI.data_ptr(), D, wsp, wsn, N.stream()),
                 "tt_inbatch_ce_bwd")
         return dU, dI
 
