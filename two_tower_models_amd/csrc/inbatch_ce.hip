@@ -320,9 +320,8 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_du_k
   for (int q = 0; q < 4; ++q)
     ybase[q] = GLDS ? 4 * h * TM::LD + 4 * ((((r >> 2) ^ (4 * h)) & TM::SW) ^ q) + (r & 3) : 4 * h * TM::LD + r;
 
-  float m = NEG_BIG, s = 0.f, dg = 0.f;
-  bool has_dg = false;
-  const int64_t want = a + p.diag_offset;
+  float m = NEG_BIG, s = 0.f;
+  const int64_t want = (a < p.RX) ? a + p.diag_offset : -1;  // rows past the end own no diagonal
 
   Stager<DP8, GLDS> stg;
   if (t0 < t1) {
@@ -340,14 +339,16 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_du_k
     const int lim4 = (lrel < BJ ? (int)lrel : BJ) - 4 * h;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
-      const f32x16 acc = score_tile<DP8, GLDS>(ys, xr, jt, r, h);
-      float v2[16];
+      // v2 lives in the score tile's own registers from here on (masked logits, then probabilities):
+      // the kernel sits at the 256-VGPR limit of 2 waves per SIMD, and a spill reload waits on
+      // vmcnt -- the counter the next tile's LDS-DMA completes on
+      f32x16 v2 = score_tile<DP8, GLDS>(ys, xr, jt, r, h);
       float tmax = NEG_BIG;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int li = jt * 32 + (e & 3) + 8 * (e >> 2);
-        const float s2 = acc[e] * LOG2E;
-        if (li == want4) { dg = s2; has_dg = true; }
+        const float s2 = v2[e] * LOG2E;
+        if (li == want4) p.diag[a] = s2;  // executes for exactly one (lane, e) per user row
         v2[e] = (li < lim4) ? s2 : NEG_BIG;
         tmax = fmaxf(tmax, v2[e]);
       }
@@ -362,46 +363,43 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_du_k
       }
       s = s * f + add;
       m = mn;
-      // rescale the accumulated rows: register e of dacc is user row brow(e, h) of this wave
-      if (h == 0) fbuf[r] = f;
-      __builtin_amdgcn_wave_barrier();
+      // rescale the accumulated rows: register e of dacc is user row brow(e, h) of this wave.
+      // A running maximum moves O(log n) times per row, so after the first tiles most sub-tiles
+      // find every factor equal to 1 and skip the exchange (wave-uniform branch).
+      if (__any(f != 1.0f)) {
+        if (h == 0) fbuf[r] = f;
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 f4 = *reinterpret_cast<const float4*>(fbuf + 8 * q + 4 * h);
+        for (int q = 0; q < 4; ++q) {
+          const float4 f4 = *reinterpret_cast<const float4*>(fbuf + 8 * q + 4 * h);
 #pragma unroll
-        for (int d = 0; d < TD; ++d) {
-          dacc[d][4 * q] *= f4.x; dacc[d][4 * q + 1] *= f4.y; dacc[d][4 * q + 2] *= f4.z; dacc[d][4 * q + 3] *= f4.w;
+          for (int d = 0; d < TD; ++d) {
+            dacc[d][4 * q] *= f4.x; dacc[d][4 * q + 1] *= f4.y; dacc[d][4 * q + 2] *= f4.z; dacc[d][4 * q + 3] *= f4.w;
+          }
         }
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
       // O[a][d] += sum_b p[a][b] * Y[b][d]  (the dU kernel's second product, same operand addressing)
-      float yv[2][TD];
-      auto yread = [&](int e, float (&dst)[TD]) {
-        const int E = (e & 3) + 8 * (e >> 2);
-        const int hi = (GLDS && TM::SW >= 8) ? ((e >> 2) & 1) : 0;
-#pragma unroll
-        for (int d = 0; d < TD; ++d) dst[d] = ys[(jt * 32 + E) * TM::LD + 32 * (d ^ hi) + ybase[e & 3]];
-      };
-      yread(0, yv[0]);
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        if (e + 1 < 16) yread(e + 1, yv[(e + 1) & 1]);
+        const int E = (e & 3) + 8 * (e >> 2);
+        const int hi = (GLDS && TM::SW >= 8) ? ((e >> 2) & 1) : 0;
+        float yv[TD];
+#pragma unroll
+        for (int d = 0; d < TD; ++d) yv[d] = ys[(jt * 32 + E) * TM::LD + 32 * (d ^ hi) + ybase[e & 3]];
 #pragma unroll
         for (int d = 0; d < TD; ++d)
-          dacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2[e], yv[e & 1][d], dacc[d], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+          dacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2[e], yv[d], dacc[d], 0, 0, 0);
       }
     }
     if (t + 1 < t1) stg.land(nxt);
     __syncthreads();
   }
   // the two lane halves hold the same m and disjoint parts of the sum
-  const float so = __shfl_xor(s, 32, 64), dgo = __shfl_xor(dg, 32, 64);
-  const bool has_o = __shfl_xor((int)has_dg, 32, 64) != 0;
+  const float so = __shfl_xor(s, 32, 64);
   if (h == 0 && a < p.RX) {
     p.part_m[(int64_t)blockIdx.y * p.RX + a] = m;
     p.part_s[(int64_t)blockIdx.y * p.RX + a] = s + so;
-    if (has_dg || has_o) p.diag[a] = has_dg ? dg : dgo;
   }
   float* out = p.out + (int64_t)blockIdx.y * p.RX * p.D;  // unnormalised, relative to 2^m of this split
   const int64_t abase = (int64_t)blockIdx.x * BI + wave * 32;
