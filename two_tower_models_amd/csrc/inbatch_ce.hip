@@ -315,10 +315,9 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_du_k
   for (int d = 0; d < TD; ++d)
 #pragma unroll
     for (int e = 0; e < 16; ++e) dacc[d][e] = 0.f;
-  int ybase[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    ybase[q] = GLDS ? 4 * h * TM::LD + 4 * ((((r >> 2) ^ (4 * h)) & TM::SW) ^ q) + (r & 3) : 4 * h * TM::LD + r;
+  // second product's B operand offsets (see ce_bwd_kernel): base + 4 * (swz ^ q), q = e & 3
+  const int ybase0 = GLDS ? 4 * h * TM::LD + (r & 3) : 4 * h * TM::LD + r;
+  const int yswz = GLDS ? (((r >> 2) ^ (4 * h)) & TM::SW) : 0;
 
   float m = NEG_BIG, s = 0.f;
   const int64_t want = (a < p.RX) ? a + p.diag_offset : -1;  // rows past the end own no diagonal
@@ -386,7 +385,7 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_du_k
         const int hi = (GLDS && TM::SW >= 8) ? ((e >> 2) & 1) : 0;
         float yv[TD];
 #pragma unroll
-        for (int d = 0; d < TD; ++d) yv[d] = ys[(jt * 32 + E) * TM::LD + 32 * (d ^ hi) + ybase[e & 3]];
+        for (int d = 0; d < TD; ++d) yv[d] = ys[(jt * 32 + E) * TM::LD + 32 * (d ^ hi) + ybase0 + (GLDS ? 4 * (yswz ^ (e & 3)) : 0)];
 #pragma unroll
         for (int d = 0; d < TD; ++d)
           dacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2[e], yv[d], dacc[d], 0, 0, 0);
