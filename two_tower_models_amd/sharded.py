@@ -78,6 +78,49 @@ def reduce_scatter_rows(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+class _Pending:
+    """Result of a collective started with `*_start`: `.wait()` makes the CURRENT stream wait for it
+    (RCCL: the collective runs on the process group's own stream meanwhile, so kernels launched in
+    between overlap it) and returns the output tensor."""
+
+    __slots__ = ("out", "work", "keep")
+
+    def __init__(self, out, work=None, keep=None):
+        self.out, self.work, self.keep = out, work, keep  # `keep`: the send buffer, alive until waited for
+
+    def wait(self) -> torch.Tensor:
+        if self.work is not None:
+            self.work.wait()
+            self.work, self.keep = None, None
+        return self.out
+
+
+def _rccl_async(x: torch.Tensor) -> bool:
+    return dist.get_world_size() > 1 and not _is_gloo() and x.is_cuda
+
+
+def all_gather_rows_start(x: torch.Tensor) -> _Pending:
+    if not _rccl_async(x):  # gloo (tests) and world size 1: nothing to overlap with
+        return _Pending(all_gather_rows(x) if dist.get_world_size() > 1 else x)
+    x = x.contiguous()
+    out = x.new_empty((dist.get_world_size() * x.shape[0],) + tuple(x.shape[1:]))
+    return _Pending(out, dist.all_gather_into_tensor(out, x, async_op=True), x)
+
+
+def reduce_scatter_rows_start(x: torch.Tensor) -> _Pending:
+    if not _rccl_async(x):
+        return _Pending(reduce_scatter_rows(x) if dist.get_world_size() > 1 else x)
+    x = x.contiguous()
+    out = x.new_empty((x.shape[0] // dist.get_world_size(),) + tuple(x.shape[1:]))
+    return _Pending(out, dist.reduce_scatter_tensor(out, x, async_op=True), x)
+
+
+def all_reduce_start_(x: torch.Tensor) -> _Pending:
+    if not _rccl_async(x):
+        return _Pending(all_reduce_(x) if dist.get_world_size() > 1 else x)
+    return _Pending(x, dist.all_reduce(x, async_op=True))
+
+
 def all_reduce_(x: torch.Tensor, op=dist.ReduceOp.SUM) -> torch.Tensor:
     if _host_staged(x):
         h = x.cpu()
@@ -446,20 +489,22 @@ class ShardedTrainer:
                 table.v.zero_()
 
     # ---- lookup through the owning ranks (fixed-size collectives, no host sync)
-    def _lookup(self, table: ShardedTable, ids: torch.Tensor) -> Tuple[Lookup, torch.Tensor]:
+    def _lookup(self, table: ShardedTable, ids: torch.Tensor) -> Tuple[Lookup, "_Pending"]:
+        """-> (routing, pending rows).  The reduce-scatter that delivers the rows is only STARTED here:
+        the caller waits for it where the rows are first used, so the next lookup's gather and the
+        other tower's GEMMs run underneath it."""
         lk = Lookup(ids, table)
         partial = self.be.gather_owned(table.weight, lk.local, lk.n_local)  # [W*B, D], zeros if not mine
-        rows = reduce_scatter_rows(partial) if self.W > 1 else partial
-        return lk, rows
+        return lk, reduce_scatter_rows_start(partial)
 
     def step(self, batch) -> torch.Tensor:
         user_id, user_feat, hist_ids, item_id, item_feat, _pos, labels = batch
         be, W, D, B = self.be, self.W, self.cfg["D"], user_id.shape[0]
         # 1. embedding rows of the local batch, served by the owning ranks
-        lk_u, u_emb = self._lookup(self.users, user_id)
+        lk_u, u_emb_p = self._lookup(self.users, user_id)
         if self.hist:  # history rows first: the reference's lookup order on the item table
-            lk_h, h_rows = self._lookup(self.items, hist_ids.reshape(-1))
-        lk_i, i_emb = self._lookup(self.items, item_id)
+            lk_h, h_rows_p = self._lookup(self.items, hist_ids.reshape(-1))
+        lk_i, i_emb_p = self._lookup(self.items, item_id)
         item_local = torch.cat([lk_h.local, lk_i.local]) if self.hist else lk_i.local
         # the tables' old rows have been read: plan, park the looked-up rows, and start the
         # zero-gradient sweep on the side stream -- it overlaps everything up to step 6
@@ -470,11 +515,13 @@ class ShardedTrainer:
                         (self.items.weight, self.items.m, self.items.v, lk_i.n_local)], self.hyper)
         pu, pi = self._tower_params("user"), self._tower_params("item")
         summary, enc_saved = None, None
+        u_emb = u_emb_p.wait()  # the item-side exchange is still in flight underneath the user tower
         if self.hist:
             enc_params = [self.params[k] for k in self.encoder_keys]
-            summary3, enc_saved = be.encoder_fwd(h_rows.view(B, -1, D), self.pe, self.heads, enc_params)
+            summary3, enc_saved = be.encoder_fwd(h_rows_p.wait().view(B, -1, D), self.pe, self.heads, enc_params)
             summary = summary3.reshape(B, 2 * D)
         u_h, u_f, U = be.tower_fwd(u_emb, user_feat, pu, extra=summary)
+        i_emb = i_emb_p.wait()
         i_h, i_f, I = be.tower_fwd(i_emb, item_feat, pi)
         # 2. logits against every rank's items
         glob = self.negatives == "global" and W > 1
@@ -496,16 +543,20 @@ class ShardedTrainer:
         dU, dI_all = be.ce_bwd(U, I_all, off, lse, coef)
         dI = reduce_scatter_rows(dI_all) if glob else dI_all
         # 5. towers backward -> dense grads (flat buffer) + embedding-row grads
+        # the row-gradient exchanges start as soon as their operand exists and run under what follows
         d_urows, d_summary = be.tower_bwd(dU, u_emb, u_h, u_f, user_feat, pu, self._tower_grads("user"), extra=summary)
-        d_irows, _ = be.tower_bwd(dI, i_emb, i_h, i_f, item_feat, pi, self._tower_grads("item"))
+        g_u_p = all_gather_rows_start(d_urows)  # aligned with lk_u.local
+        g_h_p = None
         if self.hist:
             d_hrows = be.encoder_bwd(enc_saved, d_summary.view(B, 2, D), [self.grads[k] for k in self.encoder_keys])
-        if W > 1:
-            all_reduce_(self.flat_g)
-        g_u = all_gather_rows(d_urows) if W > 1 else d_urows  # aligned with lk_u.local
-        g_i = all_gather_rows(d_irows) if W > 1 else d_irows
+            g_h_p = all_gather_rows_start(d_hrows)
+        d_irows, _ = be.tower_bwd(dI, i_emb, i_h, i_f, item_feat, pi, self._tower_grads("item"))
+        g_i_p = all_gather_rows_start(d_irows)
+        flat_p = all_reduce_start_(self.flat_g)  # every dense gradient has been written by now
+        g_u, g_i = g_u_p.wait(), g_i_p.wait()
         if self.hist:  # aligned with item_local = [history ids | item ids]
-            g_i = torch.cat([all_gather_rows(d_hrows) if W > 1 else d_hrows, g_i])
+            g_i = torch.cat([g_h_p.wait(), g_i])
+        flat_p.wait()
         # 6. dense-exact Adam: the looked-up rows of this rank's blocks, over the swept tables
         be.sweep_wait()
         be.adam_table_finish(self.users.weight, self.users.m, self.users.v, self.hyper, st_u, g_u)
