@@ -541,7 +541,7 @@ class ShardedTrainer:
         self.last_loss = loss
         # 4. backward through the loss
         dU, dI_all = be.ce_bwd(U, I_all, off, lse, coef)
-        dI = reduce_scatter_rows(dI_all) if glob else dI_all
+        dI_p = reduce_scatter_rows_start(dI_all) if glob else _Pending(dI_all)  # travels under the user tower backward
         # 5. towers backward -> dense grads (flat buffer) + embedding-row grads
         # the row-gradient exchanges start as soon as their operand exists and run under what follows
         d_urows, d_summary = be.tower_bwd(dU, u_emb, u_h, u_f, user_feat, pu, self._tower_grads("user"), extra=summary)
@@ -550,7 +550,7 @@ class ShardedTrainer:
         if self.hist:
             d_hrows = be.encoder_bwd(enc_saved, d_summary.view(B, 2, D), [self.grads[k] for k in self.encoder_keys])
             g_h_p = all_gather_rows_start(d_hrows)
-        d_irows, _ = be.tower_bwd(dI, i_emb, i_h, i_f, item_feat, pi, self._tower_grads("item"))
+        d_irows, _ = be.tower_bwd(dI_p.wait(), i_emb, i_h, i_f, item_feat, pi, self._tower_grads("item"))
         g_i_p = all_gather_rows_start(d_irows)
         flat_p = all_reduce_start_(self.flat_g)  # every dense gradient has been written by now
         g_u, g_i = g_u_p.wait(), g_i_p.wait()
