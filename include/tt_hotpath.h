@@ -278,6 +278,15 @@ int tt_attn_fwd(const float* qkv, int64_t B, int64_t H, int64_t D, int64_t heads
                 float* lse, tt_stream_t stream);
 int tt_attn_bwd(const float* qkv, const float* ctx, const float* lse, const float* d_ctx,
                 int64_t B, int64_t H, int64_t D, int64_t heads, float* d_qkv, tt_stream_t stream);
+/* The encoder's LAST layer is consumed at row 0 only (ref:...encoder.py:113): one query per sample.
+ *   q0 [B, D] (row stride ldq) = projected query of history position 0; kv [B*H, 2D] (row stride
+ *   ldkv) = [K | V] of every position; ctx0 [B, D]; probs [B, heads, H] (saved for the backward).
+ *   H <= 64.  The backward writes every row of d_kv [B*H, 2D] and d_q0 [B, D]. */
+int tt_attn_row0_fwd(const float* q0, int64_t ldq, const float* kv, int64_t ldkv, int64_t B, int64_t H,
+                     int64_t D, int64_t heads, float* ctx0, float* probs, tt_stream_t stream);
+int tt_attn_row0_bwd(const float* q0, int64_t ldq, const float* kv, int64_t ldkv, const float* probs,
+                     const float* d_ctx0, int64_t B, int64_t H, int64_t D, int64_t heads, float* d_q0,
+                     float* d_kv, int64_t ld_dkv, tt_stream_t stream);
 
 /* ---------------------------------------------------------------- K6 MIPS top-K
  * idx[b, 0:K], score[b, 0:K] = the K largest inner products q[b,:].corpus[c,:]

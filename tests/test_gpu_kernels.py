@@ -177,6 +177,36 @@ def test_inbatch_ce_fused_forward_gives_the_user_gradient(T, M, Nn, D, off, scal
     assert torch.allclose(dI2, dI, atol=1e-6 * float(dI.abs().max()) + 1e-12, rtol=1e-5)
 
 
+@pytest.mark.parametrize("B,H,D,heads", [(9, 50, 128, 4), (5, 64, 64, 4), (3, 1, 32, 2), (70, 7, 48, 3)])
+def test_single_query_attention_matches_full_attention_row0(T, B, H, D, heads):
+    """tt_attn_row0_fwd / _bwd (the encoder's last layer: only history position 0 is consumed) against
+    torch autograd on the same algebra: context of query 0, and the gradients it sends to q0, K, V."""
+    ops, N = T
+    lib = N.load()
+    dh = D // heads
+    q0 = g((B, D), 71).requires_grad_(True)
+    kv = g((B * H, 2 * D), 72).requires_grad_(True)
+    K = kv[:, :D].reshape(B, H, heads, dh).permute(0, 2, 1, 3)
+    V = kv[:, D:].reshape(B, H, heads, dh).permute(0, 2, 1, 3)
+    sc = torch.einsum("bhd,bhjd->bhj", q0.reshape(B, heads, dh) / math.sqrt(dh), K)
+    P = torch.softmax(sc, dim=-1)
+    ref = torch.einsum("bhj,bhjd->bhd", P, V).reshape(B, D)
+    d_ctx = g((B, D), 73)
+    ref.backward(d_ctx)
+    q0d, kvd = q0.detach().to(DEV), kv.detach().to(DEV)
+    ctx0, probs = torch.empty(B, D, device=DEV), torch.empty(B, heads, H, device=DEV)
+    N.check(lib.tt_attn_row0_fwd(q0d.data_ptr(), D, kvd.data_ptr(), 2 * D, B, H, D, heads, ctx0.data_ptr(),
+                                 probs.data_ptr(), N.stream()), "row0 fwd")
+    assert torch.allclose(ctx0.cpu(), ref.detach(), atol=2e-6, rtol=1e-5)
+    assert torch.allclose(probs.cpu(), P.detach(), atol=1e-6, rtol=1e-5)
+    d_q0, d_kv = torch.empty(B, D, device=DEV), torch.empty(B * H, 2 * D, device=DEV)
+    dcd = d_ctx.to(DEV)
+    N.check(lib.tt_attn_row0_bwd(q0d.data_ptr(), D, kvd.data_ptr(), 2 * D, probs.data_ptr(), dcd.data_ptr(), B, H, D,
+                                 heads, d_q0.data_ptr(), d_kv.data_ptr(), 2 * D, N.stream()), "row0 bwd")
+    assert torch.allclose(d_q0.cpu(), q0.grad, atol=2e-6 * float(q0.grad.abs().max()) + 1e-9, rtol=1e-4)
+    assert torch.allclose(d_kv.cpu(), kv.grad, atol=2e-6 * float(kv.grad.abs().max()) + 1e-9, rtol=1e-4)
+
+
 def test_weighted_mean_loss(T):
     ops, N = T
     B, Tn = 777, 3

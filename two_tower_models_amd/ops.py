@@ -364,7 +364,8 @@ class TowerInput(torch.autograd.Function):
         return dweight, None, None, dW1, db1, dW2, db2
 
 
-_FUSED_DU = os.environ.get("TT_CE_NO_FUSED_DU") is None  # A/B switch
+_FUSED_DU = os.environ.get("TT_CE_NO_FUSED_DU") is None  # A/B switches
+_ROW0_LAST = os.environ.get("TT_ENC_FULL_LAST_LAYER") is None
 
 
 class InBatchSoftmaxCE(torch.autograd.Function):
@@ -485,8 +486,24 @@ class HistoryEncoder(torch.autograd.Function):
                                        pooled.data_ptr(), 2 * D, N.oob.flag(dev).data_ptr(), N.stream()),
                 "tt_hist_embed_pool")
         saved: List[torch.Tensor] = []
+        row0_last = L > 0 and H <= 64 and D // heads <= 64 and _ROW0_LAST
         for l in range(L):
             w_in, b_in, w_out, b_out = layer_params[4 * l: 4 * l + 4]
+            if l == L - 1 and row0_last:
+                # the last layer is consumed at row 0 only: K, V for every position, Q for position 0,
+                # one query per (sample, head) -- 1/H of the attention, 2/3 of the in-projection
+                kv = torch.empty(B * H, 2 * D, dtype=torch.float32, device=dev)
+                gemm(N.TT_GEMM_NT, x, w_in[D:], kv, B * H, 2 * D, D, bias=b_in[D:])
+                x0 = x.view(B, H * D)[:, :D]  # rows b*H + 0
+                q0 = torch.empty(B, D, dtype=torch.float32, device=dev)
+                gemm(N.TT_GEMM_NT, x0, w_in[:D], q0, B, D, D, bias=b_in[:D])
+                ctx0 = torch.empty(B, D, dtype=torch.float32, device=dev)
+                probs = torch.empty(B, heads, H, dtype=torch.float32, device=dev)
+                N.check(lib.tt_attn_row0_fwd(q0.data_ptr(), D, kv.data_ptr(), 2 * D, B, H, D, heads, ctx0.data_ptr(),
+                                             probs.data_ptr(), N.stream()), "tt_attn_row0_fwd")
+                gemm(N.TT_GEMM_NT, ctx0, w_out, out[:, 0, :], B, D, D, bias=b_out)
+                saved += [x, kv, q0, ctx0, probs]
+                continue
             qkv = torch.empty(B * H, 3 * D, dtype=torch.float32, device=dev)
             gemm(N.TT_GEMM_NT, x, w_in, qkv, B * H, 3 * D, D, bias=b_in)
             ctx_t, lse = _attn_fwd(qkv, B, H, D, heads)
@@ -499,6 +516,7 @@ class HistoryEncoder(torch.autograd.Function):
         if L == 0:
             out[:, 0, :].copy_(x.view(B, H, D)[:, 0, :])
         ctx.dims = (B, H, D, L, heads)
+        ctx.row0_last = row0_last
         ctx.table = source if ids is not None else None
         ctx.has_ids = ids is not None
         ctx.save_for_backward(ids, *layer_params, *saved)
@@ -519,6 +537,27 @@ class HistoryEncoder(torch.autograd.Function):
         dx = None  # gradient wrt the current layer's OUTPUT x_{l+1}, [B*H, D]
         for l in reversed(range(L)):
             w_in, b_in, w_out, b_out = layer_params[4 * l: 4 * l + 4]
+            if l == L - 1 and ctx.row0_last:
+                x, kv, q0, ctx0, probs = saved[4 * l: 4 * l + 5]
+                dW_out = torch.empty(D, D, dtype=torch.float32, device=dev)
+                _, db_out = gemm_tn_colsum(d_recent, ctx0, dW_out)
+                d_ctx0 = torch.empty(B, D, dtype=torch.float32, device=dev)
+                gemm(N.TT_GEMM_NN, d_recent, w_out, d_ctx0, B, D, D)
+                d_q0 = torch.empty(B, D, dtype=torch.float32, device=dev)
+                d_kv = torch.empty(B * H, 2 * D, dtype=torch.float32, device=dev)
+                N.check(lib.tt_attn_row0_bwd(q0.data_ptr(), D, kv.data_ptr(), 2 * D, probs.data_ptr(), d_ctx0.data_ptr(),
+                                             B, H, D, heads, d_q0.data_ptr(), d_kv.data_ptr(), 2 * D, N.stream()),
+                        "tt_attn_row0_bwd")
+                x0 = x.view(B, H * D)[:, :D]
+                dW_in = torch.empty(3 * D, D, dtype=torch.float32, device=dev)
+                db_in = torch.empty(3 * D, dtype=torch.float32, device=dev)
+                gemm_tn_colsum(d_q0, x0, dW_in[:D], db=db_in[:D])
+                gemm_tn_colsum(d_kv, x, dW_in[D:], db=db_in[D:])
+                dx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
+                gemm(N.TT_GEMM_NN, d_kv, w_in[D:], dx, B * H, D, 2 * D)
+                gemm(N.TT_GEMM_NN, d_q0, w_in[:D], dx.view(B, H * D)[:, :D], B, D, D, accumulate=True)
+                grads[4 * l: 4 * l + 4] = [dW_in, db_in, dW_out, db_out]
+                continue
             x, qkv, ctx_t, lse = saved[4 * l: 4 * l + 4]
             dW_out = torch.empty(D, D, dtype=torch.float32, device=dev)
             if l == L - 1:
