@@ -328,11 +328,16 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // STAGES: depth of the LDS tile ring.  A bf16 tile is 1024 MFMA cycles (0.4 us) of work per wave,
 // less than the global-memory latency, so one tile of prefetch (STAGES = 2) leaves the matrix
 // cores waiting for the DMA every iteration; fp32 tiles are 8x longer and 2 stages suffice.
-template <int DT, int DPX, int NQ, int STAGES>
+// SHARE (query batches of <= 32, NQ = 1): all four waves hold the SAME 32 queries and split the
+// corpus instead -- wave w scores sub-tile w of every 128-row chunk and the four partial
+// (best, runner-up, row) triples of a group are merged through LDS at the end of the chunk.
+// Without it three of the four waves multiply zero queries (B = 16 at C = 10 M: 3.0 -> 0.9 ms).
+template <int DT, int DPX, int NQ, int STAGES, bool SHARE>
 __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p) {
   using O = Op<DT, DPX>;
   using TM = TileMap<DPX, true>;  // row bytes = 32 * DPX for both dtypes
   static_assert(DT == TT_BF16 || NQ == 1, "two query fragments only for bf16");
+  static_assert(!SHARE || NQ == 1, "shared queries: one fragment");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* const smem = reinterpret_cast<float*>(smem_raw);
   constexpr int TILE_FLOATS = CT * TM::DP;
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
   const int64_t w = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (w >= total) return;
   const int64_t bx = w % p.xblocks, by = w / p.xblocks;
-  const int64_t qbase = bx * (QB_WG * NQ) + wave * (32 * NQ) + r;
+  const int64_t qbase = SHARE ? bx * 32 + r : bx * (QB_WG * NQ) + wave * (32 * NQ) + r;
 
   typename O::Frag qf[NQ];
 #pragma unroll
@@ -380,6 +385,7 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
     const bool full = (chunk + 1) * CHUNK <= p.C;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
+      if (SHARE && (2 * (int)(t & 1) + jt) != wave) continue;  // this sub-tile belongs to another wave
       f32x16 acc[NQ];
       if constexpr (DT == TT_F32) {
         acc[0] = score_tile<DPX, true>(ys, qf[0].v, jt, r, h);
@@ -421,7 +427,30 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
         }
       }
     }
-    if (t & 1) {  // chunk complete: lane-half h holds group 2*chunk + h
+    if (SHARE && (t & 1)) {
+      // merge the four waves' partial triples of this chunk (sub-tiles in ascending row order, so
+      // "strictly greater" keeps the earlier row on ties, like the sequential scan)
+      float* red = smem + STAGES * TILE_FLOATS;  // [4][64][3]
+      red[(wave * 64 + lane) * 3] = m1[0];
+      red[(wave * 64 + lane) * 3 + 1] = m2[0];
+      red[(wave * 64 + lane) * 3 + 2] = __int_as_float(arg[0]);
+      __syncthreads();
+      if (wave == 0) {
+        float M1 = NEG_INF, M2 = NEG_INF;
+        int A = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+          const float a1 = red[(w2 * 64 + lane) * 3], a2 = red[(w2 * 64 + lane) * 3 + 1];
+          const int aa = __float_as_int(red[(w2 * 64 + lane) * 3 + 2]);
+          const bool gt = a1 > M1;
+          M2 = fmaxf(fminf(M1, a1), fmaxf(M2, a2));  // second largest of {M1, M2, a1, a2}
+          M1 = fmaxf(M1, a1);
+          A = gt ? aa : A;
+        }
+        m1[0] = M1; m2[0] = M2; arg[0] = A;
+      }
+    }
+    if ((t & 1) && (!SHARE || wave == 0)) {  // chunk complete: lane-half h holds group 2*chunk + h
       const int64_t grp = 2 * chunk + h;
       const bool nonempty = grp * GROUP < p.C;
 #pragma unroll
@@ -435,6 +464,7 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
         m1[n] = NEG_INF; m2[n] = NEG_INF; arg[n] = 0;
       }
     }
+    if (SHARE && (t & 1) && wave != 0) { m1[0] = NEG_INF; m2[0] = NEG_INF; arg[0] = 0; }
     // tile t+1 must have landed; tiles t+2 .. t+STAGES-1 may still be in flight
     if (more) wait_vmcnt<(STAGES - 2) * NI>();
     else wait_vmcnt<0>();
@@ -809,12 +839,13 @@ static int dispatch_score(int dtype, int dpx, const MipsArgs& a, dim3 grid, hipS
   return launch_score<TT_BF16, 8, PASS>(a, grid, st);
 }
 
-template <int DT, int DPX, int NQ>
+template <int DT, int DPX, int NQ, bool SHARE = false>
 static int launch_pass1_dma(MipsArgs a, int64_t, hipStream_t st) {
+  // (a deeper ring for the shared-query form -- 4 / 8 stages, one workgroup per CU -- was measured: slower)
   constexpr int STAGES = (DT == TT_BF16) ? 4 : 2;
-  const size_t lds = STAGES * (size_t)CT * 32 * DPX;
+  const size_t lds = STAGES * (size_t)CT * 32 * DPX + (SHARE ? 4 * 64 * 3 * sizeof(float) : 0);
   // 2 workgroups per CU are resident; aim at ~4 rounds of them
-  const int64_t xblocks = ceil_div(a.nq, QB_WG * NQ);
+  const int64_t xblocks = SHARE ? ceil_div(a.nq, 32) : ceil_div(a.nq, QB_WG * NQ);
   int64_t splits = ceil_div(2048, xblocks);
   if (splits > a.n_chunks) splits = a.n_chunks;
   a.chunks_per_split = ceil_div(a.n_chunks, splits);
@@ -822,19 +853,26 @@ static int launch_pass1_dma(MipsArgs a, int64_t, hipStream_t st) {
   a.xblocks = xblocks;
   a.splits = splits;
   const int64_t grid = 8 * ceil_div(xblocks * splits, 8);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mips_pass1_dma_kernel<DT, DPX, NQ, STAGES>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mips_pass1_dma_kernel<DT, DPX, NQ, STAGES, SHARE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { set_error("mips_pass1_dma_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
   ProfScope prof("mips_score_kernel", st);
-  mips_pass1_dma_kernel<DT, DPX, NQ, STAGES><<<(unsigned)grid, 256, lds, st>>>(a);
+  mips_pass1_dma_kernel<DT, DPX, NQ, STAGES, SHARE><<<(unsigned)grid, 256, lds, st>>>(a);
   return check_launch("mips_pass1_dma_kernel");
 }
 // -1: shape not covered by the DMA form
 static int dispatch_pass1_dma(int dtype, int dpx, const MipsArgs& a, int64_t splits, hipStream_t st) {
+  static const bool no_share = getenv("TT_MIPS_NO_SHARE") != nullptr;
+  const bool share = a.nq <= 32 && !no_share;  // small query batch: the waves split the corpus instead
   if (dtype == TT_F32) {
-    if (dpx == 4) return launch_pass1_dma<TT_F32, 4, 1>(a, splits, st);
-    if (dpx == 8) return launch_pass1_dma<TT_F32, 8, 1>(a, splits, st);
-    return launch_pass1_dma<TT_F32, 16, 1>(a, splits, st);
+    if (dpx == 4) return share ? launch_pass1_dma<TT_F32, 4, 1, true>(a, splits, st) : launch_pass1_dma<TT_F32, 4, 1>(a, splits, st);
+    if (dpx == 8) return share ? launch_pass1_dma<TT_F32, 8, 1, true>(a, splits, st) : launch_pass1_dma<TT_F32, 8, 1>(a, splits, st);
+    return share ? launch_pass1_dma<TT_F32, 16, 1, true>(a, splits, st) : launch_pass1_dma<TT_F32, 16, 1>(a, splits, st);
+  }
+  if (share) {
+    if (dpx == 4) return launch_pass1_dma<TT_BF16, 4, 1, true>(a, splits, st);
+    if (dpx == 8) return launch_pass1_dma<TT_BF16, 8, 1, true>(a, splits, st);
+    return -1;
   }
   static const int force_nq = getenv("TT_MIPS_NQ") ? atoi(getenv("TT_MIPS_NQ")) : 0;
   const int nqf = force_nq ? force_nq : (a.nq > 2 * QB_WG ? 4 : a.nq > QB_WG ? 2 : 1);
