@@ -324,10 +324,12 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
   const int64_t ktiles = ceil_div(K, BK);
   int64_t splits = 1;
   if (tiles < 256 && ktiles >= 16) {
-    // 2 workgroups of the 128^2 kernel are resident per CU: tiles * splits must not EXCEED the
-    // 512 slots, or one straggler workgroup runs a second round on an otherwise idle GPU
-    // (3 tiles x 171 splits = 513 cost 2x; measured on the 384x128x204800 dW GEMM)
-    splits = 512 / tiles;
+    // One workgroup per CU (256) measured as good as or better than two (512) for the split-K weight
+    // gradients and halves the slabs the reduce kernel has to read; what must NOT happen is
+    // tiles * splits landing just above a multiple of the resident slots (3 tiles x 171 splits = 513
+    // cost 2x: one straggler workgroup ran a second round on an otherwise idle GPU).
+    splits = 256 / tiles;
+    if (splits < 1) splits = 1;
     if (splits > ktiles / 4) splits = ktiles / 4;  // at least 4 K-tiles per split
     if (splits > 256) splits = 256;
     if (splits < 1) splits = 1;
