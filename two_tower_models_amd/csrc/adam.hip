@@ -37,17 +37,20 @@ __device__ __forceinline__ AdamConst load_hyper(const double* __restrict__ h) {
   return c;
 }
 
+// Every fused multiply-add is spelled out: left to -ffp-contract the compiler picks a different
+// pairing in different kernels (fma(t, g, v*b2) in one, fma(v, b2, t*g) in another), and the
+// schedules (serial / overlapped / deferred) must agree to the bit.
 __device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, const AdamConst& c) {
   m = fmaf(c.one_minus_b1, g - m, m);
-  v = v * c.b2 + (c.one_minus_b2 * g) * g;
+  v = fmaf(c.one_minus_b2 * g, g, v * c.b2);
   const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
-  p = p + c.neg_step_size * (m / denom);
+  p = fmaf(c.neg_step_size, m / denom, p);
 }
 __device__ __forceinline__ void adam_elem_zero_grad(float& p, float& m, float& v, const AdamConst& c) {
   m = fmaf(c.one_minus_b1, -m, m);
   v = v * c.b2;
   const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
-  p = p + c.neg_step_size * (m / denom);
+  p = fmaf(c.neg_step_size, m / denom, p);
 }
 
 // step-dependent constants exactly as load_hyper() hands them to the kernels
@@ -194,6 +197,50 @@ __global__ __launch_bounds__(256) void adam_writeback_kernel(float* __restrict__
     W[row * dim + d] = sp[d];
     M[row * dim + d] = sm[d];
     V[row * dim + d] = sv[d];
+  }
+}
+
+// Last phase of the overlapped schedule in ONE pass (dim % 4 == 0, 16-B aligned operands): the
+// sweep has finished, so the looked-up rows go from the stash (old p,m,v) + their summed gradient
+// straight into the table -- no second trip through the side buffer.  LPR lanes per unique row,
+// one float4 per lane and plane; gradient runs are summed in plan order, as adam_touched_kernel does.
+template <int LPR>
+__global__ __launch_bounds__(256) void adam_finish_kernel(float* __restrict__ W, float* __restrict__ M, float* __restrict__ V,
+                                                          int64_t n_rows, int64_t dim, const double* __restrict__ hyper,
+                                                          const tt_grad_sources src, const int32_t* __restrict__ sorted_ids,
+                                                          const int32_t* __restrict__ perm,
+                                                          const int32_t* __restrict__ seg_begin,
+                                                          const int32_t* __restrict__ n_unique,
+                                                          const float* __restrict__ side, int64_t cap) {
+  constexpr int ROWS = 256 / LPR;
+  const int64_t u = (int64_t)blockIdx.x * ROWS + threadIdx.x / LPR;
+  if (u >= *n_unique) return;
+  const int sub = threadIdx.x % LPR;
+  const AdamConst c = load_hyper(hyper);
+  const int32_t t0 = seg_begin[u], t1 = seg_begin[u + 1];
+  const int64_t row = sorted_ids[t0];
+  if (row >= n_rows) return;  // sentinel run
+  const int64_t n4 = dim / 4;
+  const float4* sp = reinterpret_cast<const float4*>(side + (int64_t)perm[t0] * dim);
+  const float4* sm = sp + cap * n4;
+  const float4* sv = sm + cap * n4;
+  float4* wp = reinterpret_cast<float4*>(W + row * dim);
+  float4* wm = reinterpret_cast<float4*>(M + row * dim);
+  float4* wv = reinterpret_cast<float4*>(V + row * dim);
+  for (int64_t d = sub; d < n4; d += LPR) {
+    float4 p = sp[d], m = sm[d], v = sv[d];
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int32_t t = t0; t < t1; ++t) {
+      const float4 x = reinterpret_cast<const float4*>(source_row(src, perm[t]))[d];
+      g.x += x.x; g.y += x.y; g.z += x.z; g.w += x.w;
+    }
+    adam_elem(p.x, m.x, v.x, g.x, c);
+    adam_elem(p.y, m.y, v.y, g.y, c);
+    adam_elem(p.z, m.z, v.z, g.z, c);
+    adam_elem(p.w, m.w, v.w, g.w, c);
+    wp[d] = p;
+    wm[d] = m;
+    wv[d] = v;
   }
 }
 
@@ -596,6 +643,16 @@ extern "C" int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows
   if (side_bytes < tt_adam_table_workspace_bytes(n_ids, dim)) { set_error("tt_adam_table_finish: side buffer"); return TT_E_WORKSPACE; }
   hipStream_t st = S(stream);
   float* sd = reinterpret_cast<float*>(side);
+  bool vec = dim % 4 == 0 && ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(M) | reinterpret_cast<uintptr_t>(V) |
+                               reinterpret_cast<uintptr_t>(side)) & 15) == 0;
+  for (int k = 0; vec && k < src->n_sources; ++k)
+    vec = (reinterpret_cast<uintptr_t>(src->rows[k]) & 15) == 0 && src->ld[k] % 4 == 0;
+  if (vec) {
+    if (dim <= 64) adam_finish_kernel<16><<<(unsigned)ceil_div(n_ids, 16), 256, 0, st>>>(W, M, V, n_rows, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, sd, n_ids);
+    else if (dim <= 128) adam_finish_kernel<32><<<(unsigned)ceil_div(n_ids, 8), 256, 0, st>>>(W, M, V, n_rows, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, sd, n_ids);
+    else adam_finish_kernel<64><<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, sd, n_ids);
+    return check_launch("adam_finish_kernel");
+  }
   adam_touched_kernel<true><<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, sd, n_ids);
   int rc = check_launch("adam_touched_kernel");
   if (rc) return rc;
