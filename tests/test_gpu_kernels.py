@@ -222,7 +222,8 @@ def test_weighted_mean_loss(T):
 
 
 # ------------------------------------------------------------------ row plan + Adam
-@pytest.mark.parametrize("n,n_rows", [(1, 10), (777, 100), (8192, 1_000_000), (50_000, 300), (4096, 70_000_000)])
+@pytest.mark.parametrize("n,n_rows", [(1, 10), (777, 100), (8192, 1_000_000), (50_000, 300), (4096, 70_000_000),
+                                      (63, 2), (1025, 5000), (8191, 3), (8193, 1_000_000), (5000, 1)])
 def test_rowgrad_plan_matches_stable_sort(T, n, n_rows):
     ops, N = T
     ids = torch.from_numpy(fg.uniform_ids((n,), n_rows, 51))
