@@ -511,7 +511,14 @@ struct CePlan {
 static bool plan_ce(int64_t RX, int64_t RY, int64_t D, CePlan& pl) {
   if (D <= 32) pl.dp8 = 4; else if (D <= 64) pl.dp8 = 8; else if (D <= 128) pl.dp8 = 16; else return false;
   const int64_t rowblocks = ceil_div(RX, BI), tiles = ceil_div(RY, BJ);
-  int64_t splits = ceil_div(512, rowblocks);
+  // 512 workgroups = one resident round (2 per CU).  Long streams are cut finer, up to 1024 units of
+  // >= 16 tiles: when the Adam sweep is resident only ONE of these 256-VGPR workgroups fits per CU, and
+  // with a single static round the late starters set the kernel time (8192 x 65536 under the sweep:
+  // 3.5 ms with 512 units, 2.3 ms with 1024; alone 2.18 ms either way).  TT_CE_UNITS overrides.
+  static const int64_t units_env = getenv("TT_CE_UNITS") ? atoll(getenv("TT_CE_UNITS")) : 0;
+  int64_t splits = ceil_div(units_env > 0 ? units_env : 512, rowblocks);
+  if (units_env <= 0)
+    while (rowblocks * splits < 1024 && tiles >= 32 * splits) splits *= 2;
   if (splits > ceil_div(tiles, 4)) splits = ceil_div(tiles, 4);
   if (splits > 64) splits = 64;
   if (splits < 1) splits = 1;

@@ -34,6 +34,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -437,6 +438,13 @@ class ShardedTrainer:
                     table[pos, c] = math.sin(angle) if c % 2 == 0 else math.cos(angle)
             self.pe = table.flip([0]).contiguous().to(device)
         self.hyper = self.be.new_hyper(lr, betas, eps)
+        # When does the zero-gradient sweep start?  A long one (thick row blocks) as early as possible.
+        # A short one is better started with the logits kernels: it saturates HBM, which slows the
+        # small latency-bound tower GEMMs 6x, but costs the MFMA-bound logits kernels little.
+        sweep_ms = (self.users.weight.numel() + self.items.weight.numel()) * 24 / 6.0e9
+        logits_ms = 8.0 * cfg["B"] * cfg["B"] * (self.W if negatives == "global" else 1) * cfg["D"] / 125.0e9
+        late = os.environ.get("TT_SWEEP_LATE")  # A/B switch
+        self._sweep_late = (late == "1") if late is not None else sweep_ms < 0.75 * logits_ms
         self.last_loss = torch.zeros((), dtype=torch.float32, device=device)
 
     def _tower_params(self, side):
@@ -511,8 +519,10 @@ class ShardedTrainer:
         be.adam_advance(self.hyper)
         st_u = be.adam_table_begin(self.users.weight, self.users.m, self.users.v, lk_u.n_local, lk_u.local)
         st_i = be.adam_table_begin(self.items.weight, self.items.m, self.items.v, lk_i.n_local, item_local)
-        be.sweep_async([(self.users.weight, self.users.m, self.users.v, lk_u.n_local),
-                        (self.items.weight, self.items.m, self.items.v, lk_i.n_local)], self.hyper)
+        sweep = [(self.users.weight, self.users.m, self.users.v, lk_u.n_local),
+                 (self.items.weight, self.items.m, self.items.v, lk_i.n_local)]
+        if not self._sweep_late:
+            be.sweep_async(sweep, self.hyper)
         pu, pi = self._tower_params("user"), self._tower_params("item")
         summary, enc_saved = None, None
         u_emb = u_emb_p.wait()  # the item-side exchange is still in flight underneath the user tower
@@ -527,6 +537,8 @@ class ShardedTrainer:
         glob = self.negatives == "global" and W > 1
         I_all = all_gather_rows(I) if glob else I
         off = self.rank * B if glob else 0
+        if self._sweep_late:  # a short sweep hides under the logits kernels instead of the small tower GEMMs
+            be.sweep_async(sweep, self.hyper)
         ce, lse = be.ce_fwd(U, I_all, off)
         # 3. value weights (ref :322,334-343) with the max / mean taken over the global batch
         nuv = torch.clamp(torch.sum(labels * self.uvw, dim=-1), min=0.000001)
