@@ -128,6 +128,22 @@ int tt_inbatch_ce_fwd_du(const float* U, int64_t ldu, const float* I, int64_t ld
                          int64_t D, int64_t diag_offset, float* row_lse, float* row_ce, float* du_unit,
                          int64_t ld_du, void* ws, int64_t ws_bytes, tt_stream_t stream);
 
+/* The same pair with the logits KEPT between forward and backward (wide negative sets: several
+ * ranks' items per user).  The forward also writes the masked log2-domain logits to `logits`
+ * (tt_inbatch_ce_logits_bytes(M, N) bytes: [round_up(M,128)][round_up(N,128)] fp32); the item-side
+ * backward rebuilds the gradient tile from them instead of from a second U I^T product -- 3 instead
+ * of 4 logit-sized products per training step, for one write and one read of the buffer.  Needs
+ * D in {32, 64, 128} and 16-B aligned rows (TT_E_UNSUPPORTED otherwise: use the pair above).
+ * Same workspace query as the others; dU comes from du_unit as above. */
+int64_t tt_inbatch_ce_logits_bytes(int64_t M, int64_t N);
+int tt_inbatch_ce_fwd_du_keep(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N,
+                              int64_t D, int64_t diag_offset, float* row_lse, float* row_ce, float* du_unit,
+                              int64_t ld_du, float* logits, int64_t logits_bytes, void* ws, int64_t ws_bytes,
+                              tt_stream_t stream);
+int tt_inbatch_ce_bwd_kept(const float* U, int64_t ldu, int64_t M, int64_t N, int64_t D, int64_t diag_offset,
+                           const float* row_lse, const float* coef, const float* logits, int64_t logits_bytes,
+                           float* dI, int64_t lddi, void* ws, int64_t ws_bytes, tt_stream_t stream);
+
 /* net_user_value weights, ref:...base_retrieval.py:322,334-339 for 2-D labels:
  *   nuv[i] = sum_t labels[i,t]*uvw[t];  w = clamp(nuv,1e-6);  w /= max_i w
  * then loss = mean_i(row_ce[i]*w[i]) and coef[i] = w[i]/B (gradient seed 1). */

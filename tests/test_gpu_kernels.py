@@ -177,6 +177,75 @@ def test_inbatch_ce_fused_forward_gives_the_user_gradient(T, M, Nn, D, off, scal
     assert torch.allclose(dI2, dI, atol=1e-6 * float(dI.abs().max()) + 1e-12, rtol=1e-5)
 
 
+@pytest.mark.parametrize("M,Nn,D,off,scale", [(300, 300, 128, 0, 0.5), (130, 700, 128, 400, 0.5), (96, 96, 128, 0, 3.0),
+                                               (77, 200, 64, 50, 1.0), (1, 1, 32, 0, 1.0), (129, 1000, 32, 871, 1.0),
+                                               (2048, 16384, 128, 4096, 0.3)])
+def test_inbatch_ce_kept_logits_backward(T, M, Nn, D, off, scale):
+    """tt_inbatch_ce_fwd_du_keep / tt_inbatch_ce_bwd_kept (logits written out by the forward, item-side
+    gradient rebuilt from them): same row statistics and du_unit as tt_inbatch_ce_fwd_du, same dI as the
+    recomputing backward and as the oracle -- ragged M / N (padded buffer), non-zero diagonal offset,
+    split streams, saturated softmax rows."""
+    ops, N = T
+    lib = N.load()
+    U = (g((M, D), 81) * scale).to(DEV)
+    I = (g((Nn, D), 82) * scale).to(DEV)
+    coef = (g((M,), 83).abs() / M).to(DEV)
+    wsp, wsn = ops._ws(torch.device(DEV), lib.tt_inbatch_ce_workspace_bytes(M, Nn, D), "ce_test")
+    e = lambda *shape: torch.empty(*shape, device=DEV)
+    lse1, ce1, du1, lse2, ce2, du2 = e(M), e(M), e(M, D), e(M), e(M), e(M, D)
+    N.check(lib.tt_inbatch_ce_fwd_du(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, off, lse1.data_ptr(), ce1.data_ptr(),
+                                     du1.data_ptr(), D, wsp, wsn, N.stream()), "fwd_du")
+    dI1 = e(Nn, D)
+    N.check(lib.tt_inbatch_ce_bwd(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, off, lse1.data_ptr(), coef.data_ptr(),
+                                  None, D, dI1.data_ptr(), D, wsp, wsn, N.stream()), "bwd items")
+    zn = lib.tt_inbatch_ce_logits_bytes(M, Nn)
+    assert zn >= M * Nn * 4
+    Z = torch.full((zn // 4,), float("nan"), device=DEV)  # whatever the kernels do not write must not matter
+    N.check(lib.tt_inbatch_ce_fwd_du_keep(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, off, lse2.data_ptr(), ce2.data_ptr(),
+                                          du2.data_ptr(), D, Z.data_ptr(), zn, wsp, wsn, N.stream()), "fwd_du_keep")
+    dI2 = e(Nn, D)
+    N.check(lib.tt_inbatch_ce_bwd_kept(U.data_ptr(), D, M, Nn, D, off, lse2.data_ptr(), coef.data_ptr(), Z.data_ptr(), zn,
+                                       dI2.data_ptr(), D, wsp, wsn, N.stream()), "bwd_kept")
+    assert torch.equal(ce2, ce1) and torch.equal(lse2, lse1) and torch.equal(du2, du1)
+    assert torch.isfinite(dI2).all()
+    assert torch.allclose(dI2, dI1, atol=1e-6 * float(dI1.abs().max()) + 1e-12, rtol=1e-5)
+    # the kept logits themselves: log2-domain U I^T in the top-left M x N block
+    ldk = (Nn + 127) // 128 * 128
+    S = (U.cpu().double() @ I.cpu().double().t()) * 1.4426950408889634
+    got = Z.view(-1, ldk)[:M, :Nn].cpu().double()
+    assert float((got - S).abs().max()) <= 1e-5 * max(1.0, float(S.abs().max()))
+    # and the oracle's gradient
+    P = torch.softmax(U.cpu().double() @ I.cpu().double().t(), dim=1)
+    P[torch.arange(M), torch.arange(M) + off] -= 1.0
+    ref = (P * coef.cpu().double().unsqueeze(1)).t() @ U.cpu().double()
+    assert float((dI2.cpu().double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-12
+    # too small a buffer / unsupported width are refused, not overrun
+    assert lib.tt_inbatch_ce_fwd_du_keep(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, off, lse2.data_ptr(), ce2.data_ptr(),
+                                         du2.data_ptr(), D, Z.data_ptr(), zn - 4, wsp, wsn, N.stream()) != 0
+
+
+def test_inbatch_ce_op_keep_logits_matches_default(T):
+    """ops.InBatchSoftmaxCE(keep_logits=True) == the default path through autograd, and the default
+    switches itself on for wide negative sets only."""
+    ops, N = T
+    M, Nn, D, off = 256, 1024, 128, 512
+    U0, I0 = g((M, D), 91) * 0.5, g((Nn, D), 92) * 0.5
+    coef = (g((M,), 93).abs() / M).to(DEV)
+    grads = []
+    for keep in (False, True, None):
+        U, I = U0.to(DEV).requires_grad_(True), I0.to(DEV).requires_grad_(True)
+        ce = ops.InBatchSoftmaxCE.apply(U, I, off, keep)
+        (ce * coef).sum().backward()
+        grads.append((ce.detach(), U.grad, I.grad))
+    for k in (1, 2):
+        assert torch.equal(grads[k][0], grads[0][0]) and torch.equal(grads[k][1], grads[0][1])
+        assert torch.allclose(grads[k][2], grads[0][2], atol=1e-6 * float(grads[0][2].abs().max()), rtol=1e-5)
+    # D = 40 has no kept-logits kernel: the request falls back to the recomputing pair
+    U, I = (g((64, 40), 94)).to(DEV).requires_grad_(True), (g((64, 40), 95)).to(DEV).requires_grad_(True)
+    ops.InBatchSoftmaxCE.apply(U, I, 0, True).sum().backward()
+    assert torch.isfinite(I.grad).all()
+
+
 @pytest.mark.parametrize("B,H,D,heads", [(9, 50, 128, 4), (5, 64, 64, 4), (3, 1, 32, 2), (70, 7, 48, 3)])
 def test_single_query_attention_matches_full_attention_row0(T, B, H, D, heads):
     """tt_attn_row0_fwd / _bwd (the encoder's last layer: only history position 0 is consumed) against

@@ -40,8 +40,27 @@ for M, Nn in shapes:
         N.check(lib.tt_inbatch_ce_bwd(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, 0, lse.data_ptr(), coef.data_ptr(),
                                       None, D, dI.data_ptr(), D, ws.data_ptr(), wsn, N.stream()), "bwd_items")
 
+    zn = lib.tt_inbatch_ce_logits_bytes(M, Nn)
+    Z = torch.empty(zn, dtype=torch.uint8, device=dev)
+    dI2 = torch.empty(Nn, D, device=dev)
+
+    def fwd_du_keep():  # the same, also writing the logits out
+        N.check(lib.tt_inbatch_ce_fwd_du_keep(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, 0, lse.data_ptr(), ce.data_ptr(),
+                                              du_unit.data_ptr(), D, Z.data_ptr(), zn, ws.data_ptr(), wsn, N.stream()),
+                "fwd_du_keep")
+
+    def bwd_kept():  # item-side gradient from the kept logits (no second U I^T product)
+        N.check(lib.tt_inbatch_ce_bwd_kept(U.data_ptr(), D, M, Nn, D, 0, lse.data_ptr(), coef.data_ptr(), Z.data_ptr(), zn,
+                                           dI2.data_ptr(), D, ws.data_ptr(), wsn, N.stream()), "bwd_kept")
+
+    fwd_du(); bwd_items(); fwd_du_keep(); bwd_kept()
+    torch.cuda.synchronize()
+    err = (dI2 - dI).abs().max().item() / max(dI.abs().max().item(), 1e-30)
+    print(f"M={M} N={Nn}: kept-logits dI vs recomputed dI: max rel-to-max error {err:.2e}", flush=True)
+
     for name, fn, flops in (("fwd", fwd, 2.0 * M * Nn * D), ("bwd", bwd, 8.0 * M * Nn * D),
-                            ("fwd_du", fwd_du, 4.0 * M * Nn * D), ("bwd_items", bwd_items, 4.0 * M * Nn * D)):
+                            ("fwd_du", fwd_du, 4.0 * M * Nn * D), ("bwd_items", bwd_items, 4.0 * M * Nn * D),
+                            ("fwd_du_keep", fwd_du_keep, 4.0 * M * Nn * D), ("bwd_kept", bwd_kept, 2.0 * M * Nn * D)):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()

@@ -58,6 +58,10 @@ SIGNATURES = {
     "tt_inbatch_ce_bwd": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp,
                                  _i64, _vp, _i64, _vp]),
     "tt_inbatch_ce_fwd_du": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "tt_inbatch_ce_logits_bytes": (_i64, [_i64, _i64]),
+    "tt_inbatch_ce_fwd_du_keep": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64,
+                                         _vp, _i64, _vp]),
+    "tt_inbatch_ce_bwd_kept": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "tt_weighted_mean_loss": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tt_rowgrad_workspace_bytes": (_i64, [_i64]),
     "tt_rowgrad_plan": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

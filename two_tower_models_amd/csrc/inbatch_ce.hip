@@ -54,6 +54,9 @@ struct CeArgs {
   float* out;         // [splits][RX][D] slabs (or final [RX, ldo] when splits == 1)
   int64_t ldo;
   int splits;
+  // kept logits (log2 domain, masked): Z[user][item], row stride ldk, both extents padded to 128
+  float* keep;
+  int64_t ldk;
 };
 
 // ------------------------------------------------------------------ forward
@@ -281,6 +284,138 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_bwd_kern
   }
 }
 
+// ------------------------------------------------------------------ item-side backward from kept logits
+// dI[a][:] = sum_b G[b][a] * U[b][:] with G rebuilt from the logits the forward kept (KEEP above)
+// instead of from a second U I^T product: half the MFMA work of ce_bwd_kernel<.., true, ..>, paid for
+// with one read of Z (M x N x 4 B) that streams underneath.  Lane = item a, register e = user
+// brow(e, h) of the sub-tile, exactly the layout the recomputed score tile would have; for a fixed
+// user the 32 lanes of a half-wave read 128 consecutive bytes of its row.  The 32 values of the NEXT
+// tile are requested before this tile's MFMAs and land with the next tile's LDS-DMA.
+template <int DP8>
+__global__ __launch_bounds__(256, 2) void ce_bwd_kept_kernel(const CeArgs p) {
+  using TM = TileMap<DP8, true>;
+  constexpr int TD = (DP8 + 3) / 4;
+  constexpr int TILE_FLOATS = BJ * TM::LD + 2 * BJ;
+  // TWO named LDS arrays (not one dynamic block): the compiler tags accesses to distinct LDS variables
+  // with alias scopes, and only then does it let a ds_read of one buffer proceed while the LDS-DMA
+  // into the OTHER is in flight -- with a single block every LDS read after a DMA issue waits vmcnt(0)
+  __shared__ __attribute__((aligned(16))) float buf0[TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float buf1[TILE_FLOATS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t a = (int64_t)blockIdx.x * BI + wave * 32 + r;  // item; columns of Z are padded to 128
+
+  const int64_t ntiles_all = (p.RY + BJ - 1) / BJ;
+  const int64_t t0 = (int64_t)blockIdx.y * p.tiles_per_split;
+  const int64_t t1 = (t0 + p.tiles_per_split < ntiles_all) ? t0 + p.tiles_per_split : ntiles_all;
+
+  f32x16 dacc[TD];
+#pragma unroll
+  for (int d = 0; d < TD; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dacc[d][e] = 0.f;
+  int ybase[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) ybase[q] = 4 * h * TM::LD + 4 * ((((r >> 2) ^ (4 * h)) & TM::SW) ^ q) + (r & 3);
+
+  // Z[user][item]: uniform row base (scalar registers) + one 32-bit per-lane offset
+  const float* const zblock = p.keep + (int64_t)blockIdx.x * BI;
+  const int zlane = wave * 32 + r + 4 * h * (int)p.ldk;
+  float zn[32];
+  auto zload = [&](int64_t t) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const float* zrow = zblock + (t * BJ + ((i >> 4) * 32 + (i & 3) + 8 * ((i & 15) >> 2))) * p.ldk;
+      zn[i] = zrow[zlane];
+    }
+  };
+  float st_lse = 0.f, st_coef = 0.f;  // threads 0..63 stage the streamed rows' stats (raw: masked when landed)
+  bool st_ok = false;
+  auto issue = [&](int64_t t, float* dst) {
+    tile_dma<DP8>(p.Y, p.ldy, t * BJ, p.RY, dst, wave, lane);
+    if (threadIdx.x < BJ) {
+      const int64_t b = t * BJ + threadIdx.x;
+      const int64_t bc = b < p.RY ? b : p.RY - 1;
+      st_lse = p.lse[bc];
+      st_coef = p.coef[bc];
+      st_ok = b < p.RY;
+    }
+  };
+  auto land = [&](float* dst) {
+    if (threadIdx.x < BJ) {
+      dst[BJ * TM::LD + threadIdx.x] = st_ok ? st_lse : 3.0e38f;
+      dst[BJ * TM::LD + BJ + threadIdx.x] = st_ok ? st_coef : 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  // one tile: `ys` is read, `nxt` receives tile t + 1
+  auto step = [&](int64_t t, const float* ys, float* nxt) {
+    float zc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) zc[i] = zn[i];
+    if (t + 1 < t1) { issue(t + 1, nxt); zload(t + 1); }
+    const int64_t wrel = a - p.diag_offset - t * BJ;
+    const int want4 = (wrel >= 0 && wrel < BJ) ? (int)wrel - 4 * h : -1000;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      float gt[16];
+      const float* sl = ys + BJ * TM::LD + jt * 32 + 4 * h;
+      const float* sc = sl + BJ;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 l4 = *reinterpret_cast<const float4*>(sl + 8 * q);
+        const float4 c4 = *reinterpret_cast<const float4*>(sc + 8 * q);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, cv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int e = 4 * q + c;
+          const int li = jt * 32 + (e & 3) + 8 * (e >> 2);
+          const float pr = fast_exp2(zc[jt * 16 + e] - lv[c]);
+          gt[e] = cv[c] * (pr - ((li == want4) ? 1.f : 0.f));  // coef 0 beyond RY
+        }
+      }
+      float yv[2][TD];
+      auto yread = [&](int e, float (&dst)[TD]) {
+        const int E = (e & 3) + 8 * (e >> 2);
+        const int hi = (TM::SW >= 8) ? ((e >> 2) & 1) : 0;
+#pragma unroll
+        for (int d = 0; d < TD; ++d) dst[d] = ys[(jt * 32 + E) * TM::LD + 32 * (d ^ hi) + ybase[e & 3]];
+      };
+      yread(0, yv[0]);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if (e + 1 < 16) yread(e + 1, yv[(e + 1) & 1]);
+#pragma unroll
+        for (int d = 0; d < TD; ++d)
+          dacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(gt[e], yv[e & 1][d], dacc[d], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (t + 1 < t1) land(nxt);
+    __syncthreads();
+  };
+
+  if (t0 < t1) { zload(t0); issue(t0, buf0); land(buf0); }
+  __syncthreads();
+  for (int64_t t = t0; t < t1; t += 2) {
+    step(t, buf0, buf1);
+    if (t + 1 < t1) step(t + 1, buf1, buf0);
+  }
+
+  float* out = p.out + (p.splits > 1 ? (int64_t)blockIdx.y * p.RX * p.D : 0);
+  const int64_t ldo = p.splits > 1 ? p.D : p.ldo;
+  const int64_t abase = (int64_t)blockIdx.x * BI + wave * 32;
+#pragma unroll
+  for (int d = 0; d < TD; ++d) {
+    const int64_t col = 32 * d + r;
+    if (col >= p.D) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t row = abase + brow(e, h);
+      if (row < p.RX) out[row * ldo + col] = dacc[d][e];
+    }
+  }
+}
+
 // ------------------------------------------------------------------ forward fused with dU
 // Forward that also returns E[a][:] = sum_b softmax(S)[a][b] * Y[b][:], the expected item embedding
 // of every user -- from which dU[a] = dLoss/dce[a] * (E[a] - Y[a + diag_offset]) is an elementwise
@@ -292,7 +427,9 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_bwd_kern
 // per-user factors of a wave travel through 128 B of LDS (written by the lane that owns the user,
 // read as four float4 by everybody).  Both lane halves of a user share one running maximum (one
 // cross-half exchange per sub-tile), because their probabilities are summed by the same MFMA.
-template <int DP8, bool GLDS>
+// KEEP: the masked log2-domain logits are also written to p.keep (16 B per lane and 4-row group), so
+// the item-side backward (ce_bwd_kept_kernel) reads them back instead of recomputing the product.
+template <int DP8, bool GLDS, bool KEEP = false>
 __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_du_kernel(const CeArgs p) {
   using TM = TileMap<DP8, GLDS>;
   constexpr int TD = (DP8 + 3) / 4;
@@ -350,6 +487,12 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_du_k
         if (li == want4) p.diag[a] = s2;  // executes for exactly one (lane, e) per user row
         v2[e] = (li < lim4) ? s2 : NEG_BIG;
         tmax = fmaxf(tmax, v2[e]);
+      }
+      if constexpr (KEEP) {  // rows past RX / columns past RY of the padded buffer get 0-logit / NEG_BIG filler
+        float* z = p.keep + a * p.ldk + (t * BJ + jt * 32 + 4 * h);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(z + 8 * g) = make_float4(v2[4 * g], v2[4 * g + 1], v2[4 * g + 2], v2[4 * g + 3]);
       }
       float mn = fmaxf(m, tmax);
       mn = fmaxf(mn, __shfl_xor(mn, 32, 64));  // one reference per USER: both lane halves feed the same MFMA
@@ -564,14 +707,23 @@ static int dispatch_fwd(int dp8, bool dma, const CeArgs& a, dim3 grid, hipStream
   if (dma) return dp8 == 4 ? launch_fwd<4, true>(a, grid, st) : dp8 == 8 ? launch_fwd<8, true>(a, grid, st) : launch_fwd<16, true>(a, grid, st);
   return dp8 == 4 ? launch_fwd<4, false>(a, grid, st) : dp8 == 8 ? launch_fwd<8, false>(a, grid, st) : launch_fwd<16, false>(a, grid, st);
 }
-template <int DP8, bool GLDS>
+template <int DP8, bool GLDS, bool KEEP = false>
 static int launch_fwd_du(const CeArgs& a, dim3 grid, hipStream_t st) {
   const size_t lds = (2 * BJ * TileMap<DP8, GLDS>::LD + 4 * 32) * sizeof(float);
-  int rc = opt_in_lds(ce_fwd_du_kernel<DP8, GLDS>, lds, "ce_fwd_du_kernel");
+  int rc = opt_in_lds(ce_fwd_du_kernel<DP8, GLDS, KEEP>, lds, "ce_fwd_du_kernel");
   if (rc) return rc;
   ProfScope prof("ce_fwd_kernel", st);
-  ce_fwd_du_kernel<DP8, GLDS><<<grid, 256, lds, st>>>(a);
+  ce_fwd_du_kernel<DP8, GLDS, KEEP><<<grid, 256, lds, st>>>(a);
   return check_launch("ce_fwd_du_kernel");
+}
+template <int DP8>
+static int launch_bwd_kept(const CeArgs& a, dim3 grid, hipStream_t st) {
+  ProfScope prof("ce_bwd_kernel", st);
+  ce_bwd_kept_kernel<DP8><<<grid, 256, 0, st>>>(a);  // LDS is static: two named tile buffers
+  return check_launch("ce_bwd_kept_kernel");
+}
+static int dispatch_fwd_du_keep(int dp8, const CeArgs& a, dim3 grid, hipStream_t st) {  // LDS-DMA form only
+  return dp8 == 4 ? launch_fwd_du<4, true, true>(a, grid, st) : dp8 == 8 ? launch_fwd_du<8, true, true>(a, grid, st) : launch_fwd_du<16, true, true>(a, grid, st);
 }
 static int dispatch_fwd_du(int dp8, bool dma, const CeArgs& a, dim3 grid, hipStream_t st) {
   if (dma) return dp8 == 4 ? launch_fwd_du<4, true>(a, grid, st) : dp8 == 8 ? launch_fwd_du<8, true>(a, grid, st) : launch_fwd_du<16, true>(a, grid, st);
@@ -624,9 +776,34 @@ extern "C" int tt_inbatch_ce_fwd(const float* U, int64_t ldu, const float* I, in
   return check_launch("ce_fwd_finish_kernel");
 }
 
+extern "C" int64_t tt_inbatch_ce_logits_bytes(int64_t M, int64_t N) {
+  if (M <= 0 || N <= 0) return 0;
+  return round_up(M, 128) * round_up(N, 128) * 4;
+}
+
+static int fwd_du_impl(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N,
+                       int64_t D, int64_t diag_offset, float* row_lse, float* row_ce, float* du_unit,
+                       int64_t ld_du, float* logits, int64_t logits_bytes, void* ws, int64_t ws_bytes,
+                       tt_stream_t stream);
+
 extern "C" int tt_inbatch_ce_fwd_du(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N,
                                     int64_t D, int64_t diag_offset, float* row_lse, float* row_ce, float* du_unit,
                                     int64_t ld_du, void* ws, int64_t ws_bytes, tt_stream_t stream) {
+  return fwd_du_impl(U, ldu, I, ldi, M, N, D, diag_offset, row_lse, row_ce, du_unit, ld_du, nullptr, 0, ws, ws_bytes, stream);
+}
+
+extern "C" int tt_inbatch_ce_fwd_du_keep(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N,
+                                         int64_t D, int64_t diag_offset, float* row_lse, float* row_ce, float* du_unit,
+                                         int64_t ld_du, float* logits, int64_t logits_bytes, void* ws, int64_t ws_bytes,
+                                         tt_stream_t stream) {
+  if (!logits) return fail_arg("tt_inbatch_ce_fwd_du_keep: null pointer");
+  return fwd_du_impl(U, ldu, I, ldi, M, N, D, diag_offset, row_lse, row_ce, du_unit, ld_du, logits, logits_bytes, ws, ws_bytes, stream);
+}
+
+static int fwd_du_impl(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N,
+                       int64_t D, int64_t diag_offset, float* row_lse, float* row_ce, float* du_unit,
+                       int64_t ld_du, float* logits, int64_t logits_bytes, void* ws, int64_t ws_bytes,
+                       tt_stream_t stream) {
   if (!U || !I || !row_lse || !row_ce || !du_unit || !ws) return fail_arg("tt_inbatch_ce_fwd_du: null pointer");
   if (M <= 0 || N <= 0 || D <= 0 || ldu < D || ldi < D || ld_du < D) return fail_arg("tt_inbatch_ce_fwd_du: sizes");
   if (diag_offset < 0 || diag_offset + M > N) return fail_arg("tt_inbatch_ce_fwd_du: diagonal outside the item block");
@@ -642,7 +819,18 @@ extern "C" int tt_inbatch_ce_fwd_du(const float* U, int64_t ldu, const float* I,
   a.out = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + round_up((2 * (int64_t)pl.splits * M + M) * 4, 256));
   dim3 grid((unsigned)ceil_div(M, BI), (unsigned)pl.splits);
   hipStream_t st = S(stream);
-  int rc = dispatch_fwd_du(pl.dp8, can_dma(I, ldi, D, pl.dp8), a, grid, st);
+  int rc;
+  if (logits) {
+    if (!can_dma(I, ldi, D, pl.dp8) || !al16(logits)) {
+      set_error("tt_inbatch_ce_fwd_du_keep: needs D in {32, 64, 128} with 16-B aligned rows (use tt_inbatch_ce_fwd_du)");
+      return TT_E_UNSUPPORTED;
+    }
+    if (logits_bytes < tt_inbatch_ce_logits_bytes(M, N)) { set_error("tt_inbatch_ce_fwd_du_keep: logits buffer"); return TT_E_WORKSPACE; }
+    a.keep = logits; a.ldk = round_up(N, 128);
+    rc = dispatch_fwd_du_keep(pl.dp8, a, grid, st);
+  } else {
+    rc = dispatch_fwd_du(pl.dp8, can_dma(I, ldi, D, pl.dp8), a, grid, st);
+  }
   if (rc) return rc;
   ce_fwd_du_finish_kernel<<<(unsigned)ceil_div(M, 4), 256, 0, st>>>(a.part_m, a.part_s, a.diag, a.out, pl.splits, M, D, I,
                                                                      ldi, diag_offset, row_lse, row_ce, du_unit, ld_du);
@@ -690,6 +878,37 @@ extern "C" int tt_inbatch_ce_bwd(const float* U, int64_t ldu, const float* I, in
       slab_reduce_kernel<<<(unsigned)(ceil_div(N * D, 256) < 2048 ? ceil_div(N * D, 256) : 2048), 256, 0, st>>>(slab_i, pi.splits, N, D, dI, lddi);
       if ((rc = check_launch("slab_reduce_kernel"))) return rc;
     }
+  }
+  return 0;
+}
+
+extern "C" int tt_inbatch_ce_bwd_kept(const float* U, int64_t ldu, int64_t M, int64_t N, int64_t D, int64_t diag_offset,
+                                      const float* row_lse, const float* coef, const float* logits,
+                                      int64_t logits_bytes, float* dI, int64_t lddi, void* ws, int64_t ws_bytes,
+                                      tt_stream_t stream) {
+  if (!U || !row_lse || !coef || !logits || !dI || !ws) return fail_arg("tt_inbatch_ce_bwd_kept: null pointer");
+  if (M <= 0 || N <= 0 || D <= 0 || ldu < D || lddi < D) return fail_arg("tt_inbatch_ce_bwd_kept: sizes");
+  CePlan pu, pi;
+  if (!plan_ce(M, N, D, pu) || !plan_ce(N, M, D, pi)) { set_error("tt_inbatch_ce: D=%lld > 128 not implemented", (long long)D); return TT_E_UNSUPPORTED; }
+  if (!can_dma(U, ldu, D, pi.dp8) || !al16(logits)) {
+    set_error("tt_inbatch_ce_bwd_kept: needs D in {32, 64, 128} with 16-B aligned rows");
+    return TT_E_UNSUPPORTED;
+  }
+  if (logits_bytes < tt_inbatch_ce_logits_bytes(M, N)) { set_error("tt_inbatch_ce_bwd_kept: logits buffer"); return TT_E_WORKSPACE; }
+  if (ws_bytes < tt_inbatch_ce_workspace_bytes(M, N, D)) { set_error("tt_inbatch_ce_bwd_kept: workspace"); return TT_E_WORKSPACE; }
+  hipStream_t st = S(stream);
+  float* slab_i = reinterpret_cast<float*>(ws);
+  CeArgs a{};
+  a.Y = U; a.ldy = ldu; a.RX = N; a.RY = M; a.D = D; a.diag_offset = diag_offset;
+  a.tiles_per_split = pi.tiles_per_split; a.splits = pi.splits;
+  a.lse = row_lse; a.coef = coef; a.out = pi.splits > 1 ? slab_i : dI; a.ldo = lddi;
+  a.keep = const_cast<float*>(logits); a.ldk = round_up(N, 128);
+  dim3 grid((unsigned)ceil_div(N, BI), (unsigned)pi.splits);
+  int rc = pi.dp8 == 4 ? launch_bwd_kept<4>(a, grid, st) : pi.dp8 == 8 ? launch_bwd_kept<8>(a, grid, st) : launch_bwd_kept<16>(a, grid, st);
+  if (rc) return rc;
+  if (pi.splits > 1) {
+    slab_reduce_kernel<<<(unsigned)(ceil_div(N * D, 256) < 2048 ? ceil_div(N * D, 256) : 2048), 256, 0, st>>>(slab_i, pi.splits, N, D, dI, lddi);
+    if ((rc = check_launch("slab_reduce_kernel"))) return rc;
   }
   return 0;
 }

@@ -368,12 +368,23 @@ _FUSED_DU = os.environ.get("TT_CE_NO_FUSED_DU") is None  # A/B switches (DESIGN.
 _ROW0_LAST = os.environ.get("TT_ENC_FULL_LAST_LAYER") is None
 
 
+def kept_logits_supported(U: torch.Tensor, I: torch.Tensor) -> bool:
+    """tt_inbatch_ce_fwd_du_keep / tt_inbatch_ce_bwd_kept: D in {32, 64, 128}, 16-B aligned rows."""
+    D = U.shape[1]
+    return (D in (32, 64, 128) and U.stride(0) % 4 == 0 and I.stride(0) % 4 == 0
+            and U.data_ptr() % 16 == 0 and I.data_ptr() % 16 == 0 and os.environ.get("TT_CE_NO_DMA") is None)
+
+
 class InBatchSoftmaxCE(torch.autograd.Function):
     """row_ce[i] = logsumexp_j (U I^T)[i, j] - (U I^T)[i, i + diag_offset]
     (torch.matmul + F.cross_entropy(reduction="none"), ref:...base_retrieval.py:287-312)."""
 
     @staticmethod
-    def forward(ctx, U, I, diag_offset: int = 0):
+    def forward(ctx, U, I, diag_offset: int = 0, keep_logits: Optional[bool] = None):
+        """`keep_logits`: write the [M, N] logits out in the forward so the item-side backward does not
+        recompute them (3 instead of 4 logit-sized products, for M*N*4 B of HBM each way).  Default:
+        only for wide negative sets (N >= 4 M, i.e. several ranks' items per user) -- at N = M the
+        step is bound by the Adam sweep's HBM traffic and the extra bytes cost more than the MFMAs."""
         dev = N.require_device(U, I)
         U, I = _rowmajor(U), _rowmajor(I)
         M, D = U.shape
@@ -385,12 +396,23 @@ class InBatchSoftmaxCE(torch.autograd.Function):
         pu, _, _, ldu = _f32_2d(U, "U")
         pi, _, _, ldi = _f32_2d(I, "I")
         ctx.diag_offset = diag_offset
+        ctx.kept = None
         if ctx.needs_input_grad[0] and _FUSED_DU:
             # training: the forward also accumulates E[i] = sum_j p_ij I_j, which IS the user-side
             # gradient up to the row factor -- the backward then only runs the item-side kernel
             du_unit = torch.empty(M, D, dtype=torch.float32, device=dev)
-            N.check(lib.tt_inbatch_ce_fwd_du(pu, ldu, pi, ldi, M, Nn, D, diag_offset, lse.data_ptr(), ce.data_ptr(),
-                                             du_unit.data_ptr(), D, wsp, wsn, N.stream()), "tt_inbatch_ce_fwd_du")
+            if keep_logits is None:
+                keep_logits = Nn >= 4 * M
+            keep_logits = bool(keep_logits) and ctx.needs_input_grad[1] and kept_logits_supported(U, I)
+            if keep_logits:
+                zn = lib.tt_inbatch_ce_logits_bytes(M, Nn)
+                ctx.kept = torch.empty(zn, dtype=torch.uint8, device=dev)
+                N.check(lib.tt_inbatch_ce_fwd_du_keep(pu, ldu, pi, ldi, M, Nn, D, diag_offset, lse.data_ptr(),
+                                                      ce.data_ptr(), du_unit.data_ptr(), D, ctx.kept.data_ptr(), zn,
+                                                      wsp, wsn, N.stream()), "tt_inbatch_ce_fwd_du_keep")
+            else:
+                N.check(lib.tt_inbatch_ce_fwd_du(pu, ldu, pi, ldi, M, Nn, D, diag_offset, lse.data_ptr(), ce.data_ptr(),
+                                                 du_unit.data_ptr(), D, wsp, wsn, N.stream()), "tt_inbatch_ce_fwd_du")
             ctx.save_for_backward(U, I, lse, du_unit)
             return ce
         N.check(lib.tt_inbatch_ce_fwd(pu, ldu, pi, ldi, M, Nn, D, diag_offset, lse.data_ptr(), ce.data_ptr(),
@@ -413,10 +435,16 @@ class InBatchSoftmaxCE(torch.autograd.Function):
         wsp, wsn = _ws(dev, lib.tt_inbatch_ce_workspace_bytes(M, Nn, D))
         pu, _, _, ldu = _f32_2d(U, "U")
         pi, _, _, ldi = _f32_2d(I, "I")
+        if ctx.kept is not None:  # item side from the logits the forward kept
+            N.check(lib.tt_inbatch_ce_bwd_kept(pu, ldu, M, Nn, D, ctx.diag_offset, lse.data_ptr(), coef.data_ptr(),
+                                               ctx.kept.data_ptr(), ctx.kept.numel(), dI.data_ptr(), D, wsp, wsn,
+                                               N.stream()), "tt_inbatch_ce_bwd_kept")
+            ctx.kept = None
+            return dU, dI, None, None
         N.check(lib.tt_inbatch_ce_bwd(pu, ldu, pi, ldi, M, Nn, D, ctx.diag_offset, lse.data_ptr(),
                                       coef.data_ptr(), None if du_unit is not None else dU.data_ptr(), D,
                                       dI.data_ptr(), D, wsp, wsn, N.stream()), "tt_inbatch_ce_bwd")
-        return dU, dI, None
+        return dU, dI, None, None
 
 
 class WeightedMeanLoss(torch.autograd.Function):

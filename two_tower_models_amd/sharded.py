@@ -164,6 +164,8 @@ class HipBackend:
         self.device = device
         self._sides = {}
         self._du_unit = None
+        self._kept = None
+        self.keep_logits = False  # set by the trainer when the logits dominate the step
         self._side_stream = None
         self._sweep_done = None
 
@@ -255,6 +257,16 @@ class HipBackend:
         # forward fused with the user-side gradient (kept for ce_bwd): with global negatives the
         # logits are the step at 8 GPUs, and this removes one of their five passes
         self._du_unit = self.empty(M, D)
+        self._kept = None
+        if self.keep_logits and ops.kept_logits_supported(U, I_all):
+            # wide negative sets: the logits are written out once and read back by the item-side
+            # backward instead of being recomputed (3 instead of 4 logit-sized products per step)
+            zn = lib.tt_inbatch_ce_logits_bytes(M, Nn)
+            self._kept = torch.empty(zn, dtype=torch.uint8, device=self.device)
+            N.check(lib.tt_inbatch_ce_fwd_du_keep(U.data_ptr(), D, I_all.data_ptr(), D, M, Nn, D, off, lse.data_ptr(),
+                                                  ce.data_ptr(), self._du_unit.data_ptr(), D, self._kept.data_ptr(), zn,
+                                                  wsp, wsn, N.stream()), "tt_inbatch_ce_fwd_du_keep")
+            return ce, lse
         N.check(lib.tt_inbatch_ce_fwd_du(U.data_ptr(), D, I_all.data_ptr(), D, M, Nn, D, off, lse.data_ptr(),
                                          ce.data_ptr(), self._du_unit.data_ptr(), D, wsp, wsn, N.stream()),
                 "tt_inbatch_ce_fwd_du")
@@ -267,6 +279,12 @@ class HipBackend:
         dU, dI = self._du_unit * coef.unsqueeze(1), self.empty(Nn, D)
         self._du_unit = None
         wsp, wsn = ops._ws(self.device, lib.tt_inbatch_ce_workspace_bytes(M, Nn, D))
+        if self._kept is not None:
+            N.check(lib.tt_inbatch_ce_bwd_kept(U.data_ptr(), D, M, Nn, D, off, lse.data_ptr(), coef.data_ptr(),
+                                               self._kept.data_ptr(), self._kept.numel(), dI.data_ptr(), D, wsp, wsn,
+                                               N.stream()), "tt_inbatch_ce_bwd_kept")
+            self._kept = None
+            return dU, dI
         N.check(lib.tt_inbatch_ce_bwd(U.data_ptr(), D, I_all.data_ptr(), D, M, Nn, D, off, lse.data_ptr(),
                                       coef.data_ptr(), None, D, dI.data_ptr(), D, wsp, wsn, N.stream()),
                 "tt_inbatch_ce_bwd")
@@ -445,6 +463,11 @@ class ShardedTrainer:
         logits_ms = 8.0 * cfg["B"] * cfg["B"] * (self.W if negatives == "global" else 1) * cfg["D"] / 125.0e9
         late = os.environ.get("TT_SWEEP_LATE")  # A/B switch
         self._sweep_late = (late == "1") if late is not None else sweep_ms < 0.75 * logits_ms
+        # the same regime decides whether the forward keeps the logits for the backward (one product
+        # fewer, M*N*4 B of HBM traffic each way more): worth it once the sweep no longer binds
+        keep = os.environ.get("TT_CE_KEEP_LOGITS")
+        if hasattr(self.be, "keep_logits"):
+            self.be.keep_logits = (keep == "1") if keep is not None else sweep_ms < 0.75 * logits_ms
         self.last_loss = torch.zeros((), dtype=torch.float32, device=device)
 
     def _tower_params(self, side):
