@@ -434,11 +434,13 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_du_k
   using TM = TileMap<DP8, GLDS>;
   constexpr int TD = (DP8 + 3) / 4;
   constexpr int TILE_FLOATS = BJ * TM::LD;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* const smem = reinterpret_cast<float*>(smem_raw);
+  // two NAMED tile buffers (see ce_bwd_kept_kernel): LDS reads of one no longer wait for the DMA into the other
+  __shared__ __attribute__((aligned(16))) float buf0[TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float buf1[TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float fbuf_all[4 * 32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int64_t a = (int64_t)blockIdx.x * BI + wave * 32 + r;
-  float* const fbuf = smem + 2 * TILE_FLOATS + wave * 32;  // this wave's 32 rescale factors
+  float* const fbuf = fbuf_all + wave * 32;  // this wave's 32 rescale factors
 
   float xr[DP8][4];
   load_stationary<DP8>(xr, p.X, p.ldx, a, p.RX, p.D, h, p.x_vec);
@@ -461,15 +463,12 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_du_k
 
   Stager<DP8, GLDS> stg;
   if (t0 < t1) {
-    stg.issue(p.Y, p.ldy, t0 * BJ, p.RY, p.D, p.y_vec, smem, wave, lane);
-    stg.land(smem);
+    stg.issue(p.Y, p.ldy, t0 * BJ, p.RY, p.D, p.y_vec, buf0, wave, lane);
+    stg.land(buf0);
   }
   __syncthreads();
-  for (int64_t t = t0; t < t1; ++t) {
-    const int cur = (int)((t - t0) & 1);
-    float* nxt = smem + (cur ^ 1) * TILE_FLOATS;
+  auto step = [&](int64_t t, const float* ys, float* nxt) {
     if (t + 1 < t1) stg.issue(p.Y, p.ldy, (t + 1) * BJ, p.RY, p.D, p.y_vec, nxt, wave, lane);
-    const float* ys = smem + cur * TILE_FLOATS;
     const int64_t wrel = want - t * BJ, lrel = p.RY - t * BJ;
     const int want4 = (wrel >= 0 && wrel < BJ) ? (int)wrel - 4 * h : -1000;
     const int lim4 = (lrel < BJ ? (int)lrel : BJ) - 4 * h;
@@ -536,6 +535,10 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_du_k
     }
     if (t + 1 < t1) stg.land(nxt);
     __syncthreads();
+  };
+  for (int64_t t = t0; t < t1; t += 2) {
+    step(t, buf0, buf1);
+    if (t + 1 < t1) step(t + 1, buf1, buf0);
   }
   // the two lane halves hold the same m and disjoint parts of the sum
   const float so = __shfl_xor(s, 32, 64);
@@ -709,11 +712,8 @@ static int dispatch_fwd(int dp8, bool dma, const CeArgs& a, dim3 grid, hipStream
 }
 template <int DP8, bool GLDS, bool KEEP = false>
 static int launch_fwd_du(const CeArgs& a, dim3 grid, hipStream_t st) {
-  const size_t lds = (2 * BJ * TileMap<DP8, GLDS>::LD + 4 * 32) * sizeof(float);
-  int rc = opt_in_lds(ce_fwd_du_kernel<DP8, GLDS, KEEP>, lds, "ce_fwd_du_kernel");
-  if (rc) return rc;
   ProfScope prof("ce_fwd_kernel", st);
-  ce_fwd_du_kernel<DP8, GLDS, KEEP><<<grid, 256, lds, st>>>(a);
+  ce_fwd_du_kernel<DP8, GLDS, KEEP><<<grid, 256, 0, st>>>(a);  // LDS is static: two named tile buffers
   return check_launch("ce_fwd_du_kernel");
 }
 template <int DP8>
