@@ -314,9 +314,13 @@ def main():
             # logits grow N-fold: report whichever kernel family actually dominates the step.
             if ce_cnt.value > 0 and ce_ms.value > ms.value:
                 n_neg = B * world if (use_sharded and args.negatives == "global") else B
-                flops = 2.0 * B * n_neg * cfg["D"]  # one gradient product per launch (dU or dI); the kernel
-                tf = flops * ce_cnt.value / (ce_ms.value * 1e-3) / 1e12  # also recomputes its logits tile
-                roof = {"bound": "mfma", "kernel": "ce_bwd_kernel", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF,
+                # one gradient product per launch (dI); ce_bwd_kernel also recomputes its logits tile,
+                # ce_bwd_kept_kernel reads the logits the forward kept (sharded trainer, wide negative sets)
+                kept = use_sharded and getattr(trainer.be, "keep_logits", False)
+                flops = 2.0 * B * n_neg * cfg["D"]
+                tf = flops * ce_cnt.value / (ce_ms.value * 1e-3) / 1e12
+                roof = {"bound": "mfma", "kernel": "ce_bwd_kept_kernel" if kept else "ce_bwd_kernel",
+                        "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF,
                         "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None,
                         "launches": ce_cnt.value, "avg_launch_ms": round(ce_ms.value / ce_cnt.value, 4),
                         "algorithmic_flops_per_launch": flops}
