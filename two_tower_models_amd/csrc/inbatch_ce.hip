@@ -322,10 +322,20 @@ __global__ __launch_bounds__(256, 2) void ce_bwd_kept_kernel(const CeArgs p) {
   const int zlane = wave * 32 + r + 4 * h * (int)p.ldk;
   float zn[32];
   auto zload = [&](int64_t t) {
+    // the row stride is made opaque here so that the 32 row offsets are recomputed with a scalar
+    // multiply per tile: hoisted out of the loop they occupy 64 scalar registers, which spill into
+    // VGPR lanes and come back through v_readlane in front of every load
+    int ldk = (int)p.ldk;
+    asm volatile("" : "+s"(ldk));
+    // buffer loads: tile base in a scalar resource descriptor, row offset in a scalar register, ONE
+    // 32-bit per-lane offset -- global_load would carry a 64-bit VGPR address per load (two VALU
+    // adds each, 64 per tile)
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zblock + t * BJ * (int64_t)ldk), 0, -1, 0x00020000);
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
-      const float* zrow = zblock + (t * BJ + ((i >> 4) * 32 + (i & 3) + 8 * ((i & 15) >> 2))) * p.ldk;
-      zn[i] = zrow[zlane];
+      const int row = (i >> 4) * 32 + (i & 3) + 8 * ((i & 15) >> 2);
+      zn[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, zlane * 4, row * ldk * 4, 0));
     }
   };
   float st_lse = 0.f, st_coef = 0.f;  // threads 0..63 stage the streamed rows' stats (raw: masked when landed)
