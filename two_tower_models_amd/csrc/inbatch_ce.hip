@@ -156,8 +156,9 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_bwd_kern
   using TM = TileMap<DP8, GLDS>;
   constexpr int TD = (DP8 + 3) / 4;  // 32-column tiles of the output
   constexpr int TILE_FLOATS = BJ * TM::LD + (STREAM_STATS ? 2 * BJ : 0);
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* const smem = reinterpret_cast<float*>(smem_raw);
+  // two NAMED tile buffers (see ce_bwd_kept_kernel): LDS reads of one do not wait for the DMA into the other
+  __shared__ __attribute__((aligned(16))) float buf0[TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float buf1[TILE_FLOATS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int64_t a = (int64_t)blockIdx.x * BI + wave * 32 + r;
 
@@ -201,13 +202,10 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_bwd_kern
     stg.land(dst);
   };
 
-  if (t0 < t1) { issue(t0, smem); land(smem); }
+  if (t0 < t1) { issue(t0, buf0); land(buf0); }
   __syncthreads();
-  for (int64_t t = t0; t < t1; ++t) {
-    const int cur = (int)((t - t0) & 1);
-    float* nxt = smem + (cur ^ 1) * TILE_FLOATS;
+  auto step = [&](int64_t t, const float* ys, float* nxt) {
     if (t + 1 < t1) issue(t + 1, nxt);
-    const float* ys = smem + cur * TILE_FLOATS;
     // tile-relative 32-bit indices, lane term 4h folded in (see ce_fwd_kernel).  The streamed
     // row that pairs with stationary row a is  a + diag_offset (dU) / a - diag_offset (dI).
     const int64_t wrel = (STREAM_STATS ? a - p.diag_offset : a + p.diag_offset) - t * BJ, lrel = p.RY - t * BJ;
@@ -267,6 +265,10 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_bwd_kern
     }
     if (t + 1 < t1) land(nxt);
     __syncthreads();
+  };
+  for (int64_t t = t0; t < t1; t += 2) {
+    step(t, buf0, buf1);
+    if (t + 1 < t1) step(t + 1, buf1, buf0);
   }
 
   float* out = p.out + (p.splits > 1 ? (int64_t)blockIdx.y * p.RX * p.D : 0);
@@ -704,11 +706,8 @@ static int launch_fwd(const CeArgs& a, dim3 grid, hipStream_t st) {
 }
 template <int DP8, bool SS, bool GLDS>
 static int launch_bwd(const CeArgs& a, dim3 grid, hipStream_t st) {
-  const size_t lds = 2 * (BJ * TileMap<DP8, GLDS>::LD + (SS ? 2 * BJ : 0)) * sizeof(float);
-  int rc = opt_in_lds(ce_bwd_kernel<DP8, SS, GLDS>, lds, "ce_bwd_kernel");
-  if (rc) return rc;
   ProfScope prof("ce_bwd_kernel", st);
-  ce_bwd_kernel<DP8, SS, GLDS><<<grid, 256, lds, st>>>(a);
+  ce_bwd_kernel<DP8, SS, GLDS><<<grid, 256, 0, st>>>(a);  // LDS is static: two named tile buffers
   return check_launch("ce_bwd_kernel");
 }
 // LDS-DMA staging needs an unpadded, fully valid row: D == padded D, 16-B aligned rows

@@ -112,22 +112,28 @@ struct TileMap {
 
 // LDS-DMA of one 64-row tile: each wave instruction lands 1 KiB (= 64/CPR rows); the lane
 // fetches the chunk that belongs at ITS linear LDS position after swizzling.
+// Issued as buffer loads (buffer_load_dwordx4 ... lds): the tile base sits in a scalar resource
+// descriptor and the lane contributes ONE 32-bit offset, so there is no 64-bit per-lane address
+// arithmetic and no clamping (rows past the end are outside the descriptor's range and land as
+// zeros; every consumer masks them anyway).  In the kernels at the register limit the 64-bit
+// addresses of the global_load form were spilled, and a reload waits on vmcnt -- the DMA just issued.
 template <int DP8>
 __device__ __forceinline__ void tile_dma(const float* __restrict__ Y, int64_t ld, int64_t row0, int64_t nrows,
                                          float* Ys, int wave, int lane) {
   using TM = TileMap<DP8, true>;
   constexpr int RPI = 64 / TM::CPR;        // rows per wave instruction
   constexpr int NI = BJ / RPI / 4;         // instructions per wave
+  const int64_t left = nrows - row0;
+  const int rows_here = left < BJ ? (int)left : BJ;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Y + row0 * ld), 0, rows_here * (int)ld * 4, 0x00020000);
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int rbase = (wave * NI + i) * RPI;
     const int row = rbase + lane / TM::CPR;
     const int c = (lane % TM::CPR) ^ (row & TM::SW);
-    int64_t grow = row0 + row;
-    grow = grow < nrows ? grow : nrows - 1;  // clamp: out-of-range rows are masked by the epilogue
-    const float* src = Y + grow * ld + 4 * c;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(Ys + rbase * TM::DP), 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Ys + rbase * TM::DP), 16,
+                                             (row * (int)ld + 4 * c) * 4, 0, 0, 0);
   }
 }
 
