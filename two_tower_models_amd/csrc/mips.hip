@@ -309,16 +309,20 @@ __device__ __forceinline__ void corpus_tile_dma(const char* __restrict__ Cm, int
   using TM = TileMap<DP8, true>;
   constexpr int RPI = 64 / TM::CPR;  // rows per wave instruction (1 KiB)
   constexpr int NI = CT / RPI / 4;   // instructions per wave
+  // buffer loads (see tile_dma in mfma_stream.hpp): chunk base in a scalar descriptor, one 32-bit lane
+  // offset; rows past the end of the corpus are outside the descriptor and land as zeros (the
+  // epilogue masks them)
+  const int64_t chunk0 = (t >> 1) * CHUNK, left = C - chunk0;
+  const int rows_here = left < CHUNK ? (int)left : CHUNK;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Cm + chunk0 * row_bytes), 0,
+                                                                      rows_here * (int)row_bytes, 0x00020000);
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int rbase = (wave * NI + i) * RPI;
     const int row = rbase + lane / TM::CPR;
     const int c = (lane % TM::CPR) ^ (row & TM::SW);
-    int64_t grow = (t >> 1) * CHUNK + chunk_row((int)(t & 1), row);
-    grow = grow < C ? grow : C - 1;  // rows past the end are masked by the epilogue
-    const char* src = Cm + grow * row_bytes + 16 * c;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(Ys + rbase * TM::DP), 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Ys + rbase * TM::DP), 16,
+                                             chunk_row((int)(t & 1), row) * (int)row_bytes + 16 * c, 0, 0, 0);
   }
 }
 
@@ -338,9 +342,20 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
   using TM = TileMap<DPX, true>;  // row bytes = 32 * DPX for both dtypes
   static_assert(DT == TT_BF16 || NQ == 1, "two query fragments only for bf16");
   static_assert(!SHARE || NQ == 1, "shared queries: one fragment");
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* const smem = reinterpret_cast<float*>(smem_raw);
   constexpr int TILE_FLOATS = CT * TM::DP;
+  // The ring's stages are separately NAMED LDS arrays and the tile loop is unrolled by STAGES: only
+  // then can the compiler tell that an LDS read of one stage does not depend on the DMA in flight into
+  // another (with one dynamic block it waits vmcnt(0) in front of the first LDS read after every DMA
+  // issue, which made the ring depth irrelevant).
+  // fp32 (2 stages): +14 % on the pass.  bf16 keeps the dynamic ring: its pass is bound by the
+  // epilogue's VALU work, and four copies of the NQ = 4 body do not fit the register file.
+  constexpr bool NAMED = (STAGES == 2);
+  __shared__ __attribute__((aligned(16))) float ring0[NAMED ? TILE_FLOATS : 4];
+  __shared__ __attribute__((aligned(16))) float ring1[NAMED ? TILE_FLOATS : 4];
+  __shared__ float red[SHARE ? 4 * 64 * 3 : 4];  // SHARE: the four waves' partial triples of a chunk
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // the ring when it is not NAMED
+  float* const smem = reinterpret_cast<float*>(smem_raw);
+  auto stage = [&](int k) -> float* { return NAMED ? (k == 0 ? ring0 : ring1) : smem + k * TILE_FLOATS; };
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   // XCD-aware decomposition of the 1-D grid (workgroup L runs on XCD L % 8, each XCD has its own
   // L2): the `xblocks` query blocks that stream the SAME corpus split get consecutive slots on
@@ -364,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
   constexpr int NI = CT / (64 / TM::CPR) / 4;  // DMA instructions per wave per tile
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
-    if (t0 + s < t1) corpus_tile_dma<DPX>(Cm, row_bytes, t0 + s, p.C, smem + s * TILE_FLOATS, wave, lane);
+    if (t0 + s < t1) corpus_tile_dma<DPX>(Cm, row_bytes, t0 + s, p.C, stage(s), wave, lane);
   if (t0 + STAGES - 1 <= t1) wait_vmcnt<(STAGES - 2) * NI>();  // tile t0 has landed
   else wait_vmcnt<0>();
   __syncthreads();
@@ -375,12 +390,11 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
   int arg[NQ];
 #pragma unroll
   for (int n = 0; n < NQ; ++n) { m1[n] = NEG_INF; m2[n] = NEG_INF; arg[n] = 0; }
-  for (int64_t t = t0; t < t1; ++t) {
-    const int cur = (int)((t - t0) % STAGES);
-    // the buffer of tile t-1 is free since the barrier that ended the previous iteration
+  // one tile: `ys` is scored, `dst` (the stage of tile t-1, free since the barrier that ended the
+  // previous step) receives tile t + STAGES - 1
+  auto step = [&](int64_t t, const float* ys, float* dst) {
     const bool more = t + STAGES - 1 < t1;
-    if (more) corpus_tile_dma<DPX>(Cm, row_bytes, t + STAGES - 1, p.C, smem + ((cur + STAGES - 1) % STAGES) * TILE_FLOATS, wave, lane);
-    const float* ys = smem + cur * TILE_FLOATS;
+    if (more) corpus_tile_dma<DPX>(Cm, row_bytes, t + STAGES - 1, p.C, dst, wave, lane);
     const int64_t chunk = t >> 1;
     const bool full = (chunk + 1) * CHUNK <= p.C;
 #pragma unroll
@@ -430,7 +444,6 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
     if (SHARE && (t & 1)) {
       // merge the four waves' partial triples of this chunk (sub-tiles in ascending row order, so
       // "strictly greater" keeps the earlier row on ties, like the sequential scan)
-      float* red = smem + STAGES * TILE_FLOATS;  // [4][64][3]
       red[(wave * 64 + lane) * 3] = m1[0];
       red[(wave * 64 + lane) * 3 + 1] = m2[0];
       red[(wave * 64 + lane) * 3 + 2] = __int_as_float(arg[0]);
@@ -469,6 +482,17 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
     if (more) wait_vmcnt<(STAGES - 2) * NI>();
     else wait_vmcnt<0>();
     __syncthreads();
+  };
+  if constexpr (NAMED) {
+    for (int64_t t = t0; t < t1; t += 2) {
+      step(t, ring0, ring1);
+      if (t + 1 < t1) step(t + 1, ring1, ring0);
+    }
+  } else {
+    for (int64_t t = t0; t < t1; ++t) {
+      const int cur = (int)((t - t0) % STAGES);
+      step(t, smem + cur * TILE_FLOATS, smem + ((cur + STAGES - 1) % STAGES) * TILE_FLOATS);
+    }
   }
 }
 
@@ -843,7 +867,7 @@ template <int DT, int DPX, int NQ, bool SHARE = false>
 static int launch_pass1_dma(MipsArgs a, int64_t, hipStream_t st) {
   // (a deeper ring for the shared-query form -- 4 / 8 stages, one workgroup per CU -- was measured: slower)
   constexpr int STAGES = (DT == TT_BF16) ? 4 : 2;
-  const size_t lds = STAGES * (size_t)CT * 32 * DPX + (SHARE ? 4 * 64 * 3 * sizeof(float) : 0);
+  const size_t lds = STAGES == 2 ? 0 : STAGES * (size_t)CT * 32 * DPX;  // two stages live in named static arrays
   // 2 workgroups per CU are resident; aim at ~4 rounds of them
   const int64_t xblocks = SHARE ? ceil_div(a.nq, 32) : ceil_div(a.nq, QB_WG * NQ);
   int64_t splits = ceil_div(2048, xblocks);
@@ -853,10 +877,12 @@ static int launch_pass1_dma(MipsArgs a, int64_t, hipStream_t st) {
   a.xblocks = xblocks;
   a.splits = splits;
   const int64_t grid = 8 * ceil_div(xblocks * splits, 8);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mips_pass1_dma_kernel<DT, DPX, NQ, STAGES, SHARE>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) { set_error("mips_pass1_dma_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
   ProfScope prof("mips_score_kernel", st);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mips_pass1_dma_kernel<DT, DPX, NQ, STAGES, SHARE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("mips_pass1_dma_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+  }
   mips_pass1_dma_kernel<DT, DPX, NQ, STAGES, SHARE><<<(unsigned)grid, 256, lds, st>>>(a);
   return check_launch("mips_pass1_dma_kernel");
 }
