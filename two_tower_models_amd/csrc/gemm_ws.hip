@@ -75,9 +75,11 @@ constexpr int WS_PLAIN = 0, WS_ACC = 1, WS_GENERIC = 2;
 template <int DP8, bool GLDS, bool W_TRANS, int MODE>
 __global__ __launch_bounds__(256, ((GLDS && DP8 <= 16) ? 2 : 1)) void gemm_ws_kernel(const WsArgs p) {
   using TM = TileMap<DP8, GLDS>;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* const smem = reinterpret_cast<float*>(smem_raw);
   constexpr int TILE_FLOATS = BJ * TM::LD;
+  // two NAMED tile buffers, loop unrolled by two: LDS reads of one buffer then do not wait for the
+  // LDS-DMA in flight into the other (hipcc cannot tell two halves of one dynamic block apart)
+  __shared__ __attribute__((aligned(16))) float buf0[TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float buf1[TILE_FLOATS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   // XCD-aware decomposition of the 1-D grid (workgroup b runs on XCD b % 8): the `colblocks`
   // workgroups that stream the SAME rows get consecutive slots on ONE XCD, so the activation
@@ -114,8 +116,8 @@ __global__ __launch_bounds__(256, ((GLDS && DP8 <= 16) ? 2 : 1)) void gemm_ws_ke
 
   Stager<DP8, GLDS> stg;
   if (t0 < t1) {
-    stg.issue(p.A, p.lda, t0 * BJ, p.M, p.K, p.a_vec, smem, wave, lane);
-    stg.land(smem);
+    stg.issue(p.A, p.lda, t0 * BJ, p.M, p.K, p.a_vec, buf0, wave, lane);
+    stg.land(buf0);
   }
   __syncthreads();
   // The tile's results are written by `emit`.  CDNA counts stores on vmcnt, the same counter the
@@ -183,32 +185,28 @@ __global__ __launch_bounds__(256, ((GLDS && DP8 <= 16) ? 2 : 1)) void gemm_ws_ke
   };
   f32x16 pend;
   int64_t pend_m = -1;
-  for (int64_t t = t0; t < t1; ++t) {
-    const int cur = (int)((t - t0) & 1);
-    float* nxt = smem + (cur ^ 1) * TILE_FLOATS;
+  auto step = [&](int64_t t, const float* ys, float* nxt) {
     // the deferred stores go out BEFORE the next DMA is queued: anything they wait on is older
     if (pend_m >= 0) emit(pend, pend_m);
     if (t + 1 < t1) stg.issue(p.A, p.lda, (t + 1) * BJ, p.M, p.K, p.a_vec, nxt, wave, lane);
-    const f32x16 acc0 = out_tile<DP8, GLDS>(smem + cur * TILE_FLOATS, xr, 0, r, h);
+    const f32x16 acc0 = out_tile<DP8, GLDS>(ys, xr, 0, r, h);
     emit(acc0, t * BJ + r);
-    pend = out_tile<DP8, GLDS>(smem + cur * TILE_FLOATS, xr, 1, r, h);
+    pend = out_tile<DP8, GLDS>(ys, xr, 1, r, h);
     pend_m = t * BJ + 32 + r;
     if (t + 1 < t1) stg.land(nxt);
     __syncthreads();
+  };
+  for (int64_t t = t0; t < t1; t += 2) {
+    step(t, buf0, buf1);
+    if (t + 1 < t1) step(t + 1, buf1, buf0);
   }
   if (pend_m >= 0) emit(pend, pend_m);
 }
 
 template <int DP8, bool GLDS, bool WT, int MODE>
 static int launch_ws(const WsArgs& a, dim3 grid, hipStream_t st) {
-  const size_t lds = 2 * BJ * TileMap<DP8, GLDS>::LD * sizeof(float);
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<DP8, GLDS, WT, MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("gemm_ws_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-  }
   ProfScope prof("gemm_ws_kernel", st);
-  gemm_ws_kernel<DP8, GLDS, WT, MODE><<<grid, 256, lds, st>>>(a);
+  gemm_ws_kernel<DP8, GLDS, WT, MODE><<<grid, 256, 0, st>>>(a);  // LDS is static: two named tile buffers
   return check_launch("gemm_ws_kernel");
 }
 template <bool GLDS, bool WT, int MODE>
