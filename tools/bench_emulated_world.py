@@ -53,8 +53,10 @@ steps = 30
 t0 = time.perf_counter()
 for i in range(steps):
     trainer.step(batches[i % 8])
+host_ms = (time.perf_counter() - t0) / steps * 1e3  # time to ENQUEUE a step (Python + launches)
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / steps * 1e3
+print(f"  host enqueue time {host_ms:.3f} ms/step")
 
 # where the time goes: events on the main stream around the two logits kernels
 marks = []
