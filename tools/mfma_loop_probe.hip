@@ -4,6 +4,9 @@
 //   bit 1: the gradient VALU block (16 x exp2 / compare / multiply) in front of each sub-tile
 //   bit 2: per-row statistics read from LDS for that block
 //   bit 3: workgroup barrier every two sub-tiles
+//   bit 4: the 32 logits of the next tile loaded from global memory every tile (so the gradient
+//          block is NOT loop-invariant, as it partly is without this bit)
+//   bit 5: LDS-DMA of the next 32 KiB tile into a second named buffer, vmcnt(0) before the barrier
 //   hipcc --offload-arch=gfx950 -O3 tools/mfma_loop_probe.hip -o /tmp/probe && /tmp/probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -13,6 +16,7 @@ constexpr int LD = 128, BJ = 64;
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void probe(float* out, const float* zin, int tiles) {
   __shared__ __attribute__((aligned(16))) float ys[BJ * LD + 2 * BJ];
+  __shared__ __attribute__((aligned(16))) float other[(MODE & 32) ? BJ * LD : 4];
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   for (int i = threadIdx.x; i < BJ * LD + 2 * BJ; i += 256) ys[i] = (float)((i * 37 + blockIdx.x) & 255) * (1.0f / 256.0f);
   __syncthreads();
@@ -25,7 +29,25 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, const float* zin, in
   for (int i = 0; i < 32; ++i) zc[i] = zin[(threadIdx.x * 32 + i) & 4095];
   float gt[16];
   for (int e = 0; e < 16; ++e) gt[e] = zc[e];
+  float zn[32];
+  for (int i = 0; i < 32; ++i) zn[i] = zc[i];
+  const int wave = threadIdx.x >> 6;
   for (int t = 0; t < tiles; ++t) {
+    if (MODE & 16) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) zc[i] = zn[i];
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zin), 0, 1 << 20, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < 32; ++i)
+        zn[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (threadIdx.x & 31) * 4, ((i * 97 + t * 13 + blockIdx.x) & 1023) * 128, 0));
+    }
+    if (MODE & 32) {
+      const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zin), 0, 1 << 20, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (__attribute__((address_space(3))) void*)(other + (wave * 8 + i) * 256), 16,
+                                                 lane * 16 + ((t * 8 + i) & 63) * 1024, 0, 0, 0);
+    }
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
       if (MODE & 2) {
@@ -61,6 +83,7 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, const float* zin, in
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (MODE & 32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (MODE & 8) __syncthreads();
   }
   float s = 0.f;
@@ -83,15 +106,17 @@ void run(const float* zin, float* out) {
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
   const double flop = (double)blocks * 4 * tiles * 128 * (2.0 * 32 * 32 * 2);
-  printf("mode %2d (%s%s%s%s): %7.2f ms  %.1f TFLOP/s\n", MODE, (MODE & 1) ? "lds-B " : "", (MODE & 2) ? "valu " : "",
-         (MODE & 4) ? "lds-stats " : "", (MODE & 8) ? "barrier" : "", ms, flop / ms / 1e9);
+  printf("mode %2d (%s%s%s%s%s%s): %7.2f ms  %.1f TFLOP/s\n", MODE, (MODE & 1) ? "lds-B " : "", (MODE & 2) ? "valu " : "",
+         (MODE & 4) ? "lds-stats " : "", (MODE & 8) ? "barrier " : "", (MODE & 16) ? "logit-loads " : "",
+         (MODE & 32) ? "lds-dma" : "", ms, flop / ms / 1e9);
 }
 
 int main() {
   float *zin, *out;
-  hipMalloc(&zin, 4096 * 4);
+  hipMalloc(&zin, 1 << 20);
   hipMalloc(&out, 512 * 256 * 4);
-  hipMemset(zin, 0, 4096 * 4);
+  hipMemset(zin, 0, 1 << 20);
   run<0>(zin, out); run<1>(zin, out); run<2>(zin, out); run<3>(zin, out); run<7>(zin, out); run<9>(zin, out); run<15>(zin, out);
+  run<16 + 7>(zin, out); run<16 + 15>(zin, out); run<32 + 15>(zin, out); run<32 + 16 + 15>(zin, out);
   return 0;
 }
