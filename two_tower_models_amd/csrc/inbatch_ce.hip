@@ -65,9 +65,10 @@ struct CeArgs {
 template <int DP8, bool GLDS>
 __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_kernel(const CeArgs p) {
   using TM = TileMap<DP8, GLDS>;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* const smem = reinterpret_cast<float*>(smem_raw);
   constexpr int TILE_FLOATS = BJ * TM::LD;
+  // two NAMED tile buffers, loop unrolled by two (see ce_bwd_kept_kernel)
+  __shared__ __attribute__((aligned(16))) float buf0[TILE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float buf1[TILE_FLOATS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int64_t a = (int64_t)blockIdx.x * BI + wave * 32 + r;  // this lane's user row
 
@@ -84,13 +85,11 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_kern
 
   Stager<DP8, GLDS> stg;
   if (t0 < t1) {
-    stg.issue(p.Y, p.ldy, t0 * BJ, p.RY, p.D, p.y_vec, smem, wave, lane);
-    stg.land(smem);
+    stg.issue(p.Y, p.ldy, t0 * BJ, p.RY, p.D, p.y_vec, buf0, wave, lane);
+    stg.land(buf0);
   }
   __syncthreads();
-  for (int64_t t = t0; t < t1; ++t) {
-    const int cur = (int)((t - t0) & 1);
-    float* nxt = smem + (cur ^ 1) * TILE_FLOATS;
+  auto step = [&](int64_t t, const float* ys, float* nxt) {
     if (t + 1 < t1) stg.issue(p.Y, p.ldy, (t + 1) * BJ, p.RY, p.D, p.y_vec, nxt, wave, lane);
     // tile-relative 32-bit indices with the lane term 4h folded in: row (li + 4h) of this tile
     // is the diagonal iff li == want4, and is a real item iff li < lim4
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_kern
     const int lim4 = (lrel < BJ ? (int)lrel : BJ) - 4 * h;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
-      const f32x16 acc = score_tile<DP8, GLDS>(smem + cur * TILE_FLOATS, xr, jt, r, h);
+      const f32x16 acc = score_tile<DP8, GLDS>(ys, xr, jt, r, h);
       float v2[16];
       float tmax = NEG_BIG;
 #pragma unroll
@@ -119,6 +118,10 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_kern
     }
     if (t + 1 < t1) stg.land(nxt);
     __syncthreads();
+  };
+  for (int64_t t = t0; t < t1; t += 2) {
+    step(t, buf0, buf1);
+    if (t + 1 < t1) step(t + 1, buf1, buf0);
   }
   // merge the two lane halves (same row a, disjoint b subsets)
   const float mo = __shfl_xor(m, 32, 64), so = __shfl_xor(s, 32, 64), dgo = __shfl_xor(dg, 32, 64);
@@ -686,22 +689,10 @@ static bool plan_ce(int64_t RX, int64_t RY, int64_t D, CePlan& pl) {
 }
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <typename K>
-static int opt_in_lds(K kernel, size_t lds, const char* name) {
-  if (lds <= 64 * 1024) return 0;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e)); return (int)e; }
-  return 0;
-}
-
 template <int DP8, bool GLDS>
 static int launch_fwd(const CeArgs& a, dim3 grid, hipStream_t st) {
-  const size_t lds = 2 * BJ * TileMap<DP8, GLDS>::LD * sizeof(float);
-  int rc = opt_in_lds(ce_fwd_kernel<DP8, GLDS>, lds, "ce_fwd_kernel");
-  if (rc) return rc;
   ProfScope prof("ce_fwd_kernel", st);
-  ce_fwd_kernel<DP8, GLDS><<<grid, 256, lds, st>>>(a);
+  ce_fwd_kernel<DP8, GLDS><<<grid, 256, 0, st>>>(a);  // LDS is static: two named tile buffers
   return check_launch("ce_fwd_kernel");
 }
 template <int DP8, bool SS, bool GLDS>
