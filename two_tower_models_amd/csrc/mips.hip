@@ -34,6 +34,7 @@
 namespace tt {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 
 constexpr int QB_WG = 128;   // queries per workgroup (32 per wave)
@@ -409,12 +410,36 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
         const int row = jt * 32 + r;
+        if constexpr (NAMED) {
 #pragma unroll
-        for (int g = 0; g < DPX; ++g) {
-          const uint4 y = *reinterpret_cast<const uint4*>(ys + TM::chunk(row, 2 * g + h));
+          for (int g = 0; g < DPX; ++g) {
+            const uint4 y = *reinterpret_cast<const uint4*>(ys + TM::chunk(row, 2 * g + h));
 #pragma unroll
-          for (int n = 0; n < NQ; ++n)
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, y), __builtin_bit_cast(bf16x8, qf[n].v[g]), acc[n], 0, 0, 0);
+            for (int n = 0; n < NQ; ++n)
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, y), __builtin_bit_cast(bf16x8, qf[n].v[g]), acc[n], 0, 0, 0);
+          }
+        } else {
+          // Dynamic ring (its stages cannot be told apart by the compiler): the A-operand reads are issued
+          // as ds_read_b128 from inline assembly, with our own lgkmcnt waits.  A compiler-visible LDS read
+          // here gets `s_waitcnt vmcnt(0)` in front of it -- a wait for the tile DMA'd a moment ago, one
+          // full memory latency per 0.4 us tile.  What must have landed (tile t) is guaranteed by the
+          // wait_vmcnt + barrier that ended the previous step.  Reads run one k-group ahead of the MFMAs.
+          const uint32_t lrow = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)ys + (uint32_t)row * (TM::LD * 4);
+          const int sw = row & TM::SW;
+          u32x4 yy[2];
+          auto rd = [&](u32x4& dst, int g) {
+            const uint32_t a = lrow + 16u * (uint32_t)((2 * g + h) ^ sw);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(a) : "memory");
+          };
+          rd(yy[0], 0);
+#pragma unroll
+          for (int g = 0; g < DPX; ++g) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yy[g & 1]) : : "memory");
+            if (g + 1 < DPX) rd(yy[(g + 1) & 1], g + 1);
+#pragma unroll
+            for (int n = 0; n < NQ; ++n)
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, yy[g & 1]), __builtin_bit_cast(bf16x8, qf[n].v[g]), acc[n], 0, 0, 0);
+          }
         }
       }
       const int off0 = 16 * (2 * (int)(t & 1) + jt);  // group-relative row of element 0
