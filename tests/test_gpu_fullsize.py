@@ -52,6 +52,45 @@ def test_inbatch_ce_b8192_d128(T):
     assert torch.allclose(ce8.cpu()[rows].double(), want, atol=2e-5)
 
 
+def test_inbatch_ce_8_rank_shape_kept_logits(T):
+    """One rank's logits at 8 GPUs (8192 users x 65 536 items, positives at 3*B): the kept-logits pair
+    (tt_inbatch_ce_fwd_du_keep / tt_inbatch_ce_bwd_kept, the default of ops.InBatchSoftmaxCE for N >= 4 M)
+    against the recomputing pair, and both against size-independent properties / sampled fp64 rows."""
+    ops, N = T
+    B, D, W = 8192, 128, 8
+    g = torch.Generator(device="cpu").manual_seed(5)
+    U = torch.randn(B, D, generator=g) * 0.3
+    I_all = torch.randn(W * B, D, generator=g) * 0.3
+    coef = torch.rand(B, generator=g) / (W * B)
+    res = []
+    for keep in (True, False):
+        Ud, Id = U.to(DEV).requires_grad_(True), I_all.to(DEV).requires_grad_(True)
+        ce = ops.InBatchSoftmaxCE.apply(Ud, Id, 3 * B, keep)
+        (ce * coef.to(DEV)).sum().backward()
+        res.append((ce.detach(), Ud.grad, Id.grad))
+    # same forward statistics and user gradient bit for bit; the item gradient comes from the same
+    # arithmetic on stored instead of recomputed logits
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.allclose(res[0][2], res[1][2], atol=1e-7 * float(res[1][2].abs().max()), rtol=1e-5)
+    ce, dU, dI = res[0]
+    assert float(dI.sum(0).abs().max()) < 1e-6  # softmax rows sum to one
+    rows = torch.arange(0, B, 257)
+    S = U[rows].double() @ I_all.double().t()
+    lse = torch.logsumexp(S, 1)
+    assert torch.allclose(ce.cpu()[rows].double(), lse - S[torch.arange(len(rows)), rows + 3 * B], atol=2e-5)
+    # sampled item rows: dI[j] = sum_i coef_i (p_ij - [j == i + 3B]) U_i needs every user -> fp64 on the GPU
+    items = torch.tensor([0, 12345, 3 * B, 3 * B + 4097, 4 * B - 1, W * B - 1])
+    Sd = U.to(DEV).double() @ I_all[items].to(DEV).double().t()              # [B, 6]
+    lse_all = torch.logsumexp(U.to(DEV).double() @ I_all.to(DEV).double().t(), 1)  # [B]
+    G = torch.exp(Sd - lse_all[:, None])
+    for k, j in enumerate(items.tolist()):
+        if 3 * B <= j < 4 * B:
+            G[j - 3 * B, k] -= 1.0
+    ref = (G * coef.to(DEV).double()[:, None]).t() @ U.to(DEV).double()
+    got = dI[items.to(DEV)].double()
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-12
+
+
 def test_row_plan_420k_ids_over_10m_rows(T):
     ops, N = T
     n, n_rows = 8192 * 51, 10_000_000
