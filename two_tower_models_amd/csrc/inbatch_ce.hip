@@ -214,6 +214,9 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_bwd_kern
     const int64_t wrel = (STREAM_STATS ? a - p.diag_offset : a + p.diag_offset) - t * BJ, lrel = p.RY - t * BJ;
     const int want4 = (wrel >= 0 && wrel < BJ) ? (int)wrel - 4 * h : -1000;
     const int lim4 = (lrel < BJ ? (int)lrel : BJ) - 4 * h;
+    // VALU instructions are paid in MFMA issue time (they do not co-execute): the diagonal test is
+    // kept out of the tiles that do not hold this wave's diagonal (scalar ballot -> uniform branch)
+    const bool no_diag = STREAM_STATS && __builtin_amdgcn_ballot_w64(want4 != -1000) == 0ull;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
       const f32x16 acc = score_tile<DP8, GLDS>(ys, xr, jt, r, h);
@@ -225,6 +228,18 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_bwd_kern
           const float pr = fast_exp2(mul_rounded(acc[e], LOG2E) - lse2_a);  // same rounded s2 as the forward
           const float gval = coef_a * (pr - ((li == want4) ? 1.f : 0.f));
           gt[e] = (li < lim4) ? gval : 0.f;
+        }
+      } else if (no_diag) {  // no diagonal in this tile for any lane of the wave: 4 instead of 7 VALU ops per element
+        const float* sl = ys + BJ * TM::LD + jt * 32 + 4 * h;
+        const float* sc = sl + BJ;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 l4 = *reinterpret_cast<const float4*>(sl + 8 * q);
+          const float4 c4 = *reinterpret_cast<const float4*>(sc + 8 * q);
+          gt[4 * q + 0] = c4.x * fast_exp2(mul_rounded(acc[4 * q + 0], LOG2E) - l4.x);
+          gt[4 * q + 1] = c4.y * fast_exp2(mul_rounded(acc[4 * q + 1], LOG2E) - l4.y);
+          gt[4 * q + 2] = c4.z * fast_exp2(mul_rounded(acc[4 * q + 2], LOG2E) - l4.z);
+          gt[4 * q + 3] = c4.w * fast_exp2(mul_rounded(acc[4 * q + 3], LOG2E) - l4.w);
         }
       } else {
         const float* sl = ys + BJ * TM::LD + jt * 32 + 4 * h;
@@ -370,22 +385,38 @@ __global__ __launch_bounds__(256, 2) void ce_bwd_kept_kernel(const CeArgs p) {
     if (t + 1 < t1) { issue(t + 1, nxt); zload(t + 1); }
     const int64_t wrel = a - p.diag_offset - t * BJ;
     const int want4 = (wrel >= 0 && wrel < BJ) ? (int)wrel - 4 * h : -1000;
+    // MFMA and VALU instructions do not co-execute on a SIMD (SQ_VALU_MFMA_COEXEC_CYCLES = 0): every
+    // VALU instruction here is paid in MFMA issue time.  Only the one or two tiles that hold this
+    // wave's diagonal need the per-element test (wave-uniform branch).
+    const bool no_diag = __builtin_amdgcn_ballot_w64(want4 != -1000) == 0ull;  // scalar: a uniform branch
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
       float gt[16];
       const float* sl = ys + BJ * TM::LD + jt * 32 + 4 * h;
       const float* sc = sl + BJ;
+      if (no_diag) {  // three VALU instructions per element instead of six
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 l4 = *reinterpret_cast<const float4*>(sl + 8 * q);
-        const float4 c4 = *reinterpret_cast<const float4*>(sc + 8 * q);
-        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, cv[4] = {c4.x, c4.y, c4.z, c4.w};
+        for (int q = 0; q < 4; ++q) {
+          const float4 l4 = *reinterpret_cast<const float4*>(sl + 8 * q);
+          const float4 c4 = *reinterpret_cast<const float4*>(sc + 8 * q);
+          gt[4 * q + 0] = c4.x * fast_exp2(zc[jt * 16 + 4 * q + 0] - l4.x);
+          gt[4 * q + 1] = c4.y * fast_exp2(zc[jt * 16 + 4 * q + 1] - l4.y);
+          gt[4 * q + 2] = c4.z * fast_exp2(zc[jt * 16 + 4 * q + 2] - l4.z);
+          gt[4 * q + 3] = c4.w * fast_exp2(zc[jt * 16 + 4 * q + 3] - l4.w);
+        }
+      } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int e = 4 * q + c;
-          const int li = jt * 32 + (e & 3) + 8 * (e >> 2);
-          const float pr = fast_exp2(zc[jt * 16 + e] - lv[c]);
-          gt[e] = cv[c] * (pr - ((li == want4) ? 1.f : 0.f));  // coef 0 beyond RY
+        for (int q = 0; q < 4; ++q) {
+          const float4 l4 = *reinterpret_cast<const float4*>(sl + 8 * q);
+          const float4 c4 = *reinterpret_cast<const float4*>(sc + 8 * q);
+          const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, cv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int e = 4 * q + c;
+            const int li = jt * 32 + (e & 3) + 8 * (e >> 2);
+            const float pr = fast_exp2(zc[jt * 16 + e] - lv[c]);
+            gt[e] = cv[c] * (pr - ((li == want4) ? 1.f : 0.f));  // coef 0 beyond RY
+          }
         }
       }
       float yv[2][TD];
@@ -487,6 +518,13 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_du_k
     const int64_t wrel = want - t * BJ, lrel = p.RY - t * BJ;
     const int want4 = (wrel >= 0 && wrel < BJ) ? (int)wrel - 4 * h : -1000;
     const int lim4 = (lrel < BJ ? (int)lrel : BJ) - 4 * h;
+    // MFMA and VALU instructions do not co-execute on a SIMD (SQ_VALU_MFMA_COEXEC_CYCLES = 0 for every
+    // kernel of this file): each VALU instruction costs its 4+ cycles of MFMA issue.  The diagonal
+    // test and the end-of-range mask are therefore taken out of the per-element code of the tiles
+    // that need neither (wave-uniform branch): all but the last tile, and all but the one or two
+    // tiles that hold this wave's diagonal.
+    // (not in the KEEP form: there the second code path costs more in spilled registers than it saves)
+    const bool plain = !KEEP && lrel >= BJ && __builtin_amdgcn_ballot_w64(want4 != -1000) == 0ull;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
       // v2 lives in the score tile's own registers from here on (masked logits, then probabilities):
@@ -494,13 +532,21 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_du_k
       // vmcnt -- the counter the next tile's LDS-DMA completes on
       f32x16 v2 = score_tile<DP8, GLDS>(ys, xr, jt, r, h);
       float tmax = NEG_BIG;
+      if (plain) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int li = jt * 32 + (e & 3) + 8 * (e >> 2);
-        const float s2 = v2[e] * LOG2E;
-        if (li == want4) p.diag[a] = s2;  // executes for exactly one (lane, e) per user row
-        v2[e] = (li < lim4) ? s2 : NEG_BIG;
-        tmax = fmaxf(tmax, v2[e]);
+        for (int e = 0; e < 16; ++e) {
+          v2[e] = v2[e] * LOG2E;
+          tmax = fmaxf(tmax, v2[e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int li = jt * 32 + (e & 3) + 8 * (e >> 2);
+          const float s2 = v2[e] * LOG2E;
+          if (li == want4) p.diag[a] = s2;  // executes for exactly one (lane, e) per user row
+          v2[e] = (li < lim4) ? s2 : NEG_BIG;
+          tmax = fmaxf(tmax, v2[e]);
+        }
       }
       if constexpr (KEEP) {  // rows past RX / columns past RY of the padded buffer get 0-logit / NEG_BIG filler
         float* z = p.keep + a * p.ldk + (t * BJ + jt * 32 + 4 * h);
