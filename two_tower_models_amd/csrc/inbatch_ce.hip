@@ -506,6 +506,7 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_du_k
 
   float m = NEG_BIG, s = 0.f;
   const int64_t want = (a < p.RX) ? a + p.diag_offset : -1;  // rows past the end own no diagonal
+  const int zlane = KEEP ? ((wave * 32 + r) * (int)p.ldk + 4 * h) * 4 : 0;  // byte offset of this lane's logits row
 
   Stager<DP8, GLDS> stg;
   if (t0 < t1) {
@@ -549,10 +550,16 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_du_k
         }
       }
       if constexpr (KEEP) {  // rows past RX / columns past RY of the padded buffer get 0-logit / NEG_BIG filler
-        float* z = p.keep + a * p.ldk + (t * BJ + jt * 32 + 4 * h);
+        // buffer stores: tile base in a scalar descriptor, one loop-invariant 32-bit lane offset
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t zs = __builtin_amdgcn_make_buffer_rsrc(
+            p.keep + (int64_t)blockIdx.x * BI * p.ldk + t * BJ, 0, -1, 0x00020000);
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(z + 8 * g) = make_float4(v2[4 * g], v2[4 * g + 1], v2[4 * g + 2], v2[4 * g + 3]);
+        for (int g = 0; g < 4; ++g) {
+          f32x4 o = {v2[4 * g], v2[4 * g + 1], v2[4 * g + 2], v2[4 * g + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), zs, zlane,
+                                                 (jt * 32 + 8 * g) * 4, 0);
+        }
       }
       float mn = fmaxf(m, tmax);
       mn = fmaxf(mn, __shfl_xor(mn, 32, 64));  // one reference per USER: both lane halves feed the same MFMA
