@@ -130,7 +130,7 @@ __device__ __forceinline__ void store_rows(float* __restrict__ dst, int64_t ld, 
 
 // ------------------------------------------------------------------ forward
 template <int DH, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, int64_t n_pairs,
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, int64_t n_pairs,
                                                                    int H, int D, int heads,
                                                                    float* __restrict__ ctx, float* __restrict__ lse) {
   using L = AttnLds<DH>;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_fwd_mfma_kernel(const float* 
 
 // ------------------------------------------------------------------ backward
 template <int DH, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void attn_bwd_mfma_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void attn_bwd_mfma_kernel(const float* __restrict__ qkv,
                                                                    const float* __restrict__ lse,
                                                                    const float* __restrict__ d_ctx, int64_t n_pairs,
                                                                    int H, int D, int heads,
