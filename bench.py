@@ -44,6 +44,8 @@ WORKLOADS = {
     # MI355X's 288 GB, which is what `--workload C4 --gpus 1` runs)
     "C4": dict(n_users=1_000_000, n_items=100_000_000, D=128, F=8, B=8192, H=4, model="base"),
     # logits-bound shape (what every rank sees once the tables are sharded thin): small tables, full batch
+    # BASELINE config 5's model in TRAINING (its loss head is SURVEY 8f item 2): C3 plus the debias head
+    "C5T": dict(n_users=1_000_000, n_items=1_000_000, D=128, F=8, B=4096, H=50, model="debias"),
     "CE": dict(n_users=100_000, n_items=100_000, D=128, F=8, B=8192, H=4, model="base"),
     "tiny": dict(n_users=1024, n_items=10_000, D=32, F=8, B=128, H=4, model="base"),
 }
@@ -79,6 +81,8 @@ def build_model(cfg, device):
                   user_value_weights=[1.0], mips_module=mips)
         if cfg["model"] == "hist":
             model = A.TwoTowerWithUserHistoryEncoder(user_history_seqlen=cfg["H"], **kw)
+        elif cfg["model"] == "debias":
+            model = A.TwoTowerWithDebiasing(user_history_seqlen=cfg["H"], **kw)
         else:
             model = A.TwoTowerBaseRetrieval(**kw)
     return model.to(device)
@@ -212,7 +216,7 @@ def main():
             b = list(batch)
             b[0] = torch.randint(0, cfg["n_users"], tuple(b[0].shape), device=device, generator=id_gen)
             b[3] = torch.randint(0, cfg["n_items"], tuple(b[3].shape), device=device, generator=id_gen)
-            if cfg["model"] == "hist":
+            if cfg["model"] in ("hist", "debias"):
                 b[2] = torch.randint(0, cfg["n_items"], tuple(b[2].shape), device=device, generator=id_gen)
             return b
 
@@ -333,7 +337,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: TwoTowerBaseRetrieval train step, N_u={cfg['n_users']}, "
                                    f"N_i={cfg['n_items']}, D={cfg['D']}, F={cfg['F']}, B={B}/GPU"
-                                   + (f", H={cfg['H']} history encoder" if cfg['model'] == 'hist' else ""),
+                                   + (f", H={cfg['H']} history encoder" if cfg['model'] in ('hist', 'debias') else "")
+                                   + (", debias loss head" if cfg['model'] == 'debias' else ""),
                        "global_batch": B * world,
                        "parallelism": ("single GPU" + (", whole-step hipGraph" if args.graph else "")) if not use_sharded else
                        f"row-sharded tables x{world}, {args.negatives} in-batch negatives, "

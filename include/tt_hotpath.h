@@ -151,6 +151,26 @@ int tt_weighted_mean_loss(const float* labels, int64_t B, int64_t T, const float
                           const float* row_ce, float* w_out, float* coef_out, float* loss_out,
                           tt_stream_t stream);
 
+/* Combined debias loss head (ref:src/two_tower_with_debiasing.py:77-129 on top of
+ * ref:src/two_tower_base_retrieval.py:322-345), fused -- SURVEY 8f item 2:
+ *   n = labels.uvw;  p = pos_table[position];  e = <user_emb, lin_w[:DI]> + p*lin_w[DI] + lin_b
+ *   aux = sum_i (e_i-n_i)^2 + sum_i sum_j (p_i-n_j)^2   (upstream's [B,1]-vs-[B] broadcast, in closed form)
+ *   r = max(n / max(e, 1e-3), 1e-6);  loss = mean_i(row_ce_i * r_i / max_j r_j) + aux
+ * The forward leaves n, p, e, r and the reduction scalars in `ws` (tt_debias_loss_workspace_bytes(B, DI, n_pos)),
+ * which the backward reads; `grad_loss` is the device scalar dL/dloss.  Gradients as torch defines
+ * them: clamp(min) passes where input >= min, max() splits evenly over ties.  Positions outside
+ * [0, n_pos) raise *oob_flag (torch: IndexError) and read row 0.  d_user_emb is written, not added. */
+int64_t tt_debias_loss_workspace_bytes(int64_t B, int64_t DI, int64_t n_pos);
+int tt_debias_loss_fwd(const float* row_ce, const float* labels, int64_t B, int64_t T, const float* uvw,
+                       const int64_t* position, int64_t n_pos, const float* pos_table, const float* user_emb,
+                       int64_t ld_ue, int64_t DI, const float* lin_w /*[DI+1]*/, const float* lin_b /*[1]*/,
+                       float* loss_out, void* ws, int64_t ws_bytes, int32_t* oob_flag, tt_stream_t stream);
+int tt_debias_loss_bwd(const float* grad_loss, const float* row_ce, int64_t B, const int64_t* position,
+                       int64_t n_pos, const float* user_emb, int64_t ld_ue, int64_t DI, const float* lin_w,
+                       const void* ws, int64_t ws_bytes, float* d_row_ce, float* d_user_emb, int64_t ld_due,
+                       float* d_pos_table /*[n_pos]*/, float* d_lin_w /*[DI+1]*/, float* d_lin_b /*[1]*/,
+                       tt_stream_t stream);
+
 /* ---------------------------------------------------------------- K2 row-gradient plan + dense-exact Adam
  * The embedding backward of the reference is a dense [n_rows,dim] gradient
  * (autograd embedding_dense_backward) consumed by optim.Adam over EVERY row

@@ -249,6 +249,63 @@ def test_inbatch_ce_op_keep_logits_matches_default(T):
     assert torch.isfinite(I.grad).all()
 
 
+@pytest.mark.parametrize("B,Tn,DI,case", [(64, 1, 128, "plain"), (1000, 3, 40, "plain"), (8192, 1, 128, "plain"),
+                                          (300, 1, 64, "all_zero_labels"), (257, 2, 32, "clamped_priors"), (1, 1, 8, "plain")])
+def test_debias_loss_head_matches_torch_expressions(T, B, Tn, DI, case):
+    """ops.DebiasedWeightedLoss (tt_debias_loss_fwd / _bwd) against the reference's tensor expressions
+    (ref:src/two_tower_with_debiasing.py:77-129 + ref:src/two_tower_base_retrieval.py:322-345) evaluated
+    in float64 on the CPU: loss and every gradient, including ties at the batch maximum (0/1 labels make
+    many equal weights impossible only after the division -- the all-zero case ties EVERY row), priors
+    below the 1e-3 clamp, and the [B,1]-vs-[B] broadcast of the position term."""
+    import warnings
+    ops, N = T
+    row_ce = (g((B,), 101).abs() * 3 + 0.1)
+    labels = (fg.hashed_u64((B, Tn), 102) % np.uint64(2)).astype(np.float32)
+    if case == "all_zero_labels":
+        labels[:] = 0.0
+    labels = torch.from_numpy(labels)
+    uvw = torch.tensor([1.0, 0.5, 2.0][:Tn])
+    position = torch.from_numpy((fg.hashed_u64((B,), 103) % np.uint64(100)).astype(np.int64))
+    ue = g((B, DI), 104) * 0.5
+    pos_table = g((100, 1), 105) * 0.3 + (0.0 if case == "clamped_priors" else 0.8)
+    lin_w = g((1, DI + 1), 106) * (0.02 if case != "clamped_priors" else 0.2)
+    lin_b = torch.tensor([0.7 if case != "clamped_priors" else -0.2])
+
+    def reference(row_ce, ue, pos_table, lin_w, lin_b):
+        nuv = torch.sum(labels.double() * uvw.double(), dim=-1)
+        p = pos_table[position]                                            # [B, 1]
+        e = (torch.cat([ue, p], dim=-1) @ lin_w.t() + lin_b).squeeze(1)    # [B]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            aux = torch.nn.functional.mse_loss(e, nuv, reduction="sum") + torch.nn.functional.mse_loss(p, nuv, reduction="sum")
+        w = nuv / torch.clamp(e, min=1e-3)
+        w = torch.clamp(w, min=0.000001)
+        w = w / torch.max(w)
+        return torch.mean(row_ce * w) + aux
+
+    leaves64 = [t.double().requires_grad_(True) for t in (row_ce, ue, pos_table, lin_w, lin_b)]
+    want = reference(*leaves64)
+    want.backward()
+    leaves = [t.to(DEV).requires_grad_(True) for t in (row_ce, ue, pos_table, lin_w, lin_b)]
+    got = ops.DebiasedWeightedLoss.apply(leaves[0], labels.to(DEV), uvw.to(DEV), position.to(DEV), *leaves[1:])
+    assert abs(got.item() - want.item()) <= 2e-6 * max(1.0, abs(want.item()))
+    got.backward()
+    for name, a, b in zip(("row_ce", "user_emb", "pos_table", "lin_w", "lin_b"), leaves, leaves64):
+        scale = float(b.grad.abs().max())
+        assert torch.allclose(a.grad.cpu().double(), b.grad, atol=2e-5 * scale + 1e-12, rtol=2e-4), (name, case)
+    # bit-reproducible: fixed-order reductions
+    leaves2 = [t.to(DEV).requires_grad_(True) for t in (row_ce, ue, pos_table, lin_w, lin_b)]
+    got2 = ops.DebiasedWeightedLoss.apply(leaves2[0], labels.to(DEV), uvw.to(DEV), position.to(DEV), *leaves2[1:])
+    got2.backward()
+    assert torch.equal(got2, got) and all(torch.equal(a.grad, b.grad) for a, b in zip(leaves, leaves2))
+    # an out-of-range position is reported like every other out-of-range id
+    bad = position.clone()
+    bad[0] = 100
+    ops.DebiasedWeightedLoss.apply(leaves[0].detach(), labels.to(DEV), uvw.to(DEV), bad.to(DEV), *[t.detach() for t in leaves[1:]])
+    with pytest.raises(IndexError):
+        N.oob.poll(torch.device(DEV), blocking=True)
+
+
 @pytest.mark.parametrize("B,H,D,heads", [(9, 50, 128, 4), (5, 64, 64, 4), (3, 1, 32, 2), (70, 7, 48, 3)])
 def test_single_query_attention_matches_full_attention_row0(T, B, H, D, heads):
     """tt_attn_row0_fwd / _bwd (the encoder's last layer: only history position 0 is consumed) against

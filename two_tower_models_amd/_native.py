@@ -63,6 +63,11 @@ SIGNATURES = {
                                          _vp, _i64, _vp]),
     "tt_inbatch_ce_bwd_kept": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "tt_weighted_mean_loss": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tt_debias_loss_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "tt_debias_loss_fwd": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64,
+                                  _vp, _vp]),
+    "tt_debias_loss_bwd": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp,
+                                  _vp, _vp]),
     "tt_rowgrad_workspace_bytes": (_i64, [_i64]),
     "tt_rowgrad_plan": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tt_rowgrad_dense": (_int, [C.POINTER(GradSources), _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -471,6 +471,52 @@ class WeightedMeanLoss(torch.autograd.Function):
         return coef * g, None, None
 
 
+class DebiasedWeightedLoss(torch.autograd.Function):
+    """mean_i(row_ce_i * w_i) + aux of the combined debias head (ref:src/two_tower_with_debiasing.py:77-129
+    on ref:src/two_tower_base_retrieval.py:322-345), in two kernels forward and two backward
+    (tt_debias_loss_fwd / _bwd).  labels [B, T], position [B] int64, user_embedding [B, DI],
+    pos_table [n_pos, 1], lin_w [1, DI + 1], lin_b [1]."""
+
+    @staticmethod
+    def forward(ctx, row_ce, labels, uvw, position, user_embedding, pos_table, lin_w, lin_b):
+        dev = N.require_device(row_ce, labels, uvw, position, user_embedding, pos_table, lin_w, lin_b)
+        lib = N.load()
+        labels, position = labels.contiguous(), position.contiguous()
+        row_ce, ue = row_ce.contiguous(), _rowmajor(user_embedding)
+        pos_table, lin_w, lin_b = pos_table.contiguous(), lin_w.contiguous(), lin_b.contiguous()
+        B, T = labels.shape
+        pue, _, DI, ld_ue = _f32_2d(ue, "user_embedding")
+        if position.dtype != torch.int64 or pos_table.shape[1] != 1 or lin_w.numel() != DI + 1 or uvw.numel() != T:
+            raise TypeError("DebiasedWeightedLoss: position int64 [B], pos_table [n_pos, 1], lin_w [1, DI + 1], uvw [T]")
+        wsn = lib.tt_debias_loss_workspace_bytes(B, DI, pos_table.shape[0])
+        ws = torch.empty(wsn, dtype=torch.uint8, device=dev)  # kept for the backward (n, p, e, r, scalars)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        N.check(lib.tt_debias_loss_fwd(row_ce.data_ptr(), labels.data_ptr(), B, T, uvw.data_ptr(), position.data_ptr(),
+                                       pos_table.shape[0], pos_table.data_ptr(), pue, ld_ue, DI, lin_w.data_ptr(),
+                                       lin_b.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsn, N.oob.flag(dev).data_ptr(),
+                                       N.stream()), "tt_debias_loss_fwd")
+        ctx.save_for_backward(row_ce, position, ue, pos_table, lin_w, lin_b, ws)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        row_ce, position, ue, pos_table, lin_w, lin_b, ws = ctx.saved_tensors
+        dev = row_ce.device
+        lib = N.load()
+        B = row_ce.shape[0]
+        pue, _, DI, ld_ue = _f32_2d(ue, "user_embedding")
+        g = g.contiguous().to(torch.float32)
+        d_ce = torch.empty(B, dtype=torch.float32, device=dev)
+        d_ue = torch.empty(B, DI, dtype=torch.float32, device=dev)
+        d_pos = torch.empty_like(pos_table)
+        d_w, d_b = torch.empty_like(lin_w), torch.empty_like(lin_b)
+        N.check(lib.tt_debias_loss_bwd(g.data_ptr(), row_ce.data_ptr(), B, position.data_ptr(), pos_table.shape[0], pue,
+                                       ld_ue, DI, lin_w.data_ptr(), ws.data_ptr(), ws.numel(), d_ce.data_ptr(),
+                                       d_ue.data_ptr(), DI, d_pos.data_ptr(), d_w.data_ptr(), d_b.data_ptr(), N.stream()),
+                "tt_debias_loss_bwd")
+        return d_ce, None, None, None, d_ue, d_pos, d_w, d_b
+
+
 # ----------------------------------------------------------------- history encoder
 def _attn_fwd(qkv, B, H, D, heads):
     ctx_t = torch.empty(B * H, D, dtype=torch.float32, device=qkv.device)

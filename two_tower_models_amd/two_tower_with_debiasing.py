@@ -1,20 +1,26 @@
 """TwoTowerWithDebiasing on MI355X (mirror of ref:src/two_tower_with_debiasing.py:17-129).
 
 ``forward`` (inference -> MIPS top-K, BASELINE config 5) is inherited unchanged and
-runs entirely on the HIP path.  The debias head itself is O(B) work on [B]-sized
-tensors; it is expressed with the reference's own tensor expressions so that its
-gradient semantics (through the clamp, the division and ``torch.max``) and the
-upstream [B,1]-vs-[B] ``mse_loss`` broadcast are reproduced literally, on top of the
-fused in-batch-softmax kernel (SURVEY.md 8f item 2 lists fusing it as "next")."""
+runs entirely on the HIP path.  The training loss head is fused as well
+(``ops.DebiasedWeightedLoss`` / ``tt_debias_loss_fwd``: position prior, user prior, both
+sum-MSE terms with the upstream [B,1]-vs-[B] broadcast in closed form, the division by
+the clamped prior, clamp and division by the batch maximum, weighted mean -- SURVEY.md 8f
+item 2); ``debias_net_user_value`` keeps the reference's own tensor expressions for callers
+of the hook and as the A/B partner of the fused head (TT_DEBIAS_NO_FUSED)."""
 from __future__ import annotations
 
 from typing import List, Tuple
+
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .two_tower_with_user_history_encoder import TwoTowerWithUserHistoryEncoder
+
+_FUSED_HEAD = os.environ.get("TT_DEBIAS_NO_FUSED") is None  # A/B switch
 
 
 class TwoTowerWithDebiasing(TwoTowerWithUserHistoryEncoder):
@@ -39,3 +45,17 @@ class TwoTowerWithDebiasing(TwoTowerWithUserHistoryEncoder):
         aux = F.mse_loss(user_prior, net_user_value, reduction="sum") \
             + F.mse_loss(pos_prior, net_user_value, reduction="sum")
         return net_user_value / torch.clamp(user_prior, min=1e-3), aux
+
+    def compute_training_loss(self, user_embedding: torch.Tensor, item_embeddings: torch.Tensor,
+                              position: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        """The base loss with this class's debias head, fused: one op instead of
+        ~15 elementwise launches and a [B, B] temporary.  A subclass that overrides the hook, or labels
+        of another rank, take the reference's expressions (the base class's general path)."""
+        hook_is_mine = type(self).debias_net_user_value is TwoTowerWithDebiasing.debias_net_user_value
+        if not (_FUSED_HEAD and hook_is_mine and labels.dim() == 2 and labels.shape[1] == self.user_value_weights.numel()
+                and user_embedding.is_cuda):
+            return super().compute_training_loss(user_embedding, item_embeddings, position, labels)
+        row_ce = ops.InBatchSoftmaxCE.apply(user_embedding, item_embeddings, 0)  # [B]
+        lin = self.user_debias_net_user_value[0]
+        return ops.DebiasedWeightedLoss.apply(row_ce, labels, self.user_value_weights, position, user_embedding,
+                                              self.position_bias_net_user_value.weight, lin.weight, lin.bias)
