@@ -133,7 +133,7 @@ int tt_inbatch_ce_fwd_du(const float* U, int64_t ldu, const float* I, int64_t ld
  * (tt_inbatch_ce_logits_bytes(M, N) bytes: [round_up(M,128)][round_up(N,128)] fp32); the item-side
  * backward rebuilds the gradient tile from them instead of from a second U I^T product -- 3 instead
  * of 4 logit-sized products per training step, for one write and one read of the buffer.  Needs
- * D in {32, 64, 128} and 16-B aligned rows (TT_E_UNSUPPORTED otherwise: use the pair above).
+ * D in {32, 64, 128}, 16-B aligned rows and N < 4 Mi (TT_E_UNSUPPORTED otherwise: use the pair above).
  * Same workspace query as the others; dU comes from du_unit as above. */
 int64_t tt_inbatch_ce_logits_bytes(int64_t M, int64_t N);
 int tt_inbatch_ce_fwd_du_keep(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N,

@@ -237,7 +237,7 @@ static int ws_launch_one(int layout, int64_t M, int64_t N, int64_t K, const floa
   a.w_vec = (ldw % 4 == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
   a.c_vec = (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
             (!aux || ((ldaux % 4 == 0) && ((reinterpret_cast<uintptr_t>(aux) & 15) == 0)));
-  const bool dma = a.a_vec && K == dp8 * 8;
+  const bool dma = a.a_vec && K == dp8 * 8 && lda <= (1 << 22);  // tile_dma: 32-bit byte offsets within a tile
   // one resident wave of workgroups: 256 CUs x (2 at <=128 reduction columns, else 1) slots
   const int64_t tiles = ceil_div(M, BJ), colblocks = ceil_div(N, BI);
   const int64_t slots = 256 * ((dma && dp8 <= 16) ? 2 : 1);

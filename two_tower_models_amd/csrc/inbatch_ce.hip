@@ -757,7 +757,7 @@ static int launch_bwd(const CeArgs& a, dim3 grid, hipStream_t st) {
 // LDS-DMA staging needs an unpadded, fully valid row: D == padded D, 16-B aligned rows
 static bool can_dma(const float* Y, int64_t ld, int64_t D, int dp8) {
   static const bool off = getenv("TT_CE_NO_DMA") != nullptr;
-  return !off && D == dp8 * 8 && (ld % 4 == 0) && al16(Y);
+  return !off && D == dp8 * 8 && (ld % 4 == 0) && ld <= (1 << 22) && al16(Y);  // tile_dma: 32-bit byte offsets within a tile
 }
 static int dispatch_fwd(int dp8, bool dma, const CeArgs& a, dim3 grid, hipStream_t st) {
   if (dma) return dp8 == 4 ? launch_fwd<4, true>(a, grid, st) : dp8 == 8 ? launch_fwd<8, true>(a, grid, st) : launch_fwd<16, true>(a, grid, st);
@@ -829,6 +829,9 @@ extern "C" int tt_inbatch_ce_fwd(const float* U, int64_t ldu, const float* I, in
   return check_launch("ce_fwd_finish_kernel");
 }
 
+// the kept-logits kernels address a workgroup's 128 rows of the buffer with 32-bit byte offsets
+constexpr int KEPT_MAX_COLS = 4 * 1024 * 1024 - 128;
+
 extern "C" int64_t tt_inbatch_ce_logits_bytes(int64_t M, int64_t N) {
   if (M <= 0 || N <= 0) return 0;
   return round_up(M, 128) * round_up(N, 128) * 4;
@@ -878,6 +881,7 @@ static int fwd_du_impl(const float* U, int64_t ldu, const float* I, int64_t ldi,
       set_error("tt_inbatch_ce_fwd_du_keep: needs D in {32, 64, 128} with 16-B aligned rows (use tt_inbatch_ce_fwd_du)");
       return TT_E_UNSUPPORTED;
     }
+    if (round_up(N, 128) > KEPT_MAX_COLS) { set_error("tt_inbatch_ce_fwd_du_keep: N > %d (32-bit offsets inside)", KEPT_MAX_COLS); return TT_E_UNSUPPORTED; }
     if (logits_bytes < tt_inbatch_ce_logits_bytes(M, N)) { set_error("tt_inbatch_ce_fwd_du_keep: logits buffer"); return TT_E_WORKSPACE; }
     a.keep = logits; a.ldk = round_up(N, 128);
     rc = dispatch_fwd_du_keep(pl.dp8, a, grid, st);
@@ -947,6 +951,7 @@ extern "C" int tt_inbatch_ce_bwd_kept(const float* U, int64_t ldu, int64_t M, in
     set_error("tt_inbatch_ce_bwd_kept: needs D in {32, 64, 128} with 16-B aligned rows");
     return TT_E_UNSUPPORTED;
   }
+  if (round_up(N, 128) > KEPT_MAX_COLS) { set_error("tt_inbatch_ce_bwd_kept: N > %d (32-bit offsets inside)", KEPT_MAX_COLS); return TT_E_UNSUPPORTED; }
   if (logits_bytes < tt_inbatch_ce_logits_bytes(M, N)) { set_error("tt_inbatch_ce_bwd_kept: logits buffer"); return TT_E_WORKSPACE; }
   if (ws_bytes < tt_inbatch_ce_workspace_bytes(M, N, D)) { set_error("tt_inbatch_ce_bwd_kept: workspace"); return TT_E_WORKSPACE; }
   hipStream_t st = S(stream);

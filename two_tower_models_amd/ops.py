@@ -371,7 +371,7 @@ _ROW0_LAST = os.environ.get("TT_ENC_FULL_LAST_LAYER") is None
 def kept_logits_supported(U: torch.Tensor, I: torch.Tensor) -> bool:
     """tt_inbatch_ce_fwd_du_keep / tt_inbatch_ce_bwd_kept: D in {32, 64, 128}, 16-B aligned rows."""
     D = U.shape[1]
-    return (D in (32, 64, 128) and U.stride(0) % 4 == 0 and I.stride(0) % 4 == 0
+    return (D in (32, 64, 128) and I.shape[0] < 4 * 1024 * 1024 - 256 and U.stride(0) % 4 == 0 and I.stride(0) % 4 == 0
             and U.data_ptr() % 16 == 0 and I.data_ptr() % 16 == 0 and os.environ.get("TT_CE_NO_DMA") is None)
 
 
