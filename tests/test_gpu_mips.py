@@ -61,7 +61,8 @@ def test_random_corpus_vs_reference(A, golden, K, bf16):
 
 
 @pytest.mark.parametrize("B,C,D,K", [(32, 100, 50, 10), (32, 1001, 40, 10), (3, 129, 8, 129), (200, 5000, 64, 37),
-                                     (1, 64, 128, 1), (130, 300, 2, 300)])
+                                     (1, 64, 128, 1), (130, 300, 2, 300), (50, 3000, 64, 20), (64, 5000, 128, 64),
+                                     (33, 700, 32, 5)])
 def test_ragged_shapes_match_oracle_order(A, B, C, D, K):
     """Includes the reference unit-test shapes (ref:tests/test_baseline_mips_module.py:16-36,
     ref:tests/test_two_tower_base_retrieval.py:51-71).  Integer-valued data: exact scores,

@@ -337,8 +337,12 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // corpus instead -- wave w scores sub-tile w of every 128-row chunk and the four partial
 // (best, runner-up, row) triples of a group are merged through LDS at the end of the chunk.
 // Without it three of the four waves multiply zero queries (B = 16 at C = 10 M: 3.0 -> 0.9 ms).
-template <int DT, int DPX, int NQ, int STAGES, bool SHARE>
+// SF = 2 (33..64 queries): two pairs of waves, each pair holds 32 queries and its two waves take
+// sub-tile 0 / sub-tile 1 of every 64-row tile (alternating 16-row blocks of each group).
+template <int DT, int DPX, int NQ, int STAGES, int SF>
 __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p) {
+  constexpr bool SHARE = SF != 0;
+  static_assert(SF == 0 || SF == 2 || SF == 4, "shared-query form: waves per query block");
   using O = Op<DT, DPX>;
   using TM = TileMap<DPX, true>;  // row bytes = 32 * DPX for both dtypes
   static_assert(DT == TT_BF16 || NQ == 1, "two query fragments only for bf16");
@@ -365,7 +369,9 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
   const int64_t w = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (w >= total) return;
   const int64_t bx = w % p.xblocks, by = w / p.xblocks;
-  const int64_t qbase = SHARE ? bx * 32 + r : bx * (QB_WG * NQ) + wave * (32 * NQ) + r;
+  const int member = SF == 2 ? (wave & 1) : wave;          // position among the waves that share its queries
+  const int64_t qbase = SF == 4 ? bx * 32 + r : SF == 2 ? bx * 64 + (wave >> 1) * 32 + r
+                                                        : bx * (QB_WG * NQ) + wave * (32 * NQ) + r;
 
   typename O::Frag qf[NQ];
 #pragma unroll
@@ -400,7 +406,8 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
     const bool full = (chunk + 1) * CHUNK <= p.C;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
-      if (SHARE && (2 * (int)(t & 1) + jt) != wave) continue;  // this sub-tile belongs to another wave
+      if (SF == 4 && (2 * (int)(t & 1) + jt) != wave) continue;  // this sub-tile belongs to another wave
+      if (SF == 2 && jt != member) continue;                     // the pair's other wave takes this sub-tile
       f32x16 acc[NQ];
       if constexpr (DT == TT_F32) {
         acc[0] = score_tile<DPX, true>(ys, qf[0].v, jt, r, h);
@@ -473,14 +480,15 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
       red[(wave * 64 + lane) * 3 + 1] = m2[0];
       red[(wave * 64 + lane) * 3 + 2] = __int_as_float(arg[0]);
       __syncthreads();
-      if (wave == 0) {
+      if (member == 0) {
         float M1 = NEG_INF, M2 = NEG_INF;
         int A = 0;
 #pragma unroll
-        for (int w2 = 0; w2 < 4; ++w2) {
+        for (int w2 = (SF == 2 ? wave : 0); w2 < (SF == 2 ? wave + 2 : 4); ++w2) {
           const float a1 = red[(w2 * 64 + lane) * 3], a2 = red[(w2 * 64 + lane) * 3 + 1];
           const int aa = __float_as_int(red[(w2 * 64 + lane) * 3 + 2]);
-          const bool gt = a1 > M1;
+          // SF = 2: the two waves' rows interleave in 16-row blocks, so equal scores are decided by the row
+          const bool gt = a1 > M1 || (SF == 2 && a1 == M1 && aa < A);
           M2 = fmaxf(fminf(M1, a1), fmaxf(M2, a2));  // second largest of {M1, M2, a1, a2}
           M1 = fmaxf(M1, a1);
           A = gt ? aa : A;
@@ -488,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
         m1[0] = M1; m2[0] = M2; arg[0] = A;
       }
     }
-    if ((t & 1) && (!SHARE || wave == 0)) {  // chunk complete: lane-half h holds group 2*chunk + h
+    if ((t & 1) && (!SHARE || member == 0)) {  // chunk complete: lane-half h holds group 2*chunk + h
       const int64_t grp = 2 * chunk + h;
       const bool nonempty = grp * GROUP < p.C;
 #pragma unroll
@@ -502,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
         m1[n] = NEG_INF; m2[n] = NEG_INF; arg[n] = 0;
       }
     }
-    if (SHARE && (t & 1) && wave != 0) { m1[0] = NEG_INF; m2[0] = NEG_INF; arg[0] = 0; }
+    if (SHARE && (t & 1) && member != 0) { m1[0] = NEG_INF; m2[0] = NEG_INF; arg[0] = 0; }
     // tile t+1 must have landed; tiles t+2 .. t+STAGES-1 may still be in flight
     if (more) wait_vmcnt<(STAGES - 2) * NI>();
     else wait_vmcnt<0>();
@@ -888,13 +896,14 @@ static int dispatch_score(int dtype, int dpx, const MipsArgs& a, dim3 grid, hipS
   return launch_score<TT_BF16, 8, PASS>(a, grid, st);
 }
 
-template <int DT, int DPX, int NQ, bool SHARE = false>
+template <int DT, int DPX, int NQ, int SF = 0>
 static int launch_pass1_dma(MipsArgs a, int64_t, hipStream_t st) {
+  constexpr int SHARE = SF;
   // (a deeper ring for the shared-query form -- 4 / 8 stages, one workgroup per CU -- was measured: slower)
   constexpr int STAGES = (DT == TT_BF16) ? 4 : 2;
   const size_t lds = STAGES == 2 ? 0 : STAGES * (size_t)CT * 32 * DPX;  // two stages live in named static arrays
   // 2 workgroups per CU are resident; aim at ~4 rounds of them
-  const int64_t xblocks = SHARE ? ceil_div(a.nq, 32) : ceil_div(a.nq, QB_WG * NQ);
+  const int64_t xblocks = SF == 4 ? ceil_div(a.nq, 32) : SF == 2 ? ceil_div(a.nq, 64) : ceil_div(a.nq, QB_WG * NQ);
   int64_t splits = ceil_div(2048, xblocks);
   if (splits > a.n_chunks) splits = a.n_chunks;
   a.chunks_per_split = ceil_div(a.n_chunks, splits);
@@ -914,15 +923,16 @@ static int launch_pass1_dma(MipsArgs a, int64_t, hipStream_t st) {
 // -1: shape not covered by the DMA form
 static int dispatch_pass1_dma(int dtype, int dpx, const MipsArgs& a, int64_t splits, hipStream_t st) {
   static const bool no_share = getenv("TT_MIPS_NO_SHARE") != nullptr;
-  const bool share = a.nq <= 32 && !no_share;  // small query batch: the waves split the corpus instead
+  // small query batch: waves share queries and split the corpus instead (4 waves x 32, 2 pairs x 32)
+  const int sf = no_share ? 0 : a.nq <= 32 ? 4 : a.nq <= 64 ? 2 : 0;
   if (dtype == TT_F32) {
-    if (dpx == 4) return share ? launch_pass1_dma<TT_F32, 4, 1, true>(a, splits, st) : launch_pass1_dma<TT_F32, 4, 1>(a, splits, st);
-    if (dpx == 8) return share ? launch_pass1_dma<TT_F32, 8, 1, true>(a, splits, st) : launch_pass1_dma<TT_F32, 8, 1>(a, splits, st);
-    return share ? launch_pass1_dma<TT_F32, 16, 1, true>(a, splits, st) : launch_pass1_dma<TT_F32, 16, 1>(a, splits, st);
+    if (dpx == 4) return sf == 4 ? launch_pass1_dma<TT_F32, 4, 1, 4>(a, splits, st) : sf == 2 ? launch_pass1_dma<TT_F32, 4, 1, 2>(a, splits, st) : launch_pass1_dma<TT_F32, 4, 1>(a, splits, st);
+    if (dpx == 8) return sf == 4 ? launch_pass1_dma<TT_F32, 8, 1, 4>(a, splits, st) : sf == 2 ? launch_pass1_dma<TT_F32, 8, 1, 2>(a, splits, st) : launch_pass1_dma<TT_F32, 8, 1>(a, splits, st);
+    return sf == 4 ? launch_pass1_dma<TT_F32, 16, 1, 4>(a, splits, st) : sf == 2 ? launch_pass1_dma<TT_F32, 16, 1, 2>(a, splits, st) : launch_pass1_dma<TT_F32, 16, 1>(a, splits, st);
   }
-  if (share) {
-    if (dpx == 4) return launch_pass1_dma<TT_BF16, 4, 1, true>(a, splits, st);
-    if (dpx == 8) return launch_pass1_dma<TT_BF16, 8, 1, true>(a, splits, st);
+  if (sf) {
+    if (dpx == 4) return sf == 4 ? launch_pass1_dma<TT_BF16, 4, 1, 4>(a, splits, st) : launch_pass1_dma<TT_BF16, 4, 1, 2>(a, splits, st);
+    if (dpx == 8) return sf == 4 ? launch_pass1_dma<TT_BF16, 8, 1, 4>(a, splits, st) : launch_pass1_dma<TT_BF16, 8, 1, 2>(a, splits, st);
     return -1;
   }
   static const int force_nq = getenv("TT_MIPS_NQ") ? atoi(getenv("TT_MIPS_NQ")) : 0;
