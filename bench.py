@@ -309,7 +309,10 @@ def main():
                 rec = json.load(open(tpath)).get(f"{args.workload}_gpus{world}")
                 if rec:
                     traffic = rec.get("hbm_bytes_per_launch")
-            roof = {"bound": "hbm", "kernel": "adam_sweep_kernel", "achieved": round(achieved, 1),
+            # the name rocprofv3 reports for it (profiles/r01_kernel_stats_P_1gpu_final.csv)
+            sweep_name = ("adam_sweep_bounded_kernel" if os.environ.get("TT_SWEEP_PERSIST") == "0"
+                          else "adam_sweep_persistent_kernel")
+            roof = {"bound": "hbm", "kernel": sweep_name, "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "launches": cnt.value,
                     "avg_launch_ms": round(ms.value / cnt.value, 4),
