@@ -796,67 +796,97 @@ __global__ __launch_bounds__(256) void mips_select_finish_kernel(const u64* __re
 
 // ---------------------------------------------------------------- per-query candidate sort
 // one wavefront per query: stable LSD radix sort (8-bit digits) on ~key (ascending ~key ==
-// descending key), ping-pong between the query's two candidate buffers, then emit top K.
+// descending key), then emit top K.  Up to SORT_LDS candidates (the usual ~1.0 K at K = 1000) are
+// sorted in LDS; longer lists ping-pong between the query's two global buffers.  Digits on which all
+// keys agree (the top byte of the row index, usually the exponent byte of the score) are skipped:
+// a stable pass over a constant digit is the identity.
+constexpr int SORT_LDS = 2048;
+
+template <typename Ptr>
+__device__ __forceinline__ void sort_pass(Ptr a, Ptr b, int32_t n, int shift, int32_t* base, int lane, u64 lt_mask) {
+  for (int d = lane; d < 256; d += 64) base[d] = 0;
+  __syncthreads();
+  for (int i = lane; i < n; i += 64) atomicAdd(&base[(int)((~a[i] >> shift) & 255)], 1);
+  __syncthreads();
+  {  // exclusive scan of the 256 counters, 4 per lane
+    int32_t t[4], s = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { t[c] = base[4 * lane + c]; s += t[c]; }
+    int32_t inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t u = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += u;
+    }
+    int32_t run = inc - s;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { base[4 * lane + c] = run; run += t[c]; }
+  }
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const int i = i0 + lane;
+    const bool active = i < n;
+    const u64 key = active ? a[i] : 0ull;
+    const int d = (int)((~key >> shift) & 255);
+    u64 mask = __ballot(active);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const u64 bal = __ballot((d >> bit) & 1);
+      mask &= ((d >> bit) & 1) ? bal : ~bal;
+    }
+    const int rank = __popcll(mask & lt_mask);
+    int32_t pos = 0;
+    if (active) pos = base[d] + rank;
+    __builtin_amdgcn_wave_barrier();
+    if (active && rank == 0) base[d] += __popcll(mask);
+    __builtin_amdgcn_wave_barrier();
+    if (active) b[pos] = key;
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(64) void mips_sort_emit_kernel(u64* __restrict__ cand, u64* __restrict__ tmp,
                                                             const int32_t* __restrict__ count, int64_t cap, int64_t K,
                                                             int64_t q0, int64_t* __restrict__ idx_out,
                                                             float* __restrict__ score_out, int32_t* __restrict__ status) {
   __shared__ int32_t base[256];
+  __shared__ u64 lbuf[2][SORT_LDS];
   const int lane = threadIdx.x;
   const int64_t ql = blockIdx.x;
   int32_t n = count[ql];
   if (n > cap) { n = (int32_t)cap; if (lane == 0) atomicOr(status, 1); }  // cannot happen (bound proven above)
   if (n < K && lane == 0) atomicOr(status, 2);
-  u64* a = cand + ql * cap;
-  u64* b = tmp + ql * cap;
+  u64* ga = cand + ql * cap;
+  u64* gb = tmp + ql * cap;
   const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const bool in_lds = n <= SORT_LDS;
+  // which digits differ between any two keys
+  u64 all_and = ~0ull, all_or = 0ull;
+  for (int i = lane; i < n; i += 64) {
+    const u64 k = ga[i];
+    if (in_lds) lbuf[0][i] = k;
+    all_and &= k;
+    all_or |= k;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    all_and &= __shfl_xor(all_and, o, 64);
+    all_or |= __shfl_xor(all_or, o, 64);
+  }
+  const u64 varies = all_and ^ all_or;
+  __syncthreads();
+  int cur = 0;  // buffer holding the current order (LDS: lbuf[cur]; global: cur == 0 -> ga)
   for (int pass = 0; pass < 8; ++pass) {
     const int shift = 8 * pass;
-    for (int d = lane; d < 256; d += 64) base[d] = 0;
-    __syncthreads();
-    for (int i = lane; i < n; i += 64) atomicAdd(&base[(int)((~a[i] >> shift) & 255)], 1);
-    __syncthreads();
-    {  // exclusive scan of the 256 counters, 4 per lane
-      int32_t t[4], s = 0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { t[c] = base[4 * lane + c]; s += t[c]; }
-      int32_t inc = s;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int32_t u = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += u;
-      }
-      int32_t run = inc - s;
-      __syncthreads();
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { base[4 * lane + c] = run; run += t[c]; }
-    }
-    __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += 64) {
-      const int i = i0 + lane;
-      const bool active = i < n;
-      const u64 key = active ? a[i] : 0ull;
-      const int d = (int)((~key >> shift) & 255);
-      u64 mask = __ballot(active);
-#pragma unroll
-      for (int bit = 0; bit < 8; ++bit) {
-        const u64 bal = __ballot((d >> bit) & 1);
-        mask &= ((d >> bit) & 1) ? bal : ~bal;
-      }
-      const int rank = __popcll(mask & lt_mask);
-      int32_t pos = 0;
-      if (active) pos = base[d] + rank;
-      __builtin_amdgcn_wave_barrier();
-      if (active && rank == 0) base[d] += __popcll(mask);
-      __builtin_amdgcn_wave_barrier();
-      if (active) b[pos] = key;
-    }
-    __syncthreads();
-    u64* sw = a; a = b; b = sw;
+    if (((varies >> shift) & 255) == 0) continue;
+    if (in_lds) sort_pass(&lbuf[cur][0], &lbuf[cur ^ 1][0], n, shift, base, lane, lt_mask);
+    else sort_pass(cur ? gb : ga, cur ? ga : gb, n, shift, base, lane, lt_mask);
+    cur ^= 1;
   }
-  // 8 passes: the sorted data is back in the first buffer (`a` == cand slice)
+  const u64* src = in_lds ? &lbuf[cur][0] : (cur ? gb : ga);
   for (int64_t k = lane; k < K; k += 64) {
-    const u64 key = (k < n) ? a[k] : 0ull;
+    const u64 key = (k < n) ? src[k] : 0ull;
     idx_out[(q0 + ql) * K + k] = (k < n) ? (int64_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) : (int64_t)-1;
     score_out[(q0 + ql) * K + k] = (k < n) ? ord2f((uint32_t)(key >> 32)) : 0.f;
   }
