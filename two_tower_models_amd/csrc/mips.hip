@@ -632,9 +632,22 @@ __global__ __launch_bounds__(256) void mips_select_hist_kernel(const uint32_t* _
   const int64_t g0 = (int64_t)blockIdx.y * per;
   const int64_t g1 = (g0 + per < n_groups) ? g0 + per : n_groups;
   if (live) {
-    for (int64_t g = g0 + lane8; g < g1; g += 8) {
-      const u64 key = ord_key(gmax[g * nq + q], (uint32_t)g);
-      if ((key & himask) == prefix) atomicAdd(&hist[ql][(int)((key >> shift) & 255)], 1);
+    // eight loads in flight per thread (unconditional, from clamped rows): with one guarded load per
+    // iteration the loop ran at one memory latency per element
+    constexpr int U = 8;
+    for (int64_t gb = g0 + lane8; gb < g1; gb += 8 * U) {
+      uint32_t v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t g = gb + 8 * u;
+        v[u] = gmax[(g < g1 ? g : g1 - 1) * nq + q];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t g = gb + 8 * u;
+        const u64 key = ord_key(v[u], (uint32_t)g);
+        if (g < g1 && (key & himask) == prefix) atomicAdd(&hist[ql][(int)((key >> shift) & 255)], 1);
+      }
     }
   }
   __syncthreads();
@@ -699,12 +712,23 @@ __global__ __launch_bounds__(256) void mips_select_split_kernel(const uint32_t* 
   const int64_t g0 = (int64_t)blockIdx.y * per;
   const int64_t g1 = (g0 + per < n_groups) ? g0 + per : n_groups;
   int32_t n_sure = 0, n_surv = 0;
+  constexpr int U = 8;  // loads in flight per thread, see mips_select_hist_kernel
   if (!skip) {
-    for (int64_t g = g0 + lane8; g < g1; g += 8) {
-      const u64 key = ord_key(gmax[g * nq + q], (uint32_t)g);
-      const bool sure = decided ? key >= t : (key >> 48) > (t >> 48);
-      n_sure += sure ? 1 : 0;
-      n_surv += (!sure && !decided && (key >> 48) == (t >> 48)) ? 1 : 0;
+    for (int64_t gb = g0 + lane8; gb < g1; gb += 8 * U) {
+      uint32_t v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t g = gb + 8 * u;
+        v[u] = gmax[(g < g1 ? g : g1 - 1) * nq + q];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t g = gb + 8 * u;
+        const u64 key = ord_key(v[u], (uint32_t)g);
+        const bool sure = decided ? key >= t : (key >> 48) > (t >> 48);
+        n_sure += (g < g1 && sure) ? 1 : 0;
+        n_surv += (g < g1 && !sure && !decided && (key >> 48) == (t >> 48)) ? 1 : 0;
+      }
     }
   }
   cnt_sure[ql][lane8] = n_sure;
@@ -728,16 +752,27 @@ __global__ __launch_bounds__(256) void mips_select_split_kernel(const uint32_t* 
   __syncthreads();
   if (skip || (n_sure == 0 && n_surv == 0)) return;
   int32_t pa = cnt_sure[ql][lane8], pb = cnt_surv[ql][lane8];
-  for (int64_t g = g0 + lane8; g < g1; g += 8) {
-    const u64 key = ord_key(gmax[g * nq + q], (uint32_t)g);
-    const bool sure = decided ? key >= t : (key >> 48) > (t >> 48);
-    if (sure) {
-      if (glist) {
-        if (pa < K) glist[q * K + pa] = (int32_t)g;
-        ++pa;
+  for (int64_t gb = g0 + lane8; gb < g1; gb += 8 * U) {
+    uint32_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t g = gb + 8 * u;
+      v[u] = gmax[(g < g1 ? g : g1 - 1) * nq + q];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t g = gb + 8 * u;
+      if (g >= g1) break;
+      const u64 key = ord_key(v[u], (uint32_t)g);
+      const bool sure = decided ? key >= t : (key >> 48) > (t >> 48);
+      if (sure) {
+        if (glist) {
+          if (pa < K) glist[q * K + pa] = (int32_t)g;
+          ++pa;
+        }
+      } else if (!decided && (key >> 48) == (t >> 48)) {
+        surv[q * n_groups + pb++] = key;
       }
-    } else if (!decided && (key >> 48) == (t >> 48)) {
-      surv[q * n_groups + pb++] = key;
     }
   }
 }
