@@ -692,6 +692,8 @@ __global__ void mips_select_init_kernel(int32_t* __restrict__ ghist, int32_t* __
 //   same 16-bit prefix, still undecided                               -> surv[q][..] (the keys)
 // and the remaining six digit passes run on the short survivor lists, one workgroup per query
 // (mips_select_finish_kernel), which also appends the survivors that make it to glist.
+constexpr int SPLIT_ITERS = 96;  // groups per thread and slice (3 x 32 match bits per list)
+
 __global__ __launch_bounds__(256) void mips_select_split_kernel(const uint32_t* __restrict__ gmax, int64_t n_groups,
                                                                 int64_t nq, const u64* __restrict__ tau,
                                                                 const int32_t* __restrict__ done, int64_t K,
@@ -699,8 +701,8 @@ __global__ __launch_bounds__(256) void mips_select_split_kernel(const uint32_t* 
                                                                 u64* __restrict__ surv, int32_t* __restrict__ scount) {
   // Same-address atomics serialise in L2 (~60 ns each): one atomicAdd per listed group put ~2.5 K of
   // them in a row on every query's counter, 0.15 ms whatever the batch size.  Each workgroup now
-  // counts its groups first, reserves ONE range per query and list, and fills it in a second walk
-  // over its slice (which is in L2 by then).
+  // walks its slice ONCE, remembering its (rare: ~1.6 %) matches as bit masks in registers, reserves
+  // one range per query and list, and then revisits only the groups whose bit is set.
   __shared__ int32_t cnt_sure[SEL_Q][8], cnt_surv[SEL_Q][8];
   const int ql = threadIdx.x & 31, lane8 = threadIdx.x >> 5;
   const int64_t q = (int64_t)blockIdx.x * SEL_Q + ql;
@@ -708,33 +710,41 @@ __global__ __launch_bounds__(256) void mips_select_split_kernel(const uint32_t* 
   const u64 t = live ? tau[q] : 0;
   const bool decided = live && done[q] != 0;
   const bool skip = !live || (decided && !glist);
-  const int64_t per = (n_groups + gridDim.y - 1) / gridDim.y;
+  const int64_t per = (n_groups + gridDim.y - 1) / gridDim.y;  // host: per <= 8 * SPLIT_ITERS
   const int64_t g0 = (int64_t)blockIdx.y * per;
   const int64_t g1 = (g0 + per < n_groups) ? g0 + per : n_groups;
+  uint32_t bits_sure[SPLIT_ITERS / 32], bits_surv[SPLIT_ITERS / 32];
   int32_t n_sure = 0, n_surv = 0;
-  constexpr int U = 8;  // loads in flight per thread, see mips_select_hist_kernel
-  if (!skip) {
-    for (int64_t gb = g0 + lane8; gb < g1; gb += 8 * U) {
-      uint32_t v[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int64_t g = gb + 8 * u;
+  for (int w = 0; w < SPLIT_ITERS / 32; ++w) {
+    bits_sure[w] = 0;
+    bits_surv[w] = 0;
+    if (skip || g0 + lane8 + 8 * (int64_t)(32 * w) >= g1) continue;
+#pragma unroll
+    for (int b8 = 0; b8 < 4; ++b8) {  // eight loads in flight, see mips_select_hist_kernel
+      uint32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t g = g0 + lane8 + 8 * (int64_t)(32 * w + 8 * b8 + u);
         v[u] = gmax[(g < g1 ? g : g1 - 1) * nq + q];
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int64_t g = gb + 8 * u;
+      for (int u = 0; u < 8; ++u) {
+        const int64_t g = g0 + lane8 + 8 * (int64_t)(32 * w + 8 * b8 + u);
         const u64 key = ord_key(v[u], (uint32_t)g);
-        const bool sure = decided ? key >= t : (key >> 48) > (t >> 48);
-        n_sure += (g < g1 && sure) ? 1 : 0;
-        n_surv += (g < g1 && !sure && !decided && (key >> 48) == (t >> 48)) ? 1 : 0;
+        const bool sure = g < g1 && (decided ? key >= t : (key >> 48) > (t >> 48));
+        const bool sv = g < g1 && !sure && !decided && (key >> 48) == (t >> 48);
+        bits_sure[w] |= (sure ? 1u : 0u) << (8 * b8 + u);
+        bits_surv[w] |= (sv ? 1u : 0u) << (8 * b8 + u);
       }
     }
+    n_sure += __popc(bits_sure[w]);
+    n_surv += __popc(bits_surv[w]);
   }
   cnt_sure[ql][lane8] = n_sure;
   cnt_surv[ql][lane8] = n_surv;
   __syncthreads();
-  if (lane8 == 0 && !skip) {  // exclusive prefix over the eight slots of this query; slot 0 then holds the base
+  if (lane8 == 0 && !skip) {  // exclusive prefix over the eight slots of this query; then add the reserved base
     int32_t tot_a = 0, tot_b = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -752,27 +762,22 @@ __global__ __launch_bounds__(256) void mips_select_split_kernel(const uint32_t* 
   __syncthreads();
   if (skip || (n_sure == 0 && n_surv == 0)) return;
   int32_t pa = cnt_sure[ql][lane8], pb = cnt_surv[ql][lane8];
-  for (int64_t gb = g0 + lane8; gb < g1; gb += 8 * U) {
-    uint32_t v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t g = gb + 8 * u;
-      v[u] = gmax[(g < g1 ? g : g1 - 1) * nq + q];
+  for (int w = 0; w < SPLIT_ITERS / 32; ++w) {
+    uint32_t m = glist ? bits_sure[w] : 0u;
+    while (m) {
+      const int bit = __ffs(m) - 1;
+      m &= m - 1;
+      const int64_t g = g0 + lane8 + 8 * (int64_t)(32 * w + bit);
+      if (pa < K) glist[q * K + pa] = (int32_t)g;
+      ++pa;
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t g = gb + 8 * u;
-      if (g >= g1) break;
-      const u64 key = ord_key(v[u], (uint32_t)g);
-      const bool sure = decided ? key >= t : (key >> 48) > (t >> 48);
-      if (sure) {
-        if (glist) {
-          if (pa < K) glist[q * K + pa] = (int32_t)g;
-          ++pa;
-        }
-      } else if (!decided && (key >> 48) == (t >> 48)) {
-        surv[q * n_groups + pb++] = key;
-      }
+    m = bits_surv[w];
+    while (m) {
+      const int bit = __ffs(m) - 1;
+      m &= m - 1;
+      const int64_t g = g0 + lane8 + 8 * (int64_t)(32 * w + bit);
+      surv[q * n_groups + pb++] = ord_key(gmax[g * nq + q], (uint32_t)g);
     }
   }
 }
@@ -1157,7 +1162,8 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
       }
       int32_t* gl = sparse ? glist : nullptr;
       // fewer, longer slices than the histogram passes: one counter reservation per workgroup, query and list
-      const int64_t split_slices = slices < 256 ? slices : 256;
+      int64_t split_slices = slices < 256 ? slices : 256;
+      if (split_slices * 8 * SPLIT_ITERS < pl.n_groups) split_slices = ceil_div(pl.n_groups, 8 * SPLIT_ITERS);  // match-bit capacity
       mips_select_split_kernel<<<dim3((unsigned)qblocks, (unsigned)split_slices), 256, 0, st>>>(gmax, pl.n_groups, nq, tau, done, K, gl, lcount, surv, scount);
       if ((rc = check_launch("mips_select_split_kernel"))) return rc;
       mips_select_finish_kernel<<<(unsigned)nq, 256, 0, st>>>(surv, scount, pl.n_groups, tau, want, done, K, gl, lcount);
