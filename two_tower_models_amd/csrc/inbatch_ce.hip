@@ -638,19 +638,39 @@ __global__ __launch_bounds__(256) void ce_fwd_du_finish_kernel(const float* __re
                                                                int64_t diag_offset, float* __restrict__ row_lse,
                                                                float* __restrict__ row_ce, float* __restrict__ du_unit,
                                                                int64_t ld_du) {
-  // one wavefront per user row
+  // one wavefront per user row; lane z holds split z's statistics (splits <= 64), so the maximum, the
+  // normaliser and the per-split factors are wave reductions / shuffles instead of per-lane loops,
+  // and the slab reads of a column are issued together (they were one dependent round trip each)
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int lane = threadIdx.x & 63;
-  float mx = NEG_BIG;
-  for (int z = 0; z < splits; ++z) mx = fmaxf(mx, part_m[(int64_t)z * M + row]);
+  const bool has = lane < splits;
+  const float pm = has ? part_m[(int64_t)lane * M + row] : NEG_BIG;
+  const float ps = has ? part_s[(int64_t)lane * M + row] : 0.f;
+  const float mx = wave_max(pm);
+  // the per-split factors and weighted sums go through LDS: the column loop below is divergent for
+  // D < 64, where a shuffle could read from an inactive lane
+  __shared__ float s_f[4][64], s_w[4][64];
+  const int wv = threadIdx.x >> 6;
+  const float fz = has ? exp2f(pm - mx) : 0.f;  // this split's rescale factor
+  s_f[wv][lane] = fz;
+  s_w[wv][lane] = ps * fz;
+  __builtin_amdgcn_wave_barrier();
+  // S in split order: the same sequence of additions as a serial loop over z
   float S = 0.f;
-  for (int z = 0; z < splits; ++z) S += part_s[(int64_t)z * M + row] * exp2f(part_m[(int64_t)z * M + row] - mx);
+  for (int z = 0; z < splits; ++z) S += s_w[wv][z];
   const float inv = 1.0f / S;
   for (int64_t col = lane; col < D; col += 64) {
     float e = 0.f;
-    for (int z = 0; z < splits; ++z)
-      e += slabs[((int64_t)z * M + row) * D + col] * exp2f(part_m[(int64_t)z * M + row] - mx);
+    int z = 0;
+    for (; z + 8 <= splits; z += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = slabs[((int64_t)(z + u) * M + row) * D + col];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) e += v[u] * s_f[wv][z + u];
+    }
+    for (; z < splits; ++z) e += slabs[((int64_t)z * M + row) * D + col] * s_f[wv][z];
     du_unit[row * ld_du + col] = e * inv - Y[(row + diag_offset) * ldy + col];
   }
   if (lane == 0) {
