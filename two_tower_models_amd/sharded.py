@@ -403,6 +403,8 @@ class ShardedTrainer:
         D, F = cfg["D"], cfg["F"]
         # history model (ref:src/two_tower_with_user_history_encoder.py): the encoder is replicated,
         # its input rows come out of the sharded ITEM table like every other lookup
+        if cfg.get("model", "base") not in ("base", "hist"):
+            raise ValueError(f"ShardedTrainer: model {cfg.get('model')!r} is not sharded (base and hist are)")
         self.hist = cfg.get("model", "base") == "hist"
         self.heads, self.layers = 4, 3  # hard-coded upstream (ref :64-70)
         self.users = ShardedTable(cfg["n_users"], D, device, seed + 1)
