@@ -138,10 +138,130 @@ def cpu_baseline(cfg, seconds_budget=25.0):
         pass
     return {
         "value": B * steps / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
+        "cpu_steps": steps,
         "sample": f"{steps} train steps of oracle/cpu_ref.py (torch CPU, {cores} threads), B={B}, D={D}, "
                   f"N_u={n_users}, N_i={n_items}" + ("" if n_items == cfg["n_items"] else " (shrunk to fit host RAM)")
                   + f", {dt / steps * 1e3:.0f} ms/step",
     }
+
+
+MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def _timed_train(name, device, steps, warmup, lazy=False):
+    """One module-path train workload, timed like the headline (batches resident, K steps between syncs)."""
+    import two_tower_models_amd as A
+    cfg = dict(WORKLOADS[name])
+    model = build_model(cfg, device)
+    opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep="forward", lazy=lazy)
+    batches = make_batches(cfg, 8, device)
+    total = torch.zeros((), device=device)
+
+    def step(i):
+        b, nxt = batches[i % len(batches)], batches[(i + 1) % len(batches)]
+        loss = model.train_forward(*b)
+        if lazy:
+            opt.prefetch_rows(model._lookup_plan(nxt[0], nxt[2], nxt[3]))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        total.add_(loss.detach())
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    if lazy:
+        opt.flush()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": name + (" [value-exact DEFERRED Adam, K steps + flush: not the headline schedule]" if lazy else ""),
+            "pairs_per_s": round(cfg["B"] * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
+            "steps": steps, "warmup": warmup, "B": cfg["B"], "n_items": cfg["n_items"],
+            "H": cfg["H"] if cfg["model"] != "base" else None}
+
+
+def _timed_mips(device, lib, N, Cn=10_000_000, B=1024, K=1000, D=128, reps=3):
+    """BASELINE config 5 on one GPU: BaselineMIPSModule top-K over a 10 M-row corpus, fp32 and bf16 storage;
+    roofline of the dense scoring pass (2*B*C*D flops) from HIP events on its stream."""
+    import ctypes as C
+    import two_tower_models_amd as A
+    g = torch.Generator(device=device).manual_seed(0)
+    m = A.BaselineMIPSModule(corpus_size=8, embedding_dim=D)
+    m.corpus = torch.randn(Cn, D, device=device, generator=g)
+    m.corpus_size = Cn
+    q = torch.randn(B, D, device=device, generator=g)
+    out = {}
+    for name, peak in (("fp32", MFMA_F32_PEAK_TF), ("bf16", MFMA_BF16_PEAK_TF)):
+        if name == "bf16":
+            m.use_bf16_storage()
+        m.search(q, K)  # warm-up: allocates the workspace
+        torch.cuda.synchronize()
+        lib.tt_profile_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            m.search(q, K)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        N.check(lib.tt_profile_read(b"mips_score_kernel", C.byref(ms), C.byref(cnt)), "tt_profile_read")
+        lib.tt_profile_enable(0)
+        tf = 2.0 * B * Cn * D * cnt.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else None
+        out[name] = {"queries_per_s": round(B / dt, 1), "ms_per_call": round(dt * 1e3, 3), "C": Cn, "B": B, "K": K, "D": D,
+                     "roofline": {"bound": "mfma", "kernel": "mips_pass1_dma_kernel", "achieved": round(tf, 1) if tf else None,
+                                  "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4) if tf else None,
+                                  "avg_launch_ms": round(ms.value / max(cnt.value, 1), 4), "launches": cnt.value,
+                                  "algorithmic_flops_per_launch": 2.0 * B * Cn * D}}
+    return out
+
+
+def secondary(device, lib, N):
+    """The other BASELINE configs in the driver-run record (each a few hundred ms of GPU time): C2 and C3
+    train steps, config 5's MIPS at C = 10 M / K = 1000 (fp32, bf16), and the deferred-Adam figure, labelled."""
+    sec = {}
+    for key, name, steps, lazy in (("C2", "C2", 20, False), ("C3", "C3", 10, False), ("P_lazy", "P", 20, True)):
+        try:
+            sec[key] = _timed_train(name, device, steps, 3, lazy=lazy)
+        except Exception as e:  # a secondary figure must never take the headline line down with it
+            sec[key] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+    try:
+        sec["C5_mips"] = _timed_mips(device, lib, N)
+    except Exception as e:
+        sec["C5_mips"] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
+    return sec
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-exec this script as N ranks under
+    torch.distributed.run (one rank per GPU, RCCL) on a free local port, pass the ranks' output through
+    and print rank 0's JSON line LAST.  On a box with fewer than N devices (the 1-GPU test boxes) the
+    ranks share cuda:0 and exchange through gloo -- bench.py's TT_BENCH_DIST_BACKEND test hook -- and
+    the JSON line says so in config.parallelism."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    if "TT_BENCH_DIST_BACKEND" not in env and torch.cuda.device_count() < n:
+        sys.stderr.write(f"bench.py: {torch.cuda.device_count()} device(s) < --gpus {n}: ranks share cuda:0 over gloo\n")
+        env["TT_BENCH_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, stdin=subprocess.DEVNULL)
+    lines = r.stdout.splitlines()
+    js = [i for i, l in enumerate(lines) if l.startswith('{"metric"')]
+    for i, l in enumerate(lines):
+        if not js or i != js[-1]:
+            print(l)
+    if js:
+        print(lines[js[-1]], flush=True)
+    return r.returncode if r.returncode != 0 else (0 if js else 1)
 
 
 def main():
@@ -151,6 +271,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="P", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` object (C2 / C3 / deferred-Adam train steps, config 5 MIPS) the default "
+                         "single-GPU P run appends")
     ap.add_argument("--negatives", default="global", choices=["global", "local"])
     ap.add_argument("--overlap", default="forward", choices=["forward", "zero_grad", "off"],
                     help="when DenseExactAdam starts the table sweep (optim.py); all three are bit-identical")
@@ -169,11 +292,13 @@ def main():
                          "region leave bit-identical tables")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))  # plain `python bench.py --gpus N`: become the launcher
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # TT_BENCH_DIST_BACKEND=gloo: test hook -- all ranks share cuda:0 and exchange through gloo (RCCL
     # refuses two ranks on one device), so the N > 1 code path can be exercised on a 1-GPU box.
     dist_backend = os.environ.get("TT_BENCH_DIST_BACKEND", "nccl")
@@ -187,6 +312,7 @@ def main():
     lib = N.load()
 
     use_sharded = world > 1 or args.sharded
+    n_ranks, dist_backend_seen = 1, None
     if use_sharded and (args.adam != "dense" or args.fresh_ids or args.phase != "step"):
         raise SystemExit("--adam lazy / --fresh-ids / --phase apply to the single-GPU module path")
     if use_sharded:
@@ -198,6 +324,7 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(dist_backend)
+        n_ranks, dist_backend_seen = dist.get_world_size(), dist.get_backend()
         trainer = sharded.ShardedTrainer(cfg, device, negatives=args.negatives)  # cfg['model'] selects base / hist
         step = trainer.step
         batches = trainer.make_batches(16)
@@ -314,7 +441,10 @@ def main():
                           else "adam_sweep_persistent_kernel")
             roof = {"bound": "hbm", "kernel": sweep_name, "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "launches": cnt.value,
+                    "traffic": traffic,
+                    "traffic_source": ("profiles/pmc_traffic.json (static: rocprofv3 --pmc passes of this command, "
+                                       "committed; not re-measured in this run)" if traffic is not None else None),
+                    "launches": cnt.value,
                     "avg_launch_ms": round(ms.value / cnt.value, 4),
                     "algorithmic_bytes_per_launch": sweep_bytes_step * args.steps / cnt.value}
             # With the tables sharded over many GPUs the sweep shrinks 1/N while the global-negative
@@ -347,11 +477,22 @@ def main():
                        f"row-sharded tables x{world}, {args.negatives} in-batch negatives, "
                        + ("RCCL" if dist_backend == "nccl" else dist_backend)},
             "roofline": roof,
+            # what the collective library itself reports (1 when no process group was needed)
+            "n_ranks": n_ranks, "dist_backend": dist_backend_seen,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         else:
             out["cpu_baseline"] = None
+        default_run = (world == 1 and not use_sharded and args.workload == "P" and args.phase == "step"
+                       and args.adam == "dense" and not args.graph and not args.fresh_ids)
+        if default_run and not args.no_secondary:
+            # release the headline model's 17 GB first
+            model = opt = batches = step = graphed = None  # noqa: F841
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary(device, lib, N)
         result = json.dumps(out)
     if use_sharded:
         torch.distributed.destroy_process_group()

@@ -146,7 +146,9 @@ int tt_inbatch_ce_bwd_kept(const float* U, int64_t ldu, int64_t M, int64_t N, in
 
 /* net_user_value weights, ref:...base_retrieval.py:322,334-339 for 2-D labels:
  *   nuv[i] = sum_t labels[i,t]*uvw[t];  w = clamp(nuv,1e-6);  w /= max_i w
- * then loss = mean_i(row_ce[i]*w[i]) and coef[i] = w[i]/B (gradient seed 1). */
+ * then loss = mean_i(row_ce[i]*w[i]) and coef[i] = w[i]/B (gradient seed 1).
+ * labels == NULL: every weight is 1 -- what the reference computes for train.py's 1-D [B] labels
+ * (ref:train/train.py:53-55,78: labels*uvw sums to ONE scalar, which clamp and /max turn into 1.0). */
 int tt_weighted_mean_loss(const float* labels, int64_t B, int64_t T, const float* uvw,
                           const float* row_ce, float* w_out, float* coef_out, float* loss_out,
                           tt_stream_t stream);

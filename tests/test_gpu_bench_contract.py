@@ -57,3 +57,19 @@ def test_two_rank_launch_line():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 256 and out["scaling"] == "weak"
     assert out["cpu_baseline"] is None  # rank 0 at N = 1 only
     assert out["value"] > 0 and out["roofline"]["launches"] == 2 * 3
+
+
+def test_self_launch_needs_no_env():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: bench.py re-executes itself as two ranks
+    (RCCL with one device per rank when the box has them, otherwise both on cuda:0 over gloo) and still prints
+    ONE JSON line last."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR",
+                                                            "MASTER_PORT", "TT_BENCH_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "tiny", "--steps", "3", "--warmup", "1"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900, stdin=subprocess.DEVNULL)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json(r.stdout)
+    assert KEYS <= set(out)
+    assert out["n_gpus"] == 2 and out["n_ranks"] == 2 and out["config"]["global_batch"] == 256
+    import torch
+    assert out["dist_backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")

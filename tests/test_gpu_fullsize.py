@@ -196,3 +196,189 @@ def test_history_encoder_b4096_h50_sampled(T):
     want = R.history_encoder_forward(x[rows], R.encoder_layers_from_params(params, prefix=""), 4,
                                      R.positional_table(H, D))
     assert torch.allclose(y.cpu()[rows], want, atol=2e-5, rtol=1e-4)
+
+
+# ------------------------------------------------------------------ BASELINE configs at their stated size
+def test_c2_whole_train_step_vs_oracle():
+    """BASELINE config 2 end to end at its stated size (N_u = N_i = 1 M, D = 128, B = 4096, F = 8): two whole
+    `train_forward -> zero_grad -> backward -> step` iterations (ref:train/train.py:112-125) on the HIP path vs
+    oracle/cpu_ref.train_step on the same weights and batches: losses 1e-4, every dense parameter, 256 sampled
+    looked-up and 256 sampled never-looked-up rows of each table.  The second step makes the rows of step 1
+    move by momentum alone -- the zero-gradient sweep's arithmetic."""
+    import two_tower_models_amd as A
+    from oracle import cpu_ref as R
+    NU = NI = 1_000_000
+    D, F, B = 128, 8, 4096
+    torch.manual_seed(0)
+    mips = A.BaselineMIPSModule(corpus_size=64, embedding_dim=D)
+    model = A.TwoTowerBaseRetrieval(10, NU, D, F, NI, D, F, [1.0], mips)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep="forward")
+    g = torch.Generator().manual_seed(1234)
+    batches = []
+    for _ in range(2):
+        batches.append([torch.randint(0, NU, (B,), generator=g), torch.randn(B, F, generator=g),
+                        torch.randint(0, NI, (B, 4), generator=g), torch.randint(0, NI, (B,), generator=g),
+                        torch.randn(B, F, generator=g), torch.randint(0, 10, (B,), generator=g),
+                        torch.randint(0, 2, (B, 1), generator=g).float()])
+    batches[1][0][:64] = batches[0][0][:64]  # users and items seen in BOTH steps
+    batches[1][3][:64] = batches[0][3][:64]
+    state = R.AdamState(params)
+    got, want = [], []
+    for b in batches:
+        loss = model.train_forward(*[t.to(DEV) for t in b])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        got.append(loss.item())
+        want.append(R.train_step(params, state, b, torch.tensor([1.0])))
+    assert np.allclose(got, want, atol=1e-4), (got, want)
+    sd = model.state_dict()
+    for k, v in sd.items():
+        if "embedding_arch" in k:
+            continue
+        # item_tower_arch.bias / item_features_arch.2.bias: analytically zero gradient (DESIGN.md section 3)
+        noise_only = k in ("item_tower_arch.bias", "item_features_arch.2.bias")
+        assert torch.allclose(v.cpu(), params[k], atol=2 * 2 * 1e-3 * 1.05 if noise_only else 5e-6, rtol=1e-5), k
+    pick = torch.Generator().manual_seed(5)
+    for key, col, n_rows in (("user_id_embedding_arch.weight", 0, NU), ("item_id_embedding_arch.weight", 3, NI)):
+        touched = torch.unique(torch.cat([b[col] for b in batches]))
+        hit = touched[torch.randperm(touched.numel(), generator=pick)[:256]]
+        hit = torch.cat([hit, batches[0][col][:64]])  # the rows both steps looked up
+        mask = torch.ones(n_rows, dtype=torch.bool)
+        mask[touched] = False
+        cold = torch.nonzero(mask).flatten()
+        cold = cold[torch.randperm(cold.numel(), generator=pick)[:256]]
+        table = sd[key]
+        assert torch.allclose(table[hit.to(DEV)].cpu(), params[key][hit], atol=5e-6), key
+        assert torch.equal(table[cold.to(DEV)].cpu(), params[key][cold]), key
+        # whole-table property: a row nobody looked up has m = v = 0 and must be bit-identical to its initial value
+        st = opt.state[getattr(model, key.split(".")[0]).weight]
+        assert float(st["exp_avg"][cold.to(DEV)].abs().max()) == 0.0
+
+
+def _fp64_scores(q_eff, corpus, chunk=1_000_000):
+    """[B, C] fp64 checker of q . corpus^T, computed on the device in row chunks (test infrastructure)."""
+    out = torch.empty(q_eff.shape[0], corpus.shape[0], dtype=torch.float64, device=corpus.device)
+    for lo in range(0, corpus.shape[0], chunk):
+        out[:, lo:lo + chunk] = q_eff.double() @ corpus[lo:lo + chunk].double().t()
+    return out
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_mips_10m_corpus_k1000_config5_size(T, bf16):
+    """BASELINE config 5's corpus at its stated size: C = 10 M, D = 128, K = 1000 (fp32 corpus 5.12 GB, bf16
+    2.56 GB -- both past 2^31 bytes, where 32-bit offsets would wrap).  Random corpus: every picked score against an
+    fp64 checker, k-th-score optimality, order, range, no duplicates; rows planted in the LAST 1000 rows of the
+    corpus must be found."""
+    import two_tower_models_amd as A
+    C_, D, B, K = 10_000_000, 128, 8, 1000
+    g = torch.Generator(device=DEV).manual_seed(13)
+    corpus = torch.randn(C_, D, device=DEV, generator=g)
+    q = torch.randn(B, D, device=DEV, generator=g)
+    corpus[C_ - 1000:] *= 3.0  # the tail of the corpus holds most of the winners
+    m = A.BaselineMIPSModule(corpus_size=8, embedding_dim=D)
+    m.corpus, m.corpus_size = corpus, C_
+    if bf16:
+        m.use_bf16_storage()
+        del corpus
+        q_eff = q.to(torch.bfloat16).float()
+    else:
+        q_eff = q
+    idx, sc = m.search(q, K)
+    assert idx.dtype == torch.int64 and idx.shape == (B, K) and bool(((idx >= 0) & (idx < C_)).all())
+    assert bool((sc[:, 1:] <= sc[:, :-1]).all())
+    assert all(len(set(r.tolist())) == K for r in idx.cpu())
+    full = _fp64_scores(q_eff, m.corpus)
+    picked = torch.gather(full, 1, idx)
+    assert torch.allclose(picked, sc.double(), atol=5e-4)
+    ref = torch.topk(full, K, dim=1)
+    assert bool((picked.min(1).values >= ref.values[:, -1] - 5e-4).all())
+    overlap = np.mean([len(set(a.tolist()) & set(b.tolist())) / K for a, b in zip(idx.cpu(), ref.indices.cpu())])
+    assert overlap > 0.998
+    assert float((idx >= C_ - 1000).float().mean()) > 0.3  # the planted tail rows were reached
+    # the gathered rows of forward() (ref:src/baseline_mips_module.py:63-69) at offsets past 2^31 bytes
+    idx2, sc2, emb = m(q[:2], 10)
+    assert torch.equal(idx2, idx[:2, :10]) and torch.equal(emb, m.corpus[idx2].float())
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_mips_10m_exact_arithmetic_corpus_bit_exact_order(T, bf16):
+    """C = 10 M with small-integer embeddings (dot products exact in fp32 under any summation order, lossless in
+    bf16): indices and scores must equal the CPU oracle's (score desc, index asc) order BIT FOR BIT, ties
+    included (the index digits repeat every 65 536 rows, so equal scores are common)."""
+    import two_tower_models_amd as A
+    from oracle import cpu_ref as R
+    C_, D, B, K = 10_000_000, 128, 8, 1000
+    g = torch.Generator(device=DEV).manual_seed(17)
+    corpus = torch.randint(-1, 2, (C_, D), device=DEV, generator=g, dtype=torch.int8).float()
+    i = torch.arange(C_, device=DEV)
+    corpus[:, D - 3] = ((i & 63) - 32).float()
+    corpus[:, D - 2] = (((i >> 6) & 63) - 32).float()
+    corpus[:, D - 1] = (((i >> 12) & 15) - 8).float()
+    q = torch.randint(-1, 2, (B, D), device=DEV, generator=g, dtype=torch.int8).float()
+    q[:, D - 3], q[:, D - 2], q[:, D - 1] = 2.0 ** -6, 2.0 ** -12, 2.0 ** -16
+    m = A.BaselineMIPSModule(corpus_size=8, embedding_dim=D)
+    m.corpus, m.corpus_size = corpus, C_
+    host = corpus.cpu()
+    if bf16:
+        m.use_bf16_storage()
+        assert torch.equal(m.corpus[-4096:].float(), corpus[-4096:])  # lossless
+    del corpus
+    idx, sc = m.search(q, K)
+    want_idx, want_sc, _ = R.mips_topk(q.cpu(), host, K, chunk=2)
+    assert torch.equal(sc.cpu(), want_sc)
+    assert torch.equal(idx.cpu(), want_idx)
+
+
+def test_table_beyond_2_31_elements_gather_and_adam(T):
+    """A table with more than 2^31 ELEMENTS (20 M x 128 = 2.56 G floats, 10.2 GB; 30.7 GB with both moments -- what
+    one rank of BASELINE config 4 holds at N = 8 is 12.5 M rows): gather, the row plan and two dense-exact Adam
+    steps with rows on both sides of the 2^31-element line, sampled rows vs oracle/cpu_ref.adam_update."""
+    from oracle import cpu_ref as R
+    ops, N = T
+    lib = N.load()
+    n_rows, D, n = 20_000_000, 128, 8192
+    line = (1 << 31) // D  # first row whose elements sit past 2^31
+    g = torch.Generator(device=DEV).manual_seed(23)
+    Wd = torch.randn(n_rows, D, device=DEV, generator=g)
+    Md, Vd = torch.zeros_like(Wd), torch.zeros_like(Wd)
+    cg = torch.Generator().manual_seed(29)
+    steps = []
+    for _ in (1, 2):
+        ids = torch.cat([torch.randint(0, n_rows, (n - 2048,), generator=cg),
+                         torch.randint(line, n_rows, (2040,), generator=cg),
+                         torch.tensor([n_rows - 1, n_rows - 2, line, line - 1, line + 1, 0, 1, n_rows - 1])])
+        steps.append((ids, torch.randn(n, D, generator=cg) * 0.01))
+    steps[1][0][:32] = steps[0][0][:32]
+    all_ids = torch.cat([s[0] for s in steps])
+    # gather across the line
+    out = torch.empty(all_ids.numel(), D, device=DEV)
+    ops.gather_rows_into(Wd, all_ids.to(DEV), out)
+    assert torch.equal(out, Wd[all_ids.to(DEV)])
+    sample = torch.unique(torch.cat([steps[0][0][:150], steps[0][0][-160:], steps[1][0][-160:]]))
+    W0 = Wd[sample.to(DEV)].cpu()
+    cold = torch.tensor([line - 2, line + 2, n_rows - 3, 12_345_678, 19_999_000])
+    cold = cold[~torch.isin(cold, all_ids)]
+    cold0 = Wd[cold.to(DEV)].clone()
+    hyper = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 0, 0, 0, 0], dtype=torch.float64, device=DEV)
+    for ids, rows in steps:
+        N.check(lib.tt_adam_advance(hyper.data_ptr(), N.stream()), "adv")
+        plan = ops.RowPlan.from_grads([ops.RowGrad(ids.to(DEV), rows.to(DEV))], n_rows)
+        wsp, wsn = ops._ws(torch.device(DEV), lib.tt_adam_table_workspace_bytes(plan.n, D), "adam_side")
+        N.check(lib.tt_adam_table(Wd.data_ptr(), Md.data_ptr(), Vd.data_ptr(), n_rows, D, hyper.data_ptr(),
+                                  C.byref(plan.sources), plan.n, plan.sorted_ids.data_ptr(), plan.perm.data_ptr(),
+                                  plan.seg_begin.data_ptr(), plan.n_unique.data_ptr(), wsp, wsn, N.stream()), "adam")
+    got = Wd[sample.to(DEV)].cpu()
+    for j, k in enumerate(sample.tolist()):
+        p, m_, v_ = W0[j].clone(), torch.zeros(D), torch.zeros(D)
+        for step, (ids, rows) in enumerate(steps, start=1):
+            hit = ids == k
+            R.adam_update(p, rows[hit].sum(0) if bool(hit.any()) else torch.zeros(D), m_, v_, step)
+        assert torch.allclose(got[j], p, atol=3e-6), k
+    assert torch.equal(Wd[cold.to(DEV)], cold0)  # never looked up, m = v = 0: bit-identical
+    # the moments past the line are non-zero exactly where rows were looked up
+    tail_touched = torch.unique(all_ids[all_ids >= line])
+    assert bool((Md[tail_touched.to(DEV)].abs().sum(1) > 0).all())
+    assert float(Md[line:].abs().sum(1).gt(0).sum()) == float(tail_touched.numel())

@@ -86,26 +86,64 @@ def test_base_model_seeded_init_is_reference_init(golden):
         assert torch.equal(v, T(g["p." + k])), k
 
 
-def test_adam_trajectory_dense_exact(golden):
-    """The ref:train/train.py:112-132 loop body x3 with DenseExactAdam vs torch.optim.Adam."""
+@pytest.mark.parametrize("interleave", [False, True])
+@pytest.mark.parametrize("schedule", [dict(), dict(overlap_sweep=False), dict(overlap_sweep="forward"), dict(lazy=True)])
+def test_adam_trajectory_dense_exact(golden, schedule, interleave):
+    """The ref:train/train.py:112-132 loop body x3 with DenseExactAdam vs torch.optim.Adam run in the
+    REFERENCE (fixture g2): every schedule -- default overlapped, serial, forward-announced, deferred --
+    against the reference trajectory, not against each other.  `interleave`: a no_grad eval forward and
+    an index_corpus() of more than 4 chunks between the training steps must leave no lookups behind
+    (needs_input_grad is True under no_grad)."""
     import two_tower_models_amd as A
     g = golden("g2_base_aligned")
     model = make_model("base", g)
-    opt = A.DenseExactAdam(model.parameters(), lr=1e-3)
+    opt = A.DenseExactAdam(model.parameters(), lr=1e-3, **schedule)
     losses = []
+    n_items, ii = int(g["cfg"][3]), int(g["cfg"][5])
+    cat_ids = torch.arange(n_items, device=DEV)
+    cat_feats = torch.zeros(n_items, ii, device=DEV)
     for s in range(3):
-        loss = model.train_forward(*batch_of(g, prefix=f"step{s}.in."))
+        b = batch_of(g, prefix=f"step{s}.in.")
+        if interleave:
+            with torch.no_grad():
+                model.train_forward(*b)
+                model(b[0], b[1], b[2])
+            model.index_corpus(cat_ids, cat_feats, chunk=max(n_items // 6, 1))
+        loss = model.train_forward(*b)
         opt.zero_grad()
         loss.backward()
         opt.step()
         losses.append(loss.item())
     assert np.allclose(losses, g["adam_losses"], atol=1e-4)
     assert opt.step_count == 3
+    opt.flush()
     after = state_of(g, prefix="after.")
     for k, v in model.state_dict().items():
         noise_only = float(np.abs(g["g." + k]).max()) < 1e-6  # see tests/test_oracle_golden.py
         atol = 2 * 3 * 1e-3 * 1.05 if noise_only else 5e-6
         assert torch.allclose(v.cpu(), after[k], atol=atol, rtol=1e-5), (k, float((v.cpu() - after[k]).abs().max()))
+
+
+def test_label_and_id_dtypes_follow_the_reference(golden):
+    """The reference type-promotes `labels * user_value_weights` and nn.Embedding takes int32 ids: integer /
+    bool labels and int32 ids give the float32 / int64 result; float64 labels take the torch expressions."""
+    g = golden("g2_base_aligned")
+    model = make_model("base", g)
+    b = batch_of(g)
+    want = model.train_forward(*b).item()
+    assert abs(want - float(g["loss"])) < 1e-4
+    lab = b[6]
+    if bool(((lab == 0) | (lab == 1)).all()):
+        for dt in (torch.int64, torch.bool, torch.int32):
+            assert abs(model.train_forward(*b[:6], lab.to(dt)).item() - want) < 1e-6
+    b32 = [b[0].to(torch.int32), b[1], b[2].to(torch.int32), b[3].to(torch.int32), b[4], b[5], b[6]]
+    assert abs(model.train_forward(*b32).item() - want) < 1e-6
+    l64 = model.train_forward(*b[:6], lab.double())
+    assert l64.dtype == torch.float64 and abs(l64.item() - want) < 1e-5
+    from two_tower_models_amd import ops
+    with pytest.raises(TypeError):
+        ops.WeightedMeanLoss.apply(torch.zeros(4, device=DEV), torch.zeros(4, 1, device=DEV, dtype=torch.float64),
+                                   torch.ones(1, device=DEV))
 
 
 def test_torch_optim_adam_also_works_unchanged(golden):

@@ -182,15 +182,25 @@ class _Scratch:
 
     def __init__(self):
         self._bufs = {}
+        self._captured = set()  # (device, slot) buffers whose address a captured hipGraph has baked in
+        self._retired = []  # such buffers after they were outgrown: kept alive for the graph's replays
 
     def get(self, dev: torch.device, nbytes: int, slot: str = "ws") -> torch.Tensor:
         key = (dev.index, slot)
         buf = self._bufs.get(key)
+        capturing = torch.cuda.is_current_stream_capturing()
         if buf is None or buf.numel() < nbytes:
-            if torch.cuda.is_current_stream_capturing():
+            if capturing:
                 raise RuntimeError("scratch buffer would grow during graph capture; run a warm-up step first")
+            if buf is not None and key in self._captured:
+                # an eager call after a capture needs more room: the graph keeps replaying into the old
+                # buffer, so it must never go back to the allocator
+                self._retired.append(buf)
+                self._captured.discard(key)
             buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=dev)
             self._bufs[key] = buf
+        if capturing:
+            self._captured.add(key)
         return buf
 
 

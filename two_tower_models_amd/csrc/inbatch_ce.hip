@@ -703,9 +703,12 @@ __global__ __launch_bounds__(1024) void weighted_mean_loss_kernel(const float* _
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float mx = NEG_BIG;
   for (int64_t i = threadIdx.x; i < B; i += blockDim.x) {
-    float nuv = 0.f;
-    for (int64_t t = 0; t < T; ++t) nuv += labels[i * T + t] * uvw[t];
-    nuv = fmaxf(nuv, 0.000001f);
+    float nuv = 1.f;
+    if (labels) {
+      nuv = 0.f;
+      for (int64_t t = 0; t < T; ++t) nuv += labels[i * T + t] * uvw[t];
+      nuv = fmaxf(nuv, 0.000001f);
+    }
     w_out[i] = nuv;
     mx = fmaxf(mx, nuv);
   }
@@ -994,7 +997,7 @@ extern "C" int tt_inbatch_ce_bwd_kept(const float* U, int64_t ldu, int64_t M, in
 extern "C" int tt_weighted_mean_loss(const float* labels, int64_t B, int64_t T, const float* uvw,
                                      const float* row_ce, float* w_out, float* coef_out, float* loss_out,
                                      tt_stream_t stream) {
-  if (!labels || !uvw || !row_ce || !w_out || !coef_out || !loss_out) return fail_arg("tt_weighted_mean_loss: null pointer");
+  if (!uvw || !row_ce || !w_out || !coef_out || !loss_out) return fail_arg("tt_weighted_mean_loss: null pointer");
   if (B <= 0 || T <= 0) return fail_arg("tt_weighted_mean_loss: sizes");
   weighted_mean_loss_kernel<<<1, 1024, 0, S(stream)>>>(labels, B, T, uvw, row_ce, w_out, coef_out, loss_out);
   return check_launch("weighted_mean_loss_kernel");

@@ -87,8 +87,10 @@ def colsum(X: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
 def gather_rows_into(table: torch.Tensor, ids: torch.Tensor, out: torch.Tensor) -> None:
     """out[i, :D] = table[ids[i]] ; `out` may be a column-slice view (row stride > D)."""
     dev = N.require_device(table, ids, out)
+    if ids.dtype == torch.int32:  # nn.Embedding accepts IntTensor as well
+        ids = ids.to(torch.int64)
     if ids.dtype != torch.int64:
-        raise TypeError("ids must be int64 (torch.long)")
+        raise TypeError("ids must be int64 or int32 (nn.Embedding's index types)")
     ids = ids.contiguous()
     pt, n_rows, D, ldt = _f32_2d(table, "table")
     if ldt != D:
@@ -236,13 +238,37 @@ def _route_table_grad(weight: torch.Tensor, ids: torch.Tensor, rows: torch.Tenso
 
 
 # ----------------------------------------------------------------- autograd Functions
-class EmbeddingLookup(torch.autograd.Function):
+_caller_grad_mode = [True]
+
+
+def _recording(ctx) -> bool:
+    """Is this lookup part of a forward that WILL be differentiated?  `ctx.needs_input_grad[0]` alone
+    mirrors `weight.requires_grad` even under torch.no_grad(), and inside Function.forward grad mode
+    is always off -- so the caller's grad mode is captured by `_LookupFunction.apply`.  An eval forward
+    or index_corpus() between two training steps must not leave id blocks with the optimiser."""
+    return bool(ctx.needs_input_grad[0]) and _caller_grad_mode[0]
+
+
+class _LookupFunction(torch.autograd.Function):
+    """Base of the Functions that read an embedding table: remembers the caller's grad mode."""
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        prev = _caller_grad_mode[0]
+        _caller_grad_mode[0] = torch.is_grad_enabled()
+        try:
+            return super().apply(*args, **kwargs)
+        finally:
+            _caller_grad_mode[0] = prev
+
+
+class EmbeddingLookup(_LookupFunction):
     """nn.Embedding.__call__ (ref:src/two_tower_base_retrieval.py:126,209)."""
 
     @staticmethod
     def forward(ctx, weight: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
         out = torch.empty(ids.numel(), weight.shape[1], dtype=torch.float32, device=weight.device)
-        src, row_ids, ctx.lookup_index = lookup_source(weight, ids, ctx.needs_input_grad[0])
+        src, row_ids, ctx.lookup_index = lookup_source(weight, ids, _recording(ctx))
         gather_rows_into(src, row_ids, out)
         ctx.weight = weight
         ctx.save_for_backward(ids)
@@ -319,7 +345,7 @@ class FeatureMLP(torch.autograd.Function):
         return dfe, dW1, db1, dW2, db2
 
 
-class TowerInput(torch.autograd.Function):
+class TowerInput(_LookupFunction):
     """[ table[ids] | Linear(256->D)(ReLU(Linear(F->256)(features))) ] written as two
     column slices of one [B, 2D] buffer -- the id lookup, the feature MLP and the
     torch.cat of ref:src/two_tower_base_retrieval.py:129-162 / :209-216."""
@@ -333,7 +359,7 @@ class TowerInput(torch.autograd.Function):
         Dm = W2.shape[0]
         Hd = W1.shape[0]
         tin = torch.empty(B, D + Dm, dtype=torch.float32, device=dev)
-        src, row_ids, ctx.lookup_index = lookup_source(weight, ids, ctx.needs_input_grad[0])
+        src, row_ids, ctx.lookup_index = lookup_source(weight, ids, _recording(ctx))
         gather_rows_into(src, row_ids, tin[:, :D])
         h = torch.empty(B, Hd, dtype=torch.float32, device=dev)
         gemm(N.TT_GEMM_NT, feats, W1, h, B, Hd, F, bias=b1, epilogue=N.TT_EPI_RELU)
@@ -447,19 +473,43 @@ class InBatchSoftmaxCE(torch.autograd.Function):
         return dU, dI, None, None
 
 
+def _labels_f32(labels: torch.Tensor, what: str) -> torch.Tensor:
+    """The kernels read `const float*`.  Integer / bool labels promote to float32 in the reference's
+    `labels * user_value_weights` too, so casting them is exact; any other float width would change
+    the reference's result dtype and is refused (the models route those to the torch expressions)."""
+    if labels.dtype == torch.float32:
+        return labels.contiguous()
+    if labels.dtype in (torch.bool, torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64):
+        return labels.to(torch.float32).contiguous()
+    raise TypeError(f"{what}: labels must be float32 or an integer / bool type, got {labels.dtype}")
+
+
+def labels_fusable(labels: torch.Tensor) -> bool:
+    return labels.dtype in (torch.float32, torch.bool, torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64)
+
+
 class WeightedMeanLoss(torch.autograd.Function):
     """mean_i(row_ce[i] * w[i]) with w = clamp(labels @ uvw, 1e-6) / max(...)
-    (ref:...base_retrieval.py:322,334-343, 2-D labels, identity debias hook)."""
+    (ref:...base_retrieval.py:322,334-343, 2-D labels, identity debias hook).  labels None: w = 1,
+    the value the same expressions produce for train.py's 1-D [B] labels."""
 
     @staticmethod
     def forward(ctx, row_ce, labels, uvw):
         dev = N.require_device(row_ce, labels, uvw)
-        labels = labels.contiguous()
-        B, T = labels.shape
+        if uvw.dtype != torch.float32 or row_ce.dtype != torch.float32:
+            raise TypeError("WeightedMeanLoss: row_ce and user_value_weights must be float32")
+        row_ce, uvw = row_ce.contiguous(), uvw.contiguous()
+        if labels is not None:
+            labels = _labels_f32(labels, "WeightedMeanLoss")
+            B, T = labels.shape
+            if uvw.numel() != T or row_ce.numel() != B:
+                raise RuntimeError("WeightedMeanLoss: labels [B, T], user_value_weights [T], row_ce [B]")
+        else:
+            B, T = row_ce.numel(), 1
         w = torch.empty(B, dtype=torch.float32, device=dev)
         coef = torch.empty(B, dtype=torch.float32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
-        N.check(N.load().tt_weighted_mean_loss(labels.data_ptr(), B, T, uvw.data_ptr(), row_ce.data_ptr(),
+        N.check(N.load().tt_weighted_mean_loss(N.ptr(labels), B, T, uvw.data_ptr(), row_ce.data_ptr(),
                                                w.data_ptr(), coef.data_ptr(), loss.data_ptr(), N.stream()),
                 "tt_weighted_mean_loss")
         ctx.save_for_backward(coef)
@@ -481,7 +531,9 @@ class DebiasedWeightedLoss(torch.autograd.Function):
     def forward(ctx, row_ce, labels, uvw, position, user_embedding, pos_table, lin_w, lin_b):
         dev = N.require_device(row_ce, labels, uvw, position, user_embedding, pos_table, lin_w, lin_b)
         lib = N.load()
-        labels, position = labels.contiguous(), position.contiguous()
+        labels, position = _labels_f32(labels, "DebiasedWeightedLoss"), position.contiguous()
+        if any(t.dtype != torch.float32 for t in (row_ce, uvw, user_embedding, pos_table, lin_w, lin_b)):
+            raise TypeError("DebiasedWeightedLoss: float32 operands expected")
         row_ce, ue = row_ce.contiguous(), _rowmajor(user_embedding)
         pos_table, lin_w, lin_b = pos_table.contiguous(), lin_w.contiguous(), lin_b.contiguous()
         B, T = labels.shape
@@ -526,7 +578,7 @@ def _attn_fwd(qkv, B, H, D, heads):
     return ctx_t, lse
 
 
-class HistoryEncoder(torch.autograd.Function):
+class HistoryEncoder(_LookupFunction):
     """UserHistoryEncoder.forward (ref:src/user_history_encoder.py:80-121), optionally
     fused with the history id lookup (ref:src/two_tower_with_user_history_encoder.py:105).
 
@@ -542,10 +594,12 @@ class HistoryEncoder(torch.autograd.Function):
         lib = N.load()
         ctx.lookup_index = None
         if ids is not None:
-            ids = ids.contiguous()
+            if ids.dtype not in (torch.int64, torch.int32):  # nn.Embedding accepts exactly these two
+                raise TypeError(f"user_history ids must be int64 or int32, got {ids.dtype}")
+            ids = ids.to(torch.int64).contiguous()  # tt_hist_embed_pool reads int64
             B, H = ids.shape
             D = source.shape[1]
-            src, row_ids, ctx.lookup_index = lookup_source(source, ids, ctx.needs_input_grad[0])
+            src, row_ids, ctx.lookup_index = lookup_source(source, ids, _recording(ctx))
             n_rows = src.shape[0]
             gather_ids = row_ids.reshape(B, H)
         else:

@@ -248,7 +248,9 @@ class DenseExactAdam(torch.optim.Optimizer):
 
     @property
     def step_count(self) -> int:
-        return 0 if self._hyper is None else int(self._hyper[4].item())
+        if not self._ready:  # fresh, or a checkpoint was loaded and no step has run since
+            return int(self._resume_step)
+        return int(self._hyper[4].item())
 
     def _side(self, p: torch.Tensor, nbytes: int) -> torch.Tensor:
         buf = self._side_bufs.get(id(p))

@@ -442,9 +442,15 @@ class ShardedTrainer:
                 self.params[name].copy_(dense_init[name].to(device))
             elif len(shape) == 2:
                 # nn.Linear default: U(-1/sqrt(fan_in), 1/sqrt(fan_in)); MultiheadAttention's packed
-                # in-projection: xavier-uniform.  Biases of the attention layers start at zero.
+                # in-projection: xavier-uniform.
                 bound = (math.sqrt(6.0 / (shape[0] + shape[1])) if name.endswith("in_proj_weight")
                          else 1.0 / math.sqrt(shape[1]))
+                self.params[name].copy_(((torch.rand(shape, generator=gen) * 2 - 1) * bound).to(device))
+                fan_in = shape[1]
+            elif "multihead_attn_layers" not in name:
+                # nn.Linear biases draw from the same U(-1/sqrt(fan_in), ..) as their weight (the entry
+                # just before); only the attention layers' in_proj / out_proj biases start at zero upstream
+                bound = 1.0 / math.sqrt(fan_in)
                 self.params[name].copy_(((torch.rand(shape, generator=gen) * 2 - 1) * bound).to(device))
             off += n
         broadcast_(self.flat_p, src=0)  # replicas must start bit-identical

@@ -152,8 +152,14 @@ class TwoTowerBaseRetrieval(nn.Module):
         The [B, B] logits are never materialised."""
         row_ce = ops.InBatchSoftmaxCE.apply(user_embedding, item_embeddings, 0)  # [B]
         hook_is_identity = type(self).debias_net_user_value is TwoTowerBaseRetrieval.debias_net_user_value
-        if hook_is_identity and labels.dim() == 2 and labels.shape[1] == self.user_value_weights.numel():
-            return ops.WeightedMeanLoss.apply(row_ce, labels, self.user_value_weights)
+        T = self.user_value_weights.numel()
+        if hook_is_identity and ops.labels_fusable(labels):
+            if labels.dim() == 2 and labels.shape[1] == T and labels.shape[0] == row_ce.shape[0]:
+                return ops.WeightedMeanLoss.apply(row_ce, labels, self.user_value_weights)
+            if labels.dim() == 1 and labels.shape[0] == row_ce.shape[0] and T in (1, labels.shape[0]):
+                # train.py's [B] labels (ref:train/train.py:53-55,78): labels * weights sums to ONE scalar,
+                # which clamp and / max turn into exactly 1.0 -- the plain mean of the row losses
+                return ops.WeightedMeanLoss.apply(row_ce, None, self.user_value_weights)
         # General path: exactly the reference's expressions on [B]-sized tensors, so every
         # broadcasting quirk (1-D labels collapsing to a scalar weight, SURVEY.md 3.1;
         # debias heads that differentiate through the weights) behaves identically.

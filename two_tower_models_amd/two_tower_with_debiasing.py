@@ -53,7 +53,7 @@ class TwoTowerWithDebiasing(TwoTowerWithUserHistoryEncoder):
         of another rank, take the reference's expressions (the base class's general path)."""
         hook_is_mine = type(self).debias_net_user_value is TwoTowerWithDebiasing.debias_net_user_value
         if not (_FUSED_HEAD and hook_is_mine and labels.dim() == 2 and labels.shape[1] == self.user_value_weights.numel()
-                and user_embedding.is_cuda):
+                and ops.labels_fusable(labels) and user_embedding.is_cuda):
             return super().compute_training_loss(user_embedding, item_embeddings, position, labels)
         row_ce = ops.InBatchSoftmaxCE.apply(user_embedding, item_embeddings, 0)  # [B]
         lin = self.user_debias_net_user_value[0]
