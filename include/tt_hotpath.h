@@ -326,6 +326,31 @@ int tt_attn_row0_bwd(const float* q0, int64_t ldq, const float* kv, int64_t ldkv
                      const float* d_ctx0, int64_t B, int64_t H, int64_t D, int64_t heads, float* d_q0,
                      float* d_kv, int64_t ld_dkv, tt_stream_t stream);
 
+/* ---------------------------------------------------------------- R1 owner routing (row-sharded tables)
+ * New design -- the reference has no parallelism.  Tables are split into `world`
+ * contiguous blocks of rows_per_rank rows; a rank asks each owner only for the ids that owner holds,
+ * through a padded fixed-capacity all-to-all (cap slots per peer).  Semantics to keep: the lookups of
+ * ref:src/two_tower_base_retrieval.py:126,209 and ref:src/two_tower_with_user_history_encoder.py:105.
+ * Input is the plan of the rank's OWN ids (tt_rowgrad_plan): sorted ids are grouped by owner.
+ *   tt_route_count    starts[o] (int32 [world+1]) = first sorted position owned by rank o; *max_count
+ *                     (device int32, atomicMax'ed: zero it first) = the largest bucket.  The caller
+ *                     all-reduces it (MAX) into `cap`.
+ *   tt_route_build    send_ids[o*cap + r] = r-th id owned by o (-1 = padding); slot_of[i] = slot in which
+ *                     the row of the caller's i-th id comes back; src_of[slot] = i (-1 = padding): the
+ *                     backward sends gradient row src_of[slot] in that slot.  A bucket larger than cap sets
+ *                     *overflow_flag and slot_of = -1 for the ids that did not fit (cannot happen when cap
+ *                     comes from the all-reduced count).
+ *   tt_route_localize owner side: local[i] = ids[i] - lo for lo <= ids[i] < lo + n_local, else the
+ *                     sentinel n_local (padding, foreign ids): tt_gather_rows then yields a zero row and
+ *                     the Adam kernels skip the run. */
+int tt_route_count(const int32_t* sorted_ids, int64_t n_ids, int64_t rows_per_rank, int32_t world,
+                   int32_t* starts, int32_t* max_count, tt_stream_t stream);
+int tt_route_build(const int32_t* sorted_ids, const int32_t* perm, int64_t n_ids, int64_t rows_per_rank,
+                   int32_t world, int64_t cap, const int32_t* starts, int64_t* send_ids, int64_t* slot_of,
+                   int64_t* src_of, int32_t* overflow_flag, tt_stream_t stream);
+int tt_route_localize(const int64_t* ids, int64_t n_ids, int64_t lo, int64_t n_local, int64_t* local,
+                      tt_stream_t stream);
+
 /* ---------------------------------------------------------------- K6 MIPS top-K
  * idx[b, 0:K], score[b, 0:K] = the K largest inner products q[b,:].corpus[c,:]
  * sorted by (score desc, index asc); replaces torch.topk(torch.matmul(q,

@@ -94,6 +94,9 @@ SIGNATURES = {
     "tt_attn_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "tt_attn_row0_fwd": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "tt_attn_row0_bwd": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp]),
+    "tt_route_count": (_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "tt_route_build": (_int, [_vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tt_route_localize": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "tt_mips_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64, _int]),
     "tt_mips_topk": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
     "tt_mips_merge_workspace_bytes": (_i64, [_i64, _i64]),
