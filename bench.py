@@ -326,8 +326,10 @@ def main():
             dist.init_process_group(dist_backend)
         n_ranks, dist_backend_seen = dist.get_world_size(), dist.get_backend()
         trainer = sharded.ShardedTrainer(cfg, device, negatives=args.negatives)  # cfg['model'] selects base / hist
-        step = trainer.step
         batches = trainer.make_batches(16)
+
+        def step(batch, nxt=None):  # the next batch's routes are planned underneath this step (no host wait)
+            trainer.step(batch, nxt)
     else:
         model = build_model(cfg, device)
         opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep=args.overlap, lazy=args.adam == "lazy")
@@ -383,7 +385,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    single = not use_sharded and not args.graph
+    single = not args.graph
 
     def run(i):
         if single:
@@ -480,6 +482,9 @@ def main():
             # what the collective library itself reports (1 when no process group was needed)
             "n_ranks": n_ranks, "dist_backend": dist_backend_seen,
         }
+        if use_sharded:  # bytes each rank sends to its peers per step, by exchange (sharded.py)
+            out["comm"] = {"routing": trainer.routing, "bytes_sent_per_rank_per_step": dict(trainer.comm_bytes),
+                           "total_MB": round(sum(trainer.comm_bytes.values()) / 1e6, 2)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         else:

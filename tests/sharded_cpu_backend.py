@@ -22,6 +22,38 @@ class OracleBackend:
         out[mine] = table[local[mine]]
         return out
 
+    def gather_rows(self, src, idx):
+        return self.gather_owned(src, torch.where((idx >= 0) & (idx < src.shape[0]), idx, torch.full_like(idx, src.shape[0])),
+                                 src.shape[0])
+
+    # owner routing: the CPU restatement of csrc/route.hip (stable sort by id groups the ids by owner)
+    def route_plan(self, ids, n_rows, rows_per_rank, world, max_out):
+        assert bool(((ids >= 0) & (ids < n_rows)).all()), "index out of range in self"
+        order = torch.sort(ids, stable=True)
+        owner = order.values // rows_per_rank
+        counts = torch.bincount(owner, minlength=world)
+        max_out.copy_(torch.maximum(max_out, counts.max().to(torch.int32).reshape(1)))
+        starts = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(counts, 0)])
+        return order.values, order.indices, starts
+
+    def route_build(self, planned, rows_per_rank, world, cap):
+        sorted_ids, perm, starts = planned
+        n = sorted_ids.numel()
+        owner = sorted_ids // rows_per_rank
+        slot = owner * cap + (torch.arange(n) - starts[owner])
+        assert bool((torch.arange(n) - starts[owner] < cap).all())
+        send_ids = torch.full((world * cap,), -1, dtype=torch.int64)
+        src_of = torch.full((world * cap,), -1, dtype=torch.int64)
+        slot_of = torch.empty(n, dtype=torch.int64)
+        send_ids[slot] = sorted_ids
+        src_of[slot] = perm
+        slot_of[perm] = slot
+        return send_ids, slot_of, src_of
+
+    def localize(self, ids, lo, n_local):
+        r = ids - lo
+        return torch.where((ids >= 0) & (r >= 0) & (r < n_local), r, torch.full_like(r, n_local))
+
     def tower_fwd(self, emb, feats, p, extra=None):
         W1, b1, W2, b2, W3, b3 = p
         h = torch.clamp(feats @ W1.t() + b1, min=0.0)

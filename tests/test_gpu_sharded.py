@@ -124,7 +124,7 @@ def _init_pg(backend, rank, world, port):
     return dev
 
 
-def _multi_worker(rank, world, port, outdir, cfg_name, negatives, backend="gloo"):
+def _multi_worker(rank, world, port, outdir, cfg_name, negatives, backend="gloo", routing="alltoall"):
     import os
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -138,12 +138,13 @@ def _multi_worker(rank, world, port, outdir, cfg_name, negatives, backend="gloo"
     dev = _init_pg(backend, rank, world, port)
     try:
         tr = sharded.ShardedTrainer(cfg, dev, negatives=negatives, user_value_weights=(0.7,),
-                                    dense_init=dense)
+                                    dense_init=dense, routing=routing)
         assert isinstance(tr.be, sharded.HipBackend)
         tr.users.weight[: tr.users.hi - tr.users.lo].copy_(ut[tr.users.lo:tr.users.hi])
         tr.items.weight[: tr.items.hi - tr.items.lo].copy_(it[tr.items.lo:tr.items.hi])
         batches = tr.make_batches(MULTI_STEPS, seed=99)
-        losses = [float(tr.step(b)) for b in batches]
+        # step 0 announces batch 1 (routes planned one step ahead); batch 2 arrives unannounced
+        losses = [float(tr.step(b, batches[i + 1] if i == 0 else None)) for i, b in enumerate(batches)]
         torch.cuda.synchronize()
         torch.save({"losses": losses, "users": tr.users.weight.cpu(), "items": tr.items.weight.cpu(),
                     "lo_hi": (tr.users.lo, tr.users.hi, tr.items.lo, tr.items.hi),
@@ -167,10 +168,13 @@ def _resolve_world(world, backend):
     return world
 
 
-@pytest.mark.parametrize("world,cfg_name,backend", [(2, "d128", "gloo"), (3, "ragged", "gloo"), (2, "hist", "gloo"),
-                                                    (2, "d128", "nccl"), ("all", "d128", "nccl"),
-                                                    ("all", "ragged", "nccl"), (2, "hist", "nccl")])
-def test_multi_rank_hip_backend_equals_reference_on_concatenated_batch(world, cfg_name, backend):
+@pytest.mark.parametrize("world,cfg_name,backend,routing",
+                         [(2, "d128", "gloo", "alltoall"), (3, "ragged", "gloo", "alltoall"), (2, "hist", "gloo", "alltoall"),
+                          (2, "d128", "gloo", "allgather"), (2, "hist", "gloo", "allgather"),
+                          (2, "d128", "nccl", "alltoall"), ("all", "d128", "nccl", "alltoall"),
+                          ("all", "ragged", "nccl", "alltoall"), (2, "hist", "nccl", "alltoall"),
+                          ("all", "d128", "nccl", "allgather")])
+def test_multi_rank_hip_backend_equals_reference_on_concatenated_batch(world, cfg_name, backend, routing):
     import os
     import tempfile
     import torch.multiprocessing as mp
@@ -178,7 +182,8 @@ def test_multi_rank_hip_backend_equals_reference_on_concatenated_batch(world, cf
     world = _resolve_world(world, backend)
     cfg = MULTI_CFGS[cfg_name]
     outdir = tempfile.mkdtemp()
-    mp.spawn(_multi_worker, args=(world, _free_port(), outdir, cfg_name, "global", backend), nprocs=world, join=True)
+    mp.spawn(_multi_worker, args=(world, _free_port(), outdir, cfg_name, "global", backend, routing), nprocs=world,
+             join=True)
     res = [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(world)]
     dense, ut, it = _multi_init(cfg)
     params = dict(dense)
@@ -254,3 +259,37 @@ def test_multi_rank_sharded_mips_hip_backend(world, C, K, backend):
         got = torch.load(os.path.join(outdir, f"mips{r}.pt"))
         assert torch.equal(got["idx"], want_idx[r * 6:(r + 1) * 6])
         assert torch.equal(got["sc"], want_sc[r * 6:(r + 1) * 6])
+
+
+@pytest.mark.parametrize("n,n_rows,world", [(8192, 10_000_000, 8), (240, 307, 2), (50_000, 1_000_003, 7), (64, 64, 64)])
+def test_route_kernels_match_cpu_restatement(n, n_rows, world):
+    """tt_route_count / tt_route_build / tt_route_localize (csrc/route.hip) against the test double's torch
+    restatement: bucket starts and maximum, slot assignment (stable within an owner), padding, the inverse map,
+    and the owner-side localisation with its sentinel."""
+    from sharded_cpu_backend import OracleBackend
+    from two_tower_models_amd import sharded
+    dev = torch.device("cuda:0")
+    be, cpu = sharded.HipBackend(dev), OracleBackend()
+    rpr = (n_rows + world - 1) // world
+    g = torch.Generator().manual_seed(n)
+    ids = torch.randint(0, n_rows, (n,), generator=g)
+    ids[: n // 8] = ids[n // 8: 2 * (n // 8)]  # duplicates
+    if world == 8:
+        ids[-2000:] = torch.randint(3 * rpr, 4 * rpr, (2000,), generator=g)  # a lopsided bucket
+    mx_d, mx_c = torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32)
+    pd = be.route_plan(ids.to(dev), n_rows, rpr, world, mx_d)
+    pc = cpu.route_plan(ids, n_rows, rpr, world, mx_c)
+    assert int(mx_d.item()) == int(mx_c.item())
+    assert torch.equal(pd[1].cpu().long(), pc[2])  # bucket starts
+    cap = (int(mx_c.item()) + 63) // 64 * 64
+    got = [t.cpu() for t in be.route_build(pd, rpr, world, cap)]
+    want = cpu.route_build(pc, rpr, world, cap)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    send_ids, slot_of, src_of = got
+    assert torch.equal(send_ids[slot_of], ids) and torch.equal(src_of[slot_of], torch.arange(n))
+    assert int((send_ids >= 0).sum()) == n
+    lo = 3 % world * rpr
+    n_local = max(min(lo + rpr, n_rows) - lo, 0)
+    loc = be.localize(send_ids.to(dev), lo, n_local).cpu()
+    assert torch.equal(loc, cpu.localize(send_ids, lo, n_local))

@@ -45,7 +45,7 @@ def _tables(cfg):
     return torch.randn(cfg["n_users"], cfg["D"], generator=g), torch.randn(cfg["n_items"], cfg["D"], generator=g)
 
 
-def _worker(rank, world, port, outdir, negatives):
+def _worker(rank, world, port, outdir, negatives, routing="alltoall"):
     for p in (ROOT, HERE, os.path.join(HERE, "golden")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -56,7 +56,7 @@ def _worker(rank, world, port, outdir, negatives):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         tr = sharded.ShardedTrainer(CFG, torch.device("cpu"), negatives=negatives, backend=OracleBackend(),
-                                    user_value_weights=(0.7,), dense_init=_dense_init(CFG))
+                                    user_value_weights=(0.7,), dense_init=_dense_init(CFG), routing=routing)
         ut, it = _tables(CFG)
         tr.users.weight.copy_(ut[tr.users.lo:tr.users.hi])
         tr.items.weight.copy_(it[tr.items.lo:tr.items.hi])
@@ -67,26 +67,33 @@ def _worker(rank, world, port, outdir, negatives):
         back = tr.state_dict()
         assert all(torch.equal(back[k], full[k]) for k in full), "state_dict round trip"
         batches = tr.make_batches(STEPS, seed=99)
-        losses = [float(tr.step(b)) for b in batches]
+        if routing == "alltoall":  # every id of step 1 on ONE owner: the most lopsided buckets there are
+            batches[1][0].fill_(int(batches[1][0][0]))
+            batches[1][3].copy_(batches[1][3] % max(tr.items.rows_per_rank, 1))
+        # routes of the next batch are planned one step ahead, except for the last one (planned on the spot)
+        losses = [float(tr.step(b, batches[i + 1] if i + 2 < len(batches) else None)) for i, b in enumerate(batches)]
         torch.save({"losses": losses, "users": tr.users.weight.clone(), "items": tr.items.weight.clone(),
                     "lo_hi": (tr.users.lo, tr.users.hi, tr.items.lo, tr.items.hi),
-                    "dense": {k: v.clone() for k, v in tr.params.items()},
+                    "dense": {k: v.clone() for k, v in tr.params.items()}, "comm": dict(tr.comm_bytes),
                     "batches": [tuple(t.clone() for t in b) for b in batches]},
                    os.path.join(outdir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
-def _run(world, negatives):
+def _run(world, negatives, routing="alltoall"):
     outdir = tempfile.mkdtemp()
-    mp.spawn(_worker, args=(world, _free_port(), outdir, negatives), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), outdir, negatives, routing), nprocs=world, join=True)
     return [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(world)]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_global_negatives_equal_reference_on_concatenated_batch(world):
+@pytest.mark.parametrize("world,routing", [(2, "alltoall"), (3, "alltoall"), (2, "allgather"), (3, "allgather")])
+def test_global_negatives_equal_reference_on_concatenated_batch(world, routing):
+    """`alltoall`: owners are sent only their own ids (padded fixed-capacity all-to-all, capacity all-reduced
+    one step ahead); `allgather`: round 1's fixed-size scheme.  Same reference semantics either way."""
     from oracle import cpu_ref as R
-    res = _run(world, "global")
+    res = _run(world, "global", routing)
+    assert ("lookup_rows_alltoall" in res[0]["comm"]) == (routing == "alltoall")
     ut, it = _tables(CFG)
     params = dict(_dense_init(CFG))
     params["user_id_embedding_arch.weight"] = ut.clone()

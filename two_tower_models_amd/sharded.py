@@ -9,20 +9,28 @@ Partitioning
   * both embedding tables are split into W contiguous row blocks; a rank owns the block and
     its Adam moments, and sweeps only its block (the HBM-bound part scales 1/W, no comms);
   * the batch is split by rank; dense MLP / tower parameters are replicated.
-Exchanges per step -- all FIXED size, so the step never synchronises with the host:
-  1. every rank's ids                        all_gather      [B] -> [W*B]          (x2 tables)
-     each owner gathers ITS rows for all W*B ids (zero rows for ids it does not own), then
-     rows to the requesting ranks            reduce_scatter  [W*B, D] -> [B, D]     (x2)
-     (one non-zero contribution per row, so the sum is exact)
+Exchanges per step, every size known to the host before the step starts:
+  1. lookups -- padded fixed-capacity all-to-all (`routing="alltoall"`, default).  A rank's ids are
+     stable-sorted (the row plan's radix sort), which groups them by owner; each owner is sent only
+     ITS ids, `cap` slots per peer, and returns the rows in the same slots:
+        ids   all_to_all  [W, cap] int64          rows  all_to_all  [W, cap, D]
+     `cap` = the largest (requester, owner) bucket over all ranks, rounded up to 64 -- exact, so
+     no id is ever dropped and there is no overflow path.  It is all-reduced (MAX, 3 ints) ONE STEP
+     AHEAD from the next batch's ids (`step(batch, next_batch)`), so the host never waits for it;
+     without `next_batch` the step synchronises once on that scalar.
   2. item embeddings                         all_gather      [B, D] -> [W*B, D]
   3. max of the value weights, loss          all_reduce      scalars
   4. partial dI over the gathered items      reduce_scatter  [W*B, D] -> [B, D]
   5. dense-parameter gradients (flat buffer) all_reduce      ~0.5 MB
-  6. embedding-row gradients                 all_gather      [B, D] -> [W*B, D]     (x2)
-     each owner keeps the rows it owns: ids of other ranks' blocks are mapped to a sentinel
-     row that the Adam kernels skip.
-For the base model these blocks are 4 MB per rank (32 MB gathered at W = 8), far below what
-a variable-size all_to_all would save once its host synchronisation is counted.
+  6. embedding-row gradients: back through the lookup's slots   all_to_all  [W, cap, D]
+     (each owner receives exactly the gradient rows of the ids it served, in the order it
+     served them; padding slots carry the sentinel row the Adam kernels skip).
+Per rank and step at W = 8, B = 8192, D = 128 the lookup traffic is 4 x W*cap*D*4 B ~ 4 x 4.7 MB
+(was 4 x 33.5 MB with the all-gather scheme below); with the history model B*H rows = 105 MB per
+direction (was 839 MB).  `trainer.comm_bytes` logs the bytes each exchange sends per step.
+`routing="allgather"` (TT_ROUTE=allgather) keeps round 1's fixed-size scheme as the A/B partner:
+all_gather of ids, every owner gathers W*B rows (zeros for foreign ids), reduce_scatter; row
+gradients all_gather'ed to every owner.
 Every rank then runs the dense-exact Adam of optim.py on its block, with the zero-gradient
 sweep on a side stream underneath steps 1-6.
 
@@ -116,10 +124,10 @@ def reduce_scatter_rows_start(x: torch.Tensor) -> _Pending:
     return _Pending(out, dist.reduce_scatter_tensor(out, x, async_op=True), x)
 
 
-def all_reduce_start_(x: torch.Tensor) -> _Pending:
+def all_reduce_start_(x: torch.Tensor, op=dist.ReduceOp.SUM) -> _Pending:
     if not _rccl_async(x):
-        return _Pending(all_reduce_(x) if dist.get_world_size() > 1 else x)
-    return _Pending(x, dist.all_reduce(x, async_op=True))
+        return _Pending(all_reduce_(x, op=op) if dist.get_world_size() > 1 else x)
+    return _Pending(x, dist.all_reduce(x, op=op, async_op=True))
 
 
 def all_reduce_(x: torch.Tensor, op=dist.ReduceOp.SUM) -> torch.Tensor:
@@ -151,6 +159,14 @@ def all_to_all_rows(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def all_to_all_rows_start(x: torch.Tensor) -> _Pending:
+    if not _rccl_async(x):
+        return _Pending(all_to_all_rows(x) if dist.get_world_size() > 1 else x)
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    return _Pending(out, dist.all_to_all_single(out, x, async_op=True), x)
+
+
 # ----------------------------------------------------------------- product backend
 class HipBackend:
     """All arithmetic on libtt_hotpath.so.  Raises if the library or the GPU is missing."""
@@ -179,6 +195,42 @@ class HipBackend:
         N.check(self.lib.tt_gather_rows(table.data_ptr(), n_local, table.shape[1], local.data_ptr(), local.numel(),
                                         out.data_ptr(), table.shape[1], None, N.stream()), "tt_gather_rows")
         return out
+
+    def gather_rows(self, src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """out[i] = src[idx[i]], a zero row where idx[i] is outside [0, len(src)) (padding slots)."""
+        return self.gather_owned(src, idx, src.shape[0])
+
+    # ---- owner routing (csrc/route.hip)
+    def route_plan(self, ids: torch.Tensor, n_rows: int, rows_per_rank: int, world: int, max_out: torch.Tensor):
+        """Stable sort of this rank's ids (groups them by owner) + bucket starts; the largest bucket is
+        atomicMax'ed into the int32 scalar view `max_out`.  Ids outside [0, n_rows) raise the device-side
+        out-of-range flag (IndexError at the next poll, like the single-GPU lookups)."""
+        N, lib = self.N, self.lib
+        plan = self.ops.RowPlan([ids], n_rows, slot="route")
+        starts = torch.empty(world + 1, dtype=torch.int32, device=self.device)
+        N.check(lib.tt_route_count(plan.sorted_ids.data_ptr(), plan.n, rows_per_rank, world, starts.data_ptr(),
+                                   max_out.data_ptr(), N.stream()), "tt_route_count")
+        return plan, starts
+
+    def route_build(self, planned, rows_per_rank: int, world: int, cap: int):
+        N, lib = self.N, self.lib
+        plan, starts = planned
+        send_ids = torch.empty(world * cap, dtype=torch.int64, device=self.device)
+        src_of = torch.empty(world * cap, dtype=torch.int64, device=self.device)
+        slot_of = torch.empty(plan.n, dtype=torch.int64, device=self.device)
+        N.check(lib.tt_route_build(plan.sorted_ids.data_ptr(), plan.perm.data_ptr(), plan.n, rows_per_rank, world, cap,
+                                   starts.data_ptr(), send_ids.data_ptr(), slot_of.data_ptr(), src_of.data_ptr(),
+                                   N.oob.flag(self.device).data_ptr(), N.stream()), "tt_route_build")
+        return send_ids, slot_of, src_of
+
+    def localize(self, ids: torch.Tensor, lo: int, n_local: int) -> torch.Tensor:
+        out = torch.empty_like(ids)
+        self.N.check(self.lib.tt_route_localize(ids.data_ptr(), ids.numel(), lo, n_local, out.data_ptr(), self.N.stream()),
+                     "tt_route_localize")
+        return out
+
+    def poll(self) -> None:
+        self.N.oob.poll(self.device)
 
     def tower_fwd(self, emb: torch.Tensor, feats: torch.Tensor, p: Sequence[torch.Tensor],
                   extra: Optional[torch.Tensor] = None):
@@ -385,6 +437,32 @@ class Lookup:
         self.local = torch.where(owned, local, torch.full_like(local, self.n_local))
 
 
+class _PlannedRoutes:
+    """The routing of one batch's lookups as far as it can be prepared without knowing `cap`: per lookup
+    the sorted ids + bucket starts, and the all-reduced bucket maxima on their way to the host."""
+
+    __slots__ = ("key", "planned", "counts_host", "event", "keep")
+
+    def __init__(self, key, planned, counts_host, event, keep):
+        self.key, self.planned, self.counts_host, self.event, self.keep = key, planned, counts_host, event, keep
+
+    def caps(self) -> List[int]:
+        if self.event is not None:
+            self.event.synchronize()  # planned a step ahead: long complete, no wait
+        return [max(64, (int(c) + 63) // 64 * 64) for c in self.counts_host.tolist()]
+
+
+class _RoutedLookup:
+    """One lookup in flight: requester side (slot_of, src_of) and owner side (local, n_local)."""
+
+    __slots__ = ("table", "cap", "slot_of", "src_of", "ids_p", "rows_p", "local", "n_local")
+
+    def __init__(self, table, cap, slot_of, src_of, ids_p):
+        self.table, self.cap, self.slot_of, self.src_of, self.ids_p = table, cap, slot_of, src_of, ids_p
+        self.rows_p, self.local = None, None
+        self.n_local = table.hi - table.lo
+
+
 class ShardedTrainer:
     """TwoTowerBaseRetrieval train step (ref:src/two_tower_base_retrieval.py:349-394 +
     ref:train/train.py:112-125) on W row-sharded ranks.  `cfg`: n_users, n_items, D, F, B; with
@@ -394,10 +472,15 @@ class ShardedTrainer:
 
     def __init__(self, cfg: Dict, device: torch.device, negatives: str = "global", backend=None,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, user_value_weights=(1.0,), seed: int = 0,
-                 dense_init: Optional[Dict[str, torch.Tensor]] = None):
+                 dense_init: Optional[Dict[str, torch.Tensor]] = None, routing: Optional[str] = None):
         if not dist.is_initialized():
             raise RuntimeError("ShardedTrainer needs torch.distributed to be initialised")
         self.cfg, self.device, self.negatives = dict(cfg), device, negatives
+        self.routing = routing or os.environ.get("TT_ROUTE", "alltoall")  # A/B switch
+        if self.routing not in ("alltoall", "allgather"):
+            raise ValueError("routing must be 'alltoall' or 'allgather'")
+        self._planned_next: Optional[_PlannedRoutes] = None
+        self.comm_bytes: Dict[str, int] = {}  # bytes this rank SENDS to other ranks per step, by exchange
         self.W, self.rank = dist.get_world_size(), dist.get_rank()
         self.be = backend if backend is not None else HipBackend(device)
         D, F = cfg["D"], cfg["F"]
@@ -536,7 +619,148 @@ class ShardedTrainer:
         partial = self.be.gather_owned(table.weight, lk.local, lk.n_local)  # [W*B, D], zeros if not mine
         return lk, reduce_scatter_rows_start(partial)
 
-    def step(self, batch) -> torch.Tensor:
+    # ---- routed lookups (padded all-to-all)
+    def _route_specs(self, batch):
+        specs = [(self.users, batch[0].reshape(-1))]
+        if self.hist:  # history rows first: the reference's lookup order on the item table
+            specs.append((self.items, batch[2].reshape(-1)))
+        specs.append((self.items, batch[3].reshape(-1)))
+        return specs
+
+    @staticmethod
+    def _route_key(batch):
+        return tuple((t.data_ptr(), t.numel()) for t in (batch[0], batch[2], batch[3]))
+
+    def plan_routes(self, batch) -> _PlannedRoutes:
+        """Sort each lookup's ids by owner and start the all-reduce (MAX) of the bucket maxima + its copy to
+        the host.  Called for the NEXT batch from inside `step`, so the answer is there long before the host
+        needs it; a batch that was not announced is planned on the spot (one host synchronisation)."""
+        specs = self._route_specs(batch)
+        counts = torch.zeros(len(specs), dtype=torch.int32, device=self.device)
+        planned, keep = [], []
+        for k, (table, ids) in enumerate(specs):
+            if ids.dtype != torch.int64 or not ids.is_contiguous():
+                ids = ids.to(torch.int64).contiguous()
+            keep.append(ids)
+            planned.append(self.be.route_plan(ids, table.n_rows, table.rows_per_rank, self.W, counts[k:k + 1]))
+        if self.W > 1:
+            all_reduce_start_(counts, op=dist.ReduceOp.MAX).wait()
+        if counts.is_cuda:
+            host = torch.empty(len(specs), dtype=torch.int32).pin_memory()
+            host.copy_(counts, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
+            keep.append(counts)
+        else:
+            host, event = counts, None
+        return _PlannedRoutes(self._route_key(batch), planned, host, event, keep)
+
+    def step(self, batch, next_batch=None) -> torch.Tensor:
+        """One train step on this rank's B rows.  `next_batch` (optional): the batch the NEXT call will
+        bring -- its routes are planned underneath this step, which removes the step's only host wait."""
+        if self.routing == "allgather":
+            return self._step_allgather(batch)
+        user_id, user_feat, hist_ids, item_id, item_feat, _pos, labels = batch
+        be, W, D, B = self.be, self.W, self.cfg["D"], user_id.shape[0]
+        if hasattr(be, "poll"):
+            be.poll()  # an out-of-range id seen by an earlier step surfaces here as IndexError
+        routes = self._planned_next
+        self._planned_next = None
+        if routes is None or routes.key != self._route_key(batch):
+            routes = self.plan_routes(batch)
+        caps = routes.caps()
+        # 1. each owner is sent the ids it holds (cap slots per peer), and returns the rows in the same slots
+        lks: List[_RoutedLookup] = []
+        sent_ids = sent_rows = 0
+        for (table, _ids), planned, cap in zip(self._route_specs(batch), routes.planned, caps):
+            send_ids, slot_of, src_of = be.route_build(planned, table.rows_per_rank, W, cap)
+            lks.append(_RoutedLookup(table, cap, slot_of, src_of, all_to_all_rows_start(send_ids)))
+            sent_ids += (W - 1) * cap * 8
+            sent_rows += (W - 1) * cap * D * 4
+        for lk in lks:
+            lk.local = be.localize(lk.ids_p.wait(), lk.table.lo, lk.n_local)  # sentinel n_local for padding
+            lk.rows_p = all_to_all_rows_start(be.gather_owned(lk.table.weight, lk.local, lk.n_local))
+        lk_u, lk_i = lks[0], lks[-1]
+        lk_h = lks[1] if self.hist else None
+        if next_batch is not None:
+            self._planned_next = self.plan_routes(next_batch)
+        item_local = torch.cat([lk_h.local, lk_i.local]) if self.hist else lk_i.local
+        # the tables' old rows have been read: plan, park the looked-up rows, and start the
+        # zero-gradient sweep on the side stream -- it overlaps everything up to step 6
+        be.adam_advance(self.hyper)
+        st_u = be.adam_table_begin(self.users.weight, self.users.m, self.users.v, lk_u.n_local, lk_u.local)
+        st_i = be.adam_table_begin(self.items.weight, self.items.m, self.items.v, lk_i.n_local, item_local)
+        sweep = [(self.users.weight, self.users.m, self.users.v, lk_u.n_local),
+                 (self.items.weight, self.items.m, self.items.v, lk_i.n_local)]
+        if not self._sweep_late:
+            be.sweep_async(sweep, self.hyper)
+        pu, pi = self._tower_params("user"), self._tower_params("item")
+        summary, enc_saved = None, None
+        u_emb = be.gather_rows(lk_u.rows_p.wait(), lk_u.slot_of)  # the other exchanges are still in flight
+        if self.hist:
+            enc_params = [self.params[k] for k in self.encoder_keys]
+            h_rows = be.gather_rows(lk_h.rows_p.wait(), lk_h.slot_of)
+            summary3, enc_saved = be.encoder_fwd(h_rows.view(B, -1, D), self.pe, self.heads, enc_params)
+            summary = summary3.reshape(B, 2 * D)
+        u_h, u_f, U = be.tower_fwd(u_emb, user_feat, pu, extra=summary)
+        i_emb = be.gather_rows(lk_i.rows_p.wait(), lk_i.slot_of)
+        i_h, i_f, I = be.tower_fwd(i_emb, item_feat, pi)
+        # 2. logits against every rank's items
+        glob = self.negatives == "global" and W > 1
+        I_all = all_gather_rows(I) if glob else I
+        off = self.rank * B if glob else 0
+        if self._sweep_late:  # a short sweep hides under the logits kernels instead of the small tower GEMMs
+            be.sweep_async(sweep, self.hyper)
+        ce, lse = be.ce_fwd(U, I_all, off)
+        loss, coef = self._weighted_loss(ce, labels, B, glob)
+        # 4. backward through the loss
+        dU, dI_all = be.ce_bwd(U, I_all, off, lse, coef)
+        dI_p = reduce_scatter_rows_start(dI_all) if glob else _Pending(dI_all)  # travels under the user tower backward
+        # 5. towers backward -> dense grads (flat buffer) + embedding-row grads; each row-gradient block
+        # goes back through its lookup's slots as soon as it exists
+        d_urows, d_summary = be.tower_bwd(dU, u_emb, u_h, u_f, user_feat, pu, self._tower_grads("user"), extra=summary)
+        g_u_p = all_to_all_rows_start(be.gather_rows(d_urows, lk_u.src_of))  # aligned with lk_u.local
+        g_h_p = None
+        if self.hist:
+            d_hrows = be.encoder_bwd(enc_saved, d_summary.view(B, 2, D), [self.grads[k] for k in self.encoder_keys])
+            g_h_p = all_to_all_rows_start(be.gather_rows(d_hrows, lk_h.src_of))
+        d_irows, _ = be.tower_bwd(dI_p.wait(), i_emb, i_h, i_f, item_feat, pi, self._tower_grads("item"))
+        g_i_p = all_to_all_rows_start(be.gather_rows(d_irows, lk_i.src_of))
+        flat_p = all_reduce_start_(self.flat_g)  # every dense gradient has been written by now
+        g_u, g_i = g_u_p.wait(), g_i_p.wait()
+        if self.hist:  # aligned with item_local = [history ids | item ids]
+            g_i = torch.cat([g_h_p.wait(), g_i])
+        flat_p.wait()
+        # 6. dense-exact Adam: the looked-up rows of this rank's blocks, over the swept tables
+        be.sweep_wait()
+        be.adam_table_finish(self.users.weight, self.users.m, self.users.v, self.hyper, st_u, g_u)
+        be.adam_table_finish(self.items.weight, self.items.m, self.items.v, self.hyper, st_i, g_i)
+        be.adam_dense(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.hyper)
+        self.comm_bytes = {"lookup_ids_alltoall": sent_ids, "lookup_rows_alltoall": sent_rows,
+                           "rowgrad_alltoall": sent_rows,
+                           "item_emb_allgather": (W - 1) * B * D * 4 if glob else 0,
+                           "dI_reduce_scatter": (W - 1) * B * D * 4 if glob else 0,
+                           "dense_grad_allreduce": int(2 * (W - 1) / W * self.flat_g.numel() * 4),
+                           "scalars": 3 * 4 * (W - 1)}
+        return loss
+
+    def _weighted_loss(self, ce, labels, B, glob):
+        """Value weights (ref :322,334-343) with the max / mean taken over the global batch -> (loss, dL/dce)."""
+        nuv = torch.clamp(torch.sum(labels * self.uvw, dim=-1), min=0.000001)
+        nmax = nuv.max()
+        if glob:
+            all_reduce_(nmax, op=dist.ReduceOp.MAX)
+        w = nuv / nmax
+        denom = float(B * self.W)  # global negatives: mean over W*B rows; local: mean of W per-rank means
+        coef = (w / denom).contiguous()
+        loss = (ce * w).sum() / denom
+        all_reduce_(loss)
+        self.last_loss = loss
+        return loss, coef
+
+    def _step_allgather(self, batch) -> torch.Tensor:
+        """Round 1's fixed-size routing (A/B partner, `routing="allgather"`): all_gather of ids, every owner
+        gathers W*B rows (zeros for foreign ids), reduce_scatter; row gradients all_gather'ed to every owner."""
         user_id, user_feat, hist_ids, item_id, item_feat, _pos, labels = batch
         be, W, D, B = self.be, self.W, self.cfg["D"], user_id.shape[0]
         # 1. embedding rows of the local batch, served by the owning ranks
@@ -572,16 +796,7 @@ class ShardedTrainer:
             be.sweep_async(sweep, self.hyper)
         ce, lse = be.ce_fwd(U, I_all, off)
         # 3. value weights (ref :322,334-343) with the max / mean taken over the global batch
-        nuv = torch.clamp(torch.sum(labels * self.uvw, dim=-1), min=0.000001)
-        nmax = nuv.max()
-        if glob:
-            all_reduce_(nmax, op=dist.ReduceOp.MAX)
-        w = nuv / nmax
-        denom = float(B * W)  # global negatives: mean over W*B rows; local: mean of W per-rank means
-        coef = (w / denom).contiguous()
-        loss = (ce * w).sum() / denom
-        all_reduce_(loss)
-        self.last_loss = loss
+        loss, coef = self._weighted_loss(ce, labels, B, glob)
         # 4. backward through the loss
         dU, dI_all = be.ce_bwd(U, I_all, off, lse, coef)
         dI_p = reduce_scatter_rows_start(dI_all) if glob else _Pending(dI_all)  # travels under the user tower backward
@@ -605,6 +820,14 @@ class ShardedTrainer:
         be.adam_table_finish(self.users.weight, self.users.m, self.users.v, self.hyper, st_u, g_u)
         be.adam_table_finish(self.items.weight, self.items.m, self.items.v, self.hyper, st_i, g_i)
         be.adam_dense(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.hyper)
+        n_rows_looked_up = B * (2 + (hist_ids.shape[1] if self.hist else 0))
+        self.comm_bytes = {"lookup_ids_allgather": (W - 1) * n_rows_looked_up * 8,
+                           "lookup_rows_reduce_scatter": (W - 1) * n_rows_looked_up * D * 4,
+                           "rowgrad_allgather": (W - 1) * n_rows_looked_up * D * 4,
+                           "item_emb_allgather": (W - 1) * B * D * 4 if glob else 0,
+                           "dI_reduce_scatter": (W - 1) * B * D * 4 if glob else 0,
+                           "dense_grad_allreduce": int(2 * (W - 1) / W * self.flat_g.numel() * 4),
+                           "scalars": 3 * 4 * (W - 1)}
         return loss
 
 
