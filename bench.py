@@ -278,6 +278,11 @@ def main():
     ap.add_argument("--overlap", default="forward", choices=["forward", "zero_grad", "off"],
                     help="when DenseExactAdam starts the table sweep (optim.py); all three are bit-identical")
     ap.add_argument("--sharded", action="store_true", help="use the row-sharded trainer even at --gpus 1")
+    ap.add_argument("--routing", default=None, choices=["alltoall", "allgather"],
+                    help="sharded lookups: padded all-to-all to the owning ranks (default) or round 1's all-gather scheme")
+    ap.add_argument("--transport", default=None, choices=["torch", "native"],
+                    help="sharded collectives through torch.distributed's process group (default) or the C ABI's "
+                         "tt_comm_* (RCCL bound by libtt_hotpath.so)")
     ap.add_argument("--fresh-ids", action="store_true",
                     help="draw new uniform user / item ids on the device every step instead of cycling 16 batches "
                          "(the deferred schedule's steady state: every lookup hits rows that idled for ~N/B steps)")
@@ -325,7 +330,8 @@ def main():
         else:
             dist.init_process_group(dist_backend)
         n_ranks, dist_backend_seen = dist.get_world_size(), dist.get_backend()
-        trainer = sharded.ShardedTrainer(cfg, device, negatives=args.negatives)  # cfg['model'] selects base / hist
+        trainer = sharded.ShardedTrainer(cfg, device, negatives=args.negatives, routing=args.routing,
+                                         transport=args.transport)  # cfg['model'] selects base / hist
         batches = trainer.make_batches(16)
 
         def step(batch, nxt=None):  # the next batch's routes are planned underneath this step (no host wait)
@@ -483,7 +489,7 @@ def main():
             "n_ranks": n_ranks, "dist_backend": dist_backend_seen,
         }
         if use_sharded:  # bytes each rank sends to its peers per step, by exchange (sharded.py)
-            out["comm"] = {"routing": trainer.routing, "bytes_sent_per_rank_per_step": dict(trainer.comm_bytes),
+            out["comm"] = {"routing": trainer.routing, "transport": trainer.transport, "bytes_sent_per_rank_per_step": dict(trainer.comm_bytes),
                            "total_MB": round(sum(trainer.comm_bytes.values()) / 1e6, 2)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)

@@ -331,25 +331,65 @@ int tt_attn_row0_bwd(const float* q0, int64_t ldq, const float* kv, int64_t ldkv
  * contiguous blocks of rows_per_rank rows; a rank asks each owner only for the ids that owner holds,
  * through a padded fixed-capacity all-to-all (cap slots per peer).  Semantics to keep: the lookups of
  * ref:src/two_tower_base_retrieval.py:126,209 and ref:src/two_tower_with_user_history_encoder.py:105.
- * Input is the plan of the rank's OWN ids (tt_rowgrad_plan): sorted ids are grouped by owner.
- *   tt_route_count    starts[o] (int32 [world+1]) = first sorted position owned by rank o; *max_count
- *                     (device int32, atomicMax'ed: zero it first) = the largest bucket.  The caller
- *                     all-reduces it (MAX) into `cap`.
- *   tt_route_build    send_ids[o*cap + r] = r-th id owned by o (-1 = padding); slot_of[i] = slot in which
- *                     the row of the caller's i-th id comes back; src_of[slot] = i (-1 = padding): the
- *                     backward sends gradient row src_of[slot] in that slot.  A bucket larger than cap sets
+ * Bucketing a rank's ids by owner (= id / rows_per_rank) is one stable counting pass; slots are assigned in
+ * list order, so an owner sees the ids of one requester in request order.
+ *   tt_route_count    counts[o] (int32 [world]) = ids owned by rank o; *max_count (device int32, atomicMax'ed:
+ *                     zero it first) = the largest bucket -- the caller all-reduces it (MAX) into `cap`.  Leaves
+ *                     per-tile offsets in `ws` (tt_route_workspace_bytes) for tt_route_build.  Ids outside
+ *                     [0, n_rows) set *oob_flag (may be NULL) and are routed as row 0.
+ *   tt_route_build    (same ids, same ws) send_ids[o*cap + r] = r-th id owned by o (-1 = padding); slot_of[i] =
+ *                     slot in which the row of the caller's i-th id comes back; src_of[slot] = i (-1 = padding):
+ *                     the backward sends gradient row src_of[slot] in that slot.  A bucket larger than cap sets
  *                     *overflow_flag and slot_of = -1 for the ids that did not fit (cannot happen when cap
- *                     comes from the all-reduced count).
+ *                     comes from the all-reduced count).  world <= 1024.
  *   tt_route_localize owner side: local[i] = ids[i] - lo for lo <= ids[i] < lo + n_local, else the
  *                     sentinel n_local (padding, foreign ids): tt_gather_rows then yields a zero row and
  *                     the Adam kernels skip the run. */
-int tt_route_count(const int32_t* sorted_ids, int64_t n_ids, int64_t rows_per_rank, int32_t world,
-                   int32_t* starts, int32_t* max_count, tt_stream_t stream);
-int tt_route_build(const int32_t* sorted_ids, const int32_t* perm, int64_t n_ids, int64_t rows_per_rank,
-                   int32_t world, int64_t cap, const int32_t* starts, int64_t* send_ids, int64_t* slot_of,
+int64_t tt_route_workspace_bytes(int64_t n_ids, int32_t world);
+int tt_route_count(const int64_t* ids, int64_t n_ids, int64_t n_rows, int64_t rows_per_rank, int32_t world,
+                   int32_t* counts, int32_t* max_count, int32_t* oob_flag, void* ws, int64_t ws_bytes,
+                   tt_stream_t stream);
+int tt_route_build(const int64_t* ids, int64_t n_ids, int64_t n_rows, int64_t rows_per_rank, int32_t world,
+                   int64_t cap, const void* ws, int64_t ws_bytes, int64_t* send_ids, int64_t* slot_of,
                    int64_t* src_of, int32_t* overflow_flag, tt_stream_t stream);
 int tt_route_localize(const int64_t* ids, int64_t n_ids, int64_t lo, int64_t n_local, int64_t* local,
                       tt_stream_t stream);
+
+/* ---------------------------------------------------------------- R collectives (RCCL over xGMI)
+ * New design (SURVEY.md 2b R1-R4, 8b "tt_comm_*"): the reference has no communication.  One communicator per
+ * process (= per GPU: the current HIP device at tt_comm_init), created from a 128-byte id that rank 0 obtains
+ * with tt_comm_unique_id and hands to the other ranks by any host-side channel.  The handle is the ONLY
+ * long-lived native state of this library.  RCCL is bound at run time (librccl.so.1; TT_RCCL_PATH overrides):
+ * without it these return TT_E_UNSUPPORTED and everything else keeps working.  RCCL failures return
+ * -(100 + ncclResult_t).  All calls are asynchronous on `stream`; counts are in ELEMENTS of `dtype`.
+ *   tt_comm_alltoall       chunk r of `send` (count_per_peer elements) goes to rank r; chunk r of `recv` came
+ *                          from rank r -- routed lookups: ids, rows, row gradients (R1)
+ *   tt_comm_allgather      item embeddings for the global in-batch negatives (R2)
+ *   tt_comm_reduce_scatter partial dI over the gathered items -> this rank's block (R2)
+ *   tt_comm_allreduce      dense gradients (SUM), value-weight / bucket maxima (MAX), loss (SUM) (R3); in place
+ *                          when send == recv
+ *   tt_comm_broadcast      replicated parameters at start-up */
+#define TT_COMM_ID_BYTES 128
+#define TT_COMM_F32 0
+#define TT_COMM_I32 1
+#define TT_COMM_I64 2
+#define TT_COMM_U8 3
+#define TT_COMM_SUM 0
+#define TT_COMM_MAX 1
+typedef struct tt_comm_s* tt_comm_t;
+int tt_comm_unique_id(void* id_out /* host, TT_COMM_ID_BYTES */);
+int tt_comm_init(const void* id /* host, TT_COMM_ID_BYTES */, int32_t rank, int32_t world, tt_comm_t* out);
+int tt_comm_destroy(tt_comm_t comm);
+int tt_comm_size(tt_comm_t comm, int32_t* rank_out, int32_t* world_out /* as RCCL reports it */);
+int tt_comm_alltoall(tt_comm_t comm, const void* send, void* recv, int64_t count_per_peer, int dtype,
+                     tt_stream_t stream);
+int tt_comm_allgather(tt_comm_t comm, const void* send, void* recv, int64_t count_per_rank, int dtype,
+                      tt_stream_t stream);
+int tt_comm_reduce_scatter(tt_comm_t comm, const void* send, void* recv, int64_t count_per_rank, int dtype, int op,
+                           tt_stream_t stream);
+int tt_comm_allreduce(tt_comm_t comm, const void* send, void* recv, int64_t count, int dtype, int op,
+                      tt_stream_t stream);
+int tt_comm_broadcast(tt_comm_t comm, void* buf, int64_t count, int dtype, int32_t root, tt_stream_t stream);
 
 /* ---------------------------------------------------------------- K6 MIPS top-K
  * idx[b, 0:K], score[b, 0:K] = the K largest inner products q[b,:].corpus[c,:]

@@ -26,28 +26,27 @@ class OracleBackend:
         return self.gather_owned(src, torch.where((idx >= 0) & (idx < src.shape[0]), idx, torch.full_like(idx, src.shape[0])),
                                  src.shape[0])
 
-    # owner routing: the CPU restatement of csrc/route.hip (stable sort by id groups the ids by owner)
+    # owner routing: the CPU restatement of csrc/route.hip (stable bucketing by owner, list order inside a bucket)
     def route_plan(self, ids, n_rows, rows_per_rank, world, max_out):
         assert bool(((ids >= 0) & (ids < n_rows)).all()), "index out of range in self"
-        order = torch.sort(ids, stable=True)
-        owner = order.values // rows_per_rank
+        owner = ids // rows_per_rank
         counts = torch.bincount(owner, minlength=world)
         max_out.copy_(torch.maximum(max_out, counts.max().to(torch.int32).reshape(1)))
-        starts = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(counts, 0)])
-        return order.values, order.indices, starts
+        return ids, owner, counts
 
     def route_build(self, planned, rows_per_rank, world, cap):
-        sorted_ids, perm, starts = planned
-        n = sorted_ids.numel()
-        owner = sorted_ids // rows_per_rank
-        slot = owner * cap + (torch.arange(n) - starts[owner])
-        assert bool((torch.arange(n) - starts[owner] < cap).all())
+        ids, owner, counts = planned
+        n = ids.numel()
+        order = torch.sort(owner, stable=True).indices  # positions grouped by owner, list order inside
+        starts = torch.cumsum(counts, 0) - counts
+        rank = torch.empty(n, dtype=torch.int64)
+        rank[order] = torch.arange(n) - starts[owner[order]]
+        assert bool((rank < cap).all())
+        slot_of = owner * cap + rank
         send_ids = torch.full((world * cap,), -1, dtype=torch.int64)
         src_of = torch.full((world * cap,), -1, dtype=torch.int64)
-        slot_of = torch.empty(n, dtype=torch.int64)
-        send_ids[slot] = sorted_ids
-        src_of[slot] = perm
-        slot_of[perm] = slot
+        send_ids[slot_of] = ids
+        src_of[slot_of] = torch.arange(n)
         return send_ids, slot_of, src_of
 
     def localize(self, ids, lo, n_local):

@@ -124,7 +124,7 @@ def _init_pg(backend, rank, world, port):
     return dev
 
 
-def _multi_worker(rank, world, port, outdir, cfg_name, negatives, backend="gloo", routing="alltoall"):
+def _multi_worker(rank, world, port, outdir, cfg_name, negatives, backend="gloo", routing="alltoall", transport="torch"):
     import os
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -138,8 +138,9 @@ def _multi_worker(rank, world, port, outdir, cfg_name, negatives, backend="gloo"
     dev = _init_pg(backend, rank, world, port)
     try:
         tr = sharded.ShardedTrainer(cfg, dev, negatives=negatives, user_value_weights=(0.7,),
-                                    dense_init=dense, routing=routing)
+                                    dense_init=dense, routing=routing, transport=transport)
         assert isinstance(tr.be, sharded.HipBackend)
+        assert (sharded._NATIVE is not None) == (transport == "native")
         tr.users.weight[: tr.users.hi - tr.users.lo].copy_(ut[tr.users.lo:tr.users.hi])
         tr.items.weight[: tr.items.hi - tr.items.lo].copy_(it[tr.items.lo:tr.items.hi])
         batches = tr.make_batches(MULTI_STEPS, seed=99)
@@ -168,13 +169,18 @@ def _resolve_world(world, backend):
     return world
 
 
-@pytest.mark.parametrize("world,cfg_name,backend,routing",
-                         [(2, "d128", "gloo", "alltoall"), (3, "ragged", "gloo", "alltoall"), (2, "hist", "gloo", "alltoall"),
-                          (2, "d128", "gloo", "allgather"), (2, "hist", "gloo", "allgather"),
-                          (2, "d128", "nccl", "alltoall"), ("all", "d128", "nccl", "alltoall"),
-                          ("all", "ragged", "nccl", "alltoall"), (2, "hist", "nccl", "alltoall"),
-                          ("all", "d128", "nccl", "allgather")])
-def test_multi_rank_hip_backend_equals_reference_on_concatenated_batch(world, cfg_name, backend, routing):
+@pytest.mark.parametrize("world,cfg_name,backend,routing,transport",
+                         [(2, "d128", "gloo", "alltoall", "torch"), (3, "ragged", "gloo", "alltoall", "torch"),
+                          (2, "hist", "gloo", "alltoall", "torch"), (2, "d128", "gloo", "allgather", "torch"),
+                          (2, "hist", "gloo", "allgather", "torch"),
+                          # RCCL, one device per rank: skipped on the 1-GPU test boxes, run on any multi-GPU node
+                          (2, "d128", "nccl", "alltoall", "torch"), ("all", "d128", "nccl", "alltoall", "torch"),
+                          ("all", "ragged", "nccl", "alltoall", "torch"), (2, "hist", "nccl", "alltoall", "torch"),
+                          ("all", "d128", "nccl", "allgather", "torch"),
+                          # the C ABI's own collectives (tt_comm_*) instead of torch's process group
+                          (2, "d128", "nccl", "alltoall", "native"), ("all", "hist", "nccl", "alltoall", "native"),
+                          ("all", "d128", "nccl", "allgather", "native")])
+def test_multi_rank_hip_backend_equals_reference_on_concatenated_batch(world, cfg_name, backend, routing, transport):
     import os
     import tempfile
     import torch.multiprocessing as mp
@@ -182,8 +188,8 @@ def test_multi_rank_hip_backend_equals_reference_on_concatenated_batch(world, cf
     world = _resolve_world(world, backend)
     cfg = MULTI_CFGS[cfg_name]
     outdir = tempfile.mkdtemp()
-    mp.spawn(_multi_worker, args=(world, _free_port(), outdir, cfg_name, "global", backend, routing), nprocs=world,
-             join=True)
+    mp.spawn(_multi_worker, args=(world, _free_port(), outdir, cfg_name, "global", backend, routing, transport),
+             nprocs=world, join=True)
     res = [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(world)]
     dense, ut, it = _multi_init(cfg)
     params = dict(dense)
@@ -261,10 +267,11 @@ def test_multi_rank_sharded_mips_hip_backend(world, C, K, backend):
         assert torch.equal(got["sc"], want_sc[r * 6:(r + 1) * 6])
 
 
-@pytest.mark.parametrize("n,n_rows,world", [(8192, 10_000_000, 8), (240, 307, 2), (50_000, 1_000_003, 7), (64, 64, 64)])
+@pytest.mark.parametrize("n,n_rows,world", [(8192, 10_000_000, 8), (240, 307, 2), (50_000, 1_000_003, 7), (64, 64, 64),
+                                            (204_800, 1_000_000, 8), (5000, 100_000, 1000)])
 def test_route_kernels_match_cpu_restatement(n, n_rows, world):
     """tt_route_count / tt_route_build / tt_route_localize (csrc/route.hip) against the test double's torch
-    restatement: bucket starts and maximum, slot assignment (stable within an owner), padding, the inverse map,
+    restatement: bucket sizes and maximum, slot assignment (stable within an owner), padding, the inverse map,
     and the owner-side localisation with its sentinel."""
     from sharded_cpu_backend import OracleBackend
     from two_tower_models_amd import sharded
@@ -280,7 +287,7 @@ def test_route_kernels_match_cpu_restatement(n, n_rows, world):
     pd = be.route_plan(ids.to(dev), n_rows, rpr, world, mx_d)
     pc = cpu.route_plan(ids, n_rows, rpr, world, mx_c)
     assert int(mx_d.item()) == int(mx_c.item())
-    assert torch.equal(pd[1].cpu().long(), pc[2])  # bucket starts
+    assert torch.equal(pd[3].cpu().long(), pc[2])  # bucket sizes
     cap = (int(mx_c.item()) + 63) // 64 * 64
     got = [t.cpu() for t in be.route_build(pd, rpr, world, cap)]
     want = cpu.route_build(pc, rpr, world, cap)
@@ -293,3 +300,35 @@ def test_route_kernels_match_cpu_restatement(n, n_rows, world):
     n_local = max(min(lo + rpr, n_rows) - lo, 0)
     loc = be.localize(send_ids.to(dev), lo, n_local).cpu()
     assert torch.equal(loc, cpu.localize(send_ids, lo, n_local))
+
+
+def test_native_comm_world1_every_collective():
+    """tt_comm_* of the C ABI (csrc/comm.cpp, RCCL bound at run time) with a one-rank communicator: id, init,
+    size, and every collective sharded.py uses -- at world size 1 each is the identity, which checks the binding,
+    the dtype / op mapping and the stream plumbing.  World sizes > 1 run in the nccl cases above on multi-GPU nodes."""
+    from two_tower_models_amd import _native as N
+    from two_tower_models_amd.comm import NativeComm
+    dev = torch.device("cuda:0")
+    c = NativeComm(NativeComm.unique_id(), 0, 1, dev)
+    try:
+        assert c.size() == (0, 1)
+        x = torch.randn(64, 128, device=dev)
+        ids = torch.arange(640, device=dev)
+        side = torch.cuda.Stream()
+        assert torch.equal(c.all_to_all(x), x) and torch.equal(c.all_to_all(ids), ids)
+        assert torch.equal(c.all_gather(x), x) and torch.equal(c.reduce_scatter(x), x)
+        y = x.clone()
+        assert torch.equal(c.all_reduce_(y), x) and torch.equal(c.all_reduce_(y, N.TT_COMM_MAX), x)
+        k = torch.tensor([7, 3, 9], dtype=torch.int32, device=dev)
+        assert c.all_reduce_(k, N.TT_COMM_MAX).tolist() == [7, 3, 9]
+        assert torch.equal(c.broadcast_(y, 0), x)
+        side.wait_stream(torch.cuda.current_stream())
+        z = c.all_to_all(x, stream=side)
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(z, x)
+        with pytest.raises(TypeError):
+            c.all_gather(x.double())
+        with pytest.raises(RuntimeError, match="in-place"):
+            c.all_to_all(x, recv=x)
+    finally:
+        c.close()

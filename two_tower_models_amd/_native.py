@@ -17,6 +17,9 @@ LIB_PATH = os.path.join(_PKG, "lib", "libtt_hotpath.so")
 TT_GEMM_NT, TT_GEMM_NN, TT_GEMM_TN = 0, 1, 2
 TT_EPI_NONE, TT_EPI_RELU, TT_EPI_RELU_MASK = 0, 1, 2
 TT_F32, TT_BF16 = 0, 1
+TT_COMM_ID_BYTES = 128
+TT_COMM_F32, TT_COMM_I32, TT_COMM_I64, TT_COMM_U8 = 0, 1, 2, 3
+TT_COMM_SUM, TT_COMM_MAX = 0, 1
 TT_MAX_GRAD_SOURCES = 4
 ABI_VERSION = 1
 
@@ -94,9 +97,19 @@ SIGNATURES = {
     "tt_attn_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "tt_attn_row0_fwd": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "tt_attn_row0_bwd": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp]),
-    "tt_route_count": (_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),
-    "tt_route_build": (_int, [_vp, _vp, _i64, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tt_route_workspace_bytes": (_i64, [_i64, _i32]),
+    "tt_route_count": (_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "tt_route_build": (_int, [_vp, _i64, _i64, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "tt_route_localize": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "tt_comm_unique_id": (_int, [_vp]),
+    "tt_comm_init": (_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
+    "tt_comm_destroy": (_int, [_vp]),
+    "tt_comm_size": (_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "tt_comm_alltoall": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
+    "tt_comm_allgather": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
+    "tt_comm_reduce_scatter": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
+    "tt_comm_allreduce": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp]),
+    "tt_comm_broadcast": (_int, [_vp, _vp, _i64, _int, _i32, _vp]),
     "tt_mips_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64, _int]),
     "tt_mips_topk": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
     "tt_mips_merge_workspace_bytes": (_i64, [_i64, _i64]),

@@ -11,7 +11,7 @@ Partitioning
   * the batch is split by rank; dense MLP / tower parameters are replicated.
 Exchanges per step, every size known to the host before the step starts:
   1. lookups -- padded fixed-capacity all-to-all (`routing="alltoall"`, default).  A rank's ids are
-     stable-sorted (the row plan's radix sort), which groups them by owner; each owner is sent only
+     bucketed by owner in one stable counting pass (csrc/route.hip); each owner is sent only
      ITS ids, `cap` slots per peer, and returns the rows in the same slots:
         ids   all_to_all  [W, cap] int64          rows  all_to_all  [W, cap, D]
      `cap` = the largest (requester, owner) bucket over all ranks, rounded up to 64 -- exact, so
@@ -53,6 +53,34 @@ TOWER_KEYS = ("features_arch.0.weight", "features_arch.0.bias", "features_arch.2
 
 
 # ----------------------------------------------------------------- collectives
+# Two transports behind the same helpers: torch.distributed's process group (default; "nccl" = RCCL), or the
+# C ABI's own tt_comm_* (comm.NativeComm, `use_native_transport`) -- RCCL bound by libtt_hotpath.so itself.
+_NATIVE = None  # comm.NativeComm
+_COMM_STREAM: Optional[torch.cuda.Stream] = None
+_NATIVE_DTYPES = (torch.float32, torch.int32, torch.int64, torch.uint8)
+
+
+def use_native_transport(comm) -> None:
+    """Route every device-side collective of this module through `comm` (a comm.NativeComm), or back through
+    torch.distributed with None.  The process group stays what creates / synchronises the ranks."""
+    global _NATIVE, _COMM_STREAM
+    _NATIVE = comm
+    _COMM_STREAM = torch.cuda.Stream(device=comm.device) if comm is not None else None
+
+
+def _native(x: torch.Tensor) -> bool:
+    return _NATIVE is not None and x.is_cuda and x.dtype in _NATIVE_DTYPES and dist.get_world_size() > 1
+
+
+def _native_op(op) -> int:
+    from . import _native as N
+    if op == dist.ReduceOp.SUM:
+        return N.TT_COMM_SUM
+    if op == dist.ReduceOp.MAX:
+        return N.TT_COMM_MAX
+    raise ValueError("native transport: SUM and MAX reductions only")
+
+
 def _is_gloo() -> bool:
     return dist.get_backend() == "gloo"
 
@@ -65,6 +93,8 @@ def _host_staged(x: torch.Tensor) -> bool:
 
 
 def all_gather_rows(x: torch.Tensor) -> torch.Tensor:
+    if _native(x):
+        return _NATIVE.all_gather(x)
     if _host_staged(x):
         return all_gather_rows(x.cpu()).to(x.device)
     out = x.new_empty((dist.get_world_size() * x.shape[0],) + tuple(x.shape[1:]))
@@ -73,6 +103,8 @@ def all_gather_rows(x: torch.Tensor) -> torch.Tensor:
 
 
 def reduce_scatter_rows(x: torch.Tensor) -> torch.Tensor:
+    if _native(x):
+        return _NATIVE.reduce_scatter(x)
     if _host_staged(x):
         return reduce_scatter_rows(x.cpu()).to(x.device)
     W = dist.get_world_size()
@@ -89,8 +121,8 @@ def reduce_scatter_rows(x: torch.Tensor) -> torch.Tensor:
 
 class _Pending:
     """Result of a collective started with `*_start`: `.wait()` makes the CURRENT stream wait for it
-    (RCCL: the collective runs on the process group's own stream meanwhile, so kernels launched in
-    between overlap it) and returns the output tensor."""
+    (RCCL: the collective runs on the process group's own stream -- or, native transport, on this module's
+    communication stream -- meanwhile, so kernels launched in between overlap it) and returns the output."""
 
     __slots__ = ("out", "work", "keep")
 
@@ -99,9 +131,24 @@ class _Pending:
 
     def wait(self) -> torch.Tensor:
         if self.work is not None:
-            self.work.wait()
+            if isinstance(self.work, torch.cuda.Event):
+                torch.cuda.current_stream().wait_event(self.work)
+            else:
+                self.work.wait()
             self.work, self.keep = None, None
         return self.out
+
+
+def _native_start(fn, x: torch.Tensor, *args) -> _Pending:
+    """Run `fn(x, *args, stream=<communication stream>)` after everything queued so far on the current stream."""
+    x = x.contiguous()
+    ready = torch.cuda.Event()
+    ready.record()
+    _COMM_STREAM.wait_event(ready)
+    out = fn(x, *args, stream=_COMM_STREAM)
+    done = torch.cuda.Event()
+    done.record(_COMM_STREAM)
+    return _Pending(out, done, x)
 
 
 def _rccl_async(x: torch.Tensor) -> bool:
@@ -109,6 +156,8 @@ def _rccl_async(x: torch.Tensor) -> bool:
 
 
 def all_gather_rows_start(x: torch.Tensor) -> _Pending:
+    if _native(x):
+        return _native_start(_NATIVE.all_gather, x, None)
     if not _rccl_async(x):  # gloo (tests) and world size 1: nothing to overlap with
         return _Pending(all_gather_rows(x) if dist.get_world_size() > 1 else x)
     x = x.contiguous()
@@ -117,6 +166,9 @@ def all_gather_rows_start(x: torch.Tensor) -> _Pending:
 
 
 def reduce_scatter_rows_start(x: torch.Tensor) -> _Pending:
+    if _native(x):
+        from . import _native as N
+        return _native_start(_NATIVE.reduce_scatter, x, None, N.TT_COMM_SUM)
     if not _rccl_async(x):
         return _Pending(reduce_scatter_rows(x) if dist.get_world_size() > 1 else x)
     x = x.contiguous()
@@ -125,12 +177,16 @@ def reduce_scatter_rows_start(x: torch.Tensor) -> _Pending:
 
 
 def all_reduce_start_(x: torch.Tensor, op=dist.ReduceOp.SUM) -> _Pending:
+    if _native(x):
+        return _native_start(_NATIVE.all_reduce_, x, _native_op(op))
     if not _rccl_async(x):
         return _Pending(all_reduce_(x, op=op) if dist.get_world_size() > 1 else x)
     return _Pending(x, dist.all_reduce(x, op=op, async_op=True))
 
 
 def all_reduce_(x: torch.Tensor, op=dist.ReduceOp.SUM) -> torch.Tensor:
+    if _native(x) and x.is_contiguous():
+        return _NATIVE.all_reduce_(x, _native_op(op))
     if _host_staged(x):
         h = x.cpu()
         dist.all_reduce(h, op=op)
@@ -141,6 +197,8 @@ def all_reduce_(x: torch.Tensor, op=dist.ReduceOp.SUM) -> torch.Tensor:
 
 
 def broadcast_(x: torch.Tensor, src: int) -> torch.Tensor:
+    if _native(x) and x.is_contiguous():
+        return _NATIVE.broadcast_(x, src)
     if _host_staged(x):
         h = x.cpu()
         dist.broadcast(h, src=src)
@@ -152,6 +210,8 @@ def broadcast_(x: torch.Tensor, src: int) -> torch.Tensor:
 
 def all_to_all_rows(x: torch.Tensor) -> torch.Tensor:
     """Chunk r of `x` (equal chunks along dim 0) goes to rank r."""
+    if _native(x):
+        return _NATIVE.all_to_all(x)
     if _host_staged(x):
         return all_to_all_rows(x.cpu()).to(x.device)
     out = torch.empty_like(x)
@@ -160,6 +220,8 @@ def all_to_all_rows(x: torch.Tensor) -> torch.Tensor:
 
 
 def all_to_all_rows_start(x: torch.Tensor) -> _Pending:
+    if _native(x):
+        return _native_start(_NATIVE.all_to_all, x, None)
     if not _rccl_async(x):
         return _Pending(all_to_all_rows(x) if dist.get_world_size() > 1 else x)
     x = x.contiguous()
@@ -202,24 +264,27 @@ class HipBackend:
 
     # ---- owner routing (csrc/route.hip)
     def route_plan(self, ids: torch.Tensor, n_rows: int, rows_per_rank: int, world: int, max_out: torch.Tensor):
-        """Stable sort of this rank's ids (groups them by owner) + bucket starts; the largest bucket is
+        """Count this rank's ids per owner (one stable counting pass, no sort); the largest bucket is
         atomicMax'ed into the int32 scalar view `max_out`.  Ids outside [0, n_rows) raise the device-side
         out-of-range flag (IndexError at the next poll, like the single-GPU lookups)."""
         N, lib = self.N, self.lib
-        plan = self.ops.RowPlan([ids], n_rows, slot="route")
-        starts = torch.empty(world + 1, dtype=torch.int32, device=self.device)
-        N.check(lib.tt_route_count(plan.sorted_ids.data_ptr(), plan.n, rows_per_rank, world, starts.data_ptr(),
-                                   max_out.data_ptr(), N.stream()), "tt_route_count")
-        return plan, starts
+        n = ids.numel()
+        ws = torch.empty(lib.tt_route_workspace_bytes(n, world), dtype=torch.uint8, device=self.device)
+        counts = torch.empty(world, dtype=torch.int32, device=self.device)
+        N.check(lib.tt_route_count(ids.data_ptr(), n, n_rows, rows_per_rank, world, counts.data_ptr(), max_out.data_ptr(),
+                                   N.oob.flag(self.device).data_ptr(), ws.data_ptr(), ws.numel(), N.stream()),
+                "tt_route_count")
+        return ids, n_rows, ws, counts
 
     def route_build(self, planned, rows_per_rank: int, world: int, cap: int):
         N, lib = self.N, self.lib
-        plan, starts = planned
+        ids, n_rows, ws, _counts = planned
+        n = ids.numel()
         send_ids = torch.empty(world * cap, dtype=torch.int64, device=self.device)
         src_of = torch.empty(world * cap, dtype=torch.int64, device=self.device)
-        slot_of = torch.empty(plan.n, dtype=torch.int64, device=self.device)
-        N.check(lib.tt_route_build(plan.sorted_ids.data_ptr(), plan.perm.data_ptr(), plan.n, rows_per_rank, world, cap,
-                                   starts.data_ptr(), send_ids.data_ptr(), slot_of.data_ptr(), src_of.data_ptr(),
+        slot_of = torch.empty(n, dtype=torch.int64, device=self.device)
+        N.check(lib.tt_route_build(ids.data_ptr(), n, n_rows, rows_per_rank, world, cap, ws.data_ptr(), ws.numel(),
+                                   send_ids.data_ptr(), slot_of.data_ptr(), src_of.data_ptr(),
                                    N.oob.flag(self.device).data_ptr(), N.stream()), "tt_route_build")
         return send_ids, slot_of, src_of
 
@@ -472,10 +537,22 @@ class ShardedTrainer:
 
     def __init__(self, cfg: Dict, device: torch.device, negatives: str = "global", backend=None,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, user_value_weights=(1.0,), seed: int = 0,
-                 dense_init: Optional[Dict[str, torch.Tensor]] = None, routing: Optional[str] = None):
+                 dense_init: Optional[Dict[str, torch.Tensor]] = None, routing: Optional[str] = None,
+                 transport: Optional[str] = None):
         if not dist.is_initialized():
             raise RuntimeError("ShardedTrainer needs torch.distributed to be initialised")
         self.cfg, self.device, self.negatives = dict(cfg), device, negatives
+        # which library moves the bytes: torch.distributed's process group, or the C ABI's tt_comm_* (RCCL bound by
+        # libtt_hotpath.so itself).  Same collectives, same order, same results.
+        self.transport = transport or os.environ.get("TT_COMM", "torch")
+        if self.transport not in ("torch", "native"):
+            raise ValueError("transport must be 'torch' or 'native'")
+        if self.transport == "native" and device.type == "cuda" and dist.get_world_size() > 1:
+            if _is_gloo():
+                raise RuntimeError("transport='native' needs one GPU per rank (RCCL); this group runs over gloo")
+            from .comm import NativeComm
+            if _NATIVE is None:
+                use_native_transport(NativeComm.from_torch_distributed(device))
         self.routing = routing or os.environ.get("TT_ROUTE", "alltoall")  # A/B switch
         if self.routing not in ("alltoall", "allgather"):
             raise ValueError("routing must be 'alltoall' or 'allgather'")
