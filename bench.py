@@ -228,6 +228,27 @@ def secondary(device, lib, N):
             sec[key] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
     try:
+        # the drop-in training script end to end (ref:train/train.py:138-183): dataset generated in HBM, device-side
+        # shuffle + batch slicing, 1-D [B] labels, 40 steps per epoch at the headline shapes; 2nd epoch reported
+        import argparse as _ap
+        from two_tower_models_amd import train as T
+        a = T.build_parser().parse_args([
+            "--num_users", "1000000", "--user_id_hash_size", "1000000", "--num_items", "10000000",
+            "--item_id_hash_size", "10000000", "--embedding_dim", "128", "--feature_dim", "8", "--batch_size", "8192",
+            "--num_samples", str(40 * 8192), "--num_epochs", "2", "--user_history_seqlen", "4"])
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            st = T.main(a)
+        sec["train_py_end_to_end"] = {"workload": "python -m two_tower_models_amd.train at the P shapes (N_u=1 M, N_i=10 M, D=128, "
+                                                  "B=8192), on-device DummyRecDataset + shuffled batches, [B] labels",
+                                      "pairs_per_s": round(st[-1]["pairs_per_s"], 1),
+                                      "ms_per_step": round(st[-1]["seconds"] / 40 * 1e3, 4), "steps_per_epoch": 40,
+                                      "epochs": 2}
+    except Exception as e:
+        sec["train_py_end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
+    try:
         sec["C5_mips"] = _timed_mips(device, lib, N)
     except Exception as e:
         sec["C5_mips"] = {"error": f"{type(e).__name__}: {e}"}

@@ -98,6 +98,44 @@ def test_train_script_default_flags(A, capsys):
     assert last < first
 
 
+def test_device_dataset_fields_match_the_reference_dataset(A):
+    """DummyRecDataset generated ON the device: the seven fields of ref:train/train.py:47-65 with the reference's
+    shapes, dtypes (1-D float labels!), value ranges and distributions (uniform ids: mean (n-1)/2, variance
+    (n^2-1)/12; N(0,1) features; Bernoulli(1/2) labels; positions uniform on 0..9), plus DataLoader(shuffle=True)
+    semantics of the on-device batcher: every sample exactly once per epoch, ragged last batch kept."""
+    from two_tower_models_amd import train
+    n, NU, NI, F, H = 200_000, 1000, 50_000, 8, 10
+    ds = train.DummyRecDataset(n, NU, NI, F, H, device=torch.device(DEV), seed=3)
+    uid, uf, hist, iid, itf, pos, lab = ds.fields()
+    assert all(t.is_cuda for t in ds.fields()) and len(ds) == n
+    assert (uid.dtype, iid.dtype, hist.dtype, pos.dtype) == (torch.int64,) * 4
+    assert (uf.dtype, itf.dtype, lab.dtype) == (torch.float32,) * 3
+    assert uid.shape == (n,) and iid.shape == (n,) and lab.shape == (n,) and pos.shape == (n,)
+    assert uf.shape == (n, F) and itf.shape == (n, F) and hist.shape == (n, H)
+    for t, hi in ((uid, NU), (iid, NI), (hist, NI), (pos, 10)):
+        assert int(t.min()) >= 0 and int(t.max()) < hi
+        m, v = t.double().mean().item(), t.double().var().item()
+        assert abs(m - (hi - 1) / 2) < 6 * ((hi * hi - 1) / 12 / t.numel()) ** 0.5
+        assert abs(v / ((hi * hi - 1) / 12) - 1) < 0.03
+    assert int(uid.max()) == NU - 1 and int(uid.min()) == 0 and len(torch.unique(pos)) == 10
+    assert set(torch.unique(lab).tolist()) == {0.0, 1.0} and abs(lab.mean().item() - 0.5) < 0.01
+    for t in (uf, itf):
+        assert abs(t.mean().item()) < 0.01 and abs(t.std().item() - 1) < 0.01
+        assert abs((t ** 4).mean().item() - 3.0) < 0.15  # normal kurtosis
+    same = train.DummyRecDataset(n, NU, NI, F, H, device=torch.device(DEV), seed=3)
+    assert all(torch.equal(a, b) for a, b in zip(ds.fields(), same.fields()))
+    # __getitem__ returns the reference's 7-tuple
+    rec = ds[5]
+    assert len(rec) == 7 and rec[2].shape == (H,) and rec[6].dim() == 0
+    # one epoch of the device batcher = a permutation of the dataset
+    tag = torch.arange(n, device=DEV)
+    ds.positions = tag  # reuse a field as a sample tag
+    seen = torch.cat([b[5] for b in train.DeviceBatches(ds, 8192, shuffle=True)])
+    assert seen.numel() == n and torch.equal(torch.sort(seen).values, tag) and not torch.equal(seen, tag)
+    sizes = [b[0].shape[0] for b in train.DeviceBatches(ds, 8192, shuffle=False)]
+    assert sizes == [8192] * (n // 8192) + [n % 8192]
+
+
 def test_index_corpus_serves_the_item_tower(A):
     """index_corpus installs item-tower outputs as the MIPS corpus: forward() then returns, for every
     user, the ids whose item embeddings have the largest inner products with the user embedding."""

@@ -14,6 +14,8 @@ differ, both because the upstream pipeline caps at ~46 K samples/s
 from __future__ import annotations
 
 import argparse
+import time
+from typing import Optional
 
 import torch
 
@@ -26,15 +28,22 @@ class DummyRecDataset:
     positions, labels -- ref:train/train.py:20-79, generated once, resident on `device`."""
 
     def __init__(self, num_samples: int, num_users: int, num_items: int, feature_dim: int,
-                 user_history_seqlen: int, device: torch.device = torch.device("cpu")):
+                 user_history_seqlen: int, device: torch.device = torch.device("cpu"), seed: Optional[int] = None):
+        """Fields, dtypes, shapes and distributions of ref:train/train.py:47-65, drawn in the reference's order --
+        but ON `device` (the device's own generator; `seed` pins it), so nothing crosses PCIe: a 10 M-sample
+        dataset with H = 50 is 4 GB of ids that the reference would draw on the host and copy."""
         self.num_samples, self.num_users, self.num_items, self.feature_dim = num_samples, num_users, num_items, feature_dim
-        self.user_ids = torch.randint(0, num_users, (num_samples,)).to(device)
-        self.item_ids = torch.randint(0, num_items, (num_samples,)).to(device)
-        self.labels = torch.randint(0, 2, (num_samples,)).float().to(device)
-        self.user_features = torch.randn(num_samples, feature_dim).to(device)
-        self.user_history = torch.randint(low=0, high=num_items, size=(num_samples, user_history_seqlen)).to(device)
-        self.item_features = torch.randn(num_samples, feature_dim).to(device)
-        self.positions = torch.randint(0, 10, (num_samples,)).to(device)
+        gen = None
+        if seed is not None:
+            gen = torch.Generator(device=device).manual_seed(seed)
+        kw = dict(device=device, generator=gen)
+        self.user_ids = torch.randint(0, num_users, (num_samples,), **kw)      # int64 [n], 0 .. num_users-1
+        self.item_ids = torch.randint(0, num_items, (num_samples,), **kw)      # int64 [n], 0 .. num_items-1
+        self.labels = torch.randint(0, 2, (num_samples,), **kw).float()        # fp32 [n] (1-D!), 0 or 1
+        self.user_features = torch.randn(num_samples, feature_dim, **kw)       # fp32 [n, F], N(0, 1)
+        self.user_history = torch.randint(low=0, high=num_items, size=(num_samples, user_history_seqlen), **kw)
+        self.item_features = torch.randn(num_samples, feature_dim, **kw)
+        self.positions = torch.randint(0, 10, (num_samples,), **kw)            # int64 [n], 0 .. 9
 
     def __len__(self):
         return self.num_samples
@@ -90,14 +99,18 @@ def main(args):
         raise SystemExit("two_tower_models_amd.train needs an MI355X (ROCm) device; there is no CPU path")
     device = torch.device("cuda")
     print(f"Running on device: {device}")
-    mips_module = BaselineMIPSModule(corpus_size=args.num_items, embedding_dim=args.embedding_dim)
+    # tables and the (random, upstream-style) MIPS corpus are initialised directly in HBM
+    with torch.device(device):
+        mips_module = BaselineMIPSModule(corpus_size=args.num_items, embedding_dim=args.embedding_dim)
     kw = dict(num_items=args.num_items_to_return, user_id_hash_size=args.user_id_hash_size,
               user_id_embedding_dim=args.embedding_dim, user_features_size=args.feature_dim,
               item_id_hash_size=args.item_id_hash_size, item_id_embedding_dim=args.embedding_dim,
               item_features_size=args.feature_dim, user_value_weights=[1.0], mips_module=mips_module)
     if args.model != "base":
         kw["user_history_seqlen"] = args.user_history_seqlen
-    model = MODELS[args.model](**kw).to(device)
+    with torch.device(device):
+        model = MODELS[args.model](**kw)
+    model = model.to(device)
     dataset = DummyRecDataset(num_samples=args.num_samples, num_users=args.num_users, num_items=args.num_items,
                               feature_dim=args.feature_dim, user_history_seqlen=args.user_history_seqlen, device=device)
     dataloader = DeviceBatches(dataset, batch_size=args.batch_size, shuffle=True)
@@ -105,10 +118,19 @@ def main(args):
     # forward-announced sweep start assumes (optim.py)
     optimizer = DenseExactAdam(model.parameters(), lr=args.learning_rate, overlap_sweep="forward",
                                lazy=getattr(args, "lazy_adam", False))
+    stats = []
     for epoch in range(args.num_epochs):
-        avg_loss = train_one_epoch(model, dataloader, optimizer, device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        avg_loss = train_one_epoch(model, dataloader, optimizer, device)  # ends with .item(): the device has drained
+        dt = time.perf_counter() - t0
         print(f"Epoch [{epoch + 1}/{args.num_epochs}] - Loss: {avg_loss:.4f}")
+        stats.append({"epoch": epoch + 1, "loss": avg_loss, "seconds": dt, "pairs_per_s": len(dataset) / dt})
+        if getattr(args, "report_throughput", False):
+            print(f"  {len(dataset) / dt:,.0f} user-item pairs/s end to end (shuffle + batch slicing + step), "
+                  f"{dt / len(dataloader) * 1e3:.3f} ms/step")
     optimizer.flush()  # deferred schedule: the tables are complete again from here on
+    return stats
 
 
 def build_parser() -> argparse.ArgumentParser:
@@ -129,6 +151,7 @@ def build_parser() -> argparse.ArgumentParser:
     ):
         p.add_argument(flag, type=typ, default=default, help=hlp)
     p.add_argument("--model", choices=sorted(MODELS), default="base", help="model variant (upstream: base only)")
+    p.add_argument("--report_throughput", action="store_true", help="print end-to-end pairs/s per epoch")
     p.add_argument("--lazy_adam", action="store_true",
                    help="value-exact deferred Adam: replay a row's zero-gradient steps when it is next needed")
     return p
