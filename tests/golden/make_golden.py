@@ -251,7 +251,30 @@ def mips_cases():
     save("g5_mips", **out)
 
 
+def mips_wide_case():
+    """D = 256 (> 128: the generic-width path of the build): exact-arithmetic corpus."""
+    out = {}
+    C, D = 4096, 256
+    corpus = fg.exact_mips_corpus(C, D)
+    q = fg.exact_mips_queries(16, D)
+    m = BaselineMIPSModule(corpus_size=C, embedding_dim=D)
+    m.corpus = t(corpus)
+    for K in (10, 300):
+        idx, sc, emb = m(query_embedding=t(q), num_items=K)
+        assert emb.shape == (16, K, D)
+        out[f"exact_C{C}_K{K}.idx"] = idx.numpy().astype(np.int32)
+        out[f"exact_C{C}_K{K}.scores"] = sc.numpy()
+    s = t(q) @ t(corpus).t()
+    assert all(len(torch.unique(row)) == C for row in s), "scores must be pairwise distinct"
+    save("g5_mips_d256", **out)
+
+
 if __name__ == "__main__":
+    if "--only-d256" in sys.argv:  # the round-2 additions alone (the others regenerate bit-identically anyway)
+        base_model_case("g2_base_d256", n_users=96, du=256, iu=8, n_items=128, di=256, ii=8,
+                        T=1, uvw=[1.0], B=160, H=4)
+        mips_wide_case()
+        sys.exit(0)
     base_model_case("g1_base_tiny", n_users=100, du=50, iu=20, n_items=150, di=40, ii=30,
                     T=3, uvw=[0.1, 0.2, 0.3], B=32, H=8)
     base_model_case("g2_base_aligned", n_users=256, du=128, iu=8, n_items=256, di=128, ii=8,
@@ -269,3 +292,6 @@ if __name__ == "__main__":
     corpus = fg.bf16_round(fg.gaussianish((4096, 128), 901))
     hist_model_case("g6_debias_d128", n_users=256, du=128, iu=8, n_items=256, di=128, ii=8,
                     T=1, uvw=[1.0], B=64, H=50, debias=True, corpus=corpus, topk=10)
+    base_model_case("g2_base_d256", n_users=96, du=256, iu=8, n_items=128, di=256, ii=8,
+                    T=1, uvw=[1.0], B=160, H=4)
+    mips_wide_case()

@@ -114,6 +114,7 @@ def test_gather_rows_and_oob(T, D):
 
 # ------------------------------------------------------------------ in-batch softmax CE
 @pytest.mark.parametrize("M,Nn,D,off", [(32, 32, 40, 0), (200, 200, 50, 0), (256, 256, 128, 0), (1000, 1000, 128, 0),
+                                        (300, 300, 256, 0), (130, 700, 200, 400), (64, 64, 129, 0),
                                         (128, 512, 128, 256), (100, 300, 64, 200), (64, 64, 2, 0), (1, 1, 8, 0)])
 def test_inbatch_ce_forward_backward(T, M, Nn, D, off):
     ops, N = T
@@ -406,6 +407,7 @@ def test_adam_table_equals_dense_adam(T, n_rows, D, n1, n2):
 
 # ------------------------------------------------------------------ attention
 @pytest.mark.parametrize("B,H,D,heads", [(3, 50, 128, 4), (2, 7, 40, 4), (1, 3, 2, 1), (2, 128, 64, 4), (5, 16, 40, 4),
+                                          (2, 20, 256, 2), (2, 9, 200, 2),
                                          (4, 64, 64, 4), (2, 33, 128, 2), (3, 1, 128, 4), (9, 50, 64, 2)])
 def test_attention_forward_backward(T, B, H, D, heads):
     ops, N = T

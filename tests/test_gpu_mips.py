@@ -45,6 +45,33 @@ def test_exact_corpus_bit_exact_vs_reference(A, golden, C, K, bf16):
 
 
 @pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("K", [10, 300])
+def test_exact_corpus_d256_bit_exact_vs_reference(A, golden, K, bf16):
+    """D = 256 (> 128: the generic-width form, library GEMM + group epilogues) against what the reference ranked."""
+    g = golden("g5_mips_d256")
+    corpus = T(fg.exact_mips_corpus(4096, 256))
+    m = module_with(A, corpus, bf16)
+    idx, sc, emb = m(query_embedding=T(fg.exact_mips_queries(16, 256)).to(DEV), num_items=K)
+    assert np.array_equal(idx.cpu().numpy(), g[f"exact_C4096_K{K}.idx"].astype(np.int64))
+    assert np.array_equal(sc.cpu().numpy(), g[f"exact_C4096_K{K}.scores"])
+    assert torch.equal(emb.cpu(), corpus[idx.cpu()])
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("B,C,D,K", [(40, 70_000, 200, 50), (3, 129, 130, 129), (1100, 3000, 384, 7)])
+def test_wide_embeddings_match_oracle_order(A, B, C, D, K, bf16):
+    """Widths above 128, ragged, more than one corpus slab (C > 65 536), more than one query batch (B > 1024),
+    K == C (every item a candidate): exact-arithmetic data, so indices and scores equal the oracle's bit for bit."""
+    from oracle import cpu_ref as R
+    corpus, q = T(fg.exact_mips_corpus(C, D, seed=5)), T(fg.exact_mips_queries(B, D, seed=6))
+    m = module_with(A, corpus, bf16)
+    idx, sc = m.search(q.to(DEV), K)
+    want_idx, want_sc, _ = R.mips_topk(q, corpus, K)
+    assert torch.equal(sc.cpu(), want_sc)
+    assert torch.equal(idx.cpu(), want_idx)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("K", [10, 100])
 def test_random_corpus_vs_reference(A, golden, K, bf16):
     g = golden("g5_mips")

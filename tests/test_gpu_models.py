@@ -56,7 +56,7 @@ def check_grads(model, g, rtol=2e-4, atol_scale=1e-5):
 
 
 # ------------------------------------------------------------------ base model
-@pytest.mark.parametrize("name", ["g1_base_tiny", "g2_base_aligned"])
+@pytest.mark.parametrize("name", ["g1_base_tiny", "g2_base_aligned", "g2_base_d256"])
 def test_base_model_matches_reference(golden, name):
     g = golden(name)
     model = make_model("base", g)

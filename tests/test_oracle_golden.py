@@ -70,7 +70,7 @@ def test_encoder_forward_and_grads(golden, name):
 
 
 # ---------------------------------------------------------------- base model
-@pytest.mark.parametrize("name", ["g1_base_tiny", "g2_base_aligned"])
+@pytest.mark.parametrize("name", ["g1_base_tiny", "g2_base_aligned", "g2_base_d256"])
 def test_base_model_forward_loss_grads(golden, name):
     g = golden(name)
     leaves = {k: v.requires_grad_(True) for k, v in params_of(g).items()}
@@ -169,6 +169,15 @@ def test_mips_exact_corpus_bit_exact(golden, C, K):
     assert np.array_equal(idx.numpy(), g[f"exact_C{C}_K{K}.idx"].astype(np.int64))
     assert np.array_equal(sc.numpy(), g[f"exact_C{C}_K{K}.scores"])
     assert torch.equal(rows, corpus[idx])
+
+
+@pytest.mark.parametrize("K", [10, 300])
+def test_mips_exact_corpus_d256_bit_exact(golden, K):
+    g = golden("g5_mips_d256")
+    corpus, q = T(fg.exact_mips_corpus(4096, 256)), T(fg.exact_mips_queries(16, 256))
+    idx, sc, _ = R.mips_topk(q, corpus, K)
+    assert np.array_equal(idx.numpy(), g[f"exact_C4096_K{K}.idx"].astype(np.int64))
+    assert np.array_equal(sc.numpy(), g[f"exact_C4096_K{K}.scores"])
 
 
 @pytest.mark.parametrize("K", [10, 100])

@@ -141,7 +141,9 @@ int attn_fwd_mfma(const float* qkv, int64_t B, int64_t H, int64_t D, int64_t hea
 int attn_bwd_mfma(const float* qkv, const float* lse, const float* d_ctx, int64_t B, int64_t H, int64_t D,
                   int64_t heads, float* d_qkv, hipStream_t st);
 
-static int pick_dhp(int64_t dh) { return dh <= 4 ? 4 : dh <= 16 ? 16 : dh <= 32 ? 32 : dh <= 64 ? 64 : 0; }
+// head widths above 64 (embedding_dim 512 with the history model's 4 heads) take the same kernels with 128 values per
+// lane: they spill past the VGPR file, which makes them slow, not wrong.  Wider heads are refused.
+static int pick_dhp(int64_t dh) { return dh <= 4 ? 4 : dh <= 16 ? 16 : dh <= 32 ? 32 : dh <= 64 ? 64 : dh <= 128 ? 128 : 0; }
 
 template <typename K>
 static int opt_in(K kernel, size_t lds, const char* name) {
@@ -273,7 +275,7 @@ extern "C" int tt_attn_fwd(const float* qkv, int64_t B, int64_t H, int64_t D, in
   const int64_t dh = D / heads;
   if (attn_mfma_supported(qkv, ctx, H, D, dh)) return attn_fwd_mfma(qkv, B, H, D, heads, ctx, lse, S(stream));
   const int dhp = pick_dhp(dh);
-  if (!dhp) { set_error("tt_attn_fwd: head dim %lld > 64 not implemented", (long long)dh); return TT_E_UNSUPPORTED; }
+  if (!dhp) { set_error("tt_attn_fwd: head dim %lld > 128 not implemented", (long long)dh); return TT_E_UNSUPPORTED; }
   const unsigned threads = (unsigned)(H >= 256 ? 256 : round_up(H, 64));
   const size_t lds = (size_t)2 * H * dhp * sizeof(float);
   const unsigned grid = (unsigned)(B * heads);
@@ -281,7 +283,7 @@ extern "C" int tt_attn_fwd(const float* qkv, int64_t B, int64_t H, int64_t D, in
 #define TT_FWD(P)                                                                     \
   if ((rc = opt_in(attn_fwd_kernel<P>, lds, "attn_fwd_kernel"))) return rc;           \
   attn_fwd_kernel<P><<<grid, threads, lds, S(stream)>>>(qkv, (int)H, (int)D, (int)heads, (int)dh, ctx, lse);
-  if (dhp == 4) { TT_FWD(4) } else if (dhp == 16) { TT_FWD(16) } else if (dhp == 32) { TT_FWD(32) } else { TT_FWD(64) }
+  if (dhp == 4) { TT_FWD(4) } else if (dhp == 16) { TT_FWD(16) } else if (dhp == 32) { TT_FWD(32) } else if (dhp == 64) { TT_FWD(64) } else { TT_FWD(128) }
 #undef TT_FWD
   return check_launch("attn_fwd_kernel");
 }
@@ -295,7 +297,7 @@ extern "C" int tt_attn_bwd(const float* qkv, const float* ctx, const float* lse,
   if (attn_mfma_supported(qkv, d_ctx, H, D, dh) && (reinterpret_cast<uintptr_t>(d_qkv) & 15) == 0)
     return attn_bwd_mfma(qkv, lse, d_ctx, B, H, D, heads, d_qkv, S(stream));
   const int dhp = pick_dhp(dh);
-  if (!dhp) { set_error("tt_attn_bwd: head dim %lld > 64 not implemented", (long long)dh); return TT_E_UNSUPPORTED; }
+  if (!dhp) { set_error("tt_attn_bwd: head dim %lld > 128 not implemented", (long long)dh); return TT_E_UNSUPPORTED; }
   const unsigned threads = (unsigned)(H >= 256 ? 256 : round_up(H, 64));
   const size_t lds = ((size_t)4 * H * dhp + 2 * H) * sizeof(float);
   const unsigned grid = (unsigned)(B * heads);
@@ -303,7 +305,7 @@ extern "C" int tt_attn_bwd(const float* qkv, const float* ctx, const float* lse,
 #define TT_BWD(P)                                                                     \
   if ((rc = opt_in(attn_bwd_kernel<P>, lds, "attn_bwd_kernel"))) return rc;           \
   attn_bwd_kernel<P><<<grid, threads, lds, S(stream)>>>(qkv, ctx, lse, d_ctx, (int)H, (int)D, (int)heads, (int)dh, d_qkv);
-  if (dhp == 4) { TT_BWD(4) } else if (dhp == 16) { TT_BWD(16) } else if (dhp == 32) { TT_BWD(32) } else { TT_BWD(64) }
+  if (dhp == 4) { TT_BWD(4) } else if (dhp == 16) { TT_BWD(16) } else if (dhp == 32) { TT_BWD(32) } else if (dhp == 64) { TT_BWD(64) } else { TT_BWD(128) }
 #undef TT_BWD
   return check_launch("attn_bwd_kernel");
 }

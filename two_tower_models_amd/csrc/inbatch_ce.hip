@@ -741,6 +741,12 @@ __global__ __launch_bounds__(1024) void weighted_mean_loss_kernel(const float* _
   }
 }
 
+// generic form for D > 128 (ce_wide.hip): logits materialised per row chunk, library GEMM
+int64_t ce_wide_workspace_bytes(int64_t M, int64_t N, int64_t D);
+int ce_wide_run(int mode, const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N, int64_t D,
+                int64_t diag_offset, float* row_lse, float* row_ce, const float* coef, float* dU, int64_t lddu, float* dI,
+                int64_t lddi, void* ws, int64_t ws_bytes, hipStream_t st);
+
 struct CePlan {
   int dp8, splits;
   int64_t tiles_per_split;
@@ -817,6 +823,7 @@ using namespace tt;
 
 extern "C" int64_t tt_inbatch_ce_workspace_bytes(int64_t M, int64_t N, int64_t D) {
   if (M <= 0 || N <= 0 || D <= 0) return 0;
+  if (D > 128) return ce_wide_workspace_bytes(M, N, D);
   CePlan pu, pi;
   if (!plan_ce(M, N, D, pu) || !plan_ce(N, M, D, pi)) return 0;
   const int64_t fwd = round_up((2 * (int64_t)pu.splits * M + M) * 4, 256);
@@ -835,6 +842,8 @@ extern "C" int tt_inbatch_ce_fwd(const float* U, int64_t ldu, const float* I, in
   if (!U || !I || !row_lse || !row_ce || !ws) return fail_arg("tt_inbatch_ce_fwd: null pointer");
   if (M <= 0 || N <= 0 || D <= 0 || ldu < D || ldi < D) return fail_arg("tt_inbatch_ce_fwd: sizes");
   if (diag_offset < 0 || diag_offset + M > N) return fail_arg("tt_inbatch_ce_fwd: diagonal outside the item block");
+  if (D > 128)
+    return ce_wide_run(0, U, ldu, I, ldi, M, N, D, diag_offset, row_lse, row_ce, nullptr, nullptr, 0, nullptr, 0, ws, ws_bytes, S(stream));
   CePlan pl;
   if (!plan_ce(M, N, D, pl)) { set_error("tt_inbatch_ce: D=%lld > 128 not implemented", (long long)D); return TT_E_UNSUPPORTED; }
   if (ws_bytes < tt_inbatch_ce_workspace_bytes(M, N, D)) { set_error("tt_inbatch_ce_fwd: workspace"); return TT_E_WORKSPACE; }
@@ -886,6 +895,11 @@ static int fwd_du_impl(const float* U, int64_t ldu, const float* I, int64_t ldi,
   if (!U || !I || !row_lse || !row_ce || !du_unit || !ws) return fail_arg("tt_inbatch_ce_fwd_du: null pointer");
   if (M <= 0 || N <= 0 || D <= 0 || ldu < D || ldi < D || ld_du < D) return fail_arg("tt_inbatch_ce_fwd_du: sizes");
   if (diag_offset < 0 || diag_offset + M > N) return fail_arg("tt_inbatch_ce_fwd_du: diagonal outside the item block");
+  if (D > 128) {
+    if (logits) { set_error("tt_inbatch_ce_fwd_du_keep: needs D in {32, 64, 128} (use tt_inbatch_ce_fwd_du)"); return TT_E_UNSUPPORTED; }
+    return ce_wide_run(1, U, ldu, I, ldi, M, N, D, diag_offset, row_lse, row_ce, nullptr, du_unit, ld_du, nullptr, 0, ws, ws_bytes,
+                       S(stream));
+  }
   CePlan pl;
   if (!plan_ce(M, N, D, pl)) { set_error("tt_inbatch_ce: D=%lld > 128 not implemented", (long long)D); return TT_E_UNSUPPORTED; }
   if (ws_bytes < tt_inbatch_ce_workspace_bytes(M, N, D)) { set_error("tt_inbatch_ce_fwd_du: workspace"); return TT_E_WORKSPACE; }
@@ -923,6 +937,9 @@ extern "C" int tt_inbatch_ce_bwd(const float* U, int64_t ldu, const float* I, in
                                  void* ws, int64_t ws_bytes, tt_stream_t stream) {
   if (!U || !I || !row_lse || !coef || !dI || !ws) return fail_arg("tt_inbatch_ce_bwd: null pointer");
   if (M <= 0 || N <= 0 || D <= 0 || ldu < D || ldi < D || (dU && lddu < D) || lddi < D) return fail_arg("tt_inbatch_ce_bwd: sizes");
+  if (D > 128)
+    return ce_wide_run(2, U, ldu, I, ldi, M, N, D, diag_offset, const_cast<float*>(row_lse), nullptr, coef, dU, lddu, dI, lddi, ws,
+                       ws_bytes, S(stream));
   CePlan pu, pi;
   if (!plan_ce(M, N, D, pu) || !plan_ce(N, M, D, pi)) { set_error("tt_inbatch_ce: D=%lld > 128 not implemented", (long long)D); return TT_E_UNSUPPORTED; }
   if (ws_bytes < tt_inbatch_ce_workspace_bytes(M, N, D)) { set_error("tt_inbatch_ce_bwd: workspace"); return TT_E_WORKSPACE; }

@@ -949,6 +949,103 @@ __global__ void mips_zero_kernel(u64* tau, int32_t* count, int32_t* lcount, int3
   if (i < nq) { tau[i] = 0; count[i] = 0; lcount[i] = 0; scount[i] = 0; }
 }
 
+// ---------------------------------------------------------------- D > 128: generic form
+// The register-stationary kernels above hold a query's D values in registers (D <= 128).  The reference
+// accepts any width (torch.matmul, ref:src/baseline_mips_module.py:58), so wider corpora take the same
+// pipeline with the two dense passes built from the library's fp32 GEMM instead: per corpus slab of
+// WIDE_ROWS rows the [nq, rows] score block is materialised in the workspace (bf16 operands are widened to
+// fp32 first: products of bf16 values are exact in fp32, accumulation is fp32 either way), then
+//   pass 1: every (query, group of 64 rows) -> gmax          pass 2: scores >= tau -> candidates.
+// Both passes run the SAME GEMM launches on the same slabs, so their scores are bit-identical and the
+// select / sort stages in between are the ones above.  This is the slow path by construction.
+constexpr int64_t WIDE_ROWS = 65536;
+
+__global__ __launch_bounds__(256) void mips_widen_bf16_kernel(const uint16_t* __restrict__ in, float* __restrict__ out,
+                                                              int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = __uint_as_float((uint32_t)in[i] << 16);
+}
+
+// S [nq][rows] (row stride lds) of corpus rows c0 .. c0+rows (c0 a multiple of 64).  PASS 1: gmax; PASS 2: candidates.
+template <int PASS>
+__global__ __launch_bounds__(256) void mips_wide_epilogue_kernel(const float* __restrict__ S, int64_t lds, int64_t nq,
+                                                                 int64_t c0, int64_t rows, uint32_t* __restrict__ gmax,
+                                                                 const u64* __restrict__ tau, u64* __restrict__ cand,
+                                                                 int32_t* __restrict__ count, int64_t cap) {
+  const int64_t ql = (int64_t)blockIdx.x * 256 + threadIdx.x;  // consecutive threads = consecutive queries (gmax is query-minor)
+  const int64_t g = blockIdx.y;                                // group inside the slab
+  if (ql >= nq) return;
+  const int64_t r0 = g * GROUP, r1 = (r0 + GROUP < rows) ? r0 + GROUP : rows;
+  const float* s = S + ql * lds;
+  const uint32_t grp = (uint32_t)(c0 / GROUP + g);
+  if (PASS == 1) {
+    float best = s[r0];
+    for (int64_t j = r0 + 1; j < r1; ++j) best = fmaxf(best, s[j]);
+    gmax[(int64_t)grp * nq + ql] = score_ord(best);
+  } else {
+    const u64 t = tau[ql];
+    for (int64_t j = r0; j < r1; ++j) {
+      const uint32_t ord = score_ord(s[j]);
+      if (ord_key(ord, grp) >= t) {
+        const int pos = atomicAdd(&count[ql], 1);
+        if (pos < cap) cand[ql * cap + pos] = ord_key(ord, (uint32_t)(c0 + j));
+      }
+    }
+  }
+}
+
+static int64_t wide_extra_bytes(int64_t qb, int64_t C, int64_t D, int dtype) {
+  const int64_t rows = C < WIDE_ROWS ? round_up(C, GROUP) : WIDE_ROWS;
+  int64_t n = round_up(qb * rows * 4, 256) + round_up(tt_gemm_workspace_bytes(TT_GEMM_NT, qb, rows, D), 256);
+  if (dtype == TT_BF16) n += round_up(qb * D * 4, 256) + round_up(rows * D * 4, 256);
+  return n;
+}
+
+// one dense pass over the whole corpus for queries q0 .. q0+nq
+static int mips_wide_pass(int pass, const MipsArgs& a, int dtype, void* extra, int64_t extra_bytes, int64_t qb, hipStream_t st) {
+  const int64_t rows_max = a.C < WIDE_ROWS ? round_up(a.C, GROUP) : WIDE_ROWS;
+  Carver cv(extra);
+  float* S = cv.take<float>(qb * rows_max);
+  const int64_t gemm_bytes = round_up(tt_gemm_workspace_bytes(TT_GEMM_NT, qb, rows_max, a.D), 256);
+  char* gws = cv.take<char>(gemm_bytes);
+  float *qf = nullptr, *cf = nullptr;
+  if (dtype == TT_BF16) { qf = cv.take<float>(qb * a.D); cf = cv.take<float>(rows_max * a.D); }
+  if (cv.off > extra_bytes) { set_error("tt_mips_topk (D > 128): workspace"); return TT_E_WORKSPACE; }
+  tt_stream_t ts = reinterpret_cast<tt_stream_t>(st);
+  const float* Q = reinterpret_cast<const float*>(a.Q) + a.q0 * a.D;
+  int rc;
+  if (dtype == TT_BF16) {
+    mips_widen_bf16_kernel<<<(unsigned)(ceil_div(a.nq * a.D, 256) < 2048 ? ceil_div(a.nq * a.D, 256) : 2048), 256, 0, st>>>(
+        reinterpret_cast<const uint16_t*>(a.Q) + a.q0 * a.D, qf, a.nq * a.D);
+    if ((rc = check_launch("mips_widen_bf16_kernel"))) return rc;
+    Q = qf;
+  }
+  if (pass == 1) {  // a trailing group with no rows is never visited below: it must read as "empty" (0)
+    const int64_t n_groups = 2 * a.n_chunks, tail = n_groups >= 2 ? 2 : n_groups;
+    hipError_t he = hipMemsetAsync(a.gmax + (n_groups - tail) * a.nq, 0, tail * a.nq * 4, st);
+    if (he != hipSuccess) { set_error("tt_mips_topk: memset: %s", hipGetErrorString(he)); return (int)he; }
+  }
+  ProfScope prof("mips_score_kernel", st);
+  for (int64_t c0 = 0; c0 < a.C; c0 += rows_max) {
+    const int64_t rows = (a.C - c0 < rows_max) ? a.C - c0 : rows_max;
+    const float* Cc = reinterpret_cast<const float*>(a.Cm) + c0 * a.D;
+    if (dtype == TT_BF16) {
+      mips_widen_bf16_kernel<<<2048, 256, 0, st>>>(reinterpret_cast<const uint16_t*>(a.Cm) + c0 * a.D, cf, rows * a.D);
+      if ((rc = check_launch("mips_widen_bf16_kernel"))) return rc;
+      Cc = cf;
+    }
+    if ((rc = tt_gemm_f32(TT_GEMM_NT, a.nq, rows, a.D, Q, a.D, Cc, a.D, S, rows_max, nullptr, TT_EPI_NONE, nullptr, 0, 0, gws,
+                          gemm_bytes, ts)))
+      return rc;
+    dim3 grid((unsigned)ceil_div(a.nq, 256), (unsigned)ceil_div(rows, GROUP));
+    if (pass == 1) mips_wide_epilogue_kernel<1><<<grid, 256, 0, st>>>(S, rows_max, a.nq, c0, rows, a.gmax, a.tau, a.cand, a.count, a.cap);
+    else mips_wide_epilogue_kernel<2><<<grid, 256, 0, st>>>(S, rows_max, a.nq, c0, rows, a.gmax, a.tau, a.cand, a.count, a.cap);
+    if ((rc = check_launch("mips_wide_epilogue_kernel"))) return rc;
+  }
+  return 0;
+}
+
 constexpr int64_t MIPS_QBATCH = 1024;
 
 struct MipsPlan {
@@ -957,9 +1054,9 @@ struct MipsPlan {
 };
 static bool plan_mips(int64_t B, int64_t C, int64_t D, int64_t K, int dtype, MipsPlan& pl) {
   if (dtype == TT_F32) {
-    if (D <= 32) pl.dpx = 4; else if (D <= 64) pl.dpx = 8; else if (D <= 128) pl.dpx = 16; else return false;
+    if (D <= 32) pl.dpx = 4; else if (D <= 64) pl.dpx = 8; else if (D <= 128) pl.dpx = 16; else pl.dpx = 0;  // 0: generic form
   } else if (dtype == TT_BF16) {
-    if (D <= 32) pl.dpx = 2; else if (D <= 64) pl.dpx = 4; else if (D <= 128) pl.dpx = 8; else return false;
+    if (D <= 32) pl.dpx = 2; else if (D <= 64) pl.dpx = 4; else if (D <= 128) pl.dpx = 8; else pl.dpx = 0;
   } else {
     return false;
   }
@@ -1089,7 +1186,8 @@ extern "C" int64_t tt_mips_workspace_bytes(int64_t B, int64_t C, int64_t D, int6
          + round_up(pl.qb * 8, 256)              // tau
          + round_up(pl.qb * 4, 256)              // count
          + 2 * round_up(pl.qb * pl.cap * 8, 256) // candidates + sort ping-pong
-         + 256;                                  // status word
+         + 256                                   // status word
+         + (pl.dpx == 0 ? wide_extra_bytes(pl.qb, C, D, dtype) : 0);  // D > 128: score slab, GEMM scratch, widened operands
 }
 
 extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, int64_t B, int64_t C, int64_t D,
@@ -1098,7 +1196,7 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
   if (!query || !corpus || !idx_out || !score_out || !ws) return fail_arg("tt_mips_topk: null pointer");
   if (B <= 0 || C <= 0 || D <= 0 || K <= 0 || K > C || C >= ((int64_t)1 << 32)) return fail_arg("tt_mips_topk: sizes");
   MipsPlan pl;
-  if (!plan_mips(B, C, D, K, dtype, pl)) { set_error("tt_mips_topk: D=%lld > 128 or unknown dtype", (long long)D); return TT_E_UNSUPPORTED; }
+  if (!plan_mips(B, C, D, K, dtype, pl)) { set_error("tt_mips_topk: unknown dtype %d", dtype); return TT_E_UNSUPPORTED; }
   if (ws_bytes < tt_mips_workspace_bytes(B, C, D, K, dtype)) { set_error("tt_mips_topk: workspace"); return TT_E_WORKSPACE; }
   hipStream_t st = S(stream);
   Carver cv(ws);
@@ -1117,6 +1215,9 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
   u64* cand = cv.take<u64>(pl.qb * pl.cap);
   u64* tmp = cv.take<u64>(pl.qb * pl.cap);
   int32_t* status = cv.take<int32_t>(1);
+  const bool wide = pl.dpx == 0;
+  void* wide_ws = reinterpret_cast<char*>(ws) + cv.off;
+  const int64_t wide_bytes = ws_bytes - cv.off;
   const int esz = dtype == TT_F32 ? 4 : 2;
   const bool vec = ((reinterpret_cast<uintptr_t>(query) | reinterpret_cast<uintptr_t>(corpus)) & 15) == 0 &&
                    (D * esz) % 16 == 0;
@@ -1137,13 +1238,18 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
     // sparse pass 2 reads the corpus rows as MFMA fragments straight from global memory
     static const bool no_sparse = getenv("TT_MIPS_NO_SPARSE") != nullptr;
     const int dp = pl.dpx * (dtype == TT_F32 ? 8 : 16);
-    const bool sparse = pl.n_groups > K && vec && D == dp && !no_sparse;
+    const bool sparse = pl.n_groups > K && vec && D == dp && !no_sparse && !wide;
     if (pl.n_groups > K) {  // otherwise tau = 0: every item is a candidate (cap == n_groups*64 >= C)
       static const bool no_dma = getenv("TT_MIPS_NO_DMA") != nullptr;
-      rc = (vec && D == dp && !no_dma) ? dispatch_pass1_dma(dtype, pl.dpx, a, pl.splits, st) : -1;
-      if (rc == -1) {  // generic pass 1 keeps the group maxima only
+      if (wide) {  // D > 128: dense pass from the library GEMM, group maxima only
         a.gm2 = nullptr;
-        rc = dispatch_score<1>(dtype, pl.dpx, a, grid, st);
+        rc = mips_wide_pass(1, a, dtype, wide_ws, wide_bytes, pl.qb, st);
+      } else {
+        rc = (vec && D == dp && !no_dma) ? dispatch_pass1_dma(dtype, pl.dpx, a, pl.splits, st) : -1;
+        if (rc == -1) {  // generic pass 1 keeps the group maxima only
+          a.gm2 = nullptr;
+          rc = dispatch_score<1>(dtype, pl.dpx, a, grid, st);
+        }
       }
       if (rc) return rc;
       static const bool no_top2 = getenv("TT_MIPS_NO_TOP2") != nullptr;  // A/B: re-score every selected group
@@ -1175,6 +1281,8 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
       if (gsplit > max_split) gsplit = max_split;
       if (gsplit < 1) gsplit = 1;
       if ((rc = dispatch_sparse(dtype, pl.dpx, a, dim3((unsigned)nq, (unsigned)gsplit), st))) return rc;
+    } else if (wide) {
+      if ((rc = mips_wide_pass(2, a, dtype, wide_ws, wide_bytes, pl.qb, st))) return rc;
     } else {
       if ((rc = dispatch_score<2>(dtype, pl.dpx, a, grid, st))) return rc;
     }
