@@ -28,6 +28,8 @@
 // 64h .. 64h+63, in increasing order: the group max needs no cross-lane traffic.
 //   fp32 : v_mfma_f32_32x32x2_f32   (fp32 products and accumulate)
 //   bf16 : v_mfma_f32_32x32x16_bf16 (exact products, fp32 accumulate)
+#include <type_traits>
+
 #include "common.hpp"
 #include "mfma_stream.hpp"
 
@@ -304,26 +306,44 @@ __global__ __launch_bounds__(256) void mips_score_kernel(const MipsArgs p) {
 //   * 2 workgroups per CU, so one wave's max-epilogue overlaps another's MFMAs;
 //   * NQ = 2 (bf16): every A fragment read from LDS feeds TWO MFMAs (64 queries per wave) -- at
 //     one 1-KiB LDS read per 32-cycle bf16 MFMA the LDS port, not the matrix core, is the limit.
+// The lane-dependent part of a tile DMA's addressing is the same for every tile: 2 VGPRs for the whole kernel.
+// Everything else (which rows this wave instruction lands, the tile parity, the swizzle of its base row) is
+// wave-uniform and goes into the scalar offset of the buffer load.  Keeping one precomputed 32-bit offset per DMA
+// instruction and parity instead (8-16 VGPRs) pushed the NQ = 4 bf16 kernel past 256 registers, and a spill
+// reload waits on vmcnt -- i.e. on the DMA of the tiles still in flight.
+struct DmaLane {
+  int vrow;  // chunk_row(0, lane / CPR) * row_bytes
+  int vc;    // 16 * ((lane % CPR) ^ ((lane / CPR) & SW))
+};
+template <int DP8>
+__device__ __forceinline__ DmaLane dma_lane(int lane, int64_t row_bytes) {
+  using TM = TileMap<DP8, true>;
+  const int lr = lane / TM::CPR;
+  return DmaLane{chunk_row(0, lr) * (int)row_bytes, 16 * ((lane % TM::CPR) ^ (lr & TM::SW))};
+}
+
 template <int DP8>
 __device__ __forceinline__ void corpus_tile_dma(const char* __restrict__ Cm, int64_t row_bytes, int64_t t, int64_t C,
-                                                float* Ys, int wave, int lane) {
+                                                float* Ys, int wave, const DmaLane& dl) {
   using TM = TileMap<DP8, true>;
   constexpr int RPI = 64 / TM::CPR;  // rows per wave instruction (1 KiB)
   constexpr int NI = CT / RPI / 4;   // instructions per wave
-  // buffer loads (see tile_dma in mfma_stream.hpp): chunk base in a scalar descriptor, one 32-bit lane
-  // offset; rows past the end of the corpus are outside the descriptor and land as zeros (the
-  // epilogue masks them)
+  // buffer loads (see tile_dma in mfma_stream.hpp): chunk base in a scalar descriptor; rows past the end of
+  // the corpus are outside the descriptor and land as zeros (the epilogue masks them)
   const int64_t chunk0 = (t >> 1) * CHUNK, left = C - chunk0;
   const int rows_here = left < CHUNK ? (int)left : CHUNK;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Cm + chunk0 * row_bytes), 0,
                                                                       rows_here * (int)row_bytes, 0x00020000);
+  const int w = __builtin_amdgcn_readfirstlane(wave);
+  const int par = (int)(t & 1);
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int rbase = (wave * NI + i) * RPI;
-    const int row = rbase + lane / TM::CPR;
-    const int c = (lane % TM::CPR) ^ (row & TM::SW);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Ys + rbase * TM::DP), 16,
-                                             chunk_row((int)(t & 1), row) * (int)row_bytes + 16 * c, 0, 0, 0);
+    // LDS rows rbase .. rbase + RPI - 1 (rbase a multiple of RPI, so its bits and the lane's row bits are disjoint:
+    // chunk_row(par, rbase + lr) = chunk_row(par, rbase) + chunk_row(0, lr), and the swizzles XOR)
+    const int rbase = (w * NI + i) * RPI;
+    const int voff = dl.vrow + (dl.vc ^ (16 * (rbase & TM::SW)));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Ys + rbase * TM::DP), 16, voff,
+                                             chunk_row(par, rbase) * (int)row_bytes, 0, 0);
   }
 }
 
@@ -384,9 +404,10 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
   const int64_t row_bytes = p.D * O::ESZ;
 
   constexpr int NI = CT / (64 / TM::CPR) / 4;  // DMA instructions per wave per tile
+  const DmaLane dl = dma_lane<DPX>(lane, row_bytes);
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
-    if (t0 + s < t1) corpus_tile_dma<DPX>(Cm, row_bytes, t0 + s, p.C, stage(s), wave, lane);
+    if (t0 + s < t1) corpus_tile_dma<DPX>(Cm, row_bytes, t0 + s, p.C, stage(s), wave, dl);
   if (t0 + STAGES - 1 <= t1) wait_vmcnt<(STAGES - 2) * NI>();  // tile t0 has landed
   else wait_vmcnt<0>();
   __syncthreads();
@@ -399,14 +420,17 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
   for (int n = 0; n < NQ; ++n) { m1[n] = NEG_INF; m2[n] = NEG_INF; arg[n] = 0; }
   // one tile: `ys` is scored, `dst` (the stage of tile t-1, free since the barrier that ended the
   // previous step) receives tile t + STAGES - 1
-  auto step = [&](int64_t t, const float* ys, float* dst) {
+  // PAR = t & 1 (t0 is even) as a compile-time constant: the group-relative row of every accumulator element is
+  // then an inline constant of the v_cndmask that tracks the best row -- no v_mov per element.
+  auto step = [&](auto par_c, int64_t t, const float* ys, float* dst) {
+    constexpr int PAR = decltype(par_c)::value;
     const bool more = t + STAGES - 1 < t1;
-    if (more) corpus_tile_dma<DPX>(Cm, row_bytes, t + STAGES - 1, p.C, dst, wave, lane);
+    if (more) corpus_tile_dma<DPX>(Cm, row_bytes, t + STAGES - 1, p.C, dst, wave, dl);
     const int64_t chunk = t >> 1;
     const bool full = (chunk + 1) * CHUNK <= p.C;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
-      if (SF == 4 && (2 * (int)(t & 1) + jt) != wave) continue;  // this sub-tile belongs to another wave
+      if (SF == 4 && (2 * PAR + jt) != wave) continue;  // this sub-tile belongs to another wave
       if (SF == 2 && jt != member) continue;                     // the pair's other wave takes this sub-tile
       f32x16 acc[NQ];
       if constexpr (DT == TT_F32) {
@@ -449,31 +473,42 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
           }
         }
       }
-      const int off0 = 16 * (2 * (int)(t & 1) + jt);  // group-relative row of element 0
-      const int64_t b0 = chunk * CHUNK + 64 * h + off0;
-      if constexpr (DT == TT_F32) {
-        // fp32 (one accumulator tile): mask the last partial chunk up front, keeping the per-element
-        // loop free of the select (+4 % on the pass).  With 2-4 bf16 tiles in flight the same hoist
-        // costs registers and halves the rate, so bf16 keeps the select inside the loop.
-        if (!full) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[0][e] = (b0 + e < p.C) ? acc[0][e] : NEG_INF;
-        }
-      }
-#pragma unroll
-      for (int n = 0; n < NQ; ++n) {
+      const int off0 = 16 * (2 * PAR + jt);  // group-relative row of element 0 (compile-time: jt is unrolled)
+      // Per score: compare, med3 (new runner-up), two selects (best score, best row) = 4 VALU instructions.
+      // fmaxf would add a canonicalising v_max per element, a runtime row offset a v_mov, and testing "row < C"
+      // inside the loop a 64-bit compare + two selects: 10 instructions per score, 2.5x the MFMA time of a bf16
+      // tile.  The last (partial) chunk takes the masked copy of the loop through a wave-uniform branch.
+      if (full) {
+        // element-major: the NQ chains are independent, so consecutive instructions never wait on each other's
+        // compare result (chain-major order costs an s_nop per element for the VCC hazard)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          float x = acc[n][e];
-          if (DT != TT_F32 && !full) x = (b0 + e < p.C) ? x : NEG_INF;
-          const bool gt = x > m1[n];  // strict: equal scores keep the earlier (smaller) row
-          m2[n] = __builtin_amdgcn_fmed3f(m1[n], m2[n], x);
-          m1[n] = fmaxf(m1[n], x);
-          arg[n] = gt ? off0 + e : arg[n];
+#pragma unroll
+          for (int n = 0; n < NQ; ++n) {
+            const float x = acc[n][e];
+            const bool gt = x > m1[n];  // strict: equal scores keep the earlier (smaller) row
+            m2[n] = __builtin_amdgcn_fmed3f(m1[n], m2[n], x);
+            m1[n] = gt ? x : m1[n];
+            arg[n] = gt ? off0 + e : arg[n];
+          }
+        }
+      } else {
+        const int64_t left = p.C - (chunk * CHUNK + 64 * h + off0);
+        const int valid = left < 0 ? 0 : left > 16 ? 16 : (int)left;  // elements of this lane's 16 rows inside the corpus
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float x = e < valid ? acc[n][e] : NEG_INF;
+            const bool gt = x > m1[n];
+            m2[n] = __builtin_amdgcn_fmed3f(m1[n], m2[n], x);
+            m1[n] = gt ? x : m1[n];
+            arg[n] = gt ? off0 + e : arg[n];
+          }
         }
       }
     }
-    if (SHARE && (t & 1)) {
+    if (SHARE && PAR) {
       // merge the four waves' partial triples of this chunk (sub-tiles in ascending row order, so
       // "strictly greater" keeps the earlier row on ties, like the sequential scan)
       red[(wave * 64 + lane) * 3] = m1[0];
@@ -496,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
         m1[0] = M1; m2[0] = M2; arg[0] = A;
       }
     }
-    if ((t & 1) && (!SHARE || member == 0)) {  // chunk complete: lane-half h holds group 2*chunk + h
+    if (PAR && (!SHARE || member == 0)) {  // chunk complete: lane-half h holds group 2*chunk + h
       const int64_t grp = 2 * chunk + h;
       const bool nonempty = grp * GROUP < p.C;
 #pragma unroll
@@ -510,21 +545,27 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
         m1[n] = NEG_INF; m2[n] = NEG_INF; arg[n] = 0;
       }
     }
-    if (SHARE && (t & 1) && member != 0) { m1[0] = NEG_INF; m2[0] = NEG_INF; arg[0] = 0; }
+    if (SHARE && PAR && member != 0) { m1[0] = NEG_INF; m2[0] = NEG_INF; arg[0] = 0; }
     // tile t+1 must have landed; tiles t+2 .. t+STAGES-1 may still be in flight
     if (more) wait_vmcnt<(STAGES - 2) * NI>();
     else wait_vmcnt<0>();
     __syncthreads();
   };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
   if constexpr (NAMED) {
     for (int64_t t = t0; t < t1; t += 2) {
-      step(t, ring0, ring1);
-      if (t + 1 < t1) step(t + 1, ring1, ring0);
+      step(P0{}, t, ring0, ring1);
+      if (t + 1 < t1) step(P1{}, t + 1, ring1, ring0);
     }
   } else {
-    for (int64_t t = t0; t < t1; ++t) {
-      const int cur = (int)((t - t0) % STAGES);
-      step(t, smem + cur * TILE_FLOATS, smem + ((cur + STAGES - 1) % STAGES) * TILE_FLOATS);
+    static_assert(NAMED || STAGES % 2 == 0, "the dynamic ring is walked two tiles (one chunk) at a time");
+    int cur = 0;
+    for (int64_t t = t0; t < t1; t += 2) {  // t1 - t0 is even: whole chunks
+      step(P0{}, t, smem + cur * TILE_FLOATS, smem + ((cur + STAGES - 1) % STAGES) * TILE_FLOATS);
+      cur = (cur + 1) % STAGES;
+      step(P1{}, t + 1, smem + cur * TILE_FLOATS, smem + ((cur + STAGES - 1) % STAGES) * TILE_FLOATS);
+      cur = (cur + 1) % STAGES;
     }
   }
 }
