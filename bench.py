@@ -447,7 +447,7 @@ def main():
     if rank == 0:
         B = cfg["B"]
         pairs = B * world * args.steps
-        sweep_bytes_step = algorithmic_sweep_bytes(cfg, world)  # per GPU per step (2 launches)
+        sweep_bytes_step = algorithmic_sweep_bytes(cfg, world)  # per GPU per step (one launch spans both tables)
         roof = None
         if args.adam == "lazy":
             # the flush reads and rewrites each table once (24 B/element) and replays `steps` updates per
@@ -467,7 +467,8 @@ def main():
                     traffic = rec.get("hbm_bytes_per_launch")
             # the name rocprofv3 reports for it (profiles/r01_kernel_stats_P_1gpu_final.csv)
             sweep_name = ("adam_sweep_bounded_kernel" if os.environ.get("TT_SWEEP_PERSIST") == "0"
-                          else "adam_sweep_persistent_kernel")
+                          else "adam_sweep_persistent_kernel" if os.environ.get("TT_SWEEP_ONE_LAUNCH") == "0"
+                          else "adam_sweep_tables_kernel")
             roof = {"bound": "hbm", "kernel": sweep_name, "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic,

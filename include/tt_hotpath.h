@@ -248,6 +248,12 @@ int tt_adam_table_stash_ids(const float* W, const float* M, const float* V, int6
                             tt_stream_t stream);
 int tt_adam_table_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
                         tt_stream_t stream);
+/* tt_adam_table_sweep for up to 4 tables in ONE launch (descriptor .p/.m/.v/.n = weights, moments, element count;
+ * .g unused): the chunk list spans the tables, so a step has one sweep launch and one tail.  Bit-identical to the
+ * per-table calls. */
+struct tt_adam_tensor_s;
+int tt_adam_tables_sweep(const struct tt_adam_tensor_s* tables /*host*/, int32_t n_tables, const double* hyper,
+                         tt_stream_t stream);
 int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
                          const tt_grad_sources* src /*host*/, int64_t n_ids, const int32_t* sorted_ids,
                          const int32_t* perm, const int32_t* seg_begin, const int32_t* n_unique,
@@ -286,7 +292,7 @@ int tt_adam_table_flush(float* W, float* M, float* V, int64_t n_rows, int64_t di
 
 /* dense parameters: `tensors` is a HOST array of n_tensors {p,g,m,v,n} descriptors
  * (device pointers inside); they are passed to the kernel by value, 64 per launch. */
-typedef struct {
+typedef struct tt_adam_tensor_s {
   float* p;
   const float* g;
   float* m;

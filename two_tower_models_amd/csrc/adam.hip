@@ -277,11 +277,39 @@ __global__ __launch_bounds__(256) void adam_sweep_bounded_kernel(float4* __restr
 // the forward / backward kernels' big workgroups for the whole 5 ms the sweep lasts -- with the
 // one-shot grid above the dispatcher refills every freed slot with another small sweep
 // workgroup and a 256-VGPR / 64-KiB workgroup never finds a whole CU's worth of room.
-template <int ITERS, int UNR>
+typedef float vf4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 sweep_load(const float4* p) {
+  if constexpr (NT) {
+    const vf4 t = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+  } else {
+    return *p;
+  }
+}
+template <bool NT>
+__device__ __forceinline__ void sweep_store(const float4& v, float4* p) {
+  if constexpr (NT) {
+    vf4 t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<vf4*>(p));
+  } else {
+    *p = v;
+  }
+}
+
+// NT: non-temporal loads AND stores (every byte is touched exactly once per step, nothing is worth keeping in
+// L2 / MALL).  Measured with tools/sweep_probe.hip, all variants in one process on the same buffers: nt on both
+// sides +4 % at 3 workgroups per CU, +9.5 % at 2 per CU (6.16 vs 5.62 TB/s on a slower box, 6.33 vs 6.10 on a
+// faster one); nt on the loads alone +1.5 %, on the stores alone -3 %.  (Round 1 tried nt on the one-shot grid
+// form only, where it lost.)  FEWER resident sweep waves stream better, not worse: 1-2 workgroups per CU beat 3,
+// 4, 6, 8 -- fewer DRAM pages open at once -- as long as each lane keeps 12 x 16 B in flight.
+template <int ITERS, int UNR, bool NT>
 __global__ __launch_bounds__(256) void adam_sweep_persistent_kernel(float4* __restrict__ W, float4* __restrict__ M,
                                                                     float4* __restrict__ V, int64_t n4,
                                                                     const double* __restrict__ hyper,
-                                                                    unsigned* __restrict__ ctr) {
+                                                                    unsigned* __restrict__ ctr, int prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);  // A/B (TT_SWEEP_PRIO): the sweep's waves win instruction issue on their SIMD
   const AdamConst c = load_hyper(hyper);
   const unsigned n_chunks = (unsigned)((n4 + 256 * ITERS - 1) / (256 * ITERS));
   __shared__ unsigned s_next[2];
@@ -301,12 +329,69 @@ __global__ __launch_bounds__(256) void adam_sweep_persistent_kernel(float4* __re
     for (int k = 0; k < ITERS; ++k) {
       const int64_t i = base + (int64_t)k * 256;
       if (i >= n4) break;
-      float4 p = W[i], m = M[i], v = V[i];
+      float4 p = sweep_load<NT>(W + i), m = sweep_load<NT>(M + i), v = sweep_load<NT>(V + i);
       adam_elem_zero_grad(p.x, m.x, v.x, c);
       adam_elem_zero_grad(p.y, m.y, v.y, c);
       adam_elem_zero_grad(p.z, m.z, v.z, c);
       adam_elem_zero_grad(p.w, m.w, v.w, c);
-      W[i] = p; M[i] = m; V[i] = v;
+      sweep_store<NT>(p, W + i); sweep_store<NT>(m, M + i); sweep_store<NT>(v, V + i);
+    }
+    __syncthreads();
+    par ^= 1;
+    ch = s_next[par];
+  }
+  if (threadIdx.x == 0) {
+    if (atomicAdd(&ctr[1], 1u) == gridDim.x - 1) {
+      ctr[0] = 0;
+      ctr[1] = 0;
+      __threadfence();
+    }
+  }
+}
+
+// The same sweep over SEVERAL tables in one launch (tt_adam_tables_sweep): the chunk list simply spans them,
+// so a step has one sweep launch, one tail and no launch gap between the user and the item table.
+constexpr int SWEEP_MAX_TABLES = 4;
+struct SweepTables {
+  float4* W[SWEEP_MAX_TABLES];
+  float4* M[SWEEP_MAX_TABLES];
+  float4* V[SWEEP_MAX_TABLES];
+  int64_t n4[SWEEP_MAX_TABLES];
+  unsigned first_chunk[SWEEP_MAX_TABLES + 1];  // table t owns chunks [first_chunk[t], first_chunk[t + 1])
+  int n;
+};
+template <int ITERS, int UNR, bool NT>
+__global__ __launch_bounds__(256) void adam_sweep_tables_kernel(const SweepTables tabs, const double* __restrict__ hyper,
+                                                                unsigned* __restrict__ ctr, int prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);
+  const AdamConst c = load_hyper(hyper);
+  const unsigned n_chunks = tabs.first_chunk[tabs.n];
+  __shared__ unsigned s_next[2];
+  if (threadIdx.x == 0) s_next[0] = atomicAdd(&ctr[0], 1u);
+  __syncthreads();
+  unsigned ch = s_next[0];
+  int par = 0;
+  while (ch < n_chunks) {
+    if (threadIdx.x == 0) s_next[par ^ 1] = atomicAdd(&ctr[0], 1u);
+    int t = 0;
+#pragma unroll
+    for (int q = 1; q < SWEEP_MAX_TABLES; ++q)
+      if (q < tabs.n && ch >= tabs.first_chunk[q]) t = q;
+    float4* __restrict__ W = tabs.W[t];
+    float4* __restrict__ M = tabs.M[t];
+    float4* __restrict__ V = tabs.V[t];
+    const int64_t n4 = tabs.n4[t];
+    const int64_t base = (int64_t)(ch - tabs.first_chunk[t]) * (256 * ITERS) + threadIdx.x;
+#pragma unroll UNR
+    for (int k = 0; k < ITERS; ++k) {
+      const int64_t i = base + (int64_t)k * 256;
+      if (i >= n4) break;
+      float4 p = sweep_load<NT>(W + i), m = sweep_load<NT>(M + i), v = sweep_load<NT>(V + i);
+      adam_elem_zero_grad(p.x, m.x, v.x, c);
+      adam_elem_zero_grad(p.y, m.y, v.y, c);
+      adam_elem_zero_grad(p.z, m.z, v.z, c);
+      adam_elem_zero_grad(p.w, m.w, v.w, c);
+      sweep_store<NT>(p, W + i); sweep_store<NT>(m, M + i); sweep_store<NT>(v, V + i);
     }
     __syncthreads();
     par ^= 1;
@@ -529,7 +614,10 @@ static int launch_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t di
       // hyper[7] is the library's scratch slot: two 32-bit chunk counters, zero between launches
       unsigned* ctr = reinterpret_cast<unsigned*>(const_cast<double*>(hyper) + 7);
       const unsigned grid = (unsigned)(device_cu_count() * persist);
-      adam_sweep_persistent_kernel<4, 4><<<grid, 256, 0, st>>>(w4, m4, v4, n4, hyper, ctr);
+      static const bool nt = !(getenv("TT_SWEEP_NT") && atoi(getenv("TT_SWEEP_NT")) == 0);  // A/B switch, default on
+      static const int prio = getenv("TT_SWEEP_PRIO") ? atoi(getenv("TT_SWEEP_PRIO")) : 0;
+      if (nt) adam_sweep_persistent_kernel<4, 4, true><<<grid, 256, 0, st>>>(w4, m4, v4, n4, hyper, ctr, prio);
+      else adam_sweep_persistent_kernel<4, 4, false><<<grid, 256, 0, st>>>(w4, m4, v4, n4, hyper, ctr, prio);
     } else {
       adam_sweep_bounded_kernel<<<(unsigned)ceil_div(n4, 256 * SWEEP_ITERS), 256, 0, st>>>(w4, m4, v4, n4, hyper);
     }
@@ -610,6 +698,46 @@ extern "C" int tt_adam_table_sweep(float* W, float* M, float* V, int64_t n_rows,
   if (!W || !M || !V || !hyper) return fail_arg("tt_adam_table_sweep: null pointer");
   if (n_rows <= 0 || dim <= 0) return fail_arg("tt_adam_table_sweep: sizes");
   return launch_sweep(W, M, V, n_rows, dim, hyper, S(stream));
+}
+
+extern "C" int tt_adam_tables_sweep(const tt_adam_tensor* tables, int32_t n_tables, const double* hyper, tt_stream_t stream) {
+  if (!tables || !hyper) return fail_arg("tt_adam_tables_sweep: null pointer");
+  if (n_tables <= 0 || n_tables > SWEEP_MAX_TABLES) return fail_arg("tt_adam_tables_sweep: 1..4 tables");
+  hipStream_t st = S(stream);
+  static const int persist = getenv("TT_SWEEP_PERSIST") ? atoi(getenv("TT_SWEEP_PERSIST")) : SWEEP_DEFAULT_PERSIST;
+  static const bool nt = !(getenv("TT_SWEEP_NT") && atoi(getenv("TT_SWEEP_NT")) == 0);
+  static const int prio = getenv("TT_SWEEP_PRIO") ? atoi(getenv("TT_SWEEP_PRIO")) : 0;
+  static const bool one_launch = !(getenv("TT_SWEEP_ONE_LAUNCH") && atoi(getenv("TT_SWEEP_ONE_LAUNCH")) == 0);
+  bool fused = persist > 0 && one_launch && n_tables > 1;
+  SweepTables tabs{};
+  unsigned chunks = 0;
+  for (int t = 0; t < n_tables; ++t) {
+    const tt_adam_tensor& d = tables[t];
+    if (!d.p || !d.m || !d.v || d.n <= 0) return fail_arg("tt_adam_tables_sweep: descriptor");
+    // the fused launch streams float4 only: every table 16-B aligned with n % 4 == 0 (dim % 4 == 0), else launch per table
+    if (((reinterpret_cast<uintptr_t>(d.p) | reinterpret_cast<uintptr_t>(d.m) | reinterpret_cast<uintptr_t>(d.v)) & 15) || d.n % 4) fused = false;
+    tabs.W[t] = reinterpret_cast<float4*>(d.p); tabs.M[t] = reinterpret_cast<float4*>(d.m); tabs.V[t] = reinterpret_cast<float4*>(d.v);
+    tabs.n4[t] = d.n / 4;
+    tabs.first_chunk[t] = chunks;
+    const int64_t c = ceil_div(d.n / 4, 256 * 4);
+    if (c + chunks >= (1ll << 32)) fused = false;
+    chunks += (unsigned)c;
+  }
+  tabs.first_chunk[n_tables] = chunks;
+  tabs.n = n_tables;
+  if (!fused) {
+    for (int t = 0; t < n_tables; ++t) {
+      const int rc = launch_sweep(tables[t].p, tables[t].m, tables[t].v, tables[t].n, 1, hyper, st);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  unsigned* ctr = reinterpret_cast<unsigned*>(const_cast<double*>(hyper) + 7);
+  const unsigned grid = (unsigned)(device_cu_count() * persist);
+  ProfScope prof("adam_sweep_kernel", st);
+  if (nt) adam_sweep_tables_kernel<4, 4, true><<<grid, 256, 0, st>>>(tabs, hyper, ctr, prio);
+  else adam_sweep_tables_kernel<4, 4, false><<<grid, 256, 0, st>>>(tabs, hyper, ctr, prio);
+  return check_launch("adam_sweep_tables_kernel");
 }
 
 // A HIP stream of the device's LEAST priority for the sweep: the backward kernels on the

@@ -297,11 +297,13 @@ class DenseExactAdam(torch.optim.Optimizer):
         ready = torch.cuda.Event()
         ready.record(main)  # lookups (or none yet, forward mode) + stashes are complete here
         self._side_stream.wait_event(ready)
-        for p in begun:
-            st = self.state[p]
-            N.check(lib.tt_adam_table_sweep(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                            p.shape[0], p.shape[1], hyper, self._side_stream.cuda_stream),
-                    "tt_adam_table_sweep")
+        if begun:  # ONE launch for all tables: no gap and a single tail between the user and the item table
+            descs = (N.AdamTensor * len(begun))()
+            for i, p in enumerate(begun):
+                st = self.state[p]
+                descs[i].p, descs[i].g = p.data_ptr(), None
+                descs[i].m, descs[i].v, descs[i].n = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+            N.check(lib.tt_adam_tables_sweep(descs, len(begun), hyper, self._side_stream.cuda_stream), "tt_adam_tables_sweep")
         if announced is not None:
             for ts in begun.values():
                 ts.plan.build()  # main stream, underneath the sweep

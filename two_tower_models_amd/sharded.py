@@ -441,9 +441,14 @@ class HipBackend:
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
         self._side_stream.wait_event(ready)
-        for W, M, V, n_local in tables:
-            N.check(lib.tt_adam_table_sweep(W.data_ptr(), M.data_ptr(), V.data_ptr(), n_local, W.shape[1],
-                                            hyper.data_ptr(), self._side_stream.cuda_stream), "tt_adam_table_sweep")
+        live = [(W, M, V, n_local) for W, M, V, n_local in tables if n_local > 0]
+        if live:  # one launch for both row blocks
+            descs = (N.AdamTensor * len(live))()
+            for i, (W, M, V, n_local) in enumerate(live):
+                descs[i].p, descs[i].g, descs[i].m, descs[i].v = W.data_ptr(), None, M.data_ptr(), V.data_ptr()
+                descs[i].n = n_local * W.shape[1]
+            N.check(lib.tt_adam_tables_sweep(descs, len(live), hyper.data_ptr(), self._side_stream.cuda_stream),
+                    "tt_adam_tables_sweep")
         self._sweep_done = torch.cuda.Event()
         self._sweep_done.record(self._side_stream)
 
