@@ -420,6 +420,13 @@ def main():
         else:
             step(batches[i % len(batches)])
 
+    main_ctx = None
+    k_sweep = int(os.environ.get("TT_SWEEP_CUS", "0"))
+    if 0 < k_sweep < 8 and not use_sharded:  # A/B: forward / backward on the CUs the sweep's stream does not use
+        comp = N.cu_masked_stream(device, lambda i: i % 8 >= k_sweep)
+        comp.wait_stream(torch.cuda.current_stream())
+        main_ctx = torch.cuda.stream(comp)
+        main_ctx.__enter__()
     for i in range(args.warmup):
         run(i)
     barrier()
@@ -436,6 +443,8 @@ def main():
         sharded.all_reduce_(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    if main_ctx is not None:
+        main_ctx.__exit__(None, None, None)
     import ctypes as C
     ms, cnt = C.c_double(0.0), C.c_int64(0)
     prof_kernel = b"adam_flush_kernel" if args.adam == "lazy" else b"adam_sweep_kernel"

@@ -262,6 +262,9 @@ int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows, int64_t d
 /* A HIP stream of the device's least priority (hipStreamCreateWithPriority) for
  * tt_adam_table_sweep, so the backward pass on the caller's stream is dispatched first. */
 int tt_stream_create_low_priority(void** out_stream);
+/* A stream whose kernels run only on the CUs whose bit is set in `mask` (host array, 32 CUs per word;
+ * hipExtStreamCreateWithCUMask): the sweep and the forward / backward kernels can be given disjoint CUs. */
+int tt_stream_create_cu_mask(const uint32_t* mask /*host*/, int32_t n_words, void** out_stream);
 int tt_stream_destroy(void* stream);
 
 /* Deferred ("lazy") schedule of the SAME dense Adam -- value-exact, reported separately from the

@@ -90,6 +90,7 @@ SIGNATURES = {
                                   _vp, _i64, _vp, _vp, _i64, _vp]),
     "tt_adam_table_flush": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
     "tt_stream_create_low_priority": (_int, [C.POINTER(_vp)]),
+    "tt_stream_create_cu_mask": (_int, [C.POINTER(C.c_uint32), _i32, C.POINTER(_vp)]),
     "tt_stream_destroy": (_int, [_vp]),
     "tt_adam_dense": (_int, [C.POINTER(AdamTensor), _i32, _vp, _vp]),
     "tt_hist_embed_pool": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp]),
@@ -188,6 +189,19 @@ def low_priority_stream(device: torch.device) -> torch.cuda.Stream:
     with torch.cuda.device(device):
         raw = _vp()
         check(load().tt_stream_create_low_priority(C.byref(raw)), "tt_stream_create_low_priority")
+    return torch.cuda.ExternalStream(raw.value, device=device)
+
+
+def cu_masked_stream(device: torch.device, keep, n_cus: int = 256) -> torch.cuda.Stream:
+    """Stream restricted to the CUs i for which keep(i) is true (tt_stream_create_cu_mask)."""
+    words = (n_cus + 31) // 32
+    mask = (C.c_uint32 * words)()
+    for i in range(n_cus):
+        if keep(i):
+            mask[i // 32] |= 1 << (i % 32)
+    with torch.cuda.device(device):
+        raw = _vp()
+        check(load().tt_stream_create_cu_mask(mask, words, C.byref(raw)), "tt_stream_create_cu_mask")
     return torch.cuda.ExternalStream(raw.value, device=device)
 
 

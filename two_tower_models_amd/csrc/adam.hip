@@ -753,6 +753,17 @@ extern "C" int tt_stream_create_low_priority(void** out) {
   *out = reinterpret_cast<void*>(s);
   return 0;
 }
+// A stream restricted to a subset of the CUs (hipExtStreamCreateWithCUMask): `mask` holds one bit per CU, 32 per
+// word.  Lets the HBM-bound sweep and the MFMA / latency-bound forward / backward kernels run on DISJOINT CUs, so
+// neither takes wave slots, LDS or issue cycles from the other (they still share HBM and L2).
+extern "C" int tt_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, void** out) {
+  if (!mask || !out || n_words <= 0) return fail_arg("tt_stream_create_cu_mask: null pointer / size");
+  hipStream_t s;
+  hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask);
+  if (e != hipSuccess) { set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e)); return (int)e; }
+  *out = reinterpret_cast<void*>(s);
+  return 0;
+}
 extern "C" int tt_stream_destroy(void* stream) {
   if (!stream) return 0;
   hipError_t e = hipStreamDestroy(reinterpret_cast<hipStream_t>(stream));

@@ -258,11 +258,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     }
 }
 
-// sum the split-K slabs in slab order (deterministic) and apply the epilogue
-__global__ void splitk_reduce_kernel(const float* __restrict__ ws, GemmArgs g) {
+// sum the split-K slabs in slab order (deterministic) and apply the epilogue.  Workgroups past `nb_reduce`
+// (tt_gemm_tn_colsum_f32 only) turn the per-split column-sum partials into the column sums -- what was a
+// launch of its own (colsum_stage2, same arithmetic in the same order: 13 launches per step at C3).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, GemmArgs g, int nb_reduce,
+                                                            const float* __restrict__ cs_part, float* __restrict__ cs_out) {
+  if ((int)blockIdx.x >= nb_reduce) {
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int64_t col = (int64_t)(blockIdx.x - nb_reduce) * 64 + c;
+    float sum = 0.f;
+    if (col < g.M)
+      for (int64_t p = rg; p < g.splits; p += 4) sum += cs_part[p * g.M + col];
+    red[rg][c] = sum;
+    __syncthreads();
+    if (rg == 0 && col < g.M) cs_out[col] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+    return;
+  }
   const int64_t total = g.M * g.N;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
+       i += (int64_t)nb_reduce * blockDim.x) {
     const int64_t row = i / g.N, col = i % g.N;
     float v = 0.f;
     for (int s = 0; s < g.splits; ++s) v += ws[(int64_t)s * total + i];
@@ -434,12 +449,10 @@ static int gemm_impl(int layout, int64_t M, int64_t N, int64_t K, const float* A
   if (g.splits > 1) {
     const int64_t total = M * N;
     const int64_t blocks = ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048;
-    splitk_reduce_kernel<<<blocks, 256, 0, st>>>(reinterpret_cast<const float*>(ws), g);
+    // with a_colsum: ceil(M / 64) extra workgroups reduce the per-split column-sum partials, in split order
+    const int64_t extra = a_colsum ? ceil_div(M, 64) : 0;
+    splitk_reduce_kernel<<<(unsigned)(blocks + extra), 256, 0, st>>>(reinterpret_cast<const float*>(ws), g, (int)blocks, cs_part, a_colsum);
     if ((rc = check_launch("splitk_reduce_kernel"))) return rc;
-    if (a_colsum) {  // per-split partials -> column sums, in split order
-      colsum_stage2<<<(unsigned)ceil_div(M, 64), 256, 0, st>>>(cs_part, g.splits, M, a_colsum);
-      return check_launch("colsum_stage2");
-    }
   }
   return 0;
 }

@@ -116,6 +116,8 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._hyper = None
         self._ready = False
         self._side_stream: Optional[torch.cuda.Stream] = None
+        self._plan_stream: Optional[torch.cuda.Stream] = None
+        self._plan_done: Optional[torch.cuda.Event] = None
         self._begun: Optional[Dict[torch.nn.Parameter, _TableStep]] = None
         self._sweep_done: Optional[torch.cuda.Event] = None
         self._side_bufs: Dict[int, torch.Tensor] = {}
@@ -133,7 +135,11 @@ class DenseExactAdam(torch.optim.Optimizer):
             for key in ("exp_avg", "exp_avg_sq"):  # a loaded checkpoint already supplied them
                 if key not in st or st[key].shape != p.shape or st[key].device != p.device:
                     st[key] = torch.zeros_like(p) if key not in st else st[key].to(p.device, torch.float32).contiguous()
-        self._side_stream = N.low_priority_stream(dev)
+        # TT_SWEEP_CUS=k (A/B): the sweep's stream is restricted to k of every 8 CUs; the caller may
+        # run the step itself on the complementary CUs (bench.py --cu-split)
+        import os
+        k = int(os.environ.get("TT_SWEEP_CUS", "0"))
+        self._side_stream = N.cu_masked_stream(dev, lambda i: i % 8 < k) if 0 < k < 8 else N.low_priority_stream(dev)
         start = int(self._resume_step)
         self._hyper[4] = float(start)  # [5], [6] are recomputed from the step by every advance
         self._host_steps = start
@@ -304,9 +310,19 @@ class DenseExactAdam(torch.optim.Optimizer):
                 descs[i].p, descs[i].g = p.data_ptr(), None
                 descs[i].m, descs[i].v, descs[i].n = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
             N.check(lib.tt_adam_tables_sweep(descs, len(begun), hyper, self._side_stream.cuda_stream), "tt_adam_tables_sweep")
-        if announced is not None:
-            for ts in begun.values():
-                ts.plan.build()  # main stream, underneath the sweep
+        self._plan_done = None
+        if announced is not None and begun:
+            # The stable sort of the ids is needed only by finish (in step()): it runs on a THIRD stream, next to the
+            # forward / backward kernels instead of in front of them.  Its ~15 short launches per table are latency-
+            # bound (0.55 ms for the 209 K ids of the history model) and use a handful of CUs.
+            if self._plan_stream is None:
+                self._plan_stream = torch.cuda.Stream(device=next(iter(begun)).device)
+            self._plan_stream.wait_event(ready)  # the id lists exist
+            with torch.cuda.stream(self._plan_stream):
+                for ts in begun.values():
+                    ts.plan.build()
+                self._plan_done = torch.cuda.Event()
+                self._plan_done.record(self._plan_stream)
         self._sweep_done = torch.cuda.Event()
         self._sweep_done.record(self._side_stream)
         self._begun = begun
@@ -358,6 +374,9 @@ class DenseExactAdam(torch.optim.Optimizer):
         if self._begun is not None:
             # overlapped schedule: hyper already advanced, tables already swept on the side stream
             torch.cuda.current_stream().wait_event(self._sweep_done)
+            if self._plan_done is not None:
+                torch.cuda.current_stream().wait_event(self._plan_done)
+                self._plan_done = None
             for p, ts in self._begun.items():
                 st = self.state[p]
                 ts.plan.attach(self._ordered_rows(p))
