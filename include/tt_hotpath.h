@@ -250,10 +250,12 @@ int tt_adam_table_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t di
                         tt_stream_t stream);
 /* tt_adam_table_sweep for up to 4 tables in ONE launch (descriptor .p/.m/.v/.n = weights, moments, element count;
  * .g unused): the chunk list spans the tables, so a step has one sweep launch and one tail.  Bit-identical to the
- * per-table calls. */
+ * per-table calls.  n_wgs > 0 caps the number of persistent workgroups (a THROTTLED sweep: when the step is much longer
+ * than the sweep, a thin sweep that lasts most of the step takes less HBM bandwidth from the forward / backward kernels
+ * at any moment than a saturating one at its start); 0 = the default (3 per CU). */
 struct tt_adam_tensor_s;
 int tt_adam_tables_sweep(const struct tt_adam_tensor_s* tables /*host*/, int32_t n_tables, const double* hyper,
-                         tt_stream_t stream);
+                         int32_t n_wgs, tt_stream_t stream);
 int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
                          const tt_grad_sources* src /*host*/, int64_t n_ids, const int32_t* sorted_ids,
                          const int32_t* perm, const int32_t* seg_begin, const int32_t* n_unique,

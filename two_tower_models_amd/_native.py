@@ -81,7 +81,7 @@ SIGNATURES = {
     "tt_adam_table_stash": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tt_adam_table_stash_ids": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "tt_adam_table_sweep": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
-    "tt_adam_tables_sweep": (_int, [C.POINTER(AdamTensor), _i32, _vp, _vp]),
+    "tt_adam_tables_sweep": (_int, [C.POINTER(AdamTensor), _i32, _vp, _i32, _vp]),
     "tt_adam_table_finish": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, C.POINTER(GradSources), _i64, _vp, _vp, _vp,
                                     _vp, _vp, _i64, _vp]),
     "tt_adam_advance_tab": (_int, [_vp, _vp, _i64, _vp]),

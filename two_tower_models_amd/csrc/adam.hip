@@ -700,7 +700,8 @@ extern "C" int tt_adam_table_sweep(float* W, float* M, float* V, int64_t n_rows,
   return launch_sweep(W, M, V, n_rows, dim, hyper, S(stream));
 }
 
-extern "C" int tt_adam_tables_sweep(const tt_adam_tensor* tables, int32_t n_tables, const double* hyper, tt_stream_t stream) {
+extern "C" int tt_adam_tables_sweep(const tt_adam_tensor* tables, int32_t n_tables, const double* hyper, int32_t n_wgs,
+                                    tt_stream_t stream) {
   if (!tables || !hyper) return fail_arg("tt_adam_tables_sweep: null pointer");
   if (n_tables <= 0 || n_tables > SWEEP_MAX_TABLES) return fail_arg("tt_adam_tables_sweep: 1..4 tables");
   hipStream_t st = S(stream);
@@ -733,7 +734,10 @@ extern "C" int tt_adam_tables_sweep(const tt_adam_tensor* tables, int32_t n_tabl
     return 0;
   }
   unsigned* ctr = reinterpret_cast<unsigned*>(const_cast<double*>(hyper) + 7);
-  const unsigned grid = (unsigned)(device_cu_count() * persist);
+  static const int wgs_env = getenv("TT_SWEEP_WGS") ? atoi(getenv("TT_SWEEP_WGS")) : 0;  // A/B: absolute workgroup count
+  const int want = n_wgs > 0 ? n_wgs : wgs_env;
+  unsigned grid = (unsigned)(device_cu_count() * persist);
+  if (want > 0 && (unsigned)want < grid) grid = (unsigned)want;
   ProfScope prof("adam_sweep_kernel", st);
   if (nt) adam_sweep_tables_kernel<4, 4, true><<<grid, 256, 0, st>>>(tabs, hyper, ctr, prio);
   else adam_sweep_tables_kernel<4, 4, false><<<grid, 256, 0, st>>>(tabs, hyper, ctr, prio);

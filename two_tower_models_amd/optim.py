@@ -51,6 +51,7 @@ exporting a corpus) must call ``optimizer.flush()`` first (``optimizer.state_dic
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from typing import Dict, Iterable, List, Optional, Sequence
 
@@ -116,6 +117,9 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._hyper = None
         self._ready = False
         self._side_stream: Optional[torch.cuda.Stream] = None
+        self._sweep_wgs = 0  # 0 = library default (3 workgroups per CU); lowered by the throttle controller
+        self._tune = None  # events of the step in flight: [begin, sweep start, sweep end, end, level, step number]
+        self._tune_done: List[list] = []  # finished steps whose events may still be pending on the GPU
         self._plan_stream: Optional[torch.cuda.Stream] = None
         self._plan_done: Optional[torch.cuda.Event] = None
         self._begun: Optional[Dict[torch.nn.Parameter, _TableStep]] = None
@@ -137,7 +141,6 @@ class DenseExactAdam(torch.optim.Optimizer):
                     st[key] = torch.zeros_like(p) if key not in st else st[key].to(p.device, torch.float32).contiguous()
         # TT_SWEEP_CUS=k (A/B): the sweep's stream is restricted to k of every 8 CUs; the caller may
         # run the step itself on the complementary CUs (bench.py --cu-split)
-        import os
         k = int(os.environ.get("TT_SWEEP_CUS", "0"))
         self._side_stream = N.cu_masked_stream(dev, lambda i: i % 8 < k) if 0 < k < 8 else N.low_priority_stream(dev)
         start = int(self._resume_step)
@@ -274,6 +277,9 @@ class DenseExactAdam(torch.optim.Optimizer):
         if not self._ready:
             self._init_state()
         hyper = self._hyper.data_ptr()
+        self._tune_sweep()
+        ev_begin = torch.cuda.Event(enable_timing=True)
+        ev_begin.record()
         N.check(lib.tt_adam_advance(hyper, N.stream()), "tt_adam_advance")
         self._host_steps += 1
         begun: Dict[torch.nn.Parameter, _TableStep] = {}
@@ -303,13 +309,16 @@ class DenseExactAdam(torch.optim.Optimizer):
         ready = torch.cuda.Event()
         ready.record(main)  # lookups (or none yet, forward mode) + stashes are complete here
         self._side_stream.wait_event(ready)
+        ev_s0 = torch.cuda.Event(enable_timing=True)
+        ev_s0.record(self._side_stream)
         if begun:  # ONE launch for all tables: no gap and a single tail between the user and the item table
             descs = (N.AdamTensor * len(begun))()
             for i, p in enumerate(begun):
                 st = self.state[p]
                 descs[i].p, descs[i].g = p.data_ptr(), None
                 descs[i].m, descs[i].v, descs[i].n = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
-            N.check(lib.tt_adam_tables_sweep(descs, len(begun), hyper, self._side_stream.cuda_stream), "tt_adam_tables_sweep")
+            N.check(lib.tt_adam_tables_sweep(descs, len(begun), hyper, self._sweep_wgs, self._side_stream.cuda_stream),
+                    "tt_adam_tables_sweep")
         self._plan_done = None
         if announced is not None and begun:
             # The stable sort of the ids is needed only by finish (in step()): it runs on a THIRD stream, next to the
@@ -323,9 +332,36 @@ class DenseExactAdam(torch.optim.Optimizer):
                     ts.plan.build()
                 self._plan_done = torch.cuda.Event()
                 self._plan_done.record(self._plan_stream)
-        self._sweep_done = torch.cuda.Event()
+        self._sweep_done = torch.cuda.Event(enable_timing=True)
         self._sweep_done.record(self._side_stream)
+        self._tune = [ev_begin, ev_s0, self._sweep_done, None, self._sweep_wgs, self._host_steps]
         self._begun = begun
+
+    # The sweep saturates HBM for as long as it lasts.  When the step is much LONGER than the sweep (history model:
+    # 1.1 ms of a 5.5 ms step), running it flat out at the top of the step slows the HBM-heavy kernels that share that
+    # window 2-3x (first QKV projection 542 vs 174 us, history gather 343 vs ~100 us); a thinner sweep (fewer
+    # persistent workgroups) that lasts a third to a half of the step costs them little.  C3: 5.56 -> 5.10 ms.
+    # Closed loop on the PREVIOUS step's events, queried without blocking: results do not depend on it (the chunks are
+    # handed out dynamically either way) and no host synchronisation is added.
+    _SWEEP_LEVELS = (0, 256, 128)  # workgroups; 0 = library default (3 per CU)
+
+    def _tune_sweep(self) -> None:
+        if os.environ.get("TT_SWEEP_WGS") is not None:
+            return
+        # the host runs a step or two ahead of the GPU: take the NEWEST measurement whose events have completed
+        got = None
+        while self._tune_done and self._tune_done[0][2].query() and self._tune_done[0][3].query():
+            got = self._tune_done.pop(0)
+        if got is None or got[4] != self._sweep_wgs or got[5] <= 2:
+            return  # nothing finished yet / measured at another setting / the first steps (allocations, first-use set-up)
+        step_ms, sweep_ms = got[0].elapsed_time(got[3]), got[1].elapsed_time(got[2])
+        levels = self._SWEEP_LEVELS
+        at = levels.index(self._sweep_wgs) if self._sweep_wgs in levels else 0
+        ratio = sweep_ms / max(step_ms, 1e-6)
+        if ratio < 0.35 and at + 1 < len(levels):
+            self._sweep_wgs = levels[at + 1]
+        elif ratio > 0.7 and at > 0:
+            self._sweep_wgs = levels[at - 1]
 
     def begin_step(self, lookups: Dict[torch.nn.Parameter, Sequence[torch.Tensor]]) -> bool:
         """Forward-mode entry (called by the models' train_forward before any lookup): announce
@@ -387,6 +423,13 @@ class DenseExactAdam(torch.optim.Optimizer):
                                                  ts.side.data_ptr(), ts.side.numel(), N.stream()),
                         "tt_adam_table_finish")
             self._begun = None
+            if self._tune is not None:
+                end = torch.cuda.Event(enable_timing=True)
+                end.record()
+                self._tune[3] = end
+                self._tune_done.append(self._tune)
+                del self._tune_done[:-8]
+                self._tune = None
         elif self.lazy:
             if self._prefetch_done is not None:  # rows being replayed for a later batch: finish first
                 torch.cuda.current_stream().wait_event(self._prefetch_done)

@@ -447,7 +447,7 @@ class HipBackend:
             for i, (W, M, V, n_local) in enumerate(live):
                 descs[i].p, descs[i].g, descs[i].m, descs[i].v = W.data_ptr(), None, M.data_ptr(), V.data_ptr()
                 descs[i].n = n_local * W.shape[1]
-            N.check(lib.tt_adam_tables_sweep(descs, len(live), hyper.data_ptr(), self._side_stream.cuda_stream),
+            N.check(lib.tt_adam_tables_sweep(descs, len(live), hyper.data_ptr(), 0, self._side_stream.cuda_stream),
                     "tt_adam_tables_sweep")
         self._sweep_done = torch.cuda.Event()
         self._sweep_done.record(self._side_stream)
