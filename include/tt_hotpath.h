@@ -144,6 +144,11 @@ int tt_inbatch_ce_bwd_kept(const float* U, int64_t ldu, int64_t M, int64_t N, in
                            const float* row_lse, const float* coef, const float* logits, int64_t logits_bytes,
                            float* dI, int64_t lddi, void* ws, int64_t ws_bytes, tt_stream_t stream);
 
+/* dU[i, :] = du_unit[i, :] * coef[i]: the chain-rule step that turns tt_inbatch_ce_fwd_du's unit gradient into the
+ * user-side gradient once dL/dce is known (autograd of ref:...base_retrieval.py:287-312,342). */
+int tt_scale_rows(const float* x, int64_t ldx, const float* coef, int64_t rows, int64_t D, float* out, int64_t ldo,
+                  tt_stream_t stream);
+
 /* net_user_value weights, ref:...base_retrieval.py:322,334-339 for 2-D labels:
  *   nuv[i] = sum_t labels[i,t]*uvw[t];  w = clamp(nuv,1e-6);  w /= max_i w
  * then loss = mean_i(row_ce[i]*w[i]) and coef[i] = w[i]/B (gradient seed 1).

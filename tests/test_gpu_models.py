@@ -372,9 +372,12 @@ def test_checkpoint_resume_is_bit_identical(golden, lazy):
         assert torch.equal(ref_opt.state[pa]["exp_avg_sq"], o2.state[pb]["exp_avg_sq"])
 
 
-@pytest.mark.parametrize("kind,name,lazy", [("base", "g2_base_aligned", True), ("base", "g2_base_aligned", False),
-                                            ("hist", "g4_hist_d128", True)])
-def test_graphed_train_step_is_bit_identical_to_eager(golden, kind, name, lazy):
+@pytest.mark.parametrize("kind,name,lazy,overlap", [("base", "g2_base_aligned", True, False), ("base", "g2_base_aligned", False, False),
+                                                    ("hist", "g4_hist_d128", True, False),
+                                                    # multi-stream capture: the side-stream sweep is a branch of the graph
+                                                    ("base", "g2_base_aligned", False, "forward"),
+                                                    ("hist", "g4_hist_d128", False, "forward")])
+def test_graphed_train_step_is_bit_identical_to_eager(golden, kind, name, lazy, overlap):
     """GraphedTrainStep (whole-step hipGraph: forward, zero_grad, backward, optimiser) replayed N
     times == N eager steps: the step count and bias corrections advance on the device, row plans
     are sized on the device, so nothing is baked into the captured graph but the shapes."""
@@ -407,8 +410,9 @@ def test_graphed_train_step_is_bit_identical_to_eager(golden, kind, name, lazy):
     torch.cuda.current_stream().wait_stream(side)
     del loss
     model = make_model(kind, g)
-    opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep=False, lazy=lazy)
-    step = A.GraphedTrainStep(model, opt, bs[0], warmup=W)
+    opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep=overlap, lazy=lazy)
+    step = A.GraphedTrainStep(model, opt, bs[0], warmup=W, capture_overlap=overlap == "forward")
+    assert opt.capture_overlap == (overlap == "forward")
     glosses = [step(*b).item() for b in bs[1:]]
     opt.flush()
     torch.cuda.synchronize()

@@ -691,6 +691,16 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int splits, 
   }
 }
 
+// out[i, :] = x[i, :] * coef[i]  (dU = dL/dce (.) du_unit, the chain-rule step behind tt_inbatch_ce_fwd_du)
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ coef,
+                                                         int64_t rows, int64_t D, float* __restrict__ out, int64_t ldo) {
+  const int64_t total = rows * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / D, c = i - r * D;
+    out[r * ldo + c] = x[r * ldx + c] * coef[r];
+  }
+}
+
 // ref:src/two_tower_base_retrieval.py:322,334-343 for [B,T] labels, one workgroup.
 __global__ __launch_bounds__(1024) void weighted_mean_loss_kernel(const float* __restrict__ labels, int64_t B,
                                                                   int64_t T, const float* __restrict__ uvw,
@@ -1009,6 +1019,15 @@ extern "C" int tt_inbatch_ce_bwd_kept(const float* U, int64_t ldu, int64_t M, in
     if ((rc = check_launch("slab_reduce_kernel"))) return rc;
   }
   return 0;
+}
+
+extern "C" int tt_scale_rows(const float* x, int64_t ldx, const float* coef, int64_t rows, int64_t D, float* out,
+                             int64_t ldo, tt_stream_t stream) {
+  if (!x || !coef || !out) return fail_arg("tt_scale_rows: null pointer");
+  if (rows <= 0 || D <= 0 || ldx < D || ldo < D) return fail_arg("tt_scale_rows: sizes");
+  const int64_t blocks = ceil_div(rows * D, 256) < 2048 ? ceil_div(rows * D, 256) : 2048;
+  scale_rows_kernel<<<(unsigned)blocks, 256, 0, S(stream)>>>(x, ldx, coef, rows, D, out, ldo);
+  return check_launch("scale_rows_kernel");
 }
 
 extern "C" int tt_weighted_mean_loss(const float* labels, int64_t B, int64_t T, const float* uvw,

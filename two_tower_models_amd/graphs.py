@@ -7,8 +7,11 @@ workspaces are torch tensors (allocated from the graph's private pool during cap
 What it buys: the ~85 (base model) to ~200 (history model) kernel launches of a step cost
 5-10 us of host time each; once the HBM-bound table sweep is out of the way (deferred Adam, or
 small tables) the step is launch-bound -- C2 with the deferred schedule: 1.08 -> 0.65 ms/step.
-Under capture the optimiser takes its single-stream schedules (serial sweep, or deferred), so for
-the dense schedule at large tables the eager overlapped step remains the faster one.
+`capture_overlap=True` with `DenseExactAdam(overlap_sweep="forward")` makes the capture multi-stream: the table sweep
+stays on its side stream as a parallel branch of the graph (forked and joined through the optimiser's own events).
+Replays are bit-identical to eager steps, but on ROCm 7.2 the two branches do not overlap the way two live streams do:
+C2 2.87 ms per replay vs 1.34 ms eager, C3 7.8 vs 5.2, P 6.0 vs 5.5 -- measured, so it stays opt-in and the default
+captures the single-stream schedules (serial sweep, or deferred).
 """
 from __future__ import annotations
 
@@ -27,11 +30,16 @@ class GraphedTrainStep:
     stream (torch's usual whole-network-capture rule: autograd nodes remember their stream)."""
 
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, example_batch: Sequence[torch.Tensor],
-                 warmup: int = 3) -> None:
+                 warmup: int = 3, capture_overlap: bool = False) -> None:
         self.model, self.optimizer = model, optimizer
-        if getattr(optimizer, "overlap_sweep", False):
-            # the captured step uses the single-stream schedule; warm up (and stay) on that one so its
-            # workspaces exist before capture
+        if (capture_overlap and getattr(optimizer, "overlap_sweep", False) == "forward"
+                and not getattr(optimizer, "lazy", False)):
+            # forward-announced overlapped schedule: the sweep's side stream joins the capture through the events the
+            # optimiser already uses (fork after the stashes, join in step()), so the graph keeps the overlap
+            optimizer.capture_overlap = True
+        elif getattr(optimizer, "overlap_sweep", False):
+            # zero_grad-started overlap decides on the host whether a sweep is pending: the captured step uses the
+            # single-stream schedule; warm up (and stay) on that one so its workspaces exist before capture
             optimizer.overlap_sweep = False
         self.static_inputs = [t.clone() for t in example_batch]
         side = torch.cuda.Stream()

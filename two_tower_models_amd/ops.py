@@ -188,9 +188,17 @@ class ActiveStash:
     (tt_adam_table_stash_ids).  While it is attached to a table (`weight._tt_active`), lookups
     read from here: the zero-gradient sweep may already be rewriting the table itself."""
 
+    _positions = {}  # (device index, n) -> arange(n): the same few sizes every step
+
     def __init__(self, p_plane: torch.Tensor, block_sizes: Sequence[int]):
         self.p_plane = p_plane
-        self.positions = torch.arange(p_plane.shape[0], dtype=torch.int64, device=p_plane.device)
+        key = (p_plane.device.index, p_plane.shape[0])
+        pos = ActiveStash._positions.get(key)
+        if pos is None:
+            if len(ActiveStash._positions) > 64:
+                ActiveStash._positions.clear()
+            pos = ActiveStash._positions[key] = torch.arange(p_plane.shape[0], dtype=torch.int64, device=p_plane.device)
+        self.positions = pos
         self.offsets = [0]
         for n in block_sizes:
             self.offsets.append(self.offsets[-1] + n)
@@ -456,7 +464,9 @@ class InBatchSoftmaxCE(torch.autograd.Function):
         Nn = I.shape[0]
         lib = N.load()
         coef = d_ce.contiguous()
-        dU = du_unit * coef.unsqueeze(1) if du_unit is not None else torch.empty(M, D, dtype=torch.float32, device=dev)
+        dU = torch.empty(M, D, dtype=torch.float32, device=dev)
+        if du_unit is not None:
+            N.check(lib.tt_scale_rows(du_unit.data_ptr(), D, coef.data_ptr(), M, D, dU.data_ptr(), D, N.stream()), "tt_scale_rows")
         dI = torch.empty(Nn, D, dtype=torch.float32, device=dev)
         wsp, wsn = _ws(dev, lib.tt_inbatch_ce_workspace_bytes(M, Nn, D))
         pu, _, _, ldu = _f32_2d(U, "U")

@@ -117,11 +117,14 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._hyper = None
         self._ready = False
         self._side_stream: Optional[torch.cuda.Stream] = None
+        self.capture_overlap = False  # set by graphs.GraphedTrainStep (multi-stream capture of the overlapped schedule)
         self._sweep_wgs = 0  # 0 = library default (3 workgroups per CU); lowered by the throttle controller
         self._tune = None  # events of the step in flight: [begin, sweep start, sweep end, end, level, step number]
         self._tune_done: List[list] = []  # finished steps whose events may still be pending on the GPU
         self._plan_stream: Optional[torch.cuda.Stream] = None
         self._plan_done: Optional[torch.cuda.Event] = None
+        self._plans_pending = False
+        self._plan_ready: Optional[torch.cuda.Event] = None
         self._begun: Optional[Dict[torch.nn.Parameter, _TableStep]] = None
         self._sweep_done: Optional[torch.cuda.Event] = None
         self._side_bufs: Dict[int, torch.Tensor] = {}
@@ -277,9 +280,12 @@ class DenseExactAdam(torch.optim.Optimizer):
         if not self._ready:
             self._init_state()
         hyper = self._hyper.data_ptr()
-        self._tune_sweep()
-        ev_begin = torch.cuda.Event(enable_timing=True)
-        ev_begin.record()
+        capturing = torch.cuda.is_current_stream_capturing()  # whole-step hipGraph: no timing events, no controller
+        ev_begin = None
+        if not capturing:
+            self._tune_sweep()
+            ev_begin = torch.cuda.Event(enable_timing=True)
+            ev_begin.record()
         N.check(lib.tt_adam_advance(hyper, N.stream()), "tt_adam_advance")
         self._host_steps += 1
         begun: Dict[torch.nn.Parameter, _TableStep] = {}
@@ -309,8 +315,10 @@ class DenseExactAdam(torch.optim.Optimizer):
         ready = torch.cuda.Event()
         ready.record(main)  # lookups (or none yet, forward mode) + stashes are complete here
         self._side_stream.wait_event(ready)
-        ev_s0 = torch.cuda.Event(enable_timing=True)
-        ev_s0.record(self._side_stream)
+        ev_s0 = None
+        if not capturing:
+            ev_s0 = torch.cuda.Event(enable_timing=True)
+            ev_s0.record(self._side_stream)
         if begun:  # ONE launch for all tables: no gap and a single tail between the user and the item table
             descs = (N.AdamTensor * len(begun))()
             for i, p in enumerate(begun):
@@ -319,22 +327,16 @@ class DenseExactAdam(torch.optim.Optimizer):
                 descs[i].m, descs[i].v, descs[i].n = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
             N.check(lib.tt_adam_tables_sweep(descs, len(begun), hyper, self._sweep_wgs, self._side_stream.cuda_stream),
                     "tt_adam_tables_sweep")
+        # forward mode: the stable sort of the ids is needed only by finish (in step()).  It is NOT enqueued here: its
+        # ~30 short launches would sit in front of the forward's kernels on the HOST (0.25 ms of enqueue time per step
+        # -- at C2 the main stream idled that long before its first forward kernel).  zero_grad() -- after the forward
+        # has been enqueued -- launches it on a third stream, next to the backward kernels; step() does if nobody did.
         self._plan_done = None
-        if announced is not None and begun:
-            # The stable sort of the ids is needed only by finish (in step()): it runs on a THIRD stream, next to the
-            # forward / backward kernels instead of in front of them.  Its ~15 short launches per table are latency-
-            # bound (0.55 ms for the 209 K ids of the history model) and use a handful of CUs.
-            if self._plan_stream is None:
-                self._plan_stream = torch.cuda.Stream(device=next(iter(begun)).device)
-            self._plan_stream.wait_event(ready)  # the id lists exist
-            with torch.cuda.stream(self._plan_stream):
-                for ts in begun.values():
-                    ts.plan.build()
-                self._plan_done = torch.cuda.Event()
-                self._plan_done.record(self._plan_stream)
-        self._sweep_done = torch.cuda.Event(enable_timing=True)
+        self._plans_pending = announced is not None and bool(begun)
+        self._plan_ready = ready if self._plans_pending else None
+        self._sweep_done = torch.cuda.Event(enable_timing=not capturing)
         self._sweep_done.record(self._side_stream)
-        self._tune = [ev_begin, ev_s0, self._sweep_done, None, self._sweep_wgs, self._host_steps]
+        self._tune = None if capturing else [ev_begin, ev_s0, self._sweep_done, None, self._sweep_wgs, self._host_steps]
         self._begun = begun
 
     # The sweep saturates HBM for as long as it lasts.  When the step is much LONGER than the sweep (history model:
@@ -363,12 +365,32 @@ class DenseExactAdam(torch.optim.Optimizer):
         elif ratio > 0.7 and at > 0:
             self._sweep_wgs = levels[at - 1]
 
+    def _launch_plans(self, side: bool) -> None:
+        """Enqueue the deferred row-plan sorts of a forward-mode step (see _begin_overlapped)."""
+        if not self._plans_pending or self._begun is None:
+            return
+        self._plans_pending = False
+        if not side:
+            for ts in self._begun.values():
+                ts.plan.build()
+            return
+        if self._plan_stream is None:
+            self._plan_stream = torch.cuda.Stream(device=next(iter(self._begun)).device)
+        self._plan_stream.wait_event(self._plan_ready)  # the id lists exist
+        with torch.cuda.stream(self._plan_stream):
+            for ts in self._begun.values():
+                ts.plan.build()
+            self._plan_done = torch.cuda.Event()
+            self._plan_done.record(self._plan_stream)
+
     def begin_step(self, lookups: Dict[torch.nn.Parameter, Sequence[torch.Tensor]]) -> bool:
         """Forward-mode entry (called by the models' train_forward before any lookup): announce
         the id blocks per table, in the order the forward will look them up.  Returns False
         (and does nothing) unless ``overlap_sweep == "forward"`` applies."""
-        if self.overlap_sweep != "forward" or not torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
+        if self.overlap_sweep != "forward" or not torch.is_grad_enabled():
             return False
+        if torch.cuda.is_current_stream_capturing() and not self.capture_overlap:
+            return False  # GraphedTrainStep sets capture_overlap: the side-stream sweep then becomes a branch of the graph
         if self._begun is not None:
             raise RuntimeError('overlap_sweep="forward" supports one train_forward per optimiser step')
         if not all(p.is_cuda for p in self._tables):
@@ -384,6 +406,8 @@ class DenseExactAdam(torch.optim.Optimizer):
         for p in self._tables:
             p._tt_rowgrads.clear()
         super().zero_grad(set_to_none=set_to_none)
+        if self._begun is not None and not torch.cuda.is_current_stream_capturing():
+            self._launch_plans(side=True)
         if (self.overlap_sweep and self._begun is None and any(p._tt_lookups for p in self._tables)
                 and self._tables[0].is_cuda and not torch.cuda.is_current_stream_capturing()):
             self._begin_overlapped()
@@ -409,6 +433,7 @@ class DenseExactAdam(torch.optim.Optimizer):
         hyper = self._hyper.data_ptr()
         if self._begun is not None:
             # overlapped schedule: hyper already advanced, tables already swept on the side stream
+            self._launch_plans(side=False)  # nobody called zero_grad() after the forward: sort now, in line
             torch.cuda.current_stream().wait_event(self._sweep_done)
             if self._plan_done is not None:
                 torch.cuda.current_stream().wait_event(self._plan_done)

@@ -393,7 +393,8 @@ class HipBackend:
         ops, N, lib = self.ops, self.N, self.lib
         M, D = U.shape
         Nn = I_all.shape[0]
-        dU, dI = self._du_unit * coef.unsqueeze(1), self.empty(Nn, D)
+        dU, dI = self.empty(M, D), self.empty(Nn, D)
+        N.check(lib.tt_scale_rows(self._du_unit.data_ptr(), D, coef.data_ptr(), M, D, dU.data_ptr(), D, N.stream()), "tt_scale_rows")
         self._du_unit = None
         wsp, wsn = ops._ws(self.device, lib.tt_inbatch_ce_workspace_bytes(M, Nn, D))
         if self._kept is not None:
