@@ -97,6 +97,24 @@ int64_t tt_colsum_workspace_bytes(int64_t M, int64_t N);
 int tt_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out, void* ws,
                   int64_t ws_bytes, tt_stream_t stream);
 
+/* ---------------------------------------------------------------- K3 fused tower
+ * One tower of TwoTowerBaseRetrieval in ONE launch per direction:
+ *   y = Linear(2D -> D)([ table[id] | Linear(hidden -> D)(ReLU(Linear(F -> hidden)(features))) ])
+ * replaces nn.Embedding + nn.Sequential + torch.cat + nn.Linear at ref:src/two_tower_base_retrieval.py:129-162,164-191
+ * (user tower) and :193-219 (item tower).  The forward also writes what the backward needs: h_out [B, hidden] (the ReLU
+ * output) and tin_out [B, 2D] (the tower input).  tt_tower_bwd_data is the data side of their autograd:
+ *   d_tin = dy W3;  d_emb = d_tin[:, :D] (embedding-row gradients);  d_f = d_tin[:, D:];  dh = (d_f W2) (.) [h > 0]
+ * the weight / bias gradients are tt_gemm_tn_colsum_f32(dy, tin), (d_f, h), (dh, features).
+ * Shapes: hidden = 256, D = d_out in {32, 64, 128}, F <= 64, 16-B aligned rows (tt_tower_supported says);
+ * anything else returns TT_E_UNSUPPORTED -- use tt_gather_rows + tt_gemm_f32. */
+int tt_tower_supported(int64_t D, int64_t F, int64_t hidden, int64_t d_out);
+int tt_tower_fwd(const float* table, int64_t n_rows, const int64_t* ids, const float* feats, int64_t ldf, int64_t B,
+                 int64_t D, int64_t F, int64_t hidden, const float* W1, const float* b1, const float* W2, const float* b2,
+                 const float* W3, const float* b3, int64_t d_out, float* y, int64_t ldy, float* h_out, float* tin_out,
+                 int32_t* oob_flag, tt_stream_t stream);
+int tt_tower_bwd_data(const float* dy, int64_t ldy, int64_t B, int64_t D, int64_t hidden, const float* W2, const float* W3,
+                      const float* h, float* d_emb, int64_t ld_demb, float* d_f, float* dh, tt_stream_t stream);
+
 /* ---------------------------------------------------------------- K5 in-batch softmax CE
  * Forward: S = U I^T is never written to memory.
  *   row_lse[i] = log2 sum_j 2^(S[i,j] log2 e)   (= logsumexp_j S[i,j] / ln 2; opaque to the caller,

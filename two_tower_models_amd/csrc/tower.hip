@@ -1,0 +1,310 @@
+// K3: one tower of TwoTowerBaseRetrieval as ONE kernel per direction.
+//   forward   y = Linear(2D -> D)( [ table[id] | Linear(256 -> D)(ReLU(Linear(F -> 256)(features))) ] )
+//             ref:src/two_tower_base_retrieval.py:129-162 (user), :193-219 (item): nn.Embedding lookup,
+//             nn.Sequential feature MLP, torch.cat, tower nn.Linear -- the cat never exists, nothing but
+//             the ids / features is read from HBM and only y (+ what the backward needs) is written
+//   backward  d_tin = dy W3;  d_emb = d_tin[:, :D] (the embedding-row gradients);  d_f = d_tin[:, D:];
+//             dh = (d_f W2) (.) [h > 0]          (autograd of the same lines, data side)
+// The weight gradients (dW3 = dy^T tin, dW2 = d_f^T h, dW1 = dh^T x and the three bias sums) are reductions over
+// the batch and stay with tt_gemm_tn_colsum_f32.
+//
+// One workgroup = 64 batch rows, 4 waves.  The row block's activations live in LDS ([64][K + 4] images, the layout
+// of mfma_stream.hpp's register-staged tiles), each wave owns 32 output columns and holds their weights in
+// registers as MFMA A-operand fragments (v_mfma_f32_32x32x2_f32: exact fp32), so a result tile has one batch row
+// per lane: the same structure as gemm_ws.hip with the "stream" being a single resident tile.  Layer 1 has K = F
+// (8 at the BASELINE shapes): VALU, one hidden unit per thread.  Against the unfused path (gather + 3 GEMM launches
+// forward, 3 NN GEMMs backward, each a separate pass over [B, 256]-sized intermediates): 1 launch per direction.
+// Shapes: hidden = 256 (fixed upstream), D in {32, 64, 128}, F <= 64, 16-B aligned rows; anything else returns
+// TT_E_UNSUPPORTED and the caller takes the GEMM path.
+#include "mfma_stream.hpp"
+
+namespace tt {
+
+constexpr int TW_ROWS = 64;
+constexpr int TW_HID = 256;
+constexpr int TW_FMAX = 64;
+
+struct TowerFwdArgs {
+  const float* table; int64_t n_rows; const int64_t* ids;
+  const float* feats; int64_t ldf;
+  int64_t B, F;
+  const float *W1, *b1, *W2, *b2, *W3, *b3;
+  float* y; int64_t ldy;
+  float* h_out;    // [B][256]
+  float* tin_out;  // [B][2D]
+  int32_t* oob;
+};
+
+// weights as the MFMA A operand (rows = this wave's 32 output columns), activations as B from the LDS image:
+// acc[e] = out[row = jt*32 + (lane & 31)][col = nw + (e&3) + 8*(e>>2) + 4*(lane>>5)]
+template <int DP8>
+__device__ __forceinline__ f32x16 tw_tile(const float* Ys, const float (&xr)[DP8][4], int jt, int r, int h) {
+  using TM = TileMap<DP8, false>;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int row = jt * 32 + r;
+  float4 y[2];
+  y[0] = *reinterpret_cast<const float4*>(Ys + TM::chunk(row, h));
+#pragma unroll
+  for (int g = 0; g < DP8; ++g) {
+    if (g + 1 < DP8) y[(g + 1) & 1] = *reinterpret_cast<const float4*>(Ys + TM::chunk(row, 2 * (g + 1) + h));
+    const float4 v = y[g & 1];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[g][0], v.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[g][1], v.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[g][2], v.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[g][3], v.w, acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return acc;
+}
+
+// stationary fragments from a [K][N] (row = reduction index) weight: xr[g][c] = W[8g+4h+c][n]
+template <int DP8>
+__device__ __forceinline__ void tw_load_t(float (&xr)[DP8][4], const float* __restrict__ W, int64_t ld, int64_t n, int64_t N,
+                                          int h) {
+#pragma unroll
+  for (int g = 0; g < DP8; ++g)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xr[g][c] = (n < N) ? W[(int64_t)(8 * g + 4 * h + c) * ld + n] : 0.f;
+}
+
+template <int DE8>  // D = 8 * DE8
+__global__ __launch_bounds__(256) void tower_fwd_kernel(const TowerFwdArgs p) {
+  constexpr int D = 8 * DE8, K3 = 2 * D, LDH = TW_HID + 4, LDT = K3 + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* hT = smem;                    // [64][260]  hidden activations
+  float* tT = hT + TW_ROWS * LDH;      // [64][2D+4] tower input: id row | feature-MLP output
+  float* fT = tT + TW_ROWS * LDT;      // [64][F]    dense features
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * TW_ROWS;
+  const int F = (int)p.F;
+
+  // ---- stage 0: features and id rows of the 64 batch rows into LDS
+  for (int i = threadIdx.x; i < TW_ROWS * F; i += 256) {
+    const int m = i / F, f = i - m * F;
+    fT[i] = (row0 + m < p.B) ? p.feats[(row0 + m) * p.ldf + f] : 0.f;
+  }
+  {
+    constexpr int C4 = D / 4;  // float4 per id row
+    for (int i = threadIdx.x; i < TW_ROWS * C4; i += 256) {
+      const int m = i / C4, c = i - m * C4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + m < p.B) {
+        const int64_t id = p.ids[row0 + m];
+        if (id >= 0 && id < p.n_rows) v = *reinterpret_cast<const float4*>(p.table + id * D + 4 * c);
+        else if (c == 0 && p.oob) *p.oob = 1;
+      }
+      *reinterpret_cast<float4*>(tT + m * LDT + 4 * c) = v;
+    }
+  }
+  __syncthreads();
+  // ---- stage 1: h = ReLU(x W1^T + b1), one hidden unit per thread (K = F is tiny: VALU)
+  {
+    const int j = threadIdx.x;
+    float w1r[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) w1r[f] = f < F ? p.W1[(int64_t)j * F + f] : 0.f;
+    const float bj = p.b1[j];
+    for (int m = 0; m < TW_ROWS; ++m) {
+      float acc = bj;
+#pragma unroll
+      for (int f = 0; f < 16; ++f)
+        if (f < F) acc = fmaf(fT[m * F + f], w1r[f], acc);
+      for (int f = 16; f < F; ++f) acc = fmaf(fT[m * F + f], p.W1[(int64_t)j * F + f], acc);
+      hT[m * LDH + j] = fmaxf(acc, 0.f);
+    }
+  }
+  __syncthreads();
+  const int nw = wave * 32;  // this wave's output columns (of f, then of y)
+  // ---- stage 2: f = h W2^T + b2 -> columns D .. 2D-1 of the tower input (LDS)
+  if (nw < D) {
+    float xr[TW_HID / 8][4];
+    load_stationary<TW_HID / 8>(xr, p.W2, TW_HID, nw + r, D, TW_HID, h, true);
+    float be[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) be[e] = p.b2[nw + (e & 3) + 8 * (e >> 2) + 4 * h];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      const f32x16 acc = tw_tile<TW_HID / 8>(hT, xr, jt, r, h);
+      float* dst = tT + (jt * 32 + r) * LDT + D + nw + 4 * h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(acc[4 * q] + be[4 * q], acc[4 * q + 1] + be[4 * q + 1],
+                                                             acc[4 * q + 2] + be[4 * q + 2], acc[4 * q + 3] + be[4 * q + 3]);
+    }
+  }
+  // what the backward needs: h (ReLU mask, dW2) -- coalesced copy of the LDS image
+  for (int i = threadIdx.x; i < TW_ROWS * (TW_HID / 4); i += 256) {
+    const int m = i / (TW_HID / 4), c = i - m * (TW_HID / 4);
+    if (row0 + m < p.B)
+      *reinterpret_cast<float4*>(p.h_out + (row0 + m) * TW_HID + 4 * c) = *reinterpret_cast<const float4*>(hT + m * LDH + 4 * c);
+  }
+  __syncthreads();
+  // ---- stage 3: y = tin W3^T + b3; tin goes out for dW3
+  for (int i = threadIdx.x; i < TW_ROWS * (K3 / 4); i += 256) {
+    const int m = i / (K3 / 4), c = i - m * (K3 / 4);
+    if (row0 + m < p.B)
+      *reinterpret_cast<float4*>(p.tin_out + (row0 + m) * K3 + 4 * c) = *reinterpret_cast<const float4*>(tT + m * LDT + 4 * c);
+  }
+  if (nw < D) {
+    float xr[K3 / 8][4];
+    load_stationary<K3 / 8>(xr, p.W3, K3, nw + r, D, K3, h, true);
+    float be[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) be[e] = p.b3[nw + (e & 3) + 8 * (e >> 2) + 4 * h];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      const f32x16 acc = tw_tile<K3 / 8>(tT, xr, jt, r, h);
+      const int64_t m = row0 + jt * 32 + r;
+      if (m < p.B) {
+        float* dst = p.y + m * p.ldy + nw + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(acc[4 * q] + be[4 * q], acc[4 * q + 1] + be[4 * q + 1],
+                                                               acc[4 * q + 2] + be[4 * q + 2], acc[4 * q + 3] + be[4 * q + 3]);
+      }
+    }
+  }
+}
+
+struct TowerBwdArgs {
+  const float* dy; int64_t ldy;
+  int64_t B;
+  const float *W2, *W3;
+  const float* h;        // [B][256] saved by the forward
+  float* d_emb; int64_t ld_demb;  // [B][D]
+  float* d_f;            // [B][D]
+  float* dh;             // [B][256]
+};
+
+template <int DE8>
+__global__ __launch_bounds__(256) void tower_bwd_kernel(const TowerBwdArgs p) {
+  constexpr int D = 8 * DE8, K3 = 2 * D, LDY = D + 4;
+  __shared__ __attribute__((aligned(16))) float dyT[TW_ROWS * LDY];
+  __shared__ __attribute__((aligned(16))) float dfT[TW_ROWS * LDY];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * TW_ROWS;
+  for (int i = threadIdx.x; i < TW_ROWS * (D / 4); i += 256) {
+    const int m = i / (D / 4), c = i - m * (D / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + m < p.B) v = *reinterpret_cast<const float4*>(p.dy + (row0 + m) * p.ldy + 4 * c);
+    *reinterpret_cast<float4*>(dyT + m * LDY + 4 * c) = v;
+  }
+  __syncthreads();
+  // ---- d_tin = dy W3 (W3 [D][2D]: reduction index = row): columns < D -> d_emb, columns >= D -> d_f
+  for (int cb = 0; cb * 128 < K3; ++cb) {
+    const int nw = cb * 128 + wave * 32;
+    if (nw >= K3) continue;
+    float xr[DE8][4];
+    tw_load_t<DE8>(xr, p.W3, K3, nw + r, K3, h);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      const f32x16 acc = tw_tile<DE8>(dyT, xr, jt, r, h);
+      const int ml = jt * 32 + r;
+      const int64_t m = row0 + ml;
+      if (nw < D) {  // the whole 32-column block lies in the id half (D is a multiple of 32)
+        if (m < p.B) {
+          float* dst = p.d_emb + m * p.ld_demb + nw + 4 * h;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        }
+      } else {
+        float* l = dfT + ml * LDY + (nw - D) + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+          *reinterpret_cast<float4*>(l + 8 * q) = v;
+          if (m < p.B) *reinterpret_cast<float4*>(p.d_f + m * D + (nw - D) + 4 * h + 8 * q) = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- dh = (d_f W2) (.) [h > 0]   (W2 [D][256]: reduction index = row)
+#pragma unroll 1
+  for (int cb = 0; cb < 2; ++cb) {
+    const int nw = cb * 128 + wave * 32;
+    float xr[DE8][4];
+    tw_load_t<DE8>(xr, p.W2, TW_HID, nw + r, TW_HID, h);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      const f32x16 acc = tw_tile<DE8>(dfT, xr, jt, r, h);
+      const int64_t m = row0 + jt * 32 + r;
+      if (m < p.B) {
+        const float* hm = p.h + m * TW_HID + nw + 4 * h;
+        float* dst = p.dh + m * TW_HID + nw + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 hv = *reinterpret_cast<const float4*>(hm + 8 * q);
+          *reinterpret_cast<float4*>(dst + 8 * q) =
+              make_float4(hv.x > 0.f ? acc[4 * q] : 0.f, hv.y > 0.f ? acc[4 * q + 1] : 0.f, hv.z > 0.f ? acc[4 * q + 2] : 0.f,
+                          hv.w > 0.f ? acc[4 * q + 3] : 0.f);
+        }
+      }
+    }
+  }
+}
+
+static bool tower_shape_ok(int64_t D, int64_t F, int64_t hidden, int64_t d_out) {
+  return hidden == TW_HID && d_out == D && (D == 32 || D == 64 || D == 128) && F >= 1 && F <= TW_FMAX;
+}
+static inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace tt
+
+using namespace tt;
+
+extern "C" int tt_tower_supported(int64_t D, int64_t F, int64_t hidden, int64_t d_out) {
+  return tower_shape_ok(D, F, hidden, d_out) ? 1 : 0;
+}
+
+extern "C" int tt_tower_fwd(const float* table, int64_t n_rows, const int64_t* ids, const float* feats, int64_t ldf,
+                            int64_t B, int64_t D, int64_t F, int64_t hidden, const float* W1, const float* b1,
+                            const float* W2, const float* b2, const float* W3, const float* b3, int64_t d_out, float* y,
+                            int64_t ldy, float* h_out, float* tin_out, int32_t* oob_flag, tt_stream_t stream) {
+  if (!table || !ids || !feats || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !y || !h_out || !tin_out)
+    return fail_arg("tt_tower_fwd: null pointer");
+  if (B <= 0 || n_rows <= 0 || ldf < F || ldy < d_out) return fail_arg("tt_tower_fwd: sizes");
+  if (!tower_shape_ok(D, F, hidden, d_out) || ldy % 4 || !al16p(table) || !al16p(W2) || !al16p(W3) || !al16p(y) ||
+      !al16p(h_out) || !al16p(tin_out)) {
+    set_error("tt_tower_fwd: needs hidden = 256, D = d_out in {32, 64, 128}, F <= 64, 16-B aligned operands");
+    return TT_E_UNSUPPORTED;
+  }
+  TowerFwdArgs a{table, n_rows, ids, feats, ldf, B, F, W1, b1, W2, b2, W3, b3, y, ldy, h_out, tin_out, oob_flag};
+  hipStream_t st = S(stream);
+  const unsigned grid = (unsigned)ceil_div(B, TW_ROWS);
+  const size_t lds = (size_t)(TW_ROWS * (TW_HID + 4) + TW_ROWS * (2 * D + 4) + TW_ROWS * F) * sizeof(float);
+#define TT_TWF(E)                                                                                                        \
+  {                                                                                                                      \
+    if (lds > 64 * 1024) {                                                                                               \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_kernel<E>),                            \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+      if (e != hipSuccess) { set_error("tower_fwd_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
+    }                                                                                                                    \
+    tower_fwd_kernel<E><<<grid, 256, lds, st>>>(a);                                                                      \
+  }
+  if (D == 32) TT_TWF(4) else if (D == 64) TT_TWF(8) else TT_TWF(16)
+#undef TT_TWF
+  return check_launch("tower_fwd_kernel");
+}
+
+extern "C" int tt_tower_bwd_data(const float* dy, int64_t ldy, int64_t B, int64_t D, int64_t hidden, const float* W2,
+                                 const float* W3, const float* h, float* d_emb, int64_t ld_demb, float* d_f, float* dh,
+                                 tt_stream_t stream) {
+  if (!dy || !W2 || !W3 || !h || !d_emb || !d_f || !dh) return fail_arg("tt_tower_bwd_data: null pointer");
+  if (B <= 0 || ldy < D || ld_demb < D) return fail_arg("tt_tower_bwd_data: sizes");
+  if (!tower_shape_ok(D, 1, hidden, D) || ldy % 4 || ld_demb % 4 || !al16p(dy) || !al16p(h) || !al16p(d_emb) || !al16p(d_f) ||
+      !al16p(dh)) {
+    set_error("tt_tower_bwd_data: needs hidden = 256, D in {32, 64, 128}, 16-B aligned operands");
+    return TT_E_UNSUPPORTED;
+  }
+  TowerBwdArgs a{dy, ldy, B, W2, W3, h, d_emb, ld_demb, d_f, dh};
+  hipStream_t st = S(stream);
+  const unsigned grid = (unsigned)ceil_div(B, TW_ROWS);
+  if (D == 32) tower_bwd_kernel<4><<<grid, 256, 0, st>>>(a);
+  else if (D == 64) tower_bwd_kernel<8><<<grid, 256, 0, st>>>(a);
+  else tower_bwd_kernel<16><<<grid, 256, 0, st>>>(a);
+  return check_launch("tower_bwd_kernel");
+}

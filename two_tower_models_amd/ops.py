@@ -398,6 +398,70 @@ class TowerInput(_LookupFunction):
         return dweight, None, None, dW1, db1, dW2, db2
 
 
+_FUSED_TOWER = os.environ.get("TT_NO_FUSED_TOWER") is None  # A/B switch
+
+
+def fused_tower_supported(weight, feats, W1, W2, W3) -> bool:
+    """tt_tower_fwd / tt_tower_bwd_data: hidden = 256, D = d_out in {32, 64, 128}, F <= 64."""
+    return (_FUSED_TOWER and weight.is_cuda and feats.dim() == 2 and feats.dtype == torch.float32
+            and W3.shape[1] == 2 * weight.shape[1] and W2.shape[0] == weight.shape[1]
+            and bool(N.load().tt_tower_supported(weight.shape[1], feats.shape[1], W1.shape[0], W3.shape[0])))
+
+
+class FusedTower(_LookupFunction):
+    """One whole tower -- id lookup, feature MLP, the (never materialised) cat, tower Linear -- as one kernel per
+    direction (csrc/tower.hip; ref:src/two_tower_base_retrieval.py:129-162,164-191 user, :193-219 item)."""
+
+    @staticmethod
+    def forward(ctx, weight, ids, feats, W1, b1, W2, b2, W3, b3):
+        dev = N.require_device(weight, ids, feats, W1, b1, W2, b2, W3, b3)
+        feats = _rowmajor(feats)
+        B, F = feats.shape
+        D, Hd = weight.shape[1], W1.shape[0]
+        if ids.dtype == torch.int32:
+            ids = ids.to(torch.int64)
+        if ids.dtype != torch.int64:
+            raise TypeError("ids must be int64 or int32 (nn.Embedding's index types)")
+        src, row_ids, ctx.lookup_index = lookup_source(weight, ids, _recording(ctx))
+        row_ids = row_ids.contiguous()
+        y = torch.empty(B, W3.shape[0], dtype=torch.float32, device=dev)
+        h = torch.empty(B, Hd, dtype=torch.float32, device=dev)
+        tin = torch.empty(B, 2 * D, dtype=torch.float32, device=dev)
+        W1c, W2c, W3c = W1.contiguous(), W2.contiguous(), W3.contiguous()
+        N.check(N.load().tt_tower_fwd(src.data_ptr(), src.shape[0], row_ids.data_ptr(), feats.data_ptr(), feats.stride(0), B, D,
+                                      F, Hd, W1c.data_ptr(), b1.data_ptr(), W2c.data_ptr(), b2.data_ptr(), W3c.data_ptr(),
+                                      b3.data_ptr(), W3.shape[0], y.data_ptr(), y.stride(0), h.data_ptr(), tin.data_ptr(),
+                                      N.oob.flag(dev).data_ptr(), N.stream()), "tt_tower_fwd")
+        ctx.weight = weight
+        ctx.save_for_backward(ids, feats, h, tin, W2c, W3c)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, feats, h, tin, W2, W3 = ctx.saved_tensors
+        w = ctx.weight
+        dev = dy.device
+        dy = dy.contiguous()
+        B, F = feats.shape
+        D, Hd = w.shape[1], h.shape[1]
+        d_emb = torch.empty(B, D, dtype=torch.float32, device=dev)
+        d_f = torch.empty(B, D, dtype=torch.float32, device=dev)
+        dh = torch.empty(B, Hd, dtype=torch.float32, device=dev)
+        N.check(N.load().tt_tower_bwd_data(dy.data_ptr(), dy.stride(0), B, D, Hd, W2.data_ptr(), W3.data_ptr(), h.data_ptr(),
+                                           d_emb.data_ptr(), D, d_f.data_ptr(), dh.data_ptr(), N.stream()),
+                "tt_tower_bwd_data")
+        dW3 = torch.empty(W3.shape, dtype=torch.float32, device=dev)
+        _, db3 = gemm_tn_colsum(dy, tin, dW3)
+        dW2 = torch.empty(W2.shape, dtype=torch.float32, device=dev)
+        _, db2 = gemm_tn_colsum(d_f, h, dW2)
+        dW1 = torch.empty(Hd, F, dtype=torch.float32, device=dev)
+        _, db1 = gemm_tn_colsum(dh, feats, dW1)
+        dweight = None
+        if ctx.needs_input_grad[0]:
+            dweight = _route_table_grad(w, ids.reshape(-1), d_emb, ctx.lookup_index)
+        return dweight, None, None, dW1, db1, dW2, db2, dW3, db3
+
+
 _FUSED_DU = os.environ.get("TT_CE_NO_FUSED_DU") is None  # A/B switches (DESIGN.md 9)
 _ROW0_LAST = os.environ.get("TT_ENC_FULL_LAST_LAYER") is None
 

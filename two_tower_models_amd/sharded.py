@@ -309,6 +309,20 @@ class HipBackend:
         Dm, Hd = W2.shape
         E = 0 if extra is None else extra.shape[1]
         De = W3.shape[1] - Dm - E
+        if extra is None and emb.is_contiguous() and ops.fused_tower_supported(emb, feats, W1, W2, W3):
+            # one launch (csrc/tower.hip): the routed rows play the table, looked up by position; returns
+            # (h, tin, out) -- tower_bwd recognises the [B, 2D] tower input in the `f` slot
+            key = (self.device.index, B)
+            pos = ops.ActiveStash._positions.get(key)
+            if pos is None:
+                pos = ops.ActiveStash._positions[key] = torch.arange(B, dtype=torch.int64, device=self.device)
+            h, tin, out = self.empty(B, Hd), self.empty(B, 2 * De), self.empty(B, W3.shape[0])
+            feats = feats.contiguous()
+            N.check(self.lib.tt_tower_fwd(emb.data_ptr(), B, pos.data_ptr(), feats.data_ptr(), feats.stride(0), B, De, F, Hd,
+                                          W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), b3.data_ptr(),
+                                          W3.shape[0], out.data_ptr(), out.stride(0), h.data_ptr(), tin.data_ptr(), None,
+                                          N.stream()), "tt_tower_fwd")
+            return h, tin, out
         h = self.empty(B, Hd)
         ops.gemm(N.TT_GEMM_NT, feats, W1, h, B, Hd, F, bias=b1, epilogue=N.TT_EPI_RELU)
         f = self.empty(B, Dm)
@@ -331,6 +345,16 @@ class HipBackend:
         Do, Din = W3.shape
         E = 0 if extra is None else extra.shape[1]
         De = Din - Dm - E
+        if extra is None and f.shape[1] == Din:  # the fused forward ran: `f` is the whole tower input [emb | MLP]
+            d_out = d_out.contiguous()
+            d_emb, d_f, dh = self.empty(B, De), self.empty(B, Dm), self.empty(B, Hd)
+            N.check(self.lib.tt_tower_bwd_data(d_out.data_ptr(), d_out.stride(0), B, De, Hd, W2.data_ptr(), W3.data_ptr(),
+                                               h.data_ptr(), d_emb.data_ptr(), De, d_f.data_ptr(), dh.data_ptr(), N.stream()),
+                    "tt_tower_bwd_data")
+            ops.gemm_tn_colsum(d_out, f, gW3, db=gb3)
+            ops.gemm_tn_colsum(d_f, h, gW2, db=gb2)
+            ops.gemm_tn_colsum(dh, feats, gW1, db=gb1)
+            return d_emb, None
         ops.gemm_tn_colsum(d_out, emb, gW3[:, :De], db=gb3)
         ops.gemm(N.TT_GEMM_TN, d_out, f, gW3[:, De:De + Dm], Do, Dm, B)
         d_emb = self.empty(B, De)

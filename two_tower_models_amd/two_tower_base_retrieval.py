@@ -98,6 +98,15 @@ class TwoTowerBaseRetrieval(nn.Module):
         """Query embedding [B, DI] (ref :164-191)."""
         if user_id.is_cuda:
             N.oob.poll(user_id.device)  # surfaces an out-of-range id seen by an earlier launch
+        cls = type(self)
+        mlp, tower = self.user_features_arch, self.user_tower_arch
+        if (cls.process_user_features is TwoTowerBaseRetrieval.process_user_features
+                and cls.get_user_embedding is TwoTowerBaseRetrieval.get_user_embedding
+                and ops.fused_tower_supported(self.user_id_embedding_arch.weight, user_features, mlp[0].weight,
+                                              mlp[2].weight, tower.weight)):
+            # no hook overridden: lookup + feature MLP + cat + tower Linear as ONE kernel per direction (K3)
+            return ops.FusedTower.apply(self.user_id_embedding_arch.weight, user_id, user_features, mlp[0].weight,
+                                        mlp[0].bias, mlp[2].weight, mlp[2].bias, tower.weight, tower.bias)
         user_tower_input = self.process_user_features(
             user_id=user_id, user_features=user_features, user_history=user_history
         )
@@ -107,6 +116,11 @@ class TwoTowerBaseRetrieval(nn.Module):
     def compute_item_embeddings(self, item_id: torch.Tensor, item_features: torch.Tensor) -> torch.Tensor:
         """[B, DI] item embeddings (ref :193-219)."""
         mlp = self.item_features_arch
+        if ops.fused_tower_supported(self.item_id_embedding_arch.weight, item_features, mlp[0].weight, mlp[2].weight,
+                                     self.item_tower_arch.weight):
+            return ops.FusedTower.apply(self.item_id_embedding_arch.weight, item_id, item_features, mlp[0].weight,
+                                        mlp[0].bias, mlp[2].weight, mlp[2].bias, self.item_tower_arch.weight,
+                                        self.item_tower_arch.bias)
         item_tower_input = ops.TowerInput.apply(
             self.item_id_embedding_arch.weight, item_id, item_features,
             mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias,
