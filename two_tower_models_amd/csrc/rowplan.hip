@@ -8,6 +8,8 @@
 // All sizes are device-independent of the DATA: kernels are launched for the worst
 // case (n_ids runs) and read the actual run count from device memory, which keeps
 // the whole step capturable in a hipGraph.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace tt {
@@ -209,6 +211,132 @@ __global__ __launch_bounds__(256) void seg_write_kernel(const int32_t* __restric
   }
 }
 
+// ---- small plans: the whole thing in ONE workgroup -------------------------
+// n <= PS_MAX ids (a base-model lookup: B = 8192; the sharded trainer's W * cap ~ 9 K per table): LSD radix sort with
+// 4-bit digits entirely in LDS + the run structure, one launch instead of ~15.  The sort of 8192 ids was 15 short
+// launches of 5-20 us each -- latency-bound on the GPU and, with two tables per step, 30 of the ~70 kernel launches the
+// HOST has to enqueue per step (C2 is host-bound: 1.05 ms of enqueue time per 1.3 ms step).
+// 1024 threads; thread t owns positions [t*kpt, (t+1)*kpt) of the current order (blocked: position order = (thread,
+// slot) order, which is what keeps every pass stable).  Per pass: per-thread digit counts (16 x 4-bit fields of one
+// 64-bit register, kpt <= 12) -> cnt[digit][thread] (u16) -> exclusive scan in digit-major order -> scatter from
+// registers back into LDS.  Positions >= n carry the key 0xFFFFFFFF: digit 15 in every pass, they stay behind.
+constexpr int PS_THREADS = 1024;
+constexpr int PS_KPT_MAX = 12;
+constexpr int PS_MAX = PS_THREADS * PS_KPT_MAX;
+
+__device__ __forceinline__ uint32_t ps_block_excl_scan(uint32_t v, uint32_t* wsum, uint32_t& total) {
+  // exclusive scan of one value per thread over the 1024-thread workgroup (16 waves)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const uint32_t x = wsum[w];
+    if (w < wave) woff += x;
+    tot += x;
+  }
+  total = tot;
+  __syncthreads();
+  return woff + inc - v;
+}
+
+__global__ __launch_bounds__(PS_THREADS) void plan_small_kernel(const int64_t* __restrict__ ids, int n, int64_t n_rows, int kpt,
+                                                                int passes, int32_t* __restrict__ sorted_ids,
+                                                                int32_t* __restrict__ perm, int32_t* __restrict__ seg_begin,
+                                                                int32_t* __restrict__ n_unique, int32_t* __restrict__ oob_flag) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t ps_smem[];
+  uint32_t* keys = ps_smem;                      // [1024 * kpt]
+  uint32_t* vals = keys + PS_THREADS * kpt;      // [1024 * kpt]
+  uint16_t* cnt = reinterpret_cast<uint16_t*>(vals + PS_THREADS * kpt);  // [16][1024]
+  __shared__ uint32_t wsum[16];
+  const int t = threadIdx.x;
+  uint32_t k[PS_KPT_MAX], v[PS_KPT_MAX];
+#pragma unroll
+  for (int s = 0; s < PS_KPT_MAX; ++s) {
+    k[s] = 0xFFFFFFFFu;
+    v[s] = 0;
+    const int i = t * kpt + s;
+    if (s < kpt && i < n) {
+      int64_t id = ids[i];
+      if (id < 0 || id >= n_rows) { *oob_flag = 1; id = 0; }
+      k[s] = (uint32_t)id;
+      v[s] = (uint32_t)i;
+    }
+  }
+  for (int p = 0; p < passes; ++p) {
+    const int shift = 4 * p;
+    unsigned long long lc = 0;  // 16 x 4-bit counters
+    uint32_t rank[PS_KPT_MAX];
+#pragma unroll
+    for (int s = 0; s < PS_KPT_MAX; ++s) {
+      if (s < kpt) {
+        const int d = (k[s] >> shift) & 15;
+        rank[s] = (uint32_t)((lc >> (4 * d)) & 15ull);
+        lc += 1ull << (4 * d);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 16; ++d) cnt[d * PS_THREADS + t] = (uint16_t)((lc >> (4 * d)) & 15ull);
+    __syncthreads();
+    {  // exclusive scan of cnt in flat (digit-major) order: thread t takes flat entries [16t, 16t + 16)
+      uint16_t* mine = cnt + 16 * t;
+      uint32_t loc[16], sum = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { loc[j] = sum; sum += mine[j]; }
+      uint32_t total;
+      const uint32_t base = ps_block_excl_scan(sum, wsum, total);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) mine[j] = (uint16_t)(base + loc[j]);
+    }
+    __syncthreads();
+    uint32_t pos[PS_KPT_MAX];
+#pragma unroll
+    for (int s = 0; s < PS_KPT_MAX; ++s)
+      if (s < kpt) pos[s] = (uint32_t)cnt[((k[s] >> shift) & 15) * PS_THREADS + t] + rank[s];
+    __syncthreads();  // every thread still holds its keys in registers: LDS can be overwritten
+#pragma unroll
+    for (int s = 0; s < PS_KPT_MAX; ++s)
+      if (s < kpt) { keys[pos[s]] = k[s]; vals[pos[s]] = v[s]; }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < PS_KPT_MAX; ++s)
+      if (s < kpt) { k[s] = keys[t * kpt + s]; v[s] = vals[t * kpt + s]; }
+  }
+  if (passes == 0) {  // n_rows == 1: nothing to sort, but the run structure below reads LDS
+#pragma unroll
+    for (int s = 0; s < PS_KPT_MAX; ++s)
+      if (s < kpt) { keys[t * kpt + s] = k[s]; vals[t * kpt + s] = v[s]; }
+    __syncthreads();
+  }
+  // sorted order is in registers (blocked) and in LDS; outputs + run heads
+  uint32_t heads = 0;
+#pragma unroll
+  for (int s = 0; s < PS_KPT_MAX; ++s) {
+    const int i = t * kpt + s;
+    if (s < kpt && i < n) {
+      sorted_ids[i] = (int32_t)k[s];
+      perm[i] = (int32_t)v[s];
+      if (i == 0 || keys[i - 1] != k[s]) heads |= 1u << s;
+    }
+  }
+  uint32_t total;
+  uint32_t seg = ps_block_excl_scan((uint32_t)__popc(heads), wsum, total);
+#pragma unroll
+  for (int s = 0; s < PS_KPT_MAX; ++s)
+    if (s < kpt && ((heads >> s) & 1u)) seg_begin[seg++] = t * kpt + s;
+  if (t == 0) {
+    *n_unique = (int32_t)total;
+    seg_begin[total] = n;
+  }
+}
+
 static int radix_passes(int64_t n_rows) {
   int bits = 1;
   while (bits < 31 && ((int64_t)1 << bits) < n_rows) ++bits;
@@ -238,6 +366,20 @@ extern "C" int tt_rowgrad_plan(const int64_t* ids, int64_t n_ids, int64_t n_rows
     return fail_arg("tt_rowgrad_plan: sizes");
   if (ws_bytes < tt_rowgrad_workspace_bytes(n_ids)) { set_error("tt_rowgrad_plan: workspace"); return TT_E_WORKSPACE; }
   hipStream_t st = S(stream);
+  static const bool no_small = getenv("TT_PLAN_NO_SMALL") != nullptr;  // A/B switch
+  if (n_ids <= PS_MAX && !no_small) {
+    int bits = 1;
+    while (bits < 31 && ((int64_t)1 << bits) < n_rows) ++bits;
+    const int kpt = (int)ceil_div(n_ids, PS_THREADS);
+    const size_t lds = (size_t)PS_THREADS * kpt * 8 + 16 * PS_THREADS * 2;
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { set_error("plan_small_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    plan_small_kernel<<<1, PS_THREADS, lds, st>>>(ids, (int)n_ids, n_rows, kpt, n_rows > 1 ? (bits + 3) / 4 : 0, sorted_ids, perm,
+                                                  seg_begin, n_unique, oob_flag);
+    return check_launch("plan_small_kernel");
+  }
   const int nblk = (int)ceil_div(n_ids, TILE);
   const int nseg = (int)ceil_div(n_ids, SEG_TILE);
   Carver cv(ws);
