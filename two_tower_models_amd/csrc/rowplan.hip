@@ -213,19 +213,24 @@ __global__ __launch_bounds__(256) void seg_write_kernel(const int32_t* __restric
 
 // ---- small plans: the whole thing in ONE workgroup -------------------------
 // n <= PS_MAX ids (a base-model lookup: B = 8192; the sharded trainer's W * cap ~ 9 K per table): LSD radix sort with
-// 4-bit digits entirely in LDS + the run structure, one launch instead of ~15.  The sort of 8192 ids was 15 short
-// launches of 5-20 us each -- latency-bound on the GPU and, with two tables per step, 30 of the ~70 kernel launches the
-// HOST has to enqueue per step (C2 is host-bound: 1.05 ms of enqueue time per 1.3 ms step).
-// 1024 threads; thread t owns positions [t*kpt, (t+1)*kpt) of the current order (blocked: position order = (thread,
-// slot) order, which is what keeps every pass stable).  Per pass: per-thread digit counts (16 x 4-bit fields of one
-// 64-bit register, kpt <= 12) -> cnt[digit][thread] (u16) -> exclusive scan in digit-major order -> scatter from
-// registers back into LDS.  Positions >= n carry the key 0xFFFFFFFF: digit 15 in every pass, they stay behind.
-constexpr int PS_THREADS = 1024;
-constexpr int PS_KPT_MAX = 12;
-constexpr int PS_MAX = PS_THREADS * PS_KPT_MAX;
+// 4-bit digits entirely in LDS + the run structure, one launch instead of ~15 (two tables per step: 30 of the ~70
+// kernel launches the HOST enqueues per step).
+// 512 threads; thread t owns positions [t*kpt, (t+1)*kpt) of the current order (blocked: position order = (thread,
+// slot) order, which keeps every pass stable).  Keys (u32) and original positions (u16) ping-pong between two LDS
+// images; per pass each thread counts its digits into its own column of cnt[digit][thread] (u16), the 16 x 512 counts
+// are scanned in digit-major order, and each thread scatters its slots in order, bumping its own (now exclusive)
+// counters.  Nothing but loop counters lives in registers: the sort runs NEXT TO the persistent sweep (3 waves per SIMD
+// on every CU), so it must be a light workgroup -- the first version (1024 threads, the tile in registers, 127 VGPRs)
+// could not be placed on any CU until the sweep was over and sat in the queue for 5.7 ms.  Images are padded by one word
+// per 32 (a thread's slots are kpt words apart: unpadded that is a 16-way bank conflict).  Positions >= n carry the key
+// 0xFFFFFFFF: digit 15 in every pass, they stay behind.
+constexpr int PS_THREADS = 512;
+constexpr int PS_KPT_MAX = 20;
+constexpr int PS_MAX = PS_THREADS * PS_KPT_MAX;  // 10 240 ids
+__device__ __forceinline__ int ps_pad(int i) { return i + (i >> 5); }
 
 __device__ __forceinline__ uint32_t ps_block_excl_scan(uint32_t v, uint32_t* wsum, uint32_t& total) {
-  // exclusive scan of one value per thread over the 1024-thread workgroup (16 waves)
+  // exclusive scan of one value per thread over the workgroup (PS_THREADS / 64 waves)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t inc = v;
 #pragma unroll
@@ -237,7 +242,7 @@ __device__ __forceinline__ uint32_t ps_block_excl_scan(uint32_t v, uint32_t* wsu
   __syncthreads();
   uint32_t woff = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < 16; ++w) {
+  for (int w = 0; w < PS_THREADS / 64; ++w) {
     const uint32_t x = wsum[w];
     if (w < wave) woff += x;
     tot += x;
@@ -252,38 +257,31 @@ __global__ __launch_bounds__(PS_THREADS) void plan_small_kernel(const int64_t* _
                                                                 int32_t* __restrict__ perm, int32_t* __restrict__ seg_begin,
                                                                 int32_t* __restrict__ n_unique, int32_t* __restrict__ oob_flag) {
   extern __shared__ __attribute__((aligned(16))) uint32_t ps_smem[];
-  uint32_t* keys = ps_smem;                      // [1024 * kpt]
-  uint32_t* vals = keys + PS_THREADS * kpt;      // [1024 * kpt]
-  uint16_t* cnt = reinterpret_cast<uint16_t*>(vals + PS_THREADS * kpt);  // [16][1024]
-  __shared__ uint32_t wsum[16];
+  const int cap = ps_pad(PS_THREADS * kpt) + 1;
+  uint32_t* kbuf[2] = {ps_smem, ps_smem + cap};
+  uint16_t* vbuf[2] = {reinterpret_cast<uint16_t*>(ps_smem + 2 * cap), reinterpret_cast<uint16_t*>(ps_smem + 2 * cap) + cap};
+  uint16_t* cnt = vbuf[1] + cap + (cap & 1);  // [16][512]
+  __shared__ uint32_t wsum[PS_THREADS / 64];
   const int t = threadIdx.x;
-  uint32_t k[PS_KPT_MAX], v[PS_KPT_MAX];
-#pragma unroll
-  for (int s = 0; s < PS_KPT_MAX; ++s) {
-    k[s] = 0xFFFFFFFFu;
-    v[s] = 0;
-    const int i = t * kpt + s;
-    if (s < kpt && i < n) {
+  for (int i = t; i < PS_THREADS * kpt; i += PS_THREADS) {  // coalesced load of the id list
+    uint32_t key = 0xFFFFFFFFu;
+    if (i < n) {
       int64_t id = ids[i];
       if (id < 0 || id >= n_rows) { *oob_flag = 1; id = 0; }
-      k[s] = (uint32_t)id;
-      v[s] = (uint32_t)i;
+      key = (uint32_t)id;
     }
+    kbuf[0][ps_pad(i)] = key;
+    vbuf[0][ps_pad(i)] = (uint16_t)i;
   }
+  __syncthreads();
+  int cur = 0;
   for (int p = 0; p < passes; ++p) {
     const int shift = 4 * p;
-    unsigned long long lc = 0;  // 16 x 4-bit counters
-    uint32_t rank[PS_KPT_MAX];
+    const uint32_t* kin = kbuf[cur];
+    const uint16_t* vin = vbuf[cur];
 #pragma unroll
-    for (int s = 0; s < PS_KPT_MAX; ++s) {
-      if (s < kpt) {
-        const int d = (k[s] >> shift) & 15;
-        rank[s] = (uint32_t)((lc >> (4 * d)) & 15ull);
-        lc += 1ull << (4 * d);
-      }
-    }
-#pragma unroll
-    for (int d = 0; d < 16; ++d) cnt[d * PS_THREADS + t] = (uint16_t)((lc >> (4 * d)) & 15ull);
+    for (int d = 0; d < 16; ++d) cnt[d * PS_THREADS + t] = 0;
+    for (int s = 0; s < kpt; ++s) cnt[((kin[ps_pad(t * kpt + s)] >> shift) & 15) * PS_THREADS + t] += 1;
     __syncthreads();
     {  // exclusive scan of cnt in flat (digit-major) order: thread t takes flat entries [16t, 16t + 16)
       uint16_t* mine = cnt + 16 * t;
@@ -296,41 +294,37 @@ __global__ __launch_bounds__(PS_THREADS) void plan_small_kernel(const int64_t* _
       for (int j = 0; j < 16; ++j) mine[j] = (uint16_t)(base + loc[j]);
     }
     __syncthreads();
-    uint32_t pos[PS_KPT_MAX];
-#pragma unroll
-    for (int s = 0; s < PS_KPT_MAX; ++s)
-      if (s < kpt) pos[s] = (uint32_t)cnt[((k[s] >> shift) & 15) * PS_THREADS + t] + rank[s];
-    __syncthreads();  // every thread still holds its keys in registers: LDS can be overwritten
-#pragma unroll
-    for (int s = 0; s < PS_KPT_MAX; ++s)
-      if (s < kpt) { keys[pos[s]] = k[s]; vals[pos[s]] = v[s]; }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < PS_KPT_MAX; ++s)
-      if (s < kpt) { k[s] = keys[t * kpt + s]; v[s] = vals[t * kpt + s]; }
-  }
-  if (passes == 0) {  // n_rows == 1: nothing to sort, but the run structure below reads LDS
-#pragma unroll
-    for (int s = 0; s < PS_KPT_MAX; ++s)
-      if (s < kpt) { keys[t * kpt + s] = k[s]; vals[t * kpt + s] = v[s]; }
-    __syncthreads();
-  }
-  // sorted order is in registers (blocked) and in LDS; outputs + run heads
-  uint32_t heads = 0;
-#pragma unroll
-  for (int s = 0; s < PS_KPT_MAX; ++s) {
-    const int i = t * kpt + s;
-    if (s < kpt && i < n) {
-      sorted_ids[i] = (int32_t)k[s];
-      perm[i] = (int32_t)v[s];
-      if (i == 0 || keys[i - 1] != k[s]) heads |= 1u << s;
+    uint32_t* kout = kbuf[cur ^ 1];
+    uint16_t* vout = vbuf[cur ^ 1];
+    for (int s = 0; s < kpt; ++s) {  // in slot order: equal digits keep their order
+      const uint32_t key = kin[ps_pad(t * kpt + s)];
+      uint16_t* c = cnt + ((key >> shift) & 15) * PS_THREADS + t;
+      const int pos = ps_pad((int)*c);
+      *c += 1;
+      kout[pos] = key;
+      vout[pos] = vin[ps_pad(t * kpt + s)];
     }
+    __syncthreads();
+    cur ^= 1;
+  }
+  const uint32_t* ks = kbuf[cur];
+  const uint16_t* vs = vbuf[cur];
+  // outputs (coalesced) and run heads (blocked, so that the scan below yields run numbers in position order)
+  for (int i = t; i < n; i += PS_THREADS) {
+    sorted_ids[i] = (int32_t)ks[ps_pad(i)];
+    perm[i] = (int32_t)vs[ps_pad(i)];
+  }
+  uint32_t heads = 0;
+  for (int s = 0; s < kpt; ++s) {
+    const int i = t * kpt + s;
+    if (i < n && (i == 0 || ks[ps_pad(i - 1)] != ks[ps_pad(i)])) heads += 1;
   }
   uint32_t total;
-  uint32_t seg = ps_block_excl_scan((uint32_t)__popc(heads), wsum, total);
-#pragma unroll
-  for (int s = 0; s < PS_KPT_MAX; ++s)
-    if (s < kpt && ((heads >> s) & 1u)) seg_begin[seg++] = t * kpt + s;
+  uint32_t seg = ps_block_excl_scan(heads, wsum, total);
+  for (int s = 0; s < kpt; ++s) {
+    const int i = t * kpt + s;
+    if (i < n && (i == 0 || ks[ps_pad(i - 1)] != ks[ps_pad(i)])) seg_begin[seg++] = i;
+  }
   if (t == 0) {
     *n_unique = (int32_t)total;
     seg_begin[total] = n;
@@ -371,7 +365,8 @@ extern "C" int tt_rowgrad_plan(const int64_t* ids, int64_t n_ids, int64_t n_rows
     int bits = 1;
     while (bits < 31 && ((int64_t)1 << bits) < n_rows) ++bits;
     const int kpt = (int)ceil_div(n_ids, PS_THREADS);
-    const size_t lds = (size_t)PS_THREADS * kpt * 8 + 16 * PS_THREADS * 2;
+    const size_t cap = (size_t)(PS_THREADS * kpt + (PS_THREADS * kpt >> 5)) + 1;
+    const size_t lds = 2 * cap * 4 + 2 * cap * 2 + 4 + 16 * PS_THREADS * 2;
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) { set_error("plan_small_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }

@@ -452,8 +452,8 @@ class DenseExactAdam(torch.optim.Optimizer):
                 end = torch.cuda.Event(enable_timing=True)
                 end.record()
                 self._tune[3] = end
-                self._tune_done.append(self._tune)
-                del self._tune_done[:-8]
+                if len(self._tune_done) < 16:  # never drop a PENDING measurement: when the host runs many steps ahead the
+                    self._tune_done.append(self._tune)  # oldest one is the next to complete (new ones are skipped meanwhile)
                 self._tune = None
         elif self.lazy:
             if self._prefetch_done is not None:  # rows being replayed for a later batch: finish first
