@@ -375,7 +375,7 @@ class DenseExactAdam(torch.optim.Optimizer):
                 ts.plan.build()
             return
         if self._plan_stream is None:
-            self._plan_stream = torch.cuda.Stream(device=next(iter(self._begun)).device)
+            self._plan_stream = N.aux_stream(next(iter(self._begun)).device)
         self._plan_stream.wait_event(self._plan_ready)  # the id lists exist
         with torch.cuda.stream(self._plan_stream):
             for ts in self._begun.values():
