@@ -114,7 +114,7 @@ class OracleBackend:
     def adam_table_begin(self, W, M, V, n_local, local_ids):
         return local_ids, n_local
 
-    def sweep_async(self, tables, hyper):
+    def sweep_async(self, tables, hyper, n_wgs=0):
         pass
 
     def sweep_wait(self):

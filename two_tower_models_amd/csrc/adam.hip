@@ -735,7 +735,7 @@ extern "C" int tt_adam_tables_sweep(const tt_adam_tensor* tables, int32_t n_tabl
   }
   unsigned* ctr = reinterpret_cast<unsigned*>(const_cast<double*>(hyper) + 7);
   static const int wgs_env = getenv("TT_SWEEP_WGS") ? atoi(getenv("TT_SWEEP_WGS")) : 0;  // A/B: absolute workgroup count
-  const int want = n_wgs > 0 ? n_wgs : wgs_env;
+  const int want = getenv("TT_SWEEP_WGS") ? wgs_env : n_wgs;  // the A/B switch wins over the caller's choice
   unsigned grid = (unsigned)(device_cu_count() * persist);
   if (want > 0 && (unsigned)want < grid) grid = (unsigned)want;
   ProfScope prof("adam_sweep_kernel", st);

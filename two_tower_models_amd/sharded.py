@@ -457,7 +457,7 @@ class HipBackend:
                 "tt_adam_table_stash")
         return plan, side, n_rows
 
-    def sweep_async(self, tables, hyper):
+    def sweep_async(self, tables, hyper, n_wgs: int = 0):
         """Zero-gradient sweep of every (W, M, V) on the side stream, after everything queued so
         far on the main stream (the lookups and the stashes)."""
         N, lib = self.N, self.lib
@@ -472,7 +472,7 @@ class HipBackend:
             for i, (W, M, V, n_local) in enumerate(live):
                 descs[i].p, descs[i].g, descs[i].m, descs[i].v = W.data_ptr(), None, M.data_ptr(), V.data_ptr()
                 descs[i].n = n_local * W.shape[1]
-            N.check(lib.tt_adam_tables_sweep(descs, len(live), hyper.data_ptr(), 0, self._side_stream.cuda_stream),
+            N.check(lib.tt_adam_tables_sweep(descs, len(live), hyper.data_ptr(), n_wgs, self._side_stream.cuda_stream),
                     "tt_adam_tables_sweep")
         self._sweep_done = torch.cuda.Event()
         self._sweep_done.record(self._side_stream)
@@ -659,8 +659,13 @@ class ShardedTrainer:
         # small latency-bound tower GEMMs 6x, but costs the MFMA-bound logits kernels little.
         sweep_ms = (self.users.weight.numel() + self.items.weight.numel()) * 24 / 6.0e9
         logits_ms = 8.0 * cfg["B"] * cfg["B"] * (self.W if negatives == "global" else 1) * cfg["D"] / 125.0e9
+        # Round 2 (routed lookups, fused towers: the top of the step is no longer a string of tiny GEMMs): starting the
+        # sweep at the top wins at every world size (emulated W = 8: 4.60 vs 5.12 ms, W = 4: 3.37 vs 3.59, W = 2: 3.41 vs
+        # 3.83), and a THIN sweep (256 persistent workgroups instead of 768) that lasts longer takes less from the logits
+        # kernels when they, not the sweep, are the step (W = 8: 4.49, W = 4: 3.18 ms).
         late = os.environ.get("TT_SWEEP_LATE")  # A/B switch
-        self._sweep_late = (late == "1") if late is not None else sweep_ms < 0.75 * logits_ms
+        self._sweep_late = late == "1"
+        self._sweep_wgs = 256 if sweep_ms < 0.75 * logits_ms else 0
         # the same regime decides whether the forward keeps the logits for the backward (one product
         # fewer, M*N*4 B of HBM traffic each way more): worth it once the sweep no longer binds
         keep = os.environ.get("TT_CE_KEEP_LOGITS")
@@ -800,7 +805,7 @@ class ShardedTrainer:
         sweep = [(self.users.weight, self.users.m, self.users.v, lk_u.n_local),
                  (self.items.weight, self.items.m, self.items.v, lk_i.n_local)]
         if not self._sweep_late:
-            be.sweep_async(sweep, self.hyper)
+            be.sweep_async(sweep, self.hyper, self._sweep_wgs)
         pu, pi = self._tower_params("user"), self._tower_params("item")
         summary, enc_saved = None, None
         u_emb = be.gather_rows(lk_u.rows_p.wait(), lk_u.slot_of)  # the other exchanges are still in flight
@@ -817,7 +822,7 @@ class ShardedTrainer:
         I_all = all_gather_rows(I) if glob else I
         off = self.rank * B if glob else 0
         if self._sweep_late:  # a short sweep hides under the logits kernels instead of the small tower GEMMs
-            be.sweep_async(sweep, self.hyper)
+            be.sweep_async(sweep, self.hyper, self._sweep_wgs)
         ce, lse = be.ce_fwd(U, I_all, off)
         loss, coef = self._weighted_loss(ce, labels, B, glob)
         # 4. backward through the loss
@@ -884,7 +889,7 @@ class ShardedTrainer:
         sweep = [(self.users.weight, self.users.m, self.users.v, lk_u.n_local),
                  (self.items.weight, self.items.m, self.items.v, lk_i.n_local)]
         if not self._sweep_late:
-            be.sweep_async(sweep, self.hyper)
+            be.sweep_async(sweep, self.hyper, self._sweep_wgs)
         pu, pi = self._tower_params("user"), self._tower_params("item")
         summary, enc_saved = None, None
         u_emb = u_emb_p.wait()  # the item-side exchange is still in flight underneath the user tower
@@ -900,7 +905,7 @@ class ShardedTrainer:
         I_all = all_gather_rows(I) if glob else I
         off = self.rank * B if glob else 0
         if self._sweep_late:  # a short sweep hides under the logits kernels instead of the small tower GEMMs
-            be.sweep_async(sweep, self.hyper)
+            be.sweep_async(sweep, self.hyper, self._sweep_wgs)
         ce, lse = be.ce_fwd(U, I_all, off)
         # 3. value weights (ref :322,334-343) with the max / mean taken over the global batch
         loss, coef = self._weighted_loss(ce, labels, B, glob)
