@@ -503,3 +503,75 @@ def test_out_of_range_id_raises_index_error():
         model(*bad)  # nn.Embedding would raise "index out of range in self"; inference checks eagerly
     ok = [torch.tensor([0, 1, 3, 2], device=DEV), bad[1], bad[2]]
     assert model(*ok).shape == (B, 5)
+
+
+@pytest.mark.parametrize("D,kind", [(256, "hist"), (512, "hist"), (192, "base")])
+def test_wide_embeddings_train_step_vs_oracle(D, kind):
+    """Embedding widths above 128: the reference accepts any width; here D = 256 / 512 (history
+    model: heads of 64 / 128, in-batch CE and MIPS through their generic-width forms) and a ragged 192.  One train step
+    vs the oracle: loss 1e-4, updated tables and dense parameters; then forward() top-K vs the oracle's scores."""
+    import two_tower_models_amd as A
+    from oracle import cpu_ref as R
+    torch.manual_seed(11)
+    B, H, NU, NI, F = 48, 6, 300, 500, 8
+    mips = A.BaselineMIPSModule(corpus_size=700, embedding_dim=D)
+    kw = dict(num_items=10, user_id_hash_size=NU, user_id_embedding_dim=D, user_features_size=F, item_id_hash_size=NI,
+              item_id_embedding_dim=D, item_features_size=F, user_value_weights=[1.0], mips_module=mips)
+    model = A.TwoTowerBaseRetrieval(**kw) if kind == "base" else A.TwoTowerWithUserHistoryEncoder(user_history_seqlen=H, **kw)
+    with torch.no_grad():  # keep the logits O(1): D-wide towers with default init saturate the softmax
+        for n, p in model.named_parameters():
+            if n.endswith("tower_arch.weight"):
+                p.mul_(0.2)
+            if "embedding_arch" in n:
+                p.mul_(0.3)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    corpus = mips.corpus.clone()
+    model = model.to(DEV)
+    g = torch.Generator().manual_seed(5)
+    batch = [torch.randint(0, NU, (B,), generator=g), torch.randn(B, F, generator=g), torch.randint(0, NI, (B, H), generator=g),
+             torch.randint(0, NI, (B,), generator=g), torch.randn(B, F, generator=g), torch.randint(0, 10, (B,), generator=g),
+             torch.randint(0, 2, (B, 1), generator=g).float()]
+    opt = A.DenseExactAdam(model.parameters(), lr=1e-3)
+    loss = model.train_forward(*[t.to(DEV) for t in batch])
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    fkw = dict(with_history=True, heads=4, pos_table=R.positional_table(H, D)) if kind == "hist" else {}
+    state = R.AdamState(params)
+    want = R.train_step(params, state, batch, torch.tensor([1.0]), **fkw)
+    assert abs(loss.item() - want) < 1e-4, (loss.item(), want)
+    for k, v in model.state_dict().items():
+        err = (v.cpu() - params[k]).abs()
+        assert float(err.max()) <= 2 * 1e-3 * 1.05, (k, float(err.max()))  # one Adam step moves an element by <= lr
+        noise_only = k in ("item_tower_arch.bias", "item_features_arch.2.bias") or k.endswith("in_proj_bias")
+        if not noise_only:
+            assert int((err > 5e-6).sum()) <= max(1, int(2e-3 * err.numel())), (k, int((err > 5e-6).sum()), err.numel())
+    with torch.no_grad():
+        top = model(*[t.to(DEV) for t in batch[:3]])
+        u = R.user_embedding(params, *batch[:3], **fkw) if kind == "hist" else R.user_embedding(params, *batch[:3], with_history=False)
+    full = u.double() @ corpus.double().t()
+    picked = torch.gather(full, 1, top.cpu())
+    kth = torch.topk(full, 10, dim=1).values[:, -1]
+    assert bool((picked.min(1).values >= kth - 1e-4).all())
+
+
+def test_sweep_throttle_does_not_change_results(golden):
+    """The closed-loop sweep throttle (fewer persistent sweep workgroups when the step is much longer than the sweep)
+    is a scheduling decision only: pinning the widest, a thin and the thinnest sweep gives bit-identical tables."""
+    import os
+    import two_tower_models_amd as A
+    g = golden("g2_base_aligned")
+    outs = []
+    for wgs in (0, 128, 1):
+        model = make_model("base", g)
+        opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep="forward")
+        opt._tune_sweep = lambda: None  # no controller: the width below stays
+        opt._sweep_wgs = wgs
+        for s in range(3):
+            loss = model.train_forward(*batch_of(g, prefix=f"step{s}.in."))
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        outs.append({k: v.clone() for k, v in model.state_dict().items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k]), k
