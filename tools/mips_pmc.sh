@@ -1,0 +1,24 @@
+#!/bin/bash
+# SQ counters of the bf16 MIPS pass-1 kernel (where do its wave cycles go?).  Run on the GPU box; prints one line per
+# counter, averaged over the pass-1 dispatches of tools/bench_mips.py.   tools/mips_pmc.sh [out_dir]
+R=$(cd "$(dirname "$0")/.." && pwd)
+OUT=${1:-$R/gpurun_out/mips_pmc}
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU \
+  --kernel-trace --output-format csv -d $OUT/p1 -- python $R/tools/bench_mips.py > $OUT/p1.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM \
+  --kernel-trace --output-format csv -d $OUT/p2 -- python $R/tools/bench_mips.py > $OUT/p2.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_INSTS_VMEM \
+  --kernel-trace --output-format csv -d $OUT/p3 -- python $R/tools/bench_mips.py > $OUT/p3.log 2>&1
+python - $OUT <<'PY'
+import csv, glob, sys, collections
+acc = collections.defaultdict(list)
+for f in glob.glob(sys.argv[1] + "/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "mips_pass1_dma_kernelILi1E" in r["Kernel_Name"]:  # bf16
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k in sorted(acc):
+    v = acc[k]
+    print(f"{k:28s} n={len(v)} mean={sum(v)/len(v):.4g}")
+PY

@@ -12,7 +12,8 @@ from typing import Optional
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libtt_hotpath.so")
+# TT_HOTPATH_LIB: load another build of the SAME library (tools/mips_variants.sh A/Bs compile-time kernel variants)
+LIB_PATH = os.environ.get("TT_HOTPATH_LIB") or os.path.join(_PKG, "lib", "libtt_hotpath.so")
 
 TT_GEMM_NT, TT_GEMM_NN, TT_GEMM_TN = 0, 1, 2
 TT_EPI_NONE, TT_EPI_RELU, TT_EPI_RELU_MASK = 0, 1, 2

@@ -33,6 +33,10 @@
 #include "common.hpp"
 #include "mfma_stream.hpp"
 
+#ifndef TT_MIPS_EXP
+#define TT_MIPS_EXP 0  // measurement variants of the bf16 pass 1 (tools/mips_variants.sh); 0 = the product kernel
+#endif
+
 namespace tt {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -68,6 +72,18 @@ __device__ __forceinline__ int chunk_row(int t2, int L) {
   return 64 * ((a >> 2) & 1) + 16 * T + 4 * (a >> 3) + (a & 3);
 }
 
+// What the LDS-DMA pass 1 stores per (group, query) -- RAW, so that its tile loop spends no VALU instruction on it (every
+// one is matrix-core time there); the readers, all memory-bound, decode:
+//   gmax word: the bits of the best score (0xFFFFFFFF: empty group)
+//   gm2 word : the bits of the runner-up with the low 6 bits replaced by the best item's position (its row 0..63 in the
+//              group, or its 4-row quad 0..15).  The runner-up is only ever used as an UPPER bound ("can a second item of
+//              this group reach tau?"): ord(bits with the low 6 cleared) | 63 >= ord(runner-up) for either sign.
+// The generic pass 1 and the D > 128 form store score_ord values and no runner-up (raw = 0).
+__device__ __forceinline__ uint32_t gmax_ord(uint32_t v, int raw) {
+  return raw ? (v == 0xFFFFFFFFu ? 0u : score_ord(__uint_as_float(v))) : v;
+}
+__device__ __forceinline__ uint32_t gm2_upper_ord(uint32_t v) { return score_ord(__uint_as_float(v & ~63u)) | 63u; }
+
 struct MipsArgs {
   const void* Q;       // [B, D] queries (fp32 or bf16)
   const void* Cm;      // [C, D] corpus
@@ -75,8 +91,7 @@ struct MipsArgs {
   int64_t q0, nq;      // this batch: queries q0 .. q0+nq
   int64_t chunks_per_split, n_chunks;
   uint32_t* gmax;      // [n_groups][nq] score_ord of the group max (0 = empty group)
-  uint32_t* gm2;       // [n_groups][nq] score_ord of the group's SECOND best score, or NULL
-  uint8_t* garg;       // [n_groups][nq] row offset (0..63) of the group's best item (first max)
+  uint32_t* gm2;       // [n_groups][nq] runner-up + position of the best item (see gmax_ord), or NULL
   const u64* tau;      // [nq] K-th largest group key
   u64* cand;           // [nq][cap]
   int32_t* count;      // [nq]
@@ -86,6 +101,8 @@ struct MipsArgs {
   int64_t K;
   int64_t xblocks, splits;  // DMA pass 1: 1-D grid decomposition
   int vec_ok;
+  int raw_scores;       // gmax / gm2 are in the raw format of the LDS-DMA pass 1 (see gmax_ord)
+  int arg_quads;        // the position in a gm2 word is the 4-row QUAD (0..15) of the best item, not its row (bf16 DMA pass 1)
 };
 
 // ---------------------------------------------------------------- operand traits
@@ -330,7 +347,11 @@ __device__ __forceinline__ void corpus_tile_dma(const char* __restrict__ Cm, int
   constexpr int NI = CT / RPI / 4;   // instructions per wave
   // buffer loads (see tile_dma in mfma_stream.hpp): chunk base in a scalar descriptor; rows past the end of
   // the corpus are outside the descriptor and land as zeros (the epilogue masks them)
+#if TT_MIPS_EXP & 16
+  const int64_t chunk0 = ((t >> 1) & 63) * CHUNK, left = C - chunk0;  // measurement variant: the corpus "stream" stays in L2
+#else
   const int64_t chunk0 = (t >> 1) * CHUNK, left = C - chunk0;
+#endif
   const int rows_here = left < CHUNK ? (int)left : CHUNK;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Cm + chunk0 * row_bytes), 0,
                                                                       rows_here * (int)row_bytes, 0x00020000);
@@ -347,6 +368,12 @@ __device__ __forceinline__ void corpus_tile_dma(const char* __restrict__ Cm, int
   }
 }
 
+// max of three: the compiler fuses the two fmaxf into ONE v_max3_f32 (checked in the ISA: no canonicalising
+// v_max_f32 x, x on the MFMA results).  Not inline assembly: the hazard recogniser does not see an asm statement read the
+// MFMA results and leaves out the wait states between the last v_mfma and the first read of its accumulators
+// (measured: stale scores).
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -362,6 +389,7 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 template <int DT, int DPX, int NQ, int STAGES, int SF>
 __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p) {
   constexpr bool SHARE = SF != 0;
+  constexpr bool QUADS = DT == TT_BF16;  // the best item of a group is tracked per 4-row quad (see the epilogue)
   static_assert(SF == 0 || SF == 2 || SF == 4, "shared-query form: waves per query block");
   using O = Op<DT, DPX>;
   using TM = TileMap<DPX, true>;  // row bytes = 32 * DPX for both dtypes
@@ -422,11 +450,43 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
   // previous step) receives tile t + STAGES - 1
   // PAR = t & 1 (t0 is even) as a compile-time constant: the group-relative row of every accumulator element is
   // then an inline constant of the v_cndmask that tracks the best row -- no v_mov per element.
+  // a finished chunk: lane-half h holds group 2*chunk + h.  Scalar base (chunk) + one 32-bit lane offset: no 64-bit
+  // per-lane address arithmetic in the tile loop (the NQ = 4 kernel has no register to spare for it)
+  const uint32_t nq32 = (uint32_t)p.nq, lane_q = (uint32_t)qbase, lane_off = (uint32_t)h * nq32 + lane_q;
+  auto store_chunk = [&](int64_t chunk) {
+#if TT_MIPS_EXP & 32
+    const int64_t base = 2 * (chunk & 7) * p.nq;  // measurement variant: the result stores stay in L2
+#else
+    const int64_t base = 2 * chunk * p.nq;
+#endif
+    uint32_t* const g1 = p.gmax + base;
+    uint32_t* const g2 = p.gm2 + base;
+    const bool second_empty = (2 * chunk + 1) * GROUP >= p.C;  // only the corpus' last chunk (wave-uniform)
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+#if TT_MIPS_EXP & 8
+      if (m1[n] == 12345.678f) {  // measurement variant: (practically) no result stores
+#else
+      if (lane_q + 32u * n < nq32) {
+#endif
+        uint32_t best = __float_as_uint(m1[n]);
+        if (second_empty && h) best = 0xFFFFFFFFu;
+        __builtin_nontemporal_store(best, &g1[lane_off + 32u * n]);
+        __builtin_nontemporal_store((__float_as_uint(m2[n]) & ~63u) | (uint32_t)arg[n], &g2[lane_off + 32u * n]);
+      }
+      m1[n] = NEG_INF; m2[n] = NEG_INF; arg[n] = 0;
+    }
+  };
   auto step = [&](auto par_c, int64_t t, const float* ys, float* dst) {
     constexpr int PAR = decltype(par_c)::value;
     const bool more = t + STAGES - 1 < t1;
-    if (more) corpus_tile_dma<DPX>(Cm, row_bytes, t + STAGES - 1, p.C, dst, wave, dl);
     const int64_t chunk = t >> 1;
+    // The previous chunk's results are stored HERE, in front of this step's tile DMA, not at the end of the step that
+    // finished the chunk: the wait that ends a step counts outstanding vector-memory instructions of either kind, and
+    // with the stores as the newest ones "all but 2 tiles' DMAs" also meant "wait for the tiles just requested and for
+    // the stores' write acknowledgements" -- every second tile.
+    if (!SHARE && PAR == 0 && t > t0) store_chunk(chunk - 1);
+    if (more) corpus_tile_dma<DPX>(Cm, row_bytes, t + STAGES - 1, p.C, dst, wave, dl);
     const bool full = (chunk + 1) * CHUNK <= p.C;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
@@ -462,11 +522,20 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
             const uint32_t a = lrow + 16u * (uint32_t)((2 * g + h) ^ sw);
             asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(a) : "memory");
           };
+#if TT_MIPS_EXP & 2
+          // measurement variant: ONE LDS read per sub-tile instead of one per k-group
           rd(yy[0], 0);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yy[0]) : : "memory");
+          yy[1] = yy[0];
+#else
+          rd(yy[0], 0);
+#endif
 #pragma unroll
           for (int g = 0; g < DPX; ++g) {
+#if !(TT_MIPS_EXP & 2)
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yy[g & 1]) : : "memory");
             if (g + 1 < DPX) rd(yy[(g + 1) & 1], g + 1);
+#endif
 #pragma unroll
             for (int n = 0; n < NQ; ++n)
               acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, yy[g & 1]), __builtin_bit_cast(bf16x8, qf[n].v[g]), acc[n], 0, 0, 0);
@@ -474,11 +543,56 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
         }
       }
       const int off0 = 16 * (2 * PAR + jt);  // group-relative row of element 0 (compile-time: jt is unrolled)
-      // Per score: compare, med3 (new runner-up), two selects (best score, best row) = 4 VALU instructions.
-      // fmaxf would add a canonicalising v_max per element, a runtime row offset a v_mov, and testing "row < C"
-      // inside the loop a 64-bit compare + two selects: 10 instructions per score, 2.5x the MFMA time of a bf16
-      // tile.  The last (partial) chunk takes the masked copy of the loop through a wave-uniform branch.
-      if (full) {
+#if TT_MIPS_EXP & 1
+      // measurement variant (tools/mips_variants.sh): no epilogue -- one add per accumulator quad keeps the MFMAs alive
+#pragma unroll
+      for (int n = 0; n < NQ; ++n) m1[n] += acc[n][0];
+      continue;
+#endif
+      auto rows_inside = [&]() {  // elements of this lane's 16 rows inside the corpus (last chunk only)
+        // the 64-bit part is wave-uniform (scalar registers); per lane only a 32-bit subtract and clamp
+        const int64_t rows_left = p.C - chunk * CHUNK;
+        const int left = (rows_left < CHUNK ? (int)rows_left : CHUNK) - 64 * h - off0;
+        return left < 0 ? 0 : left > 16 ? 16 : left;
+      };
+      if constexpr (QUADS) {
+        // bf16: VALU and MFMA instructions do not co-issue on a gfx950 SIMD (tools/mfma_valu_coexec.hip), so every
+        // epilogue instruction is MFMA time lost: a bf16 tile is 8 MFMAs = 256 cycles, and the row-exact epilogue
+        // below (4 instructions per score, 64 per tile and query fragment) is another 256.  Here the best score and
+        // the runner-up stay exact but the best item is tracked per QUAD of 4 consecutive rows (elements 4j .. 4j+3
+        // are rows off0 + 4j .. + 3): 7 instructions per quad = 1.75 per score.  Pass 2 finds the row inside the quad
+        // by scoring its 4 rows again (1 KiB per selected group instead of nothing -- but 16 KiB if it had to score
+        // the whole group).  v_max3 / v_med3 take two new scores per instruction:
+        //   b1 = med3(m1, x0, x1), a1 = max3(m1, x0, x1): runner-up and best of {m1, x0, x1};  b2, a2 likewise from a1;
+        //   the new runner-up is max3(m2, b1, b2) (m2 <= m1 <= a1), the new best a2.
+        auto quad = [&](int n, int j, float x0, float x1, float x2, float x3) {
+          const float b1 = __builtin_amdgcn_fmed3f(m1[n], x0, x1), a1 = max3f(m1[n], x0, x1);
+          const float b2 = __builtin_amdgcn_fmed3f(a1, x2, x3), a2 = max3f(a1, x2, x3);
+          m2[n] = max3f(m2[n], b1, b2);
+          const bool gt = a2 > m1[n];  // strict: equal scores keep the earlier quad
+          arg[n] = gt ? off0 / 4 + j : arg[n];
+          m1[n] = a2;
+        };
+        if (full) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) quad(n, j, acc[n][4 * j], acc[n][4 * j + 1], acc[n][4 * j + 2], acc[n][4 * j + 3]);
+        } else {  // last chunk: rows past the end of the corpus score -inf
+          const int valid = rows_inside();
+#pragma unroll
+          for (int n = 0; n < NQ; ++n)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              quad(n, j, 4 * j < valid ? acc[n][4 * j] : NEG_INF, 4 * j + 1 < valid ? acc[n][4 * j + 1] : NEG_INF,
+                   4 * j + 2 < valid ? acc[n][4 * j + 2] : NEG_INF, 4 * j + 3 < valid ? acc[n][4 * j + 3] : NEG_INF);
+        }
+      } else if (full) {
+        // fp32 (the MFMA time of a tile is 8x the bf16 one, the epilogue is a few percent of it): the best ROW.
+        // Per score: compare, med3 (new runner-up), two selects (best score, best row) = 4 VALU instructions.
+        // fmaxf would add a canonicalising v_max per element, a runtime row offset a v_mov, and testing "row < C"
+        // inside the loop a 64-bit compare + two selects: 10 instructions per score.  The last (partial) chunk takes
+        // the masked copy of the loop through a wave-uniform branch.
         // element-major: the NQ chains are independent, so consecutive instructions never wait on each other's
         // compare result (chain-major order costs an s_nop per element for the VCC hazard)
 #pragma unroll
@@ -493,8 +607,7 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
           }
         }
       } else {
-        const int64_t left = p.C - (chunk * CHUNK + 64 * h + off0);
-        const int valid = left < 0 ? 0 : left > 16 ? 16 : (int)left;  // elements of this lane's 16 rows inside the corpus
+        const int valid = rows_inside();
 #pragma unroll
         for (int n = 0; n < NQ; ++n) {
 #pragma unroll
@@ -531,25 +644,14 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
         m1[0] = M1; m2[0] = M2; arg[0] = A;
       }
     }
-    if (PAR && (!SHARE || member == 0)) {  // chunk complete: lane-half h holds group 2*chunk + h
-      const int64_t grp = 2 * chunk + h;
-      const bool nonempty = grp * GROUP < p.C;
-#pragma unroll
-      for (int n = 0; n < NQ; ++n) {
-        const int64_t ql = qbase + 32 * n;
-        if (ql < p.nq) {
-          p.gmax[grp * p.nq + ql] = nonempty ? score_ord(m1[n]) : 0u;
-          p.gm2[grp * p.nq + ql] = nonempty ? score_ord(m2[n]) : 0u;
-          p.garg[grp * p.nq + ql] = (uint8_t)arg[n];
-        }
-        m1[n] = NEG_INF; m2[n] = NEG_INF; arg[n] = 0;
-      }
-    }
+    if (SHARE && PAR && member == 0) store_chunk(chunk);
     if (SHARE && PAR && member != 0) { m1[0] = NEG_INF; m2[0] = NEG_INF; arg[0] = 0; }
     // tile t+1 must have landed; tiles t+2 .. t+STAGES-1 may still be in flight
     if (more) wait_vmcnt<(STAGES - 2) * NI>();
     else wait_vmcnt<0>();
+#if !(TT_MIPS_EXP & 4)
     __syncthreads();
+#endif
   };
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
@@ -568,6 +670,7 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
       cur = (cur + 1) % STAGES;
     }
   }
+  if (!SHARE && t1 > t0) store_chunk((t1 - 1) >> 1);  // the last chunk (t1 - t0 is even: whole chunks)
 }
 
 // ---------------------------------------------------------------- sparse pass 2
@@ -600,18 +703,52 @@ __global__ __launch_bounds__(256) void mips_sparse_kernel(const MipsArgs p) {
     const uint32_t my_grp = valid ? (uint32_t)gl[gi] : 0u;
     bool single = false;
     int64_t at = 0;
+    uint32_t where = 0;  // position of the best item inside the group (row, or quad)
     if (p.gm2 && valid) {
       at = (int64_t)my_grp * p.nq + ql;
-      single = ord_key(p.gm2[at], my_grp) < tau;  // the runner-up cannot qualify
+      const uint32_t w2 = p.gm2[at];
+      where = w2 & 63u;
+      single = ord_key(gm2_upper_ord(w2), my_grp) < tau;  // the runner-up cannot qualify
     }
     const u64 smask = __ballot(single);
     if (smask) {
       int pos0 = 0;
       if (lane == 0) pos0 = atomicAdd(&p.count[ql], __popcll(smask));
       pos0 = __shfl(pos0, 0, 64);
-      if (single) {
-        const int pos = pos0 + __popcll(smask & lt_mask);
-        if (pos < p.cap) p.cand[ql * p.cap + pos] = ord_key(p.gmax[at], (uint32_t)((int64_t)my_grp * GROUP + p.garg[at]));
+      const int pos = pos0 + __popcll(smask & lt_mask);
+      if (!p.arg_quads) {
+        if (single && pos < p.cap)
+          p.cand[ql * p.cap + pos] = ord_key(gmax_ord(p.gmax[at], 1), my_grp * GROUP + where);
+      } else {
+        // pass 1 kept the QUAD of the best item: score the quad's 4 rows again, 8 quads per MFMA tile (A-operand row
+        // a = 4 * (quad in tile) + row in quad).  Accumulator element e of lane-half hh is A row (e & 3) + 8 * (e >> 2)
+        // + 4 * hh, so lane (rr, hh) with rr < 4 finds the four scores of tile quad 2 * rr + hh in acc[4 rr .. 4 rr + 3].
+        const uint32_t my_row0 = single ? my_grp * GROUP + 4u * where : 0u;  // rows < 2^32 (checked by the entry point)
+#pragma unroll 1
+        for (int j = 0; j < 8; ++j) {
+          if (!((smask >> (8 * j)) & 0xFFull)) continue;  // wave-uniform: none of these eight groups is single
+          const uint32_t qrow0 = (uint32_t)__shfl((int)my_row0, 8 * j + (r >> 2), 64);
+          int64_t arow = (int64_t)qrow0 + (r & 3);
+          if (arow >= p.C) arow = p.C - 1;  // past the end (or not a single): any valid row, ignored below
+          const f32x16 acc = O::tile_at(base + arow * row_bytes + 16 * h, qf);
+          const int src = 8 * j + 2 * (r & 3) + h;  // the group lane this lane reports for (if r < 4)
+          const uint32_t srow0 = (uint32_t)__shfl((int)my_row0, src, 64);
+          const int spos = __shfl(pos, src, 64);
+          const bool s_single = (smask >> src) & 1ull;
+          float x0 = acc[0], x1 = acc[1], x2 = acc[2], x3 = acc[3];
+#pragma unroll
+          for (int jj = 1; jj < 4; ++jj)
+            if (r == jj) { x0 = acc[4 * jj]; x1 = acc[4 * jj + 1]; x2 = acc[4 * jj + 2]; x3 = acc[4 * jj + 3]; }
+          if (r < 4 && s_single && spos < p.cap) {
+            // the best of the four, the first on ties: the group's best item (its score is gmax, bit for bit)
+            uint32_t bo = score_ord(x0), be = 0;
+            const uint32_t o1 = score_ord(x1), o2 = score_ord(x2), o3 = score_ord(x3);
+            if ((int64_t)srow0 + 1 < p.C && o1 > bo) { bo = o1; be = 1; }
+            if ((int64_t)srow0 + 2 < p.C && o2 > bo) { bo = o2; be = 2; }
+            if ((int64_t)srow0 + 3 < p.C && o3 > bo) { bo = o3; be = 3; }
+            p.cand[ql * p.cap + spos] = ord_key(bo, srow0 + be);
+          }
+        }
       }
     }
     u64 todo = __ballot(valid && !single);
@@ -651,7 +788,7 @@ __global__ __launch_bounds__(256) void mips_sparse_kernel(const MipsArgs p) {
 //         are still wanted (then the prefix itself is an exact threshold).
 // `tau` doubles as the prefix being built.
 constexpr int SEL_Q = 32;
-__global__ __launch_bounds__(256) void mips_select_hist_kernel(const uint32_t* __restrict__ gmax, int64_t n_groups,
+__global__ __launch_bounds__(256) void mips_select_hist_kernel(const uint32_t* __restrict__ gmax, int raw, int64_t n_groups,
                                                                int64_t nq, int pass, const u64* __restrict__ tau,
                                                                const int32_t* __restrict__ done,
                                                                int32_t* __restrict__ ghist) {
@@ -686,7 +823,7 @@ __global__ __launch_bounds__(256) void mips_select_hist_kernel(const uint32_t* _
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t g = gb + 8 * u;
-        const u64 key = ord_key(v[u], (uint32_t)g);
+        const u64 key = ord_key(gmax_ord(v[u], raw), (uint32_t)g);
         if (g < g1 && (key & himask) == prefix) atomicAdd(&hist[ql][(int)((key >> shift) & 255)], 1);
       }
     }
@@ -735,7 +872,7 @@ __global__ void mips_select_init_kernel(int32_t* __restrict__ ghist, int32_t* __
 // (mips_select_finish_kernel), which also appends the survivors that make it to glist.
 constexpr int SPLIT_ITERS = 96;  // groups per thread and slice (3 x 32 match bits per list)
 
-__global__ __launch_bounds__(256) void mips_select_split_kernel(const uint32_t* __restrict__ gmax, int64_t n_groups,
+__global__ __launch_bounds__(256) void mips_select_split_kernel(const uint32_t* __restrict__ gmax, int raw, int64_t n_groups,
                                                                 int64_t nq, const u64* __restrict__ tau,
                                                                 const int32_t* __restrict__ done, int64_t K,
                                                                 int32_t* __restrict__ glist, int32_t* __restrict__ lcount,
@@ -772,7 +909,7 @@ __global__ __launch_bounds__(256) void mips_select_split_kernel(const uint32_t* 
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int64_t g = g0 + lane8 + 8 * (int64_t)(32 * w + 8 * b8 + u);
-        const u64 key = ord_key(v[u], (uint32_t)g);
+        const u64 key = ord_key(gmax_ord(v[u], raw), (uint32_t)g);
         const bool sure = g < g1 && (decided ? key >= t : (key >> 48) > (t >> 48));
         const bool sv = g < g1 && !sure && !decided && (key >> 48) == (t >> 48);
         bits_sure[w] |= (sure ? 1u : 0u) << (8 * b8 + u);
@@ -818,7 +955,7 @@ __global__ __launch_bounds__(256) void mips_select_split_kernel(const uint32_t* 
       const int bit = __ffs(m) - 1;
       m &= m - 1;
       const int64_t g = g0 + lane8 + 8 * (int64_t)(32 * w + bit);
-      surv[q * n_groups + pb++] = ord_key(gmax[g * nq + q], (uint32_t)g);
+      surv[q * n_groups + pb++] = ord_key(gmax_ord(gmax[g * nq + q], raw), (uint32_t)g);
     }
   }
 }
@@ -1216,8 +1353,7 @@ extern "C" int64_t tt_mips_workspace_bytes(int64_t B, int64_t C, int64_t D, int6
   MipsPlan pl;
   if (B <= 0 || C <= 0 || D <= 0 || K <= 0 || K > C || !plan_mips(B, C, D, K, dtype, pl)) return 256;
   return round_up(pl.n_groups * pl.qb * 4, 256)  // gmax
-         + round_up(pl.n_groups * pl.qb * 4, 256)  // second best per group
-         + round_up(pl.n_groups * pl.qb, 256)      // offset of the best per group
+         + round_up(pl.n_groups * pl.qb * 4, 256)  // runner-up + position of the best per group
          + round_up(pl.qb * K * 4, 256)          // selected groups
          + round_up(pl.qb * 4, 256)              // their count
          + round_up(pl.n_groups * pl.qb * 8, 256) // select survivors (keys)
@@ -1243,7 +1379,6 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
   Carver cv(ws);
   uint32_t* gmax = cv.take<uint32_t>(pl.n_groups * pl.qb);
   uint32_t* gm2 = cv.take<uint32_t>(pl.n_groups * pl.qb);
-  uint8_t* garg = cv.take<uint8_t>(pl.n_groups * pl.qb);
   int32_t* glist = cv.take<int32_t>(pl.qb * K);
   int32_t* lcount = cv.take<int32_t>(pl.qb);
   u64* surv = cv.take<u64>(pl.n_groups * pl.qb);
@@ -1272,7 +1407,7 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
     a.chunks_per_split = pl.chunks_per_split; a.n_chunks = pl.n_chunks;
     a.gmax = gmax; a.tau = tau; a.cand = cand; a.count = count; a.cap = pl.cap; a.vec_ok = vec ? 1 : 0;
     a.glist = glist; a.lcount = lcount; a.K = K;
-    a.gm2 = gm2; a.garg = garg;
+    a.gm2 = gm2;
     dim3 grid((unsigned)ceil_div(nq, QB_WG), (unsigned)pl.splits);
     mips_zero_kernel<<<(unsigned)ceil_div(nq, 256), 256, 0, st>>>(tau, count, lcount, scount, nq);
     if ((rc = check_launch("mips_zero_kernel"))) return rc;
@@ -1287,8 +1422,11 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
         rc = mips_wide_pass(1, a, dtype, wide_ws, wide_bytes, pl.qb, st);
       } else {
         rc = (vec && D == dp && !no_dma) ? dispatch_pass1_dma(dtype, pl.dpx, a, pl.splits, st) : -1;
-        if (rc == -1) {  // generic pass 1 keeps the group maxima only
+        a.arg_quads = dtype == TT_BF16;  // what the DMA pass left in the gm2 words
+        a.raw_scores = 1;
+        if (rc == -1) {  // generic pass 1 keeps the group maxima only, as score_ord values
           a.gm2 = nullptr;
+          a.raw_scores = 0;
           rc = dispatch_score<1>(dtype, pl.dpx, a, grid, st);
         }
       }
@@ -1302,7 +1440,7 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
       if (slices > ceil_div(pl.n_groups, 64)) slices = ceil_div(pl.n_groups, 64);
       if (slices < 1) slices = 1;
       for (int pass = 0; pass < 2; ++pass) {
-        mips_select_hist_kernel<<<dim3((unsigned)qblocks, (unsigned)slices), 256, 0, st>>>(gmax, pl.n_groups, nq, pass, tau, done, ghist);
+        mips_select_hist_kernel<<<dim3((unsigned)qblocks, (unsigned)slices), 256, 0, st>>>(gmax, a.raw_scores, pl.n_groups, nq, pass, tau, done, ghist);
         if ((rc = check_launch("mips_select_hist_kernel"))) return rc;
         mips_select_pick_kernel<<<(unsigned)ceil_div(nq, 64), 64, 0, st>>>(ghist, nq, pass, tau, want, done);
         if ((rc = check_launch("mips_select_pick_kernel"))) return rc;
@@ -1311,7 +1449,7 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
       // fewer, longer slices than the histogram passes: one counter reservation per workgroup, query and list
       int64_t split_slices = slices < 256 ? slices : 256;
       if (split_slices * 8 * SPLIT_ITERS < pl.n_groups) split_slices = ceil_div(pl.n_groups, 8 * SPLIT_ITERS);  // match-bit capacity
-      mips_select_split_kernel<<<dim3((unsigned)qblocks, (unsigned)split_slices), 256, 0, st>>>(gmax, pl.n_groups, nq, tau, done, K, gl, lcount, surv, scount);
+      mips_select_split_kernel<<<dim3((unsigned)qblocks, (unsigned)split_slices), 256, 0, st>>>(gmax, a.raw_scores, pl.n_groups, nq, tau, done, K, gl, lcount, surv, scount);
       if ((rc = check_launch("mips_select_split_kernel"))) return rc;
       mips_select_finish_kernel<<<(unsigned)nq, 256, 0, st>>>(surv, scount, pl.n_groups, tau, want, done, K, gl, lcount);
       if ((rc = check_launch("mips_select_finish_kernel"))) return rc;
