@@ -106,6 +106,23 @@ def test_ragged_shapes_match_oracle_order(A, B, C, D, K):
         assert torch.equal(emb.cpu(), corpus[want_idx])
 
 
+@pytest.mark.parametrize("B,C,K", [(300, 256 * 23 + 100, 40), (700, 256 * 30 + 129, 45), (1024, 256 * 40 + 255, 33),
+                                   (100, 128 * 41, 40)])
+def test_bf16_128_row_groups_ties_and_tails(A, B, C, K):
+    """bf16 storage, more than 64 queries, D = 128: pass 1 works on 256-row chunks (128-row groups), two / four query
+    fragments per wave.  Corpus sizes that end inside the first / second half of a 256-row chunk (an empty last group,
+    a one-row last group); integer-valued data = exact scores with many ties, so the (score desc, index asc) order is
+    checked bit for bit, including which row of a 4-row quad pass 2 reports."""
+    D = 128
+    corpus = T((fg.hashed_u64((C, D), 15) % np.uint64(5)).astype(np.float32) - 2.0)
+    q = T((fg.hashed_u64((B, D), 16) % np.uint64(3)).astype(np.float32) - 1.0)
+    want_idx, want_sc, _ = R.mips_topk(q, corpus, K)
+    m = module_with(A, corpus, bf16=True)
+    idx, sc = m.search(q.to(DEV), K)
+    assert torch.equal(idx.cpu(), want_idx)
+    assert torch.equal(sc.cpu(), want_sc)
+
+
 def test_all_equal_scores_returns_lowest_indices(A):
     corpus = torch.ones(1000, 16)
     m = module_with(A, corpus)

@@ -67,9 +67,11 @@ __device__ __forceinline__ u64 ord_key(uint32_t ord, uint32_t idx) {
 // LDS row L (0..63) of the t2-th (0/1) 64-row tile of a chunk -> row offset inside the chunk.
 // MFMA tile T = 2*t2 + L/32, A-operand row a = L%32 lands in lane-half (a>>2)&1, element
 // e = 4*(a>>3) + (a&3) of the accumulator; it is fed chunk row 64*half + 16*T + e.
-__device__ __forceinline__ int chunk_row(int t2, int L) {
+// `hs` = rows between the two lane halves: 64 (a 128-row chunk per tile pair), or 128 when the bf16 LDS-DMA pass 1
+// works on 256-row chunks (two tile pairs; lane-half h then sees rows 128h .. 128h+127: 128-row groups).
+__device__ __forceinline__ int chunk_row(int t2, int L, int hs = 64) {
   const int a = L & 31, T = 2 * t2 + (L >> 5);
-  return 64 * ((a >> 2) & 1) + 16 * T + 4 * (a >> 3) + (a & 3);
+  return hs * ((a >> 2) & 1) + 16 * T + 4 * (a >> 3) + (a & 3);
 }
 
 // What the LDS-DMA pass 1 stores per (group, query) -- RAW, so that its tile loop spends no VALU instruction on it (every
@@ -101,6 +103,7 @@ struct MipsArgs {
   int64_t K;
   int64_t xblocks, splits;  // DMA pass 1: 1-D grid decomposition
   int vec_ok;
+  int gshift;           // log2(rows per group): 6; 7 when the bf16 LDS-DMA pass 1 works on 256-row chunks (128 rows per lane half)
   int raw_scores;       // gmax / gm2 are in the raw format of the LDS-DMA pass 1 (see gmax_ord)
   int arg_quads;        // the position in a gm2 word is the 4-row QUAD (0..15) of the best item, not its row (bf16 DMA pass 1)
 };
@@ -333,15 +336,15 @@ struct DmaLane {
   int vc;    // 16 * ((lane % CPR) ^ ((lane / CPR) & SW))
 };
 template <int DP8>
-__device__ __forceinline__ DmaLane dma_lane(int lane, int64_t row_bytes) {
+__device__ __forceinline__ DmaLane dma_lane(int lane, int64_t row_bytes, int hs) {
   using TM = TileMap<DP8, true>;
   const int lr = lane / TM::CPR;
-  return DmaLane{chunk_row(0, lr) * (int)row_bytes, 16 * ((lane % TM::CPR) ^ (lr & TM::SW))};
+  return DmaLane{chunk_row(0, lr, hs) * (int)row_bytes, 16 * ((lane % TM::CPR) ^ (lr & TM::SW))};
 }
 
 template <int DP8>
 __device__ __forceinline__ void corpus_tile_dma(const char* __restrict__ Cm, int64_t row_bytes, int64_t t, int64_t C,
-                                                float* Ys, int wave, const DmaLane& dl) {
+                                                float* Ys, int wave, const DmaLane& dl, int g7) {
   using TM = TileMap<DP8, true>;
   constexpr int RPI = 64 / TM::CPR;  // rows per wave instruction (1 KiB)
   constexpr int NI = CT / RPI / 4;   // instructions per wave
@@ -350,9 +353,11 @@ __device__ __forceinline__ void corpus_tile_dma(const char* __restrict__ Cm, int
 #if TT_MIPS_EXP & 16
   const int64_t chunk0 = ((t >> 1) & 63) * CHUNK, left = C - chunk0;  // measurement variant: the corpus "stream" stays in L2
 #else
-  const int64_t chunk0 = (t >> 1) * CHUNK, left = C - chunk0;
+  // g7: 256-row chunks, this tile pair is its first / second 64 rows of each lane half
+  const int64_t chunk0 = (t >> (1 + g7)) * (CHUNK << g7), left = C - chunk0;
 #endif
-  const int rows_here = left < CHUNK ? (int)left : CHUNK;
+  const int chunk_rows = CHUNK << g7, hs = 64 << g7, pair_rows = g7 ? 64 * (int)((t >> 1) & 1) : 0;
+  const int rows_here = left < chunk_rows ? (int)left : chunk_rows;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Cm + chunk0 * row_bytes), 0,
                                                                       rows_here * (int)row_bytes, 0x00020000);
   const int w = __builtin_amdgcn_readfirstlane(wave);
@@ -364,7 +369,7 @@ __device__ __forceinline__ void corpus_tile_dma(const char* __restrict__ Cm, int
     const int rbase = (w * NI + i) * RPI;
     const int voff = dl.vrow + (dl.vc ^ (16 * (rbase & TM::SW)));
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Ys + rbase * TM::DP), 16, voff,
-                                             chunk_row(par, rbase) * (int)row_bytes, 0, 0);
+                                             (chunk_row(par, rbase, hs) + pair_rows) * (int)row_bytes, 0, 0);
   }
 }
 
@@ -432,10 +437,11 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
   const int64_t row_bytes = p.D * O::ESZ;
 
   constexpr int NI = CT / (64 / TM::CPR) / 4;  // DMA instructions per wave per tile
-  const DmaLane dl = dma_lane<DPX>(lane, row_bytes);
+  const int g7 = SHARE ? 0 : (p.gshift == 7);  // 256-row chunks: lane-half h holds rows 128h .. 128h+127 of it (128-row groups)
+  const DmaLane dl = dma_lane<DPX>(lane, row_bytes, 64 << g7);
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
-    if (t0 + s < t1) corpus_tile_dma<DPX>(Cm, row_bytes, t0 + s, p.C, stage(s), wave, dl);
+    if (t0 + s < t1) corpus_tile_dma<DPX>(Cm, row_bytes, t0 + s, p.C, stage(s), wave, dl, g7);
   if (t0 + STAGES - 1 <= t1) wait_vmcnt<(STAGES - 2) * NI>();  // tile t0 has landed
   else wait_vmcnt<0>();
   __syncthreads();
@@ -453,6 +459,7 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
   // a finished chunk: lane-half h holds group 2*chunk + h.  Scalar base (chunk) + one 32-bit lane offset: no 64-bit
   // per-lane address arithmetic in the tile loop (the NQ = 4 kernel has no register to spare for it)
   const uint32_t nq32 = (uint32_t)p.nq, lane_q = (uint32_t)qbase, lane_off = (uint32_t)h * nq32 + lane_q;
+  constexpr int HALFPOS = QUADS ? 16 : 64;  // positions (quads / rows) per 64 rows
   auto store_chunk = [&](int64_t chunk) {
 #if TT_MIPS_EXP & 32
     const int64_t base = 2 * (chunk & 7) * p.nq;  // measurement variant: the result stores stay in L2
@@ -461,7 +468,9 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
 #endif
     uint32_t* const g1 = p.gmax + base;
     uint32_t* const g2 = p.gm2 + base;
-    const bool second_empty = (2 * chunk + 1) * GROUP >= p.C;  // only the corpus' last chunk (wave-uniform)
+    const bool second_empty = ((2 * chunk + 1) << p.gshift) >= p.C;  // only the corpus' last chunk (wave-uniform)
+    // 256-row chunks: positions found in the first tile pair were shifted down by HALFPOS when it ended (see step)
+    const int pos_base = g7 ? HALFPOS : 0;
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
 #if TT_MIPS_EXP & 8
@@ -472,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
         uint32_t best = __float_as_uint(m1[n]);
         if (second_empty && h) best = 0xFFFFFFFFu;
         __builtin_nontemporal_store(best, &g1[lane_off + 32u * n]);
-        __builtin_nontemporal_store((__float_as_uint(m2[n]) & ~63u) | (uint32_t)arg[n], &g2[lane_off + 32u * n]);
+        __builtin_nontemporal_store((__float_as_uint(m2[n]) & ~63u) | (uint32_t)(arg[n] + pos_base), &g2[lane_off + 32u * n]);
       }
       m1[n] = NEG_INF; m2[n] = NEG_INF; arg[n] = 0;
     }
@@ -480,14 +489,15 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
   auto step = [&](auto par_c, int64_t t, const float* ys, float* dst) {
     constexpr int PAR = decltype(par_c)::value;
     const bool more = t + STAGES - 1 < t1;
-    const int64_t chunk = t >> 1;
+    const int64_t chunk = t >> (1 + g7);       // 128-row chunk, or 256-row chunk (g7: two tile pairs)
+    const int pair = g7 ? (int)((t >> 1) & 1) : 0;  // which tile pair of a 256-row chunk
     // The previous chunk's results are stored HERE, in front of this step's tile DMA, not at the end of the step that
     // finished the chunk: the wait that ends a step counts outstanding vector-memory instructions of either kind, and
     // with the stores as the newest ones "all but 2 tiles' DMAs" also meant "wait for the tiles just requested and for
     // the stores' write acknowledgements" -- every second tile.
-    if (!SHARE && PAR == 0 && t > t0) store_chunk(chunk - 1);
-    if (more) corpus_tile_dma<DPX>(Cm, row_bytes, t + STAGES - 1, p.C, dst, wave, dl);
-    const bool full = (chunk + 1) * CHUNK <= p.C;
+    if (!SHARE && PAR == 0 && pair == 0 && t > t0) store_chunk(chunk - 1);
+    if (more) corpus_tile_dma<DPX>(Cm, row_bytes, t + STAGES - 1, p.C, dst, wave, dl, g7);
+    const bool full = (chunk + 1) * (CHUNK << g7) <= p.C;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
       if (SF == 4 && (2 * PAR + jt) != wave) continue;  // this sub-tile belongs to another wave
@@ -551,8 +561,8 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
 #endif
       auto rows_inside = [&]() {  // elements of this lane's 16 rows inside the corpus (last chunk only)
         // the 64-bit part is wave-uniform (scalar registers); per lane only a 32-bit subtract and clamp
-        const int64_t rows_left = p.C - chunk * CHUNK;
-        const int left = (rows_left < CHUNK ? (int)rows_left : CHUNK) - 64 * h - off0;
+        const int64_t rows_left = p.C - chunk * (CHUNK << g7);
+        const int left = (rows_left < (CHUNK << g7) ? (int)rows_left : (CHUNK << g7)) - (64 << g7) * h - 64 * pair - off0;
         return left < 0 ? 0 : left > 16 ? 16 : left;
       };
       if constexpr (QUADS) {
@@ -621,6 +631,12 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
         }
       }
     }
+    if (!SHARE && PAR && g7 && pair == 0) {
+      // end of the first tile pair of a 256-row chunk: the positions found so far move to -HALFPOS .. -1, so that the
+      // second pair can reuse the same compile-time positions 0 .. HALFPOS-1 (store_chunk adds HALFPOS back)
+#pragma unroll
+      for (int n = 0; n < NQ; ++n) arg[n] -= HALFPOS;
+    }
     if (SHARE && PAR) {
       // merge the four waves' partial triples of this chunk (sub-tiles in ascending row order, so
       // "strictly greater" keeps the earlier row on ties, like the sequential scan)
@@ -670,7 +686,7 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
       cur = (cur + 1) % STAGES;
     }
   }
-  if (!SHARE && t1 > t0) store_chunk((t1 - 1) >> 1);  // the last chunk (t1 - t0 is even: whole chunks)
+  if (!SHARE && t1 > t0) store_chunk((t1 - 1) >> (1 + g7));  // the last chunk (t1 - t0 is a whole number of chunks)
 }
 
 // ---------------------------------------------------------------- sparse pass 2
@@ -718,12 +734,12 @@ __global__ __launch_bounds__(256) void mips_sparse_kernel(const MipsArgs p) {
       const int pos = pos0 + __popcll(smask & lt_mask);
       if (!p.arg_quads) {
         if (single && pos < p.cap)
-          p.cand[ql * p.cap + pos] = ord_key(gmax_ord(p.gmax[at], 1), my_grp * GROUP + where);
+          p.cand[ql * p.cap + pos] = ord_key(gmax_ord(p.gmax[at], 1), (my_grp << p.gshift) + where);
       } else {
         // pass 1 kept the QUAD of the best item: score the quad's 4 rows again, 8 quads per MFMA tile (A-operand row
         // a = 4 * (quad in tile) + row in quad).  Accumulator element e of lane-half hh is A row (e & 3) + 8 * (e >> 2)
         // + 4 * hh, so lane (rr, hh) with rr < 4 finds the four scores of tile quad 2 * rr + hh in acc[4 rr .. 4 rr + 3].
-        const uint32_t my_row0 = single ? my_grp * GROUP + 4u * where : 0u;  // rows < 2^32 (checked by the entry point)
+        const uint32_t my_row0 = single ? (my_grp << p.gshift) + 4u * where : 0u;  // rows < 2^32 (checked by the entry point)
 #pragma unroll 1
         for (int j = 0; j < 8; ++j) {
           if (!((smask >> (8 * j)) & 0xFFull)) continue;  // wave-uniform: none of these eight groups is single
@@ -756,9 +772,9 @@ __global__ __launch_bounds__(256) void mips_sparse_kernel(const MipsArgs p) {
       const int src = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
       const uint32_t grp = (uint32_t)__shfl((int)my_grp, src, 64);
-      const int64_t row0 = (int64_t)grp * GROUP;
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt) {
+      const int64_t row0 = (int64_t)grp << p.gshift;
+      const int n_tiles = 1 << (p.gshift - 5);
+      for (int jt = 0; jt < n_tiles; ++jt) {
         int64_t arow = row0 + 32 * jt + r;
         if (arow >= p.C) arow = p.C - 1;  // past the end: any valid row, its scores are ignored
         const f32x16 acc = O::tile_at(base + arow * row_bytes + 16 * h, qf);
@@ -1242,6 +1258,10 @@ static bool plan_mips(int64_t B, int64_t C, int64_t D, int64_t K, int dtype, Mip
   pl.n_groups = 2 * pl.n_chunks;
   const int64_t sel = K < pl.n_groups ? K : pl.n_groups;
   pl.cap = sel * GROUP;
+  if (dtype == TT_BF16) {  // the bf16 LDS-DMA pass may use 128-row groups: room for K whole groups of those
+    const int64_t n7 = 2 * ceil_div(C, 2 * CHUNK), sel7 = K < n7 ? K : n7;
+    if (sel7 * 2 * GROUP > pl.cap) pl.cap = sel7 * 2 * GROUP;
+  }
   pl.qb = B < MIPS_QBATCH ? B : MIPS_QBATCH;
   const int64_t qblocks = ceil_div(pl.qb, QB_WG);
   int64_t splits = ceil_div(1024, qblocks);
@@ -1287,6 +1307,7 @@ static int launch_pass1_dma(MipsArgs a, int64_t, hipStream_t st) {
   int64_t splits = ceil_div(2048, xblocks);
   if (splits > a.n_chunks) splits = a.n_chunks;
   a.chunks_per_split = ceil_div(a.n_chunks, splits);
+  if (a.gshift == 7) a.chunks_per_split += a.chunks_per_split & 1;  // whole 256-row chunks per split
   splits = ceil_div(a.n_chunks, a.chunks_per_split);
   a.xblocks = xblocks;
   a.splits = splits;
@@ -1408,6 +1429,7 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
     a.gmax = gmax; a.tau = tau; a.cand = cand; a.count = count; a.cap = pl.cap; a.vec_ok = vec ? 1 : 0;
     a.glist = glist; a.lcount = lcount; a.K = K;
     a.gm2 = gm2;
+    a.gshift = 6;
     dim3 grid((unsigned)ceil_div(nq, QB_WG), (unsigned)pl.splits);
     mips_zero_kernel<<<(unsigned)ceil_div(nq, 256), 256, 0, st>>>(tau, count, lcount, scount, nq);
     if ((rc = check_launch("mips_zero_kernel"))) return rc;
@@ -1415,8 +1437,18 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
     static const bool no_sparse = getenv("TT_MIPS_NO_SPARSE") != nullptr;
     const int dp = pl.dpx * (dtype == TT_F32 ? 8 : 16);
     const bool sparse = pl.n_groups > K && vec && D == dp && !no_sparse && !wide;
+    static const bool no_dma = getenv("TT_MIPS_NO_DMA") != nullptr;
+    static const bool no_g128 = getenv("TT_MIPS_NO_G128") != nullptr;  // A/B: 64-row groups for bf16 too
+    // bf16 through the LDS-DMA pass 1 (not its shared-query forms) and the sparse pass 2: 256-row chunks, i.e. 128-row
+    // groups -- half the result bytes of pass 1 and half the groups for the selection, which reads gmax three times
+    const int64_t n_groups7 = 2 * ceil_div(C, 2 * CHUNK);
+    const bool g128 = dtype == TT_BF16 && sparse && !no_dma && pl.dpx >= 4 && nq > 64 && n_groups7 > K && !no_g128;
+    const int64_t n_groups = g128 ? n_groups7 : pl.n_groups;
+    if (g128) {
+      a.gshift = 7;
+      a.n_chunks = n_groups7;  // in 128-row units, even: whole 256-row chunks
+    }
     if (pl.n_groups > K) {  // otherwise tau = 0: every item is a candidate (cap == n_groups*64 >= C)
-      static const bool no_dma = getenv("TT_MIPS_NO_DMA") != nullptr;
       if (wide) {  // D > 128: dense pass from the library GEMM, group maxima only
         a.gm2 = nullptr;
         rc = mips_wide_pass(1, a, dtype, wide_ws, wide_bytes, pl.qb, st);
@@ -1437,10 +1469,10 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
       if ((rc = check_launch("mips_select_init_kernel"))) return rc;
       const int64_t qblocks = ceil_div(nq, SEL_Q);
       int64_t slices = ceil_div(2048, qblocks);
-      if (slices > ceil_div(pl.n_groups, 64)) slices = ceil_div(pl.n_groups, 64);
+      if (slices > ceil_div(n_groups, 64)) slices = ceil_div(n_groups, 64);
       if (slices < 1) slices = 1;
       for (int pass = 0; pass < 2; ++pass) {
-        mips_select_hist_kernel<<<dim3((unsigned)qblocks, (unsigned)slices), 256, 0, st>>>(gmax, a.raw_scores, pl.n_groups, nq, pass, tau, done, ghist);
+        mips_select_hist_kernel<<<dim3((unsigned)qblocks, (unsigned)slices), 256, 0, st>>>(gmax, a.raw_scores, n_groups, nq, pass, tau, done, ghist);
         if ((rc = check_launch("mips_select_hist_kernel"))) return rc;
         mips_select_pick_kernel<<<(unsigned)ceil_div(nq, 64), 64, 0, st>>>(ghist, nq, pass, tau, want, done);
         if ((rc = check_launch("mips_select_pick_kernel"))) return rc;
@@ -1448,10 +1480,10 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
       int32_t* gl = sparse ? glist : nullptr;
       // fewer, longer slices than the histogram passes: one counter reservation per workgroup, query and list
       int64_t split_slices = slices < 256 ? slices : 256;
-      if (split_slices * 8 * SPLIT_ITERS < pl.n_groups) split_slices = ceil_div(pl.n_groups, 8 * SPLIT_ITERS);  // match-bit capacity
-      mips_select_split_kernel<<<dim3((unsigned)qblocks, (unsigned)split_slices), 256, 0, st>>>(gmax, a.raw_scores, pl.n_groups, nq, tau, done, K, gl, lcount, surv, scount);
+      if (split_slices * 8 * SPLIT_ITERS < n_groups) split_slices = ceil_div(n_groups, 8 * SPLIT_ITERS);  // match-bit capacity
+      mips_select_split_kernel<<<dim3((unsigned)qblocks, (unsigned)split_slices), 256, 0, st>>>(gmax, a.raw_scores, n_groups, nq, tau, done, K, gl, lcount, surv, scount);
       if ((rc = check_launch("mips_select_split_kernel"))) return rc;
-      mips_select_finish_kernel<<<(unsigned)nq, 256, 0, st>>>(surv, scount, pl.n_groups, tau, want, done, K, gl, lcount);
+      mips_select_finish_kernel<<<(unsigned)nq, 256, 0, st>>>(surv, scount, n_groups, tau, want, done, K, gl, lcount);
       if ((rc = check_launch("mips_select_finish_kernel"))) return rc;
     }
     if (sparse) {
