@@ -4,6 +4,7 @@
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-$R/gpurun_out/mips_pmc}
 mkdir -p $OUT
+OUT=$(cd $OUT && pwd)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU \
   --kernel-trace --output-format csv -d $OUT/p1 -- python $R/tools/bench_mips.py > $OUT/p1.log 2>&1
@@ -16,7 +17,7 @@ import csv, glob, sys, collections
 acc = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "mips_pass1_dma_kernelILi1E" in r["Kernel_Name"]:  # bf16
+        if "mips_pass1_dma_kernel<1," in r["Kernel_Name"]:  # bf16
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(acc):
     v = acc[k]

@@ -2,9 +2,11 @@
 // whose [B, C] score matrix never reaches HBM, exact under the total order
 // (score desc, index asc).
 //
-// The corpus is cut into GROUPS of 64 consecutive rows.  Per batch of <= 1024 queries:
-//   pass 1   dense score GEMM; each lane reduces the scores of one group to their max and
-//            stores it:  gmax[group][query] (4 B, order-preserving integer)      (MFMA-bound)
+// The corpus is cut into GROUPS of 64 consecutive rows (128 for bf16 storage through the LDS-DMA pass with more than 64
+// queries: MipsArgs::gshift).  Per batch of <= 1024 queries:
+//   pass 1   dense score GEMM; each lane reduces the scores of one group to their max (the LDS-DMA form also to the
+//            runner-up and the position of the best) and stores it:  gmax[group][query], gm2[group][query]
+//            (4 B each; see gmax_ord for the two formats)                              (MFMA-bound)
 //   select   the K best groups of every query under (max score desc, group asc): MSD radix
 //            select of the K-th largest 64-bit group key (ord(max) << 32 | ~group) -> tau[q].
 //            Groups are contiguous row ranges, so this is the order of their best items, and
@@ -14,7 +16,9 @@
 //            query instead of C), one wavefront per (query, group), with the same MFMA
 //            instruction sequence as pass 1 (bit-identical scores; the query simply occupies
 //            all 32 B-operand columns).  Items whose (ord(score), ~group) >= tau[q] become
-//            candidates (64-bit keys ord(score) << 32 | ~row): at most 64*K, typically ~1.01 K.
+//            candidates (64-bit keys ord(score) << 32 | ~row): at most group*K, typically ~1.01 K.  Groups whose
+//            runner-up cannot reach tau[q] are not re-read whole: their best item is known (fp32: its row; bf16: its
+//            4-row quad, of which the 4 rows are scored again).
 //            The corpus rows are read straight from HBM (contiguous 16-32 KiB per group).
 //            Ragged / unaligned D and corpora with fewer than K groups take the dense pass 2
 //            (the pass-1 kernel with the candidate epilogue) instead.
@@ -77,14 +81,15 @@ __device__ __forceinline__ int chunk_row(int t2, int L, int hs = 64) {
 // What the LDS-DMA pass 1 stores per (group, query) -- RAW, so that its tile loop spends no VALU instruction on it (every
 // one is matrix-core time there); the readers, all memory-bound, decode:
 //   gmax word: the bits of the best score (0xFFFFFFFF: empty group)
-//   gm2 word : the bits of the runner-up with the low 6 bits replaced by the best item's position (its row 0..63 in the
-//              group, or its 4-row quad 0..15).  The runner-up is only ever used as an UPPER bound ("can a second item of
-//              this group reach tau?"): ord(bits with the low 6 cleared) | 63 >= ord(runner-up) for either sign.
+//   gm2 word : the bits of the runner-up with the low 7 bits replaced by the best item's position (its row in the
+//              group, or its 4-row quad).  The runner-up is only ever used as an UPPER bound ("can a second item of
+//              this group reach tau?"): ord(bits with the low 7 cleared) | 127 >= ord(runner-up) for either sign.
 // The generic pass 1 and the D > 128 form store score_ord values and no runner-up (raw = 0).
 __device__ __forceinline__ uint32_t gmax_ord(uint32_t v, int raw) {
   return raw ? (v == 0xFFFFFFFFu ? 0u : score_ord(__uint_as_float(v))) : v;
 }
-__device__ __forceinline__ uint32_t gm2_upper_ord(uint32_t v) { return score_ord(__uint_as_float(v & ~63u)) | 63u; }
+constexpr uint32_t POS_MASK = 127u;  // 7 bits: a row of a 128-row group at most
+__device__ __forceinline__ uint32_t gm2_upper_ord(uint32_t v) { return score_ord(__uint_as_float(v & ~POS_MASK)) | POS_MASK; }
 
 struct MipsArgs {
   const void* Q;       // [B, D] queries (fp32 or bf16)
@@ -394,7 +399,11 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 template <int DT, int DPX, int NQ, int STAGES, int SF>
 __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p) {
   constexpr bool SHARE = SF != 0;
+#ifdef TT_MIPS_ROWARG  // measurement variant (tools/mips_variants.sh): the row-exact epilogue for bf16 as well
+  constexpr bool QUADS = false;
+#else
   constexpr bool QUADS = DT == TT_BF16;  // the best item of a group is tracked per 4-row quad (see the epilogue)
+#endif
   static_assert(SF == 0 || SF == 2 || SF == 4, "shared-query form: waves per query block");
   using O = Op<DT, DPX>;
   using TM = TileMap<DPX, true>;  // row bytes = 32 * DPX for both dtypes
@@ -481,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
         uint32_t best = __float_as_uint(m1[n]);
         if (second_empty && h) best = 0xFFFFFFFFu;
         __builtin_nontemporal_store(best, &g1[lane_off + 32u * n]);
-        __builtin_nontemporal_store((__float_as_uint(m2[n]) & ~63u) | (uint32_t)(arg[n] + pos_base), &g2[lane_off + 32u * n]);
+        __builtin_nontemporal_store((__float_as_uint(m2[n]) & ~POS_MASK) | (uint32_t)(arg[n] + pos_base), &g2[lane_off + 32u * n]);
       }
       m1[n] = NEG_INF; m2[n] = NEG_INF; arg[n] = 0;
     }
@@ -723,7 +732,7 @@ __global__ __launch_bounds__(256) void mips_sparse_kernel(const MipsArgs p) {
     if (p.gm2 && valid) {
       at = (int64_t)my_grp * p.nq + ql;
       const uint32_t w2 = p.gm2[at];
-      where = w2 & 63u;
+      where = w2 & POS_MASK;
       single = ord_key(gm2_upper_ord(w2), my_grp) < tau;  // the runner-up cannot qualify
     }
     const u64 smask = __ballot(single);
@@ -1454,7 +1463,11 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
         rc = mips_wide_pass(1, a, dtype, wide_ws, wide_bytes, pl.qb, st);
       } else {
         rc = (vec && D == dp && !no_dma) ? dispatch_pass1_dma(dtype, pl.dpx, a, pl.splits, st) : -1;
+#ifdef TT_MIPS_ROWARG
+        a.arg_quads = 0;
+#else
         a.arg_quads = dtype == TT_BF16;  // what the DMA pass left in the gm2 words
+#endif
         a.raw_scores = 1;
         if (rc == -1) {  // generic pass 1 keeps the group maxima only, as score_ord values
           a.gm2 = nullptr;
