@@ -123,6 +123,40 @@ def test_bf16_128_row_groups_ties_and_tails(A, B, C, K):
     assert torch.equal(sc.cpu(), want_sc)
 
 
+def test_group_size_and_pass2_switches_give_identical_results(tmp_path):
+    """The A/B switches of the bf16 path (64- vs 128-row groups, every selected group re-scored instead of the
+    best-quad shortcut, dense instead of sparse pass 2) are read once per process: run the same search in a child
+    process per setting and compare indices and scores bit for bit with the default."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, 'tests/golden'); sys.path.insert(0, '.')\n"
+        "import fixture_gen as fg, two_tower_models_amd as A\n"
+        "C, D, B, K = 256 * 37 + 77, 128, 300, 60\n"
+        "corpus = torch.from_numpy(fg.bf16_round(fg.gaussianish((C, D), 31)))\n"
+        "q = torch.from_numpy(fg.bf16_round(fg.gaussianish((B, D), 32)))\n"
+        "m = A.BaselineMIPSModule(corpus_size=C, embedding_dim=D); m.corpus = corpus; m = m.to('cuda:0').use_bf16_storage()\n"
+        "idx, sc = m.search(q.to('cuda:0'), K)\n"
+        "np.savez(sys.argv[1], idx=idx.cpu().numpy(), sc=sc.cpu().numpy())\n")
+    outs = {}
+    for name, var in (("default", None), ("g64", "TT_MIPS_NO_G128"), ("no_top2", "TT_MIPS_NO_TOP2"),
+                      ("dense", "TT_MIPS_NO_SPARSE")):
+        env = dict(os.environ)
+        if var:
+            env[var] = "1"
+        out = str(tmp_path / f"{name}.npz")
+        r = subprocess.run([sys.executable, "-c", script, out], cwd=root, env=env, capture_output=True, text=True,
+                           timeout=600, stdin=subprocess.DEVNULL)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = np.load(out)
+    for name in ("g64", "no_top2", "dense"):
+        assert np.array_equal(outs[name]["idx"], outs["default"]["idx"]), name
+        assert np.array_equal(outs[name]["sc"], outs["default"]["sc"]), name
+
+
 def test_all_equal_scores_returns_lowest_indices(A):
     corpus = torch.ones(1000, 16)
     m = module_with(A, corpus)
