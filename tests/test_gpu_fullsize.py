@@ -310,14 +310,15 @@ def test_mips_10m_corpus_k1000_config5_size(T, bf16):
     assert torch.equal(idx2, idx[:2, :10]) and torch.equal(emb, m.corpus[idx2].float())
 
 
-@pytest.mark.parametrize("bf16", [False, True])
-def test_mips_10m_exact_arithmetic_corpus_bit_exact_order(T, bf16):
+@pytest.mark.parametrize("bf16,B", [(False, 8), (True, 8), (True, 72)])
+def test_mips_10m_exact_arithmetic_corpus_bit_exact_order(T, bf16, B):
     """C = 10 M with small-integer embeddings (dot products exact in fp32 under any summation order, lossless in
     bf16): indices and scores must equal the CPU oracle's (score desc, index asc) order BIT FOR BIT, ties
-    included (the index digits repeat every 65 536 rows, so equal scores are common)."""
+    included (the index digits repeat every 65 536 rows, so equal scores are common).  B = 8: the shared-query
+    form of pass 1 with 64-row groups; B = 72 (bf16): 256-row chunks / 128-row groups, the throughput form."""
     import two_tower_models_amd as A
     from oracle import cpu_ref as R
-    C_, D, B, K = 10_000_000, 128, 8, 1000
+    C_, D, K = 10_000_000, 128, 1000
     g = torch.Generator(device=DEV).manual_seed(17)
     corpus = torch.randint(-1, 2, (C_, D), device=DEV, generator=g, dtype=torch.int8).float()
     i = torch.arange(C_, device=DEV)
