@@ -220,6 +220,17 @@ def _timed_mips(device, lib, N, Cn=10_000_000, B=1024, K=1000, D=128, reps=3):
                                   "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4) if tf else None,
                                   "avg_launch_ms": round(ms.value / max(cnt.value, 1), 4), "launches": cnt.value,
                                   "algorithmic_flops_per_launch": 2.0 * B * Cn * D}}
+        # serving-size batch: back-to-back calls of 16 queries (the pass is the corpus stream there, not the matrix cores)
+        q16 = q[:16].contiguous()
+        m.search(q16, K)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            m.search(q16, K)
+        torch.cuda.synchronize()
+        dt16 = (time.perf_counter() - t0) / 10
+        out[name]["B16_ms_per_call"] = round(dt16 * 1e3, 3)
+        out[name]["B16_corpus_stream_GBps"] = round(Cn * D * (2 if name == "bf16" else 4) / dt16 / 1e9, 1)
     return out
 
 
