@@ -90,7 +90,13 @@ def test_mips_merge_kernel_and_world1_sharded_mips():
 MULTI_CFGS = {"d128": dict(n_users=300, n_items=500, D=128, F=8, B=128, H=2),
               "ragged": dict(n_users=53, n_items=71, D=40, F=20, B=24, H=2),
               # TwoTowerWithUserHistoryEncoder: 4 heads x dh 32 (MFMA attention), B*H = 240 history rows per rank
-              "hist": dict(n_users=211, n_items=307, D=128, F=8, B=40, H=6, model="hist")}
+              "hist": dict(n_users=211, n_items=307, D=128, F=8, B=40, H=6, model="hist"),
+              # a batch larger than either table (every row looked up several times, by several ranks), tables that do
+              # not divide by the world size, fused-tower width 64
+              "crowded": dict(n_users=37, n_items=29, D=64, F=5, B=96, H=3),
+              # history model with H = 50 (the BASELINE length: attention tiles padded to 64) and a table smaller than
+              # one rank's history list
+              "hist50": dict(n_users=90, n_items=131, D=128, F=8, B=24, H=50, model="hist")}
 MULTI_STEPS = 3
 
 
@@ -173,6 +179,8 @@ def _resolve_world(world, backend):
                          [(2, "d128", "gloo", "alltoall", "torch"), (3, "ragged", "gloo", "alltoall", "torch"),
                           (2, "hist", "gloo", "alltoall", "torch"), (2, "d128", "gloo", "allgather", "torch"),
                           (2, "hist", "gloo", "allgather", "torch"),
+                          (3, "crowded", "gloo", "alltoall", "torch"), (3, "crowded", "gloo", "allgather", "torch"),
+                          (2, "hist50", "gloo", "alltoall", "torch"), (3, "hist50", "gloo", "alltoall", "torch"),
                           # RCCL, one device per rank: skipped on the 1-GPU test boxes, run on any multi-GPU node
                           (2, "d128", "nccl", "alltoall", "torch"), ("all", "d128", "nccl", "alltoall", "torch"),
                           ("all", "ragged", "nccl", "alltoall", "torch"), (2, "hist", "nccl", "alltoall", "torch"),
