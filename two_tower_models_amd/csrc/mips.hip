@@ -1107,15 +1107,54 @@ __device__ __forceinline__ void sort_pass(Ptr a, Ptr b, int32_t n, int shift, in
   __syncthreads();
 }
 
+// The usual case (n <= 2048 candidates, ~1.01 K): a 256-thread bitonic sort in LDS.  Keys are distinct (the row index
+// is part of the key), so an unstable network gives the same order as the stable radix sort; 66 compare-exchange
+// stages of 4 pairs per thread at 2048 slots instead of ~6 radix passes by one wavefront (57 -> ~12 us per call:
+// the sort is on the critical path of every call, and a third of the latency of a serving-size batch after the score
+// pass).  Queries with more candidates than that (heavy ties) take mips_sort_emit_kernel.
+__global__ __launch_bounds__(256) void mips_sort_emit_small_kernel(const u64* __restrict__ cand, const int32_t* __restrict__ count,
+                                                                   int64_t cap, int64_t K, int64_t q0,
+                                                                   int64_t* __restrict__ idx_out, float* __restrict__ score_out,
+                                                                   int32_t* __restrict__ status) {
+  __shared__ u64 keys[SORT_LDS];
+  const int64_t ql = blockIdx.x;
+  int32_t n = count[ql];
+  if (n > SORT_LDS) return;  // the wave-per-query kernel sorts this query
+  if (n > cap) { n = (int32_t)cap; if (threadIdx.x == 0) atomicOr(status, 1); }  // cannot happen (bound proven in the passes)
+  if (n < K && threadIdx.x == 0) atomicOr(status, 2);
+  int slots = 64;
+  while (slots < n) slots <<= 1;  // power of two >= n (wave-uniform loop)
+  const u64* ga = cand + ql * cap;
+  for (int i = threadIdx.x; i < slots; i += 256) keys[i] = i < n ? ga[i] : 0ull;  // 0 sorts last (no real key is 0)
+  __syncthreads();
+  for (int k = 2; k <= slots; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (slots >> 1); t += 256) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+        const bool desc = (lo & k) == 0;  // descending overall: score desc, row asc (the row is stored inverted)
+        const u64 a = keys[lo], b = keys[hi];
+        if ((a < b) == desc) { keys[lo] = b; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  for (int64_t k = threadIdx.x; k < K; k += 256) {
+    const u64 key = (k < n) ? keys[k] : 0ull;
+    idx_out[(q0 + ql) * K + k] = (k < n) ? (int64_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) : (int64_t)-1;
+    score_out[(q0 + ql) * K + k] = (k < n) ? ord2f((uint32_t)(key >> 32)) : 0.f;
+  }
+}
+
 __global__ __launch_bounds__(64) void mips_sort_emit_kernel(u64* __restrict__ cand, u64* __restrict__ tmp,
                                                             const int32_t* __restrict__ count, int64_t cap, int64_t K,
                                                             int64_t q0, int64_t* __restrict__ idx_out,
-                                                            float* __restrict__ score_out, int32_t* __restrict__ status) {
+                                                            float* __restrict__ score_out, int32_t* __restrict__ status,
+                                                            int skip_small) {
   __shared__ int32_t base[256];
   __shared__ u64 lbuf[2][SORT_LDS];
   const int lane = threadIdx.x;
   const int64_t ql = blockIdx.x;
   int32_t n = count[ql];
+  if (skip_small && n <= SORT_LDS) return;  // mips_sort_emit_small_kernel has done this query
   if (n > cap) { n = (int32_t)cap; if (lane == 0) atomicOr(status, 1); }  // cannot happen (bound proven above)
   if (n < K && lane == 0) atomicOr(status, 2);
   u64* ga = cand + ql * cap;
@@ -1500,6 +1539,10 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
       if ((rc = check_launch("mips_select_init_kernel"))) return rc;
       const int64_t qblocks = ceil_div(nq, SEL_Q);
       int64_t slices = ceil_div(2048, qblocks);
+      // every slice adds its bins to the same few global counters of a query (in the first pass nearly all keys share
+      // one bin), and same-address atomics serialise: cap the slices of small batches (A/B: TT_MIPS_SEL_SLICES)
+      static const int64_t max_slices = getenv("TT_MIPS_SEL_SLICES") ? atoll(getenv("TT_MIPS_SEL_SLICES")) : 512;
+      if (slices > max_slices) slices = max_slices;
       if (slices > ceil_div(n_groups, 64)) slices = ceil_div(n_groups, 64);
       if (slices < 1) slices = 1;
       for (int pass = 0; pass < 2; ++pass) {
@@ -1528,7 +1571,9 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
     } else {
       if ((rc = dispatch_score<2>(dtype, pl.dpx, a, grid, st))) return rc;
     }
-    mips_sort_emit_kernel<<<(unsigned)nq, 64, 0, st>>>(cand, tmp, count, pl.cap, K, q0, idx_out, score_out, status);
+    mips_sort_emit_small_kernel<<<(unsigned)nq, 256, 0, st>>>(cand, count, pl.cap, K, q0, idx_out, score_out, status);
+    if ((rc = check_launch("mips_sort_emit_small_kernel"))) return rc;
+    mips_sort_emit_kernel<<<(unsigned)nq, 64, 0, st>>>(cand, tmp, count, pl.cap, K, q0, idx_out, score_out, status, 1);
     if ((rc = check_launch("mips_sort_emit_kernel"))) return rc;
   }
   return 0;
@@ -1555,6 +1600,6 @@ extern "C" int tt_mips_merge(const float* scores, const int64_t* idx, int64_t B,
   mips_merge_keys_kernel<<<(unsigned)ceil_div(B * n_cand, 256), 256, 0, st>>>(scores, idx, B, n_cand, cand, count);
   int rc = check_launch("mips_merge_keys_kernel");
   if (rc) return rc;
-  mips_sort_emit_kernel<<<(unsigned)B, 64, 0, st>>>(cand, tmp, count, n_cand, K, 0, idx_out, score_out, status);
+  mips_sort_emit_kernel<<<(unsigned)B, 64, 0, st>>>(cand, tmp, count, n_cand, K, 0, idx_out, score_out, status, 0);
   return check_launch("mips_sort_emit_kernel");
 }
