@@ -96,8 +96,18 @@ MULTI_CFGS = {"d128": dict(n_users=300, n_items=500, D=128, F=8, B=128, H=2),
               "crowded": dict(n_users=37, n_items=29, D=64, F=5, B=96, H=3),
               # history model with H = 50 (the BASELINE length: attention tiles padded to 64) and a table smaller than
               # one rank's history list
-              "hist50": dict(n_users=90, n_items=131, D=128, F=8, B=24, H=50, model="hist")}
+              "hist50": dict(n_users=90, n_items=131, D=128, F=8, B=24, H=50, model="hist"),
+              # an item table with fewer rows than ranks x rows-per-rank: the last rank owns NO item row (found by
+              # tools/fuzz_sharded.py: the lookups and the table Adam of an empty row block used to be rejected)
+              "empty_block": dict(n_users=338, n_items=9, D=64, F=20, B=33, H=1, model="hist")}
 MULTI_STEPS = 3
+
+
+def _cfg(name):
+    """A named case, or any configuration as "json:{...}" (tools/fuzz_sharded.py; the spawned ranks re-import this
+    module, so the configuration has to travel in the name)."""
+    import json
+    return json.loads(name[5:]) if name.startswith("json:") else MULTI_CFGS[name]
 
 
 def _multi_init(cfg):
@@ -139,7 +149,7 @@ def _multi_worker(rank, world, port, outdir, cfg_name, negatives, backend="gloo"
             sys.path.insert(0, p)
     import torch.distributed as dist
     from two_tower_models_amd import sharded
-    cfg = MULTI_CFGS[cfg_name]
+    cfg = _cfg(cfg_name)
     dense, ut, it = _multi_init(cfg)
     dev = _init_pg(backend, rank, world, port)
     try:
@@ -181,6 +191,7 @@ def _resolve_world(world, backend):
                           (2, "hist", "gloo", "allgather", "torch"),
                           (3, "crowded", "gloo", "alltoall", "torch"), (3, "crowded", "gloo", "allgather", "torch"),
                           (2, "hist50", "gloo", "alltoall", "torch"), (3, "hist50", "gloo", "alltoall", "torch"),
+                          (4, "empty_block", "gloo", "alltoall", "torch"), (4, "empty_block", "gloo", "allgather", "torch"),
                           # RCCL, one device per rank: skipped on the 1-GPU test boxes, run on any multi-GPU node
                           (2, "d128", "nccl", "alltoall", "torch"), ("all", "d128", "nccl", "alltoall", "torch"),
                           ("all", "ragged", "nccl", "alltoall", "torch"), (2, "hist", "nccl", "alltoall", "torch"),
@@ -188,13 +199,14 @@ def _resolve_world(world, backend):
                           # the C ABI's own collectives (tt_comm_*) instead of torch's process group
                           (2, "d128", "nccl", "alltoall", "native"), ("all", "hist", "nccl", "alltoall", "native"),
                           ("all", "d128", "nccl", "allgather", "native")])
-def test_multi_rank_hip_backend_equals_reference_on_concatenated_batch(world, cfg_name, backend, routing, transport):
+def test_multi_rank_hip_backend_equals_reference_on_concatenated_batch(world, cfg_name, backend, routing, transport,
+                                                                       outlier_frac=2e-3):
     import os
     import tempfile
     import torch.multiprocessing as mp
     from oracle import cpu_ref as R
     world = _resolve_world(world, backend)
-    cfg = MULTI_CFGS[cfg_name]
+    cfg = _cfg(cfg_name)
     outdir = tempfile.mkdtemp()
     mp.spawn(_multi_worker, args=(world, _free_port(), outdir, cfg_name, "global", backend, routing, transport),
              nprocs=world, join=True)
@@ -224,11 +236,13 @@ def test_multi_rank_hip_backend_equals_reference_on_concatenated_batch(world, cf
         named += [(k, v, params[k]) for k, v in res[r]["dense"].items()]
         for name, got, ref in named:
             err = (got - ref).abs()
+            if err.numel() == 0:  # a rank that owns no row of a table (fewer rows than ranks)
+                continue
             assert float(err.max()) <= 2.2e-3 * MULTI_STEPS, (name, r, float(err.max()))
             # zero true gradient, noise only: the item-side biases and the key third of every in_proj_bias
             noise_only = name in ("item_tower_arch.bias", "item_features_arch.2.bias") or name.endswith("in_proj_bias")
             if not noise_only:  # all but 0.2 % of the elements (at least one: a bias has 128-256 of them) within 5e-6
-                assert int((err > 5e-6).sum()) <= max(1, int(2e-3 * err.numel())), (name, r, int((err > 5e-6).sum()), err.numel())
+                assert int((err > 5e-6).sum()) <= max(1, int(outlier_frac * err.numel())), (name, r, int((err > 5e-6).sum()), err.numel())
         # replicas stay bit-identical
         assert all(torch.equal(v, res[0]["dense"][k]) for k, v in res[r]["dense"].items())
 

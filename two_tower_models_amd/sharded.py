@@ -254,6 +254,8 @@ class HipBackend:
         """out[i] = table[local[i]] for local[i] < n_local, a zero row for the sentinel."""
         out = self.empty(local.numel(), table.shape[1])
         N = self.N
+        if n_local <= 0:  # a rank that owns no row of this table (fewer rows than ranks): every id is the sentinel
+            return out.zero_()
         N.check(self.lib.tt_gather_rows(table.data_ptr(), n_local, table.shape[1], local.data_ptr(), local.numel(),
                                         out.data_ptr(), table.shape[1], None, N.stream()), "tt_gather_rows")
         return out
@@ -444,6 +446,8 @@ class HipBackend:
         kernels skip its run."""
         ops, N, lib = self.ops, self.N, self.lib
         n_rows, dim = n_local, W.shape[1]
+        if n_rows <= 0:  # this rank owns no row of the table (fewer rows than ranks): nothing to park, nothing to finish
+            return None, None, 0
         plan = ops.RowPlan([local_ids], n_rows + 1, slot=f"plan{W.data_ptr()}")
         key = W.data_ptr()
         need = lib.tt_adam_table_workspace_bytes(plan.n, dim)
@@ -483,6 +487,8 @@ class HipBackend:
     def adam_table_finish(self, W, M, V, hyper, state, grad_rows: torch.Tensor):
         N, lib = self.N, self.lib
         plan, side, n_rows = state
+        if plan is None:  # empty row block
+            return
         plan.attach([grad_rows])
         N.check(lib.tt_adam_table_finish(W.data_ptr(), M.data_ptr(), V.data_ptr(), n_rows, W.shape[1],
                                          hyper.data_ptr(), C.byref(plan.sources), plan.n, plan.sorted_ids.data_ptr(),
