@@ -18,7 +18,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t0, n, bad = time.time(), 0, 0
 while time.time() - t0 < budget:
-    D = int(rng.choice([32, 64, 128, 128, 128, 96, 256]))
+    D = int(rng.choice([32, 64, 128, 128, 128, 96, 256, 2, 8, 50, 100, 130, 33]))
     B = int(rng.choice([1, 7, 32, 33, 64, 65, 100, 128, 129, 300, 513, 1024, 1100]))
     C = int(rng.integers(200, 60000))
     K = int(rng.integers(1, min(C, 1500)))
