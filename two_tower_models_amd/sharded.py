@@ -979,8 +979,12 @@ class ShardedMIPS:
         q_all = all_gather_rows(query) if W > 1 else query
         n_local = self.corpus.shape[0]
         k_loc = min(k, n_local)
-        idx, sc = self.be.mips_topk(q_all, self.corpus, k_loc)  # [W*B, k_loc], local row numbers
-        idx = idx + self.row_offset
+        if k_loc > 0:
+            idx, sc = self.be.mips_topk(q_all, self.corpus, k_loc)  # [W*B, k_loc], local row numbers
+            idx = idx + self.row_offset
+        else:  # this rank's block is empty (fewer corpus rows than ranks x rows per rank): "no candidate" only
+            idx = torch.empty(q_all.shape[0], 0, dtype=torch.int64, device=q_all.device)
+            sc = torch.empty(q_all.shape[0], 0, dtype=torch.float32, device=q_all.device)
         if k_loc < k:  # a block smaller than K: pad with "no candidate"
             pad = k - k_loc
             idx = torch.cat([idx, idx.new_full((idx.shape[0], pad), -1)], dim=1)
