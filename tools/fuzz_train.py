@@ -27,7 +27,7 @@ while time.time() - t0 < budget:
     F = int(rng.integers(1, 40))
     B = int(rng.choice([1, 2, 3, 17, 64, 65, 127, 128, 200, 513, 1000]))
     NU, NI = int(rng.integers(2, 5000)), int(rng.integers(max(2, 2), 5000))
-    H = int(rng.choice([1, 3, 8, 20, 50, 64])) if kind != "base" else int(rng.integers(1, 6))
+    H = int(rng.choice([1, 3, 8, 20, 50, 64, 65, 100, 130])) if kind != "base" else int(rng.integers(1, 6))
     labels_2d = bool(rng.integers(0, 2))
     torch.manual_seed(1000 + n)
     mips = A.BaselineMIPSModule(corpus_size=16, embedding_dim=D)
