@@ -2,8 +2,8 @@
 // whose [B, C] score matrix never reaches HBM, exact under the total order
 // (score desc, index asc).
 //
-// The corpus is cut into GROUPS of 64 consecutive rows (128 for bf16 storage through the LDS-DMA pass with more than 64
-// queries: MipsArgs::gshift).  Per batch of <= 1024 queries:
+// The corpus is cut into GROUPS of 64 consecutive rows (128 through the LDS-DMA pass with more than 64 queries:
+// MipsArgs::gshift).  Per batch of <= 1024 queries:
 //   pass 1   dense score GEMM; each lane reduces the scores of one group to their max (the LDS-DMA form also to the
 //            runner-up and the position of the best) and stores it:  gmax[group][query], gm2[group][query]
 //            (4 B each; see gmax_ord for the two formats)                              (MFMA-bound)
@@ -1324,7 +1324,7 @@ static bool plan_mips(int64_t B, int64_t C, int64_t D, int64_t K, int dtype, Mip
   pl.n_groups = 2 * pl.n_chunks;
   const int64_t sel = K < pl.n_groups ? K : pl.n_groups;
   pl.cap = sel * GROUP;
-  if (dtype == TT_BF16) {  // the bf16 LDS-DMA pass may use 128-row groups: room for K whole groups of those
+  if (dtype == TT_BF16 || (dtype == TT_F32 && D >= 32)) {  // the LDS-DMA pass may use 128-row groups: room for K whole groups of those
     const int64_t n7 = 2 * ceil_div(C, 2 * CHUNK), sel7 = K < n7 ? K : n7;
     if (sel7 * 2 * GROUP > pl.cap) pl.cap = sel7 * 2 * GROUP;
   }
@@ -1505,10 +1505,10 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
     const bool sparse = pl.n_groups > K && vec && D == dp && !no_sparse && !wide;
     static const bool no_dma = getenv("TT_MIPS_NO_DMA") != nullptr;
     static const bool no_g128 = getenv("TT_MIPS_NO_G128") != nullptr;  // A/B: 64-row groups for bf16 too
-    // bf16 through the LDS-DMA pass 1 (not its shared-query forms) and the sparse pass 2: 256-row chunks, i.e. 128-row
+    // the LDS-DMA pass 1 (not its shared-query forms) with the sparse pass 2: 256-row chunks, i.e. 128-row
     // groups -- half the result bytes of pass 1 and half the groups for the selection, which reads gmax three times
     const int64_t n_groups7 = 2 * ceil_div(C, 2 * CHUNK);
-    const bool g128 = dtype == TT_BF16 && sparse && !no_dma && pl.dpx >= 4 && nq > 64 && n_groups7 > K && !no_g128;
+    const bool g128 = sparse && !no_dma && pl.dpx >= 4 && nq > 64 && n_groups7 > K && !no_g128;  // pl.dpx >= 4: every DMA form
     const int64_t n_groups = g128 ? n_groups7 : pl.n_groups;
     if (g128) {
       a.gshift = 7;
