@@ -104,7 +104,10 @@ int tt_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out,
  * (user tower) and :193-219 (item tower).  The forward also writes what the backward needs: h_out [B, hidden] (the ReLU
  * output) and tin_out [B, 2D] (the tower input).  tt_tower_bwd_data is the data side of their autograd:
  *   d_tin = dy W3;  d_emb = d_tin[:, :D] (embedding-row gradients);  d_f = d_tin[:, D:];  dh = (d_f W2) (.) [h > 0]
- * the weight / bias gradients are tt_gemm_tn_colsum_f32(dy, tin), (d_f, h), (dh, features).
+ * and tt_tower_bwd_weights the parameter side -- dW3 = dy^T tin, dW2 = d_f^T h, dW1 = dh^T features and the three
+ * bias sums (autograd of the nn.Linear layers of the same lines) -- in one product launch over 64-row blocks plus one
+ * deterministic reduce over the blocks' partials (`ws`: tt_tower_bwd_weights_workspace_bytes) instead of three
+ * tt_gemm_tn_colsum_f32 calls.
  * Shapes: hidden = 256, D = d_out in {32, 64, 128}, F <= 64, 16-B aligned rows (tt_tower_supported says);
  * anything else returns TT_E_UNSUPPORTED -- use tt_gather_rows + tt_gemm_f32. */
 int tt_tower_supported(int64_t D, int64_t F, int64_t hidden, int64_t d_out);
@@ -114,6 +117,11 @@ int tt_tower_fwd(const float* table, int64_t n_rows, const int64_t* ids, const f
                  int32_t* oob_flag, tt_stream_t stream);
 int tt_tower_bwd_data(const float* dy, int64_t ldy, int64_t B, int64_t D, int64_t hidden, const float* W2, const float* W3,
                       const float* h, float* d_emb, int64_t ld_demb, float* d_f, float* dh, tt_stream_t stream);
+int64_t tt_tower_bwd_weights_workspace_bytes(int64_t B, int64_t D, int64_t F, int64_t hidden);
+int tt_tower_bwd_weights(const float* dy, int64_t ldy, const float* tin, const float* d_f, const float* h, const float* dh,
+                         const float* feats, int64_t ldf, int64_t B, int64_t D, int64_t F, int64_t hidden, float* dW1,
+                         float* db1, float* dW2, float* db2, float* dW3, float* db3, void* ws, int64_t ws_bytes,
+                         tt_stream_t stream);
 
 /* ---------------------------------------------------------------- K5 in-batch softmax CE
  * Forward: S = U I^T is never written to memory.

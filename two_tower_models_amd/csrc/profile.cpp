@@ -25,7 +25,7 @@ Slot& slot_for(const char* name) {
 }
 void clear_all() {
   for (auto& s : g_slots)
-    for (auto& p : s.ev) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    for (auto& p : s.ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   g_slots.clear();
 }
 }  // namespace
@@ -37,14 +37,14 @@ ProfScope::ProfScope(const char* name, hipStream_t st) : st_(st), slot_(-1), idx
   Slot& s = slot_for(name);
   hipEvent_t a, b;
   if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-  hipEventRecord(a, st);
+  (void)hipEventRecord(a, st);
   s.ev.emplace_back(a, b);
   slot_ = (int)(&s - &g_slots[0]);
   idx_ = (int)s.ev.size() - 1;
 }
 ProfScope::~ProfScope() {
   if (slot_ < 0) return;
-  hipEventRecord(g_slots[slot_].ev[idx_].second, st_);
+  (void)hipEventRecord(g_slots[slot_].ev[idx_].second, st_);
 }
 }  // namespace tt
 

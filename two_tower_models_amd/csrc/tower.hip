@@ -247,6 +247,129 @@ __global__ __launch_bounds__(256) void tower_bwd_kernel(const TowerBwdArgs p) {
   }
 }
 
+// ---------------------------------------------------------------- weight gradients of one tower
+// dW3 = dy^T tin, dW2 = d_f^T h, dW1 = dh^T x and the three bias sums: reductions over the batch.  As three
+// tt_gemm_tn_colsum_f32 calls they were six launches per tower (split-K product + slab reduce each).  Here ONE launch
+// writes every 64-row block's partial of all six tensors (TN products on the matrix cores: the two operands of a
+// v_mfma_f32_32x32x2_f32 step are one LDS row pair of the dy / d_f tile and of the tin / h tile), and one reduce launch
+// adds the partials in block order (deterministic).  Layout of a partial (floats):
+//   dW3 [D][2D] | dW2 [D][256] | dW1 [256][F] | db3 [D] | db2 [D] | db1 [256]
+struct TowerWgradArgs {
+  const float* dy; int64_t ldy;
+  const float *tin, *d_f, *h, *dh, *feats;
+  int64_t ldf, F, B;
+  float* part;
+};
+
+template <int D>
+__host__ __device__ constexpr int64_t tw_part_floats(int64_t F) { return (int64_t)D * 2 * D + (int64_t)D * TW_HID + TW_HID * F + 2 * D + TW_HID; }
+
+// out[n0 + i][k0 + j] = sum_m A[m][n0 + i] * Bm[m][k0 + j] over the 64 rows of the tiles; one 32 x 32 tile per call
+template <int LDA, int LDB>
+__device__ __forceinline__ void tw_tn_tile(const float* At, const float* Bt, int n0, int k0, float* out, int ldo, int r, int h) {
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const float* a = At + h * LDA + n0 + r;
+  const float* b = Bt + h * LDB + k0 + r;
+#pragma unroll 8
+  for (int s = 0; s < TW_ROWS / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * s * LDA], b[2 * s * LDB], acc, 0, 0, 0);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) out[(n0 + (e & 3) + 8 * (e >> 2) + 4 * h) * ldo + k0 + r] = acc[e];
+}
+
+template <int DE8>
+__global__ __launch_bounds__(256) void tower_wgrad_kernel(const TowerWgradArgs p) {
+  constexpr int D = 8 * DE8, K3 = 2 * D;
+  extern __shared__ __attribute__((aligned(16))) float tw_smem[];
+  float* At = tw_smem;                   // [64][D]     dy, then d_f
+  float* Bt = At + TW_ROWS * D;          // [64][256]   tin (2D <= 256 columns used), then h, then dh
+  float* Xt = Bt + TW_ROWS * TW_HID;     // [64][F]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * TW_ROWS;
+  const int F = (int)p.F;
+  float* part = p.part + (int64_t)blockIdx.x * tw_part_floats<D>(F);
+  float* pW3 = part;
+  float* pW2 = pW3 + D * K3;
+  float* pW1 = pW2 + D * TW_HID;
+  float* pb3 = pW1 + TW_HID * F;
+  float* pb2 = pb3 + D;
+  float* pb1 = pb2 + D;
+  auto load = [&](float* dst, int ld_dst, const float* src, int64_t ld_src, int cols) {  // rows past B: zeros
+    const int c4 = cols / 4;
+    for (int i = threadIdx.x; i < TW_ROWS * c4; i += 256) {
+      const int m = i / c4, c = i - m * c4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + m < p.B) v = *reinterpret_cast<const float4*>(src + (row0 + m) * ld_src + 4 * c);
+      *reinterpret_cast<float4*>(dst + m * ld_dst + 4 * c) = v;
+    }
+  };
+  auto colsum = [&](const float* T, int ld, int cols, float* out) {
+    for (int c = threadIdx.x; c < cols; c += 256) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int m = 0; m < TW_ROWS; ++m) s += T[m * ld + c];
+      out[c] = s;
+    }
+  };
+  // ---- dW3 = dy^T tin, db3
+  load(At, D, p.dy, p.ldy, D);
+  load(Bt, TW_HID, p.tin, K3, K3);
+  __syncthreads();
+  for (int t = wave; t < (D / 32) * (K3 / 32); t += 4) tw_tn_tile<D, TW_HID>(At, Bt, 32 * (t / (K3 / 32)), 32 * (t % (K3 / 32)), pW3, K3, r, h);
+  colsum(At, D, D, pb3);
+  __syncthreads();
+  // ---- dW2 = d_f^T h, db2
+  load(At, D, p.d_f, D, D);
+  load(Bt, TW_HID, p.h, TW_HID, TW_HID);
+  __syncthreads();
+  for (int t = wave; t < (D / 32) * (TW_HID / 32); t += 4) tw_tn_tile<D, TW_HID>(At, Bt, 32 * (t / (TW_HID / 32)), 32 * (t % (TW_HID / 32)), pW2, TW_HID, r, h);
+  colsum(At, D, D, pb2);
+  __syncthreads();
+  // ---- dW1 = dh^T x, db1: K = F is small (8 at the BASELINE shapes): one hidden unit per thread
+  load(Bt, TW_HID, p.dh, TW_HID, TW_HID);
+  for (int i = threadIdx.x; i < TW_ROWS * F; i += 256) {
+    const int m = i / F, f = i - m * F;
+    Xt[i] = (row0 + m < p.B) ? p.feats[(row0 + m) * p.ldf + f] : 0.f;
+  }
+  __syncthreads();
+  {
+    const int u = threadIdx.x;  // 256 threads = 256 hidden units
+    float sb = 0.f;
+#pragma unroll 8
+    for (int m = 0; m < TW_ROWS; ++m) sb += Bt[m * TW_HID + u];
+    pb1[u] = sb;
+    for (int f = 0; f < F; ++f) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int m = 0; m < TW_ROWS; ++m) s = fmaf(Bt[m * TW_HID + u], Xt[m * F + f], s);
+      pW1[u * F + f] = s;
+    }
+  }
+}
+
+// out = sum over the blocks' partials, in block order; one thread per element of the six tensors
+__global__ __launch_bounds__(256) void tower_wgrad_reduce_kernel(const float* __restrict__ part, int n_blocks, int64_t part_floats,
+                                                                 int64_t n3, int64_t n2, int64_t n1, int64_t D, float* dW3,
+                                                                 float* dW2, float* dW1, float* db3, float* db2, float* db1) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= part_floats) return;
+  float s = 0.f;
+  for (int w = 0; w < n_blocks; ++w) s += part[(int64_t)w * part_floats + i];
+  int64_t j = i;
+  if (j < n3) { dW3[j] = s; return; }
+  j -= n3;
+  if (j < n2) { dW2[j] = s; return; }
+  j -= n2;
+  if (j < n1) { dW1[j] = s; return; }
+  j -= n1;
+  if (j < D) { db3[j] = s; return; }
+  j -= D;
+  if (j < D) { db2[j] = s; return; }
+  j -= D;
+  db1[j] = s;
+}
+
 static bool tower_shape_ok(int64_t D, int64_t F, int64_t hidden, int64_t d_out) {
   return hidden == TW_HID && d_out == D && (D == 32 || D == 64 || D == 128) && F >= 1 && F <= TW_FMAX;
 }
@@ -307,4 +430,45 @@ extern "C" int tt_tower_bwd_data(const float* dy, int64_t ldy, int64_t B, int64_
   else if (D == 64) tower_bwd_kernel<8><<<grid, 256, 0, st>>>(a);
   else tower_bwd_kernel<16><<<grid, 256, 0, st>>>(a);
   return check_launch("tower_bwd_kernel");
+}
+
+extern "C" int64_t tt_tower_bwd_weights_workspace_bytes(int64_t B, int64_t D, int64_t F, int64_t hidden) {
+  if (B <= 0 || !tower_shape_ok(D, F, hidden, D)) return 256;
+  const int64_t part = D * 2 * D + D * TW_HID + TW_HID * F + 2 * D + TW_HID;
+  return round_up(ceil_div(B, TW_ROWS) * part * (int64_t)sizeof(float), 256);
+}
+
+extern "C" int tt_tower_bwd_weights(const float* dy, int64_t ldy, const float* tin, const float* d_f, const float* h,
+                                    const float* dh, const float* feats, int64_t ldf, int64_t B, int64_t D, int64_t F,
+                                    int64_t hidden, float* dW1, float* db1, float* dW2, float* db2, float* dW3, float* db3,
+                                    void* ws, int64_t ws_bytes, tt_stream_t stream) {
+  if (!dy || !tin || !d_f || !h || !dh || !feats || !dW1 || !db1 || !dW2 || !db2 || !dW3 || !db3 || !ws)
+    return fail_arg("tt_tower_bwd_weights: null pointer");
+  if (B <= 0 || ldy < D || ldf < F) return fail_arg("tt_tower_bwd_weights: sizes");
+  if (!tower_shape_ok(D, F, hidden, D) || ldy % 4 || !al16p(dy) || !al16p(tin) || !al16p(d_f) || !al16p(h) || !al16p(dh)) {
+    set_error("tt_tower_bwd_weights: needs hidden = 256, D in {32, 64, 128}, F <= 64, 16-B aligned operands");
+    return TT_E_UNSUPPORTED;
+  }
+  if (ws_bytes < tt_tower_bwd_weights_workspace_bytes(B, D, F, hidden)) { set_error("tt_tower_bwd_weights: workspace"); return TT_E_WORKSPACE; }
+  TowerWgradArgs a{dy, ldy, tin, d_f, h, dh, feats, ldf, F, B, reinterpret_cast<float*>(ws)};
+  hipStream_t st = S(stream);
+  const unsigned grid = (unsigned)ceil_div(B, TW_ROWS);
+  const size_t lds = (size_t)(TW_ROWS * D + TW_ROWS * TW_HID + TW_ROWS * F) * sizeof(float);
+#define TT_TWG(E)                                                                                                        \
+  {                                                                                                                      \
+    if (lds > 64 * 1024) {                                                                                               \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tower_wgrad_kernel<E>),                          \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+      if (e != hipSuccess) { set_error("tower_wgrad_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
+    }                                                                                                                    \
+    tower_wgrad_kernel<E><<<grid, 256, lds, st>>>(a);                                                                    \
+  }
+  if (D == 32) TT_TWG(4) else if (D == 64) TT_TWG(8) else TT_TWG(16)
+#undef TT_TWG
+  int rc = check_launch("tower_wgrad_kernel");
+  if (rc) return rc;
+  const int64_t n3 = D * 2 * D, n2 = D * TW_HID, n1 = TW_HID * F, part = n3 + n2 + n1 + 2 * D + TW_HID;
+  tower_wgrad_reduce_kernel<<<(unsigned)ceil_div(part, 256), 256, 0, st>>>(reinterpret_cast<const float*>(ws), (int)grid, part, n3, n2,
+                                                                           n1, D, dW3, dW2, dW1, db3, db2, db1);
+  return check_launch("tower_wgrad_reduce_kernel");
 }

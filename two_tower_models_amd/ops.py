@@ -450,16 +450,46 @@ class FusedTower(_LookupFunction):
         N.check(N.load().tt_tower_bwd_data(dy.data_ptr(), dy.stride(0), B, D, Hd, W2.data_ptr(), W3.data_ptr(), h.data_ptr(),
                                            d_emb.data_ptr(), D, d_f.data_ptr(), dh.data_ptr(), N.stream()),
                 "tt_tower_bwd_data")
-        dW3 = torch.empty(W3.shape, dtype=torch.float32, device=dev)
-        _, db3 = gemm_tn_colsum(dy, tin, dW3)
-        dW2 = torch.empty(W2.shape, dtype=torch.float32, device=dev)
-        _, db2 = gemm_tn_colsum(d_f, h, dW2)
-        dW1 = torch.empty(Hd, F, dtype=torch.float32, device=dev)
-        _, db1 = gemm_tn_colsum(dh, feats, dW1)
+        dW1, db1, dW2, db2, dW3, db3 = tower_weight_grads(dy, tin, d_f, h, dh, feats)
         dweight = None
         if ctx.needs_input_grad[0]:
             dweight = _route_table_grad(w, ids.reshape(-1), d_emb, ctx.lookup_index)
         return dweight, None, None, dW1, db1, dW2, db2, dW3, db3
+
+
+_TOWER_WGRAD = os.environ.get("TT_TOWER_NO_WGRAD") is None  # A/B switch
+
+
+def tower_weight_grads(dy, tin, d_f, h, dh, feats, out=None):
+    """(dW1, db1, dW2, db2, dW3, db3) of one tower: dW3 = dy^T tin, dW2 = d_f^T h, dW1 = dh^T feats and the bias sums,
+    one product launch + one reduce (tt_tower_bwd_weights) instead of three tt_gemm_tn_colsum_f32 calls.
+    `out`: the six tensors to write into (contiguous), else they are allocated."""
+    dev = dy.device
+    B, D = dy.shape
+    Hd, F = h.shape[1], feats.shape[1]
+    if out is not None:
+        dW1, db1, dW2, db2, dW3, db3 = out
+    else:
+        dW3 = torch.empty(D, 2 * D, dtype=torch.float32, device=dev)
+        dW2 = torch.empty(D, Hd, dtype=torch.float32, device=dev)
+        dW1 = torch.empty(Hd, F, dtype=torch.float32, device=dev)
+        db3 = torch.empty(D, dtype=torch.float32, device=dev)
+        db2 = torch.empty(D, dtype=torch.float32, device=dev)
+        db1 = torch.empty(Hd, dtype=torch.float32, device=dev)
+    lib = N.load()
+    if (_TOWER_WGRAD and lib.tt_tower_supported(D, F, Hd, D) and dy.stride(1) == 1 and dy.stride(0) % 4 == 0 and feats.stride(1) == 1
+            and all(t.is_contiguous() for t in (tin, d_f, h, dh, dW1, db1, dW2, db2, dW3, db3))
+            and all(t.data_ptr() % 16 == 0 for t in (dy, tin, d_f, h, dh))):
+        wsp, wsn = _ws(dev, lib.tt_tower_bwd_weights_workspace_bytes(B, D, F, Hd), "tower_wgrad")
+        N.check(lib.tt_tower_bwd_weights(dy.data_ptr(), dy.stride(0), tin.data_ptr(), d_f.data_ptr(), h.data_ptr(), dh.data_ptr(),
+                                         feats.data_ptr(), feats.stride(0), B, D, F, Hd, dW1.data_ptr(), db1.data_ptr(),
+                                         dW2.data_ptr(), db2.data_ptr(), dW3.data_ptr(), db3.data_ptr(), wsp, wsn, N.stream()),
+                "tt_tower_bwd_weights")
+        return dW1, db1, dW2, db2, dW3, db3
+    gemm_tn_colsum(dy, tin, dW3, db=db3)
+    gemm_tn_colsum(d_f, h, dW2, db=db2)
+    gemm_tn_colsum(dh, feats, dW1, db=db1)
+    return dW1, db1, dW2, db2, dW3, db3
 
 
 _FUSED_DU = os.environ.get("TT_CE_NO_FUSED_DU") is None  # A/B switches (DESIGN.md 9)

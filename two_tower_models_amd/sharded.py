@@ -353,9 +353,7 @@ class HipBackend:
             N.check(self.lib.tt_tower_bwd_data(d_out.data_ptr(), d_out.stride(0), B, De, Hd, W2.data_ptr(), W3.data_ptr(),
                                                h.data_ptr(), d_emb.data_ptr(), De, d_f.data_ptr(), dh.data_ptr(), N.stream()),
                     "tt_tower_bwd_data")
-            ops.gemm_tn_colsum(d_out, f, gW3, db=gb3)
-            ops.gemm_tn_colsum(d_f, h, gW2, db=gb2)
-            ops.gemm_tn_colsum(dh, feats, gW1, db=gb1)
+            ops.tower_weight_grads(d_out, f, d_f, h, dh, feats.contiguous(), out=(gW1, gb1, gW2, gb2, gW3, gb3))
             return d_emb, None
         ops.gemm_tn_colsum(d_out, emb, gW3[:, :De], db=gb3)
         ops.gemm(N.TT_GEMM_TN, d_out, f, gW3[:, De:De + Dm], Do, Dm, B)
