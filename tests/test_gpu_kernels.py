@@ -482,6 +482,25 @@ def test_gemm_weights_stationary_path(T, layout, M, Nn, K):
     assert torch.allclose(out2.cpu().double(), want, atol=6e-6 * math.sqrt(K) * scale)
 
 
+@pytest.mark.parametrize("B,D,F", [(8192, 128, 8), (100, 128, 64), (333, 64, 20), (65, 32, 1), (1, 128, 33)])
+def test_tower_weight_gradients_kernel_vs_fp64(T, B, D, F):
+    """tt_tower_bwd_weights (block partials in one launch + one reduce) on its own: dW3 = dy^T tin, dW2 = d_f^T h,
+    dW1 = dh^T x and the three bias sums against float64 products, incl. a ragged last 64-row block, one row, F = 64;
+    and bit-identical from call to call (the reduce adds the partials in block order)."""
+    ops, N = T
+    g = torch.Generator().manual_seed(B * 7 + D)
+    dy, tin, d_f = torch.randn(B, D, generator=g), torch.randn(B, 2 * D, generator=g), torch.randn(B, D, generator=g)
+    h, dh, x = torch.randn(B, 256, generator=g).relu(), torch.randn(B, 256, generator=g), torch.randn(B, F, generator=g)
+    dev = [t.to(DEV) for t in (dy, tin, d_f, h, dh, x)]
+    got = ops.tower_weight_grads(*dev)
+    again = ops.tower_weight_grads(*dev)
+    want = ((dh.double().t() @ x.double()), dh.double().sum(0), (d_f.double().t() @ h.double()), d_f.double().sum(0),
+            (dy.double().t() @ tin.double()), dy.double().sum(0))
+    for a, b, w in zip(got, again, want):
+        assert torch.equal(a, b)
+        assert torch.allclose(a.cpu().double(), w, rtol=1e-5, atol=2e-5 * math.sqrt(B))
+
+
 @pytest.mark.parametrize("B,D,F,n_rows", [(8192, 128, 8, 100_000), (100, 128, 8, 50), (333, 64, 20, 1000), (64, 32, 8, 200),
                                           (1, 128, 33, 7)])
 def test_fused_tower_matches_oracle_forward_and_backward(T, B, D, F, n_rows):
