@@ -85,6 +85,32 @@ def test_gemm_tn_with_fused_column_sum(T, rows, n_out, k_in):
     assert torch.equal(db, db2)
 
 
+@pytest.mark.parametrize("rows,n_out", [(204800, 384), (50001, 384), (16400, 384), (8195, 384), (8192, 384),
+                                        (50001, 256), (16400, 128)])
+def test_gemm_tn_streaming_path(T, rows, n_out):
+    """K >= 8192 rows, N = 128, M = 384 (M = 128 / 256 with TT_GEMM_TN_STREAM_ALL=1, else the tiled kernel):
+    the register-resident streaming TN kernel (gemm_tn_stream.hip) -- ragged and odd row counts, strided
+    operands, accumulate, determinism."""
+    ops, N = T
+    dy_full, x_full = g((rows, n_out + 8), 311), g((rows, 132), 312)
+    dy, x = dy_full[:, 4:4 + n_out], x_full[:, :128]
+    dyd, xd = dy_full.to(DEV)[:, 4:4 + n_out], x_full.to(DEV)[:, :128]
+    ref_w = dy.double().t() @ x.double()
+    ref_b = dy.double().sum(0)
+    base = g((n_out, 128), 313)
+    dW = base.to(DEV).clone()
+    _, db = ops.gemm_tn_colsum(dyd, xd, dW, accumulate=True)
+    tol = 3e-6 * math.sqrt(rows)
+    assert float((dW.cpu().double() - ref_w - base.double()).abs().max()) < tol * max(1.0, float(ref_w.abs().max()))
+    assert float((db.cpu().double() - ref_b).abs().max()) < tol * max(1.0, float(ref_b.abs().max()))
+    dW2 = torch.empty(n_out, 128, device=DEV)
+    _, db2 = ops.gemm_tn_colsum(dyd, xd, dW2)
+    dW3 = torch.empty(n_out, 128, device=DEV)
+    ops.gemm(N.TT_GEMM_TN, dyd, xd, dW3, n_out, 128, rows)
+    assert torch.equal(dW2, dW3) and torch.equal(db, db2)
+    assert float((dW2.cpu().double() - ref_w).abs().max()) < tol * max(1.0, float(ref_w.abs().max()))
+
+
 def test_colsum(T):
     ops, N = T
     X = g((1000, 300), 9)

@@ -388,6 +388,10 @@ static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 int gemm_ws_try(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W,
                 int64_t ldw, float* C, int64_t ldc, const float* bias, int epilogue, const float* aux,
                 int64_t ldaux, int accumulate, hipStream_t st);
+// huge-K TN products with a register-resident result (gemm_tn_stream.hip); -100 = "not applicable"
+int64_t gemm_tn_stream_ws_floats(int64_t M, int64_t N, int64_t K);
+int gemm_tn_stream_try(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                       float* C, int64_t ldc, int accumulate, float* a_colsum, void* ws, int64_t ws_bytes, hipStream_t st);
 
 }  // namespace tt
 
@@ -398,7 +402,9 @@ extern "C" int64_t tt_gemm_workspace_bytes(int layout, int64_t M, int64_t N, int
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const GemmPlan p = plan_gemm(M, N, K);
   // split-K slabs + (tt_gemm_tn_colsum_f32) one row of column-sum partials per split
-  return p.splits > 1 ? round_up((int64_t)p.splits * M * (N + 1) * (int64_t)sizeof(float), 256) : 0;
+  const int64_t generic = p.splits > 1 ? round_up((int64_t)p.splits * M * (N + 1) * (int64_t)sizeof(float), 256) : 0;
+  const int64_t stream = layout == TT_GEMM_TN ? round_up(gemm_tn_stream_ws_floats(M, N, K) * (int64_t)sizeof(float), 256) : 0;
+  return generic > stream ? generic : stream;
 }
 
 static int gemm_impl(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
@@ -413,6 +419,10 @@ static int gemm_impl(int layout, int64_t M, int64_t N, int64_t K, const float* A
   const bool a_kc = layout != TT_GEMM_TN, b_kc = layout == TT_GEMM_NT;
   if (lda < (a_kc ? K : M) || ldb < (b_kc ? K : N)) return fail_arg("tt_gemm_f32: leading dimension");
 
+  if (layout == TT_GEMM_TN && !bias && epilogue == TT_EPI_NONE) {
+    const int rc_st = gemm_tn_stream_try(M, N, K, A, lda, B, ldb, C, ldc, accumulate, a_colsum, ws, ws_bytes, S(stream));
+    if (rc_st != -100) return rc_st;
+  }
   if (!a_colsum) {
     const int rc_ws = gemm_ws_try(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, aux, ldaux, accumulate, S(stream));
     if (rc_ws != -100) return rc_ws;
