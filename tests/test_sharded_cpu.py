@@ -71,7 +71,14 @@ def _worker(rank, world, port, outdir, negatives, routing="alltoall"):
             batches[1][0].fill_(int(batches[1][0][0]))
             batches[1][3].copy_(batches[1][3] % max(tr.items.rows_per_rank, 1))
         # routes of the next batch are planned one step ahead, except for the last one (planned on the spot)
-        losses = [float(tr.step(b, batches[i + 1] if i + 2 < len(batches) else None)) for i, b in enumerate(batches)]
+        losses = []
+        for i, b in enumerate(batches):
+            losses.append(float(tr.step(b, batches[i + 1] if i + 2 < len(batches) else None)))
+            if i == 0 and routing == "alltoall":
+                # a static input buffer REFILLED IN PLACE after it was announced: same storage, new ids.  The
+                # planned routes must not be applied to them (they were counted for the old ids).
+                batches[1][0].copy_(torch.roll(batches[1][0], 3) if rank else batches[1][0].flip(0))
+                batches[1][3].copy_((batches[1][3] * 7 + 3) % CFG["n_items"])
         torch.save({"losses": losses, "users": tr.users.weight.clone(), "items": tr.items.weight.clone(),
                     "lo_hi": (tr.users.lo, tr.users.hi, tr.items.lo, tr.items.hi),
                     "dense": {k: v.clone() for k, v in tr.params.items()}, "comm": dict(tr.comm_bytes),

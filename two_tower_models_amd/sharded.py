@@ -745,7 +745,9 @@ class ShardedTrainer:
 
     @staticmethod
     def _route_key(batch):
-        return tuple((t.data_ptr(), t.numel()) for t in (batch[0], batch[2], batch[3]))
+        # storage, size AND torch's in-place version counter: a static input buffer refilled with copy_() between
+        # the announcement and the step keeps its address but not its version, and is planned again
+        return tuple((t.data_ptr(), t.numel(), t._version) for t in (batch[0], batch[2], batch[3]))
 
     def plan_routes(self, batch) -> _PlannedRoutes:
         """Sort each lookup's ids by owner and start the all-reduce (MAX) of the bucket maxima + its copy to
@@ -755,8 +757,11 @@ class ShardedTrainer:
         counts = torch.zeros(len(specs), dtype=torch.int32, device=self.device)
         planned, keep = [], []
         for k, (table, ids) in enumerate(specs):
-            if ids.dtype != torch.int64 or not ids.is_contiguous():
-                ids = ids.to(torch.int64).contiguous()
+            # a private copy: route_build ranks THESE ids against the bucket offsets counted here, whatever happens
+            # to the caller's tensor in between (a writer torch does not see -- a prefetcher's raw memcpy -- would
+            # otherwise put two ids into one send slot without tripping the overflow flag)
+            ids = ids.to(torch.int64).contiguous().clone() if ids.dtype == torch.int64 and ids.is_contiguous() \
+                else ids.to(torch.int64).contiguous()
             keep.append(ids)
             planned.append(self.be.route_plan(ids, table.n_rows, table.rows_per_rank, self.W, counts[k:k + 1]))
         if self.W > 1:
