@@ -403,7 +403,8 @@ int tt_route_localize(const int64_t* ids, int64_t n_ids, int64_t lo, int64_t n_l
  * with tt_comm_unique_id and hands to the other ranks by any host-side channel.  The handle is the ONLY
  * long-lived native state of this library.  RCCL is bound at run time (librccl.so.1; TT_RCCL_PATH overrides):
  * without it these return TT_E_UNSUPPORTED and everything else keeps working.  RCCL failures return
- * -(100 + ncclResult_t).  All calls are asynchronous on `stream`; counts are in ELEMENTS of `dtype`.
+ * -(100 + ncclResult_t).  All calls are asynchronous on `stream`; counts are in ELEMENTS of `dtype`; a count
+ * of 0 is a no-op that succeeds (pointers may then be null), as an empty tensor is for torch.distributed.
  *   tt_comm_alltoall       chunk r of `send` (count_per_peer elements) goes to rank r; chunk r of `recv` came
  *                          from rank r -- routed lookups: ids, rows, row gradients (R1)
  *   tt_comm_allgather      item embeddings for the global in-batch negatives (R2)

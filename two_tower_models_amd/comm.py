@@ -61,9 +61,17 @@ class NativeComm:
         return cls(bytes(t.cpu().tolist()), rank, world, device)
 
     def close(self) -> None:
+        """Destroy the RCCL communicator.  Called by ShardedTrainer.close() / at interpreter exit (registered
+        by `sharded.use_native_transport`), i.e. BEFORE torch.distributed's process group goes away."""
         if self._h is not None:
-            N.check(self.lib.tt_comm_destroy(self._h), "tt_comm_destroy")
-            self._h = None
+            h, self._h = self._h, None
+            N.check(self.lib.tt_comm_destroy(h), "tt_comm_destroy")
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def size(self):
         """(rank, world) -- world as RCCL itself reports it."""

@@ -594,8 +594,9 @@ static int device_cu_count() {
   return cached[dev];
 }
 
+// n_wgs > 0: upper limit of persistent workgroups (the caller's sweep throttle; 0 = TT_SWEEP_PERSIST per CU)
 static int launch_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
-                        hipStream_t st) {
+                        hipStream_t st, int n_wgs = 0) {
   int rc;
   const int64_t total = n_rows * dim;
   const bool vec = ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(M) | reinterpret_cast<uintptr_t>(V)) & 15) == 0;
@@ -613,7 +614,8 @@ static int launch_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t di
     if (persist > 0) {
       // hyper[7] is the library's scratch slot: two 32-bit chunk counters, zero between launches
       unsigned* ctr = reinterpret_cast<unsigned*>(const_cast<double*>(hyper) + 7);
-      const unsigned grid = (unsigned)(device_cu_count() * persist);
+      unsigned grid = (unsigned)(device_cu_count() * persist);
+      if (n_wgs > 0 && (unsigned)n_wgs < grid) grid = (unsigned)n_wgs;
       static const bool nt = !(getenv("TT_SWEEP_NT") && atoi(getenv("TT_SWEEP_NT")) == 0);  // A/B switch, default on
       static const int prio = getenv("TT_SWEEP_PRIO") ? atoi(getenv("TT_SWEEP_PRIO")) : 0;
       if (nt) adam_sweep_persistent_kernel<4, 4, true><<<grid, 256, 0, st>>>(w4, m4, v4, n4, hyper, ctr, prio);
@@ -726,16 +728,16 @@ extern "C" int tt_adam_tables_sweep(const tt_adam_tensor* tables, int32_t n_tabl
   }
   tabs.first_chunk[n_tables] = chunks;
   tabs.n = n_tables;
-  if (!fused) {
+  static const int wgs_env = getenv("TT_SWEEP_WGS") ? atoi(getenv("TT_SWEEP_WGS")) : 0;  // A/B: absolute workgroup count
+  const int want = getenv("TT_SWEEP_WGS") ? wgs_env : n_wgs;  // the A/B switch wins over the caller's choice
+  if (!fused) {  // one table (a rank that owns rows of one table only) or unaligned tables: per-table launches, same throttle
     for (int t = 0; t < n_tables; ++t) {
-      const int rc = launch_sweep(tables[t].p, tables[t].m, tables[t].v, tables[t].n, 1, hyper, st);
+      const int rc = launch_sweep(tables[t].p, tables[t].m, tables[t].v, tables[t].n, 1, hyper, st, want);
       if (rc) return rc;
     }
     return 0;
   }
   unsigned* ctr = reinterpret_cast<unsigned*>(const_cast<double*>(hyper) + 7);
-  static const int wgs_env = getenv("TT_SWEEP_WGS") ? atoi(getenv("TT_SWEEP_WGS")) : 0;  // A/B: absolute workgroup count
-  const int want = getenv("TT_SWEEP_WGS") ? wgs_env : n_wgs;  // the A/B switch wins over the caller's choice
   unsigned grid = (unsigned)(device_cu_count() * persist);
   if (want > 0 && (unsigned)want < grid) grid = (unsigned)want;
   ProfScope prof("adam_sweep_kernel", st);

@@ -77,10 +77,16 @@ static int64_t wide_chunk_rows(int64_t M, int64_t N) {
 
 int64_t ce_wide_workspace_bytes(int64_t M, int64_t N, int64_t D) {
   const int64_t mc = wide_chunk_rows(M, N);
-  int64_t g = tt_gemm_workspace_bytes(TT_GEMM_NT, mc, N, D);
-  const int64_t g2 = tt_gemm_workspace_bytes(TT_GEMM_NN, mc, D, N), g3 = tt_gemm_workspace_bytes(TT_GEMM_TN, N, D, mc);
-  if (g2 > g) g = g2;
-  if (g3 > g) g = g3;
+  // the GEMM scratch for BOTH chunk sizes that occur: a short ragged last chunk (M % mc rows) has fewer tiles,
+  // so the split-K planner may give it MORE splits -- and more scratch -- than the full chunk
+  int64_t g = 0;
+  const int64_t sizes[2] = {mc, M % mc};
+  for (int64_t rows : sizes) {
+    if (rows <= 0) continue;
+    const int64_t cand[3] = {tt_gemm_workspace_bytes(TT_GEMM_NT, rows, N, D), tt_gemm_workspace_bytes(TT_GEMM_NN, rows, D, N),
+                             tt_gemm_workspace_bytes(TT_GEMM_TN, N, D, rows)};
+    for (int64_t c : cand) if (c > g) g = c;
+  }
   return round_up(mc * N * 4, 256) + round_up(g, 256);
 }
 

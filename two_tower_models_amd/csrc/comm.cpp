@@ -142,21 +142,23 @@ extern "C" int tt_comm_size(tt_comm_t comm, int32_t* rank_out, int32_t* world_ou
 
 extern "C" int tt_comm_allgather(tt_comm_t comm, const void* send, void* recv, int64_t count_per_rank, int dtype,
                                  tt_stream_t stream) {
-  if (!comm || !send || !recv) return fail_arg("tt_comm_allgather: null pointer");
+  if (!comm || (count_per_rank != 0 && (!send || !recv))) return fail_arg("tt_comm_allgather: null pointer");
   ncclDataType_t dt;
   int64_t sz;
-  if (count_per_rank <= 0 || !dtype_of(dtype, dt, sz)) return fail_arg("tt_comm_allgather: count / dtype");
+  if (count_per_rank < 0 || !dtype_of(dtype, dt, sz)) return fail_arg("tt_comm_allgather: count / dtype");
+  if (count_per_rank == 0) return 0;  // an empty exchange is a no-op, as in torch.distributed
   Comm* c = reinterpret_cast<Comm*>(comm);
   return rc_of(g_rccl.AllGather(send, recv, (size_t)count_per_rank, dt, c->comm, S(stream)), "ncclAllGather");
 }
 
 extern "C" int tt_comm_reduce_scatter(tt_comm_t comm, const void* send, void* recv, int64_t count_per_rank, int dtype,
                                       int op, tt_stream_t stream) {
-  if (!comm || !send || !recv) return fail_arg("tt_comm_reduce_scatter: null pointer");
+  if (!comm || (count_per_rank != 0 && (!send || !recv))) return fail_arg("tt_comm_reduce_scatter: null pointer");
   ncclDataType_t dt;
   int64_t sz;
-  if (count_per_rank <= 0 || !dtype_of(dtype, dt, sz) || (op != TT_COMM_SUM && op != TT_COMM_MAX))
+  if (count_per_rank < 0 || !dtype_of(dtype, dt, sz) || (op != TT_COMM_SUM && op != TT_COMM_MAX))
     return fail_arg("tt_comm_reduce_scatter: count / dtype / op");
+  if (count_per_rank == 0) return 0;
   Comm* c = reinterpret_cast<Comm*>(comm);
   return rc_of(g_rccl.ReduceScatter(send, recv, (size_t)count_per_rank, dt, op == TT_COMM_MAX ? ncclMax : ncclSum, c->comm,
                                     S(stream)), "ncclReduceScatter");
@@ -164,9 +166,10 @@ extern "C" int tt_comm_reduce_scatter(tt_comm_t comm, const void* send, void* re
 
 extern "C" int tt_comm_allreduce(tt_comm_t comm, const void* send, void* recv, int64_t count, int dtype, int op,
                                  tt_stream_t stream) {
-  if (!comm || !send || !recv) return fail_arg("tt_comm_allreduce: null pointer");
+  if (!comm || (count != 0 && (!send || !recv))) return fail_arg("tt_comm_allreduce: null pointer");
   ncclDataType_t dt;
   int64_t sz;
+  if (count == 0 && dtype_of(dtype, dt, sz) && (op == TT_COMM_SUM || op == TT_COMM_MAX)) return 0;
   if (count <= 0 || !dtype_of(dtype, dt, sz) || (op != TT_COMM_SUM && op != TT_COMM_MAX))
     return fail_arg("tt_comm_allreduce: count / dtype / op");
   Comm* c = reinterpret_cast<Comm*>(comm);
@@ -176,20 +179,22 @@ extern "C" int tt_comm_allreduce(tt_comm_t comm, const void* send, void* recv, i
 
 extern "C" int tt_comm_alltoall(tt_comm_t comm, const void* send, void* recv, int64_t count_per_peer, int dtype,
                                 tt_stream_t stream) {
-  if (!comm || !send || !recv) return fail_arg("tt_comm_alltoall: null pointer");
+  if (!comm || (count_per_peer != 0 && (!send || !recv))) return fail_arg("tt_comm_alltoall: null pointer");
   if (send == recv) return fail_arg("tt_comm_alltoall: in-place exchange is not supported");
   ncclDataType_t dt;
   int64_t sz;
-  if (count_per_peer <= 0 || !dtype_of(dtype, dt, sz)) return fail_arg("tt_comm_alltoall: count / dtype");
+  if (count_per_peer < 0 || !dtype_of(dtype, dt, sz)) return fail_arg("tt_comm_alltoall: count / dtype");
+  if (count_per_peer == 0) return 0;
   Comm* c = reinterpret_cast<Comm*>(comm);
   return rc_of(g_rccl.AllToAll(send, recv, (size_t)count_per_peer, dt, c->comm, S(stream)), "ncclAllToAll");
 }
 
 extern "C" int tt_comm_broadcast(tt_comm_t comm, void* buf, int64_t count, int dtype, int32_t root, tt_stream_t stream) {
-  if (!comm || !buf) return fail_arg("tt_comm_broadcast: null pointer");
+  if (!comm || (count != 0 && !buf)) return fail_arg("tt_comm_broadcast: null pointer");
   ncclDataType_t dt;
   int64_t sz;
   Comm* c = reinterpret_cast<Comm*>(comm);
-  if (count <= 0 || !dtype_of(dtype, dt, sz) || root < 0 || root >= c->world) return fail_arg("tt_comm_broadcast: count / dtype / root");
+  if (count < 0 || !dtype_of(dtype, dt, sz) || root < 0 || root >= c->world) return fail_arg("tt_comm_broadcast: count / dtype / root");
+  if (count == 0) return 0;
   return rc_of(g_rccl.Broadcast(buf, buf, (size_t)count, dt, root, c->comm, S(stream)), "ncclBroadcast");
 }

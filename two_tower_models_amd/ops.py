@@ -188,17 +188,27 @@ class ActiveStash:
     (tt_adam_table_stash_ids).  While it is attached to a table (`weight._tt_active`), lookups
     read from here: the zero-gradient sweep may already be rewriting the table itself."""
 
-    _positions = {}  # (device index, n) -> arange(n): the same few sizes every step
+    _positions = {}  # (concrete device index, n) -> arange(n): the same few sizes every step
+
+    @staticmethod
+    def positions_for(device: torch.device, n: int) -> torch.Tensor:
+        """arange(n) on `device`, cached per CONCRETE device index (torch.device('cuda') carries None: two devices
+        of one process must not share an entry) and bounded.  An entry is never created while a hipGraph is being
+        captured: its contents would exist only once that graph is replayed, yet eager code would read it."""
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        key = (idx, int(n))
+        pos = ActiveStash._positions.get(key)
+        if pos is None:
+            if torch.cuda.is_current_stream_capturing():
+                return torch.arange(n, dtype=torch.int64, device=device)  # part of the graph, not of the cache
+            if len(ActiveStash._positions) > 64:
+                ActiveStash._positions.clear()
+            pos = ActiveStash._positions[key] = torch.arange(n, dtype=torch.int64, device=device)
+        return pos
 
     def __init__(self, p_plane: torch.Tensor, block_sizes: Sequence[int]):
         self.p_plane = p_plane
-        key = (p_plane.device.index, p_plane.shape[0])
-        pos = ActiveStash._positions.get(key)
-        if pos is None:
-            if len(ActiveStash._positions) > 64:
-                ActiveStash._positions.clear()
-            pos = ActiveStash._positions[key] = torch.arange(p_plane.shape[0], dtype=torch.int64, device=p_plane.device)
-        self.positions = pos
+        self.positions = ActiveStash.positions_for(p_plane.device, p_plane.shape[0])
         self.offsets = [0]
         for n in block_sizes:
             self.offsets.append(self.offsets[-1] + n)

@@ -64,8 +64,14 @@ def use_native_transport(comm) -> None:
     """Route every device-side collective of this module through `comm` (a comm.NativeComm), or back through
     torch.distributed with None.  The process group stays what creates / synchronises the ranks."""
     global _NATIVE, _COMM_STREAM
+    if _NATIVE is not None and _NATIVE is not comm:
+        _NATIVE.close()
     _NATIVE = comm
     _COMM_STREAM = torch.cuda.Stream(device=comm.device) if comm is not None else None
+    if comm is not None and not getattr(use_native_transport, "_atexit", False):
+        import atexit
+        atexit.register(lambda: use_native_transport(None))  # the communicator goes before the process group
+        use_native_transport._atexit = True
 
 
 def _native(x: torch.Tensor) -> bool:
@@ -314,10 +320,7 @@ class HipBackend:
         if extra is None and emb.is_contiguous() and ops.fused_tower_supported(emb, feats, W1, W2, W3):
             # one launch (csrc/tower.hip): the routed rows play the table, looked up by position; returns
             # (h, tin, out) -- tower_bwd recognises the [B, 2D] tower input in the `f` slot
-            key = (self.device.index, B)
-            pos = ops.ActiveStash._positions.get(key)
-            if pos is None:
-                pos = ops.ActiveStash._positions[key] = torch.arange(B, dtype=torch.int64, device=self.device)
+            pos = ops.ActiveStash.positions_for(self.device, B)
             h, tin, out = self.empty(B, Hd), self.empty(B, 2 * De), self.empty(B, W3.shape[0])
             feats = feats.contiguous()
             N.check(self.lib.tt_tower_fwd(emb.data_ptr(), B, pos.data_ptr(), feats.data_ptr(), feats.stride(0), B, De, F, Hd,
