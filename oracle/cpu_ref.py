@@ -286,15 +286,17 @@ def adam_update(
     p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor,
     step: int, lr: float = 1e-3, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
 ) -> None:
-    """In-place torch.optim.Adam semantics (no weight decay, no amsgrad), in the
-    operation order of torch's single-tensor path: lerp for m, mul+addcmul for
-    v, denom = sqrt(v)/sqrt(bc2) + eps, p += -(lr/bc1) * m/denom."""
-    m.add_((g - m) * (1.0 - beta1))
-    v.mul_(beta2).add_(g * g * (1.0 - beta2))
+    """In-place torch.optim.Adam semantics (no weight decay, no amsgrad) with the very tensor ops of torch's
+    single-tensor path (torch/optim/adam.py `_single_tensor_adam`, the code behind ref:train/train.py:179):
+    lerp_ for m, mul_ + addcmul_ for v, denom = sqrt(v) / sqrt(bc2) + eps, addcdiv_ for p.  One temporary
+    (denom) per call -- the earlier spelled-out expressions allocated five table-sized ones, which made this
+    port slower than the reference it restates."""
+    m.lerp_(g, 1.0 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step
-    denom = v.sqrt() / math.sqrt(bc2) + eps
-    p.add_(m / denom * (-(lr / bc1)))
+    denom = v.sqrt().div_(math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
 
 
 class AdamState:

@@ -265,6 +265,108 @@ def test_c2_whole_train_step_vs_oracle():
         assert float(st["exp_avg"][cold.to(DEV)].abs().max()) == 0.0
 
 
+def _dense_params_close(sd, params, steps, noise_keys=("item_tower_arch.bias", "item_features_arch.2.bias")):
+    """Dense parameters after `steps` Adam steps vs the oracle's: all but <= 0.2 % of a tensor's elements within 5e-6,
+    every element within the steps * lr bound (Adam's first updates are lr * g / (|g| + eps): an element whose
+    gradient is ~1e-4 of the typical size turns a 1e-7 summation-order difference into a 1e-5 step difference)."""
+    for k, v in sd.items():
+        if "embedding_arch" in k or k not in params:
+            continue
+        err = (v.cpu() - params[k]).abs()
+        assert float(err.max()) <= 2 * steps * 1e-3 * 1.05, (k, float(err.max()))
+        if k not in noise_keys:
+            assert float((err > 5e-6).float().mean()) <= 2e-3, (k, float((err > 5e-6).float().mean()), float(err.max()))
+
+
+def _sampled_rows_close(sd, opt, model, params, key, looked_up, n_rows, seed):
+    pick = torch.Generator().manual_seed(seed)
+    touched = torch.unique(looked_up)
+    hit = touched[torch.randperm(touched.numel(), generator=pick)[:256]]
+    mask = torch.ones(n_rows, dtype=torch.bool)
+    mask[touched] = False
+    cold = torch.nonzero(mask).flatten()
+    cold = cold[torch.randperm(cold.numel(), generator=pick)[:256]]
+    table = sd[key]
+    assert torch.allclose(table[hit.to(DEV)].cpu(), params[key][hit], atol=5e-6), key
+    assert torch.equal(table[cold.to(DEV)].cpu(), params[key][cold]), key
+    st = opt.state[getattr(model, key.split(".")[0]).weight]
+    assert float(st["exp_avg"][cold.to(DEV)].abs().max()) == 0.0
+    return hit
+
+
+def test_c3_whole_train_step_vs_oracle():
+    """BASELINE config 3 end to end at its stated size (C2 + H = 50, 4 heads, 3 layers, B = 4096, 1 M items): one
+    whole `train_forward -> zero_grad -> backward -> step` (ref:train/train.py:112-125 over
+    ref:src/two_tower_with_user_history_encoder.py:85-122) on the HIP path vs oracle/cpu_ref.train_step: loss 1e-4,
+    every dense parameter incl. the encoder's twelve, 256 sampled looked-up rows of each table -- the item rows
+    include rows fed by BOTH an id lookup and history lookups -- and 256 never-looked-up rows (bit-identical)."""
+    import two_tower_models_amd as A
+    from oracle import cpu_ref as R
+    NU = NI = 1_000_000
+    D, F, B, H = 128, 8, 4096, 50
+    torch.manual_seed(0)
+    mips = A.BaselineMIPSModule(corpus_size=64, embedding_dim=D)
+    model = A.TwoTowerWithUserHistoryEncoder(10, NU, D, F, H, NI, D, F, [1.0], mips)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep="forward")
+    g = torch.Generator().manual_seed(4321)
+    b = [torch.randint(0, NU, (B,), generator=g), torch.randn(B, F, generator=g),
+         torch.randint(0, NI, (B, H), generator=g), torch.randint(0, NI, (B,), generator=g),
+         torch.randn(B, F, generator=g), torch.randint(0, 10, (B,), generator=g),
+         torch.randint(0, 2, (B, 1), generator=g).float()]
+    b[2][:128, 0] = b[3][:128]      # items that are somebody's positive AND in histories (most recent slot ...
+    b[2][128:256, 7] = b[3][:128]   # ... and a middle slot of other users)
+    loss = model.train_forward(*[t.to(DEV) for t in b])
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    state = R.AdamState(params)
+    want = R.train_step(params, state, b, torch.tensor([1.0]), with_history=True, heads=4, pos_table=R.positional_table(H, D))
+    assert abs(loss.item() - want) < 1e-4, (loss.item(), want)
+    sd = model.state_dict()
+    _dense_params_close(sd, params, 1)
+    _sampled_rows_close(sd, opt, model, params, "user_id_embedding_arch.weight", b[0], NU, 5)
+    _sampled_rows_close(sd, opt, model, params, "item_id_embedding_arch.weight", torch.cat([b[2].reshape(-1), b[3]]), NI, 6)
+    both = b[3][:128]
+    assert torch.allclose(sd["item_id_embedding_arch.weight"][both.to(DEV)].cpu(), params["item_id_embedding_arch.weight"][both],
+                          atol=5e-6)
+
+
+def test_p_shape_train_step_vs_oracle():
+    """The headline shape itself (BASELINE.json's metric: N_i = 10 M, N_u = 1 M, D = 128, B = 8192, F = 8): one whole
+    step vs oracle/cpu_ref.train_step (about ten seconds of CPU), same checks as C2."""
+    import two_tower_models_amd as A
+    from oracle import cpu_ref as R
+    NU, NI = 1_000_000, 10_000_000
+    D, F, B = 128, 8, 8192
+    torch.manual_seed(0)
+    mips = A.BaselineMIPSModule(corpus_size=64, embedding_dim=D)
+    model = A.TwoTowerBaseRetrieval(10, NU, D, F, NI, D, F, [1.0], mips)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep="forward")
+    g = torch.Generator().manual_seed(99)
+    b = [torch.randint(0, NU, (B,), generator=g), torch.randn(B, F, generator=g),
+         torch.randint(0, NI, (B, 4), generator=g), torch.randint(0, NI, (B,), generator=g),
+         torch.randn(B, F, generator=g), torch.randint(0, 10, (B,), generator=g),
+         torch.randint(0, 2, (B, 1), generator=g).float()]
+    b[3][:32] = b[3][32:64]  # duplicate positives inside the batch
+    loss = model.train_forward(*[t.to(DEV) for t in b])
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    state = R.AdamState(params)
+    want = R.train_step(params, state, b, torch.tensor([1.0]))
+    assert abs(loss.item() - want) < 1e-4, (loss.item(), want)
+    sd = model.state_dict()
+    _dense_params_close(sd, params, 1)
+    _sampled_rows_close(sd, opt, model, params, "user_id_embedding_arch.weight", b[0], NU, 7)
+    _sampled_rows_close(sd, opt, model, params, "item_id_embedding_arch.weight", b[3], NI, 8)
+    dup = b[3][:32]
+    assert torch.allclose(sd["item_id_embedding_arch.weight"][dup.to(DEV)].cpu(), params["item_id_embedding_arch.weight"][dup], atol=5e-6)
+
+
 def _fp64_scores(q_eff, corpus, chunk=1_000_000):
     """[B, C] fp64 checker of q . corpus^T, computed on the device in row chunks (test infrastructure)."""
     out = torch.empty(q_eff.shape[0], corpus.shape[0], dtype=torch.float64, device=corpus.device)

@@ -127,8 +127,15 @@ def test_adam_trajectory_dense_exact(golden, schedule, interleave):
         # 3-steps * 2 * lr bound, and all but <= 0.1 % of them within 5e-6.
         assert float(err.max()) <= 2 * 3 * 1e-3 * 1.05, (k, float(err.max()))
         if not noise_only:
-            n_out = int((err > 5e-6).sum())
+            out = err > 5e-6
+            n_out = int(out.sum())
             assert n_out <= max(1, int(1e-3 * err.numel())) and float(err.max()) <= 2e-4, (k, n_out, float(err.max()))
+            if n_out:
+                # ... and the elements outside ARE the small-gradient ones, not an arbitrary 0.1 % (a bug confined
+                # to, say, the last row of a block would sit on typical gradients): their first-step |g| in the
+                # reference is below 2 % of the tensor's largest, most far below
+                g0 = torch.from_numpy(np.abs(g["g." + k])).reshape(err.shape)
+                assert float(g0[out].max()) <= 2e-2 * float(g0.max()), (k, n_out, float(g0[out].max()), float(g0.max()))
 
 
 def test_label_and_id_dtypes_follow_the_reference(golden):
@@ -505,12 +512,15 @@ def test_out_of_range_id_raises_index_error():
     assert model(*ok).shape == (B, 5)
 
 
-@pytest.mark.parametrize("D,kind", [(256, "hist"), (512, "hist"), (192, "base")])
+@pytest.mark.parametrize("D,kind", [(256, "hist"), (512, "hist"), (192, "base"), (96, "base"), (96, "hist")])
 def test_wide_embeddings_train_step_vs_oracle(D, kind):
-    """Embedding widths above 128: the reference accepts any width; here D = 256 / 512 (history
-    model: heads of 64 / 128, in-batch CE and MIPS through their generic-width forms) and a ragged 192.  One train step
-    vs the oracle: loss 1e-4, updated tables and dense parameters; then forward() top-K vs the oracle's scores."""
+    """Embedding widths off the tuned set: the reference accepts any width; here D = 256 / 512 (history model: heads
+    of 64 / 128, in-batch CE and MIPS through their generic-width forms), a ragged 192, and 96 (the
+    fused tower and the matrix-core attention do not take it -- heads of 24 -- so the generic kernels run, and SAY so:
+    `ops.generic_paths` names each path and the constraint, with a one-time RuntimeWarning).  One train step vs the
+    oracle: loss 1e-4, updated tables and dense parameters; then forward() top-K vs the oracle's scores."""
     import two_tower_models_amd as A
+    from two_tower_models_amd import ops
     from oracle import cpu_ref as R
     torch.manual_seed(11)
     B, H, NU, NI, F = 48, 6, 300, 500, 8
@@ -553,6 +563,13 @@ def test_wide_embeddings_train_step_vs_oracle(D, kind):
     picked = torch.gather(full, 1, top.cpu())
     kth = torch.topk(full, 10, dim=1).values[:, -1]
     assert bool((picked.min(1).values >= kth - 1e-4).all())
+    # a fast path that was not taken is reported, with the constraint that ruled it out
+    tower = [v for k, v in ops.generic_paths.items() if k.startswith("tower")]
+    assert tower and "F <= 64" in tower[0]
+    if D > 128:
+        assert "in-batch softmax CE" in ops.generic_paths and "MIPS top-K" in ops.generic_paths
+    if kind == "hist" and D in (96, 512):
+        assert "head width" in ops.generic_paths["history-encoder attention"]
 
 
 def test_sweep_throttle_does_not_change_results(golden):

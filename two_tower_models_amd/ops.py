@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import warnings
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -36,6 +37,19 @@ def _ws(dev: torch.device, nbytes: int, slot: str = "ws") -> Tuple[Optional[int]
         return None, 0
     buf = N.scratch.get(dev, nbytes, slot)
     return buf.data_ptr(), buf.numel()
+
+
+# ----------------------------------------------------------------- "a fast path was not taken"
+# Every tuned kernel has a correct generic form behind it; which one ran is reported once per process (a
+# RuntimeWarning naming the constraint) and kept here for bench.py's `generic_paths` field -- a run at
+# --embedding_dim 96 should SAY that it left most of the speed behind, not just be slow.
+generic_paths: dict = {}
+
+
+def note_generic(path: str, why: str) -> None:
+    if path not in generic_paths:
+        generic_paths[path] = why
+        warnings.warn(f"two_tower_models_amd: {path} runs on the generic kernels ({why})", RuntimeWarning, stacklevel=3)
 
 
 def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, M: int, Nn: int, K: int,
@@ -413,9 +427,15 @@ _FUSED_TOWER = os.environ.get("TT_NO_FUSED_TOWER") is None  # A/B switch (DESIGN
 
 def fused_tower_supported(weight, feats, W1, W2, W3) -> bool:
     """tt_tower_fwd / tt_tower_bwd_data: hidden = 256, D = d_out in {32, 64, 128}, F <= 64."""
-    return (_FUSED_TOWER and weight.is_cuda and feats.dim() == 2 and feats.dtype == torch.float32
-            and W3.shape[1] == 2 * weight.shape[1] and W2.shape[0] == weight.shape[1]
-            and bool(N.load().tt_tower_supported(weight.shape[1], feats.shape[1], W1.shape[0], W3.shape[0])))
+    if not (_FUSED_TOWER and weight.is_cuda and feats.dim() == 2 and feats.dtype == torch.float32):
+        return False
+    ok = (W3.shape[1] == 2 * weight.shape[1] and W2.shape[0] == weight.shape[1]
+          and bool(N.load().tt_tower_supported(weight.shape[1], feats.shape[1], W1.shape[0], W3.shape[0])))
+    if not ok:
+        note_generic("tower (id lookup + feature MLP + tower Linear)",
+                     f"the fused kernel takes hidden = 256, D = d_out in {{32, 64, 128}}, F <= 64; got hidden = {W1.shape[0]}, "
+                     f"D = {weight.shape[1]}, d_out = {W3.shape[0]}, F = {feats.shape[1]}: gather + three GEMM launches per direction")
+    return ok
 
 
 class FusedTower(_LookupFunction):
@@ -539,8 +559,15 @@ class InBatchSoftmaxCE(torch.autograd.Function):
             # training: the forward also accumulates E[i] = sum_j p_ij I_j, which IS the user-side
             # gradient up to the row factor -- the backward then only runs the item-side kernel
             du_unit = torch.empty(M, D, dtype=torch.float32, device=dev)
+            if D > 128:
+                note_generic("in-batch softmax CE", f"D = {D} > 128: logits materialised per row chunk + library GEMMs "
+                                                    "(csrc/ce_wide.hip) instead of the register-stationary kernels")
             if keep_logits is None:
                 keep_logits = Nn >= 4 * M
+            if keep_logits and ctx.needs_input_grad[1] and not kept_logits_supported(U, I):
+                note_generic("in-batch softmax CE backward (wide negative sets)",
+                             f"kept logits need D in {{32, 64, 128}}, N < 4 Mi and 16-B aligned rows; got D = {D}, N = {Nn}: "
+                             "the item-side backward recomputes the logits (4 instead of 3 logit-sized products)")
             keep_logits = bool(keep_logits) and ctx.needs_input_grad[1] and kept_logits_supported(U, I)
             if keep_logits:
                 zn = lib.tt_inbatch_ce_logits_bytes(M, Nn)
@@ -729,6 +756,11 @@ class HistoryEncoder(_LookupFunction):
                 "tt_hist_embed_pool")
         saved: List[torch.Tensor] = []
         row0_last = L > 0 and H <= 64 and D // heads <= 64 and _ROW0_LAST
+        dh = D // max(heads, 1)
+        if L > 0 and (H > 64 or dh not in (16, 32, 64) or D % 4):
+            note_generic("history-encoder attention",
+                         f"the matrix-core kernels take H <= 64 and head width in {{16, 32, 64}}; got H = {H}, head width = {dh}: "
+                         "VALU attention" + ("" if row0_last else ", last layer computed for every position"))
         for l in range(L):
             w_in, b_in, w_out, b_out = layer_params[4 * l: 4 * l + 4]
             if l == L - 1 and row0_last:
@@ -849,6 +881,8 @@ def mips_topk(query: torch.Tensor, corpus: torch.Tensor, k: int) -> Tuple[torch.
     if not (0 < k <= Cn):
         raise RuntimeError("selected index k out of range")  # torch.topk's message
     corpus = corpus.contiguous()
+    if D > 128:
+        note_generic("MIPS top-K", f"D = {D} > 128: score slabs from the library GEMM instead of the register-stationary pass")
     if corpus.dtype == torch.bfloat16:
         dtype = N.TT_BF16
         q = torch.empty(B, D, dtype=torch.bfloat16, device=dev)
