@@ -290,6 +290,87 @@ def test_multi_rank_sharded_mips_hip_backend(world, C, K, backend):
         assert torch.equal(got["sc"], want_sc[r * 6:(r + 1) * 6])
 
 
+# ------------------------------------------------------------------ SURVEY 8f-4 under the product backend
+def _ckpt_worker(rank, world, port, outdir, backend):
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here, os.path.join(here, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from two_tower_models_amd import sharded
+    g = np.load(os.path.join(here, "golden", "g2_base_aligned.npz"))
+    n_users, du, iu, n_items, di, ii, Tn, B, H = (int(v) for v in g["cfg"])
+    dev = _init_pg(backend, rank, world, port)
+    try:
+        Bl = B // world
+        cfg = dict(n_users=n_users, n_items=n_items, D=du, F=iu, B=Bl, H=H)
+        tr = sharded.ShardedTrainer(cfg, dev, negatives="global", user_value_weights=tuple(float(v) for v in g["uvw"]))
+        assert isinstance(tr.be, sharded.HipBackend)
+        # a REFERENCE-format checkpoint (the parameters the reference model was created with) into the shards ...
+        tr.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("p.")})
+        names = ("user_id", "user_features", "user_history", "item_id", "item_features", "position", "labels")
+        losses = []
+        for s in range(3):  # ... the reference's three batches, split by rank ...
+            b = [torch.from_numpy(g[f"step{s}.in.{n}"])[rank * Bl:(rank + 1) * Bl].to(dev) for n in names]
+            losses.append(float(tr.step(b)))
+        sd = tr.state_dict()  # ... and back out under the reference's Parameter names
+        # serve the trained item table: this rank's catalogue block through the item tower -> ShardedMIPS
+        feats = torch.from_numpy(g["step0.in.item_features"])  # any [*, II] features: row r of the catalogue gets row r % B
+        cat_feats = feats[torch.arange(n_items) % B]
+        mips = tr.index_corpus(cat_feats[tr.items.lo:tr.items.hi])
+        torch.save({"losses": losses, "sd": {k: v.cpu() for k, v in sd.items()}, "cat_feats": cat_feats},
+                   os.path.join(outdir, f"ckpt{rank}.pt"))
+        dist.barrier()
+        # queries: the user embeddings of the trained model, from a single-device module fed the gathered state
+        import two_tower_models_amd as A
+        single = A.TwoTowerBaseRetrieval(10, n_users, du, iu, n_items, di, ii, [float(v) for v in g["uvw"]],
+                                         A.BaselineMIPSModule(corpus_size=n_items, embedding_dim=di))
+        single.load_state_dict(sd)
+        single = single.to(dev)
+        with torch.no_grad():
+            single.index_corpus(torch.arange(n_items, device=dev), cat_feats.to(dev))
+            users = [torch.from_numpy(g[f"step2.in.{n}"])[rank * Bl:(rank + 1) * Bl].to(dev) for n in names[:3]]
+            want_top = single(*users)
+            q = single.compute_user_embedding(*users)
+        idx, _ = mips.search(q, 10)
+        torch.save({"idx": idx.cpu(), "want": want_top.cpu()}, os.path.join(outdir, f"serve{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (2, "nccl"), ("all", "nccl")])
+def test_sharded_checkpoint_adaptor_and_corpus_serving_hip_backend(world, backend):
+    """SURVEY 8f item 4 on the product backend: ShardedTrainer.load_state_dict(reference parameters of fixture g2)
+    -> the reference's 3 Adam steps on its batches split by rank -> state_dict() equals the reference's `after.*`
+    arrays (trajectory tolerances of test_gpu_models.py::test_adam_trajectory_dense_exact), and the item table
+    trained that way, served through index_corpus -> ShardedMIPS, returns the single-device model's top-K."""
+    import os
+    import tempfile
+    import torch.multiprocessing as mp
+    if world != 1:
+        world = _resolve_world(world, backend)
+    outdir = tempfile.mkdtemp()
+    mp.spawn(_ckpt_worker, args=(world, _free_port(), outdir, backend), nprocs=world, join=True)
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = np.load(os.path.join(here, "golden", "g2_base_aligned.npz"))
+    for r in range(world):
+        res = torch.load(os.path.join(outdir, f"ckpt{r}.pt"))
+        assert np.allclose(res["losses"], g["adam_losses"], atol=1e-4), (res["losses"], g["adam_losses"])
+        for k, v in res["sd"].items():
+            after = torch.from_numpy(g["after." + k])
+            assert v.shape == after.shape, k
+            noise_only = float(np.abs(g["g." + k]).max()) < 1e-6
+            err = (v - after).abs() - 1e-5 * after.abs()
+            assert float(err.max()) <= 2 * 3 * 1e-3 * 1.05, (k, float(err.max()))
+            if not noise_only:
+                n_out = int((err > 5e-6).sum())
+                assert n_out <= max(1, int(2e-3 * err.numel())) and float(err.max()) <= 2e-4, (k, n_out, float(err.max()))
+        serve = torch.load(os.path.join(outdir, f"serve{r}.pt"))
+        assert torch.equal(serve["idx"], serve["want"]), r
+
+
 @pytest.mark.parametrize("n,n_rows,world", [(8192, 10_000_000, 8), (240, 307, 2), (50_000, 1_000_003, 7), (64, 64, 64),
                                             (204_800, 1_000_000, 8), (5000, 100_000, 1000)])
 def test_route_kernels_match_cpu_restatement(n, n_rows, world):

@@ -79,7 +79,13 @@ def _worker(rank, world, port, outdir, negatives, routing="alltoall"):
                 # planned routes must not be applied to them (they were counted for the old ids).
                 batches[1][0].copy_(torch.roll(batches[1][0], 3) if rank else batches[1][0].flip(0))
                 batches[1][3].copy_((batches[1][3] * 7 + 3) % CFG["n_items"])
+        # serve the trained item table: this rank's catalogue block -> item tower -> ShardedMIPS
+        gq = torch.Generator().manual_seed(31)
+        cat_feats = torch.randn(CFG["n_items"], CFG["F"], generator=gq)
+        queries = torch.randn(4 * world, CFG["D"], generator=gq)[rank * 4:(rank + 1) * 4]
+        served = tr.index_corpus(cat_feats[tr.items.lo:tr.items.hi]).search(queries, 9)
         torch.save({"losses": losses, "users": tr.users.weight.clone(), "items": tr.items.weight.clone(),
+                    "served": served, "cat_feats": cat_feats, "queries": queries,
                     "lo_hi": (tr.users.lo, tr.users.hi, tr.items.lo, tr.items.hi),
                     "dense": {k: v.clone() for k, v in tr.params.items()}, "comm": dict(tr.comm_bytes),
                     "batches": [tuple(t.clone() for t in b) for b in batches]},
@@ -111,6 +117,15 @@ def test_global_negatives_equal_reference_on_concatenated_batch(world, routing):
     for s in range(STEPS):
         cat = [torch.cat([res[r]["batches"][s][k] for r in range(world)]) for k in range(7)]
         want_losses.append(R.train_step(params, state, cat, uvw))
+    # the catalogue served from the shards == exact top-K over the item tower applied to the trained reference table.
+    # (The two item-side biases carry +-lr steps of noise -- zero true gradient -- which shifts EVERY item embedding by
+    # the same vector: each query's scores move by one constant, the ranking does not.)
+    corpus = R.item_embeddings(params, torch.arange(CFG["n_items"]), res[0]["cat_feats"])
+    for r in range(world):
+        want_idx, want_sc, _ = R.mips_topk(res[r]["queries"], corpus, 9)
+        got_idx, got_sc = res[r]["served"]
+        shift = (got_sc - want_sc)
+        assert float((shift - shift[:, :1]).abs().max()) < 1e-4 and float((got_idx == want_idx).float().mean()) > 0.95
     for r in range(world):
         assert np.allclose(res[r]["losses"], want_losses, atol=1e-5), (res[r]["losses"], want_losses)
         ulo, uhi, ilo, ihi = res[r]["lo_hi"]
@@ -172,7 +187,13 @@ def _hist_worker(rank, world, port, outdir):
         tr.items.weight[: tr.items.hi - tr.items.lo].copy_(0.5 * it[tr.items.lo:tr.items.hi])
         batches = tr.make_batches(STEPS, seed=41)
         losses = [float(tr.step(b)) for b in batches]
+        # serve the trained item table: this rank's catalogue block -> item tower -> ShardedMIPS
+        gq = torch.Generator().manual_seed(31)
+        cat_feats = torch.randn(CFG["n_items"], CFG["F"], generator=gq)
+        queries = torch.randn(4 * world, CFG["D"], generator=gq)[rank * 4:(rank + 1) * 4]
+        served = tr.index_corpus(cat_feats[tr.items.lo:tr.items.hi]).search(queries, 9)
         torch.save({"losses": losses, "users": tr.users.weight.clone(), "items": tr.items.weight.clone(),
+                    "served": served, "cat_feats": cat_feats, "queries": queries,
                     "lo_hi": (tr.users.lo, tr.users.hi, tr.items.lo, tr.items.hi),
                     "dense": {k: v.clone() for k, v in tr.params.items()},
                     "batches": [tuple(t.clone() for t in b) for b in batches]},

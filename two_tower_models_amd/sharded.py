@@ -729,6 +729,23 @@ class ShardedTrainer:
                 table.m.zero_()
                 table.v.zero_()
 
+    def index_corpus(self, item_features_block: torch.Tensor) -> "ShardedMIPS":
+        """Serve what was trained (upstream searches a random corpus,
+        ref:src/baseline_mips_module.py:29-30): the item tower over THIS rank's rows of the catalogue -- item r is
+        row r of the item table, `item_features_block` [hi - lo, II] the features of rows [items.lo, items.hi) --
+        installed as this rank's block of a ShardedMIPS.  Its search() equals TwoTowerBaseRetrieval.index_corpus +
+        forward on one device with the gathered state_dict()."""
+        n = self.items.hi - self.items.lo
+        feats = item_features_block.to(self.device, torch.float32)
+        if feats.shape[0] != n:
+            raise ValueError(f"item_features_block: expected {n} rows (this rank's item rows), got {feats.shape[0]}")
+        if n > 0:
+            with torch.no_grad():
+                _, _, corpus = self.be.tower_fwd(self.items.weight[:n], feats, self._tower_params("item"))
+        else:  # a rank that owns no item row
+            corpus = torch.empty(0, self.cfg["D"], dtype=torch.float32, device=self.device)
+        return ShardedMIPS(corpus, self.items.lo, backend=self.be)
+
     # ---- lookup through the owning ranks (fixed-size collectives, no host sync)
     def _lookup(self, table: ShardedTable, ids: torch.Tensor) -> Tuple[Lookup, "_Pending"]:
         """-> (routing, pending rows).  The reduce-scatter that delivers the rows is only STARTED here:
