@@ -286,6 +286,15 @@ def secondary(device, lib, N):
             sec[key] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
     try:
+        # what the 10 M pairs/s @ 8 GPUs target rests on: ONE rank's kernels of the W = 8 step,
+        # stand-in collectives -- clearly labelled, with the two logits kernels' own rooflines and the host's cost
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        import bench_emulated_world as _emu
+        sec["emulated_W8"] = _emu.emulated(8, "P", steps=30, warmup=5, device=device)
+    except Exception as e:
+        sec["emulated_W8"] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
+    try:
         # the drop-in training script end to end (ref:train/train.py:138-183): dataset generated in HBM, device-side
         # shuffle + batch slicing, 1-D [B] labels, 40 steps per epoch at the headline shapes; 2nd epoch reported
         import argparse as _ap

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_sharded.py -x -q -m gpu -k "checkpoint_adaptor" 2>&1 | tail -15
+timeout 600 python tools/bench_emulated_world.py 8 P 2>&1 | tail -12

@@ -3,7 +3,9 @@ is replaced by a local stand-in whose collectives produce tensors of the right s
 data between processes (all_gather = W copies of the local block, reduce_scatter = the first block,
 all_reduce = identity).  The numbers are NOT a training run -- they show what one rank's kernels cost
 once the tables are W times thinner and the in-batch negatives W times wider, i.e. the step time at
-W GPUs minus the collectives.  Usage: python tools/bench_emulated_world.py [W] [workload]   (TT_ROUTE=alltoall|allgather)"""
+W GPUs minus the collectives.  bench.py puts `emulated(8, "P")` into the default line's `secondary`.
+Usage: python tools/bench_emulated_world.py [W] [workload]   (TT_ROUTE=alltoall|allgather)"""
+import ctypes as C
 import os
 import sys
 import time
@@ -12,12 +14,10 @@ import types
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import bench  # noqa: E402
-from two_tower_models_amd import sharded  # noqa: E402
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
-W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-workload = sys.argv[2] if len(sys.argv) > 2 else "P"
+MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: fp32 MFMA peak
 
 
 class _Done:
@@ -25,90 +25,161 @@ class _Done:
         return True
 
 
-def _all_gather(out, x, async_op=False):
-    out.view(W, -1).copy_(x.reshape(1, -1).expand(W, -1))
-    return _Done() if async_op else None
+def _fake_dist(W):
+    def _all_gather(out, x, async_op=False):
+        out.view(W, -1).copy_(x.reshape(1, -1).expand(W, -1))
+        return _Done() if async_op else None
+
+    def _reduce_scatter(out, x, async_op=False):
+        out.copy_(x[: out.shape[0]])
+        return _Done() if async_op else None
+
+    def _all_to_all(out, x, async_op=False):
+        # routed lookups.  Float rows: same shape, data irrelevant.  Id lists [W, cap]: a real owner receives from
+        # every peer the ~B/W ids of ITS block that the peer looked up; this rank's own chunk for itself has exactly
+        # that content and statistics, so every "peer" is given a copy of it.
+        if x.dtype == torch.int64 and x.dim() == 1:
+            out.view(W, -1).copy_(x.view(W, -1)[0:1].expand(W, -1))
+        else:
+            out.copy_(x)
+        return _Done() if async_op else None
+
+    return types.SimpleNamespace(
+        all_to_all_single=_all_to_all, get_backend=lambda: "emulated", get_world_size=lambda: W, get_rank=lambda: 0,
+        is_initialized=lambda: True, all_gather_into_tensor=_all_gather, reduce_scatter_tensor=_reduce_scatter,
+        all_reduce=lambda x, op=None, async_op=False: (_Done() if async_op else None),
+        broadcast=lambda x, src=0: None, ReduceOp=torch.distributed.ReduceOp, barrier=lambda: None)
 
 
-def _reduce_scatter(out, x, async_op=False):
-    out.copy_(x[: out.shape[0]])
-    return _Done() if async_op else None
-
-
-def _all_to_all(out, x, async_op=False):
-    # routed lookups.  Float rows: same shape, data irrelevant.  Id lists [W, cap]: a real owner receives from
-    # every peer the ~B/W ids of ITS block that the peer looked up; this rank's own chunk for itself has exactly
-    # that content and statistics, so every "peer" is given a copy of it.
-    if x.dtype == torch.int64 and x.dim() == 1:
-        out.view(W, -1).copy_(x.view(W, -1)[0:1].expand(W, -1))
-    else:
-        out.copy_(x)
-    return _Done() if async_op else None
-
-
-fake = types.SimpleNamespace(all_to_all_single=_all_to_all,
-    get_backend=lambda: "emulated", get_world_size=lambda: W, get_rank=lambda: 0, is_initialized=lambda: True,
-    all_gather_into_tensor=_all_gather, reduce_scatter_tensor=_reduce_scatter,
-    all_reduce=lambda x, op=None, async_op=False: (_Done() if async_op else None),
-    broadcast=lambda x, src=0: None, ReduceOp=torch.distributed.ReduceOp, barrier=lambda: None)
-sharded.dist = fake
-
-device = torch.device("cuda:0")
-cfg = dict(bench.WORKLOADS[workload])
-trainer = sharded.ShardedTrainer(cfg, device, negatives="global")
-batches = trainer.make_batches(8)
-for i in range(5):
-    trainer.step(batches[i % 8], batches[(i + 1) % 8])
-torch.cuda.synchronize()
-steps = 30
-t0 = time.perf_counter()
-for i in range(steps):
-    trainer.step(batches[i % 8], batches[(i + 1) % 8])
-host_ms = (time.perf_counter() - t0) / steps * 1e3  # time to ENQUEUE a step (Python + launches)
-torch.cuda.synchronize()
-ms = (time.perf_counter() - t0) / steps * 1e3
-print(f"  host enqueue time {host_ms:.3f} ms/step")
-
-# where the time goes: events on the main stream around the two logits kernels
-marks = []
-
-
-def _ev():
-    e = torch.cuda.Event(enable_timing=True)
-    e.record()
-    marks.append(e)
-
-
-be = trainer.be
-_fwd, _bwd = be.ce_fwd, be.ce_bwd
-
-
-def ce_fwd(*a, **k):
-    _ev()
-    out = _fwd(*a, **k)
-    _ev()
-    return out
-
-
-def ce_bwd(*a, **k):
-    _ev()
-    out = _bwd(*a, **k)
-    _ev()
-    return out
-
-
-be.ce_fwd, be.ce_bwd = ce_fwd, ce_bwd
-acc = [0.0] * 5
-for i in range(10):
-    marks.clear()
-    _ev()
-    trainer.step(batches[i % 8], batches[(i + 1) % 8])
-    _ev()
+def _time_steps(trainer, batches, steps):
+    """-> (ms to ENQUEUE a step, ms per step): wall clock around the enqueue loop, then around the drain."""
+    n = len(batches)
     torch.cuda.synchronize()
-    for k in range(5):
-        acc[k] += marks[k].elapsed_time(marks[k + 1]) / 10
-print("  main-stream phases (ms): lookups+towers %.3f | logits fwd + dU %.3f | weights/loss %.3f | logits bwd (dI) %.3f | "
-      "towers bwd + row Adam %.3f" % tuple(acc))
-print(f"emulated W={W} workload={workload} routing={trainer.routing}: {ms:.3f} ms/step per rank (no collectives) -> "
-      f"{cfg['B'] * W / ms * 1e3 / 1e6:.2f} M pairs/s if the collectives were free")
-print(f"  bytes this rank would send per step: {trainer.comm_bytes} = {sum(trainer.comm_bytes.values()) / 1e6:.1f} MB")
+    t0 = time.perf_counter()
+    for i in range(steps):
+        trainer.step(batches[i % n], batches[(i + 1) % n])
+    host = (time.perf_counter() - t0) / steps * 1e3
+    torch.cuda.synchronize()
+    return host, (time.perf_counter() - t0) / steps * 1e3
+
+
+def emulated(W=8, workload="P", steps=30, warmup=5, device=None, verbose=False):
+    """One rank's kernels of the W-GPU step (stand-in collectives), as a record for bench.py's `secondary`."""
+    import bench
+    from two_tower_models_amd import _native as N
+    from two_tower_models_amd import sharded
+    device = device or torch.device("cuda:0")
+    lib = N.load()
+    real_dist = sharded.dist
+    sharded.dist = _fake_dist(W)
+    try:
+        cfg = dict(bench.WORKLOADS[workload])
+        # (1) the host's own cost of enqueueing a step -- Python + ~150 launches -- measured where the GPU can never
+        # be what the enqueue loop waits for: the SAME step on tables and batches 64 times smaller (every kernel of
+        # the full-size step is launched, each finishes in microseconds, the queue never fills)
+        tiny_cfg = dict(cfg, n_users=max(cfg["n_users"] // 64, 1024), n_items=max(cfg["n_items"] // 64, 1024), B=128)
+        tiny = sharded.ShardedTrainer(tiny_cfg, device, negatives="global")
+        tb = tiny.make_batches(8)
+        for i in range(warmup):
+            tiny.step(tb[i % 8], tb[(i + 1) % 8])
+        host_only_ms, _ = _time_steps(tiny, tb, steps)
+        del tiny, tb
+        torch.cuda.empty_cache()
+
+        trainer = sharded.ShardedTrainer(cfg, device, negatives="global")
+        batches = trainer.make_batches(8)
+        for i in range(warmup):
+            trainer.step(batches[i % 8], batches[(i + 1) % 8])
+        lib.tt_profile_enable(1)
+        host_ms, ms = _time_steps(trainer, batches, steps)
+        prof = {}
+        for name in (b"ce_fwd_kernel", b"ce_bwd_kernel", b"adam_sweep_kernel"):
+            t, c = C.c_double(0.0), C.c_int64(0)
+            N.check(lib.tt_profile_read(name, C.byref(t), C.byref(c)), "tt_profile_read")
+            prof[name.decode()] = (t.value / max(c.value, 1), c.value)
+        lib.tt_profile_enable(0)
+
+        # where the time goes: events on the main stream around the two logits kernels
+        marks = []
+
+        def _ev():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append(e)
+
+        be = trainer.be
+        _fwd, _bwd = be.ce_fwd, be.ce_bwd
+
+        def ce_fwd(*a, **k):
+            _ev()
+            out = _fwd(*a, **k)
+            _ev()
+            return out
+
+        def ce_bwd(*a, **k):
+            _ev()
+            out = _bwd(*a, **k)
+            _ev()
+            return out
+
+        be.ce_fwd, be.ce_bwd = ce_fwd, ce_bwd
+        acc = [0.0] * 5
+        for i in range(10):
+            marks.clear()
+            _ev()
+            trainer.step(batches[i % 8], batches[(i + 1) % 8])
+            _ev()
+            torch.cuda.synchronize()
+            for k in range(5):
+                acc[k] += marks[k].elapsed_time(marks[k + 1]) / 10
+        be.ce_fwd, be.ce_bwd = _fwd, _bwd
+        B, D = cfg["B"], cfg["D"]
+        M, Nn = B, B * W
+        kept = bool(getattr(trainer.be, "keep_logits", False))
+        # logit-sized products: forward S = U.I^T and E = P.I (2), backward dI = G^T.U from the kept logits (1) or
+        # with S recomputed (2); 2*M*N*D flops each
+        fl_fwd, fl_bwd = 4.0 * M * Nn * D, (2.0 if kept else 4.0) * M * Nn * D
+        roof = []
+        for kname, fl, key in (("ce_fwd_du_kernel", fl_fwd, "ce_fwd_kernel"),
+                               ("ce_bwd_kept_kernel" if kept else "ce_bwd_kernel", fl_bwd, "ce_bwd_kernel")):
+            avg_ms, launches = prof[key]
+            if launches:
+                tf = fl / (avg_ms * 1e-3) / 1e12
+                roof.append({"bound": "mfma", "kernel": kname, "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                             "frac": round(tf / MFMA_F32_PEAK_TF, 4), "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+                             "algorithmic_flops_per_launch": fl})
+        out = {
+            "what": f"ONE rank's kernels of the row-sharded step at W = {W} on one GPU: tables 1/{W} as thick, {W}x{B} in-batch "
+                    "negatives per user, routed lookups; torch.distributed replaced by stand-ins that return tensors of the right "
+                    "shape without moving data -- NOT a training run, the collectives' time comes on top",
+            "workload": workload, "world": W, "routing": trainer.routing, "kept_logits": kept,
+            "ms_per_step_per_rank": round(ms, 4),
+            "pairs_per_s_if_collectives_were_free": round(B * W / ms * 1e3, 1),
+            "host_enqueue_ms_per_step": round(host_ms, 4),
+            "host_only_enqueue_ms_per_step": round(host_only_ms, 4),
+            "host_note": "host_only: the same step on 64x smaller tables / B = 128 (the GPU is never the wait); the difference to "
+                         "host_enqueue is queue back-pressure, not Python",
+            "main_stream_phases_ms": {"lookups_towers": round(acc[0], 3), "logits_fwd_dU": round(acc[1], 3), "weights_loss": round(acc[2], 3),
+                                      "logits_bwd_dI": round(acc[3], 3), "towers_bwd_row_adam": round(acc[4], 3)},
+            "roofline": roof,
+            "sweep_avg_launch_ms": round(prof["adam_sweep_kernel"][0], 4),
+            "bytes_this_rank_would_send_per_step": dict(trainer.comm_bytes),
+            "total_MB_sent": round(sum(trainer.comm_bytes.values()) / 1e6, 2),
+            "steps": steps, "warmup": warmup,
+        }
+        if verbose:
+            print(f"  host enqueue time {host_ms:.3f} ms/step (host only, GPU never the wait: {host_only_ms:.3f})")
+            print("  main-stream phases (ms): lookups+towers %.3f | logits fwd + dU %.3f | weights/loss %.3f | logits bwd (dI) %.3f | "
+                  "towers bwd + row Adam %.3f" % tuple(acc))
+            print(f"emulated W={W} workload={workload} routing={trainer.routing}: {ms:.3f} ms/step per rank (no collectives) -> "
+                  f"{B * W / ms * 1e3 / 1e6:.2f} M pairs/s if the collectives were free")
+            for r in roof:
+                print(f"  {r['kernel']}: {r['avg_launch_ms']:.3f} ms = {r['achieved']} TFLOP/s = {r['frac']:.3f} of the fp32 MFMA peak")
+            print(f"  bytes this rank would send per step: {trainer.comm_bytes} = {sum(trainer.comm_bytes.values()) / 1e6:.1f} MB")
+        return out
+    finally:
+        sharded.dist = real_dist
+
+
+if __name__ == "__main__":
+    emulated(int(sys.argv[1]) if len(sys.argv) > 1 else 8, sys.argv[2] if len(sys.argv) > 2 else "P", verbose=True)
