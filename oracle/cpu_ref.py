@@ -215,6 +215,24 @@ def debias_combined(nuv, position, user_emb, params: Params):
     return nuv / e_user, user_loss + pos_loss
 
 
+def debias_position(nuv, position, user_emb, params: Params):
+    """ref:src/two_tower_with_position_debiased_weights.py:76-113: prior = Embedding(100, 1)[position]; sum-MSE of the
+    raw prior; divide by clamp(prior, 1e-3)."""
+    e_pos = params["position_bias_net_user_value.weight"][position].squeeze(1)  # [B]
+    loss = ((e_pos - nuv) ** 2).sum()
+    return nuv / torch.clamp(e_pos, min=1e-3), loss
+
+
+def debias_user(nuv, position, user_emb, params: Params):
+    """ref:src/two_tower_with_user_debiased_weights.py:102-135: prior = clamp(Linear(DI -> 1)(user_emb), 0.1) -- the
+    clamp BEFORE the sum-MSE --, divide by it."""
+    w = params["user_debias_net_user_value.0.weight"]  # [1, DI]
+    b = params["user_debias_net_user_value.0.bias"]
+    e_user = torch.clamp((user_emb @ w.t() + b).squeeze(1), min=1e-1)
+    loss = ((e_user - nuv) ** 2).sum()
+    return nuv / e_user, loss
+
+
 def training_loss(
     user_emb: torch.Tensor,
     item_emb: torch.Tensor,

@@ -26,6 +26,8 @@ import fixture_gen as fg  # noqa: E402
 from src.baseline_mips_module import BaselineMIPSModule  # noqa: E402
 from src.two_tower_base_retrieval import TwoTowerBaseRetrieval  # noqa: E402
 from src.two_tower_with_debiasing import TwoTowerWithDebiasing  # noqa: E402
+from src.two_tower_with_position_debiased_weights import TwoTowerWithPositionDebiasedWeights  # noqa: E402
+from src.two_tower_with_user_debiased_weights import TwoTowerWithUserDebiasedWeights  # noqa: E402
 from src.two_tower_with_user_history_encoder import TwoTowerWithUserHistoryEncoder  # noqa: E402
 from src.user_history_encoder import UserHistoryEncoder  # noqa: E402
 
@@ -183,7 +185,8 @@ def hist_model_case(name, *, n_users, du, iu, n_items, di, ii, T, uvw, B, H, deb
     mips = BaselineMIPSModule(corpus_size=64 if corpus is None else corpus.shape[0], embedding_dim=di)
     if corpus is not None:
         mips.corpus = t(corpus)
-    cls = TwoTowerWithDebiasing if debias else TwoTowerWithUserHistoryEncoder
+    cls = {False: TwoTowerWithUserHistoryEncoder, True: TwoTowerWithDebiasing, "position": TwoTowerWithPositionDebiasedWeights,
+           "user": TwoTowerWithUserDebiasedWeights}[debias]
     model = cls(
         num_items=topk, user_id_hash_size=n_users, user_id_embedding_dim=du,
         user_features_size=iu, user_history_seqlen=H, item_id_hash_size=n_items,
@@ -275,6 +278,11 @@ if __name__ == "__main__":
                         T=1, uvw=[1.0], B=160, H=4)
         mips_wide_case()
         sys.exit(0)
+    if "--only-g8" in sys.argv:  # the round-3 additions alone
+        for kind in ("position", "user"):
+            hist_model_case(f"g8_debias_{kind}", n_users=120, du=64, iu=8, n_items=140, di=64, ii=8,
+                            T=2, uvw=[0.6, 0.4], B=48, H=12, debias=kind)
+        sys.exit(0)
     base_model_case("g1_base_tiny", n_users=100, du=50, iu=20, n_items=150, di=40, ii=30,
                     T=3, uvw=[0.1, 0.2, 0.3], B=32, H=8)
     base_model_case("g2_base_aligned", n_users=256, du=128, iu=8, n_items=256, di=128, ii=8,
@@ -292,6 +300,10 @@ if __name__ == "__main__":
     corpus = fg.bf16_round(fg.gaussianish((4096, 128), 901))
     hist_model_case("g6_debias_d128", n_users=256, du=128, iu=8, n_items=256, di=128, ii=8,
                     T=1, uvw=[1.0], B=64, H=50, debias=True, corpus=corpus, topk=10)
+    # the two single-term debias heads (SURVEY 8f item 2's siblings): B = 48, positions 0..9, T = 2
+    for kind in ("position", "user"):
+        hist_model_case(f"g8_debias_{kind}", n_users=120, du=64, iu=8, n_items=140, di=64, ii=8,
+                        T=2, uvw=[0.6, 0.4], B=48, H=12, debias=kind)
     base_model_case("g2_base_d256", n_users=96, du=256, iu=8, n_items=128, di=256, ii=8,
                     T=1, uvw=[1.0], B=160, H=4)
     mips_wide_case()

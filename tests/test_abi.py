@@ -72,5 +72,15 @@ def test_module_surface_matches_reference_names():
               "position_bias_net_user_value.weight", "user_debias_net_user_value.0.weight"):
         assert k in keys, k
     assert m.user_tower_arch.weight.shape == (8, 2 * 8 + 2 * 8)
+    # the two single-term siblings: same constructor keywords, one extra parameter tensor (pair) each
+    kw = ["num_items", "user_id_hash_size", "user_id_embedding_dim", "user_features_size", "user_history_seqlen",
+          "item_id_hash_size", "item_id_embedding_dim", "item_features_size", "user_value_weights", "mips_module"]
+    for cls, extra in ((A.TwoTowerWithPositionDebiasedWeights, {"position_bias_net_user_value.weight": (100, 1)}),
+                       (A.TwoTowerWithUserDebiasedWeights, {"user_debias_net_user_value.0.weight": (1, 8),
+                                                            "user_debias_net_user_value.0.bias": (1,)})):
+        assert list(inspect.signature(cls.__init__).parameters)[1:] == kw
+        sd = cls(4, 10, 8, 4, 6, 10, 8, 4, [1.0], mips).state_dict()
+        assert set(sd) - set(A.TwoTowerWithUserHistoryEncoder(4, 10, 8, 4, 6, 10, 8, 4, [1.0], mips).state_dict()) == set(extra)
+        assert all(tuple(sd[k].shape) == shp for k, shp in extra.items())
     enc = A.UserHistoryEncoder(8, 6, 2, 1, True)
     assert enc.get_output_dim() == 16 and enc.positional_embeddings.shape == (6, 8)

@@ -38,6 +38,10 @@ def make_model(kind, g, corpus=None, topk=10):
         m = A.TwoTowerBaseRetrieval(**common)
     elif kind == "hist":
         m = A.TwoTowerWithUserHistoryEncoder(user_history_seqlen=H, **common)
+    elif kind == "position":
+        m = A.TwoTowerWithPositionDebiasedWeights(user_history_seqlen=H, **common)
+    elif kind == "user":
+        m = A.TwoTowerWithUserDebiasedWeights(user_history_seqlen=H, **common)
     else:
         m = A.TwoTowerWithDebiasing(user_history_seqlen=H, **common)
     missing, unexpected = m.load_state_dict(state_of(g), strict=True) if True else (None, None)
@@ -244,6 +248,32 @@ def test_history_model_dense_exact_adam_runs_and_matches_torch_adam(golden):
     for (k, v1), (_, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
         noise_only = k in ("item_tower_arch.bias", "item_features_arch.2.bias")
         assert torch.allclose(v1, v2, atol=4.4e-3 if noise_only else 5e-6, rtol=1e-5), k
+
+
+@pytest.mark.parametrize("kind", ["position", "user"])
+def test_single_term_debias_models_loss_and_grads(golden, kind):
+    """TwoTowerWithPositionDebiasedWeights / TwoTowerWithUserDebiasedWeights (ref:src/two_tower_with_position_debiased_weights.py,
+    ref:src/two_tower_with_user_debiased_weights.py): reference parameters loaded by name, loss 1e-4 and every gradient
+    -- incl. the head's, which flow through the example weights and through the batch maximum -- vs the reference."""
+    g = golden(f"g8_debias_{kind}")
+    model = make_model(kind, g)
+    loss = model.train_forward(*batch_of(g))
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"]))), (loss.item(), float(g["loss"]))
+    loss.backward()
+    check_grads(model, g)
+    # one optimiser step moves the head as torch.optim.Adam moves it: first step = -lr * sign(g) where g is not noise
+    import two_tower_models_amd as A
+    head = model.position_bias_net_user_value.weight if kind == "position" else model.user_debias_net_user_value[0].weight
+    before, grad = head.detach().clone(), head.grad.detach().clone()
+    opt = A.DenseExactAdam(model.parameters(), lr=1e-3)
+    loss2 = model.train_forward(*batch_of(g))
+    opt.zero_grad()
+    loss2.backward()
+    opt.step()
+    moved = (head.detach() - before)
+    big = grad.abs() > 1e-4 * float(grad.abs().max())
+    assert torch.allclose(moved[big], -1e-3 * torch.sign(grad[big]), atol=2e-6)
+    assert float(moved[grad == 0].abs().max() if bool((grad == 0).any()) else 0.0) == 0.0
 
 
 def test_debias_model_loss_and_grads(golden):

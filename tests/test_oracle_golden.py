@@ -157,6 +157,21 @@ def test_debias_model_loss_grads_and_topk(golden):
     assert np.array_equal(idx.numpy()[gate], g["top_items"][gate])
 
 
+@pytest.mark.parametrize("kind", ["position", "user"])
+def test_single_term_debias_heads_loss_and_grads(golden, kind):
+    """The two sibling heads of SURVEY 8f item 2 (ref:src/two_tower_with_position_debiased_weights.py:76-113, clamp 1e-3
+    after the MSE; ref:src/two_tower_with_user_debiased_weights.py:102-135, clamp 1e-1 before it): loss and every
+    gradient, including the head's own parameters, against fixtures produced by the reference classes."""
+    g = golden(f"g8_debias_{kind}")
+    leaves = {k: v.requires_grad_(True) for k, v in params_of(g).items()}
+    kw = dict(with_history=True, heads=4, pos_table=T(g["pe_table"]))
+    loss = R.train_forward(leaves, batch_of(g), T(g["uvw"]), debias=R.debias_position if kind == "position" else R.debias_user, **kw)
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
+    for k, gr in grads_of(loss, leaves).items():
+        want = T(g["g." + k])
+        assert torch.allclose(gr, want, atol=1e-5 * max(1.0, float(want.abs().max())), rtol=2e-4), k
+
+
 # ---------------------------------------------------------------- MIPS
 @pytest.mark.parametrize("C", [4096, 65536])
 @pytest.mark.parametrize("K", [10, 1000])

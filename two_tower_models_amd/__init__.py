@@ -5,10 +5,13 @@ from .graphs import GraphedTrainStep
 from .optim import DenseExactAdam
 from .two_tower_base_retrieval import TwoTowerBaseRetrieval
 from .two_tower_with_debiasing import TwoTowerWithDebiasing
+from .two_tower_with_position_debiased_weights import TwoTowerWithPositionDebiasedWeights
+from .two_tower_with_user_debiased_weights import TwoTowerWithUserDebiasedWeights
 from .two_tower_with_user_history_encoder import TwoTowerWithUserHistoryEncoder
 from .user_history_encoder import UserHistoryEncoder
 
 __all__ = [
     "BaselineMIPSModule", "DenseExactAdam", "GraphedTrainStep", "TwoTowerBaseRetrieval", "TwoTowerWithDebiasing",
-    "TwoTowerWithUserHistoryEncoder", "UserHistoryEncoder",
+    "TwoTowerWithPositionDebiasedWeights", "TwoTowerWithUserDebiasedWeights", "TwoTowerWithUserHistoryEncoder",
+    "UserHistoryEncoder",
 ]

@@ -1,0 +1,34 @@
+"""TwoTowerWithPositionDebiasedWeights on MI355X (mirror of ref:src/two_tower_with_position_debiased_weights.py:16-113).
+
+The history model with ONE extra parameter tensor -- a scalar prior of the net user value per position bucket,
+`position_bias_net_user_value` Embedding(100, 1) (ref :72-74) -- and its `debias_net_user_value` hook (ref :76-113).
+Lookups, towers, encoder, in-batch logits / CE and the optimiser are the inherited HIP path; the hook itself is five
+[B]-sized tensor expressions and runs as such on the GPU (the general branch of
+TwoTowerBaseRetrieval.compute_training_loss, which keeps every hook override exact)."""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+import torch.nn as nn
+
+from .two_tower_with_user_history_encoder import TwoTowerWithUserHistoryEncoder
+
+
+class TwoTowerWithPositionDebiasedWeights(TwoTowerWithUserHistoryEncoder):
+    # constructor keywords = ref :29-41
+    def __init__(self, num_items: int, user_id_hash_size: int, user_id_embedding_dim: int, user_features_size: int,
+                 user_history_seqlen: int, item_id_hash_size: int, item_id_embedding_dim: int,
+                 item_features_size: int, user_value_weights: List[float], mips_module: nn.Module) -> None:
+        super().__init__(num_items, user_id_hash_size, user_id_embedding_dim, user_features_size,
+                         user_history_seqlen, item_id_hash_size, item_id_embedding_dim, item_features_size,
+                         user_value_weights, mips_module)
+        self.position_bias_net_user_value = nn.Embedding(100, 1)
+
+    def debias_net_user_value(self, net_user_value: torch.Tensor, position: torch.Tensor,
+                              user_embedding: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(value / max(position prior, 1e-3), sum of squared prior errors): the auxiliary loss sees the RAW prior,
+        the division its clamped copy (ref :95-113)."""
+        prior = self.position_bias_net_user_value.weight[position, 0]  # [B]
+        aux = torch.sum((prior - net_user_value) ** 2)
+        return net_user_value / prior.clamp(min=1e-3), aux
