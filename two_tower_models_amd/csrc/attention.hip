@@ -137,6 +137,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 
 // fast path, attention_mfma.hip
 bool attn_mfma_supported(const void* a, const void* b, int64_t H, int64_t D, int64_t dh);
+// one sample per 8-wave workgroup (attention_wg.hip): 4 heads x 32, H <= 56
+bool attn_bwd_wg_supported(const void* qkv, const void* ctx, const void* d_ctx, const void* d_qkv, int64_t H, int64_t D,
+                           int64_t heads);
+int attn_bwd_wg(const float* qkv, const float* ctx, const float* lse, const float* d_ctx, int64_t B, int64_t H, float* d_qkv,
+                hipStream_t st);
 int attn_fwd_mfma(const float* qkv, int64_t B, int64_t H, int64_t D, int64_t heads, float* ctx, float* lse, hipStream_t st);
 int attn_bwd_mfma(const float* qkv, const float* lse, const float* d_ctx, int64_t B, int64_t H, int64_t D,
                   int64_t heads, float* d_qkv, hipStream_t st);
@@ -294,6 +299,7 @@ extern "C" int tt_attn_bwd(const float* qkv, const float* ctx, const float* lse,
   if (B < 0 || H <= 0 || D <= 0 || heads <= 0 || D % heads != 0) return fail_arg("tt_attn_bwd: sizes");
   if (B == 0) return 0;
   const int64_t dh = D / heads;
+  if (attn_bwd_wg_supported(qkv, ctx, d_ctx, d_qkv, H, D, heads)) return attn_bwd_wg(qkv, ctx, lse, d_ctx, B, H, d_qkv, S(stream));
   if (attn_mfma_supported(qkv, d_ctx, H, D, dh) && (reinterpret_cast<uintptr_t>(d_qkv) & 15) == 0)
     return attn_bwd_mfma(qkv, lse, d_ctx, B, H, D, heads, d_qkv, S(stream));
   const int dhp = pick_dhp(dh);
