@@ -483,7 +483,11 @@ def test_hist_embed_pool(T, D, H, B):
 @pytest.mark.parametrize("layout", [0, 1])
 @pytest.mark.parametrize("M,Nn,K", [(20000, 384, 128), (16389, 130, 100), (16384, 128, 256), (17000, 50, 200),
                                     (16500, 128, 384), (16390, 70, 300),
-                                    (40000, 128, 32), (16400, 257, 64)])
+                                    (40000, 128, 32), (16400, 257, 64),
+                                    # N = 128 exactly, K in {128, 256, 384}: gemm_ws16.hip (16 columns per wave, three-stage ring);
+                                    # ragged last stages (rows % 32 / 48 / 96 != 0) and a single-stage problem per workgroup
+                                    (204800, 128, 128), (16385, 128, 128), (20001, 128, 256), (33333, 128, 384),
+                                    (204800, 384, 128), (17777, 384, 128), (30001, 256, 128)])
 def test_gemm_weights_stationary_path(T, layout, M, Nn, K):
     """M >= 16384 and K <= 256 route NT / NN products to gemm_ws.hip (LDS-DMA when K is 32/64/128/256
     and rows are aligned, register staging otherwise); epilogues, strides and accumulate included."""

@@ -388,6 +388,9 @@ static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 int gemm_ws_try(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W,
                 int64_t ldw, float* C, int64_t ldc, const float* bias, int epilogue, const float* aux,
                 int64_t ldaux, int accumulate, hipStream_t st);
+// tall-M products with exactly 128 output columns, K in {128, 256, 384} (gemm_ws16.hip); -100 = "not applicable"
+int gemm_ws16_try(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
+                  float* C, int64_t ldc, const float* bias, int epilogue, int accumulate, hipStream_t st);
 // huge-K TN products with a register-resident result (gemm_tn_stream.hip); -100 = "not applicable"
 int64_t gemm_tn_stream_ws_floats(int64_t M, int64_t N, int64_t K);
 int gemm_tn_stream_try(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
@@ -424,6 +427,8 @@ static int gemm_impl(int layout, int64_t M, int64_t N, int64_t K, const float* A
     if (rc_st != -100) return rc_st;
   }
   if (!a_colsum) {
+    const int rc_16 = gemm_ws16_try(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, accumulate, S(stream));
+    if (rc_16 != -100) return rc_16;
     const int rc_ws = gemm_ws_try(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, aux, ldaux, accumulate, S(stream));
     if (rc_ws != -100) return rc_ws;
   }
