@@ -144,15 +144,37 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void attn_fwd_mfm
   const int64_t b = pair / heads, hd = pair % heads;
   const float* base = qkv + b * H * 3 * (int64_t)D + hd * DH;
   const float scale = 1.0f / sqrtf((float)DH);
-  stage<DH>(Ks, base + D, 3 * D, H, 1.f, lane);
-  stage<DH>(Vs, base + 2 * D, 3 * D, H, 1.f, lane);
+  // every global load of the pair goes out BEFORE the first wait: K and V rows for the LDS images and the Q fragments
+  // of both query tiles.  (Staged one after the other -- K, V, then Q per tile -- the wave sat out four memory round
+  // trips per pair with one partner wave to cover them: 136 us per layer against 55 us of MFMA time.)
+  constexpr int C4 = DH / 4, NST = HP * C4 / 64;
+  float4 kst[NST], vst[NST];
+#pragma unroll
+  for (int it = 0; it < NST; ++it) {
+    const int f = it * 64 + lane, row = f / C4, c4 = f % C4;
+    const float* pr = base + (int64_t)(row < H ? row : H - 1) * (3 * D) + 4 * c4;
+    kst[it] = *reinterpret_cast<const float4*>(pr + D);
+    vst[it] = *reinterpret_cast<const float4*>(pr + 2 * D);
+  }
+  float4 qf0[DH / 8], qf1[DH / 8];  // (two named arrays: a reference to a row of a 2-D array keeps the whole array in scratch memory)
+  load_bfrag<DH>(qf0, base, 3 * D, r, H, scale, h);
+  load_bfrag<DH>(qf1, base, 3 * D, 32 + r, H, scale, h);
+#pragma unroll
+  for (int it = 0; it < NST; ++it) {
+    const int f = it * 64 + lane, row = f / C4, c4 = f % C4;
+    const bool ok = row < H;
+    // (by value, then masked: `ok ? kst[it] : z` selects between ADDRESSES of two structs and parks the arrays in scratch)
+    float4 kv = kst[it], vv = vst[it];
+    const float m = ok ? 1.f : 0.f;
+    kv.x *= m; kv.y *= m; kv.z *= m; kv.w *= m;
+    vv.x *= m; vv.y *= m; vv.z *= m; vv.w *= m;
+    *reinterpret_cast<float4*>(Ks + row * L::LD + 4 * c4) = kv;
+    *reinterpret_cast<float4*>(Vs + row * L::LD + 4 * c4) = vv;
+  }
   __builtin_amdgcn_wave_barrier();
 
   float* out = ctx + b * H * (int64_t)D + hd * DH;
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {  // 32 queries at a time: lane r <-> query it*32 + r
-    float4 qf[DH / 8];
-    load_bfrag<DH>(qf, base, 3 * D, it * 32 + r, H, scale, h);
+  auto query_tile = [&](int it, const float4 (&qf)[DH / 8]) {  // 32 queries at a time: lane r <-> query it*32 + r
     f32x16 st[2];
     float mx = -3.0e38f;
 #pragma unroll
@@ -190,7 +212,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void attn_fwd_mfm
     store_rows<DH>(out, D, o, it * 32, H, 1.f, r, h);
     const int i = it * 32 + r;
     if (h == 0 && i < H) lse[(b * heads + hd) * H + i] = mx + __logf(l);
-  }
+  };
+  query_tile(0, qf0);
+  query_tile(1, qf1);
 }
 
 // ------------------------------------------------------------------ backward

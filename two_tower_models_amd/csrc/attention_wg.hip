@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_wg_kernel(const AttnWgArgs p)
       }                                                                                             \
       sl = p.lse[((BB) * HEADS + head) * H + (lane < H ? lane : 0)];                                \
     } while (0)
-    auto dot8 = [](const float4& x, const float4& y, bool ok) {  // sum over the 8 lanes that hold one head's 32 columns of a row
+    auto dot8 = [](const float4 x, const float4 y, bool ok) {  // sum over the 8 lanes that hold one head's 32 columns of a row
       float part = ok ? x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w : 0.f;
       part += __shfl_xor(part, 1, 64);
       part += __shfl_xor(part, 2, 64);
@@ -138,7 +138,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_wg_kernel(const AttnWgArgs p)
         if (ok) {
           const int off = hh * IMG + row * LD + 4 * cc;
           *reinterpret_cast<float4*>(Qs + off) = make_float4(sq[k].x * scale, sq[k].y * scale, sq[k].z * scale, sq[k].w * scale);
-          *reinterpret_cast<float4*>(Ks + off) = sk[k];
+          // (member by member: a whole-struct copy out of the array is a memcpy from an alloca, and the array then stays in scratch)
+          *reinterpret_cast<float4*>(Ks + off) = make_float4(sk[k].x, sk[k].y, sk[k].z, sk[k].w);
           *reinterpret_cast<float4*>(Gs + off) = sg[k];
           if (cc == 0) Ds[hh * 64 + row] = part;
         }
