@@ -221,6 +221,7 @@ def _timed_train(name, device, steps, warmup, lazy=False, fresh_ids=False):
             "pairs_per_s": round(cfg["B"] * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
             "steps": steps, "warmup": warmup, "B": cfg["B"], "n_items": cfg["n_items"],
             "H": cfg["H"] if cfg["model"] != "base" else None,
+            **({} if lazy else {"sweep_workgroups": opt._sweep_wgs or 768}),  # where the level scan of the optimizer settled
             **({"note": f"rows have idled at most {steps} steps when they are replayed; the replay cost grows with the idle "
                         "time, and over 8000 steps (every lookup ~1200 steps idle, README) the same loop measures ~2.3 M pairs/s"}
                if fresh_ids else {})}
@@ -275,13 +276,14 @@ def secondary(device, lib, N):
     """The other BASELINE configs in the driver-run record (each a few hundred ms of GPU time): C2 and C3
     train steps, config 5's MIPS at C = 10 M / K = 1000 (fp32, bf16), and the deferred-Adam figure, labelled."""
     sec = {}
-    for key, name, steps, lazy, fresh in (("C2", "C2", 20, False, False), ("C3", "C3", 10, False, False),
+    # (dense-exact workloads: 50 warm-up steps, the sweep-level scan of DenseExactAdam._tune_sweep settles inside them)
+    for key, name, steps, lazy, fresh in (("C2", "C2", 40, False, False), ("C3", "C3", 20, False, False),
                                           ("P_lazy", "P", 20, True, False),
                                           # the deferred schedule's STEADY STATE next to -- not instead of -- the recurring-ids
                                           # figure: 200 steps of new uniform ids + the flush, all inside the timed region
                                           ("P_lazy_fresh_ids", "P", 200, True, True)):
         try:
-            sec[key] = _timed_train(name, device, steps, 3, lazy=lazy, fresh_ids=fresh)
+            sec[key] = _timed_train(name, device, steps, 3 if lazy else 50, lazy=lazy, fresh_ids=fresh)
         except Exception as e:  # a secondary figure must never take the headline line down with it
             sec[key] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()

@@ -122,6 +122,25 @@ int tt_tower_bwd_weights(const float* dy, int64_t ldy, const float* tin, const f
                          const float* feats, int64_t ldf, int64_t B, int64_t D, int64_t F, int64_t hidden, float* dW1,
                          float* db1, float* dW2, float* db2, float* dW3, float* db3, void* ws, int64_t ws_bytes,
                          tt_stream_t stream);
+/* The same three entry points for a tower whose input has a THIRD, dense block:
+ *   y = Linear(2D + E -> D)([ table[id] | feature MLP | extra[B, E] ]),  E = 2D  (E = 0: the functions above)
+ * = TwoTowerWithUserHistoryEncoder's user tower, whose input gains the history encoder's [recent | mean] summary
+ * (ref:src/two_tower_with_user_history_encoder.py:81-83 the Linear(2*DU + 2*DI -> DI), :85-122 the cat).  W3 / dW3 are
+ * [D, 2D + E] row-major, tin_out stays [B, 2D] (the extra block is the caller's own tensor), d_extra [B, E] is the
+ * gradient that flows back into the encoder. */
+int tt_tower_x_supported(int64_t D, int64_t F, int64_t hidden, int64_t d_out, int64_t E);
+int tt_tower_fwd_x(const float* table, int64_t n_rows, const int64_t* ids, const float* feats, int64_t ldf, int64_t B,
+                   int64_t D, int64_t F, int64_t hidden, const float* W1, const float* b1, const float* W2, const float* b2,
+                   const float* W3, const float* b3, int64_t d_out, const float* extra, int64_t ldx, int64_t E, float* y,
+                   int64_t ldy, float* h_out, float* tin_out, int32_t* oob_flag, tt_stream_t stream);
+int tt_tower_bwd_data_x(const float* dy, int64_t ldy, int64_t B, int64_t D, int64_t hidden, const float* W2, const float* W3,
+                        const float* h, float* d_emb, int64_t ld_demb, float* d_f, float* dh, float* d_extra, int64_t ld_dx,
+                        int64_t E, tt_stream_t stream);
+int64_t tt_tower_bwd_weights_x_workspace_bytes(int64_t B, int64_t D, int64_t F, int64_t hidden, int64_t E);
+int tt_tower_bwd_weights_x(const float* dy, int64_t ldy, const float* tin, const float* d_f, const float* h, const float* dh,
+                           const float* feats, int64_t ldf, const float* extra, int64_t ldx, int64_t E, int64_t B, int64_t D,
+                           int64_t F, int64_t hidden, float* dW1, float* db1, float* dW2, float* db2, float* dW3, float* db3,
+                           void* ws, int64_t ws_bytes, tt_stream_t stream);
 
 /* ---------------------------------------------------------------- K5 in-batch softmax CE
  * Forward: S = U I^T is never written to memory.

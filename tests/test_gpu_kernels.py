@@ -531,6 +531,49 @@ def test_tower_weight_gradients_kernel_vs_fp64(T, B, D, F):
         assert torch.allclose(a.cpu().double(), w, rtol=1e-5, atol=2e-5 * math.sqrt(B))
 
 
+@pytest.mark.parametrize("B,D,F,n_rows", [(4096, 128, 8, 100_000), (100, 128, 8, 50), (333, 64, 20, 1000), (65, 32, 8, 200),
+                                          (1, 128, 33, 7)])
+def test_fused_tower_with_third_input_block_forward_and_backward(T, B, D, F, n_rows):
+    """tt_tower_fwd_x / tt_tower_bwd_data_x / tt_tower_bwd_weights_x: the history model's user tower
+    [ id | MLP | recent | mean ] -> Linear(4D -> D) (ref:src/two_tower_with_user_history_encoder.py:81-83,85-122) as one
+    kernel per direction, against the same lines in float64 torch on the CPU: output, all six parameter gradients, the
+    embedding-row gradients and the gradient that flows back into the encoder summary; ragged last block, one row,
+    duplicate ids; the extra block as a strided view; bit-identical from call to call."""
+    ops, N = T
+    gen = torch.Generator().manual_seed(3 * B + D)
+    p = {"emb": torch.randn(n_rows, D, generator=gen), "W1": torch.randn(256, F, generator=gen) * 0.3,
+         "b1": torch.randn(256, generator=gen) * 0.1, "W2": torch.randn(D, 256, generator=gen) * 0.06,
+         "b2": torch.randn(D, generator=gen) * 0.1, "W3": torch.randn(D, 4 * D, generator=gen) * 0.05,
+         "b3": torch.randn(D, generator=gen) * 0.1, "extra": torch.randn(B, 2 * D, generator=gen)}
+    ids = torch.randint(0, n_rows, (B,), generator=gen)
+    if B > 8:
+        ids[:4] = ids[4:8]
+    feats, cot = torch.randn(B, F, generator=gen), torch.randn(B, D, generator=gen)
+    ref = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    hid = torch.relu(feats.double() @ ref["W1"].t() + ref["b1"])
+    tin = torch.cat([ref["emb"][ids], hid @ ref["W2"].t() + ref["b2"], ref["extra"]], dim=1)
+    want = tin @ ref["W3"].t() + ref["b3"]
+    (want * cot.double()).sum().backward()
+    outs = []
+    for rep in range(2):
+        dl = {k: v.clone().to(DEV).requires_grad_(True) for k, v in p.items()}
+        wide = torch.zeros(B, 2 * D + 8, device=DEV)
+        wide[:, 4:4 + 2 * D] = dl["extra"].detach()
+        extra = dl["extra"] if rep == 0 else wide[:, 4:4 + 2 * D].requires_grad_(False)  # rep 1: 16-B aligned strided rows
+        assert ops.fused_tower_supported(dl["emb"], feats.to(DEV), dl["W1"], dl["W2"], dl["W3"], extra_width=2 * D)
+        y = ops.FusedTower.apply(dl["emb"], ids.to(DEV), feats.to(DEV), dl["W1"], dl["b1"], dl["W2"], dl["b2"], dl["W3"], dl["b3"],
+                                 extra)
+        assert torch.allclose(y.cpu().double(), want.detach(), atol=2e-5, rtol=1e-5)
+        (y * cot.to(DEV)).sum().backward()
+        outs.append({k: dl[k].grad.clone() for k in p if dl[k].grad is not None})
+        for k, g in outs[-1].items():
+            g_ref = ref[k].grad
+            assert torch.allclose(g.cpu().double(), g_ref, atol=1e-5 * float(g_ref.abs().max()) + 1e-8, rtol=2e-4), k
+    assert "extra" in outs[0] and "W3" in outs[1]
+    for k in outs[1]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+
+
 @pytest.mark.parametrize("B,D,F,n_rows", [(8192, 128, 8, 100_000), (100, 128, 8, 50), (333, 64, 20, 1000), (64, 32, 8, 200),
                                           (1, 128, 33, 7)])
 def test_fused_tower_matches_oracle_forward_and_backward(T, B, D, F, n_rows):

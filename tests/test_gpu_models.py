@@ -286,7 +286,10 @@ def test_debias_model_loss_and_grads(golden):
         loss = model.train_forward(*batch_of(g))
     assert abs(loss.item() - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
     loss.backward()
-    check_grads(model, g, rtol=5e-4)
+    # atol 4e-5 of max|g|: the sum-MSE debias terms put O(100) addends that cancel into d(user embedding); column 36 of
+    # user_tower_arch.weight's gradient (max|g| 4.3) then differs from the float32 CPU reference by 1.0-1.3e-4 whichever
+    # product path computes it (generic GEMM 1.06e-4, fused tower 1.24e-4: rounding order, not a defect)
+    check_grads(model, g, rtol=5e-4, atol_scale=4e-5)
 
 
 @pytest.mark.parametrize("kind,name", [("base", "g2_base_aligned"), ("hist", "g4_hist_d128")])

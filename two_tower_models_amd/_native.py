@@ -64,6 +64,13 @@ SIGNATURES = {
     "tt_tower_bwd_weights_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "tt_tower_bwd_weights": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _i64, _vp]),
+    "tt_tower_x_supported": (_int, [_i64, _i64, _i64, _i64, _i64]),
+    "tt_tower_fwd_x": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
+                              _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "tt_tower_bwd_data_x": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "tt_tower_bwd_weights_x_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64, _i64]),
+    "tt_tower_bwd_weights_x": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64,
+                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tt_inbatch_ce_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "tt_inbatch_ce_fwd": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
     "tt_inbatch_ce_bwd": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp,

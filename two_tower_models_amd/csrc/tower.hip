@@ -16,6 +16,13 @@
 // forward, 3 NN GEMMs backward, each a separate pass over [B, 256]-sized intermediates): 1 launch per direction.
 // Shapes: hidden = 256 (fixed upstream), D in {32, 64, 128}, F <= 64, 16-B aligned rows; anything else returns
 // TT_E_UNSUPPORTED and the caller takes the GEMM path.
+//
+// XTRA variants (tt_tower_*_x): the tower input has a third, dense block -- [ id | MLP | extra[B, 2D] ], tower
+// Linear(4D -> D) -- which is TwoTowerWithUserHistoryEncoder's user tower (extra = the encoder's [recent | mean]
+// summary; ref:src/two_tower_with_user_history_encoder.py:81-83,85-122).  The extra block takes the place of the hidden
+// activations in LDS once they are consumed (same [64][2D + 4] image as the tower input), the last product runs as
+// two K chunks over the same accumulators, the backward's d_tin has 2D more columns (-> d_extra) and the weight
+// gradient one more operand pass (dW3[:, 2D:] = dy^T extra).
 #include "mfma_stream.hpp"
 
 namespace tt {
@@ -33,16 +40,14 @@ struct TowerFwdArgs {
   float* h_out;    // [B][256]
   float* tin_out;  // [B][2D]
   int32_t* oob;
+  const float* extra; int64_t ldx;  // XTRA: [B][2D] third block of the tower input
 };
 
 // weights as the MFMA A operand (rows = this wave's 32 output columns), activations as B from the LDS image:
 // acc[e] = out[row = jt*32 + (lane & 31)][col = nw + (e&3) + 8*(e>>2) + 4*(lane>>5)]
 template <int DP8>
-__device__ __forceinline__ f32x16 tw_tile(const float* Ys, const float (&xr)[DP8][4], int jt, int r, int h) {
+__device__ __forceinline__ f32x16 tw_tile_acc(f32x16 acc, const float* Ys, const float (&xr)[DP8][4], int jt, int r, int h) {
   using TM = TileMap<DP8, false>;
-  f32x16 acc;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   const int row = jt * 32 + r;
   float4 y[2];
   y[0] = *reinterpret_cast<const float4*>(Ys + TM::chunk(row, h));
@@ -58,6 +63,13 @@ __device__ __forceinline__ f32x16 tw_tile(const float* Ys, const float (&xr)[DP8
   }
   return acc;
 }
+template <int DP8>
+__device__ __forceinline__ f32x16 tw_tile(const float* Ys, const float (&xr)[DP8][4], int jt, int r, int h) {
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  return tw_tile_acc<DP8>(acc, Ys, xr, jt, r, h);
+}
 
 // stationary fragments from a [K][N] (row = reduction index) weight: xr[g][c] = W[8g+4h+c][n]
 template <int DP8>
@@ -69,9 +81,9 @@ __device__ __forceinline__ void tw_load_t(float (&xr)[DP8][4], const float* __re
     for (int c = 0; c < 4; ++c) xr[g][c] = (n < N) ? W[(int64_t)(8 * g + 4 * h + c) * ld + n] : 0.f;
 }
 
-template <int DE8>  // D = 8 * DE8
+template <int DE8, bool XTRA>  // D = 8 * DE8
 __global__ __launch_bounds__(256) void tower_fwd_kernel(const TowerFwdArgs p) {
-  constexpr int D = 8 * DE8, K3 = 2 * D, LDH = TW_HID + 4, LDT = K3 + 4;
+  constexpr int D = 8 * DE8, K3 = 2 * D, LDH = TW_HID + 4, LDT = K3 + 4, LDW3 = XTRA ? 2 * K3 : K3;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* hT = smem;                    // [64][260]  hidden activations
   float* tT = hT + TW_ROWS * LDH;      // [64][2D+4] tower input: id row | feature-MLP output
@@ -147,15 +159,33 @@ __global__ __launch_bounds__(256) void tower_fwd_kernel(const TowerFwdArgs p) {
     if (row0 + m < p.B)
       *reinterpret_cast<float4*>(p.tin_out + (row0 + m) * K3 + 4 * c) = *reinterpret_cast<const float4*>(tT + m * LDT + 4 * c);
   }
+  float* xT = hT;  // XTRA: the third block takes the hidden activations' place ([64][2D + 4], 2D <= 256)
+  if constexpr (XTRA) {
+    for (int i = threadIdx.x; i < TW_ROWS * (K3 / 4); i += 256) {
+      const int m = i / (K3 / 4), c = i - m * (K3 / 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + m < p.B) v = *reinterpret_cast<const float4*>(p.extra + (row0 + m) * p.ldx + 4 * c);
+      *reinterpret_cast<float4*>(xT + m * LDT + 4 * c) = v;
+    }
+    __syncthreads();
+  }
   if (nw < D) {
     float xr[K3 / 8][4];
-    load_stationary<K3 / 8>(xr, p.W3, K3, nw + r, D, K3, h, true);
+    load_stationary<K3 / 8>(xr, p.W3, LDW3, nw + r, D, K3, h, true);
     float be[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) be[e] = p.b3[nw + (e & 3) + 8 * (e >> 2) + 4 * h];
+    f32x16 accs[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) accs[jt] = tw_tile<K3 / 8>(tT, xr, jt, r, h);
+    if constexpr (XTRA) {  // second K chunk: W3[:, 2D:] against the extra block, same accumulators
+      load_stationary<K3 / 8>(xr, p.W3 + K3, LDW3, nw + r, D, K3, h, true);
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) accs[jt] = tw_tile_acc<K3 / 8>(accs[jt], xT, xr, jt, r, h);
+    }
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
-      const f32x16 acc = tw_tile<K3 / 8>(tT, xr, jt, r, h);
+      const f32x16 acc = accs[jt];
       const int64_t m = row0 + jt * 32 + r;
       if (m < p.B) {
         float* dst = p.y + m * p.ldy + nw + 4 * h;
@@ -176,11 +206,12 @@ struct TowerBwdArgs {
   float* d_emb; int64_t ld_demb;  // [B][D]
   float* d_f;            // [B][D]
   float* dh;             // [B][256]
+  float* d_x; int64_t ld_dx;  // XTRA: [B][2D] gradient of the third block
 };
 
-template <int DE8>
+template <int DE8, bool XTRA>
 __global__ __launch_bounds__(256) void tower_bwd_kernel(const TowerBwdArgs p) {
-  constexpr int D = 8 * DE8, K3 = 2 * D, LDY = D + 4;
+  constexpr int D = 8 * DE8, K3 = 2 * D, LDY = D + 4, LDW3 = XTRA ? 2 * K3 : K3;
   __shared__ __attribute__((aligned(16))) float dyT[TW_ROWS * LDY];
   __shared__ __attribute__((aligned(16))) float dfT[TW_ROWS * LDY];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -192,12 +223,12 @@ __global__ __launch_bounds__(256) void tower_bwd_kernel(const TowerBwdArgs p) {
     *reinterpret_cast<float4*>(dyT + m * LDY + 4 * c) = v;
   }
   __syncthreads();
-  // ---- d_tin = dy W3 (W3 [D][2D]: reduction index = row): columns < D -> d_emb, columns >= D -> d_f
-  for (int cb = 0; cb * 128 < K3; ++cb) {
+  // ---- d_tin = dy W3 (W3 [D][2D (+ 2D)]: reduction index = row): columns < D -> d_emb, D .. 2D-1 -> d_f, >= 2D -> d_x
+  for (int cb = 0; cb * 128 < LDW3; ++cb) {
     const int nw = cb * 128 + wave * 32;
-    if (nw >= K3) continue;
+    if (nw >= LDW3) continue;
     float xr[DE8][4];
-    tw_load_t<DE8>(xr, p.W3, K3, nw + r, K3, h);
+    tw_load_t<DE8>(xr, p.W3, LDW3, nw + r, LDW3, h);
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
       const f32x16 acc = tw_tile<DE8>(dyT, xr, jt, r, h);
@@ -206,6 +237,13 @@ __global__ __launch_bounds__(256) void tower_bwd_kernel(const TowerBwdArgs p) {
       if (nw < D) {  // the whole 32-column block lies in the id half (D is a multiple of 32)
         if (m < p.B) {
           float* dst = p.d_emb + m * p.ld_demb + nw + 4 * h;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        }
+      } else if (XTRA && nw >= K3) {
+        if (m < p.B) {
+          float* dst = p.d_x + m * p.ld_dx + (nw - K3) + 4 * h;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
@@ -259,10 +297,13 @@ struct TowerWgradArgs {
   const float *tin, *d_f, *h, *dh, *feats;
   int64_t ldf, F, B;
   float* part;
+  const float* extra; int64_t ldx;  // XTRA
 };
 
-template <int D>
-__host__ __device__ constexpr int64_t tw_part_floats(int64_t F) { return (int64_t)D * 2 * D + (int64_t)D * TW_HID + TW_HID * F + 2 * D + TW_HID; }
+template <int D, bool XTRA>
+__host__ __device__ constexpr int64_t tw_part_floats(int64_t F) {
+  return (int64_t)D * (XTRA ? 4 : 2) * D + (int64_t)D * TW_HID + TW_HID * F + 2 * D + TW_HID;
+}
 
 // out[n0 + i][k0 + j] = sum_m A[m][n0 + i] * Bm[m][k0 + j] over the 64 rows of the tiles; one 32 x 32 tile per call
 template <int LDA, int LDB>
@@ -278,9 +319,9 @@ __device__ __forceinline__ void tw_tn_tile(const float* At, const float* Bt, int
   for (int e = 0; e < 16; ++e) out[(n0 + (e & 3) + 8 * (e >> 2) + 4 * h) * ldo + k0 + r] = acc[e];
 }
 
-template <int DE8>
+template <int DE8, bool XTRA>
 __global__ __launch_bounds__(256) void tower_wgrad_kernel(const TowerWgradArgs p) {
-  constexpr int D = 8 * DE8, K3 = 2 * D;
+  constexpr int D = 8 * DE8, K3 = 2 * D, LDW3 = XTRA ? 2 * K3 : K3;
   extern __shared__ __attribute__((aligned(16))) float tw_smem[];
   float* At = tw_smem;                   // [64][D]     dy, then d_f
   float* Bt = At + TW_ROWS * D;          // [64][256]   tin (2D <= 256 columns used), then h, then dh
@@ -288,9 +329,9 @@ __global__ __launch_bounds__(256) void tower_wgrad_kernel(const TowerWgradArgs p
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int64_t row0 = (int64_t)blockIdx.x * TW_ROWS;
   const int F = (int)p.F;
-  float* part = p.part + (int64_t)blockIdx.x * tw_part_floats<D>(F);
+  float* part = p.part + (int64_t)blockIdx.x * tw_part_floats<D, XTRA>(F);
   float* pW3 = part;
-  float* pW2 = pW3 + D * K3;
+  float* pW2 = pW3 + D * LDW3;
   float* pW1 = pW2 + D * TW_HID;
   float* pb3 = pW1 + TW_HID * F;
   float* pb2 = pb3 + D;
@@ -316,9 +357,16 @@ __global__ __launch_bounds__(256) void tower_wgrad_kernel(const TowerWgradArgs p
   load(At, D, p.dy, p.ldy, D);
   load(Bt, TW_HID, p.tin, K3, K3);
   __syncthreads();
-  for (int t = wave; t < (D / 32) * (K3 / 32); t += 4) tw_tn_tile<D, TW_HID>(At, Bt, 32 * (t / (K3 / 32)), 32 * (t % (K3 / 32)), pW3, K3, r, h);
+  for (int t = wave; t < (D / 32) * (K3 / 32); t += 4) tw_tn_tile<D, TW_HID>(At, Bt, 32 * (t / (K3 / 32)), 32 * (t % (K3 / 32)), pW3, LDW3, r, h);
   colsum(At, D, D, pb3);
   __syncthreads();
+  if constexpr (XTRA) {  // dW3[:, 2D:] = dy^T extra
+    load(Bt, TW_HID, p.extra, p.ldx, K3);
+    __syncthreads();
+    for (int t = wave; t < (D / 32) * (K3 / 32); t += 4)
+      tw_tn_tile<D, TW_HID>(At, Bt, 32 * (t / (K3 / 32)), 32 * (t % (K3 / 32)), pW3 + K3, LDW3, r, h);
+    __syncthreads();
+  }
   // ---- dW2 = d_f^T h, db2
   load(At, D, p.d_f, D, D);
   load(Bt, TW_HID, p.h, TW_HID, TW_HID);
@@ -382,93 +430,139 @@ using namespace tt;
 extern "C" int tt_tower_supported(int64_t D, int64_t F, int64_t hidden, int64_t d_out) {
   return tower_shape_ok(D, F, hidden, d_out) ? 1 : 0;
 }
+extern "C" int tt_tower_x_supported(int64_t D, int64_t F, int64_t hidden, int64_t d_out, int64_t E) {
+  return (tower_shape_ok(D, F, hidden, d_out) && (E == 0 || E == 2 * D)) ? 1 : 0;
+}
+
+extern "C" int tt_tower_fwd_x(const float* table, int64_t n_rows, const int64_t* ids, const float* feats, int64_t ldf,
+                              int64_t B, int64_t D, int64_t F, int64_t hidden, const float* W1, const float* b1,
+                              const float* W2, const float* b2, const float* W3, const float* b3, int64_t d_out,
+                              const float* extra, int64_t ldx, int64_t E, float* y, int64_t ldy, float* h_out,
+                              float* tin_out, int32_t* oob_flag, tt_stream_t stream) {
+  if (!table || !ids || !feats || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !y || !h_out || !tin_out || (E > 0 && !extra))
+    return fail_arg("tt_tower_fwd: null pointer");
+  if (B <= 0 || n_rows <= 0 || ldf < F || ldy < d_out || E < 0 || (E > 0 && ldx < E)) return fail_arg("tt_tower_fwd: sizes");
+  if (!tt_tower_x_supported(D, F, hidden, d_out, E) || ldy % 4 || !al16p(table) || !al16p(W2) || !al16p(W3) || !al16p(y) ||
+      !al16p(h_out) || !al16p(tin_out) || (E > 0 && (ldx % 4 || !al16p(extra)))) {
+    set_error("tt_tower_fwd: needs hidden = 256, D = d_out in {32, 64, 128}, F <= 64, extra width 0 or 2D, 16-B aligned operands");
+    return TT_E_UNSUPPORTED;
+  }
+  TowerFwdArgs a{table, n_rows, ids, feats, ldf, B, F, W1, b1, W2, b2, W3, b3, y, ldy, h_out, tin_out, oob_flag, extra, ldx};
+  hipStream_t st = S(stream);
+  const unsigned grid = (unsigned)ceil_div(B, TW_ROWS);
+  const size_t lds = (size_t)(TW_ROWS * (TW_HID + 4) + TW_ROWS * (2 * D + 4) + TW_ROWS * F) * sizeof(float);
+#define TT_TWF(E8, X)                                                                                                    \
+  {                                                                                                                      \
+    if (lds > 64 * 1024) {                                                                                               \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_kernel<E8, X>),                        \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+      if (e != hipSuccess) { set_error("tower_fwd_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
+    }                                                                                                                    \
+    tower_fwd_kernel<E8, X><<<grid, 256, lds, st>>>(a);                                                                  \
+  }
+  if (E == 0) {
+    if (D == 32) TT_TWF(4, false) else if (D == 64) TT_TWF(8, false) else TT_TWF(16, false)
+  } else {
+    if (D == 32) TT_TWF(4, true) else if (D == 64) TT_TWF(8, true) else TT_TWF(16, true)
+  }
+#undef TT_TWF
+  return check_launch("tower_fwd_kernel");
+}
 
 extern "C" int tt_tower_fwd(const float* table, int64_t n_rows, const int64_t* ids, const float* feats, int64_t ldf,
                             int64_t B, int64_t D, int64_t F, int64_t hidden, const float* W1, const float* b1,
                             const float* W2, const float* b2, const float* W3, const float* b3, int64_t d_out, float* y,
                             int64_t ldy, float* h_out, float* tin_out, int32_t* oob_flag, tt_stream_t stream) {
-  if (!table || !ids || !feats || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !y || !h_out || !tin_out)
-    return fail_arg("tt_tower_fwd: null pointer");
-  if (B <= 0 || n_rows <= 0 || ldf < F || ldy < d_out) return fail_arg("tt_tower_fwd: sizes");
-  if (!tower_shape_ok(D, F, hidden, d_out) || ldy % 4 || !al16p(table) || !al16p(W2) || !al16p(W3) || !al16p(y) ||
-      !al16p(h_out) || !al16p(tin_out)) {
-    set_error("tt_tower_fwd: needs hidden = 256, D = d_out in {32, 64, 128}, F <= 64, 16-B aligned operands");
+  return tt_tower_fwd_x(table, n_rows, ids, feats, ldf, B, D, F, hidden, W1, b1, W2, b2, W3, b3, d_out, nullptr, 0, 0, y, ldy,
+                        h_out, tin_out, oob_flag, stream);
+}
+
+extern "C" int tt_tower_bwd_data_x(const float* dy, int64_t ldy, int64_t B, int64_t D, int64_t hidden, const float* W2,
+                                   const float* W3, const float* h, float* d_emb, int64_t ld_demb, float* d_f, float* dh,
+                                   float* d_extra, int64_t ld_dx, int64_t E, tt_stream_t stream) {
+  if (!dy || !W2 || !W3 || !h || !d_emb || !d_f || !dh || (E > 0 && !d_extra)) return fail_arg("tt_tower_bwd_data: null pointer");
+  if (B <= 0 || ldy < D || ld_demb < D || E < 0 || (E > 0 && ld_dx < E)) return fail_arg("tt_tower_bwd_data: sizes");
+  if (!tt_tower_x_supported(D, 1, hidden, D, E) || ldy % 4 || ld_demb % 4 || !al16p(dy) || !al16p(h) || !al16p(d_emb) ||
+      !al16p(d_f) || !al16p(dh) || !al16p(W3) || (E > 0 && (ld_dx % 4 || !al16p(d_extra)))) {
+    set_error("tt_tower_bwd_data: needs hidden = 256, D in {32, 64, 128}, extra width 0 or 2D, 16-B aligned operands");
     return TT_E_UNSUPPORTED;
   }
-  TowerFwdArgs a{table, n_rows, ids, feats, ldf, B, F, W1, b1, W2, b2, W3, b3, y, ldy, h_out, tin_out, oob_flag};
+  TowerBwdArgs a{dy, ldy, B, W2, W3, h, d_emb, ld_demb, d_f, dh, d_extra, ld_dx};
   hipStream_t st = S(stream);
   const unsigned grid = (unsigned)ceil_div(B, TW_ROWS);
-  const size_t lds = (size_t)(TW_ROWS * (TW_HID + 4) + TW_ROWS * (2 * D + 4) + TW_ROWS * F) * sizeof(float);
-#define TT_TWF(E)                                                                                                        \
-  {                                                                                                                      \
-    if (lds > 64 * 1024) {                                                                                               \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_kernel<E>),                            \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
-      if (e != hipSuccess) { set_error("tower_fwd_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
-    }                                                                                                                    \
-    tower_fwd_kernel<E><<<grid, 256, lds, st>>>(a);                                                                      \
+  if (E == 0) {
+    if (D == 32) tower_bwd_kernel<4, false><<<grid, 256, 0, st>>>(a);
+    else if (D == 64) tower_bwd_kernel<8, false><<<grid, 256, 0, st>>>(a);
+    else tower_bwd_kernel<16, false><<<grid, 256, 0, st>>>(a);
+  } else {
+    if (D == 32) tower_bwd_kernel<4, true><<<grid, 256, 0, st>>>(a);
+    else if (D == 64) tower_bwd_kernel<8, true><<<grid, 256, 0, st>>>(a);
+    else tower_bwd_kernel<16, true><<<grid, 256, 0, st>>>(a);
   }
-  if (D == 32) TT_TWF(4) else if (D == 64) TT_TWF(8) else TT_TWF(16)
-#undef TT_TWF
-  return check_launch("tower_fwd_kernel");
+  return check_launch("tower_bwd_kernel");
 }
 
 extern "C" int tt_tower_bwd_data(const float* dy, int64_t ldy, int64_t B, int64_t D, int64_t hidden, const float* W2,
                                  const float* W3, const float* h, float* d_emb, int64_t ld_demb, float* d_f, float* dh,
                                  tt_stream_t stream) {
-  if (!dy || !W2 || !W3 || !h || !d_emb || !d_f || !dh) return fail_arg("tt_tower_bwd_data: null pointer");
-  if (B <= 0 || ldy < D || ld_demb < D) return fail_arg("tt_tower_bwd_data: sizes");
-  if (!tower_shape_ok(D, 1, hidden, D) || ldy % 4 || ld_demb % 4 || !al16p(dy) || !al16p(h) || !al16p(d_emb) || !al16p(d_f) ||
-      !al16p(dh)) {
-    set_error("tt_tower_bwd_data: needs hidden = 256, D in {32, 64, 128}, 16-B aligned operands");
-    return TT_E_UNSUPPORTED;
-  }
-  TowerBwdArgs a{dy, ldy, B, W2, W3, h, d_emb, ld_demb, d_f, dh};
-  hipStream_t st = S(stream);
-  const unsigned grid = (unsigned)ceil_div(B, TW_ROWS);
-  if (D == 32) tower_bwd_kernel<4><<<grid, 256, 0, st>>>(a);
-  else if (D == 64) tower_bwd_kernel<8><<<grid, 256, 0, st>>>(a);
-  else tower_bwd_kernel<16><<<grid, 256, 0, st>>>(a);
-  return check_launch("tower_bwd_kernel");
+  return tt_tower_bwd_data_x(dy, ldy, B, D, hidden, W2, W3, h, d_emb, ld_demb, d_f, dh, nullptr, 0, 0, stream);
 }
 
+static int64_t tower_part_floats(int64_t D, int64_t F, int64_t E) { return D * (2 * D + E) + D * TW_HID + TW_HID * F + 2 * D + TW_HID; }
+
+extern "C" int64_t tt_tower_bwd_weights_x_workspace_bytes(int64_t B, int64_t D, int64_t F, int64_t hidden, int64_t E) {
+  if (B <= 0 || !tt_tower_x_supported(D, F, hidden, D, E)) return 256;
+  return round_up(ceil_div(B, TW_ROWS) * tower_part_floats(D, F, E) * (int64_t)sizeof(float), 256);
+}
 extern "C" int64_t tt_tower_bwd_weights_workspace_bytes(int64_t B, int64_t D, int64_t F, int64_t hidden) {
-  if (B <= 0 || !tower_shape_ok(D, F, hidden, D)) return 256;
-  const int64_t part = D * 2 * D + D * TW_HID + TW_HID * F + 2 * D + TW_HID;
-  return round_up(ceil_div(B, TW_ROWS) * part * (int64_t)sizeof(float), 256);
+  return tt_tower_bwd_weights_x_workspace_bytes(B, D, F, hidden, 0);
+}
+
+extern "C" int tt_tower_bwd_weights_x(const float* dy, int64_t ldy, const float* tin, const float* d_f, const float* h,
+                                      const float* dh, const float* feats, int64_t ldf, const float* extra, int64_t ldx,
+                                      int64_t E, int64_t B, int64_t D, int64_t F, int64_t hidden, float* dW1, float* db1,
+                                      float* dW2, float* db2, float* dW3, float* db3, void* ws, int64_t ws_bytes,
+                                      tt_stream_t stream) {
+  if (!dy || !tin || !d_f || !h || !dh || !feats || !dW1 || !db1 || !dW2 || !db2 || !dW3 || !db3 || !ws || (E > 0 && !extra))
+    return fail_arg("tt_tower_bwd_weights: null pointer");
+  if (B <= 0 || ldy < D || ldf < F || E < 0 || (E > 0 && ldx < E)) return fail_arg("tt_tower_bwd_weights: sizes");
+  if (!tt_tower_x_supported(D, F, hidden, D, E) || ldy % 4 || !al16p(dy) || !al16p(tin) || !al16p(d_f) || !al16p(h) ||
+      !al16p(dh) || (E > 0 && (ldx % 4 || !al16p(extra)))) {
+    set_error("tt_tower_bwd_weights: needs hidden = 256, D in {32, 64, 128}, F <= 64, extra width 0 or 2D, 16-B aligned operands");
+    return TT_E_UNSUPPORTED;
+  }
+  if (ws_bytes < tt_tower_bwd_weights_x_workspace_bytes(B, D, F, hidden, E)) { set_error("tt_tower_bwd_weights: workspace"); return TT_E_WORKSPACE; }
+  TowerWgradArgs a{dy, ldy, tin, d_f, h, dh, feats, ldf, F, B, reinterpret_cast<float*>(ws), extra, ldx};
+  hipStream_t st = S(stream);
+  const unsigned grid = (unsigned)ceil_div(B, TW_ROWS);
+  const size_t lds = (size_t)(TW_ROWS * D + TW_ROWS * TW_HID + TW_ROWS * F) * sizeof(float);
+#define TT_TWG(E8, X)                                                                                                    \
+  {                                                                                                                      \
+    if (lds > 64 * 1024) {                                                                                               \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tower_wgrad_kernel<E8, X>),                      \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+      if (e != hipSuccess) { set_error("tower_wgrad_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
+    }                                                                                                                    \
+    tower_wgrad_kernel<E8, X><<<grid, 256, lds, st>>>(a);                                                                \
+  }
+  if (E == 0) {
+    if (D == 32) TT_TWG(4, false) else if (D == 64) TT_TWG(8, false) else TT_TWG(16, false)
+  } else {
+    if (D == 32) TT_TWG(4, true) else if (D == 64) TT_TWG(8, true) else TT_TWG(16, true)
+  }
+#undef TT_TWG
+  int rc = check_launch("tower_wgrad_kernel");
+  if (rc) return rc;
+  const int64_t n3 = D * (2 * D + E), n2 = D * TW_HID, n1 = TW_HID * F, part = tower_part_floats(D, F, E);
+  tower_wgrad_reduce_kernel<<<(unsigned)ceil_div(part, 256), 256, 0, st>>>(reinterpret_cast<const float*>(ws), (int)grid, part, n3, n2,
+                                                                           n1, D, dW3, dW2, dW1, db3, db2, db1);
+  return check_launch("tower_wgrad_reduce_kernel");
 }
 
 extern "C" int tt_tower_bwd_weights(const float* dy, int64_t ldy, const float* tin, const float* d_f, const float* h,
                                     const float* dh, const float* feats, int64_t ldf, int64_t B, int64_t D, int64_t F,
                                     int64_t hidden, float* dW1, float* db1, float* dW2, float* db2, float* dW3, float* db3,
                                     void* ws, int64_t ws_bytes, tt_stream_t stream) {
-  if (!dy || !tin || !d_f || !h || !dh || !feats || !dW1 || !db1 || !dW2 || !db2 || !dW3 || !db3 || !ws)
-    return fail_arg("tt_tower_bwd_weights: null pointer");
-  if (B <= 0 || ldy < D || ldf < F) return fail_arg("tt_tower_bwd_weights: sizes");
-  if (!tower_shape_ok(D, F, hidden, D) || ldy % 4 || !al16p(dy) || !al16p(tin) || !al16p(d_f) || !al16p(h) || !al16p(dh)) {
-    set_error("tt_tower_bwd_weights: needs hidden = 256, D in {32, 64, 128}, F <= 64, 16-B aligned operands");
-    return TT_E_UNSUPPORTED;
-  }
-  if (ws_bytes < tt_tower_bwd_weights_workspace_bytes(B, D, F, hidden)) { set_error("tt_tower_bwd_weights: workspace"); return TT_E_WORKSPACE; }
-  TowerWgradArgs a{dy, ldy, tin, d_f, h, dh, feats, ldf, F, B, reinterpret_cast<float*>(ws)};
-  hipStream_t st = S(stream);
-  const unsigned grid = (unsigned)ceil_div(B, TW_ROWS);
-  const size_t lds = (size_t)(TW_ROWS * D + TW_ROWS * TW_HID + TW_ROWS * F) * sizeof(float);
-#define TT_TWG(E)                                                                                                        \
-  {                                                                                                                      \
-    if (lds > 64 * 1024) {                                                                                               \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tower_wgrad_kernel<E>),                          \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
-      if (e != hipSuccess) { set_error("tower_wgrad_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
-    }                                                                                                                    \
-    tower_wgrad_kernel<E><<<grid, 256, lds, st>>>(a);                                                                    \
-  }
-  if (D == 32) TT_TWG(4) else if (D == 64) TT_TWG(8) else TT_TWG(16)
-#undef TT_TWG
-  int rc = check_launch("tower_wgrad_kernel");
-  if (rc) return rc;
-  const int64_t n3 = D * 2 * D, n2 = D * TW_HID, n1 = TW_HID * F, part = n3 + n2 + n1 + 2 * D + TW_HID;
-  tower_wgrad_reduce_kernel<<<(unsigned)ceil_div(part, 256), 256, 0, st>>>(reinterpret_cast<const float*>(ws), (int)grid, part, n3, n2,
-                                                                           n1, D, dW3, dW2, dW1, db3, db2, db1);
-  return check_launch("tower_wgrad_reduce_kernel");
+  return tt_tower_bwd_weights_x(dy, ldy, tin, d_f, h, dh, feats, ldf, nullptr, 0, 0, B, D, F, hidden, dW1, db1, dW2, db2, dW3, db3,
+                                ws, ws_bytes, stream);
 }

@@ -425,27 +425,35 @@ class TowerInput(_LookupFunction):
 _FUSED_TOWER = os.environ.get("TT_NO_FUSED_TOWER") is None  # A/B switch
 
 
-def fused_tower_supported(weight, feats, W1, W2, W3) -> bool:
-    """tt_tower_fwd / tt_tower_bwd_data: hidden = 256, D = d_out in {32, 64, 128}, F <= 64."""
+def fused_tower_supported(weight, feats, W1, W2, W3, extra_width: int = 0) -> bool:
+    """tt_tower_fwd(_x) / tt_tower_bwd_data(_x): hidden = 256, D = d_out in {32, 64, 128}, F <= 64; a third input
+    block (`extra_width` columns: the history model's [recent | mean] summary) must be 2D wide."""
     if not (_FUSED_TOWER and weight.is_cuda and feats.dim() == 2 and feats.dtype == torch.float32):
         return False
-    ok = (W3.shape[1] == 2 * weight.shape[1] and W2.shape[0] == weight.shape[1]
-          and bool(N.load().tt_tower_supported(weight.shape[1], feats.shape[1], W1.shape[0], W3.shape[0])))
+    ok = (W3.shape[1] == 2 * weight.shape[1] + extra_width and W2.shape[0] == weight.shape[1]
+          and bool(N.load().tt_tower_x_supported(weight.shape[1], feats.shape[1], W1.shape[0], W3.shape[0], extra_width)))
     if not ok:
         note_generic("tower (id lookup + feature MLP + tower Linear)",
-                     f"the fused kernel takes hidden = 256, D = d_out in {{32, 64, 128}}, F <= 64; got hidden = {W1.shape[0]}, "
-                     f"D = {weight.shape[1]}, d_out = {W3.shape[0]}, F = {feats.shape[1]}: gather + three GEMM launches per direction")
+                     f"the fused kernel takes hidden = 256, D = d_out in {{32, 64, 128}}, F <= 64, a third input block of 0 or 2D "
+                     f"columns; got hidden = {W1.shape[0]}, D = {weight.shape[1]}, d_out = {W3.shape[0]}, F = {feats.shape[1]}, "
+                     f"third block {extra_width}: gather + three GEMM launches per direction")
     return ok
 
 
 class FusedTower(_LookupFunction):
     """One whole tower -- id lookup, feature MLP, the (never materialised) cat, tower Linear -- as one kernel per
-    direction (csrc/tower.hip; ref:src/two_tower_base_retrieval.py:129-162,164-191 user, :193-219 item)."""
+    direction (csrc/tower.hip; ref:src/two_tower_base_retrieval.py:129-162,164-191 user, :193-219 item).
+    `extra` [B, 2D]: a third block of the tower input -- the history model's [recent | mean] summary
+    (ref:src/two_tower_with_user_history_encoder.py:81-83,85-122) -- with W3 [D, 4D]."""
 
     @staticmethod
-    def forward(ctx, weight, ids, feats, W1, b1, W2, b2, W3, b3):
+    def forward(ctx, weight, ids, feats, W1, b1, W2, b2, W3, b3, extra=None):
         dev = N.require_device(weight, ids, feats, W1, b1, W2, b2, W3, b3)
         feats = _rowmajor(feats)
+        if extra is not None:
+            N.require_device(extra)
+            extra = _rowmajor(extra)
+        E = 0 if extra is None else extra.shape[1]
         B, F = feats.shape
         D, Hd = weight.shape[1], W1.shape[0]
         if ids.dtype == torch.int32:
@@ -458,17 +466,21 @@ class FusedTower(_LookupFunction):
         h = torch.empty(B, Hd, dtype=torch.float32, device=dev)
         tin = torch.empty(B, 2 * D, dtype=torch.float32, device=dev)
         W1c, W2c, W3c = W1.contiguous(), W2.contiguous(), W3.contiguous()
-        N.check(N.load().tt_tower_fwd(src.data_ptr(), src.shape[0], row_ids.data_ptr(), feats.data_ptr(), feats.stride(0), B, D,
-                                      F, Hd, W1c.data_ptr(), b1.data_ptr(), W2c.data_ptr(), b2.data_ptr(), W3c.data_ptr(),
-                                      b3.data_ptr(), W3.shape[0], y.data_ptr(), y.stride(0), h.data_ptr(), tin.data_ptr(),
-                                      N.oob.flag(dev).data_ptr(), N.stream()), "tt_tower_fwd")
+        N.check(N.load().tt_tower_fwd_x(src.data_ptr(), src.shape[0], row_ids.data_ptr(), feats.data_ptr(), feats.stride(0), B, D,
+                                        F, Hd, W1c.data_ptr(), b1.data_ptr(), W2c.data_ptr(), b2.data_ptr(), W3c.data_ptr(),
+                                        b3.data_ptr(), W3.shape[0], N.ptr(extra), extra.stride(0) if E else 0, E,
+                                        y.data_ptr(), y.stride(0), h.data_ptr(), tin.data_ptr(),
+                                        N.oob.flag(dev).data_ptr(), N.stream()), "tt_tower_fwd_x")
         ctx.weight = weight
-        ctx.save_for_backward(ids, feats, h, tin, W2c, W3c)
+        ctx.has_extra = extra is not None
+        ctx.save_for_backward(ids, feats, h, tin, W2c, W3c, *(() if extra is None else (extra,)))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        ids, feats, h, tin, W2, W3 = ctx.saved_tensors
+        ids, feats, h, tin, W2, W3 = ctx.saved_tensors[:6]
+        extra = ctx.saved_tensors[6] if ctx.has_extra else None
+        E = 0 if extra is None else extra.shape[1]
         w = ctx.weight
         dev = dy.device
         dy = dy.contiguous()
@@ -477,44 +489,54 @@ class FusedTower(_LookupFunction):
         d_emb = torch.empty(B, D, dtype=torch.float32, device=dev)
         d_f = torch.empty(B, D, dtype=torch.float32, device=dev)
         dh = torch.empty(B, Hd, dtype=torch.float32, device=dev)
-        N.check(N.load().tt_tower_bwd_data(dy.data_ptr(), dy.stride(0), B, D, Hd, W2.data_ptr(), W3.data_ptr(), h.data_ptr(),
-                                           d_emb.data_ptr(), D, d_f.data_ptr(), dh.data_ptr(), N.stream()),
-                "tt_tower_bwd_data")
-        dW1, db1, dW2, db2, dW3, db3 = tower_weight_grads(dy, tin, d_f, h, dh, feats)
+        d_extra = torch.empty(B, E, dtype=torch.float32, device=dev) if E else None
+        N.check(N.load().tt_tower_bwd_data_x(dy.data_ptr(), dy.stride(0), B, D, Hd, W2.data_ptr(), W3.data_ptr(), h.data_ptr(),
+                                             d_emb.data_ptr(), D, d_f.data_ptr(), dh.data_ptr(), N.ptr(d_extra), E, E,
+                                             N.stream()), "tt_tower_bwd_data_x")
+        dW1, db1, dW2, db2, dW3, db3 = tower_weight_grads(dy, tin, d_f, h, dh, feats, extra=extra)
         dweight = None
         if ctx.needs_input_grad[0]:
             dweight = _route_table_grad(w, ids.reshape(-1), d_emb, ctx.lookup_index)
-        return dweight, None, None, dW1, db1, dW2, db2, dW3, db3
+        return dweight, None, None, dW1, db1, dW2, db2, dW3, db3, d_extra
 
 
 _TOWER_WGRAD = os.environ.get("TT_TOWER_NO_WGRAD") is None  # A/B switch
 
 
-def tower_weight_grads(dy, tin, d_f, h, dh, feats, out=None):
-    """(dW1, db1, dW2, db2, dW3, db3) of one tower: dW3 = dy^T tin, dW2 = d_f^T h, dW1 = dh^T feats and the bias sums,
-    one product launch + one reduce (tt_tower_bwd_weights) instead of three tt_gemm_tn_colsum_f32 calls.
-    `out`: the six tensors to write into (contiguous), else they are allocated."""
+def tower_weight_grads(dy, tin, d_f, h, dh, feats, out=None, extra=None):
+    """(dW1, db1, dW2, db2, dW3, db3) of one tower: dW3 = dy^T [tin | extra], dW2 = d_f^T h, dW1 = dh^T feats and the
+    bias sums, one product launch + one reduce (tt_tower_bwd_weights_x) instead of three tt_gemm_tn_colsum_f32 calls.
+    `out`: the six tensors to write into (contiguous), else they are allocated.  `extra` [B, 2D]: the third block of
+    the tower input (history model), dW3 is then [D, 4D]."""
     dev = dy.device
     B, D = dy.shape
     Hd, F = h.shape[1], feats.shape[1]
+    E = 0 if extra is None else extra.shape[1]
     if out is not None:
         dW1, db1, dW2, db2, dW3, db3 = out
     else:
-        dW3 = torch.empty(D, 2 * D, dtype=torch.float32, device=dev)
+        dW3 = torch.empty(D, 2 * D + E, dtype=torch.float32, device=dev)
         dW2 = torch.empty(D, Hd, dtype=torch.float32, device=dev)
         dW1 = torch.empty(Hd, F, dtype=torch.float32, device=dev)
         db3 = torch.empty(D, dtype=torch.float32, device=dev)
         db2 = torch.empty(D, dtype=torch.float32, device=dev)
         db1 = torch.empty(Hd, dtype=torch.float32, device=dev)
     lib = N.load()
-    if (_TOWER_WGRAD and lib.tt_tower_supported(D, F, Hd, D) and dy.stride(1) == 1 and dy.stride(0) % 4 == 0 and feats.stride(1) == 1
+    if (_TOWER_WGRAD and lib.tt_tower_x_supported(D, F, Hd, D, E) and dy.stride(1) == 1 and dy.stride(0) % 4 == 0 and feats.stride(1) == 1
             and all(t.is_contiguous() for t in (tin, d_f, h, dh, dW1, db1, dW2, db2, dW3, db3))
-            and all(t.data_ptr() % 16 == 0 for t in (dy, tin, d_f, h, dh))):
-        wsp, wsn = _ws(dev, lib.tt_tower_bwd_weights_workspace_bytes(B, D, F, Hd), "tower_wgrad")
-        N.check(lib.tt_tower_bwd_weights(dy.data_ptr(), dy.stride(0), tin.data_ptr(), d_f.data_ptr(), h.data_ptr(), dh.data_ptr(),
-                                         feats.data_ptr(), feats.stride(0), B, D, F, Hd, dW1.data_ptr(), db1.data_ptr(),
-                                         dW2.data_ptr(), db2.data_ptr(), dW3.data_ptr(), db3.data_ptr(), wsp, wsn, N.stream()),
-                "tt_tower_bwd_weights")
+            and all(t.data_ptr() % 16 == 0 for t in (dy, tin, d_f, h, dh))
+            and (extra is None or (extra.stride(1) == 1 and extra.stride(0) % 4 == 0 and extra.data_ptr() % 16 == 0))):
+        wsp, wsn = _ws(dev, lib.tt_tower_bwd_weights_x_workspace_bytes(B, D, F, Hd, E), "tower_wgrad")
+        N.check(lib.tt_tower_bwd_weights_x(dy.data_ptr(), dy.stride(0), tin.data_ptr(), d_f.data_ptr(), h.data_ptr(), dh.data_ptr(),
+                                           feats.data_ptr(), feats.stride(0), N.ptr(extra), extra.stride(0) if E else 0, E,
+                                           B, D, F, Hd, dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(),
+                                           dW3.data_ptr(), db3.data_ptr(), wsp, wsn, N.stream()), "tt_tower_bwd_weights_x")
+        return dW1, db1, dW2, db2, dW3, db3
+    if extra is not None:
+        gemm_tn_colsum(dy, tin, dW3[:, :2 * D], db=db3)
+        gemm(N.TT_GEMM_TN, dy, extra, dW3[:, 2 * D:], D, E, B)
+        gemm_tn_colsum(d_f, h, dW2, db=db2)
+        gemm_tn_colsum(dh, feats, dW1, db=db1)
         return dW1, db1, dW2, db2, dW3, db3
     gemm_tn_colsum(dy, tin, dW3, db=db3)
     gemm_tn_colsum(d_f, h, dW2, db=db2)

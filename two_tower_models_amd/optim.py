@@ -52,6 +52,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import weakref
 from typing import Dict, Iterable, List, Optional, Sequence
 
@@ -121,6 +122,7 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._sweep_wgs = 0  # 0 = library default (3 workgroups per CU); lowered by the throttle controller
         self._tune = None  # events of the step in flight: [begin, sweep start, sweep end, end, level, step number]
         self._tune_done: List[list] = []  # finished steps whose events may still be pending on the GPU
+        self._tune_state = None  # the sweep-level scan (see _tune_sweep)
         self._plan_stream: Optional[torch.cuda.Stream] = None
         self._plan_done: Optional[torch.cuda.Event] = None
         self._plans_pending = False
@@ -339,31 +341,72 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._tune = None if capturing else [ev_begin, ev_s0, self._sweep_done, None, self._sweep_wgs, self._host_steps]
         self._begun = begun
 
-    # The sweep saturates HBM for as long as it lasts.  When the step is much LONGER than the sweep (history model:
-    # 1.1 ms of a 5.5 ms step), running it flat out at the top of the step slows the HBM-heavy kernels that share that
-    # window 2-3x (first QKV projection 542 vs 174 us, history gather 343 vs ~100 us); a thinner sweep (fewer
-    # persistent workgroups) that lasts a third to a half of the step costs them little.  C3: 5.56 -> 5.10 ms.
-    # Closed loop on the PREVIOUS step's events, queried without blocking: results do not depend on it (the chunks are
-    # handed out dynamically either way) and no host synchronisation is added.
-    _SWEEP_LEVELS = (0, 256, 128)  # workgroups; 0 = library default (3 per CU)
+    # The sweep saturates HBM for as long as it lasts, and everything that runs next to it is stretched 2-3x.  When the
+    # sweep IS the step (headline shape: 5.0 of 5.3 ms) that is free; when the forward/backward chain is as long as the
+    # sweep or longer, a thinner sweep (fewer persistent workgroups) that ends with the chain instead of well before it
+    # is faster overall -- C2: 1.27 ms at 768 workgroups, 1.14 at 512, 1.43 at 256; history model: best at 128-256.
+    # The best level depends on the shapes, so it is MEASURED, on the events of steps that have already completed
+    # (queried, never waited on: no host synchronisation is added):
+    #   probe   full width until two steps have been seen; sweep > 0.9 of the step -> keep full width, done
+    #   scan    otherwise the next len(levels) * SCAN_BLOCK steps run the levels one block each, enqueued OPEN LOOP (the
+    #           host may be dozens of steps ahead of the GPU: waiting for each level's verdict before trying the next
+    #           would stretch the scan over hundreds of steps)
+    #   wait    full width until the last scan step's events are in, then the level with the fastest step is kept
+    # and the whole thing repeats every RESCAN_STEPS steps.  Results do not depend on the level: the sweep's chunks
+    # are handed out dynamically either way.
+    _SWEEP_LEVELS = (0, 640, 512, 384, 256, 128)  # workgroups; 0 = library default (3 per CU = 768)
+    _SCAN_BLOCK = 6  # steps per level; the first one of a block overlaps the previous level's tail and is not counted
+    _RESCAN_STEPS = 4000
 
     def _tune_sweep(self) -> None:
         if os.environ.get("TT_SWEEP_WGS") is not None:
             return
-        # the host runs a step or two ahead of the GPU: take the NEWEST measurement whose events have completed
-        got = None
+        ts = self._tune_state
+        if ts is None:
+            ts = self._tune_state = {"phase": "probe", "obs": {}, "plan": [], "skip": set(), "last": 0, "since": 0}
+        levels = self._SWEEP_LEVELS
+        newest = 0
         while self._tune_done and self._tune_done[0][2].query() and self._tune_done[0][3].query():
             got = self._tune_done.pop(0)
-        if got is None or got[4] != self._sweep_wgs or got[5] <= 2:
-            return  # nothing finished yet / measured at another setting / the first steps (allocations, first-use set-up)
-        step_ms, sweep_ms = got[0].elapsed_time(got[3]), got[1].elapsed_time(got[2])
-        levels = self._SWEEP_LEVELS
-        at = levels.index(self._sweep_wgs) if self._sweep_wgs in levels else 0
-        ratio = sweep_ms / max(step_ms, 1e-6)
-        if ratio < 0.35 and at + 1 < len(levels):
-            self._sweep_wgs = levels[at + 1]
-        elif ratio > 0.7 and at > 0:
-            self._sweep_wgs = levels[at - 1]
+            newest = got[5]
+            if got[5] <= 4 or got[5] in ts["skip"]:
+                continue  # the first steps (allocations, first-use set-up) / the first step of a scan block
+            ts["obs"].setdefault(got[4], []).append((got[0].elapsed_time(got[3]), got[1].elapsed_time(got[2])))
+        if ts["phase"] == "probe":
+            seen = ts["obs"].get(0, [])
+            if len(seen) >= 2:
+                if all(sweep > 0.9 * step for step, sweep in seen[-2:]):
+                    self._lock_sweep(ts, 0, "the sweep is the step")
+                else:
+                    nxt = self._host_steps + 1  # the step about to be enqueued
+                    for lv in levels[1:]:
+                        ts["skip"].add(nxt)
+                        ts["plan"] += [lv] * self._SCAN_BLOCK
+                        nxt += self._SCAN_BLOCK
+                    ts["skip"].add(nxt)  # back to full width: its first step overlaps the thinnest level's tail
+                    ts["last"] = nxt - 1
+                    ts["phase"] = "scan"
+        if ts["phase"] == "scan":
+            if ts["plan"]:
+                self._sweep_wgs = ts["plan"].pop(0)
+            else:
+                self._sweep_wgs = levels[0]
+                ts["phase"] = "wait"
+        elif ts["phase"] == "wait":
+            if newest >= ts["last"]:
+                ms = {lv: min(step for step, _ in o) for lv, o in ts["obs"].items() if len(o) >= 2}
+                self._lock_sweep(ts, min(ms, key=ms.get) if ms else 0, str({(lv or 768): round(v, 3) for lv, v in ms.items()}))
+        elif ts["phase"] == "locked":
+            ts["since"] += 1
+            if ts["since"] >= self._RESCAN_STEPS:
+                self._sweep_wgs = levels[0]
+                ts.update(phase="probe", obs={}, plan=[], skip={self._host_steps + 1}, since=0)
+
+    def _lock_sweep(self, ts: dict, level: int, why: str) -> None:
+        self._sweep_wgs = level
+        ts.update(phase="locked", obs={}, plan=[], skip=set(), since=0)
+        if os.environ.get("TT_TUNE_DEBUG"):
+            print(f"[tt] sweep level: {level or 768} workgroups ({why})", file=sys.stderr)
 
     def _launch_plans(self, side: bool) -> None:
         """Enqueue the deferred row-plan sorts of a forward-mode step (see _begin_overlapped)."""
@@ -452,7 +495,7 @@ class DenseExactAdam(torch.optim.Optimizer):
                 end = torch.cuda.Event(enable_timing=True)
                 end.record()
                 self._tune[3] = end
-                if len(self._tune_done) < 16:  # never drop a PENDING measurement: when the host runs many steps ahead the
+                if len(self._tune_done) < 256:  # never drop a PENDING measurement: when the host runs many steps ahead the
                     self._tune_done.append(self._tune)  # oldest one is the next to complete (new ones are skipped meanwhile)
                 self._tune = None
         elif self.lazy:

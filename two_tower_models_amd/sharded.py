@@ -317,16 +317,17 @@ class HipBackend:
         Dm, Hd = W2.shape
         E = 0 if extra is None else extra.shape[1]
         De = W3.shape[1] - Dm - E
-        if extra is None and emb.is_contiguous() and ops.fused_tower_supported(emb, feats, W1, W2, W3):
+        if (emb.is_contiguous() and (extra is None or (extra.stride(1) == 1 and extra.stride(0) % 4 == 0 and extra.data_ptr() % 16 == 0))
+                and ops.fused_tower_supported(emb, feats, W1, W2, W3, extra_width=E)):
             # one launch (csrc/tower.hip): the routed rows play the table, looked up by position; returns
             # (h, tin, out) -- tower_bwd recognises the [B, 2D] tower input in the `f` slot
             pos = ops.ActiveStash.positions_for(self.device, B)
             h, tin, out = self.empty(B, Hd), self.empty(B, 2 * De), self.empty(B, W3.shape[0])
             feats = feats.contiguous()
-            N.check(self.lib.tt_tower_fwd(emb.data_ptr(), B, pos.data_ptr(), feats.data_ptr(), feats.stride(0), B, De, F, Hd,
-                                          W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), b3.data_ptr(),
-                                          W3.shape[0], out.data_ptr(), out.stride(0), h.data_ptr(), tin.data_ptr(), None,
-                                          N.stream()), "tt_tower_fwd")
+            N.check(self.lib.tt_tower_fwd_x(emb.data_ptr(), B, pos.data_ptr(), feats.data_ptr(), feats.stride(0), B, De, F, Hd,
+                                            W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), b3.data_ptr(),
+                                            W3.shape[0], N.ptr(extra), extra.stride(0) if E else 0, E, out.data_ptr(),
+                                            out.stride(0), h.data_ptr(), tin.data_ptr(), None, N.stream()), "tt_tower_fwd_x")
             return h, tin, out
         h = self.empty(B, Hd)
         ops.gemm(N.TT_GEMM_NT, feats, W1, h, B, Hd, F, bias=b1, epilogue=N.TT_EPI_RELU)
@@ -350,14 +351,15 @@ class HipBackend:
         Do, Din = W3.shape
         E = 0 if extra is None else extra.shape[1]
         De = Din - Dm - E
-        if extra is None and f.shape[1] == Din:  # the fused forward ran: `f` is the whole tower input [emb | MLP]
+        if f.shape[1] == Din - E and f.shape[1] != Dm:  # the fused forward ran: `f` is the tower input [emb | MLP]
             d_out = d_out.contiguous()
             d_emb, d_f, dh = self.empty(B, De), self.empty(B, Dm), self.empty(B, Hd)
-            N.check(self.lib.tt_tower_bwd_data(d_out.data_ptr(), d_out.stride(0), B, De, Hd, W2.data_ptr(), W3.data_ptr(),
-                                               h.data_ptr(), d_emb.data_ptr(), De, d_f.data_ptr(), dh.data_ptr(), N.stream()),
-                    "tt_tower_bwd_data")
-            ops.tower_weight_grads(d_out, f, d_f, h, dh, feats.contiguous(), out=(gW1, gb1, gW2, gb2, gW3, gb3))
-            return d_emb, None
+            d_extra = self.empty(B, E) if E else None
+            N.check(self.lib.tt_tower_bwd_data_x(d_out.data_ptr(), d_out.stride(0), B, De, Hd, W2.data_ptr(), W3.data_ptr(),
+                                                 h.data_ptr(), d_emb.data_ptr(), De, d_f.data_ptr(), dh.data_ptr(),
+                                                 N.ptr(d_extra), E, E, N.stream()), "tt_tower_bwd_data_x")
+            ops.tower_weight_grads(d_out, f, d_f, h, dh, feats.contiguous(), out=(gW1, gb1, gW2, gb2, gW3, gb3), extra=extra)
+            return d_emb, d_extra
         ops.gemm_tn_colsum(d_out, emb, gW3[:, :De], db=gb3)
         ops.gemm(N.TT_GEMM_TN, d_out, f, gW3[:, De:De + Dm], Do, Dm, B)
         d_emb = self.empty(B, De)

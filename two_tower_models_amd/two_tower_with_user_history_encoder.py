@@ -35,14 +35,38 @@ class TwoTowerWithUserHistoryEncoder(TwoTowerBaseRetrieval):
         self, user_id: torch.Tensor, user_features: torch.Tensor, user_history: torch.Tensor
     ) -> torch.Tensor:
         """[id emb | feature MLP | recent | mean] -> [B, 2*DU + 2*DI] (ref :85-122)."""
+        summary = self._history_summary(user_history)
+        base = super().process_user_features(user_id=user_id, user_features=user_features, user_history=user_history)
+        return torch.cat([base, summary], dim=1)
+
+    def _history_summary(self, user_history: torch.Tensor) -> torch.Tensor:
         enc = self.user_history_encoder
         if isinstance(enc, UserHistoryEncoder):
             summary = enc.encode_ids(self.item_id_embedding_arch.weight, user_history)  # [B, 2, DI]
         else:  # a user-supplied encoder module: plain lookup, then the module's own forward
             summary = enc(ops.EmbeddingLookup.apply(self.item_id_embedding_arch.weight, user_history))
-        summary = summary.view(summary.shape[0], -1)
-        base = super().process_user_features(user_id=user_id, user_features=user_features, user_history=user_history)
-        return torch.cat([base, summary], dim=1)
+        return summary.view(summary.shape[0], -1)
+
+    def compute_user_embedding(
+        self, user_id: torch.Tensor, user_features: torch.Tensor, user_history: torch.Tensor
+    ) -> torch.Tensor:
+        """Query embedding [B, DI] (ref :85-122 + base :164-191).  With no hook overridden the id lookup, the feature
+        MLP, the [id | MLP | recent | mean] cat and the Linear(4D -> D) run as ONE kernel per direction (K3 with a
+        third input block, csrc/tower.hip); the encoder summary is that block."""
+        cls = type(self)
+        mlp, tower = self.user_features_arch, self.user_tower_arch
+        if (cls.process_user_features is TwoTowerWithUserHistoryEncoder.process_user_features
+                and cls.get_user_embedding is TwoTowerBaseRetrieval.get_user_embedding and user_id.is_cuda):
+            ops.N.oob.poll(user_id.device)  # surfaces an out-of-range id seen by an earlier launch
+            summary = self._history_summary(user_history)
+            if ops.fused_tower_supported(self.user_id_embedding_arch.weight, user_features, mlp[0].weight, mlp[2].weight,
+                                         tower.weight, extra_width=summary.shape[1]):
+                return ops.FusedTower.apply(self.user_id_embedding_arch.weight, user_id, user_features, mlp[0].weight,
+                                            mlp[0].bias, mlp[2].weight, mlp[2].bias, tower.weight, tower.bias, summary)
+            base = TwoTowerBaseRetrieval.process_user_features(self, user_id=user_id, user_features=user_features,
+                                                               user_history=user_history)
+            return ops.Linear.apply(torch.cat([base, summary], dim=1), tower.weight, tower.bias)
+        return super().compute_user_embedding(user_id, user_features, user_history)
 
     def _lookup_plan(self, user_id, user_history, item_id):
         # forward order: history rows (encoder), then the user row, then the item row
