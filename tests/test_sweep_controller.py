@@ -1,0 +1,62 @@
+"""DenseExactAdam's sweep-width controller (optim.py::_tune_sweep) on stub events: no GPU, no library.
+The controller only ever sees (step time, sweep time, level, step number) of steps that have completed, with the host
+an arbitrary number of steps ahead -- which is exactly what the stubs model."""
+import types
+
+import pytest
+
+from two_tower_models_amd.optim import DenseExactAdam
+
+
+class _Ev:
+    def __init__(self, t, done):
+        self.t, self.done = t, done
+
+    def query(self):
+        return self.done()
+
+    def elapsed_time(self, other):
+        return other.t - self.t
+
+
+def _drive(step_ms_of, sweep_ms_of, lag, n_steps):
+    """Run the controller for n_steps host steps; the GPU completes step k when the host is at step k + lag."""
+    me = types.SimpleNamespace(_tune_done=[], _tune_state=None, _host_steps=0, _sweep_wgs=0,
+                               _SWEEP_LEVELS=DenseExactAdam._SWEEP_LEVELS, _SCAN_BLOCK=DenseExactAdam._SCAN_BLOCK,
+                               _RESCAN_STEPS=DenseExactAdam._RESCAN_STEPS)
+    me._lock_sweep = types.MethodType(DenseExactAdam._lock_sweep, me)
+    tune = types.MethodType(DenseExactAdam._tune_sweep, me)
+    history = []
+    for _ in range(n_steps):
+        tune()
+        me._host_steps += 1
+        k, lv = me._host_steps, me._sweep_wgs
+        done = (lambda k=k: me._host_steps >= k + lag)
+        st, sw = step_ms_of(lv), sweep_ms_of(lv)
+        me._tune_done.append([_Ev(0.0, done), _Ev(0.0, done), _Ev(sw, done), _Ev(st, done), lv, k])
+        history.append(lv)
+    return me, history
+
+
+@pytest.mark.parametrize("lag", [0, 2, 40])
+def test_sweep_bound_step_keeps_full_width(lag):
+    me, hist = _drive(lambda lv: 5.3, lambda lv: 5.0, lag, 200)
+    assert set(hist) == {0} and me._tune_state["phase"] == "locked"
+
+
+@pytest.mark.parametrize("lag", [0, 3, 40])
+def test_chain_bound_step_scans_every_level_once_and_keeps_the_fastest(lag):
+    ms = {0: 1.30, 640: 1.31, 512: 1.18, 384: 1.21, 256: 1.41, 128: 2.3}
+    me, hist = _drive(lambda lv: ms[lv], lambda lv: 1.0, lag, 300)
+    assert me._tune_state["phase"] == "locked" and me._sweep_wgs == 512
+    for lv in (640, 512, 384, 256, 128):  # one block per level while scanning, the winner for the rest
+        assert hist.count(lv) >= DenseExactAdam._SCAN_BLOCK
+        if lv != 512:
+            assert hist.count(lv) == DenseExactAdam._SCAN_BLOCK
+    assert all(lv == 512 for lv in hist[-100:])
+
+
+def test_rescan_after_the_interval():
+    ms = {0: 1.30, 640: 1.31, 512: 1.18, 384: 1.21, 256: 1.41, 128: 2.3}
+    me, hist = _drive(lambda lv: ms[lv], lambda lv: 1.0, 1, DenseExactAdam._RESCAN_STEPS + 200)
+    assert hist.count(128) == 2 * DenseExactAdam._SCAN_BLOCK and me._sweep_wgs == 512

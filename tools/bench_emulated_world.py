@@ -139,6 +139,40 @@ def emulated(W=8, workload="P", steps=30, warmup=5, device=None, verbose=False):
         # logit-sized products: forward S = U.I^T and E = P.I (2), backward dI = G^T.U from the kept logits (1) or
         # with S recomputed (2); 2*M*N*D flops each
         fl_fwd, fl_bwd = 4.0 * M * Nn * D, (2.0 if kept else 4.0) * M * Nn * D
+        # the same two kernels with the GPU to themselves (no sweep next to them, nothing else in the queue): what the
+        # kernels reach vs what the step gets out of them
+        alone = {}
+        if kept:
+            U = torch.randn(M, D, device=device) * 0.3
+            I = torch.randn(Nn, D, device=device) * 0.3
+            coef = torch.rand(M, device=device) / M
+            lse, ce = torch.empty(M, device=device), torch.empty(M, device=device)
+            du, dI = torch.empty(M, D, device=device), torch.empty(Nn, D, device=device)
+            wsn = lib.tt_inbatch_ce_workspace_bytes(M, Nn, D)
+            ws = torch.empty(wsn, dtype=torch.uint8, device=device)
+            zn = lib.tt_inbatch_ce_logits_bytes(M, Nn)
+            Z = torch.empty(zn, dtype=torch.uint8, device=device)
+
+            def k_fwd():
+                N.check(lib.tt_inbatch_ce_fwd_du_keep(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, 0, lse.data_ptr(), ce.data_ptr(),
+                                                      du.data_ptr(), D, Z.data_ptr(), zn, ws.data_ptr(), wsn, N.stream()), "fwd_du_keep")
+
+            def k_bwd():
+                N.check(lib.tt_inbatch_ce_bwd_kept(U.data_ptr(), D, M, Nn, D, 0, lse.data_ptr(), coef.data_ptr(), Z.data_ptr(), zn,
+                                                   dI.data_ptr(), D, ws.data_ptr(), wsn, N.stream()), "bwd_kept")
+
+            for fn, key in ((k_fwd, "ce_fwd_kernel"), (k_bwd, "ce_bwd_kernel")):
+                fn()
+                torch.cuda.synchronize()
+                lib.tt_profile_enable(1)
+                for _ in range(10):
+                    fn()
+                torch.cuda.synchronize()
+                t, c = C.c_double(0.0), C.c_int64(0)
+                N.check(lib.tt_profile_read(key.encode(), C.byref(t), C.byref(c)), "tt_profile_read")
+                lib.tt_profile_enable(0)
+                alone[key] = t.value / max(c.value, 1)
+            del U, I, Z, ws, dI, du
         roof = []
         for kname, fl, key in (("ce_fwd_du_kernel", fl_fwd, "ce_fwd_kernel"),
                                ("ce_bwd_kept_kernel" if kept else "ce_bwd_kernel", fl_bwd, "ce_bwd_kernel")):
@@ -147,7 +181,11 @@ def emulated(W=8, workload="P", steps=30, warmup=5, device=None, verbose=False):
                 tf = fl / (avg_ms * 1e-3) / 1e12
                 roof.append({"bound": "mfma", "kernel": kname, "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                              "frac": round(tf / MFMA_F32_PEAK_TF, 4), "avg_launch_ms": round(avg_ms, 4), "launches": launches,
-                             "algorithmic_flops_per_launch": fl})
+                             "algorithmic_flops_per_launch": fl,
+                             **({"alone_avg_launch_ms": round(alone[key], 4), "alone_frac": round(fl / (alone[key] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
+                                 "alone_note": "the same kernel at the same shape with the GPU to itself (10 launches back to back): the "
+                                               "difference to `frac` is what sharing HBM and CUs with the Adam sweep costs it in the step"}
+                                if key in alone else {})})
         out = {
             "what": f"ONE rank's kernels of the row-sharded step at W = {W} on one GPU: tables 1/{W} as thick, {W}x{B} in-batch "
                     "negatives per user, routed lookups; torch.distributed replaced by stand-ins that return tensors of the right "
@@ -174,7 +212,8 @@ def emulated(W=8, workload="P", steps=30, warmup=5, device=None, verbose=False):
             print(f"emulated W={W} workload={workload} routing={trainer.routing}: {ms:.3f} ms/step per rank (no collectives) -> "
                   f"{B * W / ms * 1e3 / 1e6:.2f} M pairs/s if the collectives were free")
             for r in roof:
-                print(f"  {r['kernel']}: {r['avg_launch_ms']:.3f} ms = {r['achieved']} TFLOP/s = {r['frac']:.3f} of the fp32 MFMA peak")
+                print(f"  {r['kernel']}: {r['avg_launch_ms']:.3f} ms = {r['achieved']} TFLOP/s = {r['frac']:.3f} of the fp32 MFMA peak"
+                      + (f" (alone: {r['alone_avg_launch_ms']:.3f} ms = {r['alone_frac']:.3f})" if "alone_frac" in r else ""))
             print(f"  bytes this rank would send per step: {trainer.comm_bytes} = {sum(trainer.comm_bytes.values()) / 1e6:.1f} MB")
         return out
     finally:

@@ -675,6 +675,8 @@ class ShardedTrainer:
         late = os.environ.get("TT_SWEEP_LATE")  # A/B switch
         self._sweep_late = late == "1"
         self._sweep_wgs = 256 if sweep_ms < 0.75 * logits_ms else 0
+        if os.environ.get("TT_SWEEP_WGS") is not None:  # A/B switch
+            self._sweep_wgs = int(os.environ["TT_SWEEP_WGS"])
         # the same regime decides whether the forward keeps the logits for the backward (one product
         # fewer, M*N*4 B of HBM traffic each way more): worth it once the sweep no longer binds
         keep = os.environ.get("TT_CE_KEEP_LOGITS")
