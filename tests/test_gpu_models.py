@@ -90,6 +90,29 @@ def test_base_model_seeded_init_is_reference_init(golden):
         assert torch.equal(v, T(g["p." + k])), k
 
 
+def assert_reference_trajectory(model, g):
+    """The model's state after the fixture's three Adam steps vs the reference's `after.*` arrays."""
+    after = state_of(g, prefix="after.")
+    for k, v in model.state_dict().items():
+        noise_only = float(np.abs(g["g." + k]).max()) < 1e-6  # see tests/test_oracle_golden.py
+        err = (v.cpu() - after[k]).abs() - 1e-5 * after[k].abs()
+        # Adam's first updates are lr * g / (|g| + eps): an element whose gradient happens to be ~1e-4 of the typical size
+        # turns a 1e-7 relative summation-order difference into a ~1e-5 step difference -- between ANY two fp32
+        # implementations (torch CPU vs torch CPU with another reduction order included).  So: every element within the
+        # 3-steps * 2 * lr bound, and all but <= 0.1 % of them within 5e-6.
+        assert float(err.max()) <= 2 * 3 * 1e-3 * 1.05, (k, float(err.max()))
+        if not noise_only:
+            out = err > 5e-6
+            n_out = int(out.sum())
+            assert n_out <= max(1, int(1e-3 * err.numel())) and float(err.max()) <= 2e-4, (k, n_out, float(err.max()))
+            if n_out:
+                # ... and the elements outside ARE the small-gradient ones, not an arbitrary 0.1 % (a bug confined
+                # to, say, the last row of a block would sit on typical gradients): their first-step |g| in the
+                # reference is below 2 % of the tensor's largest, most far below
+                g0 = torch.from_numpy(np.abs(g["g." + k])).reshape(err.shape)
+                assert float(g0[out].max()) <= 2e-2 * float(g0.max()), (k, n_out, float(g0[out].max()), float(g0.max()))
+
+
 @pytest.mark.parametrize("interleave", [False, True])
 @pytest.mark.parametrize("schedule", [dict(), dict(overlap_sweep=False), dict(overlap_sweep="forward"), dict(lazy=True)])
 def test_adam_trajectory_dense_exact(golden, schedule, interleave):
@@ -121,25 +144,60 @@ def test_adam_trajectory_dense_exact(golden, schedule, interleave):
     assert np.allclose(losses, g["adam_losses"], atol=1e-4)
     assert opt.step_count == 3
     opt.flush()
-    after = state_of(g, prefix="after.")
-    for k, v in model.state_dict().items():
-        noise_only = float(np.abs(g["g." + k]).max()) < 1e-6  # see tests/test_oracle_golden.py
-        err = (v.cpu() - after[k]).abs() - 1e-5 * after[k].abs()
-        # Adam's first updates are lr * g / (|g| + eps): an element whose gradient happens to be ~1e-4 of the typical size
-        # turns a 1e-7 relative summation-order difference into a ~1e-5 step difference -- between ANY two fp32
-        # implementations (torch CPU vs torch CPU with another reduction order included).  So: every element within the
-        # 3-steps * 2 * lr bound, and all but <= 0.1 % of them within 5e-6.
-        assert float(err.max()) <= 2 * 3 * 1e-3 * 1.05, (k, float(err.max()))
-        if not noise_only:
-            out = err > 5e-6
-            n_out = int(out.sum())
-            assert n_out <= max(1, int(1e-3 * err.numel())) and float(err.max()) <= 2e-4, (k, n_out, float(err.max()))
-            if n_out:
-                # ... and the elements outside ARE the small-gradient ones, not an arbitrary 0.1 % (a bug confined
-                # to, say, the last row of a block would sit on typical gradients): their first-step |g| in the
-                # reference is below 2 % of the tensor's largest, most far below
-                g0 = torch.from_numpy(np.abs(g["g." + k])).reshape(err.shape)
-                assert float(g0[out].max()) <= 2e-2 * float(g0.max()), (k, n_out, float(g0[out].max()), float(g0.max()))
+    assert_reference_trajectory(model, g)
+
+
+@pytest.mark.parametrize("overlap", [False, "forward"])
+def test_graphed_train_step_vs_reference_trajectory(golden, overlap):
+    """GraphedTrainStep anchored on the REFERENCE (not on the eager HIP path): the warm-up step is the fixture's step 0,
+    the two replays its steps 1 and 2; losses and the final state against torch.optim.Adam run in the reference."""
+    import two_tower_models_amd as A
+    g = golden("g2_base_aligned")
+    model = make_model("base", g)
+    opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep=overlap)
+    batches = [batch_of(g, prefix=f"step{s}.in.") for s in range(3)]
+    step = A.GraphedTrainStep(model, opt, batches[0], warmup=1, capture_overlap=overlap == "forward")
+    losses = [step(*b).item() for b in batches[1:]]
+    opt.flush()
+    torch.cuda.synchronize()
+    assert opt.step_count == 3
+    assert np.allclose(losses, g["adam_losses"][1:], atol=1e-4)
+    assert_reference_trajectory(model, g)
+
+
+@pytest.mark.parametrize("lazy", [False, True])
+def test_checkpoint_resume_vs_reference_trajectory(golden, lazy):
+    """Checkpoint after the fixture's step 0 (model + optimiser state_dict through torch.save / torch.load), fresh objects,
+    steps 1 and 2: the REFERENCE's uninterrupted three-step trajectory, losses included."""
+    import io
+    import two_tower_models_amd as A
+    g = golden("g2_base_aligned")
+    batches = [batch_of(g, prefix=f"step{s}.in.") for s in range(3)]
+    losses = []
+
+    def run(model, opt, bs):
+        for b in bs:
+            loss = model.train_forward(*b)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+
+    m1 = make_model("base", g)
+    o1 = A.DenseExactAdam(m1.parameters(), lr=1e-3, lazy=lazy)
+    run(m1, o1, batches[:1])
+    buf = io.BytesIO()
+    torch.save({"opt": o1.state_dict(), "model": m1.state_dict()}, buf)  # optimiser first: it flushes
+    ck = torch.load(io.BytesIO(buf.getvalue()))
+    model = make_model("base", g)
+    model.load_state_dict(ck["model"])
+    opt = A.DenseExactAdam(model.parameters(), lr=1e-3, lazy=lazy)
+    opt.load_state_dict(ck["opt"])
+    run(model, opt, batches[1:])
+    opt.flush()
+    assert opt.step_count == 3
+    assert np.allclose(losses, g["adam_losses"], atol=1e-4)
+    assert_reference_trajectory(model, g)
 
 
 def test_label_and_id_dtypes_follow_the_reference(golden):

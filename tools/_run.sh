@@ -1,5 +1,2 @@
 cd $GRAFT_REPO_ROOT
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r3i; mkdir -p $OUT
-python tools/bench_emulated_world.py 8 P 2>&1 | grep -v amdgpu.ids | tail -6 | cut -c1-200
-timeout 2400 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -5 $OUT/pytest_gpu.log
-timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 600 $OUT/bench_default.json
+timeout 900 python -m pytest tests/test_gpu_models.py -x -q -m gpu -k "trajectory" 2>&1 | tail -4
