@@ -203,6 +203,19 @@ int tt_weighted_mean_loss(const float* labels, int64_t B, int64_t T, const float
                           const float* row_ce, float* w_out, float* coef_out, float* loss_out,
                           tt_stream_t stream);
 
+/* tt_inbatch_ce_fwd_du followed by tt_weighted_mean_loss, the loss head running in the forward's finishing launch
+ * (ref:src/two_tower_base_retrieval.py:287-312 logits + cross entropy, :322,334-343 value weights + mean): same
+ * outputs as the two calls, the loss bit-identical to theirs; needs M user rows = B label rows.  `ws`:
+ * tt_inbatch_ce_workspace_bytes(M, N, D).  tt_scale_rows_g is the matching first step of the backward:
+ *   coef_g[i] = coef[i] * g;  out[i, :] = x[i, :] * coef_g[i]      (g: device scalar dL/dloss)
+ * i.e. dU from du_unit and the row factors the item-side backward (tt_inbatch_ce_bwd) takes as `coef`. */
+int tt_inbatch_ce_fwd_du_loss(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N, int64_t D,
+                              int64_t diag_offset, const float* labels, int64_t T, const float* uvw, float* row_lse,
+                              float* row_ce, float* du_unit, int64_t ld_du, float* w_out, float* coef_out, float* loss_out,
+                              void* ws, int64_t ws_bytes, tt_stream_t stream);
+int tt_scale_rows_g(const float* x, int64_t ldx, const float* coef, const float* g, int64_t rows, int64_t D, float* out,
+                    int64_t ldo, float* coef_g, tt_stream_t stream);
+
 /* Combined debias loss head (ref:src/two_tower_with_debiasing.py:77-129 on top of
  * ref:src/two_tower_base_retrieval.py:322-345), fused -- SURVEY 8f item 2:
  *   n = labels.uvw;  p = pos_table[position];  e = <user_emb, lin_w[:DI]> + p*lin_w[DI] + lin_b

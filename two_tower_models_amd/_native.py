@@ -64,6 +64,9 @@ SIGNATURES = {
     "tt_tower_bwd_weights_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "tt_tower_bwd_weights": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _i64, _vp]),
+    "tt_inbatch_ce_fwd_du_loss": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
+                                         _vp, _vp, _i64, _vp]),
+    "tt_scale_rows_g": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     "tt_tower_x_supported": (_int, [_i64, _i64, _i64, _i64, _i64]),
     "tt_tower_fwd_x": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
                               _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),

@@ -57,6 +57,7 @@ struct CeArgs {
   // kept logits (log2 domain, masked): Z[user][item], row stride ldk, both extents padded to 128
   float* keep;
   int64_t ldk;
+  unsigned* counter;  // fused loss epilogue: arrival counter of the finish kernel's blocks (zeroed by the product kernel)
 };
 
 // ------------------------------------------------------------------ forward
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_du_k
 
   float xr[DP8][4];
   load_stationary<DP8>(xr, p.X, p.ldx, a, p.RX, p.D, h, p.x_vec);
+  if (p.counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *p.counter = 0u;  // see ce_fwd_du_finish_loss_kernel
 
   const int64_t ntiles_all = (p.RY + BJ - 1) / BJ;
   const int64_t t0 = (int64_t)blockIdx.y * p.tiles_per_split;
@@ -630,27 +632,25 @@ __global__ __launch_bounds__(256, ((GLDS || DP8 < 16) ? 2 : 1)) void ce_fwd_du_k
 
 // merge the splits: row statistics as ce_fwd_finish_kernel, E = sum_z O_z 2^(m_z - M) / S, and
 // du_unit[a] = E[a] - Y[a + diag_offset]  (dU[a] = dLoss/dce[a] * du_unit[a])
-__global__ __launch_bounds__(256) void ce_fwd_du_finish_kernel(const float* __restrict__ part_m,
-                                                               const float* __restrict__ part_s,
-                                                               const float* __restrict__ diag,
-                                                               const float* __restrict__ slabs, int splits, int64_t M,
-                                                               int64_t D, const float* __restrict__ Y, int64_t ldy,
-                                                               int64_t diag_offset, float* __restrict__ row_lse,
-                                                               float* __restrict__ row_ce, float* __restrict__ du_unit,
-                                                               int64_t ld_du) {
+template <int ROWS_PER_BLOCK, bool AGENT_CE = false>
+__device__ __forceinline__ void ce_fwd_du_finish_row(const float* __restrict__ part_m, const float* __restrict__ part_s,
+                                                     const float* __restrict__ diag, const float* __restrict__ slabs, int splits,
+                                                     int64_t M, int64_t D, const float* __restrict__ Y, int64_t ldy,
+                                                     int64_t diag_offset, float* __restrict__ row_lse, float* __restrict__ row_ce,
+                                                     float* __restrict__ du_unit, int64_t ld_du) {
   // one wavefront per user row; lane z holds split z's statistics (splits <= 64), so the maximum, the
   // normaliser and the per-split factors are wave reductions / shuffles instead of per-lane loops,
   // and the slab reads of a column are issued together (they were one dependent round trip each)
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  // the per-split factors and weighted sums go through LDS: the column loop below is divergent for
+  // D < 64, where a shuffle could read from an inactive lane
+  __shared__ float s_f[ROWS_PER_BLOCK][64], s_w[ROWS_PER_BLOCK][64];
   if (row >= M) return;
   const int lane = threadIdx.x & 63;
   const bool has = lane < splits;
   const float pm = has ? part_m[(int64_t)lane * M + row] : NEG_BIG;
   const float ps = has ? part_s[(int64_t)lane * M + row] : 0.f;
   const float mx = wave_max(pm);
-  // the per-split factors and weighted sums go through LDS: the column loop below is divergent for
-  // D < 64, where a shuffle could read from an inactive lane
-  __shared__ float s_f[4][64], s_w[4][64];
   const int wv = threadIdx.x >> 6;
   const float fz = has ? exp2f(pm - mx) : 0.f;  // this split's rescale factor
   s_f[wv][lane] = fz;
@@ -676,8 +676,22 @@ __global__ __launch_bounds__(256) void ce_fwd_du_finish_kernel(const float* __re
   if (lane == 0) {
     const float lse2 = mx + log2f(S);
     row_lse[row] = lse2;
-    row_ce[row] = (lse2 - diag[row]) * LN2;
+    const float cev = (lse2 - diag[row]) * LN2;
+    // AGENT_CE: written through to the device-wide coherence point (another XCD's workgroup reads it in this launch)
+    if constexpr (AGENT_CE) __hip_atomic_store(row_ce + row, cev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else row_ce[row] = cev;
   }
+}
+
+__global__ __launch_bounds__(256) void ce_fwd_du_finish_kernel(const float* __restrict__ part_m,
+                                                               const float* __restrict__ part_s,
+                                                               const float* __restrict__ diag,
+                                                               const float* __restrict__ slabs, int splits, int64_t M,
+                                                               int64_t D, const float* __restrict__ Y, int64_t ldy,
+                                                               int64_t diag_offset, float* __restrict__ row_lse,
+                                                               float* __restrict__ row_ce, float* __restrict__ du_unit,
+                                                               int64_t ld_du) {
+  ce_fwd_du_finish_row<4>(part_m, part_s, diag, slabs, splits, M, D, Y, ldy, diag_offset, row_lse, row_ce, du_unit, ld_du);
 }
 
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int splits, int64_t rows, int64_t D,
@@ -701,13 +715,12 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict
   }
 }
 
-// ref:src/two_tower_base_retrieval.py:322,334-343 for [B,T] labels, one workgroup.
-__global__ __launch_bounds__(1024) void weighted_mean_loss_kernel(const float* __restrict__ labels, int64_t B,
-                                                                  int64_t T, const float* __restrict__ uvw,
-                                                                  const float* __restrict__ row_ce,
-                                                                  float* __restrict__ w_out,
-                                                                  float* __restrict__ coef_out,
-                                                                  float* __restrict__ loss_out) {
+// ref:src/two_tower_base_retrieval.py:322,334-343 for [B,T] labels, one workgroup of 1024 threads.
+template <bool AGENT_CE = false>
+__device__ __forceinline__ void weighted_mean_loss_block(const float* __restrict__ labels, int64_t B, int64_t T,
+                                                         const float* __restrict__ uvw, float* row_ce,
+                                                         float* __restrict__ w_out, float* __restrict__ coef_out,
+                                                         float* __restrict__ loss_out) {
   __shared__ float red[16];
   __shared__ float bcast;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -738,7 +751,8 @@ __global__ __launch_bounds__(1024) void weighted_mean_loss_kernel(const float* _
     const float w = w_out[i] / wmax;
     w_out[i] = w;
     coef_out[i] = w * invB;
-    acc += row_ce[i] * w;
+    const float cev = AGENT_CE ? __hip_atomic_load(row_ce + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : row_ce[i];
+    acc += cev * w;
   }
   acc = wave_sum(acc);
   __syncthreads();
@@ -748,6 +762,59 @@ __global__ __launch_bounds__(1024) void weighted_mean_loss_kernel(const float* _
     float v = 0.f;
     for (int k = 0; k < (int)(blockDim.x >> 6); ++k) v += red[k];
     *loss_out = v * invB;
+  }
+}
+
+__global__ __launch_bounds__(1024) void weighted_mean_loss_kernel(const float* __restrict__ labels, int64_t B,
+                                                                  int64_t T, const float* __restrict__ uvw,
+                                                                  const float* __restrict__ row_ce,
+                                                                  float* __restrict__ w_out,
+                                                                  float* __restrict__ coef_out,
+                                                                  float* __restrict__ loss_out) {
+  weighted_mean_loss_block(labels, B, T, uvw, const_cast<float*>(row_ce), w_out, coef_out, loss_out);
+}
+
+// ce_fwd_du_finish_kernel + weighted_mean_loss_kernel in one launch (16 rows per 1024-thread block): the block that
+// ARRIVES LAST (device-scope counter, zeroed by the product kernel that precedes this one in the stream) runs the loss
+// head over all M rows -- the same code on the same 1024-thread shape as the stand-alone kernel, reading complete
+// arrays in a fixed order, so the loss is bit-identical to the two-launch form whichever block happens to be last.
+// Inside the train step every launch of this latency-bound chain (finish -> weights -> loss) is stretched 5-7x by
+// the table sweep's HBM traffic; one launch instead of two is 40 us of the 1.2 ms C2 step.
+// NO __threadfence(): a device-scope release fence is an L2 write-back on this chip (buffer_wbl2), and 4096 waves each
+// flushing an L2 that the Adam sweep keeps full of dirty lines made the step 0.2 ms LONGER.  Only row_ce crosses
+// workgroups: it is stored and loaded as a device-scope relaxed atomic (write-through / cache-bypassing accesses), the
+// workgroup barrier waits for the stores' acknowledgement, and the counter's atomic publishes them.
+__global__ __launch_bounds__(1024) void ce_fwd_du_finish_loss_kernel(const float* __restrict__ part_m, const float* __restrict__ part_s,
+                                                                     const float* __restrict__ diag, const float* __restrict__ slabs,
+                                                                     int splits, int64_t M, int64_t D, const float* __restrict__ Y,
+                                                                     int64_t ldy, int64_t diag_offset, float* __restrict__ row_lse,
+                                                                     float* row_ce, float* __restrict__ du_unit, int64_t ld_du,
+                                                                     const float* __restrict__ labels, int64_t T,
+                                                                     const float* __restrict__ uvw, float* __restrict__ w_out,
+                                                                     float* __restrict__ coef_out, float* __restrict__ loss_out,
+                                                                     unsigned* counter) {
+  ce_fwd_du_finish_row<16, true>(part_m, part_s, diag, slabs, splits, M, D, Y, ldy, diag_offset, row_lse, row_ce, du_unit, ld_du);
+  __shared__ int is_last;
+  __syncthreads();  // every wave's stores (row_ce among them) have been acknowledged
+  if (threadIdx.x == 0)
+    is_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (!is_last) return;
+  weighted_mean_loss_block<true>(labels, M, T, uvw, row_ce, w_out, coef_out, loss_out);
+}
+
+// dU[i, :] = du_unit[i, :] * coef[i] * g and coef_g[i] = coef[i] * g, g = the upstream gradient of the scalar loss (device
+// scalar): the `coef * g` elementwise launch and tt_scale_rows of the two-op form in one
+__global__ __launch_bounds__(256) void scale_rows_g_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ coef,
+                                                           const float* __restrict__ g, int64_t rows, int64_t D,
+                                                           float* __restrict__ out, int64_t ldo, float* __restrict__ coef_g) {
+  const float gv = *g;
+  const int64_t total = rows * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / D, c = i - r * D;
+    const float cg = coef[r] * gv;
+    out[r * ldo + c] = x[r * ldx + c] * cg;
+    if (c == 0) coef_g[r] = cg;
   }
 }
 
@@ -860,7 +927,7 @@ extern "C" int64_t tt_inbatch_ce_workspace_bytes(int64_t M, int64_t N, int64_t D
   // tt_inbatch_ce_fwd_du keeps the statistics and ALWAYS writes its per-split slabs
   const int64_t fwd_du = fwd + round_up((int64_t)pu.splits * M * D * 4, 256);
   const int64_t most = fwd > bwd ? fwd : bwd;
-  return most > fwd_du ? most : fwd_du;
+  return (most > fwd_du ? most : fwd_du) + 256;  // + the fused loss epilogue's arrival counter (last 256 B)
 }
 
 extern "C" int tt_inbatch_ce_fwd(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M,
@@ -896,10 +963,14 @@ extern "C" int64_t tt_inbatch_ce_logits_bytes(int64_t M, int64_t N) {
   return round_up(M, 128) * round_up(N, 128) * 4;
 }
 
+struct CeLossTail {  // the weighted-mean loss head fused behind the forward (tt_inbatch_ce_fwd_du_loss)
+  const float* labels; int64_t T; const float* uvw;
+  float *w_out, *coef_out, *loss_out;
+};
 static int fwd_du_impl(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N,
                        int64_t D, int64_t diag_offset, float* row_lse, float* row_ce, float* du_unit,
                        int64_t ld_du, float* logits, int64_t logits_bytes, void* ws, int64_t ws_bytes,
-                       tt_stream_t stream);
+                       tt_stream_t stream, const CeLossTail* tail = nullptr);
 
 extern "C" int tt_inbatch_ce_fwd_du(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N,
                                     int64_t D, int64_t diag_offset, float* row_lse, float* row_ce, float* du_unit,
@@ -918,14 +989,18 @@ extern "C" int tt_inbatch_ce_fwd_du_keep(const float* U, int64_t ldu, const floa
 static int fwd_du_impl(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N,
                        int64_t D, int64_t diag_offset, float* row_lse, float* row_ce, float* du_unit,
                        int64_t ld_du, float* logits, int64_t logits_bytes, void* ws, int64_t ws_bytes,
-                       tt_stream_t stream) {
+                       tt_stream_t stream, const CeLossTail* tail) {
   if (!U || !I || !row_lse || !row_ce || !du_unit || !ws) return fail_arg("tt_inbatch_ce_fwd_du: null pointer");
   if (M <= 0 || N <= 0 || D <= 0 || ldu < D || ldi < D || ld_du < D) return fail_arg("tt_inbatch_ce_fwd_du: sizes");
   if (diag_offset < 0 || diag_offset + M > N) return fail_arg("tt_inbatch_ce_fwd_du: diagonal outside the item block");
   if (D > 128) {
     if (logits) { set_error("tt_inbatch_ce_fwd_du_keep: needs D in {32, 64, 128} (use tt_inbatch_ce_fwd_du)"); return TT_E_UNSUPPORTED; }
-    return ce_wide_run(1, U, ldu, I, ldi, M, N, D, diag_offset, row_lse, row_ce, nullptr, du_unit, ld_du, nullptr, 0, ws, ws_bytes,
-                       S(stream));
+    int rc = ce_wide_run(1, U, ldu, I, ldi, M, N, D, diag_offset, row_lse, row_ce, nullptr, du_unit, ld_du, nullptr, 0, ws, ws_bytes,
+                         S(stream));
+    if (rc || !tail) return rc;
+    weighted_mean_loss_kernel<<<1, 1024, 0, S(stream)>>>(tail->labels, M, tail->T, tail->uvw, row_ce, tail->w_out, tail->coef_out,
+                                                         tail->loss_out);
+    return check_launch("weighted_mean_loss_kernel");
   }
   CePlan pl;
   if (!plan_ce(M, N, D, pl)) { set_error("tt_inbatch_ce: D=%lld > 128 not implemented", (long long)D); return TT_E_UNSUPPORTED; }
@@ -937,6 +1012,7 @@ static int fwd_du_impl(const float* U, int64_t ldu, const float* I, int64_t ldi,
   a.x_vec = (ldu % 4 == 0) && al16(U); a.y_vec = (ldi % 4 == 0) && al16(I);
   a.part_m = w; a.part_s = w + (int64_t)pl.splits * M; a.diag = w + 2 * (int64_t)pl.splits * M;
   a.out = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + round_up((2 * (int64_t)pl.splits * M + M) * 4, 256));
+  if (tail) a.counter = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + tt_inbatch_ce_workspace_bytes(M, N, D) - 256);
   dim3 grid((unsigned)ceil_div(M, BI), (unsigned)pl.splits);
   hipStream_t st = S(stream);
   int rc;
@@ -953,9 +1029,36 @@ static int fwd_du_impl(const float* U, int64_t ldu, const float* I, int64_t ldi,
     rc = dispatch_fwd_du(pl.dp8, can_dma(I, ldi, D, pl.dp8), a, grid, st);
   }
   if (rc) return rc;
+  if (tail) {
+    ce_fwd_du_finish_loss_kernel<<<(unsigned)ceil_div(M, 16), 1024, 0, st>>>(a.part_m, a.part_s, a.diag, a.out, pl.splits, M, D, I, ldi,
+                                                                              diag_offset, row_lse, row_ce, du_unit, ld_du, tail->labels,
+                                                                              tail->T, tail->uvw, tail->w_out, tail->coef_out,
+                                                                              tail->loss_out, a.counter);
+    return check_launch("ce_fwd_du_finish_loss_kernel");
+  }
   ce_fwd_du_finish_kernel<<<(unsigned)ceil_div(M, 4), 256, 0, st>>>(a.part_m, a.part_s, a.diag, a.out, pl.splits, M, D, I,
                                                                      ldi, diag_offset, row_lse, row_ce, du_unit, ld_du);
   return check_launch("ce_fwd_du_finish_kernel");
+}
+
+extern "C" int tt_inbatch_ce_fwd_du_loss(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N,
+                                         int64_t D, int64_t diag_offset, const float* labels, int64_t T, const float* uvw,
+                                         float* row_lse, float* row_ce, float* du_unit, int64_t ld_du, float* w_out,
+                                         float* coef_out, float* loss_out, void* ws, int64_t ws_bytes, tt_stream_t stream) {
+  if (!uvw || !w_out || !coef_out || !loss_out) return fail_arg("tt_inbatch_ce_fwd_du_loss: null pointer");
+  if (labels && T <= 0) return fail_arg("tt_inbatch_ce_fwd_du_loss: sizes");
+  const CeLossTail tail{labels, T, uvw, w_out, coef_out, loss_out};
+  return fwd_du_impl(U, ldu, I, ldi, M, N, D, diag_offset, row_lse, row_ce, du_unit, ld_du, nullptr, 0, ws, ws_bytes, stream, &tail);
+}
+
+extern "C" int tt_scale_rows_g(const float* x, int64_t ldx, const float* coef, const float* g, int64_t rows, int64_t D,
+                               float* out, int64_t ldo, float* coef_g, tt_stream_t stream) {
+  if (!x || !coef || !g || !out || !coef_g) return fail_arg("tt_scale_rows_g: null pointer");
+  if (rows <= 0 || D <= 0 || ldx < D || ldo < D) return fail_arg("tt_scale_rows_g: sizes");
+  const int64_t total = rows * D;
+  const unsigned blocks = (unsigned)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096);
+  scale_rows_g_kernel<<<blocks, 256, 0, S(stream)>>>(x, ldx, coef, g, rows, D, out, ldo, coef_g);
+  return check_launch("scale_rows_g_kernel");
 }
 
 extern "C" int tt_inbatch_ce_bwd(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M,

@@ -684,6 +684,75 @@ class WeightedMeanLoss(torch.autograd.Function):
         return coef * g, None, None
 
 
+_FUSED_LOSS = os.environ.get("TT_CE_NO_FUSED_LOSS") is None  # A/B switch
+
+
+def fused_loss_supported(U: torch.Tensor, I: torch.Tensor, labels: Optional[torch.Tensor], uvw: torch.Tensor) -> bool:
+    """InBatchSoftmaxWeightedLoss: a training forward (U needs a gradient) with in-batch negatives only (N < 4 M: the wide
+    form keeps its logits and has its own forward), float32 everywhere, one label row per user row."""
+    return bool(_FUSED_LOSS and _FUSED_DU and U.is_cuda and U.requires_grad and torch.is_grad_enabled() and U.dim() == 2 and I.dim() == 2
+                and U.dtype == torch.float32 and I.dtype == torch.float32 and uvw.dtype == torch.float32
+                and I.shape[0] < 4 * U.shape[0]
+                and (labels is None or (labels.dim() == 2 and labels.shape[0] == U.shape[0] and labels.shape[1] == uvw.numel()
+                                        and labels_fusable(labels))))
+
+
+class InBatchSoftmaxWeightedLoss(torch.autograd.Function):
+    """WeightedMeanLoss(InBatchSoftmaxCE(U, I), labels, uvw) as one op: the loss head runs in the launch that finishes
+    the forward (tt_inbatch_ce_fwd_du_loss; ref:src/two_tower_base_retrieval.py:287-312,322,334-343), and the backward
+    starts with ONE launch that forms dL/dce * g and dU (tt_scale_rows_g) instead of an elementwise multiply and a row
+    scaling.  Same values as the two ops, bit for bit; two launches fewer on the step's critical path."""
+
+    @staticmethod
+    def forward(ctx, U, I, labels, uvw):
+        dev = N.require_device(U, I, labels, uvw)
+        U, I, uvw = _rowmajor(U), _rowmajor(I), uvw.contiguous()
+        M, D = U.shape
+        Nn = I.shape[0]
+        T = 1
+        if labels is not None:
+            labels = _labels_f32(labels, "InBatchSoftmaxWeightedLoss")
+            T = labels.shape[1]
+        if D > 128:
+            note_generic("in-batch softmax CE", f"D = {D} > 128: logits materialised per row chunk + library GEMMs "
+                                                "(csrc/ce_wide.hip) instead of the register-stationary kernels")
+        lib = N.load()
+        lse = torch.empty(M, dtype=torch.float32, device=dev)
+        ce = torch.empty(M, dtype=torch.float32, device=dev)
+        w = torch.empty(M, dtype=torch.float32, device=dev)
+        coef = torch.empty(M, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        du_unit = torch.empty(M, D, dtype=torch.float32, device=dev)
+        wsp, wsn = _ws(dev, lib.tt_inbatch_ce_workspace_bytes(M, Nn, D))
+        pu, _, _, ldu = _f32_2d(U, "U")
+        pi, _, _, ldi = _f32_2d(I, "I")
+        N.check(lib.tt_inbatch_ce_fwd_du_loss(pu, ldu, pi, ldi, M, Nn, D, 0, N.ptr(labels), T, uvw.data_ptr(), lse.data_ptr(),
+                                              ce.data_ptr(), du_unit.data_ptr(), D, w.data_ptr(), coef.data_ptr(), loss.data_ptr(),
+                                              wsp, wsn, N.stream()), "tt_inbatch_ce_fwd_du_loss")
+        ctx.save_for_backward(U, I, lse, du_unit, coef)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        U, I, lse, du_unit, coef = ctx.saved_tensors
+        dev = U.device
+        M, D = U.shape
+        Nn = I.shape[0]
+        lib = N.load()
+        g = g.contiguous()
+        dU = torch.empty(M, D, dtype=torch.float32, device=dev)
+        coef_g = torch.empty(M, dtype=torch.float32, device=dev)
+        N.check(lib.tt_scale_rows_g(du_unit.data_ptr(), D, coef.data_ptr(), g.data_ptr(), M, D, dU.data_ptr(), D, coef_g.data_ptr(),
+                                    N.stream()), "tt_scale_rows_g")
+        dI = torch.empty(Nn, D, dtype=torch.float32, device=dev)
+        wsp, wsn = _ws(dev, lib.tt_inbatch_ce_workspace_bytes(M, Nn, D))
+        pu, _, _, ldu = _f32_2d(U, "U")
+        pi, _, _, ldi = _f32_2d(I, "I")
+        N.check(lib.tt_inbatch_ce_bwd(pu, ldu, pi, ldi, M, Nn, D, 0, lse.data_ptr(), coef_g.data_ptr(), None, D,
+                                      dI.data_ptr(), D, wsp, wsn, N.stream()), "tt_inbatch_ce_bwd")
+        return dU, dI, None, None
+
+
 class DebiasedWeightedLoss(torch.autograd.Function):
     """mean_i(row_ce_i * w_i) + aux of the combined debias head (ref:src/two_tower_with_debiasing.py:77-129
     on ref:src/two_tower_base_retrieval.py:322-345), in two kernels forward and two backward

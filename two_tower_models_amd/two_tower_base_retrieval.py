@@ -164,16 +164,21 @@ class TwoTowerBaseRetrieval(nn.Module):
     ) -> torch.Tensor:
         """In-batch softmax loss weighted by normalised net user value (ref :279-347).
         The [B, B] logits are never materialised."""
-        row_ce = ops.InBatchSoftmaxCE.apply(user_embedding, item_embeddings, 0)  # [B]
         hook_is_identity = type(self).debias_net_user_value is TwoTowerBaseRetrieval.debias_net_user_value
         T = self.user_value_weights.numel()
-        if hook_is_identity and ops.labels_fusable(labels):
-            if labels.dim() == 2 and labels.shape[1] == T and labels.shape[0] == row_ce.shape[0]:
-                return ops.WeightedMeanLoss.apply(row_ce, labels, self.user_value_weights)
-            if labels.dim() == 1 and labels.shape[0] == row_ce.shape[0] and T in (1, labels.shape[0]):
-                # train.py's [B] labels (ref:train/train.py:53-55,78): labels * weights sums to ONE scalar,
-                # which clamp and / max turn into exactly 1.0 -- the plain mean of the row losses
-                return ops.WeightedMeanLoss.apply(row_ce, None, self.user_value_weights)
+        B = user_embedding.shape[0]
+        # train.py's [B] labels (ref:train/train.py:53-55,78): labels * weights sums to ONE scalar, which clamp and
+        # / max turn into exactly 1.0 -- the plain mean of the row losses (labels = None below)
+        plain_mean = labels.dim() == 1 and labels.shape[0] == B and T in (1, labels.shape[0])
+        weighted = labels.dim() == 2 and labels.shape[1] == T and labels.shape[0] == B
+        if hook_is_identity and ops.labels_fusable(labels) and (weighted or plain_mean):
+            lab = labels if weighted else None
+            if ops.fused_loss_supported(user_embedding, item_embeddings, lab, self.user_value_weights):
+                # the loss head inside the launch that finishes the logits forward (one op, two launches fewer)
+                return ops.InBatchSoftmaxWeightedLoss.apply(user_embedding, item_embeddings, lab, self.user_value_weights)
+            row_ce = ops.InBatchSoftmaxCE.apply(user_embedding, item_embeddings, 0)  # [B]
+            return ops.WeightedMeanLoss.apply(row_ce, lab, self.user_value_weights)
+        row_ce = ops.InBatchSoftmaxCE.apply(user_embedding, item_embeddings, 0)  # [B]
         # General path: exactly the reference's expressions on [B]-sized tensors, so every
         # broadcasting quirk (1-D labels collapsing to a scalar weight, SURVEY.md 3.1;
         # debias heads that differentiate through the weights) behaves identically.
