@@ -377,6 +377,35 @@ def test_weighted_mean_loss(T):
     assert torch.allclose(ced.grad.cpu(), w / B, atol=1e-8)
 
 
+@pytest.mark.parametrize("M,D,Tn", [(8192, 128, 3), (4096, 128, 0), (777, 64, 3), (17, 32, 1), (300, 256, 3)])
+def test_inbatch_ce_with_fused_loss_head_is_the_two_op_path_bit_for_bit(T, M, D, Tn):
+    """tt_inbatch_ce_fwd_du_loss + tt_scale_rows_g (loss head inside the forward's finishing launch, run by whichever
+    workgroup arrives last) against InBatchSoftmaxCE + WeightedMeanLoss: the loss and every gradient are IDENTICAL, run
+    after run (the head reads complete arrays in a fixed order); ragged row counts (not a multiple of 16), labels None
+    (train.py's 1-D labels), the D > 128 generic form; and the loss against the CPU oracle within 1e-5."""
+    ops, N = T
+    gen = torch.Generator().manual_seed(M + D)
+    U0, I0 = torch.randn(M, D, generator=gen) * 0.4, torch.randn(M, D, generator=gen) * 0.4
+    labels = (torch.rand(M, Tn, generator=gen) < 0.4).float() if Tn else None
+    uvw = torch.tensor([0.1, 0.2, 0.3][:max(Tn, 1)])
+    labd, uvwd = (labels.to(DEV) if Tn else None), uvw.to(DEV)
+    outs = []
+    for fused in (True, False, True):
+        U, I = U0.clone().to(DEV).requires_grad_(True), I0.clone().to(DEV).requires_grad_(True)
+        if fused:
+            assert ops.fused_loss_supported(U, I, labd, uvwd)
+            loss = ops.InBatchSoftmaxWeightedLoss.apply(U, I, labd, uvwd)
+        else:
+            loss = ops.WeightedMeanLoss.apply(ops.InBatchSoftmaxCE.apply(U, I, 0), labd, uvwd)
+        (loss * 1.75).backward()  # an upstream gradient other than 1
+        outs.append((loss.detach().clone(), U.grad.clone(), I.grad.clone()))
+    for a, b in ((outs[0], outs[1]), (outs[0], outs[2])):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    ce = R.inbatch_rowwise_ce(U0, I0)
+    w = R.normalise_value_weights(R.net_user_value(labels, uvw)) if Tn else torch.ones(M)
+    assert abs(outs[0][0].item() - float((ce * w).mean())) < 1e-5 * max(1.0, float(ce.mean()))
+
+
 # ------------------------------------------------------------------ row plan + Adam
 @pytest.mark.parametrize("n,n_rows", [(1, 10), (777, 100), (8192, 1_000_000), (50_000, 300), (4096, 70_000_000),
                                       (63, 2), (1025, 5000), (8191, 3), (8193, 1_000_000), (5000, 1)])
