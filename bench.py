@@ -292,7 +292,7 @@ def secondary(device, lib, N):
         # stand-in collectives -- clearly labelled, with the two logits kernels' own rooflines and the host's cost
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
         import bench_emulated_world as _emu
-        sec["emulated_W8"] = _emu.emulated(8, "P", steps=30, warmup=5, device=device)
+        sec["emulated_W8"] = _emu.emulated(8, "P", steps=30, warmup=25, device=device)  # warm-up covers the trainer's 15-step schedule scan
     except Exception as e:
         sec["emulated_W8"] = {"error": f"{type(e).__name__}: {e}"}
     torch.cuda.empty_cache()

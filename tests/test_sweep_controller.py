@@ -60,3 +60,33 @@ def test_rescan_after_the_interval():
     ms = {0: 1.30, 640: 1.31, 512: 1.18, 384: 1.21, 256: 1.41, 128: 2.3}
     me, hist = _drive(lambda lv: ms[lv], lambda lv: 1.0, 1, DenseExactAdam._RESCAN_STEPS + 200)
     assert hist.count(128) == 2 * DenseExactAdam._SCAN_BLOCK and me._sweep_wgs == 512
+
+
+@pytest.mark.parametrize("lag", [0, 2, 25])
+def test_sharded_schedule_scan_runs_each_candidate_one_block_and_keeps_the_fastest(lag):
+    """sharded._ScheduleScan (where the sweep starts / how wide it runs in the row-sharded step) on stub events: the host
+    `lag` steps ahead of the GPU, every candidate exactly one block, the fastest kept from then on."""
+    from two_tower_models_amd.sharded import _ScheduleScan
+    ms = {(0, 256): 4.55, (2, 256): 4.35, (0, 0): 4.46}
+    clock = {"host": 0, "t": 0.0}
+
+    class Ev:
+        def record(self):
+            self.step, self.t = clock["host"], clock["t"]
+
+        def query(self):
+            return clock["host"] >= self.step + lag
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    scan = _ScheduleScan(list(ms), block=4, skip_first=3, new_event=Ev)
+    hist = []
+    for _ in range(80):
+        cand = scan.begin()
+        clock["t"] += ms[cand]  # the step's duration on the GPU's clock
+        scan.end()
+        clock["host"] += 1
+        hist.append(cand)
+    assert scan.best == (2, 256) and all(c == (2, 256) for c in hist[-30:])
+    assert hist[:3] == [(0, 256)] * 3 and hist[3:15] == [(0, 256)] * 4 + [(2, 256)] * 4 + [(0, 0)] * 4

@@ -63,7 +63,7 @@ def _time_steps(trainer, batches, steps):
     return host, (time.perf_counter() - t0) / steps * 1e3
 
 
-def emulated(W=8, workload="P", steps=30, warmup=5, device=None, verbose=False):
+def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False):
     """One rank's kernels of the W-GPU step (stand-in collectives), as a record for bench.py's `secondary`."""
     import bench
     from two_tower_models_amd import _native as N

@@ -567,6 +567,65 @@ class _RoutedLookup:
         self.n_local = table.hi - table.lo
 
 
+class _ScheduleScan:
+    """Pick the fastest of a few step schedules by MEASURING them (the sharded step's counterpart of
+    DenseExactAdam._tune_sweep): full steps are timed with events recorded on the main stream, queried but never
+    waited on.  Each candidate runs one block of `block` consecutive steps, enqueued open loop (the host may be many
+    steps ahead of the GPU); the first step of a block overlaps the previous candidate's tail and is not counted; once
+    the last block's events are in, the candidate with the smallest step time is kept.  Results never depend on the
+    choice: every candidate is the same arithmetic in the same order."""
+
+    def __init__(self, candidates, block: int = 6, skip_first: int = 4, new_event=None):
+        self._new_event = new_event or (lambda: torch.cuda.Event(enable_timing=True))  # (tests: stub events)
+        self.cands = list(candidates)
+        self.plan = [c for c in self.cands for _ in range(block)]
+        self.block, self.skip_first = block, skip_first
+        self.n = 0
+        self.pending: list = []
+        self.obs = {c: [] for c in self.cands}
+        self.best = None
+        self._cur = None
+
+    def begin(self):
+        """-> the candidate this step runs with; call end() when the step has been enqueued."""
+        if self.best is not None:
+            return self.best
+        self._drain()
+        if self.best is not None:
+            return self.best
+        k = self.n - self.skip_first
+        self.n += 1
+        if k >= len(self.plan):  # every block has been enqueued: first candidate until the last measurements are in
+            self._cur = None
+            return self.cands[0]
+        cand = self.cands[0] if k < 0 else self.plan[k]
+        ev = self._new_event()
+        ev.record()
+        self._cur = [ev, None, cand, k >= 0 and k % self.block != 0]
+        return cand
+
+    def end(self) -> None:
+        if self.best is not None or self._cur is None:
+            return
+        ev = self._new_event()
+        ev.record()
+        self._cur[1] = ev
+        self.pending.append(self._cur)
+        self._cur = None
+
+    def _drain(self) -> None:
+        while self.pending and self.pending[0][1].query():
+            a, b, cand, counted = self.pending.pop(0)
+            if counted:
+                self.obs[cand].append(a.elapsed_time(b))
+        if self.n >= self.skip_first + len(self.plan) and not self.pending:
+            ms = {c: min(v) for c, v in self.obs.items() if len(v) >= 2}
+            self.best = min(ms, key=ms.get) if ms else self.cands[0]
+            if os.environ.get("TT_TUNE_DEBUG"):
+                import sys
+                print(f"[tt] sharded step schedule (sweep start, workgroups): {ms} -> {self.best}", file=sys.stderr)
+
+
 class ShardedTrainer:
     """TwoTowerBaseRetrieval train step (ref:src/two_tower_base_retrieval.py:349-394 +
     ref:train/train.py:112-125) on W row-sharded ranks.  `cfg`: n_users, n_items, D, F, B; with
@@ -674,9 +733,19 @@ class ShardedTrainer:
         # kernels when they, not the sweep, are the step (W = 8: 4.49, W = 4: 3.18 ms).
         late = os.environ.get("TT_SWEEP_LATE")  # A/B switch
         self._sweep_late = late == "1"
+        self._sweep_bwd = late == "2"  # start the sweep with the BACKWARD logits kernel
         self._sweep_wgs = 256 if sweep_ms < 0.75 * logits_ms else 0
         if os.environ.get("TT_SWEEP_WGS") is not None:  # A/B switch
             self._sweep_wgs = int(os.environ["TT_SWEEP_WGS"])
+        # Round 3: when the logits kernels are the step (thin row blocks, several ranks' items per user) WHERE the sweep
+        # starts and how wide it runs are worth 3-8 % of the step and the best pair is a narrow optimum (emulated W = 8:
+        # top of the step / 256 workgroups 4.49 ms, with the backward logits kernel / 256: 4.38, / 320: 4.67, / 192:
+        # 4.57) -- so it is measured on the first steps instead of guessed (see _ScheduleScan).  (start, workgroups),
+        # start 0 = top of the step, 2 = with the backward logits kernel.
+        self._scan = None
+        if (late is None and os.environ.get("TT_SWEEP_WGS") is None and sweep_ms < 0.75 * logits_ms
+                and getattr(self.be, "device", device).type == "cuda" and self.routing != "allgather"):
+            self._scan = _ScheduleScan([(0, 256), (2, 256), (0, 0)], block=4, skip_first=3)  # 15 steps, then fixed
         # the same regime decides whether the forward keeps the logits for the backward (one product
         # fewer, M*N*4 B of HBM traffic each way more): worth it once the sweep no longer binds
         keep = os.environ.get("TT_CE_KEEP_LOGITS")
@@ -809,6 +878,9 @@ class ShardedTrainer:
         be, W, D, B = self.be, self.W, self.cfg["D"], user_id.shape[0]
         if hasattr(be, "poll"):
             be.poll()  # an out-of-range id seen by an earlier step surfaces here as IndexError
+        if self._scan is not None:
+            start, self._sweep_wgs = self._scan.begin()
+            self._sweep_late, self._sweep_bwd = False, start == 2
         routes = self._planned_next
         self._planned_next = None
         if routes is None or routes.key != self._route_key(batch):
@@ -837,7 +909,7 @@ class ShardedTrainer:
         st_i = be.adam_table_begin(self.items.weight, self.items.m, self.items.v, lk_i.n_local, item_local)
         sweep = [(self.users.weight, self.users.m, self.users.v, lk_u.n_local),
                  (self.items.weight, self.items.m, self.items.v, lk_i.n_local)]
-        if not self._sweep_late:
+        if not self._sweep_late and not self._sweep_bwd:
             be.sweep_async(sweep, self.hyper, self._sweep_wgs)
         pu, pi = self._tower_params("user"), self._tower_params("item")
         summary, enc_saved = None, None
@@ -858,6 +930,8 @@ class ShardedTrainer:
             be.sweep_async(sweep, self.hyper, self._sweep_wgs)
         ce, lse = be.ce_fwd(U, I_all, off)
         loss, coef = self._weighted_loss(ce, labels, B, glob)
+        if self._sweep_bwd:
+            be.sweep_async(sweep, self.hyper, self._sweep_wgs)
         # 4. backward through the loss
         dU, dI_all = be.ce_bwd(U, I_all, off, lse, coef)
         dI_p = reduce_scatter_rows_start(dI_all) if glob else _Pending(dI_all)  # travels under the user tower backward
@@ -887,6 +961,8 @@ class ShardedTrainer:
                            "dI_reduce_scatter": (W - 1) * B * D * 4 if glob else 0,
                            "dense_grad_allreduce": int(2 * (W - 1) / W * self.flat_g.numel() * 4),
                            "scalars": 3 * 4 * (W - 1)}
+        if self._scan is not None:
+            self._scan.end()
         return loss
 
     def _weighted_loss(self, ce, labels, B, glob):
