@@ -561,7 +561,7 @@ def test_tower_weight_gradients_kernel_vs_fp64(T, B, D, F):
 
 
 @pytest.mark.parametrize("B,D,F,n_rows", [(4096, 128, 8, 100_000), (100, 128, 8, 50), (333, 64, 20, 1000), (65, 32, 8, 200),
-                                          (1, 128, 33, 7)])
+                                          (1, 128, 33, 7), (8192, 128, 8, 5000)])  # > 4096 rows: the 64-row-per-workgroup form
 def test_fused_tower_with_third_input_block_forward_and_backward(T, B, D, F, n_rows):
     """tt_tower_fwd_x / tt_tower_bwd_data_x / tt_tower_bwd_weights_x: the history model's user tower
     [ id | MLP | recent | mean ] -> Linear(4D -> D) (ref:src/two_tower_with_user_history_encoder.py:81-83,85-122) as one
@@ -604,7 +604,7 @@ def test_fused_tower_with_third_input_block_forward_and_backward(T, B, D, F, n_r
 
 
 @pytest.mark.parametrize("B,D,F,n_rows", [(8192, 128, 8, 100_000), (100, 128, 8, 50), (333, 64, 20, 1000), (64, 32, 8, 200),
-                                          (1, 128, 33, 7)])
+                                          (1, 128, 33, 7), (4200, 64, 8, 5000)])  # > 4096 rows: the 64-row-per-workgroup form
 def test_fused_tower_matches_oracle_forward_and_backward(T, B, D, F, n_rows):
     """tt_tower_fwd / tt_tower_bwd_data (one launch per direction: lookup + feature MLP + cat + tower Linear,
     ref:src/two_tower_base_retrieval.py:129-219) against the CPU oracle's item tower: output, every parameter gradient,

@@ -81,25 +81,28 @@ __device__ __forceinline__ void tw_load_t(float (&xr)[DP8][4], const float* __re
     for (int c = 0; c < 4; ++c) xr[g][c] = (n < N) ? W[(int64_t)(8 * g + 4 * h + c) * ld + n] : 0.f;
 }
 
-template <int DE8, bool XTRA>  // D = 8 * DE8
+// RT = 32-row tiles per workgroup: 2 (64 batch rows) when that still gives every CU a workgroup, else 1 -- at B = 8192 the
+// 64-row form is 128 workgroups on a 256-CU chip, and the tower is latency-bound (weights from L2, three dependent stages).
+template <int DE8, bool XTRA, int RT>  // D = 8 * DE8
 __global__ __launch_bounds__(256) void tower_fwd_kernel(const TowerFwdArgs p) {
+  constexpr int ROWS = 32 * RT;
   constexpr int D = 8 * DE8, K3 = 2 * D, LDH = TW_HID + 4, LDT = K3 + 4, LDW3 = XTRA ? 2 * K3 : K3;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* hT = smem;                    // [64][260]  hidden activations
-  float* tT = hT + TW_ROWS * LDH;      // [64][2D+4] tower input: id row | feature-MLP output
-  float* fT = tT + TW_ROWS * LDT;      // [64][F]    dense features
+  float* tT = hT + ROWS * LDH;      // [64][2D+4] tower input: id row | feature-MLP output
+  float* fT = tT + ROWS * LDT;      // [64][F]    dense features
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-  const int64_t row0 = (int64_t)blockIdx.x * TW_ROWS;
+  const int64_t row0 = (int64_t)blockIdx.x * ROWS;
   const int F = (int)p.F;
 
   // ---- stage 0: features and id rows of the 64 batch rows into LDS
-  for (int i = threadIdx.x; i < TW_ROWS * F; i += 256) {
+  for (int i = threadIdx.x; i < ROWS * F; i += 256) {
     const int m = i / F, f = i - m * F;
     fT[i] = (row0 + m < p.B) ? p.feats[(row0 + m) * p.ldf + f] : 0.f;
   }
   {
     constexpr int C4 = D / 4;  // float4 per id row
-    for (int i = threadIdx.x; i < TW_ROWS * C4; i += 256) {
+    for (int i = threadIdx.x; i < ROWS * C4; i += 256) {
       const int m = i / C4, c = i - m * C4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row0 + m < p.B) {
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void tower_fwd_kernel(const TowerFwdArgs p) {
 #pragma unroll
     for (int f = 0; f < 16; ++f) w1r[f] = f < F ? p.W1[(int64_t)j * F + f] : 0.f;
     const float bj = p.b1[j];
-    for (int m = 0; m < TW_ROWS; ++m) {
+    for (int m = 0; m < ROWS; ++m) {
       float acc = bj;
 #pragma unroll
       for (int f = 0; f < 16; ++f)
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256) void tower_fwd_kernel(const TowerFwdArgs p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) be[e] = p.b2[nw + (e & 3) + 8 * (e >> 2) + 4 * h];
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
+    for (int jt = 0; jt < RT; ++jt) {
       const f32x16 acc = tw_tile<TW_HID / 8>(hT, xr, jt, r, h);
       float* dst = tT + (jt * 32 + r) * LDT + D + nw + 4 * h;
 #pragma unroll
@@ -147,21 +150,21 @@ __global__ __launch_bounds__(256) void tower_fwd_kernel(const TowerFwdArgs p) {
     }
   }
   // what the backward needs: h (ReLU mask, dW2) -- coalesced copy of the LDS image
-  for (int i = threadIdx.x; i < TW_ROWS * (TW_HID / 4); i += 256) {
+  for (int i = threadIdx.x; i < ROWS * (TW_HID / 4); i += 256) {
     const int m = i / (TW_HID / 4), c = i - m * (TW_HID / 4);
     if (row0 + m < p.B)
       *reinterpret_cast<float4*>(p.h_out + (row0 + m) * TW_HID + 4 * c) = *reinterpret_cast<const float4*>(hT + m * LDH + 4 * c);
   }
   __syncthreads();
   // ---- stage 3: y = tin W3^T + b3; tin goes out for dW3
-  for (int i = threadIdx.x; i < TW_ROWS * (K3 / 4); i += 256) {
+  for (int i = threadIdx.x; i < ROWS * (K3 / 4); i += 256) {
     const int m = i / (K3 / 4), c = i - m * (K3 / 4);
     if (row0 + m < p.B)
       *reinterpret_cast<float4*>(p.tin_out + (row0 + m) * K3 + 4 * c) = *reinterpret_cast<const float4*>(tT + m * LDT + 4 * c);
   }
   float* xT = hT;  // XTRA: the third block takes the hidden activations' place ([64][2D + 4], 2D <= 256)
   if constexpr (XTRA) {
-    for (int i = threadIdx.x; i < TW_ROWS * (K3 / 4); i += 256) {
+    for (int i = threadIdx.x; i < ROWS * (K3 / 4); i += 256) {
       const int m = i / (K3 / 4), c = i - m * (K3 / 4);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row0 + m < p.B) v = *reinterpret_cast<const float4*>(p.extra + (row0 + m) * p.ldx + 4 * c);
@@ -175,16 +178,16 @@ __global__ __launch_bounds__(256) void tower_fwd_kernel(const TowerFwdArgs p) {
     float be[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) be[e] = p.b3[nw + (e & 3) + 8 * (e >> 2) + 4 * h];
-    f32x16 accs[2];
+    f32x16 accs[RT];
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) accs[jt] = tw_tile<K3 / 8>(tT, xr, jt, r, h);
+    for (int jt = 0; jt < RT; ++jt) accs[jt] = tw_tile<K3 / 8>(tT, xr, jt, r, h);
     if constexpr (XTRA) {  // second K chunk: W3[:, 2D:] against the extra block, same accumulators
       load_stationary<K3 / 8>(xr, p.W3 + K3, LDW3, nw + r, D, K3, h, true);
 #pragma unroll
-      for (int jt = 0; jt < 2; ++jt) accs[jt] = tw_tile_acc<K3 / 8>(accs[jt], xT, xr, jt, r, h);
+      for (int jt = 0; jt < RT; ++jt) accs[jt] = tw_tile_acc<K3 / 8>(accs[jt], xT, xr, jt, r, h);
     }
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
+    for (int jt = 0; jt < RT; ++jt) {
       const f32x16 acc = accs[jt];
       const int64_t m = row0 + jt * 32 + r;
       if (m < p.B) {
@@ -209,14 +212,15 @@ struct TowerBwdArgs {
   float* d_x; int64_t ld_dx;  // XTRA: [B][2D] gradient of the third block
 };
 
-template <int DE8, bool XTRA>
+template <int DE8, bool XTRA, int RT>
 __global__ __launch_bounds__(256) void tower_bwd_kernel(const TowerBwdArgs p) {
+  constexpr int ROWS = 32 * RT;
   constexpr int D = 8 * DE8, K3 = 2 * D, LDY = D + 4, LDW3 = XTRA ? 2 * K3 : K3;
-  __shared__ __attribute__((aligned(16))) float dyT[TW_ROWS * LDY];
-  __shared__ __attribute__((aligned(16))) float dfT[TW_ROWS * LDY];
+  __shared__ __attribute__((aligned(16))) float dyT[ROWS * LDY];
+  __shared__ __attribute__((aligned(16))) float dfT[ROWS * LDY];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-  const int64_t row0 = (int64_t)blockIdx.x * TW_ROWS;
-  for (int i = threadIdx.x; i < TW_ROWS * (D / 4); i += 256) {
+  const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+  for (int i = threadIdx.x; i < ROWS * (D / 4); i += 256) {
     const int m = i / (D / 4), c = i - m * (D / 4);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row0 + m < p.B) v = *reinterpret_cast<const float4*>(p.dy + (row0 + m) * p.ldy + 4 * c);
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256) void tower_bwd_kernel(const TowerBwdArgs p) {
     float xr[DE8][4];
     tw_load_t<DE8>(xr, p.W3, LDW3, nw + r, LDW3, h);
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
+    for (int jt = 0; jt < RT; ++jt) {
       const f32x16 acc = tw_tile<DE8>(dyT, xr, jt, r, h);
       const int ml = jt * 32 + r;
       const int64_t m = row0 + ml;
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(256) void tower_bwd_kernel(const TowerBwdArgs p) {
     float xr[DE8][4];
     tw_load_t<DE8>(xr, p.W2, TW_HID, nw + r, TW_HID, h);
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
+    for (int jt = 0; jt < RT; ++jt) {
       const f32x16 acc = tw_tile<DE8>(dfT, xr, jt, r, h);
       const int64_t m = row0 + jt * 32 + r;
       if (m < p.B) {
@@ -396,28 +400,60 @@ __global__ __launch_bounds__(256) void tower_wgrad_kernel(const TowerWgradArgs p
   }
 }
 
-// out = sum over the blocks' partials, in block order; one thread per element of the six tensors
-__global__ __launch_bounds__(256) void tower_wgrad_reduce_kernel(const float* __restrict__ part, int n_blocks, int64_t part_floats,
-                                                                 int64_t n3, int64_t n2, int64_t n1, int64_t D, float* dW3,
-                                                                 float* dW2, float* dW1, float* db3, float* db2, float* db1) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= part_floats) return;
+// out = sum over the blocks' partials, in a FIXED order (deterministic): 64 elements of the six tensors per 1024-thread
+// workgroup, sixteen threads per element -- thread (q, t) adds blocks q, q + 16, ... with eight independent loads in
+// flight, the sixteen slices are combined in order through LDS.  (One thread per element walking all the blocks was a
+// chain of ~128 loads issued a few at a time: 32 us for 35 MB, 270-310 us next to the table sweep.)
+__global__ __launch_bounds__(1024) void tower_wgrad_reduce_kernel(const float* __restrict__ part, int n_blocks, int64_t part_floats,
+                                                                  int64_t n3, int64_t n2, int64_t n1, int64_t D, float* dW3,
+                                                                  float* dW2, float* dW1, float* db3, float* db2, float* db1) {
+  __shared__ float sh[16][64];
+  const int t = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + t;
   float s = 0.f;
-  for (int w = 0; w < n_blocks; ++w) s += part[(int64_t)w * part_floats + i];
+  if (i < part_floats) {
+    const float* src = part + i;
+    int w = q;
+    for (; w + 112 < n_blocks; w += 128) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(w + 16 * u) * part_floats];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; w < n_blocks; w += 16) s += src[(int64_t)w * part_floats];
+  }
+  sh[q][t] = s;
+  __syncthreads();
+  if (q != 0 || i >= part_floats) return;
+  float tot = 0.f;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) tot += sh[u][t];
   int64_t j = i;
-  if (j < n3) { dW3[j] = s; return; }
+  if (j < n3) { dW3[j] = tot; return; }
   j -= n3;
-  if (j < n2) { dW2[j] = s; return; }
+  if (j < n2) { dW2[j] = tot; return; }
   j -= n2;
-  if (j < n1) { dW1[j] = s; return; }
+  if (j < n1) { dW1[j] = tot; return; }
   j -= n1;
-  if (j < D) { db3[j] = s; return; }
+  if (j < D) { db3[j] = tot; return; }
   j -= D;
-  if (j < D) { db2[j] = s; return; }
+  if (j < D) { db2[j] = tot; return; }
   j -= D;
-  db1[j] = s;
+  db1[j] = tot;
 }
 
+// 32-row tiles per workgroup of the forward / backward-data kernels: one (32 batch rows) up to B = 4096, else two.  Either
+// way a tower of the BASELINE shapes is at most 128 workgroups -- HALF the chip, on purpose: in the overlapped train step
+// the row plan's single 118 KB-LDS workgroup (plan_small_kernel, third stream) has to find a CU with that much LDS free
+// while the towers run, and with 256 tower workgroups of 68 KB it could not start before the logits kernels (132 KB per
+// CU) had come and gone -- 1.5 ms late, the step's tail 0.1 ms longer at the headline shape.  Below B = 4096 the 32-row
+// form halves the towers' latency (B = 4096: 64 -> 128 workgroups; C2 step 1.216 -> 1.202 ms).
+static int tower_row_tiles(int64_t B) {
+  static const int forced = [] { const char* e = getenv("TT_TOWER_ROW_TILES"); return e ? atoi(e) : 0; }();  // A/B switch
+  if (forced == 1 || forced == 2) return forced;
+  return B <= 4096 ? 1 : 2;
+}
 static bool tower_shape_ok(int64_t D, int64_t F, int64_t hidden, int64_t d_out) {
   return hidden == TW_HID && d_out == D && (D == 32 || D == 64 || D == 128) && F >= 1 && F <= TW_FMAX;
 }
@@ -449,23 +485,27 @@ extern "C" int tt_tower_fwd_x(const float* table, int64_t n_rows, const int64_t*
   }
   TowerFwdArgs a{table, n_rows, ids, feats, ldf, B, F, W1, b1, W2, b2, W3, b3, y, ldy, h_out, tin_out, oob_flag, extra, ldx};
   hipStream_t st = S(stream);
-  const unsigned grid = (unsigned)ceil_div(B, TW_ROWS);
-  const size_t lds = (size_t)(TW_ROWS * (TW_HID + 4) + TW_ROWS * (2 * D + 4) + TW_ROWS * F) * sizeof(float);
-#define TT_TWF(E8, X)                                                                                                    \
+  const int rt = tower_row_tiles(B);
+  const int rows = 32 * rt;
+  const unsigned grid = (unsigned)ceil_div(B, rows);
+  const size_t lds = (size_t)(rows * (TW_HID + 4) + rows * (2 * D + 4) + rows * F) * sizeof(float);
+#define TT_TWF1(E8, X, R)                                                                                                \
   {                                                                                                                      \
     if (lds > 64 * 1024) {                                                                                               \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_kernel<E8, X>),                        \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_kernel<E8, X, R>),                     \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
       if (e != hipSuccess) { set_error("tower_fwd_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
     }                                                                                                                    \
-    tower_fwd_kernel<E8, X><<<grid, 256, lds, st>>>(a);                                                                  \
+    tower_fwd_kernel<E8, X, R><<<grid, 256, lds, st>>>(a);                                                               \
   }
+#define TT_TWF(E8, X) { if (rt == 1) TT_TWF1(E8, X, 1) else TT_TWF1(E8, X, 2) }
   if (E == 0) {
     if (D == 32) TT_TWF(4, false) else if (D == 64) TT_TWF(8, false) else TT_TWF(16, false)
   } else {
     if (D == 32) TT_TWF(4, true) else if (D == 64) TT_TWF(8, true) else TT_TWF(16, true)
   }
 #undef TT_TWF
+#undef TT_TWF1
   return check_launch("tower_fwd_kernel");
 }
 
@@ -489,16 +529,15 @@ extern "C" int tt_tower_bwd_data_x(const float* dy, int64_t ldy, int64_t B, int6
   }
   TowerBwdArgs a{dy, ldy, B, W2, W3, h, d_emb, ld_demb, d_f, dh, d_extra, ld_dx};
   hipStream_t st = S(stream);
-  const unsigned grid = (unsigned)ceil_div(B, TW_ROWS);
+  const int rt = tower_row_tiles(B);
+  const unsigned grid = (unsigned)ceil_div(B, 32 * rt);
+#define TT_TWB(E8, X) { if (rt == 1) tower_bwd_kernel<E8, X, 1><<<grid, 256, 0, st>>>(a); else tower_bwd_kernel<E8, X, 2><<<grid, 256, 0, st>>>(a); }
   if (E == 0) {
-    if (D == 32) tower_bwd_kernel<4, false><<<grid, 256, 0, st>>>(a);
-    else if (D == 64) tower_bwd_kernel<8, false><<<grid, 256, 0, st>>>(a);
-    else tower_bwd_kernel<16, false><<<grid, 256, 0, st>>>(a);
+    if (D == 32) TT_TWB(4, false) else if (D == 64) TT_TWB(8, false) else TT_TWB(16, false)
   } else {
-    if (D == 32) tower_bwd_kernel<4, true><<<grid, 256, 0, st>>>(a);
-    else if (D == 64) tower_bwd_kernel<8, true><<<grid, 256, 0, st>>>(a);
-    else tower_bwd_kernel<16, true><<<grid, 256, 0, st>>>(a);
+    if (D == 32) TT_TWB(4, true) else if (D == 64) TT_TWB(8, true) else TT_TWB(16, true)
   }
+#undef TT_TWB
   return check_launch("tower_bwd_kernel");
 }
 
@@ -554,7 +593,7 @@ extern "C" int tt_tower_bwd_weights_x(const float* dy, int64_t ldy, const float*
   int rc = check_launch("tower_wgrad_kernel");
   if (rc) return rc;
   const int64_t n3 = D * (2 * D + E), n2 = D * TW_HID, n1 = TW_HID * F, part = tower_part_floats(D, F, E);
-  tower_wgrad_reduce_kernel<<<(unsigned)ceil_div(part, 256), 256, 0, st>>>(reinterpret_cast<const float*>(ws), (int)grid, part, n3, n2,
+  tower_wgrad_reduce_kernel<<<(unsigned)ceil_div(part, 64), 1024, 0, st>>>(reinterpret_cast<const float*>(ws), (int)grid, part, n3, n2,
                                                                            n1, D, dW3, dW2, dW1, db3, db2, db1);
   return check_launch("tower_wgrad_reduce_kernel");
 }
