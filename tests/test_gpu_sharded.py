@@ -241,8 +241,10 @@ def test_multi_rank_hip_backend_equals_reference_on_concatenated_batch(world, cf
             assert float(err.max()) <= 2.2e-3 * MULTI_STEPS, (name, r, float(err.max()))
             # zero true gradient, noise only: the item-side biases and the key third of every in_proj_bias
             noise_only = name in ("item_tower_arch.bias", "item_features_arch.2.bias") or name.endswith("in_proj_bias")
-            if not noise_only:  # all but 0.2 % of the elements (at least one: a bias has 128-256 of them) within 5e-6
-                assert int((err > 5e-6).sum()) <= max(1, int(outlier_frac * err.numel())), (name, r, int((err > 5e-6).sum()), err.numel())
+            if not noise_only:  # all but 0.2 % of the elements (at least two: a bias has 128-256 of them) within 5e-6
+                # (two, not one: tools/fuzz_sharded.py seed 32 case 24 -- W = 3, B = 8 per rank, D = 24 -- has two such elements
+                # in a 256-element bias; the round-2 tree shows the identical finding, so it is the lottery described above)
+                assert int((err > 5e-6).sum()) <= max(2, int(outlier_frac * err.numel())), (name, r, int((err > 5e-6).sum()), err.numel())
         # replicas stay bit-identical
         assert all(torch.equal(v, res[0]["dense"][k]) for k, v in res[r]["dense"].items())
 
