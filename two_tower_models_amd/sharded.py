@@ -451,18 +451,28 @@ class HipBackend:
         n_rows, dim = n_local, W.shape[1]
         if n_rows <= 0:  # this rank owns no row of the table (fewer rows than ranks): nothing to park, nothing to finish
             return None, None, 0
-        plan = ops.RowPlan([local_ids], n_rows + 1, slot=f"plan{W.data_ptr()}")
+        # The old rows are parked by OCCURRENCE (slot i = occurrence i: needs nothing but the ids), so the sweep can start
+        # without the sorted plan; the sort itself -- one 118 KB-LDS workgroup for <= 10 K ids, ~15 launches beyond -- runs
+        # on a third stream underneath the towers and is waited for by adam_table_finish only (round 3: 85 us off the top
+        # of the W = 8 step; it was plan -> stash -> plan -> stash in line, in front of everything).
+        plan = ops.RowPlan([local_ids], n_rows + 1, slot=f"plan{W.data_ptr()}", defer=True)
         key = W.data_ptr()
         need = lib.tt_adam_table_workspace_bytes(plan.n, dim)
         side = self._sides.get(key)
         if side is None or side.numel() < need:
             side = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.device)
             self._sides[key] = side
-        N.check(lib.tt_adam_table_stash(W.data_ptr(), M.data_ptr(), V.data_ptr(), n_rows, dim, plan.n,
-                                        plan.sorted_ids.data_ptr(), plan.perm.data_ptr(), plan.seg_begin.data_ptr(),
-                                        plan.n_unique.data_ptr(), side.data_ptr(), side.numel(), N.stream()),
-                "tt_adam_table_stash")
-        return plan, side, n_rows
+        N.check(lib.tt_adam_table_stash_ids(W.data_ptr(), M.data_ptr(), V.data_ptr(), n_rows, dim, plan.ids.data_ptr(), plan.n,
+                                            side.data_ptr(), side.numel(), N.stream()), "tt_adam_table_stash_ids")
+        main, aux = torch.cuda.current_stream(), N.aux_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)  # the localised ids exist
+        aux.wait_event(ready)
+        with torch.cuda.stream(aux):
+            plan.build()
+            done = torch.cuda.Event()
+            done.record(aux)
+        return plan, side, n_rows, done
 
     def sweep_async(self, tables, hyper, n_wgs: int = 0):
         """Zero-gradient sweep of every (W, M, V) on the side stream, after everything queued so
@@ -489,9 +499,10 @@ class HipBackend:
 
     def adam_table_finish(self, W, M, V, hyper, state, grad_rows: torch.Tensor):
         N, lib = self.N, self.lib
-        plan, side, n_rows = state
+        plan, side, n_rows = state[:3]
         if plan is None:  # empty row block
             return
+        torch.cuda.current_stream().wait_event(state[3])  # the sorted plan (third stream, see adam_table_begin)
         plan.attach([grad_rows])
         N.check(lib.tt_adam_table_finish(W.data_ptr(), M.data_ptr(), V.data_ptr(), n_rows, W.shape[1],
                                          hyper.data_ptr(), C.byref(plan.sources), plan.n, plan.sorted_ids.data_ptr(),
