@@ -11,9 +11,9 @@
 //     onto a zero row); V is needed as an MFMA B operand only and stays in registers.  The NEXT sample's rows are
 //     requested right after the current one's have been written to LDS and ride in the LOADER waves' registers (28
 //     float4 per thread) through the whole computation; the loaders also scale Q and form delta, VALU work that runs
-//     beside the compute waves' MFMAs.  (With the staging in the compute waves' own registers hipcc spilled one staging
-//     array -- and a spill store waits for the very load it was meant to hide.)  Global latency is off the critical path
-//     whatever the memory system is busy with.
+//     beside the compute waves' MFMAs.  (With the staging in the compute waves' own registers the kernel is over its
+//     register budget: 100 staging + 64 accumulator + operand registers per thread.)  Global latency is off the critical
+//     path whatever the memory system is busy with.
 //   * S and dP are computed once, in the "lane = key" orientation: P and dS are then A operands of dV = P^T dO and
 //     dK = dS^T Q as they stand.  dQ = dS K reduces over the keys: dS goes through the wave's own [56][68] LDS scratch
 //     (written as four 16-byte runs per lane, read back one element per lane) instead of being recomputed:
@@ -91,8 +91,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_wg_kernel(const AttnWgArgs p)
     float4 sq[NS], sk[NS], sg[NS], so[NS], sx;
     float sl = 0.f;
     const int fx = NS * 256 + (tid & 63), mx = tid >> 6;  // the remainder element / whose it is
-    // (a macro, not a lambda: with the arrays captured by reference hipcc kept one of them in scratch memory -- a
-    // "spilled" staging register waits for the very load it is meant to hide)
+    // NOTE on the staging arrays: what looked like hipcc "spilling one of them" through several versions of this kernel
+    // was an alloca it could not split into registers (ScratchSize > 0 with vgpr_spill_count = 0): a whole-struct copy
+    // `*(float4*)dst = sk[k]` out of the array is a memcpy from the alloca (see the store of K below), as is a select
+    // between two float4 lvalues.  A staging register in scratch waits for the very load it is meant to hide.  The
+    // macro (instead of a lambda capturing the arrays by reference) and the unconditional fetch below date from that
+    // hunt and are kept: both forms are known to stay in registers.
 #define AWG_FETCH_ROWS(BB)                                                                          \
     do {                                                                                            \
       const char* __restrict__ qb = reinterpret_cast<const char*>(p.qkv + (BB) * H * (3 * D));      \
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_wg_kernel(const AttnWgArgs p)
       }
       __syncthreads();  // A: images and statistics of sample b are in place
       // unconditional (past the end: the current sample again, unused): a conditional fetch makes every staging
-      // register a merge of "old" and "new", and hipcc then keeps one whole array in scratch memory
+      // register a merge of "old" and "new" across the loop's back edge (see the NOTE above)
       const int64_t bn = b + gridDim.x < p.B ? b + gridDim.x : b;
       AWG_FETCH_ROWS(bn);  // in flight while the compute waves work; consumed at the next "top"
       __syncthreads();  // C: every read of the images is done
