@@ -324,6 +324,33 @@ int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows, int64_t d
                          const int32_t* perm, const int32_t* seg_begin, const int32_t* n_unique,
                          void* side, int64_t side_bytes, tt_stream_t stream);
 
+/* The two ends of an overlapped step, each as ONE launch over all tables (the step has three tiny dependent launches in
+ * front of the sweep and three behind it otherwise; at 1 M-row tables the sweep's start is the critical path):
+ *   tt_adam_begin_ids      = tt_adam_advance (tab == NULL) or tt_adam_advance_tab, then tt_adam_table_stash_ids per job
+ *   tt_adam_tables_finish  = tt_adam_table_finish per job
+ * Same results as the separate calls, which they fall back to for more than 4 tables / mixed row widths / unaligned rows.
+ * Replaces the same reference lines (ref:train/train.py:123-125, optimizer.step()). */
+typedef struct {
+  const float *W, *M, *V;
+  int64_t n_rows, dim;
+  const int64_t* ids;
+  int64_t n_ids;
+  void* side;
+  int64_t side_bytes;
+} tt_adam_stash_job;
+typedef struct {
+  float *W, *M, *V;
+  int64_t n_rows, dim;
+  const tt_grad_sources* src;
+  int64_t n_ids;
+  const int32_t *sorted_ids, *perm, *seg_begin, *n_unique;
+  void* side;
+  int64_t side_bytes;
+} tt_adam_finish_job;
+int tt_adam_begin_ids(double* hyper, float* tab, int64_t tab_steps, const tt_adam_stash_job* jobs, int32_t n_jobs,
+                      tt_stream_t stream);
+int tt_adam_tables_finish(const tt_adam_finish_job* jobs, int32_t n_jobs, const double* hyper, tt_stream_t stream);
+
 /* A HIP stream of the device's least priority (hipStreamCreateWithPriority) for
  * tt_adam_table_sweep, so the backward pass on the caller's stream is dispatched first. */
 int tt_stream_create_low_priority(void** out_stream);

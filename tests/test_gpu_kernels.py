@@ -460,6 +460,76 @@ def test_adam_table_equals_dense_adam(T, n_rows, D, n1, n2):
     assert float(hyper[4]) == 3.0
 
 
+@pytest.mark.parametrize("dims", [(128, 128), (128, 64), (50, 50), (128,), (128, 128, 128, 128, 128)])
+def test_adam_merged_begin_and_finish_equal_the_separate_calls(T, dims):
+    """tt_adam_begin_ids (advance + every table's plan-free stash) and tt_adam_tables_finish (every table's looked-up
+    rows) in one launch each vs tt_adam_advance / tt_adam_table_stash_ids / tt_adam_table_finish per table: hyper, side
+    buffers and tables bit for bit -- equal row widths (one launch), mixed widths, unaligned widths and five tables
+    (the fall-backs inside the library)."""
+    import ctypes as C
+    ops, N = T
+    lib = N.load()
+    dev = torch.device(DEV)
+    gen = torch.Generator().manual_seed(len(dims) * 1000 + dims[0])
+
+    def run(merged):
+        hyper = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 4, 0, 0, 0], dtype=torch.float64, device=DEV)
+        g2 = torch.Generator().manual_seed(17)
+        tabs = []
+        for k, D in enumerate(dims):
+            n_rows, n = 500 + 37 * k, 300 + 11 * k
+            W = torch.randn(n_rows, D, generator=g2).to(DEV)
+            M, V = (torch.randn(n_rows, D, generator=g2) * 0.01).to(DEV), (torch.rand(n_rows, D, generator=g2) * 1e-4).to(DEV)
+            ids = torch.randint(0, n_rows, (n,), generator=g2)
+            ids[:5] = ids[5:10]
+            ids[10] = n_rows + 3  # an id outside the block parks zeros and is skipped by the finish
+            rows = (torch.randn(n, D, generator=g2) * 0.01).to(DEV)
+            side = torch.full((lib.tt_adam_table_workspace_bytes(n, D) + 64,), 7, dtype=torch.uint8, device=DEV)
+            tabs.append([W, M, V, ids.to(DEV), rows, side, n_rows, n, D])
+        if merged:
+            jobs = (N.AdamStashJob * len(tabs))()
+            for j, (W, M, V, ids, rows, side, n_rows, n, D) in zip(jobs, tabs):
+                j.W, j.M, j.V, j.n_rows, j.dim, j.ids, j.n_ids = W.data_ptr(), M.data_ptr(), V.data_ptr(), n_rows, D, ids.data_ptr(), n
+                j.side, j.side_bytes = side.data_ptr(), side.numel()
+            N.check(lib.tt_adam_begin_ids(hyper.data_ptr(), None, 0, jobs, len(tabs), N.stream()), "begin_ids")
+        else:
+            N.check(lib.tt_adam_advance(hyper.data_ptr(), N.stream()), "advance")
+            for W, M, V, ids, rows, side, n_rows, n, D in tabs:
+                N.check(lib.tt_adam_table_stash_ids(W.data_ptr(), M.data_ptr(), V.data_ptr(), n_rows, D, ids.data_ptr(), n,
+                                                    side.data_ptr(), side.numel(), N.stream()), "stash_ids")
+        sides = [t[5].clone() for t in tabs]
+        plans = []
+        for W, M, V, ids, rows, side, n_rows, n, D in tabs:
+            plan = ops.RowPlan([ids], n_rows + 8)  # rows beyond n_rows sort last; the finish skips them
+            plan.attach([rows])
+            plans.append(plan)
+        if merged:
+            fj = (N.AdamFinishJob * len(tabs))()
+            for j, plan, (W, M, V, ids, rows, side, n_rows, n, D) in zip(fj, plans, tabs):
+                j.W, j.M, j.V, j.n_rows, j.dim, j.src, j.n_ids = W.data_ptr(), M.data_ptr(), V.data_ptr(), n_rows, D, C.pointer(plan.sources), n
+                j.sorted_ids, j.perm, j.seg_begin, j.n_unique = (plan.sorted_ids.data_ptr(), plan.perm.data_ptr(),
+                                                                 plan.seg_begin.data_ptr(), plan.n_unique.data_ptr())
+                j.side, j.side_bytes = side.data_ptr(), side.numel()
+            N.check(lib.tt_adam_tables_finish(fj, len(tabs), hyper.data_ptr(), N.stream()), "tables_finish")
+        else:
+            for plan, (W, M, V, ids, rows, side, n_rows, n, D) in zip(plans, tabs):
+                N.check(lib.tt_adam_table_finish(W.data_ptr(), M.data_ptr(), V.data_ptr(), n_rows, D, hyper.data_ptr(),
+                                                 C.byref(plan.sources), n, plan.sorted_ids.data_ptr(), plan.perm.data_ptr(),
+                                                 plan.seg_begin.data_ptr(), plan.n_unique.data_ptr(), side.data_ptr(),
+                                                 side.numel(), N.stream()), "finish")
+        torch.cuda.synchronize()
+        return hyper, sides, [(t[0], t[1], t[2]) for t in tabs]
+
+    ha, sa, ta = run(True)
+    hb, sb, tb = run(False)
+    assert torch.equal(ha, hb) and float(ha[4]) == 5.0
+    for x, y in zip(sa, sb):
+        assert torch.equal(x, y)
+    for (w1, m1, v1), (w2, m2, v2) in zip(ta, tb):
+        assert torch.equal(w1, w2) and torch.equal(m1, m2) and torch.equal(v1, v2)
+        assert not torch.equal(w1, torch.zeros_like(w1))
+
+
 # ------------------------------------------------------------------ attention
 @pytest.mark.parametrize("B,H,D,heads", [(3, 50, 128, 4), (2, 7, 40, 4), (1, 3, 2, 1), (2, 128, 64, 4), (5, 16, 40, 4),
                                           (2, 20, 256, 2), (2, 9, 200, 2),

@@ -44,6 +44,21 @@ class AdamTensor(C.Structure):
     _fields_ = [("p", _vp), ("g", _vp), ("m", _vp), ("v", _vp), ("n", _i64)]
 
 
+class AdamStashJob(C.Structure):
+    """tt_adam_stash_job."""
+
+    _fields_ = [("W", _vp), ("M", _vp), ("V", _vp), ("n_rows", _i64), ("dim", _i64), ("ids", _vp), ("n_ids", _i64),
+                ("side", _vp), ("side_bytes", _i64)]
+
+
+class AdamFinishJob(C.Structure):
+    """tt_adam_finish_job."""
+
+    _fields_ = [("W", _vp), ("M", _vp), ("V", _vp), ("n_rows", _i64), ("dim", _i64), ("src", C.POINTER(GradSources)),
+                ("n_ids", _i64), ("sorted_ids", _vp), ("perm", _vp), ("seg_begin", _vp), ("n_unique", _vp), ("side", _vp),
+                ("side_bytes", _i64)]
+
+
 # name -> (restype, argtypes); mirrors include/tt_hotpath.h declaration by declaration
 SIGNATURES = {
     "tt_abi_version": (_int, []),
@@ -64,6 +79,8 @@ SIGNATURES = {
     "tt_tower_bwd_weights_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "tt_tower_bwd_weights": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _i64, _vp]),
+    "tt_adam_begin_ids": (_int, [_vp, _vp, _i64, C.POINTER(AdamStashJob), _i32, _vp]),
+    "tt_adam_tables_finish": (_int, [C.POINTER(AdamFinishJob), _i32, _vp, _vp]),
     "tt_inbatch_ce_fwd_du_loss": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                          _vp, _vp, _i64, _vp]),
     "tt_scale_rows_g": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),

@@ -20,6 +20,8 @@
 
 namespace tt {
 
+constexpr int SWEEP_MAX_TABLES_DECL = 4;  // = SWEEP_MAX_TABLES (tables per multi-table launch)
+
 constexpr int SWEEP_DEFAULT_PERSIST = 3;
 
 struct AdamConst {
@@ -148,11 +150,11 @@ __global__ __launch_bounds__(256) void adam_stash_kernel(const float* __restrict
 // the same values several times; the finish uses the first).  Needs nothing but the ids, so the
 // sweep can start a few microseconds into the step while the sort runs underneath it.  Ids
 // outside [0, n_rows) (another rank's rows, or invalid input that the plan will flag) park zeros.
-__global__ __launch_bounds__(256) void adam_stash_ids_kernel(const float* __restrict__ W, const float* __restrict__ M,
-                                                             const float* __restrict__ V, int64_t n_rows, int64_t dim,
-                                                             const int64_t* __restrict__ ids, int64_t n_ids,
-                                                             float* __restrict__ side) {
-  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void adam_stash_ids_body(const float* __restrict__ W, const float* __restrict__ M,
+                                                    const float* __restrict__ V, int64_t n_rows, int64_t dim,
+                                                    const int64_t* __restrict__ ids, int64_t n_ids, float* __restrict__ side,
+                                                    int64_t block) {
+  const int64_t i = block * 4 + (threadIdx.x >> 6);
   if (i >= n_ids) return;
   const int lane = threadIdx.x & 63;
   const int64_t row = ids[i];
@@ -175,6 +177,50 @@ __global__ __launch_bounds__(256) void adam_stash_ids_kernel(const float* __rest
       sv[d] = ok ? V[row * dim + d] : 0.f;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void adam_stash_ids_kernel(const float* __restrict__ W, const float* __restrict__ M,
+                                                             const float* __restrict__ V, int64_t n_rows, int64_t dim,
+                                                             const int64_t* __restrict__ ids, int64_t n_ids,
+                                                             float* __restrict__ side) {
+  adam_stash_ids_body(W, M, V, n_rows, dim, ids, n_ids, side, blockIdx.x);
+}
+
+// The top of an overlapped step in ONE launch (tt_adam_begin_ids): adam_advance_kernel's step-constant update (last
+// workgroup; nothing below reads the constants) and the plan-free stash of every table (the workgroups before it, table
+// after table).  Three tiny dependent launches cost three trips through the queue's inter-kernel dependency latency
+// in front of the sweep -- and at the 1 M-row shapes the sweep's start is the step's critical path.
+struct StashJobs {
+  const float* W[SWEEP_MAX_TABLES_DECL];
+  const float* M[SWEEP_MAX_TABLES_DECL];
+  const float* V[SWEEP_MAX_TABLES_DECL];
+  const int64_t* ids[SWEEP_MAX_TABLES_DECL];
+  float* side[SWEEP_MAX_TABLES_DECL];
+  int64_t n_rows[SWEEP_MAX_TABLES_DECL], dim[SWEEP_MAX_TABLES_DECL], n_ids[SWEEP_MAX_TABLES_DECL];
+  unsigned first_block[SWEEP_MAX_TABLES_DECL + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void adam_begin_ids_kernel(const StashJobs jobs, double* h, float* tab, int64_t tab_cap) {
+  const unsigned n_stash = jobs.first_block[jobs.n];
+  if (blockIdx.x == n_stash) {
+    if (threadIdx.x == 0) {
+      const double step = h[4] + 1.0;
+      h[4] = step;
+      step_consts_from_doubles(h[0], h[1], h[2], step, h[5], h[6]);
+      const int64_t j = (int64_t)step;
+      if (tab && j < tab_cap) {
+        tab[2 * j] = (float)(-h[5]);
+        tab[2 * j + 1] = (float)h[6];
+      }
+    }
+    return;
+  }
+  int t = 0;
+#pragma unroll
+  for (int q = 1; q < SWEEP_MAX_TABLES_DECL; ++q)
+    if (q < jobs.n && blockIdx.x >= jobs.first_block[q]) t = q;
+  adam_stash_ids_body(jobs.W[t], jobs.M[t], jobs.V[t], jobs.n_rows[t], jobs.dim[t], jobs.ids[t], jobs.n_ids[t], jobs.side[t],
+                      blockIdx.x - jobs.first_block[t]);
 }
 
 __global__ __launch_bounds__(256) void adam_writeback_kernel(float* __restrict__ W, float* __restrict__ M,
@@ -205,15 +251,14 @@ __global__ __launch_bounds__(256) void adam_writeback_kernel(float* __restrict__
 // straight into the table -- no second trip through the side buffer.  LPR lanes per unique row,
 // one float4 per lane and plane; gradient runs are summed in plan order, as adam_touched_kernel does.
 template <int LPR>
-__global__ __launch_bounds__(256) void adam_finish_kernel(float* __restrict__ W, float* __restrict__ M, float* __restrict__ V,
-                                                          int64_t n_rows, int64_t dim, const double* __restrict__ hyper,
-                                                          const tt_grad_sources src, const int32_t* __restrict__ sorted_ids,
-                                                          const int32_t* __restrict__ perm,
-                                                          const int32_t* __restrict__ seg_begin,
-                                                          const int32_t* __restrict__ n_unique,
-                                                          const float* __restrict__ side, int64_t cap) {
+__device__ __forceinline__ void adam_finish_body(float* __restrict__ W, float* __restrict__ M, float* __restrict__ V,
+                                                 int64_t n_rows, int64_t dim, const double* __restrict__ hyper,
+                                                 const tt_grad_sources& src, const int32_t* __restrict__ sorted_ids,
+                                                 const int32_t* __restrict__ perm, const int32_t* __restrict__ seg_begin,
+                                                 const int32_t* __restrict__ n_unique, const float* __restrict__ side,
+                                                 int64_t cap, int64_t block) {
   constexpr int ROWS = 256 / LPR;
-  const int64_t u = (int64_t)blockIdx.x * ROWS + threadIdx.x / LPR;
+  const int64_t u = block * ROWS + threadIdx.x / LPR;
   if (u >= *n_unique) return;
   const int sub = threadIdx.x % LPR;
   const AdamConst c = load_hyper(hyper);
@@ -242,6 +287,44 @@ __global__ __launch_bounds__(256) void adam_finish_kernel(float* __restrict__ W,
     wm[d] = m;
     wv[d] = v;
   }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void adam_finish_kernel(float* __restrict__ W, float* __restrict__ M, float* __restrict__ V,
+                                                          int64_t n_rows, int64_t dim, const double* __restrict__ hyper,
+                                                          const tt_grad_sources src, const int32_t* __restrict__ sorted_ids,
+                                                          const int32_t* __restrict__ perm,
+                                                          const int32_t* __restrict__ seg_begin,
+                                                          const int32_t* __restrict__ n_unique,
+                                                          const float* __restrict__ side, int64_t cap) {
+  adam_finish_body<LPR>(W, M, V, n_rows, dim, hyper, src, sorted_ids, perm, seg_begin, n_unique, side, cap, blockIdx.x);
+}
+
+// The same for SEVERAL tables in one launch (tt_adam_tables_finish): after the sweep the step's tail is finish, finish,
+// dense Adam -- each a few microseconds of work behind a dependent launch.
+struct FinishJobs {
+  float* W[SWEEP_MAX_TABLES_DECL];
+  float* M[SWEEP_MAX_TABLES_DECL];
+  float* V[SWEEP_MAX_TABLES_DECL];
+  int64_t n_rows[SWEEP_MAX_TABLES_DECL], dim[SWEEP_MAX_TABLES_DECL], cap[SWEEP_MAX_TABLES_DECL];
+  tt_grad_sources src[SWEEP_MAX_TABLES_DECL];
+  const int32_t* sorted_ids[SWEEP_MAX_TABLES_DECL];
+  const int32_t* perm[SWEEP_MAX_TABLES_DECL];
+  const int32_t* seg_begin[SWEEP_MAX_TABLES_DECL];
+  const int32_t* n_unique[SWEEP_MAX_TABLES_DECL];
+  const float* side[SWEEP_MAX_TABLES_DECL];
+  unsigned first_block[SWEEP_MAX_TABLES_DECL + 1];
+  int n;
+};
+template <int LPR>
+__global__ __launch_bounds__(256) void adam_finish_tables_kernel(const FinishJobs jobs, const double* __restrict__ hyper) {
+  int t = 0;
+#pragma unroll
+  for (int q = 1; q < SWEEP_MAX_TABLES_DECL; ++q)
+    if (q < jobs.n && blockIdx.x >= jobs.first_block[q]) t = q;
+  adam_finish_body<LPR>(jobs.W[t], jobs.M[t], jobs.V[t], jobs.n_rows[t], jobs.dim[t], hyper, jobs.src[t], jobs.sorted_ids[t],
+                        jobs.perm[t], jobs.seg_begin[t], jobs.n_unique[t], jobs.side[t], jobs.cap[t],
+                        blockIdx.x - jobs.first_block[t]);
 }
 
 // The roofline kernel: 3 x 16-B loads + 3 x 16-B stores per lane per float4, nothing else.
@@ -351,7 +434,7 @@ __global__ __launch_bounds__(256) void adam_sweep_persistent_kernel(float4* __re
 
 // The same sweep over SEVERAL tables in one launch (tt_adam_tables_sweep): the chunk list simply spans them,
 // so a step has one sweep launch, one tail and no launch gap between the user and the item table.
-constexpr int SWEEP_MAX_TABLES = 4;
+constexpr int SWEEP_MAX_TABLES = SWEEP_MAX_TABLES_DECL;
 struct SweepTables {
   float4* W[SWEEP_MAX_TABLES];
   float4* M[SWEEP_MAX_TABLES];
@@ -695,6 +778,36 @@ extern "C" int tt_adam_table_stash_ids(const float* W, const float* M, const flo
   return check_launch("adam_stash_ids_kernel");
 }
 
+extern "C" int tt_adam_begin_ids(double* hyper, float* tab, int64_t tab_steps, const tt_adam_stash_job* jobs, int32_t n_jobs,
+                                 tt_stream_t stream) {
+  if (!hyper || (n_jobs > 0 && !jobs) || n_jobs < 0) return fail_arg("tt_adam_begin_ids: null pointer");
+  if (tab && tab_steps <= 0) return fail_arg("tt_adam_begin_ids: sizes");
+  hipStream_t st = S(stream);
+  if (n_jobs > SWEEP_MAX_TABLES) {  // more tables than one launch takes: the separate entry points, same result
+    int rc = tab ? tt_adam_advance_tab(hyper, tab, tab_steps, stream) : tt_adam_advance(hyper, stream);
+    for (int i = 0; i < n_jobs && !rc; ++i)
+      rc = tt_adam_table_stash_ids(jobs[i].W, jobs[i].M, jobs[i].V, jobs[i].n_rows, jobs[i].dim, jobs[i].ids, jobs[i].n_ids,
+                                   jobs[i].side, jobs[i].side_bytes, stream);
+    return rc;
+  }
+  StashJobs a{};
+  a.n = n_jobs;
+  unsigned blocks = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const tt_adam_stash_job& j = jobs[i];
+    if (!j.W || !j.M || !j.V || !j.ids || !j.side) return fail_arg("tt_adam_begin_ids: null pointer");
+    if (j.n_rows <= 0 || j.dim <= 0 || j.n_ids <= 0) return fail_arg("tt_adam_begin_ids: sizes");
+    if (j.side_bytes < tt_adam_table_workspace_bytes(j.n_ids, j.dim)) { set_error("tt_adam_begin_ids: side buffer"); return TT_E_WORKSPACE; }
+    a.W[i] = j.W; a.M[i] = j.M; a.V[i] = j.V; a.ids[i] = j.ids; a.side[i] = reinterpret_cast<float*>(j.side);
+    a.n_rows[i] = j.n_rows; a.dim[i] = j.dim; a.n_ids[i] = j.n_ids;
+    a.first_block[i] = blocks;
+    blocks += (unsigned)ceil_div(j.n_ids, 4);
+  }
+  for (int i = n_jobs; i <= SWEEP_MAX_TABLES; ++i) a.first_block[i] = blocks;
+  adam_begin_ids_kernel<<<blocks + 1, 256, 0, st>>>(a, hyper, tab, tab ? tab_steps : 0);
+  return check_launch("adam_begin_ids_kernel");
+}
+
 extern "C" int tt_adam_table_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
                                    tt_stream_t stream) {
   if (!W || !M || !V || !hyper) return fail_arg("tt_adam_table_sweep: null pointer");
@@ -803,6 +916,55 @@ extern "C" int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows
   if (rc) return rc;
   adam_writeback_kernel<<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, sorted_ids, seg_begin, perm, n_unique, sd, n_ids);
   return check_launch("adam_writeback_kernel");
+}
+
+extern "C" int tt_adam_tables_finish(const tt_adam_finish_job* jobs, int32_t n_jobs, const double* hyper, tt_stream_t stream) {
+  if (!jobs || !hyper || n_jobs <= 0) return fail_arg("tt_adam_tables_finish: null pointer");
+  // one launch when every table takes the vector form with the same lanes-per-row class; else table by table
+  bool one = n_jobs <= SWEEP_MAX_TABLES;
+  int lpr = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const tt_adam_finish_job& j = jobs[i];
+    if (!j.W || !j.M || !j.V || !j.src || !j.sorted_ids || !j.perm || !j.seg_begin || !j.n_unique || !j.side)
+      return fail_arg("tt_adam_tables_finish: null pointer");
+    if (j.n_rows <= 0 || j.dim <= 0 || j.n_ids <= 0) return fail_arg("tt_adam_tables_finish: sizes");
+    if (!check_sources(j.src, j.n_ids, j.dim)) return fail_arg("tt_adam_tables_finish: gradient sources");
+    if (j.side_bytes < tt_adam_table_workspace_bytes(j.n_ids, j.dim)) { set_error("tt_adam_tables_finish: side buffer"); return TT_E_WORKSPACE; }
+    bool vec = j.dim % 4 == 0 && ((reinterpret_cast<uintptr_t>(j.W) | reinterpret_cast<uintptr_t>(j.M) | reinterpret_cast<uintptr_t>(j.V) |
+                                   reinterpret_cast<uintptr_t>(j.side)) & 15) == 0;
+    for (int k = 0; vec && k < j.src->n_sources; ++k)
+      vec = (reinterpret_cast<uintptr_t>(j.src->rows[k]) & 15) == 0 && j.src->ld[k] % 4 == 0;
+    const int cls = j.dim <= 64 ? 16 : j.dim <= 128 ? 32 : 64;
+    if (!vec || (lpr && cls != lpr)) one = false;
+    lpr = lpr ? lpr : cls;
+  }
+  if (!one) {
+    for (int i = 0; i < n_jobs; ++i) {
+      const tt_adam_finish_job& j = jobs[i];
+      int rc = tt_adam_table_finish(j.W, j.M, j.V, j.n_rows, j.dim, hyper, j.src, j.n_ids, j.sorted_ids, j.perm, j.seg_begin,
+                                    j.n_unique, j.side, j.side_bytes, stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  FinishJobs a{};
+  a.n = n_jobs;
+  unsigned blocks = 0;
+  const int rows_per_block = 256 / lpr;
+  for (int i = 0; i < n_jobs; ++i) {
+    const tt_adam_finish_job& j = jobs[i];
+    a.W[i] = j.W; a.M[i] = j.M; a.V[i] = j.V; a.n_rows[i] = j.n_rows; a.dim[i] = j.dim; a.cap[i] = j.n_ids;
+    a.src[i] = *j.src; a.sorted_ids[i] = j.sorted_ids; a.perm[i] = j.perm; a.seg_begin[i] = j.seg_begin; a.n_unique[i] = j.n_unique;
+    a.side[i] = reinterpret_cast<const float*>(j.side);
+    a.first_block[i] = blocks;
+    blocks += (unsigned)ceil_div(j.n_ids, rows_per_block);
+  }
+  for (int i = n_jobs; i <= SWEEP_MAX_TABLES; ++i) a.first_block[i] = blocks;
+  hipStream_t st = S(stream);
+  if (lpr == 16) adam_finish_tables_kernel<16><<<blocks, 256, 0, st>>>(a, hyper);
+  else if (lpr == 32) adam_finish_tables_kernel<32><<<blocks, 256, 0, st>>>(a, hyper);
+  else adam_finish_tables_kernel<64><<<blocks, 256, 0, st>>>(a, hyper);
+  return check_launch("adam_finish_tables_kernel");
 }
 
 // ---- deferred ("lazy") schedule: see the kernels above

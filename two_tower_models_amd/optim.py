@@ -288,9 +288,11 @@ class DenseExactAdam(torch.optim.Optimizer):
             self._tune_sweep()
             ev_begin = torch.cuda.Event(enable_timing=True)
             ev_begin.record()
-        N.check(lib.tt_adam_advance(hyper, N.stream()), "tt_adam_advance")
+        if announced is None:
+            N.check(lib.tt_adam_advance(hyper, N.stream()), "tt_adam_advance")
         self._host_steps += 1
         begun: Dict[torch.nn.Parameter, _TableStep] = {}
+        stash_jobs = []  # forward mode: the step-count advance and every table's stash go out as ONE launch
         for p in self._tables:
             blocks = announced.get(id(p)) if announced is not None else p._tt_lookups
             if not blocks:
@@ -302,9 +304,8 @@ class DenseExactAdam(torch.optim.Optimizer):
             plan = ops.RowPlan(blocks, n_rows, slot=f"plan{id(p)}", defer=announced is not None)
             side = self._side(p, lib.tt_adam_table_workspace_bytes(plan.n, dim))
             if announced is not None:
-                N.check(lib.tt_adam_table_stash_ids(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                                    n_rows, dim, plan.ids.data_ptr(), plan.n, side.data_ptr(),
-                                                    side.numel(), N.stream()), "tt_adam_table_stash_ids")
+                stash_jobs.append((p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), n_rows, dim,
+                                   plan.ids.data_ptr(), plan.n, side.data_ptr(), side.numel()))
                 p_plane = side[: plan.n * dim * 4].view(torch.float32).view(plan.n, dim)
                 p._tt_active = ops.ActiveStash(p_plane, plan.block_sizes)
             else:
@@ -313,6 +314,12 @@ class DenseExactAdam(torch.optim.Optimizer):
                                                 plan.seg_begin.data_ptr(), plan.n_unique.data_ptr(), side.data_ptr(),
                                                 side.numel(), N.stream()), "tt_adam_table_stash")
             begun[p] = _TableStep(plan, side, announced is not None)
+        if announced is not None:
+            jobs = (N.AdamStashJob * max(len(stash_jobs), 1))()
+            for i, j in enumerate(stash_jobs):
+                (jobs[i].W, jobs[i].M, jobs[i].V, jobs[i].n_rows, jobs[i].dim, jobs[i].ids, jobs[i].n_ids, jobs[i].side,
+                 jobs[i].side_bytes) = j
+            N.check(lib.tt_adam_begin_ids(hyper, None, 0, jobs, len(stash_jobs), N.stream()), "tt_adam_begin_ids")
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(main)  # lookups (or none yet, forward mode) + stashes are complete here
@@ -481,15 +488,18 @@ class DenseExactAdam(torch.optim.Optimizer):
             if self._plan_done is not None:
                 torch.cuda.current_stream().wait_event(self._plan_done)
                 self._plan_done = None
-            for p, ts in self._begun.items():
-                st = self.state[p]
-                ts.plan.attach(self._ordered_rows(p))
-                N.check(lib.tt_adam_table_finish(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                                 p.shape[0], p.shape[1], hyper, C.byref(ts.plan.sources), ts.plan.n,
-                                                 ts.plan.sorted_ids.data_ptr(), ts.plan.perm.data_ptr(),
-                                                 ts.plan.seg_begin.data_ptr(), ts.plan.n_unique.data_ptr(),
-                                                 ts.side.data_ptr(), ts.side.numel(), N.stream()),
-                        "tt_adam_table_finish")
+            if self._begun:  # every table's looked-up rows in ONE launch
+                jobs = (N.AdamFinishJob * len(self._begun))()
+                for i, (p, ts) in enumerate(self._begun.items()):
+                    st = self.state[p]
+                    ts.plan.attach(self._ordered_rows(p))
+                    j = jobs[i]
+                    j.W, j.M, j.V = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                    j.n_rows, j.dim, j.src, j.n_ids = p.shape[0], p.shape[1], C.pointer(ts.plan.sources), ts.plan.n
+                    j.sorted_ids, j.perm = ts.plan.sorted_ids.data_ptr(), ts.plan.perm.data_ptr()
+                    j.seg_begin, j.n_unique = ts.plan.seg_begin.data_ptr(), ts.plan.n_unique.data_ptr()
+                    j.side, j.side_bytes = ts.side.data_ptr(), ts.side.numel()
+                N.check(lib.tt_adam_tables_finish(jobs, len(self._begun), hyper, N.stream()), "tt_adam_tables_finish")
             self._begun = None
             if self._tune is not None:
                 end = torch.cuda.Event(enable_timing=True)

@@ -474,6 +474,63 @@ class HipBackend:
             done.record(aux)
         return plan, side, n_rows, done
 
+    def adam_begin_tables(self, hyper, tables):
+        """adam_advance + adam_table_begin for every (W, M, V, n_local, local_ids) as ONE launch (tt_adam_begin_ids); the
+        row plans sort on the third stream as in adam_table_begin.  -> the per-table states."""
+        ops, N, lib = self.ops, self.N, self.lib
+        jobs = (N.AdamStashJob * max(len(tables), 1))()
+        states, n_jobs = [], 0
+        for W, M, V, n_local, local_ids in tables:
+            if n_local <= 0:
+                states.append((None, None, 0, None))
+                continue
+            dim = W.shape[1]
+            plan = ops.RowPlan([local_ids], n_local + 1, slot=f"plan{W.data_ptr()}", defer=True)
+            need = lib.tt_adam_table_workspace_bytes(plan.n, dim)
+            side = self._sides.get(W.data_ptr())
+            if side is None or side.numel() < need:
+                side = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.device)
+                self._sides[W.data_ptr()] = side
+            j = jobs[n_jobs]
+            j.W, j.M, j.V, j.n_rows, j.dim = W.data_ptr(), M.data_ptr(), V.data_ptr(), n_local, dim
+            j.ids, j.n_ids, j.side, j.side_bytes = plan.ids.data_ptr(), plan.n, side.data_ptr(), side.numel()
+            n_jobs += 1
+            states.append([plan, side, n_local, None])
+        N.check(lib.tt_adam_begin_ids(hyper.data_ptr(), None, 0, jobs, n_jobs, N.stream()), "tt_adam_begin_ids")
+        main, aux = torch.cuda.current_stream(), N.aux_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        aux.wait_event(ready)
+        with torch.cuda.stream(aux):
+            for st in states:
+                if st[0] is not None:
+                    st[0].build()
+            done = torch.cuda.Event()
+            done.record(aux)
+        return [tuple(st[:3]) + (done,) if st[0] is not None else st for st in states]
+
+    def adam_finish_tables(self, hyper, tables) -> None:
+        """adam_table_finish for every (W, M, V, state, grad_rows) as ONE launch (tt_adam_tables_finish)."""
+        N, lib = self.N, self.lib
+        live = [t for t in tables if t[3][0] is not None]
+        if not live:
+            return
+        jobs = (N.AdamFinishJob * len(live))()
+        waited = set()
+        for i, (W, M, V, state, grad_rows) in enumerate(live):
+            plan, side, n_rows, done = state
+            if id(done) not in waited:
+                torch.cuda.current_stream().wait_event(done)
+                waited.add(id(done))
+            plan.attach([grad_rows])
+            j = jobs[i]
+            j.W, j.M, j.V, j.n_rows, j.dim = W.data_ptr(), M.data_ptr(), V.data_ptr(), n_rows, W.shape[1]
+            j.src, j.n_ids = C.pointer(plan.sources), plan.n
+            j.sorted_ids, j.perm, j.seg_begin, j.n_unique = (plan.sorted_ids.data_ptr(), plan.perm.data_ptr(),
+                                                             plan.seg_begin.data_ptr(), plan.n_unique.data_ptr())
+            j.side, j.side_bytes = side.data_ptr(), side.numel()
+        N.check(lib.tt_adam_tables_finish(jobs, len(live), hyper.data_ptr(), N.stream()), "tt_adam_tables_finish")
+
     def sweep_async(self, tables, hyper, n_wgs: int = 0):
         """Zero-gradient sweep of every (W, M, V) on the side stream, after everything queued so
         far on the main stream (the lookups and the stashes)."""
@@ -915,9 +972,13 @@ class ShardedTrainer:
         item_local = torch.cat([lk_h.local, lk_i.local]) if self.hist else lk_i.local
         # the tables' old rows have been read: plan, park the looked-up rows, and start the
         # zero-gradient sweep on the side stream -- it overlaps everything up to step 6
-        be.adam_advance(self.hyper)
-        st_u = be.adam_table_begin(self.users.weight, self.users.m, self.users.v, lk_u.n_local, lk_u.local)
-        st_i = be.adam_table_begin(self.items.weight, self.items.m, self.items.v, lk_i.n_local, item_local)
+        if hasattr(be, "adam_begin_tables"):  # advance + both stashes as one launch
+            st_u, st_i = be.adam_begin_tables(self.hyper, [(self.users.weight, self.users.m, self.users.v, lk_u.n_local, lk_u.local),
+                                                           (self.items.weight, self.items.m, self.items.v, lk_i.n_local, item_local)])
+        else:
+            be.adam_advance(self.hyper)
+            st_u = be.adam_table_begin(self.users.weight, self.users.m, self.users.v, lk_u.n_local, lk_u.local)
+            st_i = be.adam_table_begin(self.items.weight, self.items.m, self.items.v, lk_i.n_local, item_local)
         sweep = [(self.users.weight, self.users.m, self.users.v, lk_u.n_local),
                  (self.items.weight, self.items.m, self.items.v, lk_i.n_local)]
         if not self._sweep_late and not self._sweep_bwd:
@@ -963,8 +1024,12 @@ class ShardedTrainer:
         flat_p.wait()
         # 6. dense-exact Adam: the looked-up rows of this rank's blocks, over the swept tables
         be.sweep_wait()
-        be.adam_table_finish(self.users.weight, self.users.m, self.users.v, self.hyper, st_u, g_u)
-        be.adam_table_finish(self.items.weight, self.items.m, self.items.v, self.hyper, st_i, g_i)
+        if hasattr(be, "adam_finish_tables"):  # both tables' looked-up rows as one launch
+            be.adam_finish_tables(self.hyper, [(self.users.weight, self.users.m, self.users.v, st_u, g_u),
+                                               (self.items.weight, self.items.m, self.items.v, st_i, g_i)])
+        else:
+            be.adam_table_finish(self.users.weight, self.users.m, self.users.v, self.hyper, st_u, g_u)
+            be.adam_table_finish(self.items.weight, self.items.m, self.items.v, self.hyper, st_i, g_i)
         be.adam_dense(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.hyper)
         self.comm_bytes = {"lookup_ids_alltoall": sent_ids, "lookup_rows_alltoall": sent_rows,
                            "rowgrad_alltoall": sent_rows,
@@ -1003,9 +1068,13 @@ class ShardedTrainer:
         item_local = torch.cat([lk_h.local, lk_i.local]) if self.hist else lk_i.local
         # the tables' old rows have been read: plan, park the looked-up rows, and start the
         # zero-gradient sweep on the side stream -- it overlaps everything up to step 6
-        be.adam_advance(self.hyper)
-        st_u = be.adam_table_begin(self.users.weight, self.users.m, self.users.v, lk_u.n_local, lk_u.local)
-        st_i = be.adam_table_begin(self.items.weight, self.items.m, self.items.v, lk_i.n_local, item_local)
+        if hasattr(be, "adam_begin_tables"):  # advance + both stashes as one launch
+            st_u, st_i = be.adam_begin_tables(self.hyper, [(self.users.weight, self.users.m, self.users.v, lk_u.n_local, lk_u.local),
+                                                           (self.items.weight, self.items.m, self.items.v, lk_i.n_local, item_local)])
+        else:
+            be.adam_advance(self.hyper)
+            st_u = be.adam_table_begin(self.users.weight, self.users.m, self.users.v, lk_u.n_local, lk_u.local)
+            st_i = be.adam_table_begin(self.items.weight, self.items.m, self.items.v, lk_i.n_local, item_local)
         sweep = [(self.users.weight, self.users.m, self.users.v, lk_u.n_local),
                  (self.items.weight, self.items.m, self.items.v, lk_i.n_local)]
         if not self._sweep_late:
@@ -1049,8 +1118,12 @@ class ShardedTrainer:
         flat_p.wait()
         # 6. dense-exact Adam: the looked-up rows of this rank's blocks, over the swept tables
         be.sweep_wait()
-        be.adam_table_finish(self.users.weight, self.users.m, self.users.v, self.hyper, st_u, g_u)
-        be.adam_table_finish(self.items.weight, self.items.m, self.items.v, self.hyper, st_i, g_i)
+        if hasattr(be, "adam_finish_tables"):  # both tables' looked-up rows as one launch
+            be.adam_finish_tables(self.hyper, [(self.users.weight, self.users.m, self.users.v, st_u, g_u),
+                                               (self.items.weight, self.items.m, self.items.v, st_i, g_i)])
+        else:
+            be.adam_table_finish(self.users.weight, self.users.m, self.users.v, self.hyper, st_u, g_u)
+            be.adam_table_finish(self.items.weight, self.items.m, self.items.v, self.hyper, st_i, g_i)
         be.adam_dense(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.hyper)
         n_rows_looked_up = B * (2 + (hist_ids.shape[1] if self.hist else 0))
         self.comm_bytes = {"lookup_ids_allgather": (W - 1) * n_rows_looked_up * 8,
