@@ -1,5 +1,5 @@
 """Per-step kernel timeline from a rocprofv3 --kernel-trace CSV: for the LAST complete step
-(delimited by adam_advance_kernel) print every kernel's start / end relative to the step start.
+(delimited by adam_advance_kernel or adam_begin_ids_kernel, the first launch of a step) print every kernel's start / end relative to the step start.
 usage: python tools/timeline.py <kernel_trace.csv> [min_us]"""
 import csv
 import sys
@@ -8,7 +8,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 20.0
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r.get("Queue_Id", "?")))
              for r in rows), key=lambda e: e[0])
-marks = [i for i, e in enumerate(ev) if "adam_advance_kernel" in e[2]]
+marks = [i for i, e in enumerate(ev) if "adam_advance_kernel" in e[2] or "adam_begin_ids_kernel" in e[2]]
 if len(marks) < 3:
     raise SystemExit("need >= 3 steps in the trace")
 a, b = marks[-3], marks[-2]
