@@ -3,6 +3,7 @@
 # each with tools/bench_mips.py: which part of a tile's time goes where.  Variant results are WRONG by design.
 #   bit 1 (2): one LDS read per sub-tile   bit 2 (4): no per-tile barrier   bit 3 (8): no result stores
 #   bit 4 (16): corpus tiles from a 64-chunk window (L2 hits)   bit 5 (32): result stores into an 8-chunk window (L2)
+#   bit 6 (64): bare s_barrier instead of __syncthreads() (no vmcnt(0) drain)   +128: one tile fewer in flight   +256: vmcnt(0) + bare barrier
 #   "row": the row-exact epilogue (4 VALU / score) instead of the quad one -- this one is correct, just slower
 #   tools/mips_variants.sh build      (here: hipcc cross-compiles)        tools/mips_variants.sh run   (on the GPU box)
 set -e

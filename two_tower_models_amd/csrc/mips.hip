@@ -672,9 +672,29 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
     if (SHARE && PAR && member == 0) store_chunk(chunk);
     if (SHARE && PAR && member != 0) { m1[0] = NEG_INF; m2[0] = NEG_INF; arg[0] = 0; }
     // tile t+1 must have landed; tiles t+2 .. t+STAGES-1 may still be in flight
+    // NOTE (round 3, ISA): __syncthreads() below is `s_waitcnt vmcnt(0); s_barrier` -- the release fence it carries
+    // drains every DMA in flight, so the counted wait in front of it is moot and the 4-stage ring prefetches like a
+    // 2-stage one.  Measured with the variants of tools/mips_variants.sh on one box, bf16 pass 1: product 2.43-2.44 ms,
+    // counted wait + bare s_barrier (64) 2.38-2.42, one tile fewer in flight (192) 2.41-2.44, vmcnt(0) + bare barrier
+    // (320) 2.39 -- all the same: with two workgroups per CU the other workgroup's MFMAs cover the drain, the kernel is
+    // not waiting for its corpus stream at this point.  Left as it is.
+#if TT_MIPS_EXP & 128
+    if (more) wait_vmcnt<(STAGES >= 3 ? STAGES - 3 : 0) * NI>();
+    else wait_vmcnt<0>();
+#elif TT_MIPS_EXP & 256
+    wait_vmcnt<0>();
+#else
     if (more) wait_vmcnt<(STAGES - 2) * NI>();
     else wait_vmcnt<0>();
-#if !(TT_MIPS_EXP & 4)
+#endif
+#if TT_MIPS_EXP & 64
+    if constexpr (SHARE) {
+      __syncthreads();
+    } else {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+#elif !(TT_MIPS_EXP & 4)
     __syncthreads();
 #endif
   };
