@@ -276,14 +276,14 @@ def secondary(device, lib, N):
     """The other BASELINE configs in the driver-run record (each a few hundred ms of GPU time): C2 and C3
     train steps, config 5's MIPS at C = 10 M / K = 1000 (fp32, bf16), and the deferred-Adam figure, labelled."""
     sec = {}
-    # (dense-exact workloads: 50 warm-up steps, the sweep-level scan of DenseExactAdam._tune_sweep settles inside them)
+    # (dense-exact workloads: 80 warm-up steps, the sweep-level scan of DenseExactAdam._tune_sweep settles inside them)
     for key, name, steps, lazy, fresh in (("C2", "C2", 40, False, False), ("C3", "C3", 20, False, False),
                                           ("P_lazy", "P", 20, True, False),
                                           # the deferred schedule's STEADY STATE next to -- not instead of -- the recurring-ids
                                           # figure: 200 steps of new uniform ids + the flush, all inside the timed region
                                           ("P_lazy_fresh_ids", "P", 200, True, True)):
         try:
-            sec[key] = _timed_train(name, device, steps, 3 if lazy else 50, lazy=lazy, fresh_ids=fresh)
+            sec[key] = _timed_train(name, device, steps, 3 if lazy else 80, lazy=lazy, fresh_ids=fresh)
         except Exception as e:  # a secondary figure must never take the headline line down with it
             sec[key] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
