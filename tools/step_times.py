@@ -1,5 +1,5 @@
 """Per-step GPU time distribution of one bench workload (events around every step, no host sync in the loop).
-usage: python tools/step_times.py [workload] [steps]"""
+usage: python tools/step_times.py [workload] [steps] [warm-up steps]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, two_tower_models_amd as A
@@ -11,7 +11,8 @@ opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep="forward")
 batches = bench.make_batches(cfg, 16, dev)
 def step(i):
     loss = model.train_forward(*batches[i % 16]); opt.zero_grad(); loss.backward(); opt.step()
-for i in range(120): step(i)
+warm = int(sys.argv[3]) if len(sys.argv) > 3 else 120
+for i in range(warm): step(i)
 torch.cuda.synchronize()
 evs = []
 for i in range(steps):
