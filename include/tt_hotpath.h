@@ -426,6 +426,35 @@ int tt_attn_row0_fwd(const float* q0, int64_t ldq, const float* kv, int64_t ldkv
 int tt_attn_row0_bwd(const float* q0, int64_t ldq, const float* kv, int64_t ldkv, const float* probs,
                      const float* d_ctx0, int64_t B, int64_t H, int64_t D, int64_t heads, float* d_q0,
                      float* d_kv, int64_t ld_dkv, tt_stream_t stream);
+/* One WHOLE attention layer of the encoder in one launch (round 4; ref:src/user_history_encoder.py:103-108 =
+ * nn.MultiheadAttention(x, x, x)[0]): y = (softmax((x Wq^T + bq)(x Wk^T + bk)^T / sqrt(dh)) (x Wv^T + bv)) Wo^T + bo per
+ * sample, one sample per workgroup, the packed projection and the context held in LDS.  x [B*H, D]; y [B*H, D]
+ * (ld_y = D) or, rows0_only != 0, row 0 of every sample into y [B, ld_y].  qkv [B*H, 3D], ctx [B*H, D], lse
+ * [B, heads, H] may each be NULL; when given they receive what tt_gemm_f32 + tt_attn_fwd would have produced (the
+ * backward's inputs).  Shape class: D = 128, heads = 4, H <= 55 (tt_enc_layer_fwd_supported), 16-byte aligned. */
+int tt_enc_layer_fwd_supported(int64_t H, int64_t D, int64_t heads);
+int tt_enc_layer_fwd(const float* x, int64_t B, int64_t H, int64_t D, int64_t heads, const float* w_in,
+                     const float* b_in, const float* w_out, const float* b_out, float* y, int64_t ld_y,
+                     int rows0_only, float* qkv, float* ctx, float* lse, tt_stream_t stream);
+/* The same layer WITHOUT projecting K and V (round 4; ref:src/user_history_encoder.py:103-116 with only row 0 of
+ * the last nn.MultiheadAttention consumed).  x [B*H, D] is the layer's input, w_in [3D, D] / b_in [3D] / w_out [D, D] /
+ * b_out [D] its packed parameters.  With q0 = W_q x[b,0] + b_q:  score_h[j] = scale (W_k,h^T q0_h) . x[b,j]  (the K bias
+ * shifts every score of a head alike and drops out of the softmax) and ctx0_h = W_v,h (sum_j p_h[j] x[b,j]) + b_v,h,
+ * so each sample's rows are read once and the [B*H, 2D] projection never exists.  Forward writes recent [B, D] (row
+ * stride ld_recent) = W_out ctx0 + b_out and, for the backward, q0 [B, D], t [B, heads, D] (= W_k,h^T q0_h), probs
+ * [B, heads, H], xbar [B, heads, D], ctx0 [B, D].  Backward writes dx [B*H, D] (every row), dW_in [3D, D], db_in [3D]
+ * (the K third exactly zero), dW_out [D, D], db_out [D]; weight gradients are per-workgroup partial sums added in a
+ * fixed order (deterministic).  Shapes: H <= 64, D <= 128, D % 4 == 0, D % heads == 0, heads <= 16
+ * (tt_enc_last_supported); x, dx, w_in, w_out, t, xbar and ws 16-byte aligned. */
+int tt_enc_last_supported(int64_t H, int64_t D, int64_t heads);
+int tt_enc_last_fwd(const float* x, int64_t B, int64_t H, int64_t D, int64_t heads, const float* w_in,
+                    const float* b_in, const float* w_out, const float* b_out, float* recent, int64_t ld_recent,
+                    float* q0, float* t, float* probs, float* xbar, float* ctx0, tt_stream_t stream);
+int64_t tt_enc_last_bwd_workspace_bytes(int64_t B, int64_t H, int64_t D, int64_t heads);
+int tt_enc_last_bwd(const float* x, int64_t B, int64_t H, int64_t D, int64_t heads, const float* w_in,
+                    const float* w_out, const float* d_recent, int64_t ld_dr, const float* q0, const float* t,
+                    const float* probs, const float* xbar, const float* ctx0, float* dx, float* dW_in, float* db_in,
+                    float* dW_out, float* db_out, void* ws, int64_t ws_bytes, tt_stream_t stream);
 
 /* ---------------------------------------------------------------- R1 owner routing (row-sharded tables)
  * New design -- the reference has no parallelism.  Tables are split into `world`

@@ -559,6 +559,114 @@ def test_attention_forward_backward(T, B, H, D, heads):
     assert torch.allclose(d_qkv.cpu(), qkv.grad, atol=2e-6 * float(qkv.grad.abs().max()) + 1e-7, rtol=2e-4)
 
 
+@pytest.mark.parametrize("B,H,D,heads", [(9, 50, 128, 4), (5, 64, 64, 4), (3, 1, 32, 2), (70, 7, 48, 3), (4, 3, 4, 1),
+                                         (300, 50, 128, 4), (33, 10, 100, 5), (2, 64, 128, 16)])
+def test_encoder_last_layer_without_kv_projection(T, B, H, D, heads):
+    """tt_enc_last_fwd / _bwd (csrc/encoder_last.hip): the encoder's last attention layer, consumed at row 0 only
+    (ref:src/user_history_encoder.py:103-116), with K / V never projected -- against the oracle's full layer
+    (oracle/cpu_ref.self_attention_layer, every position, row 0 taken) and torch autograd through it: output,
+    input gradient, and all four parameter gradients (the K third of the in-projection bias: zero both ways)."""
+    ops, N = T
+    lib = N.load()
+    assert lib.tt_enc_last_supported(H, D, heads)
+    x = g((B, H, D), 301).requires_grad_(True)
+    w_in = (g((3 * D, D), 302) * (1.0 / math.sqrt(D))).requires_grad_(True)
+    b_in = (g((3 * D,), 303) * 0.1).requires_grad_(True)
+    w_out = (g((D, D), 304) * (1.0 / math.sqrt(D))).requires_grad_(True)
+    b_out = (g((D,), 305) * 0.1).requires_grad_(True)
+    ref = R.self_attention_layer(x, w_in, b_in, w_out, b_out, heads)[:, 0, :]
+    cot = g((B, 2 * D), 306)[:, :D]  # strided rows, like out[:, 0, :] of the [B, 2, D] encoder output
+    (ref * cot).sum().backward()
+    xd = x.detach().reshape(B * H, D).to(DEV)
+    wi, bi, wo, bo = (t.detach().to(DEV) for t in (w_in, b_in, w_out, b_out))
+    out = torch.zeros(B, 2 * D, device=DEV)
+    q0, ctx0 = torch.empty(B, D, device=DEV), torch.empty(B, D, device=DEV)
+    tq, xbar = torch.empty(B, heads, D, device=DEV), torch.empty(B, heads, D, device=DEV)
+    probs = torch.empty(B, heads, H, device=DEV)
+    N.check(lib.tt_enc_last_fwd(xd.data_ptr(), B, H, D, heads, wi.data_ptr(), bi.data_ptr(), wo.data_ptr(), bo.data_ptr(),
+                                out.data_ptr(), 2 * D, q0.data_ptr(), tq.data_ptr(), probs.data_ptr(), xbar.data_ptr(),
+                                ctx0.data_ptr(), N.stream()), "enc_last_fwd")
+    assert torch.allclose(out[:, :D].cpu(), ref.detach(), atol=3e-6, rtol=1e-5)
+    assert float(out[:, D:].abs().max()) == 0.0  # the other half of each row is not touched
+    assert torch.allclose(probs.sum(-1).cpu(), torch.ones(B, heads), atol=1e-5)
+    cd = torch.zeros(B, 2 * D, device=DEV)
+    cd[:, :D] = cot.to(DEV)
+    dx = torch.empty(B * H, D, device=DEV)
+    dWi, dbi = torch.empty(3 * D, D, device=DEV), torch.empty(3 * D, device=DEV)
+    dWo, dbo = torch.empty(D, D, device=DEV), torch.empty(D, device=DEV)
+    nb = lib.tt_enc_last_bwd_workspace_bytes(B, H, D, heads)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    for _ in range(2):  # twice: the partial buffers are overwritten, not accumulated into
+        N.check(lib.tt_enc_last_bwd(xd.data_ptr(), B, H, D, heads, wi.data_ptr(), wo.data_ptr(), cd.data_ptr(), 2 * D,
+                                    q0.data_ptr(), tq.data_ptr(), probs.data_ptr(), xbar.data_ptr(), ctx0.data_ptr(),
+                                    dx.data_ptr(), dWi.data_ptr(), dbi.data_ptr(), dWo.data_ptr(), dbo.data_ptr(),
+                                    ws.data_ptr(), nb, N.stream()), "enc_last_bwd")
+
+    def close(got, want, name):
+        tol = 3e-6 * float(want.abs().max()) + 1e-8
+        assert torch.allclose(got.cpu().reshape(want.shape), want, atol=tol, rtol=2e-4), (name, float((got.cpu().reshape(want.shape) - want).abs().max()), tol)
+
+    close(dx, x.grad, "dx")
+    close(dWo, w_out.grad, "dW_out")
+    close(dbo, b_out.grad, "db_out")
+    close(dWi, w_in.grad, "dW_in")
+    assert float(dbi[D:2 * D].abs().max()) == 0.0 and float(b_in.grad[D:2 * D].abs().max()) < 1e-5 * float(b_in.grad.abs().max()) + 1e-7
+    keep = torch.ones(3 * D, dtype=torch.bool)
+    keep[D:2 * D] = False
+    close(dbi[keep.to(DEV)], b_in.grad[keep], "db_in")
+
+
+@pytest.mark.parametrize("B,H", [(1, 50), (5, 50), (300, 50), (7, 1), (3, 55), (258, 7), (513, 33)])
+@pytest.mark.parametrize("rows0", [False, True])
+def test_fused_encoder_layer_forward(T, B, H, rows0):
+    """tt_enc_layer_fwd (csrc/encoder_layer.hip: in-projection + attention + out-projection of one sample per
+    workgroup, D = 128, 4 heads) against the oracle's layer (oracle/cpu_ref.self_attention_layer) -- the output and the
+    three by-products the backward consumes (packed projection, context, row log-sum-exp)."""
+    ops, N = T
+    lib = N.load()
+    D, heads = 128, 4
+    assert lib.tt_enc_layer_fwd_supported(H, D, heads)
+    x = g((B, H, D), 401)
+    w_in = g((3 * D, D), 402) * (1.0 / math.sqrt(D))
+    b_in = g((3 * D,), 403) * 0.1
+    w_out = g((D, D), 404) * (1.0 / math.sqrt(D))
+    b_out = g((D,), 405) * 0.1
+    want = R.self_attention_layer(x, w_in, b_in, w_out, b_out, heads)
+    qkv_w = x.reshape(B * H, D) @ w_in.t() + b_in
+    dh = D // heads
+    q, k, v = (t_.reshape(B, H, heads, dh).permute(0, 2, 1, 3) for t_ in (qkv_w[:, :D], qkv_w[:, D:2 * D], qkv_w[:, 2 * D:]))
+    sc = (q / math.sqrt(dh)) @ k.transpose(-1, -2)
+    ctx_w = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B * H, D)
+    lse_w = torch.logsumexp(sc, -1)
+    xd = x.reshape(B * H, D).to(DEV)
+    wi, bi, wo, bo = (t_.to(DEV) for t_ in (w_in, b_in, w_out, b_out))
+    qkv = torch.full((B * H, 3 * D), float("nan"), device=DEV)
+    ctx = torch.full((B * H, D), float("nan"), device=DEV)
+    lse = torch.full((B, heads, H), float("nan"), device=DEV)
+    if rows0:
+        y = torch.zeros(B, 2 * D, device=DEV)
+        ld = 2 * D
+    else:
+        y = torch.full((B * H, D), float("nan"), device=DEV)
+        ld = D
+    N.check(lib.tt_enc_layer_fwd(xd.data_ptr(), B, H, D, heads, wi.data_ptr(), bi.data_ptr(), wo.data_ptr(), bo.data_ptr(),
+                                 y.data_ptr(), ld, 1 if rows0 else 0, qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(),
+                                 N.stream()), "enc_layer_fwd")
+    assert torch.allclose(qkv.cpu(), qkv_w, atol=3e-6, rtol=1e-5)
+    assert torch.allclose(ctx.cpu(), ctx_w, atol=3e-6, rtol=1e-5)
+    assert torch.allclose(lse.cpu(), lse_w, atol=1e-5)
+    if rows0:
+        assert torch.allclose(y[:, :D].cpu(), want[:, 0, :], atol=3e-6, rtol=1e-5)
+        assert float(y[:, D:].abs().max()) == 0.0
+    else:
+        assert torch.allclose(y.cpu().reshape(B, H, D), want, atol=3e-6, rtol=1e-5)
+    # without the by-products (inference): same output
+    y2 = torch.zeros_like(y) if rows0 else torch.full_like(y, float("nan"))
+    N.check(lib.tt_enc_layer_fwd(xd.data_ptr(), B, H, D, heads, wi.data_ptr(), bi.data_ptr(), wo.data_ptr(), bo.data_ptr(),
+                                 y2.data_ptr(), ld, 1 if rows0 else 0, None, None, None, N.stream()), "enc_layer_fwd")
+    assert torch.equal(y2, y)
+
+
 @pytest.mark.parametrize("D,H,B", [(128, 50, 9), (50, 7, 4)])
 def test_hist_embed_pool(T, D, H, B):
     ops, N = T

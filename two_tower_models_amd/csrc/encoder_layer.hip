@@ -1,0 +1,403 @@
+// K4 fused forward layer: one nn.MultiheadAttention self-attention layer of the history
+// encoder (ref:src/user_history_encoder.py:103-108) -- packed in-projection, per-head softmax attention,
+// out-projection -- for ONE SAMPLE at a time inside one workgroup, at the BASELINE shape class
+// D = 128, heads = 4 (head width 32), H <= 55:
+//
+//   x[H,128] --LDS-DMA--> LDS --(W_in stationary in registers)--> QKV[64,384] in LDS
+//        --(wave = head: S = QK^T, softmax, PV on the matrix cores)--> ctx over the Q columns, in LDS
+//        --(W_out streamed from L2)--> y[H,128] -> global
+//
+// The packed projection qkv [B*H, 384] (314 MB per layer at B = 4096, H = 50) and the context are never
+// READ back from HBM in the forward; they are still WRITTEN (fire-and-forget stores) when the caller wants
+// them for the backward, which consumes qkv / ctx / lse exactly as tt_attn_fwd's callers did.
+//
+// Shape of the workgroup: FOUR waves, one per SIMD, ~270 registers each -- not eight at 256.  The layer
+// runs next to the persistent Adam sweep (3 waves of 64 registers per SIMD): 270 + 192 <= 512, so a
+// fused workgroup and the sweep's waves share a CU, where an 8-wave / 256-register workgroup could not be
+// placed until the sweep had left ("starvation").  One wave per SIMD is enough for
+// the fp32 matrix pipe: the in-projection keeps six independent 16x16x4 accumulators in flight per
+// activation fragment (24 MFMAs per ds_read_b128), the attention and out-projection eight.
+//
+// Wave w owns head w end to end: the 96 in-projection columns of its Q, K, V slices (W_in rows in
+// registers: 6 column tiles x 8 k-groups x 4 = 192), its head's attention, and 32 out-projection
+// columns.  Two workgroup barriers per sample: ctx of all heads before the out-projection, and the QKV
+// buffer / the next x stage between samples.
+#include <stdlib.h>
+
+#include "common.hpp"
+
+namespace tt {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+constexpr int EL_D = 128, EL_HEADS = 4, EL_DH = 32;
+constexpr int EL_XROWS = 56;            // rows of an x stage: 28 one-KiB DMA pieces, 7 per wave; rows >= H land as zeros
+constexpr int EL_PPW = 7;
+constexpr int EL_LDQ = 3 * EL_D + 4;    // row stride of the QKV image: 388 = 4 (mod 64) -> one-row-per-lane b128 reads are conflict free
+constexpr int EL_HP = 64;               // padded history length
+
+struct EncLayerArgs {
+  const float* x;      // [B*H, 128]
+  const float* w_in;   // [384, 128]
+  const float* b_in;   // [384]
+  const float* w_out;  // [128, 128]
+  const float* b_out;  // [128]
+  float* y;            // [B*H, 128] or, rows0_only, [B, ld_y] (row 0 of every sample)
+  float* qkv;          // [B*H, 384] or null
+  float* ctx;          // [B*H, 128] or null
+  float* lse;          // [B, 4, H] or null
+  int64_t B, ld_y;
+  int H, rows0_only;
+  long long* trace;  // measurement only (TT_ENC_FWD_TRACE): per-wave clock at the phase boundaries of workgroup 0
+  int dbg;  // measurement only (TT_ENC_FWD_DBG): 1 skip the in-projection, 2 the attention, 4 the out-projection
+};
+
+__device__ __forceinline__ int el_arow(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
+
+// LDS-DMA of sample s's rows into one stage: chunk c of row `row` lands at chunk position c ^ (row & 15)
+__device__ __forceinline__ void el_issue_x(const EncLayerArgs& p, float* stage, int64_t s, int wave, int lane) {
+  const int64_t left = s < p.B ? p.H : 0;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(left ? p.x + s * p.H * EL_D : p.x), 0, (int)left * EL_D * 4, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < EL_PPW; ++i) {
+    const int q = wave * EL_PPW + i;
+    const int pos = q * 64 + lane;
+    const int row = pos / 32, cp = pos % 32;
+    const int c = cp ^ (row & 15);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(stage + q * 256), 16,
+                                             (row * EL_D + 4 * c) * 4, 0, 0, 0);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void el_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+}  // namespace
+
+// fence for the instruction scheduler: operand requests issued above it stay above it (hipcc otherwise sinks every
+// prefetch down to its first use -- fewer live registers, and every round trip exposed)
+#define EL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// One sample through the layer.  A free function, not a lambda of the kernel: buffer builtins inside a kernel-scope
+// lambda make the host pass drop the kernel's launch stub.
+// One wave per SIMD: nothing else hides an LDS round trip, so every phase requests its operands a step ahead of the
+// MFMAs that consume them, and no global store sits between a global load and its use (the wait for a load also waits
+// for every older store): per sample the order is DMA(next x) | qkv stores | W_out loads | (barrier) | y, ctx, lse stores.
+// All global stores are buffer stores off per-sample descriptors (rows >= H fall outside and are dropped): one
+// loop-invariant lane offset instead of a strength-reduced 64-bit pointer per store (32 + 24 of them).
+#define EL_MARK()                                                                                   \
+  do {                                                                                              \
+    if (p.trace && blockIdx.x == 0 && lane == 0 && tk < 64) p.trace[(wave * 64 + tk++) * 8] = clock64(); \
+  } while (0)
+
+template <bool ROWS0>
+__device__ __forceinline__ void el_sample(const EncLayerArgs& p, const float* xs, float* qs, const float* bias_s,
+                                          const float (&wr)[6][8][4], const float* wo_row, int64_t s, int wave, int lane,
+                                          int& tk) {
+  const int tl = lane & 15, q4 = lane >> 4;  // 16x16x4 roles: row-in-tile / k-quarter
+  const int r = lane & 31, h = lane >> 5;    // 32x32x2 roles: row / k-half
+  const int H = p.H;
+  const float scale = 0.17677669529663687f;  // 1 / sqrt(32)
+  EL_MARK();  // 0: sample start (after the barrier + DMA issue)
+  // ---------------- in-projection: QKV[row][col] for this head's 96 columns, all 64 rows
+  const __amdgpu_buffer_rsrc_t rs_qkv = __builtin_amdgcn_make_buffer_rsrc(
+      p.qkv ? p.qkv + s * H * (3 * EL_D) : nullptr, 0, p.qkv ? H * 3 * EL_D * 4 : 0, 0x00020000);
+  const int qkv_lane = (tl * 3 * EL_D + EL_DH * wave + 4 * q4) * 4;
+#pragma unroll 1
+  for (int i = (p.dbg & 1) ? 4 : 0; i < 4; ++i) {
+    const int row = 16 * i + tl;
+    const int rowc = row < H ? row : H;  // rows >= H: the stage's zero rows
+    const float* xrow = xs + rowc * EL_D;
+    const int sw = rowc & 15;
+    f32x4 acc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      acc[j] = *reinterpret_cast<const f32x4*>(bias_s + EL_D * (j >> 1) + EL_DH * wave + 16 * (j & 1) + 4 * q4);
+    f32x4 xc = *reinterpret_cast<const f32x4*>(xrow + 4 * (q4 ^ sw));
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      f32x4 xn = xc;
+      if (g + 1 < 8) xn = *reinterpret_cast<const f32x4*>(xrow + 4 * ((4 * (g + 1) + q4) ^ sw));
+      EL_SCHED_FENCE();
+      // (c outer, j inner: consecutive MFMAs go to DIFFERENT accumulators -- a dependent 16x16x4 issues after 40
+      // cycles, an independent one after 32)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[j][g][c], xc[c], acc[j], 0, 0, 0);
+      EL_SCHED_FENCE();
+      xc = xn;
+    }
+    // lane (tl, q4) holds row 16 i + tl, columns col(j) + 4 q4 .. + 3
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int col = EL_D * (j >> 1) + EL_DH * wave + 16 * (j & 1) + 4 * q4;
+      *reinterpret_cast<f32x4*>(qs + row * EL_LDQ + col) = acc[j];
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[j]), rs_qkv, qkv_lane,
+                                             (16 * i * 3 * EL_D + EL_D * (j >> 1) + 16 * (j & 1)) * 4, 0);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  EL_MARK();  // 1: in-projection done
+  float4 bq[4];  // first out-projection weight fragments: requested now, used after the attention (an L2 round trip)
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(wo_row + 8 * g);
+  // ---------------- attention of head `wave`: lane = query, St[key][query]
+  const float* Qh = qs + EL_DH * wave;
+  const float* Kh = qs + EL_D + EL_DH * wave;
+  const float* Vh = qs + 2 * EL_D + EL_DH * wave;
+  float lse_v[2] = {0.f, 0.f};
+#pragma unroll 1
+  for (int it = (p.dbg & 2) ? 2 : 0; it < 2; ++it) {
+    float4 qf[4], ka[2][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) qf[g] = *reinterpret_cast<const float4*>(Qh + (32 * it + r) * EL_LDQ + 8 * g + 4 * h);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) ka[jt][g] = *reinterpret_cast<const float4*>(Kh + (32 * jt + r) * EL_LDQ + 8 * g + 4 * h);
+    EL_SCHED_FENCE();
+    f32x16 st[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[jt][e] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        st[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[jt][g].x, qf[g].x * scale, st[jt], 0, 0, 0);
+        st[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[jt][g].y, qf[g].y * scale, st[jt], 0, 0, 0);
+        st[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[jt][g].z, qf[g].z * scale, st[jt], 0, 0, 0);
+        st[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[jt][g].w, qf[g].w * scale, st[jt], 0, 0, 0);
+      }
+    }
+    // V of this head, element-wise operand of P.V: requested before the softmax, consumed after it
+    float yv[2][16];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) yv[jt][e] = Vh[(32 * jt + el_arow(e, h)) * EL_LDQ + r];
+    EL_SCHED_FENCE();
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const bool valid = 32 * jt + el_arow(e, h) < H;
+        st[jt][e] = valid ? st[jt][e] : -3.0e38f;
+        mx = fmaxf(mx, st[jt][e]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        st[jt][e] = __expf(st[jt][e] - mx);
+        l += st[jt][e];
+      }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (it == 0) lse_v[0] = mx + __logf(l);
+    else lse_v[1] = mx + __logf(l);
+    f32x16 o;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o = __builtin_amdgcn_mfma_f32_32x32x2f32(st[jt][e] * inv, yv[jt][e], o, 0, 0, 0);
+    // context of queries 32 it + arow: over this head's Q columns (only this wave reads them, and it is done with tile `it`)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) qs[(32 * it + el_arow(e, h)) * EL_LDQ + EL_DH * wave + r] = o[e];
+  }
+  EL_MARK();  // 2: attention done
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // every head's context is in place (bare barrier: __syncthreads() would also drain vmcnt)
+  asm volatile("" ::: "memory");
+  // ---------------- out-projection: y[row][32 wave + r] = ctx[row] . W_out[32 wave + r] + b_out
+  EL_MARK();  // 3: past the barrier
+  constexpr int RT = ROWS0 ? 1 : 2;
+  f32x16 ya[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ya[t][e] = 0.f;
+  float4 bw[16];  // the remaining 12 weight fragments: all requested up front, behind the four that are here already
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bw[g] = bq[g];
+#pragma unroll
+  for (int g = 4; g < 16; ++g) bw[g] = *reinterpret_cast<const float4*>(wo_row + 8 * g);
+  float4 a_cur[RT], a_nxt[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) a_cur[t] = *reinterpret_cast<const float4*>(qs + (32 * t + r) * EL_LDQ + 4 * h);
+  EL_SCHED_FENCE();
+  if (!(p.dbg & 4))
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      a_nxt[t] = a_cur[t];
+      if (g + 1 < 16) a_nxt[t] = *reinterpret_cast<const float4*>(qs + (32 * t + r) * EL_LDQ + 8 * (g + 1) + 4 * h);
+    }
+    EL_SCHED_FENCE();
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      ya[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].x, bw[g].x, ya[t], 0, 0, 0);
+      ya[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].y, bw[g].y, ya[t], 0, 0, 0);
+      ya[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].z, bw[g].z, ya[t], 0, 0, 0);
+      ya[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t].w, bw[g].w, ya[t], 0, 0, 0);
+    }
+    EL_SCHED_FENCE();
+#pragma unroll
+    for (int t = 0; t < RT; ++t) a_cur[t] = a_nxt[t];
+  }
+  // Everything older than this point has long completed (the qkv stores were issued a whole attention ago, the
+  // weight loads were consumed above): the wait is free, and it is what guarantees that the NEXT sample's x stage
+  // (requested at the top of this sample) has landed before the barrier that precedes its use; the stores below stay
+  // in flight across that barrier.
+  EL_MARK();  // 4: out-projection MFMAs issued
+  el_wait_vmcnt<0>();
+  EL_MARK();  // 5: vmcnt(0)
+  const float bo = bias_s[3 * EL_D + EL_DH * wave + r];
+  if constexpr (ROWS0) {
+    if (h == 0) p.y[s * p.ld_y + EL_DH * wave + r] = ya[0][0] + bo;  // arow(0, 0) = 0: row 0 of the sample
+  } else {
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y + s * H * EL_D, 0, H * EL_D * 4, 0x00020000);
+    const int y_lane = (4 * h * EL_D + EL_DH * wave + r) * 4;
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ya[t][e] + bo), rs_y, y_lane,
+                                              (32 * t + (e & 3) + 8 * (e >> 2)) * EL_D * 4, 0);
+  }
+  {  // the context rows, from their LDS image (all heads): 16-byte pieces, coalesced; the row log-sum-exps
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(
+        p.ctx ? p.ctx + s * H * EL_D : nullptr, 0, p.ctx ? H * EL_D * 4 : 0, 0x00020000);
+    const int t256 = wave * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < (EL_XROWS * (EL_D / 4) + 255) / 256; ++k) {
+      const int f = t256 + 256 * k, row = f >> 5, c4 = f & 31;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(qs + row * EL_LDQ + 4 * c4);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_c, (row * EL_D + 4 * c4) * 4, 0, 0);
+    }
+    const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(
+        p.lse ? p.lse + (s * EL_HEADS + wave) * H : nullptr, 0, p.lse ? H * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lse_v[it]), rs_l, h == 0 ? (32 * it + r) * 4 : 0x7fffff00, 0, 0);
+  }
+  EL_MARK();  // 6: stores issued
+}
+
+template <bool ROWS0>
+__global__ __launch_bounds__(256, 1) void enc_layer_fwd_kernel(const EncLayerArgs p) {
+  __shared__ __attribute__((aligned(16))) float xs0[EL_XROWS * EL_D];
+  __shared__ __attribute__((aligned(16))) float xs1[EL_XROWS * EL_D];
+  __shared__ __attribute__((aligned(16))) float qs[EL_HP * EL_LDQ];
+  __shared__ __attribute__((aligned(16))) float bias_s[3 * EL_D + EL_D];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tl = lane & 15, q4 = lane >> 4;
+  const int r = lane & 31, h = lane >> 5;
+
+  // column tile j of this wave: j / 2 picks Q | K | V, j % 2 the 16-column half of head `wave`
+  // stationary in-projection weights: wr[j][g][c] = W_in[col(j) + tl][16 g + 4 q4 + c]
+  float wr[6][8][4];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int n = EL_D * (j >> 1) + EL_DH * wave + 16 * (j & 1) + tl;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const float4 v = *reinterpret_cast<const float4*>(p.w_in + (int64_t)n * EL_D + 16 * g + 4 * q4);
+      wr[j][g][0] = v.x; wr[j][g][1] = v.y; wr[j][g][2] = v.z; wr[j][g][3] = v.w;
+    }
+  }
+  for (int i = threadIdx.x; i < 3 * EL_D; i += 256) bias_s[i] = p.b_in[i];
+  if (threadIdx.x < EL_D) bias_s[3 * EL_D + threadIdx.x] = p.b_out[threadIdx.x];
+  const float* wo_row = p.w_out + (int64_t)(EL_DH * wave + r) * EL_D + 4 * h;  // B operand of the out-projection
+
+  const int64_t s0 = blockIdx.x, step = gridDim.x;
+  int tk = 0;
+  if (s0 >= p.B) return;
+  el_issue_x(p, xs0, s0, wave, lane);
+  // the BUILTIN wait, not inline assembly: hipcc's wait-count pass must SEE that the weight loads above have completed,
+  // or it re-waits vmcnt(0) at the top of every loop iteration (behind the next stage's DMA and the previous stores)
+  __builtin_amdgcn_s_waitcnt(0);  // weights, first x stage, bias image
+  for (int64_t s = s0; s < p.B; s += 2 * step) {
+    __builtin_amdgcn_s_barrier();  // x of sample s landed for every wave (each waited for its own pieces inside the
+    asm volatile("" ::: "memory");  // previous sample); everyone is done with the previous sample's context
+    el_issue_x(p, xs1, s + step, wave, lane);
+    el_sample<ROWS0>(p, xs0, qs, bias_s, wr, wo_row, s, wave, lane, tk);
+    if (s + step < p.B) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      el_issue_x(p, xs0, s + 2 * step, wave, lane);
+      el_sample<ROWS0>(p, xs1, qs, bias_s, wr, wo_row, s + step, wave, lane, tk);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  el_wait_vmcnt<0>();
+}
+
+}  // namespace tt
+
+using namespace tt;
+
+// 1 = the fused layer takes this shape (D = 128, heads = 4, H <= 55, 16-byte aligned rows)
+extern "C" int tt_enc_layer_fwd_supported(int64_t H, int64_t D, int64_t heads) {
+  return D == EL_D && heads == EL_HEADS && H >= 1 && H <= EL_XROWS - 1;
+}
+
+extern "C" int tt_enc_layer_fwd(const float* x, int64_t B, int64_t H, int64_t D, int64_t heads, const float* w_in,
+                                const float* b_in, const float* w_out, const float* b_out, float* y, int64_t ld_y,
+                                int rows0_only, float* qkv, float* ctx, float* lse, tt_stream_t stream) {
+  if (!x || !w_in || !b_in || !w_out || !b_out || !y) return fail_arg("tt_enc_layer_fwd: null pointer");
+  if (B < 0 || !(D == EL_D && heads == EL_HEADS && H >= 1 && H <= EL_XROWS - 1)) {
+    set_error("tt_enc_layer_fwd: takes D = 128, heads = 4, H <= 55 (got D = %lld, heads = %lld, H = %lld)", (long long)D,
+              (long long)heads, (long long)H);
+    return TT_E_UNSUPPORTED;
+  }
+  const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_in) | reinterpret_cast<uintptr_t>(w_out) |
+                       reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(b_in);
+  if (al & 15) return fail_arg("tt_enc_layer_fwd: x, w_in, b_in, w_out, qkv must be 16-byte aligned");
+  if (rows0_only ? ld_y < D : ld_y != D) return fail_arg("tt_enc_layer_fwd: ld_y");
+  if (B == 0) return 0;
+  static const int dbg = [] { const char* e = getenv("TT_ENC_FWD_DBG"); return e ? atoi(e) : 0; }();
+  static long long* trace = [] {
+    long long* t = nullptr;
+    if (getenv("TT_ENC_FWD_TRACE") && hipMalloc(&t, 4 * 64 * 8 * sizeof(long long)) != hipSuccess) t = nullptr;
+    return t;
+  }();
+  EncLayerArgs a{x, w_in, b_in, w_out, b_out, y, qkv, ctx, lse, B, ld_y, (int)H, rows0_only ? 1 : 0, trace, dbg};
+  hipStream_t st = S(stream);
+  static const int wgs = [] { const char* e = getenv("TT_ENC_FWD_WGS"); return e ? atoi(e) : 256; }();
+  const unsigned grid = (unsigned)(B < wgs ? B : wgs);
+  ProfScope prof("enc_layer_fwd_kernel", st);
+  if (rows0_only) enc_layer_fwd_kernel<true><<<grid, 256, 0, st>>>(a);
+  else enc_layer_fwd_kernel<false><<<grid, 256, 0, st>>>(a);
+  if (trace) {  // measurement only: phase boundaries of workgroup 0's first samples, cycles relative to the first mark
+    static int printed = 0;
+    if (printed++ == 3) {
+      (void)hipStreamSynchronize(st);
+      long long hbuf[4 * 64 * 8];
+      (void)hipMemcpy(hbuf, trace, sizeof(hbuf), hipMemcpyDeviceToHost);
+      for (int w = 0; w < 4; ++w) {
+        fprintf(stderr, "wave %d:", w);
+        for (int k = 1; k < 64; ++k) {
+          const long long d = hbuf[(w * 64 + k) * 8] - hbuf[(w * 64 + k - 1) * 8];
+          if (hbuf[(w * 64 + k) * 8] == 0) break;
+          fprintf(stderr, " %lld", d);
+        }
+        fprintf(stderr, "\n");
+      }
+    }
+  }
+  return check_launch("enc_layer_fwd_kernel");
+}

@@ -546,6 +546,10 @@ def tower_weight_grads(dy, tin, d_f, h, dh, feats, out=None, extra=None):
 
 _FUSED_DU = os.environ.get("TT_CE_NO_FUSED_DU") is None  # A/B switches
 _ROW0_LAST = os.environ.get("TT_ENC_FULL_LAST_LAYER") is None
+_ENC_LAST_COLLAPSED = os.environ.get("TT_ENC_NO_COLLAPSED_LAST") is None  # last layer without K / V projections (encoder_last.hip)
+# whole-layer forward in one launch (encoder_layer.hip): measured round 4 -- 440 us per layer alone against 375-390 us for
+# the three launches it replaces (one wave per SIMD, rows padded 50 -> 64), and no better next to the sweep; opt-in
+_ENC_FUSED_FWD = os.environ.get("TT_ENC_FUSED_FWD") is not None
 
 
 def kept_logits_supported(U: torch.Tensor, I: torch.Tensor) -> bool:
@@ -847,6 +851,10 @@ class HistoryEncoder(_LookupFunction):
                 "tt_hist_embed_pool")
         saved: List[torch.Tensor] = []
         row0_last = L > 0 and H <= 64 and D // heads <= 64 and _ROW0_LAST
+        collapsed_last = (row0_last and _ENC_LAST_COLLAPSED and bool(lib.tt_enc_last_supported(H, D, heads))
+                          and x.data_ptr() % 16 == 0)
+        fused_layer = (_ENC_FUSED_FWD and L > 0 and bool(lib.tt_enc_layer_fwd_supported(H, D, heads))
+                       and x.data_ptr() % 16 == 0)
         dh = D // max(heads, 1)
         if L > 0 and (H > 64 or dh not in (16, 32, 64) or D % 4):
             note_generic("history-encoder attention",
@@ -854,6 +862,21 @@ class HistoryEncoder(_LookupFunction):
                          "VALU attention" + ("" if row0_last else ", last layer computed for every position"))
         for l in range(L):
             w_in, b_in, w_out, b_out = layer_params[4 * l: 4 * l + 4]
+            if l == L - 1 and collapsed_last:
+                # the last layer is consumed at row 0 only and its K / V projections fold into two D-wide vectors per
+                # (sample, head): x is read once, no [B*H, 2D] projection (csrc/encoder_last.hip)
+                q0 = torch.empty(B, D, dtype=torch.float32, device=dev)
+                tq = torch.empty(B, heads, D, dtype=torch.float32, device=dev)
+                probs = torch.empty(B, heads, H, dtype=torch.float32, device=dev)
+                xbar = torch.empty(B, heads, D, dtype=torch.float32, device=dev)
+                ctx0 = torch.empty(B, D, dtype=torch.float32, device=dev)
+                w_in_c, w_out_c = w_in.contiguous(), w_out.contiguous()
+                N.check(lib.tt_enc_last_fwd(x.data_ptr(), B, H, D, heads, w_in_c.data_ptr(), b_in.contiguous().data_ptr(),
+                                            w_out_c.data_ptr(), b_out.contiguous().data_ptr(), out.data_ptr(), 2 * D,
+                                            q0.data_ptr(), tq.data_ptr(), probs.data_ptr(), xbar.data_ptr(), ctx0.data_ptr(),
+                                            N.stream()), "tt_enc_last_fwd")
+                saved += [x, q0, tq, probs, xbar, ctx0]
+                continue
             if l == L - 1 and row0_last:
                 # the last layer is consumed at row 0 only: K, V for every position, Q for position 0,
                 # one query per (sample, head) -- 1/H of the attention, 2/3 of the in-projection
@@ -870,6 +893,22 @@ class HistoryEncoder(_LookupFunction):
                 saved += [x, kv, q0, ctx0, probs]
                 continue
             qkv = torch.empty(B * H, 3 * D, dtype=torch.float32, device=dev)
+            if fused_layer:
+                # in-projection + attention + out-projection of one sample per workgroup (csrc/encoder_layer.hip): qkv /
+                # ctx / lse are written for the backward, never read back here
+                ctx_t = torch.empty(B * H, D, dtype=torch.float32, device=dev)
+                lse = torch.empty(B, heads, H, dtype=torch.float32, device=dev)
+                last = l + 1 == L
+                y = out if last else torch.empty(B * H, D, dtype=torch.float32, device=dev)
+                N.check(lib.tt_enc_layer_fwd(x.data_ptr(), B, H, D, heads, w_in.contiguous().data_ptr(),
+                                             b_in.contiguous().data_ptr(), w_out.contiguous().data_ptr(),
+                                             b_out.contiguous().data_ptr(), y.data_ptr(), 2 * D if last else D,
+                                             1 if last else 0, qkv.data_ptr(), ctx_t.data_ptr(), lse.data_ptr(),
+                                             N.stream()), "tt_enc_layer_fwd")
+                saved += [x, qkv, ctx_t, lse]
+                if not last:
+                    x = y
+                continue
             gemm(N.TT_GEMM_NT, x, w_in, qkv, B * H, 3 * D, D, bias=b_in)
             ctx_t, lse = _attn_fwd(qkv, B, H, D, heads)
             saved += [x, qkv, ctx_t, lse]
@@ -882,6 +921,7 @@ class HistoryEncoder(_LookupFunction):
             out[:, 0, :].copy_(x.view(B, H, D)[:, 0, :])
         ctx.dims = (B, H, D, L, heads)
         ctx.row0_last = row0_last
+        ctx.collapsed_last = collapsed_last
         ctx.table = source if ids is not None else None
         ctx.has_ids = ids is not None
         ctx.save_for_backward(ids, *layer_params, *saved)
@@ -902,6 +942,21 @@ class HistoryEncoder(_LookupFunction):
         dx = None  # gradient wrt the current layer's OUTPUT x_{l+1}, [B*H, D]
         for l in reversed(range(L)):
             w_in, b_in, w_out, b_out = layer_params[4 * l: 4 * l + 4]
+            if l == L - 1 and ctx.collapsed_last:
+                x, q0, tq, probs, xbar, ctx0 = saved[4 * l: 4 * l + 6]
+                dx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
+                dW_in = torch.empty(3 * D, D, dtype=torch.float32, device=dev)
+                db_in = torch.empty(3 * D, dtype=torch.float32, device=dev)
+                dW_out = torch.empty(D, D, dtype=torch.float32, device=dev)
+                db_out = torch.empty(D, dtype=torch.float32, device=dev)
+                wsp, wsn = _ws(dev, lib.tt_enc_last_bwd_workspace_bytes(B, H, D, heads), "enc_last")
+                N.check(lib.tt_enc_last_bwd(x.data_ptr(), B, H, D, heads, w_in.contiguous().data_ptr(),
+                                            w_out.contiguous().data_ptr(), d_recent.data_ptr(), 2 * D, q0.data_ptr(),
+                                            tq.data_ptr(), probs.data_ptr(), xbar.data_ptr(), ctx0.data_ptr(), dx.data_ptr(),
+                                            dW_in.data_ptr(), db_in.data_ptr(), dW_out.data_ptr(), db_out.data_ptr(),
+                                            wsp, wsn, N.stream()), "tt_enc_last_bwd")
+                grads[4 * l: 4 * l + 4] = [dW_in, db_in, dW_out, db_out]
+                continue
             if l == L - 1 and ctx.row0_last:
                 x, kv, q0, ctx0, probs = saved[4 * l: 4 * l + 5]
                 dW_out = torch.empty(D, D, dtype=torch.float32, device=dev)
