@@ -444,17 +444,28 @@ int tt_enc_layer_fwd(const float* x, int64_t B, int64_t H, int64_t D, int64_t he
  * stride ld_recent) = W_out ctx0 + b_out and, for the backward, q0 [B, D], t [B, heads, D] (= W_k,h^T q0_h), probs
  * [B, heads, H], xbar [B, heads, D], ctx0 [B, D].  Backward writes dx [B*H, D] (every row), dW_in [3D, D], db_in [3D]
  * (the K third exactly zero), dW_out [D, D], db_out [D]; weight gradients are per-workgroup partial sums added in a
- * fixed order (deterministic).  Shapes: H <= 64, D <= 128, D % 4 == 0, D % heads == 0, heads <= 16
- * (tt_enc_last_supported); x, dx, w_in, w_out, t, xbar and ws 16-byte aligned. */
+ * fixed order (deterministic).
+ * w_prev_out / b_prev_out != NULL: the layer in FRONT of this one (ref:...encoder.py:103-108, second to last iteration of
+ * the loop) hands over its attention CONTEXT c [B*H, D] in `x` instead of its output c W_prev_out^T + b_prev_out --
+ * every use of that output here is linear in it, so its out-projection, the d_ctx product and the weight-gradient
+ * product of that layer ([B*H, D] x [D, D] each) are replaced by [B (1 + 2 heads), D] x [D, D] ones.  Then the forward
+ * also saves tp, cbar [B, heads, D] and x0 [B, D] (row 0 of the output that is never formed); the backward's dx is the
+ * gradient of c, and dW_prev_out [D, D] / db_prev_out [D] are that layer's out-projection gradients.
+ * Shapes: H <= 64, D <= 128, D % 4 == 0, D % heads == 0, (D / heads) % 4 == 0, heads <= 16 (tt_enc_last_supported
+ * returns 1; 2 when the w_prev_out form is taken as well: 32 (D + 4) (2 + heads) floats of LDS); x, dx, d_recent, the
+ * weights, t, tp, xbar, cbar and ws 16-byte aligned. */
 int tt_enc_last_supported(int64_t H, int64_t D, int64_t heads);
 int tt_enc_last_fwd(const float* x, int64_t B, int64_t H, int64_t D, int64_t heads, const float* w_in,
-                    const float* b_in, const float* w_out, const float* b_out, float* recent, int64_t ld_recent,
-                    float* q0, float* t, float* probs, float* xbar, float* ctx0, tt_stream_t stream);
+                    const float* b_in, const float* w_out, const float* b_out, const float* w_prev_out,
+                    const float* b_prev_out, float* recent, int64_t ld_recent, float* q0, float* t, float* probs,
+                    float* xbar, float* ctx0, float* tp, float* cbar, float* x0, tt_stream_t stream);
 int64_t tt_enc_last_bwd_workspace_bytes(int64_t B, int64_t H, int64_t D, int64_t heads);
 int tt_enc_last_bwd(const float* x, int64_t B, int64_t H, int64_t D, int64_t heads, const float* w_in,
-                    const float* w_out, const float* d_recent, int64_t ld_dr, const float* q0, const float* t,
-                    const float* probs, const float* xbar, const float* ctx0, float* dx, float* dW_in, float* db_in,
-                    float* dW_out, float* db_out, void* ws, int64_t ws_bytes, tt_stream_t stream);
+                    const float* w_out, const float* w_prev_out, const float* d_recent, int64_t ld_dr, const float* q0,
+                    const float* t, const float* probs, const float* xbar, const float* ctx0, const float* tp,
+                    const float* cbar, const float* x0, float* dx, float* dW_in, float* db_in, float* dW_out,
+                    float* db_out, float* dW_prev_out, float* db_prev_out, void* ws, int64_t ws_bytes,
+                    tt_stream_t stream);
 
 /* ---------------------------------------------------------------- R1 owner routing (row-sharded tables)
  * New design -- the reference has no parallelism.  Tables are split into `world`

@@ -138,10 +138,11 @@ SIGNATURES = {
     "tt_enc_layer_fwd_supported": (_int, [_i64, _i64, _i64]),
     "tt_enc_layer_fwd": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
     "tt_enc_last_supported": (_int, [_i64, _i64, _i64]),
-    "tt_enc_last_fwd": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tt_enc_last_fwd": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
+                               _vp, _vp, _vp, _vp]),
     "tt_enc_last_bwd_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
-    "tt_enc_last_bwd": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                               _vp, _vp, _vp, _i64, _vp]),
+    "tt_enc_last_bwd": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tt_route_workspace_bytes": (_i64, [_i64, _i32]),
     "tt_route_count": (_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tt_route_build": (_int, [_vp, _i64, _i64, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),

@@ -33,7 +33,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int EL_MAXD = 128;   // columns lane and lane + 64 of the main kernels
 constexpr int EL_MAXH = 64;    // one history position per lane
 constexpr int EL_MAXHEADS = 16;
-constexpr int EL_ROWS = 32;    // samples per workgroup of the pre / post / a / b kernels
+constexpr int EL_ROWS = 32;    // samples per workgroup of the pre / post / a / b kernels (half of a 32-row MFMA tile: these
+                               // kernels are latency-bound chains of small products, 2x the workgroups beats full tiles)
+constexpr int EL_IMG = 32;     // rows of an LDS image (one MFMA tile)
 
 __device__ __forceinline__ float dot4(const float4 a, const float4 b, float acc) {
   acc = fmaf(a.x, b.x, acc);
@@ -67,30 +69,49 @@ __device__ __forceinline__ void fma4(float4& acc, float s, const float4 v) {
 // am / bm are the lane's operand masks (1 or 0): a 32-wide tile may span several heads.
 template <bool KC>
 __device__ __forceinline__ float4 el_fetch(const float* p, int64_t ld, int k, int K) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  // UNCONDITIONAL loads from clamped positions, masked afterwards: a guarded load sits in its own basic block and hipcc
+  // waits for it before evaluating the next guard -- one exposed memory round trip per load (gemm.hip has the same note)
+  float4 v;
   if constexpr (KC) {
-    if (k < K) v = *reinterpret_cast<const float4*>(p + k);
+    const int kc = k < K ? k : K - 4;
+    v = *reinterpret_cast<const float4*>(p + kc);
+    const float m = k < K ? 1.f : 0.f;
+    v.x *= m; v.y *= m; v.z *= m; v.w *= m;
   } else {
-    if (k + 0 < K) v.x = p[(int64_t)(k + 0) * ld];
-    if (k + 1 < K) v.y = p[(int64_t)(k + 1) * ld];
-    if (k + 2 < K) v.z = p[(int64_t)(k + 2) * ld];
-    if (k + 3 < K) v.w = p[(int64_t)(k + 3) * ld];
+    const int k0 = k + 0 < K ? k + 0 : K - 1, k1 = k + 1 < K ? k + 1 : K - 1, k2 = k + 2 < K ? k + 2 : K - 1, k3 = k + 3 < K ? k + 3 : K - 1;
+    const float x0 = p[(int64_t)k0 * ld], x1 = p[(int64_t)k1 * ld], x2 = p[(int64_t)k2 * ld], x3 = p[(int64_t)k3 * ld];
+    v.x = k + 0 < K ? x0 : 0.f;
+    v.y = k + 1 < K ? x1 : 0.f;
+    v.z = k + 2 < K ? x2 : 0.f;
+    v.w = k + 3 < K ? x3 : 0.f;
   }
   return v;
 }
 template <bool A_KC, bool B_KC>
 __device__ __forceinline__ void mma_tile(f32x16& acc, const float* pa, int64_t lda, float am, const float* pb,
                                          int64_t ldb, float bm, int K) {
+  // operands come straight from global memory / L2 (or LDS): FOUR k-groups (32 k) are requested ahead of the MFMAs that
+  // consume them -- with one group ahead every group paid most of an L2 round trip (4 MFMAs = 256 cycles of cover)
   const int h4 = ((threadIdx.x & 63) >> 5) * 4;
-  float4 a = el_fetch<A_KC>(pa, lda, h4, K), b = el_fetch<B_KC>(pb, ldb, h4, K);
-  for (int k0 = 0; k0 < K; k0 += 8) {
-    const float4 an = el_fetch<A_KC>(pa, lda, k0 + 8 + h4, K), bn = el_fetch<B_KC>(pb, ldb, k0 + 8 + h4, K);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x * am, b.x * bm, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y * am, b.y * bm, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z * am, b.z * bm, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w * am, b.w * bm, acc, 0, 0, 0);
-    a = an;
-    b = bn;
+  float4 a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = el_fetch<A_KC>(pa, lda, 8 * i + h4, K);
+    b[i] = el_fetch<B_KC>(pb, ldb, 8 * i + h4, K);
+  }
+  for (int k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (k0 + 8 * i < K) {  // (wave-uniform)
+        const float4 ac = a[i], bc = b[i];
+        a[i] = el_fetch<A_KC>(pa, lda, k0 + 32 + 8 * i + h4, K);
+        b[i] = el_fetch<B_KC>(pb, ldb, k0 + 32 + 8 * i + h4, K);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.x * am, bc.x * bm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.y * am, bc.y * bm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.z * am, bc.z * bm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac.w * am, bc.w * bm, acc, 0, 0, 0);
+      }
+    }
   }
 }
 __device__ __forceinline__ f32x16 zero16() {
@@ -109,43 +130,123 @@ struct ElLane {
 
 }  // namespace
 
-// ------------------------------------------------------------------ forward: q0, t
-// q0[b] = W_q X[b, 0] + b_q ;  t[b, h, :] = W_k,h^T q0_h[b]
-__global__ __launch_bounds__(256) void enc_last_pre_kernel(const float* __restrict__ x, int64_t B, int H, int D, int heads,
-                                                           const float* __restrict__ w_in, const float* __restrict__ b_in,
-                                                           float* __restrict__ q0, float* __restrict__ t) {
+// Arguments shared by the four small kernels.  PREV = the layer in front of this one hands over its attention
+// CONTEXT c [B*H, D] instead of its output x = c W_oa^T + b_oa (w_pa / b_pa = that layer's out-projection): every use of
+// x in this layer is linear in it, so
+//   X0 = x[b, 0] = c[b, 0] W_oa^T + b_oa          (the only row that is ever formed)
+//   t_h . x[j]   = (W_oa^T t_h) . c[j] + const     -> the main kernels run on c with tp_h = W_oa^T t_h
+//   xbar_h       = (sum_j p_h[j] c[j]) W_oa^T + b_oa = cbar_h W_oa^T + b_oa
+// and the [B*H, D] x [D, D] out-projection of that layer, its d_ctx product and its weight-gradient product
+// (3 x 6.7 GFLOP at the BASELINE shape) shrink to [B * (1 + 2 heads), D] x [D, D] ones.
+struct ElArgs {
+  const float* x;      // [B*H, D]: this layer's input, or (PREV) the previous layer's context
+  const float* w_in;   // [3D, D]
+  const float* b_in;   // [3D]
+  const float* w_out;  // [D, D]
+  const float* b_out;  // [D]
+  const float* w_pa;   // PREV: previous layer's out-projection weight [D, D]
+  const float* b_pa;   // PREV: its bias [D]
+  int64_t B;
+  int H, D, heads;
+  // saved by the forward, read by the backward
+  float* q0;     // [B, D]
+  float* t;      // [B, heads, D]   W_k,h^T q0_h
+  float* tp;     // PREV: [B, heads, D]   W_oa^T t_h  (else unused: the main kernels take t)
+  float* cbar;   // PREV: [B, heads, D]   sum_j p_h[j] c[j]  (else unused: the main forward writes xbar)
+  float* xbar;   // [B, heads, D]
+  float* ctx0;   // [B, D]
+  float* x0;     // PREV: [B, D]  row 0 of the never-formed x
+  float* recent; int64_t ld_recent;            // forward output [B, D]
+  const float* d_recent; int64_t ld_dr;        // backward input
+  float* d_xbar;  // backward scratch [B, heads, D]: what the main backward consumes (d_xbar, or PREV d_cbar)
+  float* dt;      // backward scratch [B, heads, D]: what the main backward produces (dt, or PREV dt')
+  float* dx;      // backward output [B*H, D] (PREV: gradient of the previous layer's context)
+  float* part_a;  // per-workgroup partial sums, backward a
+  float* part_b;  // per-workgroup partial sums, backward b
+};
+
+// floats per workgroup in the partial buffers:  a = [dW_out | dW_v | dW_pa(1) | db_out | db_v | db_pa(1)]
+//                                               b = [dW_q | dW_k | dW_pa(2+3) | db_q | db_pa(2)]
+__host__ __device__ inline int64_t el_part_a(int64_t D) { return 3 * D * D + 3 * D; }
+__host__ __device__ inline int64_t el_part_b(int64_t D) { return 3 * D * D + 2 * D; }
+
+// the [32, D] result tile `acc` of column tile ct -> LDS image (row stride ldq) and / or global rows (row stride ldg)
+#define EL_TILE_COLS(ct) const int col = 32 * (ct) + L.li, nc = col < D ? col : D - 1
+
+// ------------------------------------------------------------------ forward: q0, t (, X0, tp)
+template <bool PREV>
+__global__ __launch_bounds__(256, 1) void enc_last_pre_kernel(const ElArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* qs = reinterpret_cast<float*>(smem_raw);  // [32][D + 4]
+  const int D = p.D, H = p.H, heads = p.heads;
   const int ldq = D + 4, dh = D / heads, NT = (D + 31) / 32;
+  float* qs = reinterpret_cast<float*>(smem_raw);  // [32][ldq] q0
+  float* xs = qs + EL_IMG * ldq;                  // PREV: [32][ldq] X0
+  float* ts = xs + EL_IMG * ldq;                  // PREV: [heads][32][ldq] t
   const ElLane L;
   const int64_t b0 = (int64_t)blockIdx.x * EL_ROWS;
-  const int nb = (int)((B - b0) < EL_ROWS ? (B - b0) : EL_ROWS);
+  const int nb = (int)((p.B - b0) < EL_ROWS ? (p.B - b0) : EL_ROWS);
   const int rowA = L.li < nb ? L.li : nb - 1;
-  for (int ct = L.w; ct < NT; ct += 4) {
-    const int col = 32 * ct + L.li, nc = col < D ? col : D - 1;
+  if constexpr (PREV) {  // X0 = c[b, 0] W_oa^T + b_oa
+    for (int ct = L.w; ct < NT; ct += 4) {
+      EL_TILE_COLS(ct);
+      f32x16 acc = zero16();
+      mma_tile<true, true>(acc, p.x + (b0 + rowA) * H * D, 0, 1.f, p.w_pa + (int64_t)nc * D, 0, 1.f, D);
+      const float bias = p.b_pa[nc];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r);
+        const float v = acc[r] + bias;
+        if (col < D) {
+          xs[row * ldq + col] = v;
+          if (row < nb) p.x0[(b0 + row) * D + col] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int ct = L.w; ct < NT; ct += 4) {  // q0 = X0 W_q^T + b_q
+    EL_TILE_COLS(ct);
     f32x16 acc = zero16();
-    mma_tile<true, true>(acc, x + (b0 + rowA) * H * D, 0, 1.f, w_in + (int64_t)nc * D, 0, 1.f, D);
-    const float bias = b_in[nc];
+    if constexpr (PREV) mma_tile<true, true>(acc, xs + L.li * ldq, 0, 1.f, p.w_in + (int64_t)nc * D, 0, 1.f, D);
+    else mma_tile<true, true>(acc, p.x + (b0 + rowA) * H * D, 0, 1.f, p.w_in + (int64_t)nc * D, 0, 1.f, D);
+    const float bias = p.b_in[nc];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = acc_row(r);
       const float v = acc[r] + bias;
       if (col < D) {
         qs[row * ldq + col] = v;
-        if (row < nb) q0[(b0 + row) * D + col] = v;
+        if (row < nb) p.q0[(b0 + row) * D + col] = v;
       }
     }
   }
   __syncthreads();
-  for (int u = L.w; u < heads * NT; u += 4) {
+  for (int u = L.w; u < heads * NT; u += 4) {  // t_h = q0_h W_k,h
     const int hh = u / NT, ct = u % NT;
-    const int col = 32 * ct + L.li, nc = col < D ? col : D - 1;
+    EL_TILE_COLS(ct);
     f32x16 acc = zero16();
-    mma_tile<true, false>(acc, qs + L.li * ldq + hh * dh, 0, 1.f, w_in + (int64_t)(D + hh * dh) * D + nc, D, 1.f, dh);
+    mma_tile<true, false>(acc, qs + L.li * ldq + hh * dh, 0, 1.f, p.w_in + (int64_t)(D + hh * dh) * D + nc, D, 1.f, dh);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = acc_row(r);
-      if (col < D && row < nb) t[((b0 + row) * heads + hh) * D + col] = acc[r];
+      if (col < D) {
+        if constexpr (PREV) ts[(hh * EL_IMG + row) * ldq + col] = acc[r];
+        if (row < nb) p.t[((b0 + row) * heads + hh) * D + col] = acc[r];
+      }
+    }
+  }
+  if constexpr (PREV) {  // tp_h = t_h W_oa
+    __syncthreads();
+    for (int u = L.w; u < heads * NT; u += 4) {
+      const int hh = u / NT, ct = u % NT;
+      EL_TILE_COLS(ct);
+      f32x16 acc = zero16();
+      mma_tile<true, false>(acc, ts + (hh * EL_IMG + L.li) * ldq, 0, 1.f, p.w_pa + nc, D, 1.f, D);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r);
+        if (col < D && row < nb) p.tp[((b0 + row) * heads + hh) * D + col] = acc[r];
+      }
     }
   }
 }
@@ -193,71 +294,89 @@ __global__ __launch_bounds__(256) void enc_last_main_fwd_kernel(const float* __r
   }
 }
 
-// ------------------------------------------------------------------ forward: ctx0, recent
-// ctx0[b, i] = W_v[i] . xbar[b, head(i)] + b_v[i] ;  recent[b] = W_out ctx0[b] + b_out
-__global__ __launch_bounds__(256) void enc_last_post_kernel(const float* __restrict__ xbar, int64_t B, int D, int heads,
-                                                            const float* __restrict__ w_in, const float* __restrict__ b_in,
-                                                            const float* __restrict__ w_out, const float* __restrict__ b_out,
-                                                            float* __restrict__ ctx0, float* __restrict__ recent,
-                                                            int64_t ld_recent) {
+// ------------------------------------------------------------------ forward: (xbar,) ctx0, recent
+// ctx0[b, i] = W_v[i] . xbar[b, head(i)] + b_v[i] ;  recent[b] = W_out ctx0[b] + b_out ;  PREV: xbar_h = cbar_h W_oa^T + b_oa first
+template <bool PREV>
+__global__ __launch_bounds__(256, 1) void enc_last_post_kernel(const ElArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* cs = reinterpret_cast<float*>(smem_raw);  // [32][D + 4]
+  const int D = p.D, heads = p.heads;
   const int ldq = D + 4, dh = D / heads, NT = (D + 31) / 32;
+  float* cs = reinterpret_cast<float*>(smem_raw);  // [32][ldq] ctx0
+  float* xb = cs + EL_IMG * ldq;                  // PREV: [heads][32][ldq] xbar
   const ElLane L;
   const int64_t b0 = (int64_t)blockIdx.x * EL_ROWS;
-  const int nb = (int)((B - b0) < EL_ROWS ? (B - b0) : EL_ROWS);
+  const int nb = (int)((p.B - b0) < EL_ROWS ? (p.B - b0) : EL_ROWS);
   const int rowA = L.li < nb ? L.li : nb - 1;
+  if constexpr (PREV) {
+    for (int u = L.w; u < heads * NT; u += 4) {
+      const int hh = u / NT, ct = u % NT;
+      EL_TILE_COLS(ct);
+      f32x16 acc = zero16();
+      mma_tile<true, true>(acc, p.cbar + ((b0 + rowA) * heads + hh) * D, 0, 1.f, p.w_pa + (int64_t)nc * D, 0, 1.f, D);
+      const float bias = p.b_pa[nc];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r);
+        const float v = acc[r] + bias;
+        if (col < D) {
+          xb[(hh * EL_IMG + row) * ldq + col] = v;
+          if (row < nb) p.xbar[((b0 + row) * heads + hh) * D + col] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
   for (int ct = L.w; ct < NT; ct += 4) {
-    const int col = 32 * ct + L.li, nc = col < D ? col : D - 1;
+    EL_TILE_COLS(ct);
     const int h_lo = (32 * ct) / dh, h_hi = ((32 * ct + 31 < D ? 32 * ct + 31 : D - 1)) / dh;
     f32x16 acc = zero16();
-    for (int hh = h_lo; hh <= h_hi; ++hh)
-      mma_tile<true, true>(acc, xbar + ((b0 + rowA) * heads + hh) * D, 0, 1.f, w_in + (int64_t)(2 * D + nc) * D, 0,
-                           nc / dh == hh ? 1.f : 0.f, D);
-    const float bias = b_in[2 * D + nc];
+    for (int hh = h_lo; hh <= h_hi; ++hh) {
+      const float bm = nc / dh == hh ? 1.f : 0.f;
+      if constexpr (PREV) mma_tile<true, true>(acc, xb + (hh * EL_IMG + L.li) * ldq, 0, 1.f, p.w_in + (int64_t)(2 * D + nc) * D, 0, bm, D);
+      else mma_tile<true, true>(acc, p.xbar + ((b0 + rowA) * heads + hh) * D, 0, 1.f, p.w_in + (int64_t)(2 * D + nc) * D, 0, bm, D);
+    }
+    const float bias = p.b_in[2 * D + nc];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = acc_row(r);
       const float v = acc[r] + bias;
       if (col < D) {
         cs[row * ldq + col] = v;
-        if (row < nb) ctx0[(b0 + row) * D + col] = v;
+        if (row < nb) p.ctx0[(b0 + row) * D + col] = v;
       }
     }
   }
   __syncthreads();
   for (int ct = L.w; ct < NT; ct += 4) {
-    const int col = 32 * ct + L.li, nc = col < D ? col : D - 1;
+    EL_TILE_COLS(ct);
     f32x16 acc = zero16();
-    mma_tile<true, true>(acc, cs + L.li * ldq, 0, 1.f, w_out + (int64_t)nc * D, 0, 1.f, D);
-    const float bias = b_out[nc];
+    mma_tile<true, true>(acc, cs + L.li * ldq, 0, 1.f, p.w_out + (int64_t)nc * D, 0, 1.f, D);
+    const float bias = p.b_out[nc];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = acc_row(r);
-      if (col < D && row < nb) recent[(b0 + row) * ld_recent + col] = acc[r] + bias;
+      if (col < D && row < nb) p.recent[(b0 + row) * p.ld_recent + col] = acc[r] + bias;
     }
   }
 }
 
-// ------------------------------------------------------------------ backward a: d_ctx0, d_xbar; dW_out, dW_v, db_out, db_v
-// partial layout per workgroup (floats): [dW_out D*D | dW_v D*D | db_out D | db_v D]
-__global__ __launch_bounds__(256) void enc_last_bwd_a_kernel(const float* __restrict__ d_recent, int64_t ld_dr, int64_t B,
-                                                             int D, int heads, const float* __restrict__ w_in,
-                                                             const float* __restrict__ w_out,
-                                                             const float* __restrict__ ctx0, const float* __restrict__ xbar,
-                                                             float* __restrict__ d_xbar, float* __restrict__ part) {
+// ------------------------------------------------------------------ backward a: d_ctx0, d_xbar (, d_cbar); dW_out, dW_v (, dW_pa), biases
+template <bool PREV>
+__global__ __launch_bounds__(256, 1) void enc_last_bwd_a_kernel(const ElArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* dc = reinterpret_cast<float*>(smem_raw);  // [32][D + 4] d_ctx0, rows past the batch = 0
+  const int D = p.D, heads = p.heads;
   const int ldq = D + 4, dh = D / heads, NT = (D + 31) / 32;
+  float* dc = reinterpret_cast<float*>(smem_raw);  // [32][ldq] d_ctx0, rows past the batch = 0
+  float* dxb = dc + EL_IMG * ldq;                 // PREV: [heads][32][ldq] d_xbar, rows past the batch = 0
   const ElLane L;
   const int64_t b0 = (int64_t)blockIdx.x * EL_ROWS;
-  const int nb = (int)((B - b0) < EL_ROWS ? (B - b0) : EL_ROWS);
+  const int nb = (int)((p.B - b0) < EL_ROWS ? (p.B - b0) : EL_ROWS);
   const int rowA = L.li < nb ? L.li : nb - 1;
   // d_ctx0[b][n] = sum_k d_recent[b][k] W_out[k][n]
   for (int ct = L.w; ct < NT; ct += 4) {
-    const int col = 32 * ct + L.li, nc = col < D ? col : D - 1;
+    EL_TILE_COLS(ct);
     f32x16 acc = zero16();
-    mma_tile<true, false>(acc, d_recent + (b0 + rowA) * ld_dr, 0, 1.f, w_out + nc, D, 1.f, D);
+    mma_tile<true, false>(acc, p.d_recent + (b0 + rowA) * p.ld_dr, 0, 1.f, p.w_out + nc, D, 1.f, D);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = acc_row(r);
@@ -268,45 +387,73 @@ __global__ __launch_bounds__(256) void enc_last_bwd_a_kernel(const float* __rest
   // d_xbar[b][h][n] = sum_{k in head h} d_ctx0[b][k] W_v[k][n]
   for (int u = L.w; u < heads * NT; u += 4) {
     const int hh = u / NT, ct = u % NT;
-    const int col = 32 * ct + L.li, nc = col < D ? col : D - 1;
+    EL_TILE_COLS(ct);
     f32x16 acc = zero16();
-    mma_tile<true, false>(acc, dc + L.li * ldq + hh * dh, 0, 1.f, w_in + (int64_t)(2 * D + hh * dh) * D + nc, D, 1.f, dh);
+    mma_tile<true, false>(acc, dc + L.li * ldq + hh * dh, 0, 1.f, p.w_in + (int64_t)(2 * D + hh * dh) * D + nc, D, 1.f, dh);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = acc_row(r);
-      if (col < D && row < nb) d_xbar[((b0 + row) * heads + hh) * D + col] = acc[r];
+      if (col < D) {
+        if constexpr (PREV) dxb[(hh * EL_IMG + row) * ldq + col] = row < nb ? acc[r] : 0.f;
+        else if (row < nb) p.d_xbar[((b0 + row) * heads + hh) * D + col] = acc[r];
+      }
+    }
+  }
+  if constexpr (PREV) {  // d_cbar_h = d_xbar_h W_oa
+    __syncthreads();
+    for (int u = L.w; u < heads * NT; u += 4) {
+      const int hh = u / NT, ct = u % NT;
+      EL_TILE_COLS(ct);
+      f32x16 acc = zero16();
+      mma_tile<true, false>(acc, dxb + (hh * EL_IMG + L.li) * ldq, 0, 1.f, p.w_pa + nc, D, 1.f, D);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r);
+        if (col < D && row < nb) p.d_xbar[((b0 + row) * heads + hh) * D + col] = acc[r];
+      }
     }
   }
   // dW_out[m][n] = sum_b d_recent[b][m] ctx0[b][n] ;  dW_v[m][n] = sum_b d_ctx0[b][m] xbar[b][head(m)][n]
-  float* mine = part + (int64_t)blockIdx.x * (2 * D * D + 2 * D);
+  // PREV: dW_pa(1)[m][n] = sum_b sum_h d_xbar[b][h][m] cbar[b][h][n]
+  float* mine = p.part_a + (int64_t)blockIdx.x * el_part_a(D);
+  const int64_t DD = (int64_t)D * D;
   for (int u = L.w; u < NT * NT; u += 4) {
     const int rt = u / NT, ct = u % NT;
     const int mrow = 32 * rt + L.li, mc = mrow < D ? mrow : D - 1;
-    const int col = 32 * ct + L.li, nc = col < D ? col : D - 1;
+    EL_TILE_COLS(ct);
     f32x16 acc = zero16();
-    mma_tile<false, false>(acc, d_recent + b0 * ld_dr + mc, ld_dr, 1.f, ctx0 + b0 * D + nc, D, 1.f, nb);
+    mma_tile<false, false>(acc, p.d_recent + b0 * p.ld_dr + mc, p.ld_dr, 1.f, p.ctx0 + b0 * D + nc, D, 1.f, nb);
     f32x16 acv = zero16();
     const int h_lo = (32 * rt) / dh, h_hi = ((32 * rt + 31 < D ? 32 * rt + 31 : D - 1)) / dh;
     for (int hh = h_lo; hh <= h_hi; ++hh)
-      mma_tile<false, false>(acv, dc + mc, ldq, mc / dh == hh ? 1.f : 0.f, xbar + (b0 * heads + hh) * D + nc,
+      mma_tile<false, false>(acv, dc + mc, ldq, mc / dh == hh ? 1.f : 0.f, p.xbar + (b0 * heads + hh) * D + nc,
                              (int64_t)heads * D, 1.f, nb);
+    f32x16 acp = zero16();
+    if constexpr (PREV)
+      for (int hh = 0; hh < heads; ++hh)
+        mma_tile<false, false>(acp, dxb + hh * EL_IMG * ldq + mc, ldq, 1.f, p.cbar + (b0 * heads + hh) * D + nc,
+                               (int64_t)heads * D, 1.f, nb);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = 32 * rt + acc_row(r);
       if (row < D && col < D) {
         mine[row * D + col] = acc[r];
-        mine[D * D + row * D + col] = acv[r];
+        mine[DD + row * D + col] = acv[r];
+        if constexpr (PREV) mine[2 * DD + row * D + col] = acp[r];
       }
     }
   }
   if ((int)threadIdx.x < D) {
-    float so = 0.f, sv = 0.f;
+    float so = 0.f, sv = 0.f, sp = 0.f;
     for (int b = 0; b < nb; ++b) {
-      so += d_recent[(b0 + b) * ld_dr + threadIdx.x];
+      so += p.d_recent[(b0 + b) * p.ld_dr + threadIdx.x];
       sv += dc[b * ldq + threadIdx.x];
+      if constexpr (PREV)
+        for (int hh = 0; hh < heads; ++hh) sp += dxb[(hh * EL_IMG + b) * ldq + threadIdx.x];
     }
-    mine[2 * D * D + threadIdx.x] = so;
-    mine[2 * D * D + D + threadIdx.x] = sv;
+    mine[3 * DD + threadIdx.x] = so;
+    mine[3 * DD + D + threadIdx.x] = sv;
+    mine[3 * DD + 2 * D + threadIdx.x] = sp;
   }
 }
 
@@ -370,27 +517,43 @@ __global__ __launch_bounds__(256) void enc_last_main_bwd_kernel(const float* __r
   }
 }
 
-// ------------------------------------------------------------------ backward b: dq0 -> dX[0]; dW_k, dW_q, db_q
-// partial layout per workgroup (floats): [dW_q D*D | dW_k D*D | db_q D]
-__global__ __launch_bounds__(256) void enc_last_bwd_b_kernel(const float* __restrict__ x, int64_t B, int H, int D, int heads,
-                                                             const float* __restrict__ w_in, const float* __restrict__ q0,
-                                                             const float* __restrict__ dt, float* __restrict__ dx,
-                                                             float* __restrict__ part) {
+// ------------------------------------------------------------------ backward b: (dt,) dq0 -> dX[0]; dW_k, dW_q (, dW_pa), biases
+template <bool PREV>
+__global__ __launch_bounds__(256, 1) void enc_last_bwd_b_kernel(const ElArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* dq = reinterpret_cast<float*>(smem_raw);  // [32][D + 4] dq0, rows past the batch = 0
+  const int D = p.D, H = p.H, heads = p.heads;
   const int ldq = D + 4, dh = D / heads, NT = (D + 31) / 32;
+  float* dq = reinterpret_cast<float*>(smem_raw);  // [32][ldq] dq0, rows past the batch = 0
+  float* dxs = dq + EL_IMG * ldq;                 // PREV: [32][ldq] dX0, rows past the batch = 0
+  float* dts = dxs + EL_IMG * ldq;                // PREV: [heads][32][ldq] dt, rows past the batch = 0
   const ElLane L;
   const int64_t b0 = (int64_t)blockIdx.x * EL_ROWS;
-  const int nb = (int)((B - b0) < EL_ROWS ? (B - b0) : EL_ROWS);
+  const int nb = (int)((p.B - b0) < EL_ROWS ? (p.B - b0) : EL_ROWS);
   const int rowA = L.li < nb ? L.li : nb - 1;
+  if constexpr (PREV) {  // dt_h = dt'_h W_oa^T   (p.dt holds dt' = sum_j ds_h[j] c[j])
+    for (int u = L.w; u < heads * NT; u += 4) {
+      const int hh = u / NT, ct = u % NT;
+      EL_TILE_COLS(ct);
+      f32x16 acc = zero16();
+      mma_tile<true, true>(acc, p.dt + ((b0 + rowA) * heads + hh) * D, 0, 1.f, p.w_pa + (int64_t)nc * D, 0, 1.f, D);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r);
+        if (col < D) dts[(hh * EL_IMG + row) * ldq + col] = row < nb ? acc[r] : 0.f;
+      }
+    }
+    __syncthreads();
+  }
   // dq0[b][n] = W_k[n] . dt[b][head(n)]
   for (int ct = L.w; ct < NT; ct += 4) {
-    const int col = 32 * ct + L.li, nc = col < D ? col : D - 1;
+    EL_TILE_COLS(ct);
     const int h_lo = (32 * ct) / dh, h_hi = ((32 * ct + 31 < D ? 32 * ct + 31 : D - 1)) / dh;
     f32x16 acc = zero16();
-    for (int hh = h_lo; hh <= h_hi; ++hh)
-      mma_tile<true, true>(acc, dt + ((b0 + rowA) * heads + hh) * D, 0, 1.f, w_in + (int64_t)(D + nc) * D, 0,
-                           nc / dh == hh ? 1.f : 0.f, D);
+    for (int hh = h_lo; hh <= h_hi; ++hh) {
+      const float bm = nc / dh == hh ? 1.f : 0.f;
+      if constexpr (PREV) mma_tile<true, true>(acc, dts + (hh * EL_IMG + L.li) * ldq, 0, 1.f, p.w_in + (int64_t)(D + nc) * D, 0, bm, D);
+      else mma_tile<true, true>(acc, p.dt + ((b0 + rowA) * heads + hh) * D, 0, 1.f, p.w_in + (int64_t)(D + nc) * D, 0, bm, D);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = acc_row(r);
@@ -398,85 +561,123 @@ __global__ __launch_bounds__(256) void enc_last_bwd_b_kernel(const float* __rest
     }
   }
   __syncthreads();
-  // dX[b, 0][n] += sum_k dq0[b][k] W_q[k][n]
+  // dX0[b][n] = sum_k dq0[b][k] W_q[k][n]:  added to row 0 of the sample's dx, or (PREV) kept for the next product
   for (int ct = L.w; ct < NT; ct += 4) {
-    const int col = 32 * ct + L.li, nc = col < D ? col : D - 1;
+    EL_TILE_COLS(ct);
     f32x16 acc = zero16();
-    mma_tile<true, false>(acc, dq + L.li * ldq, 0, 1.f, w_in + nc, D, 1.f, D);
+    mma_tile<true, false>(acc, dq + L.li * ldq, 0, 1.f, p.w_in + nc, D, 1.f, D);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = acc_row(r);
-      if (col < D && row < nb) dx[(b0 + row) * H * D + col] += acc[r];
+      if (col < D) {
+        if constexpr (PREV) dxs[row * ldq + col] = row < nb ? acc[r] : 0.f;
+        else if (row < nb) p.dx[(b0 + row) * H * D + col] += acc[r];
+      }
     }
   }
-  // dW_q[m][n] = sum_b dq0[b][m] X[b, 0][n] ;  dW_k[m][n] = sum_b q0[b][m] dt[b][head(m)][n]
-  float* mine = part + (int64_t)blockIdx.x * (2 * D * D + D);
+  if constexpr (PREV) {  // d_c[b, 0][n] += sum_k dX0[b][k] W_oa[k][n]
+    __syncthreads();
+    for (int ct = L.w; ct < NT; ct += 4) {
+      EL_TILE_COLS(ct);
+      f32x16 acc = zero16();
+      mma_tile<true, false>(acc, dxs + L.li * ldq, 0, 1.f, p.w_pa + nc, D, 1.f, D);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r);
+        if (col < D && row < nb) p.dx[(b0 + row) * H * D + col] += acc[r];
+      }
+    }
+  }
+  // dW_q[m][n] = sum_b dq0[b][m] X0[b][n] ;  dW_k[m][n] = sum_b q0[b][m] dt[b][head(m)][n]
+  // PREV: dW_pa(2+3)[m][n] = sum_b sum_h t[b][h][m] dt'[b][h][n] + sum_b dX0[b][m] c[b, 0][n]
+  float* mine = p.part_b + (int64_t)blockIdx.x * el_part_b(D);
+  const int64_t DD = (int64_t)D * D;
   for (int u = L.w; u < NT * NT; u += 4) {
     const int rt = u / NT, ct = u % NT;
     const int mrow = 32 * rt + L.li, mc = mrow < D ? mrow : D - 1;
-    const int col = 32 * ct + L.li, nc = col < D ? col : D - 1;
+    EL_TILE_COLS(ct);
     f32x16 acc = zero16();
-    mma_tile<false, false>(acc, dq + mc, ldq, 1.f, x + b0 * H * D + nc, (int64_t)H * D, 1.f, nb);
+    if constexpr (PREV) mma_tile<false, false>(acc, dq + mc, ldq, 1.f, p.x0 + b0 * D + nc, D, 1.f, nb);
+    else mma_tile<false, false>(acc, dq + mc, ldq, 1.f, p.x + b0 * H * D + nc, (int64_t)H * D, 1.f, nb);
     f32x16 ack = zero16();
     const int h_lo = (32 * rt) / dh, h_hi = ((32 * rt + 31 < D ? 32 * rt + 31 : D - 1)) / dh;
-    for (int hh = h_lo; hh <= h_hi; ++hh)
-      mma_tile<false, false>(ack, q0 + b0 * D + mc, D, mc / dh == hh ? 1.f : 0.f, dt + (b0 * heads + hh) * D + nc,
-                             (int64_t)heads * D, 1.f, nb);
+    for (int hh = h_lo; hh <= h_hi; ++hh) {
+      const float am = mc / dh == hh ? 1.f : 0.f;
+      if constexpr (PREV) mma_tile<false, false>(ack, p.q0 + b0 * D + mc, D, am, dts + hh * EL_IMG * ldq + nc, ldq, 1.f, nb);
+      else mma_tile<false, false>(ack, p.q0 + b0 * D + mc, D, am, p.dt + (b0 * heads + hh) * D + nc, (int64_t)heads * D, 1.f, nb);
+    }
+    f32x16 acp = zero16();
+    if constexpr (PREV) {
+      for (int hh = 0; hh < heads; ++hh)
+        mma_tile<false, false>(acp, p.t + (b0 * heads + hh) * D + mc, (int64_t)heads * D, 1.f, p.dt + (b0 * heads + hh) * D + nc,
+                               (int64_t)heads * D, 1.f, nb);
+      mma_tile<false, false>(acp, dxs + mc, ldq, 1.f, p.x + b0 * H * D + nc, (int64_t)H * D, 1.f, nb);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = 32 * rt + acc_row(r);
       if (row < D && col < D) {
         mine[row * D + col] = acc[r];
-        mine[D * D + row * D + col] = ack[r];
+        mine[DD + row * D + col] = ack[r];
+        if constexpr (PREV) mine[2 * DD + row * D + col] = acp[r];
       }
     }
   }
   if ((int)threadIdx.x < D) {
-    float sq = 0.f;
-    for (int b = 0; b < nb; ++b) sq += dq[b * ldq + threadIdx.x];
-    mine[2 * D * D + threadIdx.x] = sq;
+    float sq = 0.f, sx = 0.f;
+    for (int b = 0; b < nb; ++b) {
+      sq += dq[b * ldq + threadIdx.x];
+      if constexpr (PREV) sx += dxs[b * ldq + threadIdx.x];
+    }
+    mine[3 * DD + threadIdx.x] = sq;
+    mine[3 * DD + D + threadIdx.x] = sx;
   }
 }
 
 // ------------------------------------------------------------------ reduce the partials (fixed order)
-// dW_in [3D, D] = [dW_q | dW_k | dW_v], db_in [3D] = [db_q | 0 | db_v], dW_out [D, D], db_out [D]
-__global__ __launch_bounds__(256) void enc_last_reduce_kernel(const float* __restrict__ part_a, int n_a,
-                                                              const float* __restrict__ part_b, int n_b, int D,
-                                                              float* __restrict__ dW_in, float* __restrict__ db_in,
-                                                              float* __restrict__ dW_out, float* __restrict__ db_out) {
+// dW_in [3D, D] = [dW_q | dW_k | dW_v], db_in [3D] = [db_q | 0 | db_v], dW_out [D, D], db_out [D];
+// PREV: dW_pa [D, D] = a.dW_pa(1) + b.dW_pa(2+3), db_pa [D] = a.db_pa(1) + b.db_pa(2)
+__device__ __forceinline__ float el_sum_parts(const float* src, int64_t stride, int n) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four interleaved chains: independent loads in flight
+  int w = 0;
+  for (; w + 3 < n; w += 4) {
+    s0 += src[(int64_t)w * stride];
+    s1 += src[(int64_t)(w + 1) * stride];
+    s2 += src[(int64_t)(w + 2) * stride];
+    s3 += src[(int64_t)(w + 3) * stride];
+  }
+  for (; w < n; ++w) s0 += src[(int64_t)w * stride];
+  return (s0 + s1) + (s2 + s3);
+}
+__global__ __launch_bounds__(256) void enc_last_reduce_kernel(const float* __restrict__ part_a, const float* __restrict__ part_b,
+                                                              int n, int D, float* __restrict__ dW_in, float* __restrict__ db_in,
+                                                              float* __restrict__ dW_out, float* __restrict__ db_out,
+                                                              float* __restrict__ dW_pa, float* __restrict__ db_pa) {
   const int DD = D * D;
-  const int total = 4 * DD + 3 * D;
-  const int sa = 2 * DD + 2 * D, sb = 2 * DD + D;
+  const int64_t sa = el_part_a(D), sb = el_part_b(D);
+  const int total = 5 * DD + 4 * D;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-    const float* src;
-    int stride, n;
-    float* dst;
-    if (e < DD) {  // dW_q
-      src = part_b + e; stride = sb; n = n_b; dst = dW_in + e;
-    } else if (e < 2 * DD) {  // dW_k
-      src = part_b + e; stride = sb; n = n_b; dst = dW_in + e;
+    if (e < 2 * DD) {  // dW_q | dW_k
+      dW_in[e] = el_sum_parts(part_b + e, sb, n);
     } else if (e < 3 * DD) {  // dW_v
-      src = part_a + DD + (e - 2 * DD); stride = sa; n = n_a; dst = dW_in + e;
+      dW_in[e] = el_sum_parts(part_a + DD + (e - 2 * DD), sa, n);
     } else if (e < 4 * DD) {  // dW_out
-      src = part_a + (e - 3 * DD); stride = sa; n = n_a; dst = dW_out + (e - 3 * DD);
-    } else if (e < 4 * DD + D) {  // db_q
-      src = part_b + 2 * DD + (e - 4 * DD); stride = sb; n = n_b; dst = db_in + (e - 4 * DD);
-    } else if (e < 4 * DD + 2 * D) {  // db_v
-      src = part_a + 2 * DD + D + (e - 4 * DD - D); stride = sa; n = n_a; dst = db_in + 2 * D + (e - 4 * DD - D);
-    } else {  // db_out
-      src = part_a + 2 * DD + (e - 4 * DD - 2 * D); stride = sa; n = n_a; dst = db_out + (e - 4 * DD - 2 * D);
+      dW_out[e - 3 * DD] = el_sum_parts(part_a + (e - 3 * DD), sa, n);
+    } else if (e < 5 * DD) {  // dW_pa
+      if (dW_pa) dW_pa[e - 4 * DD] = el_sum_parts(part_a + 2 * DD + (e - 4 * DD), sa, n) + el_sum_parts(part_b + 2 * DD + (e - 4 * DD), sb, n);
+    } else {
+      const int k = e - 5 * DD, which = k / D, i = k % D;
+      if (which == 0) {  // db_q, and the K third: exactly zero
+        db_in[i] = el_sum_parts(part_b + 3 * DD + i, sb, n);
+        db_in[D + i] = 0.f;
+      } else if (which == 1) {
+        db_in[2 * D + i] = el_sum_parts(part_a + 3 * DD + D + i, sa, n);
+      } else if (which == 2) {
+        db_out[i] = el_sum_parts(part_a + 3 * DD + i, sa, n);
+      } else if (db_pa) {
+        db_pa[i] = el_sum_parts(part_a + 3 * DD + 2 * D + i, sa, n) + el_sum_parts(part_b + 3 * DD + D + i, sb, n);
+      }
     }
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four interleaved chains: independent loads in flight
-    int w = 0;
-    for (; w + 3 < n; w += 4) {
-      s0 += src[(int64_t)w * stride];
-      s1 += src[(int64_t)(w + 1) * stride];
-      s2 += src[(int64_t)(w + 2) * stride];
-      s3 += src[(int64_t)(w + 3) * stride];
-    }
-    for (; w < n; ++w) s0 += src[(int64_t)w * stride];
-    *dst = (s0 + s1) + (s2 + s3);
-    if (e >= 4 * DD + D && e < 4 * DD + 2 * D) db_in[D + (e - 4 * DD - D)] = 0.f;  // db_k: exactly zero
   }
 }
 
@@ -494,44 +695,81 @@ int64_t el_groups(int64_t B) { return ceil_div(B, EL_ROWS); }
 
 bool el_aligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// LDS of the small kernels: one [32][D+4] image, PREV: + one more and a [heads][32][D+4] one
+size_t el_small_lds(int64_t D, int64_t heads, bool prev, int plain_images) {
+  const size_t img = (size_t)EL_IMG * (D + 4) * sizeof(float);
+  return prev ? img * (plain_images + heads) : img;
+}
+
 }  // namespace
 }  // namespace tt
 
 using namespace tt;
 
+// 0 = shape not taken; 1 = taken; 2 = taken, and so is the form with the previous layer's out-projection folded in
+// (w_prev_out != NULL: two plain and `heads` per-head [32, D + 4] LDS images)
 extern "C" int tt_enc_last_supported(int64_t H, int64_t D, int64_t heads) {
-  return H >= 1 && H <= EL_MAXH && D >= 4 && D <= EL_MAXD && D % 4 == 0 && heads >= 1 && heads <= EL_MAXHEADS &&
-         D % heads == 0 && (D / heads) % 4 == 0;
+  if (!(H >= 1 && H <= EL_MAXH && D >= 4 && D <= EL_MAXD && D % 4 == 0 && heads >= 1 && heads <= EL_MAXHEADS &&
+        D % heads == 0 && (D / heads) % 4 == 0))
+    return 0;
+  return (size_t)EL_IMG * (D + 4) * 4 * (2 + heads) <= 160 * 1024 ? 2 : 1;
 }
 
 extern "C" int tt_enc_last_fwd(const float* x, int64_t B, int64_t H, int64_t D, int64_t heads, const float* w_in,
-                               const float* b_in, const float* w_out, const float* b_out, float* recent,
-                               int64_t ld_recent, float* q0, float* t, float* probs, float* xbar, float* ctx0,
-                               tt_stream_t stream) {
+                               const float* b_in, const float* w_out, const float* b_out, const float* w_prev_out,
+                               const float* b_prev_out, float* recent, int64_t ld_recent, float* q0, float* t, float* probs,
+                               float* xbar, float* ctx0, float* tp, float* cbar, float* x0, tt_stream_t stream) {
+  const bool prev = w_prev_out != nullptr;
   if (!x || !w_in || !b_in || !w_out || !b_out || !recent || !q0 || !t || !probs || !xbar || !ctx0)
     return fail_arg("tt_enc_last_fwd: null pointer");
+  if (prev && (!b_prev_out || !tp || !cbar || !x0)) return fail_arg("tt_enc_last_fwd: w_prev_out needs b_prev_out, tp, cbar, x0");
+  if (prev && tt_enc_last_supported(H, D, heads) < 2) {
+    set_error("tt_enc_last_fwd: the folded previous out-projection does not fit the LDS at heads = %lld, D = %lld", (long long)heads, (long long)D);
+    return TT_E_UNSUPPORTED;
+  }
   if (B < 0 || !tt_enc_last_supported(H, D, heads) || ld_recent < D) {
     set_error("tt_enc_last_fwd: shape outside H <= 64, D <= 128, D %% 4 == 0, head width %% 4 == 0 (H = %lld, D = %lld, heads = %lld)",
               (long long)H, (long long)D, (long long)heads);
     return TT_E_UNSUPPORTED;
   }
-  if (!el_aligned(x) || !el_aligned(w_in) || !el_aligned(w_out) || !el_aligned(t) || !el_aligned(xbar))
-    return fail_arg("tt_enc_last_fwd: x, w_in, w_out, t, xbar must be 16-byte aligned");
+  if (!el_aligned(x) || !el_aligned(w_in) || !el_aligned(w_out) || !el_aligned(t) || !el_aligned(xbar) || !el_aligned(w_prev_out) ||
+      !el_aligned(tp) || !el_aligned(cbar))
+    return fail_arg("tt_enc_last_fwd: x, w_in, w_out, w_prev_out, t, tp, xbar, cbar must be 16-byte aligned");
   if (B == 0) return 0;
   hipStream_t st = S(stream);
   const unsigned G = (unsigned)el_groups(B);
-  const size_t lds32 = (size_t)EL_ROWS * (D + 4) * sizeof(float);
+  ElArgs a{};
+  a.x = x; a.w_in = w_in; a.b_in = b_in; a.w_out = w_out; a.b_out = b_out; a.w_pa = w_prev_out; a.b_pa = b_prev_out;
+  a.B = B; a.H = (int)H; a.D = (int)D; a.heads = (int)heads;
+  a.q0 = q0; a.t = t; a.tp = tp; a.cbar = cbar; a.xbar = xbar; a.ctx0 = ctx0; a.x0 = x0;
+  a.recent = recent; a.ld_recent = ld_recent;
   int rc;
-  enc_last_pre_kernel<<<G, 256, lds32, st>>>(x, B, (int)H, (int)D, (int)heads, w_in, b_in, q0, t);
-  if ((rc = check_launch("enc_last_pre_kernel"))) return rc;
+  {
+    const size_t lds = el_small_lds(D, heads, prev, 2);
+    if (prev) {
+      if ((rc = el_opt_in(enc_last_pre_kernel<true>, lds, "enc_last_pre_kernel"))) return rc;
+      enc_last_pre_kernel<true><<<G, 256, lds, st>>>(a);
+    } else {
+      enc_last_pre_kernel<false><<<G, 256, lds, st>>>(a);
+    }
+    if ((rc = check_launch("enc_last_pre_kernel"))) return rc;
+  }
   {
     const size_t lds = ((size_t)H * (D + 4) + heads * D) * sizeof(float);
     if ((rc = el_opt_in(enc_last_main_fwd_kernel, lds, "enc_last_main_fwd_kernel"))) return rc;
     ProfScope prof("enc_last_main_fwd_kernel", st);
-    enc_last_main_fwd_kernel<<<(unsigned)B, 256, lds, st>>>(x, (int)H, (int)D, (int)heads, t, probs, xbar);
+    enc_last_main_fwd_kernel<<<(unsigned)B, 256, lds, st>>>(x, (int)H, (int)D, (int)heads, prev ? tp : t, probs, prev ? cbar : xbar);
     if ((rc = check_launch("enc_last_main_fwd_kernel"))) return rc;
   }
-  enc_last_post_kernel<<<G, 256, lds32, st>>>(xbar, B, (int)D, (int)heads, w_in, b_in, w_out, b_out, ctx0, recent, ld_recent);
+  {
+    const size_t lds = el_small_lds(D, heads, prev, 1);
+    if (prev) {
+      if ((rc = el_opt_in(enc_last_post_kernel<true>, lds, "enc_last_post_kernel"))) return rc;
+      enc_last_post_kernel<true><<<G, 256, lds, st>>>(a);
+    } else {
+      enc_last_post_kernel<false><<<G, 256, lds, st>>>(a);
+    }
+  }
   return check_launch("enc_last_post_kernel");
 }
 
@@ -539,53 +777,88 @@ extern "C" int64_t tt_enc_last_bwd_workspace_bytes(int64_t B, int64_t H, int64_t
   if (B <= 0 || !tt_enc_last_supported(H, D, heads)) return 0;
   const int64_t G = el_groups(B);
   // d_xbar [B, heads, D] | dt [B, heads, D] | partials a | partials b
-  return round_up(B * heads * D * 4, 256) * 2 + round_up(G * (2 * D * D + 2 * D) * 4, 256) + round_up(G * (2 * D * D + D) * 4, 256);
+  return round_up(B * heads * D * 4, 256) * 2 + round_up(G * el_part_a(D) * 4, 256) + round_up(G * el_part_b(D) * 4, 256);
 }
 
 extern "C" int tt_enc_last_bwd(const float* x, int64_t B, int64_t H, int64_t D, int64_t heads, const float* w_in,
-                               const float* w_out, const float* d_recent, int64_t ld_dr, const float* q0, const float* t,
-                               const float* probs, const float* xbar, const float* ctx0, float* dx, float* dW_in,
-                               float* db_in, float* dW_out, float* db_out, void* ws, int64_t ws_bytes,
-                               tt_stream_t stream) {
+                               const float* w_out, const float* w_prev_out, const float* d_recent, int64_t ld_dr,
+                               const float* q0, const float* t, const float* probs, const float* xbar, const float* ctx0,
+                               const float* tp, const float* cbar, const float* x0, float* dx, float* dW_in, float* db_in,
+                               float* dW_out, float* db_out, float* dW_prev_out, float* db_prev_out, void* ws,
+                               int64_t ws_bytes, tt_stream_t stream) {
+  const bool prev = w_prev_out != nullptr;
   if (!x || !w_in || !w_out || !d_recent || !q0 || !t || !probs || !xbar || !ctx0 || !dx || !dW_in || !db_in || !dW_out ||
       !db_out)
     return fail_arg("tt_enc_last_bwd: null pointer");
+  if (prev && (!tp || !cbar || !x0 || !dW_prev_out || !db_prev_out))
+    return fail_arg("tt_enc_last_bwd: w_prev_out needs tp, cbar, x0, dW_prev_out, db_prev_out");
+  if (prev && tt_enc_last_supported(H, D, heads) < 2) {
+    set_error("tt_enc_last_bwd: the folded previous out-projection does not fit the LDS at heads = %lld, D = %lld", (long long)heads, (long long)D);
+    return TT_E_UNSUPPORTED;
+  }
   if (B < 0 || !tt_enc_last_supported(H, D, heads) || ld_dr < D) {
     set_error("tt_enc_last_bwd: shape outside H <= 64, D <= 128, D %% 4 == 0, head width %% 4 == 0");
     return TT_E_UNSUPPORTED;
   }
   if (!el_aligned(x) || !el_aligned(w_in) || !el_aligned(w_out) || !el_aligned(t) || !el_aligned(xbar) || !el_aligned(dx) ||
-      !el_aligned(ws) || !el_aligned(d_recent) || (ld_dr % 4) != 0)
-    return fail_arg("tt_enc_last_bwd: x, dx, w_in, w_out, t, xbar, d_recent, ws must be 16-byte aligned, ld_dr % 4 == 0");
+      !el_aligned(ws) || !el_aligned(d_recent) || (ld_dr % 4) != 0 || !el_aligned(w_prev_out) || !el_aligned(tp) || !el_aligned(cbar))
+    return fail_arg("tt_enc_last_bwd: x, dx, w_in, w_out, w_prev_out, t, tp, xbar, cbar, d_recent, ws must be 16-byte aligned, ld_dr % 4 == 0");
   hipStream_t st = S(stream);
   if (B == 0) {
     (void)hipMemsetAsync(dW_in, 0, sizeof(float) * 3 * D * D, st);
     (void)hipMemsetAsync(db_in, 0, sizeof(float) * 3 * D, st);
     (void)hipMemsetAsync(dW_out, 0, sizeof(float) * D * D, st);
     (void)hipMemsetAsync(db_out, 0, sizeof(float) * D, st);
+    if (prev) {
+      (void)hipMemsetAsync(dW_prev_out, 0, sizeof(float) * D * D, st);
+      (void)hipMemsetAsync(db_prev_out, 0, sizeof(float) * D, st);
+    }
     return 0;
   }
   if (!ws || ws_bytes < tt_enc_last_bwd_workspace_bytes(B, H, D, heads)) return fail_arg("tt_enc_last_bwd: workspace too small");
   const int64_t G = el_groups(B);
   Carver cv(ws);
-  float* d_xbar = cv.take<float>(B * heads * D);
-  float* dt = cv.take<float>(B * heads * D);
-  float* part_a = cv.take<float>(G * (2 * D * D + 2 * D));
-  float* part_b = cv.take<float>(G * (2 * D * D + D));
-  const size_t lds32 = (size_t)EL_ROWS * (D + 4) * sizeof(float);
+  ElArgs a{};
+  a.x = x; a.w_in = w_in; a.w_out = w_out; a.w_pa = w_prev_out;
+  a.B = B; a.H = (int)H; a.D = (int)D; a.heads = (int)heads;
+  a.q0 = const_cast<float*>(q0); a.t = const_cast<float*>(t); a.tp = const_cast<float*>(tp); a.cbar = const_cast<float*>(cbar);
+  a.xbar = const_cast<float*>(xbar); a.ctx0 = const_cast<float*>(ctx0); a.x0 = const_cast<float*>(x0);
+  a.d_recent = d_recent; a.ld_dr = ld_dr;
+  a.d_xbar = cv.take<float>(B * heads * D);
+  a.dt = cv.take<float>(B * heads * D);
+  a.part_a = cv.take<float>(G * el_part_a(D));
+  a.part_b = cv.take<float>(G * el_part_b(D));
+  a.dx = dx;
   int rc;
-  enc_last_bwd_a_kernel<<<(unsigned)G, 256, lds32, st>>>(d_recent, ld_dr, B, (int)D, (int)heads, w_in, w_out, ctx0, xbar, d_xbar, part_a);
-  if ((rc = check_launch("enc_last_bwd_a_kernel"))) return rc;
+  {
+    const size_t lds = el_small_lds(D, heads, prev, 1);
+    if (prev) {
+      if ((rc = el_opt_in(enc_last_bwd_a_kernel<true>, lds, "enc_last_bwd_a_kernel"))) return rc;
+      enc_last_bwd_a_kernel<true><<<(unsigned)G, 256, lds, st>>>(a);
+    } else {
+      enc_last_bwd_a_kernel<false><<<(unsigned)G, 256, lds, st>>>(a);
+    }
+    if ((rc = check_launch("enc_last_bwd_a_kernel"))) return rc;
+  }
   {
     const size_t lds = ((size_t)H * (D + 4) + 2 * heads * D + 2 * heads * 64) * sizeof(float);
     if ((rc = el_opt_in(enc_last_main_bwd_kernel, lds, "enc_last_main_bwd_kernel"))) return rc;
     ProfScope prof("enc_last_main_bwd_kernel", st);
-    enc_last_main_bwd_kernel<<<(unsigned)B, 256, lds, st>>>(x, (int)H, (int)D, (int)heads, t, probs, d_xbar, dt, dx);
+    enc_last_main_bwd_kernel<<<(unsigned)B, 256, lds, st>>>(x, (int)H, (int)D, (int)heads, prev ? tp : t, probs, a.d_xbar, a.dt, dx);
     if ((rc = check_launch("enc_last_main_bwd_kernel"))) return rc;
   }
-  enc_last_bwd_b_kernel<<<(unsigned)G, 256, lds32, st>>>(x, B, (int)H, (int)D, (int)heads, w_in, q0, dt, dx, part_b);
-  if ((rc = check_launch("enc_last_bwd_b_kernel"))) return rc;
-  const int total = (int)(4 * D * D + 3 * D);
-  enc_last_reduce_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(part_a, (int)G, part_b, (int)G, (int)D, dW_in, db_in, dW_out, db_out);
+  {
+    const size_t lds = el_small_lds(D, heads, prev, 2);
+    if (prev) {
+      if ((rc = el_opt_in(enc_last_bwd_b_kernel<true>, lds, "enc_last_bwd_b_kernel"))) return rc;
+      enc_last_bwd_b_kernel<true><<<(unsigned)G, 256, lds, st>>>(a);
+    } else {
+      enc_last_bwd_b_kernel<false><<<(unsigned)G, 256, lds, st>>>(a);
+    }
+    if ((rc = check_launch("enc_last_bwd_b_kernel"))) return rc;
+  }
+  const int total = (int)(5 * D * D + 4 * D);
+  enc_last_reduce_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(a.part_a, a.part_b, (int)G, (int)D, dW_in, db_in, dW_out, db_out,
+                                                                     prev ? dW_prev_out : nullptr, prev ? db_prev_out : nullptr);
   return check_launch("enc_last_reduce_kernel");
 }

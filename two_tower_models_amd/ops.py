@@ -550,6 +550,7 @@ _ENC_LAST_COLLAPSED = os.environ.get("TT_ENC_NO_COLLAPSED_LAST") is None  # last
 # whole-layer forward in one launch (encoder_layer.hip): measured round 4 -- 440 us per layer alone against 375-390 us for
 # the three launches it replaces (one wave per SIMD, rows padded 50 -> 64), and no better next to the sweep; opt-in
 _ENC_FUSED_FWD = os.environ.get("TT_ENC_FUSED_FWD") is not None
+_ENC_COLLAPSE_PREV = os.environ.get("TT_ENC_NO_COLLAPSED_PREV") is None  # second-to-last layer's out-projection folded into the last
 
 
 def kept_logits_supported(U: torch.Tensor, I: torch.Tensor) -> bool:
@@ -853,6 +854,7 @@ class HistoryEncoder(_LookupFunction):
         row0_last = L > 0 and H <= 64 and D // heads <= 64 and _ROW0_LAST
         collapsed_last = (row0_last and _ENC_LAST_COLLAPSED and bool(lib.tt_enc_last_supported(H, D, heads))
                           and x.data_ptr() % 16 == 0)
+        collapse_prev = collapsed_last and L >= 2 and _ENC_COLLAPSE_PREV and lib.tt_enc_last_supported(H, D, heads) >= 2
         fused_layer = (_ENC_FUSED_FWD and L > 0 and bool(lib.tt_enc_layer_fwd_supported(H, D, heads))
                        and x.data_ptr() % 16 == 0)
         dh = D // max(heads, 1)
@@ -871,11 +873,19 @@ class HistoryEncoder(_LookupFunction):
                 xbar = torch.empty(B, heads, D, dtype=torch.float32, device=dev)
                 ctx0 = torch.empty(B, D, dtype=torch.float32, device=dev)
                 w_in_c, w_out_c = w_in.contiguous(), w_out.contiguous()
+                extra = []
+                w_pa = b_pa = None
+                if collapse_prev:  # x is the previous layer's CONTEXT; its out-projection folds into this layer
+                    w_pa, b_pa = layer_params[4 * (l - 1) + 2].contiguous(), layer_params[4 * (l - 1) + 3].contiguous()
+                    extra = [torch.empty(B, heads, D, dtype=torch.float32, device=dev),  # tp
+                             torch.empty(B, heads, D, dtype=torch.float32, device=dev),  # cbar
+                             torch.empty(B, D, dtype=torch.float32, device=dev)]         # x0
                 N.check(lib.tt_enc_last_fwd(x.data_ptr(), B, H, D, heads, w_in_c.data_ptr(), b_in.contiguous().data_ptr(),
-                                            w_out_c.data_ptr(), b_out.contiguous().data_ptr(), out.data_ptr(), 2 * D,
-                                            q0.data_ptr(), tq.data_ptr(), probs.data_ptr(), xbar.data_ptr(), ctx0.data_ptr(),
+                                            w_out_c.data_ptr(), b_out.contiguous().data_ptr(), N.ptr(w_pa), N.ptr(b_pa),
+                                            out.data_ptr(), 2 * D, q0.data_ptr(), tq.data_ptr(), probs.data_ptr(),
+                                            xbar.data_ptr(), ctx0.data_ptr(), *(N.ptr(e) for e in (extra or [None] * 3)),
                                             N.stream()), "tt_enc_last_fwd")
-                saved += [x, q0, tq, probs, xbar, ctx0]
+                saved += [x, q0, tq, probs, xbar, ctx0] + extra
                 continue
             if l == L - 1 and row0_last:
                 # the last layer is consumed at row 0 only: K, V for every position, Q for position 0,
@@ -912,7 +922,9 @@ class HistoryEncoder(_LookupFunction):
             gemm(N.TT_GEMM_NT, x, w_in, qkv, B * H, 3 * D, D, bias=b_in)
             ctx_t, lse = _attn_fwd(qkv, B, H, D, heads)
             saved += [x, qkv, ctx_t, lse]
-            if l + 1 < L:
+            if l + 2 == L and collapse_prev:
+                x = ctx_t  # no out-projection here: the last layer takes the context (csrc/encoder_last.hip, PREV)
+            elif l + 1 < L:
                 x = torch.empty(B * H, D, dtype=torch.float32, device=dev)
                 gemm(N.TT_GEMM_NT, ctx_t, w_out, x, B * H, D, D, bias=b_out)
             else:  # rows b*H + 0 only, straight into out[:, 0, :]
@@ -922,6 +934,7 @@ class HistoryEncoder(_LookupFunction):
         ctx.dims = (B, H, D, L, heads)
         ctx.row0_last = row0_last
         ctx.collapsed_last = collapsed_last
+        ctx.collapse_prev = collapse_prev
         ctx.table = source if ids is not None else None
         ctx.has_ids = ids is not None
         ctx.save_for_backward(ids, *layer_params, *saved)
@@ -940,10 +953,17 @@ class HistoryEncoder(_LookupFunction):
         d_recent, d_pooled = d_out[:, 0, :], d_out[:, 1, :]
         grads: List[Optional[torch.Tensor]] = [None] * (4 * L)
         dx = None  # gradient wrt the current layer's OUTPUT x_{l+1}, [B*H, D]
+        prev_out_grads = None
         for l in reversed(range(L)):
             w_in, b_in, w_out, b_out = layer_params[4 * l: 4 * l + 4]
             if l == L - 1 and ctx.collapsed_last:
                 x, q0, tq, probs, xbar, ctx0 = saved[4 * l: 4 * l + 6]
+                tp = cbar = x0 = w_pa = dW_pa = db_pa = None
+                if ctx.collapse_prev:
+                    tp, cbar, x0 = saved[4 * l + 6: 4 * l + 9]
+                    w_pa = layer_params[4 * (l - 1) + 2].contiguous()
+                    dW_pa = torch.empty(D, D, dtype=torch.float32, device=dev)
+                    db_pa = torch.empty(D, dtype=torch.float32, device=dev)
                 dx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
                 dW_in = torch.empty(3 * D, D, dtype=torch.float32, device=dev)
                 db_in = torch.empty(3 * D, dtype=torch.float32, device=dev)
@@ -951,11 +971,13 @@ class HistoryEncoder(_LookupFunction):
                 db_out = torch.empty(D, dtype=torch.float32, device=dev)
                 wsp, wsn = _ws(dev, lib.tt_enc_last_bwd_workspace_bytes(B, H, D, heads), "enc_last")
                 N.check(lib.tt_enc_last_bwd(x.data_ptr(), B, H, D, heads, w_in.contiguous().data_ptr(),
-                                            w_out.contiguous().data_ptr(), d_recent.data_ptr(), 2 * D, q0.data_ptr(),
-                                            tq.data_ptr(), probs.data_ptr(), xbar.data_ptr(), ctx0.data_ptr(), dx.data_ptr(),
-                                            dW_in.data_ptr(), db_in.data_ptr(), dW_out.data_ptr(), db_out.data_ptr(),
+                                            w_out.contiguous().data_ptr(), N.ptr(w_pa), d_recent.data_ptr(), 2 * D,
+                                            q0.data_ptr(), tq.data_ptr(), probs.data_ptr(), xbar.data_ptr(), ctx0.data_ptr(),
+                                            N.ptr(tp), N.ptr(cbar), N.ptr(x0), dx.data_ptr(), dW_in.data_ptr(),
+                                            db_in.data_ptr(), dW_out.data_ptr(), db_out.data_ptr(), N.ptr(dW_pa), N.ptr(db_pa),
                                             wsp, wsn, N.stream()), "tt_enc_last_bwd")
                 grads[4 * l: 4 * l + 4] = [dW_in, db_in, dW_out, db_out]
+                prev_out_grads = (dW_pa, db_pa)  # dx is then the gradient of the previous layer's CONTEXT
                 continue
             if l == L - 1 and ctx.row0_last:
                 x, kv, q0, ctx0, probs = saved[4 * l: 4 * l + 5]
@@ -980,7 +1002,10 @@ class HistoryEncoder(_LookupFunction):
                 continue
             x, qkv, ctx_t, lse = saved[4 * l: 4 * l + 4]
             dW_out = torch.empty(D, D, dtype=torch.float32, device=dev)
-            if l == L - 1:
+            if l == L - 2 and ctx.collapse_prev:
+                dW_out, db_out = prev_out_grads
+                d_ctx = dx
+            elif l == L - 1:
                 rows0 = ctx_t.view(B, H * D)[:, :D]
                 _, db_out = gemm_tn_colsum(d_recent, rows0, dW_out)
                 d_ctx = torch.zeros(B * H, D, dtype=torch.float32, device=dev)
