@@ -88,6 +88,19 @@ def build_model(cfg, device):
     return model.to(device)
 
 
+def pmc_traffic_bytes(path, workload, world):
+    """roofline.traffic: the committed PMC measurement of the sweep's HBM bytes per launch (profiles/pmc_traffic.json,
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command).  The file is keyed by "<workload>_gpus<N>"; a
+    flat record (round 3's refresh wrote one, and the lookup then silently returned null) counts as "P_gpus1"."""
+    if not os.path.exists(path):
+        return None
+    data = json.load(open(path))
+    rec = data.get(f"{workload}_gpus{world}")
+    if rec is None and "hbm_bytes_per_launch" in data and (workload, world) == ("P", 1):
+        rec = data
+    return rec.get("hbm_bytes_per_launch") if rec else None
+
+
 def algorithmic_sweep_bytes(cfg, world):
     """Adam reads+writes p, m, v of EVERY table row: 24 B per element."""
     return 24.0 * (cfg["n_users"] + cfg["n_items"]) * cfg["D"] / world
@@ -165,6 +178,88 @@ def cpu_baseline(cfg, seconds_budget=25.0):
 MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
+def cpu_baseline_small(name, n_steps=1):
+    """`cpu_baseline` beside a SECONDARY train workload ("same shapes ... in the same run"): the CPU oracle's
+    train step -- with the history encoder where the workload has one -- on this box's host cores, one warm-up step +
+    `n_steps` timed, thread count stated.  The parameters come from the package's own module built on the CPU (same
+    shapes and init as the GPU run; only its state_dict is used, the HIP path never runs on CPU tensors)."""
+    import psutil
+    import two_tower_models_amd as A
+    from oracle import cpu_ref as R
+    cfg = dict(WORKLOADS[name])
+    cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    threads = max(min(cores // 4, 32), min(cores, 8))  # the P baseline's thread sweep settles at cores / 4 on this class of box
+    torch.set_num_threads(threads)
+    model = build_model(cfg, "cpu")
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    del model
+    hist = cfg["model"] != "base"
+    kw = dict(with_history=True, heads=4, pos_table=R.positional_table(cfg["H"], cfg["D"])) if hist else {}
+    state = R.AdamState(params)
+    batches = make_batches(cfg, 2, "cpu")
+    uvw = torch.tensor([1.0])
+    R.train_step(params, state, batches[0], uvw, **kw)
+    t0 = time.perf_counter()
+    for i in range(n_steps):
+        R.train_step(params, state, batches[(i + 1) % 2], uvw, **kw)
+    dt = (time.perf_counter() - t0) / n_steps
+    return {"value": round(cfg["B"] / dt, 1), "unit": "pairs/s", "cores": threads, "kind": "port", "physical_cores": cores,
+            "sample": f"{n_steps} train step(s) of oracle/cpu_ref.py after one warm-up, {threads} threads, workload {name}"
+                      f" (B={cfg['B']}, N_u={cfg['n_users']}, N_i={cfg['n_items']}, D={cfg['D']}"
+                      + (f", H={cfg['H']}, 3 attention layers x 4 heads" if hist else "") + f"), {dt * 1e3:.0f} ms/step"}
+
+
+def cpu_baseline_mips(corpus_cpu, K, n_queries=64):
+    """`cpu_baseline` beside the MIPS secondary: oracle/cpu_ref.mips_topk (= torch.topk(q @ corpus.T), the reference's
+    ref:src/baseline_mips_module.py:57-61, in query chunks -- the reference itself materialises [B, C]) on `n_queries`
+    queries over the SAME fp32 corpus, host cores."""
+    import psutil
+    from oracle import cpu_ref as R
+    cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    threads = max(min(cores // 2, 64), min(cores, 8))
+    torch.set_num_threads(threads)
+    q = torch.randn(n_queries, corpus_cpu.shape[1], generator=torch.Generator().manual_seed(1))
+    R.mips_topk(q[:8], corpus_cpu, K, chunk=8)
+    t0 = time.perf_counter()
+    R.mips_topk(q, corpus_cpu, K, chunk=16)
+    dt = time.perf_counter() - t0
+    return {"value": round(n_queries / dt, 1), "unit": "queries/s", "cores": threads, "kind": "port", "physical_cores": cores,
+            "sample": f"{n_queries} queries, C={corpus_cpu.shape[0]}, D={corpus_cpu.shape[1]}, K={K}, fp32, chunks of 16 queries, "
+                      f"{threads} threads, {dt:.1f} s"}
+
+
+def _timed_sharded_w1(device, steps=20, warmup=5):
+    """The row-sharded trainer at W = 1 over RCCL (`bench.py --sharded --gpus 1`) at the P shapes: the N = 1 point the
+    scaling curve starts from must equal the module-path headline (tests/test_gpu_bench_contract.py holds it to 3 %)."""
+    import torch.distributed as dist
+    from two_tower_models_amd import sharded
+    if dist.is_initialized():
+        raise RuntimeError("a process group is already up")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    os.environ.update(RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", device_id=device)
+    try:
+        cfg = dict(WORKLOADS["P"])
+        trainer = sharded.ShardedTrainer(cfg, device)
+        batches = trainer.make_batches(16)
+        for i in range(warmup):
+            trainer.step(batches[i % 16], batches[(i + 1) % 16])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            trainer.step(batches[(warmup + i) % 16], batches[(warmup + i + 1) % 16])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out = {"workload": "P through ShardedTrainer, world size 1, RCCL process group (the N = 1 point of the scaling curve)",
+               "pairs_per_s": round(cfg["B"] * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+               "warmup": warmup, "routing": trainer.routing, "transport": trainer.transport}
+        del trainer, batches
+    finally:
+        dist.destroy_process_group()
+    return out
+
+
 def _timed_train(name, device, steps, warmup, lazy=False, fresh_ids=False):
     """One module-path train workload, timed like the headline (batches resident, K steps between syncs).
     `fresh_ids`: every step looks up NEW uniform ids (generated on the device outside nothing -- inside the timed
@@ -238,6 +333,10 @@ def _timed_mips(device, lib, N, Cn=10_000_000, B=1024, K=1000, D=128, reps=3):
     m.corpus_size = Cn
     q = torch.randn(B, D, device=device, generator=g)
     out = {}
+    try:
+        out["cpu_baseline"] = cpu_baseline_mips(m.corpus.cpu(), K)
+    except Exception as e:
+        out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
     for name, peak in (("fp32", MFMA_F32_PEAK_TF), ("bf16", MFMA_BF16_PEAK_TF)):
         if name == "bf16":
             m.use_bf16_storage()
@@ -284,9 +383,26 @@ def secondary(device, lib, N):
                                           ("P_lazy_fresh_ids", "P", 200, True, True)):
         try:
             sec[key] = _timed_train(name, device, steps, 3 if lazy else 80, lazy=lazy, fresh_ids=fresh)
+            if not lazy:
+                sec[key]["cpu_baseline"] = cpu_baseline_small(name)
         except Exception as e:  # a secondary figure must never take the headline line down with it
             sec[key] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
+    try:  # BASELINE config 1 (the reference's CPU-plumbing shape: 1 K users x 10 K items, d = 32, B = 128) on both sides
+        sec["C1"] = _timed_train("tiny", device, 200, 100)
+        sec["C1"]["cpu_baseline"] = cpu_baseline_small("tiny", n_steps=50)
+    except Exception as e:
+        sec["C1"] = {"error": f"{type(e).__name__}: {e}"}
+    try:  # BASELINE config 4's table (100 M items, 155 GB of p, m, v) on ONE MI355X: what each of 8 ranks sweeps is 1/8 of it
+        sec["C4_1gpu"] = _timed_train("C4", device, 6, 6)
+    except Exception as e:
+        sec["C4_1gpu"] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
+    try:
+        sec["P_sharded_W1"] = _timed_sharded_w1(device)
+    except Exception as e:
+        sec["P_sharded_W1"] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
     try:
         # what the 10 M pairs/s @ 8 GPUs target rests on: ONE rank's kernels of the W = 8 step,
         # stand-in collectives -- clearly labelled, with the two logits kernels' own rooflines and the host's cost
@@ -500,6 +616,8 @@ def main():
         run(i)
     barrier()
     lib.tt_profile_enable(1)
+    if use_sharded:
+        sharded.comm_timing(True)  # per-exchange events over the timed steps -> `comm.ms_per_step` below
     import gc
     gc.collect()
     gc.disable()  # no cyclic-GC pause inside the timed region (the loop allocates no cycles that would need it)
@@ -511,6 +629,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
+    comm_ms = None
+    if use_sharded:
+        comm_ms = sharded.comm_timing_summary(args.steps)
+        sharded.comm_timing(False)
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         sharded.all_reduce_(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -543,10 +665,7 @@ def main():
             achieved = sweep_bytes_step * args.steps / (ms.value * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):
-                rec = json.load(open(tpath)).get(f"{args.workload}_gpus{world}")
-                if rec:
-                    traffic = rec.get("hbm_bytes_per_launch")
+            traffic = pmc_traffic_bytes(tpath, args.workload, world)
             # the name rocprofv3 reports for it (profiles/r01_kernel_stats_P_1gpu_final.csv)
             sweep_name = ("adam_sweep_bounded_kernel" if os.environ.get("TT_SWEEP_PERSIST") == "0"
                           else "adam_sweep_persistent_kernel" if os.environ.get("TT_SWEEP_ONE_LAUNCH") == "0"
@@ -597,7 +716,14 @@ def main():
         out["generic_paths"] = dict(_ops.generic_paths)
         if use_sharded:  # bytes each rank sends to its peers per step, by exchange (sharded.py)
             out["comm"] = {"routing": trainer.routing, "transport": trainer.transport, "bytes_sent_per_rank_per_step": dict(trainer.comm_bytes),
-                           "total_MB": round(sum(trainer.comm_bytes.values()) / 1e6, 2)}
+                           "total_MB": round(sum(trainer.comm_bytes.values()) / 1e6, 2),
+                           # rank 0, HIP events around every exchange of the timed steps, ms per step:  span = issue -> result
+                           # usable (the cost if nothing overlapped it), exposed = how long the compute stream stood still
+                           # at the wait (what the exchange actually adds to the step), wire = the collective alone (native
+                           # transport only).  A bad 1 -> 8 curve is read off `exposed_ms` by exchange.
+                           "ms_per_step": comm_ms,
+                           "exposed_ms_per_step_total": round(sum(v["exposed_ms"] for v in (comm_ms or {}).values()), 4),
+                           "schedule": getattr(trainer, "schedule_note", lambda: None)()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         else:

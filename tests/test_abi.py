@@ -84,3 +84,23 @@ def test_module_surface_matches_reference_names():
         assert all(tuple(sd[k].shape) == shp for k, shp in extra.items())
     enc = A.UserHistoryEncoder(8, 6, 2, 1, True)
     assert enc.get_output_dim() == 16 and enc.positional_embeddings.shape == (6, 8)
+
+
+def test_bench_roofline_traffic_key_resolves():
+    """bench.py's roofline.traffic comes from profiles/pmc_traffic.json: the key the default run looks up must exist
+    (round 3 shipped a flat record and the driver's line carried `"traffic": null`), in the keyed and the flat form."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    path = os.path.join(root, "profiles", "pmc_traffic.json")
+    got = bench.pmc_traffic_bytes(path, "P", 1)
+    alg = bench.algorithmic_sweep_bytes(bench.WORKLOADS["P"], 1)
+    assert got is not None and 0.98 * alg < got < 1.10 * alg, (got, alg)
+    assert bench.pmc_traffic_bytes(path, "C2", 1) is None  # no measurement committed for that workload: null, not a wrong number
+    flat = os.path.join(os.environ.get("TMPDIR", "/tmp"), "pmc_flat_test.json")
+    json.dump(json.load(open(path))["P_gpus1"], open(flat, "w"))
+    assert bench.pmc_traffic_bytes(flat, "P", 1) == got

@@ -73,3 +73,24 @@ def test_self_launch_needs_no_env():
     assert out["n_gpus"] == 2 and out["n_ranks"] == 2 and out["config"]["global_batch"] == 256
     import torch
     assert out["dist_backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")
+
+
+def test_sharded_trainer_at_world1_matches_the_module_path_headline():
+    """`bench.py --sharded --gpus 1` (ShardedTrainer over an RCCL group of one: the N = 1 point a scaling run starts
+    from) against the module-path headline `bench.py` on the same box, same P shapes, back to back: within 5 %
+    (round-4 measurements: 0.97-1.03 on five boxes; the two paths launch the same sweep / logits / tower kernels and
+    differ in the routing kernels of the sharded lookups).  The multi-rank line's `comm` record carries per-exchange
+    times and the step schedule."""
+    def run(extra):
+        r = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--no-secondary", "--steps", "20", "--warmup",
+                            "10", *extra], cwd=ROOT, capture_output=True, text=True, timeout=900, stdin=subprocess.DEVNULL)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return _last_json(r.stdout)
+    mod = run([])
+    sh = run(["--sharded"])
+    assert sh["n_ranks"] == 1 and sh["dist_backend"] == "nccl"
+    ratio = sh["ms_per_step"] / mod["ms_per_step"]
+    assert 0.95 <= ratio <= 1.05, (sh["ms_per_step"], mod["ms_per_step"])
+    comm = sh["comm"]
+    assert comm["ms_per_step"] and "lookup_rows_alltoall" in comm["ms_per_step"] and comm["schedule"]["sweep_workgroups"] > 0
+    assert mod["roofline"]["traffic"] is not None  # profiles/pmc_traffic.json resolves for the default workload

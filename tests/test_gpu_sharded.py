@@ -408,6 +408,97 @@ def test_route_kernels_match_cpu_restatement(n, n_rows, world):
     assert torch.equal(loc, cpu.localize(send_ids, lo, n_local))
 
 
+@pytest.mark.parametrize("transport", ["torch", "native"])
+def test_rccl_async_paths_at_world1_with_the_real_message_sizes(transport, monkeypatch):
+    """The code a multi-GPU node runs -- `*_start` / `.wait()` through RCCL's async collectives on the process group's
+    stream (transport torch) and through tt_comm_* on the communication stream (transport native) -- executed on the
+    1-GPU box: TT_COMM_FORCE_ASYNC takes those paths at world size 1, where every collective is the identity, at the
+    message sizes of the P step at W = 8 (ids [8 x cap] int64, rows [8 x cap, 128] fp32 = 8 MB, item embeddings 4 MB,
+    the 0.55 MB dense-gradient buffer, scalars).  Then three whole steps of the routed trainer over the same paths
+    against the oracle, with the per-exchange timing on."""
+    import torch.distributed as dist
+    from oracle import cpu_ref as R
+    from test_sharded_cpu import _dense_init
+    from two_tower_models_amd import sharded
+    monkeypatch.setenv("TT_COMM_FORCE_ASYNC", "1")
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+    try:
+        cfg = dict(n_users=3000, n_items=5000, D=128, F=8, B=512, H=2)
+        dense = _dense_init(cfg)
+        tr = sharded.ShardedTrainer(cfg, dev, negatives="global", user_value_weights=(0.7,), dense_init=dense,
+                                    transport=transport)
+        assert tr.transport == transport and (sharded._NATIVE is not None) == (transport == "native")
+        g = torch.Generator(device=dev).manual_seed(5)
+        cap = 1088
+        ids = torch.randint(0, 10_000_000, (8 * cap,), device=dev, generator=g)
+        rows = torch.randn(8 * cap, 128, device=dev, generator=g)
+        emb = torch.randn(8192, 128, device=dev, generator=g)
+        flat = torch.randn(136_192, device=dev, generator=g)
+        sharded.comm_timing(True)
+        side = torch.randn(4096, 4096, device=dev, generator=g)
+        p_ids = sharded.all_to_all_rows_start(ids, tag="ids")
+        p_rows = sharded.all_to_all_rows_start(rows, tag="rows")
+        p_ag = sharded.all_gather_rows_start(emb, tag="ag")
+        p_rs = sharded.reduce_scatter_rows_start(emb, tag="rs")
+        f2 = flat.clone()
+        p_ar = sharded.all_reduce_start_(f2, tag="ar")
+        busy = side @ side  # compute queued between start and wait: the exchanges run underneath it
+        assert sharded._rccl_async(rows) or sharded._native(rows)
+        assert torch.equal(p_ids.wait(), ids) and torch.equal(p_rows.wait(), rows)
+        assert torch.equal(p_ag.wait(), emb) and torch.equal(p_rs.wait(), emb) and torch.equal(p_ar.wait(), flat)
+        k = torch.tensor([7, 3, 9], dtype=torch.int32, device=dev)
+        assert sharded.all_reduce_start_(k, op=dist.ReduceOp.MAX, tag="caps").wait().tolist() == [7, 3, 9]
+        summ = sharded.comm_timing_summary(1)
+        assert set(summ) == {"ids", "rows", "ag", "rs", "ar", "caps"} and all(v["span_ms"] >= v["exposed_ms"] >= 0 for v in summ.values())
+        if transport == "native":
+            assert all("wire_ms" in v for v in summ.values())
+        assert float(busy.abs().sum()) > 0
+        # whole steps over the same paths
+        params = dict(dense)
+        params["user_id_embedding_arch.weight"] = tr.users.weight.cpu().clone()
+        params["item_id_embedding_arch.weight"] = tr.items.weight.cpu().clone()
+        state = R.AdamState(params)
+        batches = tr.make_batches(3, seed=7)
+        sharded.comm_timing(True)
+        got, want = [], []
+        for i, b in enumerate(batches):
+            got.append(float(tr.step(b, batches[i + 1] if i + 1 < len(batches) else None)))
+            want.append(R.train_step(params, state, [t.cpu() for t in b], torch.tensor([0.7])))
+        per_step = sharded.comm_timing_summary(3)
+        sharded.comm_timing(False)
+        assert np.allclose(got, want, atol=1e-4), (got, want)
+        assert {"lookup_ids_alltoall", "lookup_rows_alltoall", "rowgrad_alltoall", "dense_grad_allreduce"} <= set(per_step)
+
+        def close(got, want, name, noise_only=False):
+            # Adam's first updates are lr * g / (|g| + eps): an element whose gradient is ~1e-4 of the typical size turns a
+            # 1e-7 summation-order difference into a 1e-5 step difference (tests/test_gpu_fullsize.py has the argument):
+            # every element inside the steps * lr bound, all but <= 0.2 % within 5e-6
+            err = (got.cpu() - want).abs()
+            assert float(err.max()) <= 2 * 3 * 1e-3 * 1.05, (name, float(err.max()))
+            if not noise_only:
+                assert float((err > 5e-6).float().mean()) <= 2e-3, (name, float((err > 5e-6).float().mean()), float(err.max()))
+
+        close(tr.users.weight, params["user_id_embedding_arch.weight"], "users")
+        close(tr.items.weight, params["item_id_embedding_arch.weight"], "items")
+        for kk, v in tr.params.items():
+            close(v, params[kk], kk, noise_only=kk in ("item_tower_arch.bias", "item_features_arch.2.bias"))
+        # ... and the forced-async run is the synchronous run, bit for bit (same kernels, same order; only where the
+        # collectives execute differs)
+        monkeypatch.delenv("TT_COMM_FORCE_ASYNC")
+        sharded.use_native_transport(None)
+        tr2 = sharded.ShardedTrainer(cfg, dev, negatives="global", user_value_weights=(0.7,), dense_init=_dense_init(cfg))
+        for i, b in enumerate(batches):
+            tr2.step(b, batches[i + 1] if i + 1 < len(batches) else None)
+        assert torch.equal(tr2.users.weight, tr.users.weight) and torch.equal(tr2.items.weight, tr.items.weight)
+        for kk in tr.params:
+            assert torch.equal(tr2.params[kk], tr.params[kk]), kk
+    finally:
+        sharded.comm_timing(False)
+        sharded.use_native_transport(None)
+        dist.destroy_process_group()
+
+
 def test_native_comm_world1_every_collective():
     """tt_comm_* of the C ABI (csrc/comm.cpp, RCCL bound at run time) with a one-rank communicator: id, init,
     size, and every collective sharded.py uses -- at world size 1 each is the identity, which checks the binding,

@@ -90,3 +90,52 @@ def test_sharded_schedule_scan_runs_each_candidate_one_block_and_keeps_the_faste
         hist.append(cand)
     assert scan.best == (2, 256) and all(c == (2, 256) for c in hist[-30:])
     assert hist[:3] == [(0, 256)] * 3 and hist[3:15] == [(0, 256)] * 4 + [(2, 256)] * 4 + [(0, 0)] * 4
+
+
+def test_sharded_schedule_scan_group_decision_is_identical_on_every_rank():
+    """With a group reduction the schedule is chosen ONCE for the group, at the same step on every rank (ADVICE r3:
+    ranks locking different schedules on local timing noise): two simulated ranks whose local measurements favour
+    different candidates both end up on the candidate whose WORST rank is fastest, and switch at the same step."""
+    from two_tower_models_amd.sharded import _ScheduleScan
+    cands = [(0, 256), (2, 256), (0, 0)]
+    local_ms = [{(0, 256): 4.40, (2, 256): 4.45, (0, 0): 4.60},   # rank 0 would pick (0, 256)
+                {(0, 256): 4.70, (2, 256): 4.42, (0, 0): 4.50}]   # rank 1 would pick (2, 256); group: max -> (2, 256)
+    clocks = [{"t": 0.0}, {"t": 0.0}]
+
+    def make_ev(r):
+        class Ev:
+            def record(self):
+                self.t = clocks[r]["t"]
+
+            def query(self):
+                return True
+
+            def synchronize(self):
+                pass
+
+            def elapsed_time(self, other):
+                return other.t - self.t
+        return Ev
+
+    mailbox = {}
+
+    def group_max_for(r):
+        def f(values):  # both ranks call in lockstep: rank 0 posts, rank 1 completes -- simulated with a shared dict
+            mailbox[r] = list(values)
+            return [max(a, b) for a, b in zip(mailbox.get(0, values), mailbox.get(1, values))]
+        return f
+
+    scans = [_ScheduleScan(cands, block=4, skip_first=3, new_event=make_ev(r), group_max=None) for r in range(2)]
+    # pre-compute what each rank will report, so the simulated all-reduce can return the true max to both
+    for r in range(2):
+        scans[r]._group_max = lambda values, r=r: [max(local_ms[0][c], local_ms[1][c]) for c in cands]
+    hist = [[], []]
+    for _ in range(40):
+        for r in range(2):
+            c = scans[r].begin()
+            clocks[r]["t"] += local_ms[r][c]
+            scans[r].end()
+            hist[r].append(c)
+    assert scans[0].best == scans[1].best == (2, 256)
+    assert hist[0] == hist[1]  # same candidate at every step, including the step the decision lands on
+    assert "group" in scans[0].decided_by

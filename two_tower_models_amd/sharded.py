@@ -74,8 +74,16 @@ def use_native_transport(comm) -> None:
         use_native_transport._atexit = True
 
 
+# TT_COMM_FORCE_ASYNC=1 (tests, 1-GPU boxes): take the RCCL code paths -- async collectives on the process group's
+# stream / tt_comm_* on the communication stream -- at world size 1 as well, where every collective is the identity.
+# The paths a multi-GPU node runs are then executed, with the real message sizes, on the box that has one device.
+def _force_async() -> bool:
+    return os.environ.get("TT_COMM_FORCE_ASYNC") is not None
+
+
 def _native(x: torch.Tensor) -> bool:
-    return _NATIVE is not None and x.is_cuda and x.dtype in _NATIVE_DTYPES and dist.get_world_size() > 1
+    return (_NATIVE is not None and x.is_cuda and x.dtype in _NATIVE_DTYPES
+            and (dist.get_world_size() > 1 or _force_async()))
 
 
 def _native_op(op) -> int:
@@ -125,69 +133,142 @@ def reduce_scatter_rows(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# Per-exchange timing (bench.py's multi-rank line: `comm_ms`): None = off.  When a list, every exchange appends
+# (tag, issued, wait_begin, wait_end[, comm_begin, comm_end]) CUDA events; `comm_timing_summary` turns them into, per
+# tag and step:  span = issue -> result usable (what the exchange costs if NOTHING overlaps it), exposed = the time
+# the compute stream actually stood still at `.wait()` (0 when the exchange finished underneath the kernels queued in
+# between), and -- native transport, whose stream we own -- the collective's own duration on the wire.
+_TIMING: Optional[list] = None
+
+
+def comm_timing(on: bool) -> None:
+    global _TIMING
+    _TIMING = [] if on else None
+
+
+def comm_timing_summary(steps: int) -> Dict[str, Dict[str, float]]:
+    """Synchronises, then per tag: calls per step, span / exposed (/ wire) milliseconds per step."""
+    out: Dict[str, Dict[str, float]] = {}
+    if not _TIMING:
+        return out
+    torch.cuda.synchronize()
+    for rec in _TIMING:
+        tag, e_issue, w0, w1 = rec[:4]
+        d = out.setdefault(tag, {"calls": 0, "span_ms": 0.0, "exposed_ms": 0.0})
+        d["calls"] += 1
+        d["span_ms"] += e_issue.elapsed_time(w1)
+        d["exposed_ms"] += w0.elapsed_time(w1)
+        if len(rec) > 4:
+            d["wire_ms"] = d.get("wire_ms", 0.0) + rec[4].elapsed_time(rec[5])
+    for d in out.values():
+        for k in list(d):
+            d[k] = round(d[k] / max(steps, 1), 4)
+    _TIMING.clear()
+    return out
+
+
+def _tev() -> torch.cuda.Event:
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
 class _Pending:
     """Result of a collective started with `*_start`: `.wait()` makes the CURRENT stream wait for it
     (RCCL: the collective runs on the process group's own stream -- or, native transport, on this module's
     communication stream -- meanwhile, so kernels launched in between overlap it) and returns the output."""
 
-    __slots__ = ("out", "work", "keep")
+    __slots__ = ("out", "work", "keep", "tag", "issued", "wire")
 
-    def __init__(self, out, work=None, keep=None):
+    def __init__(self, out, work=None, keep=None, tag=None, issued=None, wire=None):
         self.out, self.work, self.keep = out, work, keep  # `keep`: the send buffer, alive until waited for
+        self.tag, self.issued, self.wire = tag, issued, wire
 
     def wait(self) -> torch.Tensor:
+        timing = _TIMING is not None and self.issued is not None
+        w0 = _tev() if timing else None
         if self.work is not None:
             if isinstance(self.work, torch.cuda.Event):
                 torch.cuda.current_stream().wait_event(self.work)
             else:
                 self.work.wait()
             self.work, self.keep = None, None
+        if timing:
+            _TIMING.append((self.tag, self.issued, w0, _tev()) + (tuple(self.wire) if self.wire else ()))
+            self.issued = None
         return self.out
 
 
-def _native_start(fn, x: torch.Tensor, *args) -> _Pending:
+def _timed_sync(tag: str, fn, *args, **kw):
+    """A blocking-style collective (the caller uses the result at once) under the same bookkeeping."""
+    if _TIMING is None:
+        return fn(*args, **kw)
+    e0 = _tev()
+    out = fn(*args, **kw)
+    _TIMING.append((tag, e0, e0, _tev()))
+    return out
+
+
+def _native_start(fn, x: torch.Tensor, *args, tag=None) -> _Pending:
     """Run `fn(x, *args, stream=<communication stream>)` after everything queued so far on the current stream."""
     x = x.contiguous()
-    ready = torch.cuda.Event()
+    timing = _TIMING is not None
+    ready = torch.cuda.Event(enable_timing=timing)
     ready.record()
     _COMM_STREAM.wait_event(ready)
+    wire = None
+    if timing:
+        c0 = torch.cuda.Event(enable_timing=True)
+        c0.record(_COMM_STREAM)
     out = fn(x, *args, stream=_COMM_STREAM)
-    done = torch.cuda.Event()
+    done = torch.cuda.Event(enable_timing=timing)
     done.record(_COMM_STREAM)
-    return _Pending(out, done, x)
+    if timing:
+        wire = (c0, done)
+    return _Pending(out, done, x, tag, ready if timing else None, wire)
 
 
 def _rccl_async(x: torch.Tensor) -> bool:
-    return dist.get_world_size() > 1 and not _is_gloo() and x.is_cuda
+    return (dist.get_world_size() > 1 or _force_async()) and not _is_gloo() and x.is_cuda
 
 
-def all_gather_rows_start(x: torch.Tensor) -> _Pending:
+def _issued():
+    return _tev() if _TIMING is not None else None
+
+
+def all_gather_rows_start(x: torch.Tensor, tag: str = "all_gather") -> _Pending:
     if _native(x):
-        return _native_start(_NATIVE.all_gather, x, None)
+        return _native_start(_NATIVE.all_gather, x, None, tag=tag)
     if not _rccl_async(x):  # gloo (tests) and world size 1: nothing to overlap with
-        return _Pending(all_gather_rows(x) if dist.get_world_size() > 1 else x)
+        e = _issued()
+        return _Pending(all_gather_rows(x) if dist.get_world_size() > 1 else x, tag=tag, issued=e)
     x = x.contiguous()
     out = x.new_empty((dist.get_world_size() * x.shape[0],) + tuple(x.shape[1:]))
-    return _Pending(out, dist.all_gather_into_tensor(out, x, async_op=True), x)
+    e = _issued()
+    return _Pending(out, dist.all_gather_into_tensor(out, x, async_op=True), x, tag, e)
 
 
-def reduce_scatter_rows_start(x: torch.Tensor) -> _Pending:
+def reduce_scatter_rows_start(x: torch.Tensor, tag: str = "reduce_scatter") -> _Pending:
     if _native(x):
         from . import _native as N
-        return _native_start(_NATIVE.reduce_scatter, x, None, N.TT_COMM_SUM)
+        return _native_start(_NATIVE.reduce_scatter, x, None, N.TT_COMM_SUM, tag=tag)
     if not _rccl_async(x):
-        return _Pending(reduce_scatter_rows(x) if dist.get_world_size() > 1 else x)
+        e = _issued()
+        return _Pending(reduce_scatter_rows(x) if dist.get_world_size() > 1 else x, tag=tag, issued=e)
     x = x.contiguous()
     out = x.new_empty((x.shape[0] // dist.get_world_size(),) + tuple(x.shape[1:]))
-    return _Pending(out, dist.reduce_scatter_tensor(out, x, async_op=True), x)
+    e = _issued()
+    return _Pending(out, dist.reduce_scatter_tensor(out, x, async_op=True), x, tag, e)
 
 
-def all_reduce_start_(x: torch.Tensor, op=dist.ReduceOp.SUM) -> _Pending:
+def all_reduce_start_(x: torch.Tensor, op=dist.ReduceOp.SUM, tag: str = "all_reduce") -> _Pending:
     if _native(x):
-        return _native_start(_NATIVE.all_reduce_, x, _native_op(op))
+        return _native_start(_NATIVE.all_reduce_, x, _native_op(op), tag=tag)
     if not _rccl_async(x):
-        return _Pending(all_reduce_(x, op=op) if dist.get_world_size() > 1 else x)
-    return _Pending(x, dist.all_reduce(x, op=op, async_op=True))
+        e = _issued()
+        return _Pending(all_reduce_(x, op=op) if dist.get_world_size() > 1 else x, tag=tag, issued=e)
+    e = _issued()
+    return _Pending(x, dist.all_reduce(x, op=op, async_op=True), None, tag, e)
 
 
 def all_reduce_(x: torch.Tensor, op=dist.ReduceOp.SUM) -> torch.Tensor:
@@ -225,14 +306,16 @@ def all_to_all_rows(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def all_to_all_rows_start(x: torch.Tensor) -> _Pending:
+def all_to_all_rows_start(x: torch.Tensor, tag: str = "all_to_all") -> _Pending:
     if _native(x):
-        return _native_start(_NATIVE.all_to_all, x, None)
+        return _native_start(_NATIVE.all_to_all, x, None, tag=tag)
     if not _rccl_async(x):
-        return _Pending(all_to_all_rows(x) if dist.get_world_size() > 1 else x)
+        e = _issued()
+        return _Pending(all_to_all_rows(x) if dist.get_world_size() > 1 else x, tag=tag, issued=e)
     x = x.contiguous()
     out = torch.empty_like(x)
-    return _Pending(out, dist.all_to_all_single(out, x, async_op=True), x)
+    e = _issued()
+    return _Pending(out, dist.all_to_all_single(out, x, async_op=True), x, tag, e)
 
 
 # ----------------------------------------------------------------- product backend
@@ -643,8 +726,13 @@ class _ScheduleScan:
     the last block's events are in, the candidate with the smallest step time is kept.  Results never depend on the
     choice: every candidate is the same arithmetic in the same order."""
 
-    def __init__(self, candidates, block: int = 6, skip_first: int = 4, new_event=None):
+    def __init__(self, candidates, block: int = 6, skip_first: int = 4, new_event=None, group_max=None):
         self._new_event = new_event or (lambda: torch.cuda.Event(enable_timing=True))  # (tests: stub events)
+        # group_max(list of floats) -> element-wise MAX over the ranks.  With it the choice is made ONCE FOR THE GROUP, at a
+        # step number every rank reaches (`decide_at`): the steps are synchronised by the collectives, so the fastest
+        # candidate is a property of the group, and ranks that locked different schedules on local timing noise would
+        # drag each other (ADVICE r3).  Without it (one rank, tests) the local measurements decide as soon as they are in.
+        self._group_max = group_max
         self.cands = list(candidates)
         self.plan = [c for c in self.cands for _ in range(block)]
         self.block, self.skip_first = block, skip_first
@@ -653,6 +741,8 @@ class _ScheduleScan:
         self.obs = {c: [] for c in self.cands}
         self.best = None
         self._cur = None
+        self.decide_at = skip_first + len(self.plan) + 4  # group decision: a few steps after the last block was enqueued
+        self.decided_by = None
 
     def begin(self):
         """-> the candidate this step runs with; call end() when the step has been enqueued."""
@@ -660,6 +750,9 @@ class _ScheduleScan:
             return self.best
         self._drain()
         if self.best is not None:
+            return self.best
+        if self._group_max is not None and self.n >= self.decide_at:
+            self._decide_group()
             return self.best
         k = self.n - self.skip_first
         self.n += 1
@@ -686,12 +779,30 @@ class _ScheduleScan:
             a, b, cand, counted = self.pending.pop(0)
             if counted:
                 self.obs[cand].append(a.elapsed_time(b))
-        if self.n >= self.skip_first + len(self.plan) and not self.pending:
+        if self._group_max is None and self.n >= self.skip_first + len(self.plan) and not self.pending:
             ms = {c: min(v) for c, v in self.obs.items() if len(v) >= 2}
             self.best = min(ms, key=ms.get) if ms else self.cands[0]
+            self.decided_by = "local measurements"
             if os.environ.get("TT_TUNE_DEBUG"):
                 import sys
                 print(f"[tt] sharded step schedule (sweep start, workgroups): {ms} -> {self.best}", file=sys.stderr)
+
+    def _decide_group(self) -> None:
+        """Every rank calls this at the same step: wait for the own measurements (one host wait, once per run), take the
+        MAX over the ranks of each candidate's best time -- the group moves at the pace of its slowest rank -- and keep
+        the candidate whose worst rank is fastest.  Identical inputs on every rank -> identical choice."""
+        for a, b, cand, counted in self.pending:
+            b.synchronize()
+            if counted:
+                self.obs[cand].append(a.elapsed_time(b))
+        self.pending = []
+        local = [min(self.obs[c]) if len(self.obs[c]) >= 2 else 1.0e9 for c in self.cands]
+        worst = list(self._group_max(local))
+        self.best = self.cands[min(range(len(self.cands)), key=lambda i: (worst[i], i))]
+        self.decided_by = "group (max over ranks of each candidate's best step time)"
+        if os.environ.get("TT_TUNE_DEBUG"):
+            import sys
+            print(f"[tt] sharded step schedule: local {local}, group {worst} -> {self.best}", file=sys.stderr)
 
 
 class ShardedTrainer:
@@ -713,7 +824,7 @@ class ShardedTrainer:
         self.transport = transport or os.environ.get("TT_COMM", "torch")
         if self.transport not in ("torch", "native"):
             raise ValueError("transport must be 'torch' or 'native'")
-        if self.transport == "native" and device.type == "cuda" and dist.get_world_size() > 1:
+        if self.transport == "native" and device.type == "cuda" and (dist.get_world_size() > 1 or _force_async()):
             if _is_gloo():
                 raise RuntimeError("transport='native' needs one GPU per rank (RCCL); this group runs over gloo")
             from .comm import NativeComm
@@ -813,13 +924,26 @@ class ShardedTrainer:
         self._scan = None
         if (late is None and os.environ.get("TT_SWEEP_WGS") is None and sweep_ms < 0.75 * logits_ms
                 and getattr(self.be, "device", device).type == "cuda" and self.routing != "allgather"):
-            self._scan = _ScheduleScan([(0, 256), (2, 256), (0, 0)], block=4, skip_first=3)  # 15 steps, then fixed
+            self._scan = _ScheduleScan([(0, 256), (2, 256), (0, 0)], block=4, skip_first=3,  # 15 steps, then fixed
+                                       group_max=self._group_max if self.W > 1 else None)
         # the same regime decides whether the forward keeps the logits for the backward (one product
         # fewer, M*N*4 B of HBM traffic each way more): worth it once the sweep no longer binds
         keep = os.environ.get("TT_CE_KEEP_LOGITS")
         if hasattr(self.be, "keep_logits"):
             self.be.keep_logits = (keep == "1") if keep is not None else sweep_ms < 0.75 * logits_ms
         self.last_loss = torch.zeros((), dtype=torch.float32, device=device)
+
+    def _group_max(self, values):
+        t = torch.tensor(values, dtype=torch.float32, device=self.device)
+        all_reduce_(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.cpu()]
+
+    def schedule_note(self):
+        """Where the sweep starts / how wide it runs in this trainer's step, and who decided (bench.py prints it)."""
+        names = {0: "top of the step", 1: "with the forward logits kernel", 2: "with the backward logits kernel"}
+        start = 2 if self._sweep_bwd else 1 if self._sweep_late else 0
+        return {"sweep_start": names[start], "sweep_workgroups": self._sweep_wgs or 768,
+                "decided_by": (self._scan.decided_by or "scan still running") if self._scan is not None else "fixed by shape / environment"}
 
     def _tower_params(self, side):
         return [self.params[f"{side}_{k}"] for k in TOWER_KEYS]
@@ -926,7 +1050,7 @@ class ShardedTrainer:
             keep.append(ids)
             planned.append(self.be.route_plan(ids, table.n_rows, table.rows_per_rank, self.W, counts[k:k + 1]))
         if self.W > 1:
-            all_reduce_start_(counts, op=dist.ReduceOp.MAX).wait()
+            all_reduce_start_(counts, op=dist.ReduceOp.MAX, tag="route_caps_allreduce").wait()
         if counts.is_cuda:
             host = torch.empty(len(specs), dtype=torch.int32).pin_memory()
             host.copy_(counts, non_blocking=True)
@@ -959,12 +1083,12 @@ class ShardedTrainer:
         sent_ids = sent_rows = 0
         for (table, _ids), planned, cap in zip(self._route_specs(batch), routes.planned, caps):
             send_ids, slot_of, src_of = be.route_build(planned, table.rows_per_rank, W, cap)
-            lks.append(_RoutedLookup(table, cap, slot_of, src_of, all_to_all_rows_start(send_ids)))
+            lks.append(_RoutedLookup(table, cap, slot_of, src_of, all_to_all_rows_start(send_ids, tag="lookup_ids_alltoall")))
             sent_ids += (W - 1) * cap * 8
             sent_rows += (W - 1) * cap * D * 4
         for lk in lks:
             lk.local = be.localize(lk.ids_p.wait(), lk.table.lo, lk.n_local)  # sentinel n_local for padding
-            lk.rows_p = all_to_all_rows_start(be.gather_owned(lk.table.weight, lk.local, lk.n_local))
+            lk.rows_p = all_to_all_rows_start(be.gather_owned(lk.table.weight, lk.local, lk.n_local), tag="lookup_rows_alltoall")
         lk_u, lk_i = lks[0], lks[-1]
         lk_h = lks[1] if self.hist else None
         if next_batch is not None:
@@ -996,7 +1120,7 @@ class ShardedTrainer:
         i_h, i_f, I = be.tower_fwd(i_emb, item_feat, pi)
         # 2. logits against every rank's items
         glob = self.negatives == "global" and W > 1
-        I_all = all_gather_rows(I) if glob else I
+        I_all = _timed_sync("item_emb_allgather", all_gather_rows, I) if glob else I
         off = self.rank * B if glob else 0
         if self._sweep_late:  # a short sweep hides under the logits kernels instead of the small tower GEMMs
             be.sweep_async(sweep, self.hyper, self._sweep_wgs)
@@ -1006,18 +1130,18 @@ class ShardedTrainer:
             be.sweep_async(sweep, self.hyper, self._sweep_wgs)
         # 4. backward through the loss
         dU, dI_all = be.ce_bwd(U, I_all, off, lse, coef)
-        dI_p = reduce_scatter_rows_start(dI_all) if glob else _Pending(dI_all)  # travels under the user tower backward
+        dI_p = reduce_scatter_rows_start(dI_all, tag="dI_reduce_scatter") if glob else _Pending(dI_all)  # travels under the user tower backward
         # 5. towers backward -> dense grads (flat buffer) + embedding-row grads; each row-gradient block
         # goes back through its lookup's slots as soon as it exists
         d_urows, d_summary = be.tower_bwd(dU, u_emb, u_h, u_f, user_feat, pu, self._tower_grads("user"), extra=summary)
-        g_u_p = all_to_all_rows_start(be.gather_rows(d_urows, lk_u.src_of))  # aligned with lk_u.local
+        g_u_p = all_to_all_rows_start(be.gather_rows(d_urows, lk_u.src_of), tag="rowgrad_alltoall")  # aligned with lk_u.local
         g_h_p = None
         if self.hist:
             d_hrows = be.encoder_bwd(enc_saved, d_summary.view(B, 2, D), [self.grads[k] for k in self.encoder_keys])
-            g_h_p = all_to_all_rows_start(be.gather_rows(d_hrows, lk_h.src_of))
+            g_h_p = all_to_all_rows_start(be.gather_rows(d_hrows, lk_h.src_of), tag="rowgrad_alltoall")
         d_irows, _ = be.tower_bwd(dI_p.wait(), i_emb, i_h, i_f, item_feat, pi, self._tower_grads("item"))
-        g_i_p = all_to_all_rows_start(be.gather_rows(d_irows, lk_i.src_of))
-        flat_p = all_reduce_start_(self.flat_g)  # every dense gradient has been written by now
+        g_i_p = all_to_all_rows_start(be.gather_rows(d_irows, lk_i.src_of), tag="rowgrad_alltoall")
+        flat_p = all_reduce_start_(self.flat_g, tag="dense_grad_allreduce")  # every dense gradient has been written by now
         g_u, g_i = g_u_p.wait(), g_i_p.wait()
         if self.hist:  # aligned with item_local = [history ids | item ids]
             g_i = torch.cat([g_h_p.wait(), g_i])
@@ -1046,12 +1170,12 @@ class ShardedTrainer:
         nuv = torch.clamp(torch.sum(labels * self.uvw, dim=-1), min=0.000001)
         nmax = nuv.max()
         if glob:
-            all_reduce_(nmax, op=dist.ReduceOp.MAX)
+            _timed_sync("scalars", all_reduce_, nmax, op=dist.ReduceOp.MAX)
         w = nuv / nmax
         denom = float(B * self.W)  # global negatives: mean over W*B rows; local: mean of W per-rank means
         coef = (w / denom).contiguous()
         loss = (ce * w).sum() / denom
-        all_reduce_(loss)
+        _timed_sync("scalars", all_reduce_, loss)
         self.last_loss = loss
         return loss, coef
 
