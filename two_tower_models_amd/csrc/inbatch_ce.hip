@@ -795,6 +795,12 @@ __global__ __launch_bounds__(1024) void ce_fwd_du_finish_loss_kernel(const float
                                                                      unsigned* counter) {
   ce_fwd_du_finish_row<16, true>(part_m, part_s, diag, slabs, splits, M, D, Y, ldy, diag_offset, row_lse, row_ce, du_unit, ld_du);
   __shared__ int is_last;
+  // The hand-off is MI355X_MICROARCH.md's "handoff-flag, drained sc1" form: write-through (sc1) payload stores ->
+  // s_waitcnt vmcnt(0) in the storing wave -> sc1 flag; reader: sc1 loads.  The wait is written out as inline assembly so it
+  // does not depend on what hipcc chooses to emit for __syncthreads() (today: vmcnt(0) + s_barrier; the LLVM memory model
+  // would allow a workgroup-scope barrier without it -- ADVICE r3); inline asm is invisible to the wait-count pass, so it
+  // cannot be optimised away.  TT_CE_NO_FUSED_LOSS=1 takes the two-launch form, which has no cross-workgroup hand-off.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // every wave's stores (row_ce among them) have been acknowledged
   if (threadIdx.x == 0)
     is_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;

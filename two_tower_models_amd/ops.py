@@ -203,6 +203,7 @@ class ActiveStash:
     read from here: the zero-gradient sweep may already be rewriting the table itself."""
 
     _positions = {}  # (concrete device index, n) -> arange(n): the same few sizes every step
+    _pinned = set()  # keys whose tensor was used while a hipGraph was being captured: never evicted
 
     @staticmethod
     def positions_for(device: torch.device, n: int) -> torch.Tensor:
@@ -212,12 +213,18 @@ class ActiveStash:
         idx = device.index if device.index is not None else torch.cuda.current_device()
         key = (idx, int(n))
         pos = ActiveStash._positions.get(key)
+        capturing = torch.cuda.is_current_stream_capturing()
         if pos is None:
-            if torch.cuda.is_current_stream_capturing():
+            if capturing:
                 return torch.arange(n, dtype=torch.int64, device=device)  # part of the graph, not of the cache
             if len(ActiveStash._positions) > 64:
-                ActiveStash._positions.clear()
+                # evict, but never an entry a captured hipGraph has baked the address of: the graph keeps replaying reads
+                # of that memory, and a cleared entry would hand it back to the allocator
+                for k in [k for k in ActiveStash._positions if k not in ActiveStash._pinned]:
+                    del ActiveStash._positions[k]
             pos = ActiveStash._positions[key] = torch.arange(n, dtype=torch.int64, device=device)
+        elif capturing:
+            ActiveStash._pinned.add(key)
         return pos
 
     def __init__(self, p_plane: torch.Tensor, block_sizes: Sequence[int]):
@@ -453,6 +460,10 @@ class FusedTower(_LookupFunction):
         if extra is not None:
             N.require_device(extra)
             extra = _rowmajor(extra)
+            # tt_tower_*_x read the third block with 16-byte loads: an encoder that returns an offset / oddly strided view
+            # (a user-supplied module may) gets a packed copy instead of TT_E_UNSUPPORTED
+            if extra.data_ptr() % 16 or extra.stride(0) % 4:
+                extra = extra.contiguous()
         E = 0 if extra is None else extra.shape[1]
         B, F = feats.shape
         D, Hd = weight.shape[1], W1.shape[0]

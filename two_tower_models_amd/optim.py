@@ -376,8 +376,8 @@ class DenseExactAdam(torch.optim.Optimizer):
         while self._tune_done and self._tune_done[0][2].query() and self._tune_done[0][3].query():
             got = self._tune_done.pop(0)
             newest = got[5]
-            if got[5] <= 4 or got[5] in ts["skip"]:
-                continue  # the first steps (allocations, first-use set-up) / the first step of a scan block
+            if got[5] - int(getattr(self, "_resume_step", 0)) <= 4 or got[5] in ts["skip"]:
+                continue  # the first steps SINCE CONSTRUCTION OR RESUME (allocations, first-use set-up) / the first step of a scan block
             ts["obs"].setdefault(got[4], []).append((got[0].elapsed_time(got[3]), got[1].elapsed_time(got[2])))
         if ts["phase"] == "probe":
             seen = ts["obs"].get(0, [])
