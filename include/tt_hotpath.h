@@ -203,6 +203,16 @@ int tt_weighted_mean_loss(const float* labels, int64_t B, int64_t T, const float
                           const float* row_ce, float* w_out, float* coef_out, float* loss_out,
                           tt_stream_t stream);
 
+/* The same head cut at its two batch-wide reductions, for a batch that is split over ranks (row-sharded step: every rank
+ * holds B of the global rows; ref:...base_retrieval.py:322,334-343 on the concatenated batch):
+ *   tt_value_weights         nuv[i] = clamp(sum_t labels[i,t]*uvw[t], 1e-6);  *max_out = max_i nuv      (-> all-reduce MAX)
+ *   tt_weighted_loss_global  w = nuv / *gmax;  coef[i] = w[i] / denom;  *loss_out = sum_i row_ce[i]*w[i] / denom
+ *                            (denom = global batch size; -> all-reduce SUM of the scalar). */
+int tt_value_weights(const float* labels, int64_t B, int64_t T, const float* uvw, float* nuv_out, float* max_out,
+                     tt_stream_t stream);
+int tt_weighted_loss_global(const float* nuv, const float* gmax, const float* row_ce, int64_t B, float denom,
+                            float* coef_out, float* loss_out, tt_stream_t stream);
+
 /* tt_inbatch_ce_fwd_du followed by tt_weighted_mean_loss, the loss head running in the forward's finishing launch
  * (ref:src/two_tower_base_retrieval.py:287-312 logits + cross entropy, :322,334-343 value weights + mean): same
  * outputs as the two calls, the loss bit-identical to theirs; needs M user rows = B label rows.  `ws`:

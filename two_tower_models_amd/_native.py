@@ -102,6 +102,8 @@ SIGNATURES = {
     "tt_inbatch_ce_bwd_kept": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "tt_scale_rows": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "tt_weighted_mean_loss": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tt_value_weights": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "tt_weighted_loss_global": (_int, [_vp, _vp, _vp, _i64, C.c_float, _vp, _vp, _vp]),
     "tt_debias_loss_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "tt_debias_loss_fwd": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64,
                                   _vp, _vp]),

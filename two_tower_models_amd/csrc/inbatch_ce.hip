@@ -765,6 +765,54 @@ __device__ __forceinline__ void weighted_mean_loss_block(const float* __restrict
   }
 }
 
+// The same head split around the two scalar exchanges of the row-sharded step (every rank holds B of the W*B rows):
+//   value_weights_kernel        nuv[i] = clamp(sum_t labels[i,t] uvw[t], 1e-6), *max_out = max_i nuv   -> all-reduce MAX
+//   weighted_loss_global_kernel w = nuv / *gmax, coef = w / denom, *loss_out = sum_i ce[i] w[i] / denom -> all-reduce SUM
+// (denom = W*B).  One 1024-thread workgroup each; they replace nine B-sized torch launches per step.
+__global__ __launch_bounds__(1024) void value_weights_kernel(const float* __restrict__ labels, int64_t B, int64_t T,
+                                                             const float* __restrict__ uvw, float* __restrict__ nuv_out,
+                                                             float* __restrict__ max_out) {
+  __shared__ float red[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float mx = NEG_BIG;
+  for (int64_t i = threadIdx.x; i < B; i += blockDim.x) {
+    float nuv = 0.f;
+    for (int64_t t = 0; t < T; ++t) nuv += labels[i * T + t] * uvw[t];
+    nuv = fmaxf(nuv, 0.000001f);
+    nuv_out[i] = nuv;
+    mx = fmaxf(mx, nuv);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = red[0];
+    for (int k = 1; k < (int)(blockDim.x >> 6); ++k) v = fmaxf(v, red[k]);
+    *max_out = v;
+  }
+}
+__global__ __launch_bounds__(1024) void weighted_loss_global_kernel(const float* __restrict__ nuv, const float* __restrict__ gmax,
+                                                                    const float* __restrict__ row_ce, int64_t B, float denom,
+                                                                    float* __restrict__ coef_out, float* __restrict__ loss_out) {
+  __shared__ float red[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float wmax = *gmax;
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < B; i += blockDim.x) {
+    const float w = nuv[i] / wmax;
+    coef_out[i] = w / denom;
+    acc += row_ce[i] * w;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = 0.f;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) v += red[k];
+    *loss_out = v / denom;
+  }
+}
+
 __global__ __launch_bounds__(1024) void weighted_mean_loss_kernel(const float* __restrict__ labels, int64_t B,
                                                                   int64_t T, const float* __restrict__ uvw,
                                                                   const float* __restrict__ row_ce,
@@ -1154,6 +1202,22 @@ extern "C" int tt_scale_rows(const float* x, int64_t ldx, const float* coef, int
   const int64_t blocks = ceil_div(rows * D, 256) < 2048 ? ceil_div(rows * D, 256) : 2048;
   scale_rows_kernel<<<(unsigned)blocks, 256, 0, S(stream)>>>(x, ldx, coef, rows, D, out, ldo);
   return check_launch("scale_rows_kernel");
+}
+
+extern "C" int tt_value_weights(const float* labels, int64_t B, int64_t T, const float* uvw, float* nuv_out, float* max_out,
+                                tt_stream_t stream) {
+  if (!labels || !uvw || !nuv_out || !max_out) return fail_arg("tt_value_weights: null pointer");
+  if (B <= 0 || T <= 0) return fail_arg("tt_value_weights: sizes");
+  value_weights_kernel<<<1, 1024, 0, S(stream)>>>(labels, B, T, uvw, nuv_out, max_out);
+  return check_launch("value_weights_kernel");
+}
+
+extern "C" int tt_weighted_loss_global(const float* nuv, const float* gmax, const float* row_ce, int64_t B, float denom,
+                                       float* coef_out, float* loss_out, tt_stream_t stream) {
+  if (!nuv || !gmax || !row_ce || !coef_out || !loss_out) return fail_arg("tt_weighted_loss_global: null pointer");
+  if (B <= 0 || !(denom > 0.f)) return fail_arg("tt_weighted_loss_global: sizes");
+  weighted_loss_global_kernel<<<1, 1024, 0, S(stream)>>>(nuv, gmax, row_ce, B, denom, coef_out, loss_out);
+  return check_launch("weighted_loss_global_kernel");
 }
 
 extern "C" int tt_weighted_mean_loss(const float* labels, int64_t B, int64_t T, const float* uvw,

@@ -133,6 +133,13 @@ def reduce_scatter_rows(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# A/B (opt-in): user tower backward on the third stream underneath the dI logits kernel.  Measured round 4 on the emulated
+# W = 8 step: the towers' 0.1 ms leave the tail, the logits kernel they now share the chip with takes as much longer --
+# 4.237 vs 4.246 ms per step; not the default.
+_UTOWER_EARLY = os.environ.get("TT_SHARDED_EARLY_UTOWER") is not None
+_LOSS_KERNELS = os.environ.get("TT_SHARDED_TORCH_LOSS") is None  # A/B: the value-weight tail as two kernels
+
+
 # Per-exchange timing (bench.py's multi-rank line: `comm_ms`): None = off.  When a list, every exchange appends
 # (tag, issued, wait_begin, wait_end[, comm_begin, comm_end]) CUDA events; `comm_timing_summary` turns them into, per
 # tag and step:  span = issue -> result usable (what the exchange costs if NOTHING overlaps it), exposed = the time
@@ -388,6 +395,23 @@ class HipBackend:
     def poll(self) -> None:
         self.N.oob.poll(self.device)
 
+    def value_weights(self, labels: torch.Tensor, uvw: torch.Tensor):
+        """-> (nuv [B] = clamp(labels . uvw, 1e-6), its maximum as a 1-element tensor) -- tt_value_weights."""
+        labels = labels.contiguous()
+        B, T = labels.shape
+        nuv, mx = self.empty(B), self.empty(1)
+        self.N.check(self.lib.tt_value_weights(labels.data_ptr(), B, T, uvw.contiguous().data_ptr(), nuv.data_ptr(), mx.data_ptr(),
+                                               self.N.stream()), "tt_value_weights")
+        return nuv, mx
+
+    def weighted_loss_global(self, nuv, gmax, ce, denom: float):
+        """-> (coef [B] = nuv / gmax / denom, loss scalar = sum(ce * nuv / gmax) / denom) -- tt_weighted_loss_global."""
+        B = nuv.shape[0]
+        coef, loss = self.empty(B), torch.empty((), dtype=torch.float32, device=self.device)
+        self.N.check(self.lib.tt_weighted_loss_global(nuv.data_ptr(), gmax.data_ptr(), ce.contiguous().data_ptr(), B, float(denom),
+                                                      coef.data_ptr(), loss.data_ptr(), self.N.stream()), "tt_weighted_loss_global")
+        return coef, loss
+
     def tower_fwd(self, emb: torch.Tensor, feats: torch.Tensor, p: Sequence[torch.Tensor],
                   extra: Optional[torch.Tensor] = None):
         """out = [emb | MLP(feats) (| extra)] W3^T + b3 without building the concatenation: one
@@ -501,13 +525,21 @@ class HipBackend:
                 "tt_inbatch_ce_fwd_du")
         return ce, lse
 
-    def ce_bwd(self, U, I_all, off, lse, coef):
+    def ce_du(self, coef):
+        """dU = dL/dce (.) du_unit: the user-side gradient, from the forward's unit form alone (no logits kernel)."""
+        N, lib = self.N, self.lib
+        M, D = self._du_unit.shape
+        dU = self.empty(M, D)
+        N.check(lib.tt_scale_rows(self._du_unit.data_ptr(), D, coef.data_ptr(), M, D, dU.data_ptr(), D, N.stream()), "tt_scale_rows")
+        self._du_unit = None
+        return dU
+
+    def ce_bwd(self, U, I_all, off, lse, coef, want_du: bool = True):
         ops, N, lib = self.ops, self.N, self.lib
         M, D = U.shape
         Nn = I_all.shape[0]
-        dU, dI = self.empty(M, D), self.empty(Nn, D)
-        N.check(lib.tt_scale_rows(self._du_unit.data_ptr(), D, coef.data_ptr(), M, D, dU.data_ptr(), D, N.stream()), "tt_scale_rows")
-        self._du_unit = None
+        dI = self.empty(Nn, D)
+        dU = self.ce_du(coef) if want_du else None
         wsp, wsn = ops._ws(self.device, lib.tt_inbatch_ce_workspace_bytes(M, Nn, D))
         if self._kept is not None:
             N.check(lib.tt_inbatch_ce_bwd_kept(U.data_ptr(), D, M, Nn, D, off, lse.data_ptr(), coef.data_ptr(),
@@ -932,6 +964,8 @@ class ShardedTrainer:
         if hasattr(self.be, "keep_logits"):
             self.be.keep_logits = (keep == "1") if keep is not None else sweep_ms < 0.75 * logits_ms
         self.last_loss = torch.zeros((), dtype=torch.float32, device=device)
+        self._tower_stream = None
+        self._hold = None
 
     def _group_max(self, values):
         t = torch.tensor(values, dtype=torch.float32, device=self.device)
@@ -1092,6 +1126,9 @@ class ShardedTrainer:
         lk_u, lk_i = lks[0], lks[-1]
         lk_h = lks[1] if self.hist else None
         if next_batch is not None:
+            # (on the step's own stream, here: planned on a side stream -- at the top of the step, or underneath the logits
+            # kernels -- the plan's event arrived LATER, the host waits for it at the top of the next step, and the emulated
+            # W = 8 step went from 4.23 to 5.9 - 6.1 ms; round 4, measured and dropped)
             self._planned_next = self.plan_routes(next_batch)
         item_local = torch.cat([lk_h.local, lk_i.local]) if self.hist else lk_i.local
         # the tables' old rows have been read: plan, park the looked-up rows, and start the
@@ -1129,12 +1166,41 @@ class ShardedTrainer:
         if self._sweep_bwd:
             be.sweep_async(sweep, self.hyper, self._sweep_wgs)
         # 4. backward through the loss
-        dU, dI_all = be.ce_bwd(U, I_all, off, lse, coef)
+        early = None
+        if _UTOWER_EARLY and not self.hist and hasattr(be, "ce_du") and self.device.type == "cuda":
+            # The user-side gradient dU exists as soon as the loss weights do (the forward kernel produced its unit form), so
+            # the user tower's backward does not have to queue up behind the item-side logits kernel: it runs on a second
+            # stream UNDERNEATH it (ce_bwd_kept's 202-register workgroups leave wave slots for the tower kernels).
+            dU = be.ce_du(coef)
+            if self._tower_stream is None:
+                # the library's existing third stream (idle by now: it sorted the row plans at the top of the step), NOT a
+                # new one: ROCm multiplexes HIP streams onto a handful of hardware queues in creation order, and a fifth
+                # stream landed on the sweep's queue -- its kernels then waited for the persistent sweep, 6.2 ms per step
+                self._tower_stream = be.N.aux_stream(self.device)
+            ready = torch.cuda.Event()
+            ready.record()
+            self._tower_stream.wait_event(ready)
+            with torch.cuda.stream(self._tower_stream):
+                d_urows, d_summary = be.tower_bwd(dU, u_emb, u_h, u_f, user_feat, pu, self._tower_grads("user"), extra=summary)
+                send_u = be.gather_rows(d_urows, lk_u.src_of)
+                early = torch.cuda.Event()
+                early.record()
+            # (no Tensor.record_stream here: blocks marked that way are not reusable until the allocator has seen their
+            # events, the pool then grows by hipMalloc every step and the HOST stalls -- 6.3 instead of 4.2 ms per step.
+            # References held until the next step instead: by then this stream has waited for `early`.)
+            self._hold = [dU, u_emb, u_h, u_f, user_feat, d_urows, d_summary, send_u]
+            _dU2, dI_all = be.ce_bwd(U, I_all, off, lse, coef, want_du=False)
+        else:
+            dU, dI_all = be.ce_bwd(U, I_all, off, lse, coef)
         dI_p = reduce_scatter_rows_start(dI_all, tag="dI_reduce_scatter") if glob else _Pending(dI_all)  # travels under the user tower backward
         # 5. towers backward -> dense grads (flat buffer) + embedding-row grads; each row-gradient block
         # goes back through its lookup's slots as soon as it exists
-        d_urows, d_summary = be.tower_bwd(dU, u_emb, u_h, u_f, user_feat, pu, self._tower_grads("user"), extra=summary)
-        g_u_p = all_to_all_rows_start(be.gather_rows(d_urows, lk_u.src_of), tag="rowgrad_alltoall")  # aligned with lk_u.local
+        if early is not None:
+            torch.cuda.current_stream().wait_event(early)
+            g_u_p = all_to_all_rows_start(send_u, tag="rowgrad_alltoall")
+        else:
+            d_urows, d_summary = be.tower_bwd(dU, u_emb, u_h, u_f, user_feat, pu, self._tower_grads("user"), extra=summary)
+            g_u_p = all_to_all_rows_start(be.gather_rows(d_urows, lk_u.src_of), tag="rowgrad_alltoall")  # aligned with lk_u.local
         g_h_p = None
         if self.hist:
             d_hrows = be.encoder_bwd(enc_saved, d_summary.view(B, 2, D), [self.grads[k] for k in self.encoder_keys])
@@ -1167,12 +1233,21 @@ class ShardedTrainer:
 
     def _weighted_loss(self, ce, labels, B, glob):
         """Value weights (ref :322,334-343) with the max / mean taken over the global batch -> (loss, dL/dce)."""
+        denom = float(B * self.W)  # global negatives: mean over W*B rows; local: mean of W per-rank means
+        if hasattr(self.be, "value_weights") and labels.dim() == 2 and labels.dtype == torch.float32 and _LOSS_KERNELS:
+            # two launches around the two scalar exchanges instead of nine B-sized torch launches (csrc/inbatch_ce.hip)
+            nuv, nmax = self.be.value_weights(labels, self.uvw)
+            if glob:
+                _timed_sync("scalars", all_reduce_, nmax, op=dist.ReduceOp.MAX)
+            coef, loss = self.be.weighted_loss_global(nuv, nmax, ce, denom)
+            _timed_sync("scalars", all_reduce_, loss)
+            self.last_loss = loss
+            return loss, coef
         nuv = torch.clamp(torch.sum(labels * self.uvw, dim=-1), min=0.000001)
         nmax = nuv.max()
         if glob:
             _timed_sync("scalars", all_reduce_, nmax, op=dist.ReduceOp.MAX)
         w = nuv / nmax
-        denom = float(B * self.W)  # global negatives: mean over W*B rows; local: mean of W per-rank means
         coef = (w / denom).contiguous()
         loss = (ce * w).sum() / denom
         _timed_sync("scalars", all_reduce_, loss)
