@@ -52,6 +52,65 @@ def note_generic(path: str, why: str) -> None:
         warnings.warn(f"two_tower_models_amd: {path} runs on the generic kernels ({why})", RuntimeWarning, stacklevel=3)
 
 
+# ----------------------------------------------------------------- gradient work off the critical path
+# Weight-gradient products feed nothing but the optimiser, so a backward function may hand them to the library's third
+# stream (N.aux_stream: it sorts the row plans during the forward and is idle during the backward) and return at once: the
+# kernels then run underneath whatever the rest of the backward pass queues on the main stream.  The main stream is made to
+# wait for them ONCE, by a callback the autograd engine runs when the backward pass has finished (before `.backward()`
+# returns) -- every consumer of `.grad` (this package's optimiser, torch.optim, user code) therefore sees completed
+# gradients by ordinary stream order.  Operands are held until then.  Not used while a hipGraph is being captured.
+# (The third stream, not a new one: ROCm multiplexes HIP streams onto a handful of hardware queues in creation order, and
+# one more stream can land on the sweep's queue -- measured in sharded.py, round 4.)
+_SIDE_GRADS = os.environ.get("TT_WGRAD_MAIN") is None
+_TOWER_WGRAD_SIDE = os.environ.get("TT_TOWER_WGRAD_SIDE") is not None
+_side_state = {"held": [], "armed": False, "dev": None, "encoder": False}  # "encoder": a HistoryEncoder forward ran since the last join
+
+
+def _join_side_grads() -> None:
+    st = _side_state
+    if st["dev"] is not None:
+        done = torch.cuda.Event()
+        done.record(N.aux_stream(st["dev"]))
+        torch.cuda.current_stream(st["dev"]).wait_event(done)
+    st["held"].clear()
+    st["armed"], st["dev"], st["encoder"] = False, None, False
+
+
+def run_on_side(dev: torch.device, fn, hold: Sequence[Optional[torch.Tensor]] = (),
+                leaves: Sequence[Optional[torch.Tensor]] = ()) -> bool:
+    """Run fn() on the third stream, after everything queued so far on the current one; -> False (and fn() runs in
+    place) when side execution is off, the device is not a GPU, a graph is being captured, or no backward pass is running.
+    `hold`: the INPUTS of fn (kept alive until the join) -- never its outputs: autograd's AccumulateGrad takes a returned
+    gradient over as `.grad` without launching anything only if nobody else references it; a held output would be CLONED
+    on the main stream, at once, before the side kernel has written it.  `leaves`: the tensors the gradients are for; the
+    work is deferred only if each of them is a leaf whose `.grad` is None (then AccumulateGrad steals) -- a defined
+    `.grad` (zero_grad(set_to_none=False)) means an in-place add on the main stream right after backward() returns its
+    outputs, and a non-leaf means an arbitrary consumer: both get completed gradients instead."""
+    if not (_SIDE_GRADS and dev.type == "cuda") or torch.cuda.is_current_stream_capturing() or torch.is_grad_enabled():
+        fn()
+        return False
+    for t in leaves:
+        if t is None or not (t.is_leaf and t.grad is None):
+            fn()
+            return False
+    st = _side_state
+    if not st["armed"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_side_grads)
+        except RuntimeError:  # not inside a backward pass: nobody would join
+            fn()
+            return False
+        st["armed"], st["dev"] = True, dev
+    side = N.aux_stream(dev)
+    ev = torch.cuda.Event()
+    ev.record()
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        fn()
+    st["held"].extend(t for t in hold if t is not None)
+    return True
+
+
 def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, M: int, Nn: int, K: int,
          bias: Optional[torch.Tensor] = None, epilogue: int = N.TT_EPI_NONE,
          aux: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
@@ -71,7 +130,7 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, M: in
 
 
 def gemm_tn_colsum(dy: torch.Tensor, x: torch.Tensor, dW: torch.Tensor, accumulate: bool = False,
-                   db: Optional[torch.Tensor] = None):
+                   db: Optional[torch.Tensor] = None, slot: str = "ws"):
     """Weight gradient and bias gradient of y = x W^T + b in one pass over dy:
     dW[N_out, K_in] (+)= dy^T x,  db[N_out] = sum over rows of dy  (tt_gemm_tn_colsum_f32)."""
     dev = N.require_device(dy, x, dW)
@@ -81,7 +140,7 @@ def gemm_tn_colsum(dy: torch.Tensor, x: torch.Tensor, dW: torch.Tensor, accumula
     pc, _, _, ldc = _f32_2d(dW, "dW")
     if db is None:
         db = torch.empty(Nout, dtype=torch.float32, device=dev)
-    wsp, wsn = _ws(dev, lib.tt_gemm_workspace_bytes(N.TT_GEMM_TN, Nout, Kin, Mrows))
+    wsp, wsn = _ws(dev, lib.tt_gemm_workspace_bytes(N.TT_GEMM_TN, Nout, Kin, Mrows), slot)
     N.check(lib.tt_gemm_tn_colsum_f32(Nout, Kin, Mrows, pa, lda, pb, ldb, pc, ldc, 1 if accumulate else 0,
                                       db.data_ptr(), wsp, wsn, N.stream()), "tt_gemm_tn_colsum_f32")
     return dW, db
@@ -484,6 +543,7 @@ class FusedTower(_LookupFunction):
                                         N.oob.flag(dev).data_ptr(), N.stream()), "tt_tower_fwd_x")
         ctx.weight = weight
         ctx.has_extra = extra is not None
+        ctx.tower_leaves = (W1, b1, W2, b2, W3, b3)  # as passed in: the Parameters (ops.run_on_side: `leaves`)
         ctx.save_for_backward(ids, feats, h, tin, W2c, W3c, *(() if extra is None else (extra,)))
         return y
 
@@ -504,7 +564,19 @@ class FusedTower(_LookupFunction):
         N.check(N.load().tt_tower_bwd_data_x(dy.data_ptr(), dy.stride(0), B, D, Hd, W2.data_ptr(), W3.data_ptr(), h.data_ptr(),
                                              d_emb.data_ptr(), D, d_f.data_ptr(), dh.data_ptr(), N.ptr(d_extra), E, E,
                                              N.stream()), "tt_tower_bwd_data_x")
-        dW1, db1, dW2, db2, dW3, db3 = tower_weight_grads(dy, tin, d_f, h, dh, feats, extra=extra)
+        E3 = 0 if extra is None else extra.shape[1]
+        outs = (torch.empty(Hd, F, dtype=torch.float32, device=dev), torch.empty(Hd, dtype=torch.float32, device=dev),
+                torch.empty(D, Hd, dtype=torch.float32, device=dev), torch.empty(D, dtype=torch.float32, device=dev),
+                torch.empty(D, 2 * D + E3, dtype=torch.float32, device=dev), torch.empty(D, dtype=torch.float32, device=dev))
+        # (the towers' weight gradients go to the third stream only in a step that also runs the history encoder -- there
+        # they are worth 0.1 ms of the 4.3 ms C3 step, underneath the encoder's backward; in the sweep-bound base model the
+        # extra stream hop COSTS 0.06 ms of the 1.15 ms C2 step)
+        if _TOWER_WGRAD_SIDE or _side_state["encoder"]:
+            run_on_side(dev, lambda: tower_weight_grads(dy, tin, d_f, h, dh, feats, out=outs, extra=extra),
+                        hold=(dy, tin, d_f, h, dh, feats, extra), leaves=ctx.tower_leaves)
+        else:
+            tower_weight_grads(dy, tin, d_f, h, dh, feats, out=outs, extra=extra)
+        dW1, db1, dW2, db2, dW3, db3 = outs
         dweight = None
         if ctx.needs_input_grad[0]:
             dweight = _route_table_grad(w, ids.reshape(-1), d_emb, ctx.lookup_index)
@@ -946,6 +1018,9 @@ class HistoryEncoder(_LookupFunction):
         ctx.row0_last = row0_last
         ctx.collapsed_last = collapsed_last
         ctx.collapse_prev = collapse_prev
+        ctx.layer_leaves = tuple(layer_params)  # the Parameter objects themselves (see ops.run_on_side: `leaves`)
+        if L > 0 and _caller_grad_mode[0] and any(ctx.needs_input_grad[4:]):  # (grad mode is always off in here: _recording)
+            _side_state["encoder"] = True
         ctx.table = source if ids is not None else None
         ctx.has_ids = ids is not None
         ctx.save_for_backward(ids, *layer_params, *saved)
@@ -965,6 +1040,14 @@ class HistoryEncoder(_LookupFunction):
         grads: List[Optional[torch.Tensor]] = [None] * (4 * L)
         dx = None  # gradient wrt the current layer's OUTPUT x_{l+1}, [B*H, D]
         prev_out_grads = None
+        leaf_params = ctx.layer_leaves
+
+        def wgrad(dy, xin, dW, tag, l):  # off the critical path: see run_on_side
+            db = torch.empty(dW.shape[0], dtype=torch.float32, device=dev)
+            run_on_side(dev, lambda: gemm_tn_colsum(dy, xin, dW, db=db, slot="ws_side_" + tag), hold=(dy, xin),
+                        leaves=leaf_params[4 * l: 4 * l + 4])
+            return db
+
         for l in reversed(range(L)):
             w_in, b_in, w_out, b_out = layer_params[4 * l: 4 * l + 4]
             if l == L - 1 and ctx.collapsed_last:
@@ -1022,14 +1105,14 @@ class HistoryEncoder(_LookupFunction):
                 d_ctx = torch.zeros(B * H, D, dtype=torch.float32, device=dev)
                 gemm(N.TT_GEMM_NN, d_recent, w_out, d_ctx.view(B, H * D)[:, :D], B, D, D)
             else:
-                _, db_out = gemm_tn_colsum(dx, ctx_t, dW_out)
+                db_out = wgrad(dx, ctx_t, dW_out, "o", l)
                 d_ctx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
                 gemm(N.TT_GEMM_NN, dx, w_out, d_ctx, B * H, D, D)
             d_qkv = torch.empty(B * H, 3 * D, dtype=torch.float32, device=dev)
             N.check(lib.tt_attn_bwd(qkv.data_ptr(), ctx_t.data_ptr(), lse.data_ptr(), d_ctx.data_ptr(), B, H, D,
                                     heads, d_qkv.data_ptr(), N.stream()), "tt_attn_bwd")
             dW_in = torch.empty(3 * D, D, dtype=torch.float32, device=dev)
-            _, db_in = gemm_tn_colsum(d_qkv, x, dW_in)
+            db_in = wgrad(d_qkv, x, dW_in, "i", l)
             dx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
             gemm(N.TT_GEMM_NN, d_qkv, w_in, dx, B * H, D, 3 * D)
             grads[4 * l: 4 * l + 4] = [dW_in, db_in, dW_out, db_out]
