@@ -590,7 +590,11 @@ def test_tiny_batches_and_all_duplicate_ids(kind, B, H):
     # parameters are bounded by steps*lr here; the loss trajectory (above) and the tables are tight.
     for k, v in model.state_dict().items():
         is_table = k.endswith("embedding_arch.weight")
-        assert torch.allclose(v.cpu(), want[k], atol=1e-5 if is_table else 2 * 1.1e-3), k
+        # item_tower_arch.bias / item_features_arch.2.bias: analytically ZERO gradient -- both sides
+        # take +-lr steps of arbitrary sign on rounding noise, so two correct implementations can end 2 * steps * lr apart
+        noise_only = k in ("item_tower_arch.bias", "item_features_arch.2.bias")
+        atol = 1e-5 if is_table else (2 * 2 * 1.05e-3 if noise_only else 2 * 1.1e-3)
+        assert torch.allclose(v.cpu(), want[k], atol=atol), k
 
 
 def test_out_of_range_id_raises_index_error():

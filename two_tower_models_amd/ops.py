@@ -633,6 +633,7 @@ _ENC_LAST_COLLAPSED = os.environ.get("TT_ENC_NO_COLLAPSED_LAST") is None  # last
 # whole-layer forward in one launch (encoder_layer.hip): measured round 4 -- 440 us per layer alone against 375-390 us for
 # the three launches it replaces (one wave per SIMD, rows padded 50 -> 64), and no better next to the sweep; opt-in
 _ENC_FUSED_FWD = os.environ.get("TT_ENC_FUSED_FWD") is not None
+_ENC_FOLD_OUT = os.environ.get("TT_ENC_NO_FOLDED_OUT") is None  # out-projection of layer l composed with the in-projection of l + 1
 _ENC_COLLAPSE_PREV = os.environ.get("TT_ENC_NO_COLLAPSED_PREV") is None  # second-to-last layer's out-projection folded into the last
 
 
@@ -945,6 +946,12 @@ class HistoryEncoder(_LookupFunction):
             note_generic("history-encoder attention",
                          f"the matrix-core kernels take H <= 64 and head width in {{16, 32, 64}}; got H = {H}, head width = {dh}: "
                          "VALU attention" + ("" if row0_last else ", last layer computed for every position"))
+        fold = _ENC_FOLD_OUT and not fused_layer
+
+        def folded_in(l):  # layer l (a full layer, not the first) reads the previous layer's context through composed weights
+            return fold and 1 <= l < L and not (l == L - 1 and row0_last)
+
+        folded_w = {}
         for l in range(L):
             w_in, b_in, w_out, b_out = layer_params[4 * l: 4 * l + 4]
             if l == L - 1 and collapsed_last:
@@ -1002,11 +1009,23 @@ class HistoryEncoder(_LookupFunction):
                 if not last:
                     x = y
                 continue
-            gemm(N.TT_GEMM_NT, x, w_in, qkv, B * H, 3 * D, D, bias=b_in)
+            if folded_in(l):
+                # x is the previous layer's CONTEXT c: x_l = c W_o^T + b_o never exists, the two Linear maps are composed --
+                #   qkv = c (W_in W_o)^T + (W_in b_o + b_in)          ([3D, D] x [D, D]: 12.6 MFLOP instead of a [B*H, D] x [D, D]
+                # out-projection, and its d_ctx / dW_out products in the backward)
+                w_po, b_po = layer_params[4 * (l - 1) + 2], layer_params[4 * (l - 1) + 3]
+                w_eff = torch.empty(3 * D, D, dtype=torch.float32, device=dev)
+                gemm(N.TT_GEMM_NN, w_in, w_po, w_eff, 3 * D, D, D)
+                b_eff = torch.empty(1, 3 * D, dtype=torch.float32, device=dev)
+                gemm(N.TT_GEMM_NT, b_po.view(1, D), w_in, b_eff, 1, 3 * D, D, bias=b_in)
+                gemm(N.TT_GEMM_NT, x, w_eff, qkv, B * H, 3 * D, D, bias=b_eff.view(-1))
+                folded_w[l] = w_eff
+            else:
+                gemm(N.TT_GEMM_NT, x, w_in, qkv, B * H, 3 * D, D, bias=b_in)
             ctx_t, lse = _attn_fwd(qkv, B, H, D, heads)
             saved += [x, qkv, ctx_t, lse]
-            if l + 2 == L and collapse_prev:
-                x = ctx_t  # no out-projection here: the last layer takes the context (csrc/encoder_last.hip, PREV)
+            if (l + 2 == L and collapse_prev) or folded_in(l + 1):
+                x = ctx_t  # no out-projection here: the next layer takes the context (fold above / csrc/encoder_last.hip, PREV)
             elif l + 1 < L:
                 x = torch.empty(B * H, D, dtype=torch.float32, device=dev)
                 gemm(N.TT_GEMM_NT, ctx_t, w_out, x, B * H, D, D, bias=b_out)
@@ -1018,6 +1037,7 @@ class HistoryEncoder(_LookupFunction):
         ctx.row0_last = row0_last
         ctx.collapsed_last = collapsed_last
         ctx.collapse_prev = collapse_prev
+        ctx.folded = {l: w for l, w in folded_w.items()}  # layer -> its composed in-projection weight W_in W_o(prev)
         ctx.layer_leaves = tuple(layer_params)  # the Parameter objects themselves (see ops.run_on_side: `leaves`)
         if L > 0 and _caller_grad_mode[0] and any(ctx.needs_input_grad[4:]):  # (grad mode is always off in here: _recording)
             _side_state["encoder"] = True
@@ -1071,7 +1091,8 @@ class HistoryEncoder(_LookupFunction):
                                             db_in.data_ptr(), dW_out.data_ptr(), db_out.data_ptr(), N.ptr(dW_pa), N.ptr(db_pa),
                                             wsp, wsn, N.stream()), "tt_enc_last_bwd")
                 grads[4 * l: 4 * l + 4] = [dW_in, db_in, dW_out, db_out]
-                prev_out_grads = (dW_pa, db_pa)  # dx is then the gradient of the previous layer's CONTEXT
+                if ctx.collapse_prev:
+                    prev_out_grads = (dW_pa, db_pa)  # dx is then the gradient of the previous layer's CONTEXT
                 continue
             if l == L - 1 and ctx.row0_last:
                 x, kv, q0, ctx0, probs = saved[4 * l: 4 * l + 5]
@@ -1096,9 +1117,10 @@ class HistoryEncoder(_LookupFunction):
                 continue
             x, qkv, ctx_t, lse = saved[4 * l: 4 * l + 4]
             dW_out = torch.empty(D, D, dtype=torch.float32, device=dev)
-            if l == L - 2 and ctx.collapse_prev:
+            if prev_out_grads is not None:  # the layer after this one took the context: its backward produced these
                 dW_out, db_out = prev_out_grads
                 d_ctx = dx
+                prev_out_grads = None
             elif l == L - 1:
                 rows0 = ctx_t.view(B, H * D)[:, :D]
                 _, db_out = gemm_tn_colsum(d_recent, rows0, dW_out)
@@ -1112,9 +1134,33 @@ class HistoryEncoder(_LookupFunction):
             N.check(lib.tt_attn_bwd(qkv.data_ptr(), ctx_t.data_ptr(), lse.data_ptr(), d_ctx.data_ptr(), B, H, D,
                                     heads, d_qkv.data_ptr(), N.stream()), "tt_attn_bwd")
             dW_in = torch.empty(3 * D, D, dtype=torch.float32, device=dev)
-            db_in = wgrad(d_qkv, x, dW_in, "i", l)
-            dx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
-            gemm(N.TT_GEMM_NN, d_qkv, w_in, dx, B * H, D, 3 * D)
+            if l in ctx.folded:
+                # x is the previous layer's context c and qkv = c W_eff^T + b_eff with W_eff = W_in W_o, b_eff = W_in b_o + b_in:
+                #   G = dQKV^T c, s = colsum(dQKV)      dW_in = G W_o^T + s (x) b_o      db_in = s
+                #   dW_o = W_in^T G                      db_o = W_in^T s                  d_c = dQKV W_eff  (the data path)
+                w_po, b_po = layer_params[4 * (l - 1) + 2], layer_params[4 * (l - 1) + 3]
+                w_eff = ctx.folded[l]
+                dx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
+                gemm(N.TT_GEMM_NN, d_qkv, w_eff, dx, B * H, D, 3 * D)
+                G = torch.empty(3 * D, D, dtype=torch.float32, device=dev)
+                db_in = torch.empty(3 * D, dtype=torch.float32, device=dev)
+                dW_po = torch.empty(D, D, dtype=torch.float32, device=dev)
+                db_po = torch.empty(D, dtype=torch.float32, device=dev)
+
+                def folded_weights(d_qkv=d_qkv, x=x, G=G, db_in=db_in, dW_in=dW_in, dW_po=dW_po, db_po=db_po, w_po=w_po, b_po=b_po, w_in=w_in):
+                    gemm_tn_colsum(d_qkv, x, G, db=db_in, slot="ws_side_i")
+                    gemm(N.TT_GEMM_NT, G, w_po, dW_in, 3 * D, D, D)
+                    gemm(N.TT_GEMM_NT, db_in.view(3 * D, 1), b_po.view(D, 1), dW_in, 3 * D, D, 1, accumulate=True)
+                    gemm(N.TT_GEMM_TN, w_in, G, dW_po, D, D, 3 * D)
+                    gemm(N.TT_GEMM_NN, db_in.view(1, 3 * D), w_in, db_po.view(1, D), 1, D, 3 * D)
+
+                run_on_side(dev, folded_weights, hold=(d_qkv, x, G, w_po, b_po, w_in, w_eff),
+                            leaves=list(leaf_params[4 * l: 4 * l + 2]) + list(leaf_params[4 * (l - 1) + 2: 4 * (l - 1) + 4]))
+                prev_out_grads = (dW_po, db_po)
+            else:
+                db_in = wgrad(d_qkv, x, dW_in, "i", l)
+                dx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
+                gemm(N.TT_GEMM_NN, d_qkv, w_in, dx, B * H, D, 3 * D)
             grads[4 * l: 4 * l + 4] = [dW_in, db_in, dW_out, db_out]
         if dx is None:  # L == 0: slot 0 is row 0 of (x + pe)
             dx = torch.zeros(B * H, D, dtype=torch.float32, device=dev)
