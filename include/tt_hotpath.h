@@ -234,13 +234,21 @@ int tt_scale_rows_g(const float* x, int64_t ldx, const float* coef, const float*
  * The forward leaves n, p, e, r and the reduction scalars in `ws` (tt_debias_loss_workspace_bytes(B, DI, n_pos)),
  * which the backward reads; `grad_loss` is the device scalar dL/dloss.  Gradients as torch defines
  * them: clamp(min) passes where input >= min, max() splits evenly over ties.  Positions outside
- * [0, n_pos) raise *oob_flag (torch: IndexError) and read row 0.  d_user_emb is written, not added. */
+ * [0, n_pos) raise *oob_flag (torch: IndexError) and read row 0.  d_user_emb is written, not added.
+ * `mode` (round 4): TT_DEBIAS_COMBINED the above; TT_DEBIAS_POSITION the position-only sibling
+ * (ref:src/two_tower_with_position_debiased_weights.py:76-113: r = max(n / max(p, 1e-3), 1e-6), aux = sum (p - n)^2, lin_w /
+ * lin_b unused, d_user_emb written as zeros); TT_DEBIAS_USER the user-only sibling
+ * (ref:src/two_tower_with_user_debiased_weights.py:100-135: c = max(<user_emb, lin_w[:DI]> + lin_b, 1e-1) first, aux =
+ * sum (c - n)^2, r = max(n / c, 1e-6); lin_w has DI entries, position / pos_table unused and may be NULL). */
+#define TT_DEBIAS_COMBINED 0
+#define TT_DEBIAS_POSITION 1
+#define TT_DEBIAS_USER 2
 int64_t tt_debias_loss_workspace_bytes(int64_t B, int64_t DI, int64_t n_pos);
-int tt_debias_loss_fwd(const float* row_ce, const float* labels, int64_t B, int64_t T, const float* uvw,
+int tt_debias_loss_fwd(int mode, const float* row_ce, const float* labels, int64_t B, int64_t T, const float* uvw,
                        const int64_t* position, int64_t n_pos, const float* pos_table, const float* user_emb,
                        int64_t ld_ue, int64_t DI, const float* lin_w /*[DI+1]*/, const float* lin_b /*[1]*/,
                        float* loss_out, void* ws, int64_t ws_bytes, int32_t* oob_flag, tt_stream_t stream);
-int tt_debias_loss_bwd(const float* grad_loss, const float* row_ce, int64_t B, const int64_t* position,
+int tt_debias_loss_bwd(int mode, const float* grad_loss, const float* row_ce, int64_t B, const int64_t* position,
                        int64_t n_pos, const float* user_emb, int64_t ld_ue, int64_t DI, const float* lin_w,
                        const void* ws, int64_t ws_bytes, float* d_row_ce, float* d_user_emb, int64_t ld_due,
                        float* d_pos_table /*[n_pos]*/, float* d_lin_w /*[DI+1]*/, float* d_lin_b /*[1]*/,

@@ -333,6 +333,71 @@ def test_debias_loss_head_matches_torch_expressions(T, B, Tn, DI, case):
         N.oob.poll(torch.device(DEV), blocking=True)
 
 
+@pytest.mark.parametrize("mode", ["position", "user"])
+@pytest.mark.parametrize("B,Tn,DI,case", [(64, 1, 128, "plain"), (1000, 3, 40, "plain"), (8192, 1, 128, "plain"),
+                                          (300, 1, 64, "all_zero_labels"), (257, 2, 32, "clamped_priors"), (1, 1, 8, "plain")])
+def test_single_term_debias_heads_match_torch_expressions(T, B, Tn, DI, case, mode):
+    """The fused head's position-only / user-only modes (tt_debias_loss_fwd(mode = TT_DEBIAS_POSITION | TT_DEBIAS_USER))
+    against the two sibling hooks' tensor expressions (ref:src/two_tower_with_position_debiased_weights.py:95-113: the MSE
+    sees the RAW prior, the division its 1e-3-clamped copy; ref:src/two_tower_with_user_debiased_weights.py:121-135: the
+    1e-1 clamp comes FIRST, a clamped row sends the head no gradient) on ref:src/two_tower_base_retrieval.py:334-343, in
+    float64: loss and every gradient, incl. all-tied weights and priors below their clamp."""
+    ops, N = T
+    row_ce = (g((B,), 111).abs() * 3 + 0.1)
+    labels = (fg.hashed_u64((B, Tn), 112) % np.uint64(2)).astype(np.float32)
+    if case == "all_zero_labels":
+        labels[:] = 0.0
+    labels = torch.from_numpy(labels)
+    uvw = torch.tensor([1.0, 0.5, 2.0][:Tn])
+    position = torch.from_numpy((fg.hashed_u64((B,), 113) % np.uint64(100)).astype(np.int64))
+    ue = g((B, DI), 114) * 0.5
+    pos_table = g((100, 1), 115) * 0.3 + (0.0 if case == "clamped_priors" else 0.8)
+    lin_w = g((1, DI), 116) * (0.02 if case != "clamped_priors" else 0.2)
+    lin_b = torch.tensor([0.7 if case != "clamped_priors" else 0.05])
+
+    def reference(row_ce, ue, pos_table, lin_w, lin_b):
+        nuv = torch.sum(labels.double() * uvw.double(), dim=-1)
+        if mode == "position":
+            prior = pos_table[position, 0]
+            aux = torch.sum((prior - nuv) ** 2)
+            w = nuv / prior.clamp(min=1e-3)
+        else:
+            prior = (ue @ lin_w[0] + lin_b[0]).clamp(min=1e-1)
+            aux = torch.sum((prior - nuv) ** 2)
+            w = nuv / prior
+        w = torch.clamp(w, min=0.000001)
+        w = w / torch.max(w)
+        return torch.mean(row_ce * w) + aux
+
+    leaves64 = [t.double().requires_grad_(True) for t in (row_ce, ue, pos_table, lin_w, lin_b)]
+    want = reference(*leaves64)
+    want.backward()
+    leaves = [t.to(DEV).requires_grad_(True) for t in (row_ce, ue, pos_table, lin_w, lin_b)]
+
+    def run(lv):
+        if mode == "position":
+            return ops.DebiasedWeightedLoss.apply(lv[0], labels.to(DEV), uvw.to(DEV), position.to(DEV), lv[1], lv[2], None, None,
+                                                  N.TT_DEBIAS_POSITION)
+        return ops.DebiasedWeightedLoss.apply(lv[0], labels.to(DEV), uvw.to(DEV), position.to(DEV), lv[1], None, lv[3], lv[4],
+                                              N.TT_DEBIAS_USER)
+
+    got = run(leaves)
+    assert abs(got.item() - want.item()) <= 2e-6 * max(1.0, abs(want.item()))
+    got.backward()
+    used = {"position": ("row_ce", "user_emb", "pos_table"), "user": ("row_ce", "user_emb", "lin_w", "lin_b")}[mode]
+    for name, a, b in zip(("row_ce", "user_emb", "pos_table", "lin_w", "lin_b"), leaves, leaves64):
+        if name not in used:
+            assert a.grad is None
+            continue
+        want_g = b.grad if b.grad is not None else torch.zeros_like(b)
+        scale = float(want_g.abs().max())
+        assert torch.allclose(a.grad.cpu().double(), want_g, atol=2e-5 * scale + 1e-12, rtol=2e-4), (name, case, mode)
+    leaves2 = [t.to(DEV).requires_grad_(True) for t in (row_ce, ue, pos_table, lin_w, lin_b)]
+    got2 = run(leaves2)
+    got2.backward()
+    assert torch.equal(got2, got) and all(a.grad is None or torch.equal(a.grad, b.grad) for a, b in zip(leaves, leaves2))
+
+
 @pytest.mark.parametrize("B,H,D,heads", [(9, 50, 128, 4), (5, 64, 64, 4), (3, 1, 32, 2), (70, 7, 48, 3)])
 def test_single_query_attention_matches_full_attention_row0(T, B, H, D, heads):
     """tt_attn_row0_fwd / _bwd (the encoder's last layer: only history position 0 is consumed) against

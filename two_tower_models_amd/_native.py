@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("TT_HOTPATH_LIB") or os.path.join(_PKG, "lib", "libtt_
 TT_GEMM_NT, TT_GEMM_NN, TT_GEMM_TN = 0, 1, 2
 TT_EPI_NONE, TT_EPI_RELU, TT_EPI_RELU_MASK = 0, 1, 2
 TT_F32, TT_BF16 = 0, 1
+TT_DEBIAS_COMBINED, TT_DEBIAS_POSITION, TT_DEBIAS_USER = 0, 1, 2
 TT_COMM_ID_BYTES = 128
 TT_COMM_F32, TT_COMM_I32, TT_COMM_I64, TT_COMM_U8 = 0, 1, 2, 3
 TT_COMM_SUM, TT_COMM_MAX = 0, 1
@@ -105,9 +106,9 @@ SIGNATURES = {
     "tt_value_weights": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "tt_weighted_loss_global": (_int, [_vp, _vp, _vp, _i64, C.c_float, _vp, _vp, _vp]),
     "tt_debias_loss_workspace_bytes": (_i64, [_i64, _i64, _i64]),
-    "tt_debias_loss_fwd": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64,
+    "tt_debias_loss_fwd": (_int, [_int, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64,
                                   _vp, _vp]),
-    "tt_debias_loss_bwd": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp,
+    "tt_debias_loss_bwd": (_int, [_int, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp,
                                   _vp, _vp]),
     "tt_rowgrad_workspace_bytes": (_i64, [_i64]),
     "tt_rowgrad_plan": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

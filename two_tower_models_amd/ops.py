@@ -843,37 +843,50 @@ class InBatchSoftmaxWeightedLoss(torch.autograd.Function):
 
 
 class DebiasedWeightedLoss(torch.autograd.Function):
-    """mean_i(row_ce_i * w_i) + aux of the combined debias head (ref:src/two_tower_with_debiasing.py:77-129
-    on ref:src/two_tower_base_retrieval.py:322-345), in two kernels forward and two backward
-    (tt_debias_loss_fwd / _bwd).  labels [B, T], position [B] int64, user_embedding [B, DI],
-    pos_table [n_pos, 1], lin_w [1, DI + 1], lin_b [1]."""
+    """mean_i(row_ce_i * w_i) + aux of a debias head (ref:src/two_tower_with_debiasing.py:77-129,
+    ref:src/two_tower_with_position_debiased_weights.py:76-113, ref:src/two_tower_with_user_debiased_weights.py:100-135,
+    each on ref:src/two_tower_base_retrieval.py:322-345), in two kernels forward and three backward
+    (tt_debias_loss_fwd / _bwd).  labels [B, T], position [B] int64, user_embedding [B, DI].
+    mode N.TT_DEBIAS_COMBINED: pos_table [n_pos, 1], lin_w [1, DI + 1], lin_b [1];  TT_DEBIAS_POSITION: pos_table only
+    (lin_w = lin_b = None);  TT_DEBIAS_USER: lin_w [1, DI], lin_b [1] (pos_table = None, position ignored)."""
 
     @staticmethod
-    def forward(ctx, row_ce, labels, uvw, position, user_embedding, pos_table, lin_w, lin_b):
+    def forward(ctx, row_ce, labels, uvw, position, user_embedding, pos_table, lin_w, lin_b, mode=0):
         dev = N.require_device(row_ce, labels, uvw, position, user_embedding, pos_table, lin_w, lin_b)
         lib = N.load()
         labels, position = _labels_f32(labels, "DebiasedWeightedLoss"), position.contiguous()
-        if any(t.dtype != torch.float32 for t in (row_ce, uvw, user_embedding, pos_table, lin_w, lin_b)):
+        if any(t is not None and t.dtype != torch.float32 for t in (row_ce, uvw, user_embedding, pos_table, lin_w, lin_b)):
             raise TypeError("DebiasedWeightedLoss: float32 operands expected")
         row_ce, ue = row_ce.contiguous(), _rowmajor(user_embedding)
-        pos_table, lin_w, lin_b = pos_table.contiguous(), lin_w.contiguous(), lin_b.contiguous()
+        pos_table = pos_table.contiguous() if pos_table is not None else None
+        lin_w = lin_w.contiguous() if lin_w is not None else None
+        lin_b = lin_b.contiguous() if lin_b is not None else None
         B, T = labels.shape
         pue, _, DI, ld_ue = _f32_2d(ue, "user_embedding")
-        if position.dtype != torch.int64 or pos_table.shape[1] != 1 or lin_w.numel() != DI + 1 or uvw.numel() != T:
-            raise TypeError("DebiasedWeightedLoss: position int64 [B], pos_table [n_pos, 1], lin_w [1, DI + 1], uvw [T]")
-        wsn = lib.tt_debias_loss_workspace_bytes(B, DI, pos_table.shape[0])
+        want_w = {N.TT_DEBIAS_COMBINED: DI + 1, N.TT_DEBIAS_POSITION: None, N.TT_DEBIAS_USER: DI}[mode]
+        if (position.dtype != torch.int64 or uvw.numel() != T
+                or (mode != N.TT_DEBIAS_USER and (pos_table is None or pos_table.shape[1] != 1))
+                or (want_w is not None and (lin_w is None or lin_b is None or lin_w.numel() != want_w))):
+            raise TypeError("DebiasedWeightedLoss: position int64 [B], pos_table [n_pos, 1], lin_w [1, DI + 1] (combined) / "
+                            "[1, DI] (user-only), uvw [T]")
+        n_pos = pos_table.shape[0] if pos_table is not None else 1
+        wsn = lib.tt_debias_loss_workspace_bytes(B, DI, n_pos)
         ws = torch.empty(wsn, dtype=torch.uint8, device=dev)  # kept for the backward (n, p, e, r, scalars)
         loss = torch.empty((), dtype=torch.float32, device=dev)
-        N.check(lib.tt_debias_loss_fwd(row_ce.data_ptr(), labels.data_ptr(), B, T, uvw.data_ptr(), position.data_ptr(),
-                                       pos_table.shape[0], pos_table.data_ptr(), pue, ld_ue, DI, lin_w.data_ptr(),
-                                       lin_b.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsn, N.oob.flag(dev).data_ptr(),
-                                       N.stream()), "tt_debias_loss_fwd")
-        ctx.save_for_backward(row_ce, position, ue, pos_table, lin_w, lin_b, ws)
+        N.check(lib.tt_debias_loss_fwd(mode, row_ce.data_ptr(), labels.data_ptr(), B, T, uvw.data_ptr(), position.data_ptr(),
+                                       n_pos, N.ptr(pos_table), pue, ld_ue, DI, N.ptr(lin_w), N.ptr(lin_b), loss.data_ptr(),
+                                       ws.data_ptr(), wsn, N.oob.flag(dev).data_ptr(), N.stream()), "tt_debias_loss_fwd")
+        ctx.mode, ctx.n_pos = mode, n_pos
+        ctx.have = (pos_table is not None, lin_w is not None)
+        ctx.save_for_backward(row_ce, position, ue, ws, *(t for t in (pos_table, lin_w, lin_b) if t is not None))
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        row_ce, position, ue, pos_table, lin_w, lin_b, ws = ctx.saved_tensors
+        row_ce, position, ue, ws, *rest = ctx.saved_tensors
+        has_pos, has_lin = ctx.have
+        pos_table = rest.pop(0) if has_pos else None
+        lin_w, lin_b = (rest[0], rest[1]) if has_lin else (None, None)
         dev = row_ce.device
         lib = N.load()
         B = row_ce.shape[0]
@@ -881,13 +894,13 @@ class DebiasedWeightedLoss(torch.autograd.Function):
         g = g.contiguous().to(torch.float32)
         d_ce = torch.empty(B, dtype=torch.float32, device=dev)
         d_ue = torch.empty(B, DI, dtype=torch.float32, device=dev)
-        d_pos = torch.empty_like(pos_table)
-        d_w, d_b = torch.empty_like(lin_w), torch.empty_like(lin_b)
-        N.check(lib.tt_debias_loss_bwd(g.data_ptr(), row_ce.data_ptr(), B, position.data_ptr(), pos_table.shape[0], pue,
-                                       ld_ue, DI, lin_w.data_ptr(), ws.data_ptr(), ws.numel(), d_ce.data_ptr(),
-                                       d_ue.data_ptr(), DI, d_pos.data_ptr(), d_w.data_ptr(), d_b.data_ptr(), N.stream()),
+        d_pos = torch.empty_like(pos_table) if has_pos else None
+        d_w, d_b = (torch.empty_like(lin_w), torch.empty_like(lin_b)) if has_lin else (None, None)
+        N.check(lib.tt_debias_loss_bwd(ctx.mode, g.data_ptr(), row_ce.data_ptr(), B, position.data_ptr(), ctx.n_pos, pue,
+                                       ld_ue, DI, N.ptr(lin_w), ws.data_ptr(), ws.numel(), d_ce.data_ptr(),
+                                       d_ue.data_ptr(), DI, N.ptr(d_pos), N.ptr(d_w), N.ptr(d_b), N.stream()),
                 "tt_debias_loss_bwd")
-        return d_ce, None, None, None, d_ue, d_pos, d_w, d_b
+        return d_ce, None, None, None, d_ue, d_pos, d_w, d_b, None
 
 
 # ----------------------------------------------------------------- history encoder

@@ -2,17 +2,24 @@
 
 The history model with ONE extra parameter tensor -- a scalar prior of the net user value per position bucket,
 `position_bias_net_user_value` Embedding(100, 1) (ref :72-74) -- and its `debias_net_user_value` hook (ref :76-113).
-Lookups, towers, encoder, in-batch logits / CE and the optimiser are the inherited HIP path; the hook itself is five
-[B]-sized tensor expressions and runs as such on the GPU (the general branch of
-TwoTowerBaseRetrieval.compute_training_loss, which keeps every hook override exact)."""
+Lookups, towers, encoder, in-batch logits / CE and the optimiser are the inherited HIP path; the loss head -- hook,
+clamp, division by the batch maximum, weighted mean -- is the fused debias kernel in its position-only mode
+(csrc/debias.hip, TT_DEBIAS_POSITION).  A subclass that overrides the hook again, or labels the kernel does
+not take, fall back to the hook's tensor expressions (general branch of TwoTowerBaseRetrieval.compute_training_loss)."""
 from __future__ import annotations
 
 from typing import List, Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 
+from . import _native as N
+from . import ops
 from .two_tower_with_user_history_encoder import TwoTowerWithUserHistoryEncoder
+
+_FUSED_HEAD = os.environ.get("TT_DEBIAS_NO_FUSED") is None  # A/B switch (DESIGN.md section 9)
 
 
 class TwoTowerWithPositionDebiasedWeights(TwoTowerWithUserHistoryEncoder):
@@ -32,3 +39,13 @@ class TwoTowerWithPositionDebiasedWeights(TwoTowerWithUserHistoryEncoder):
         prior = self.position_bias_net_user_value.weight[position, 0]  # [B]
         aux = torch.sum((prior - net_user_value) ** 2)
         return net_user_value / prior.clamp(min=1e-3), aux
+
+    def compute_training_loss(self, user_embedding: torch.Tensor, item_embeddings: torch.Tensor,
+                              position: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        hook_is_mine = type(self).debias_net_user_value is TwoTowerWithPositionDebiasedWeights.debias_net_user_value
+        if not (_FUSED_HEAD and hook_is_mine and labels.dim() == 2 and labels.shape[1] == self.user_value_weights.numel()
+                and ops.labels_fusable(labels) and user_embedding.is_cuda):
+            return super().compute_training_loss(user_embedding, item_embeddings, position, labels)
+        row_ce = ops.InBatchSoftmaxCE.apply(user_embedding, item_embeddings, 0)  # [B]
+        return ops.DebiasedWeightedLoss.apply(row_ce, labels, self.user_value_weights, position, user_embedding,
+                                              self.position_bias_net_user_value.weight, None, None, N.TT_DEBIAS_POSITION)

@@ -2,16 +2,24 @@
 
 The history model plus a one-unit head on the user embedding, `user_debias_net_user_value` = Sequential(Linear(DI, 1))
 (ref :96-100), that estimates how much value a user yields whatever is shown; the example weight is divided by it
-(ref :102-135).  Everything up to the [B]-sized hook is the inherited HIP path; the hook runs as tensor expressions on
-the GPU (general branch of TwoTowerBaseRetrieval.compute_training_loss)."""
+(ref :102-135).  Everything up to the loss head is the inherited HIP path; the head -- hook (the Linear(DI, 1) prior with
+its clamp FIRST), clamp, division by the batch maximum, weighted mean -- is the fused debias kernel in its user-only
+mode (csrc/debias.hip, TT_DEBIAS_USER): no library gemv on the product path.  A subclass that overrides
+the hook again, or labels the kernel does not take, fall back to the hook's tensor expressions."""
 from __future__ import annotations
 
 from typing import List, Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 
+from . import _native as N
+from . import ops
 from .two_tower_with_user_history_encoder import TwoTowerWithUserHistoryEncoder
+
+_FUSED_HEAD = os.environ.get("TT_DEBIAS_NO_FUSED") is None  # A/B switch (DESIGN.md section 9)
 
 
 class TwoTowerWithUserDebiasedWeights(TwoTowerWithUserHistoryEncoder):
@@ -33,3 +41,14 @@ class TwoTowerWithUserDebiasedWeights(TwoTowerWithUserHistoryEncoder):
         prior = (user_embedding @ head.weight[0] + head.bias[0]).clamp(min=1e-1)  # [B]
         aux = torch.sum((prior - net_user_value) ** 2)
         return net_user_value / prior, aux
+
+    def compute_training_loss(self, user_embedding: torch.Tensor, item_embeddings: torch.Tensor,
+                              position: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        hook_is_mine = type(self).debias_net_user_value is TwoTowerWithUserDebiasedWeights.debias_net_user_value
+        if not (_FUSED_HEAD and hook_is_mine and labels.dim() == 2 and labels.shape[1] == self.user_value_weights.numel()
+                and ops.labels_fusable(labels) and user_embedding.is_cuda):
+            return super().compute_training_loss(user_embedding, item_embeddings, position, labels)
+        row_ce = ops.InBatchSoftmaxCE.apply(user_embedding, item_embeddings, 0)  # [B]
+        head = self.user_debias_net_user_value[0]
+        return ops.DebiasedWeightedLoss.apply(row_ce, labels, self.user_value_weights, position, user_embedding,
+                                              None, head.weight, head.bias, N.TT_DEBIAS_USER)
