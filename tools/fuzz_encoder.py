@@ -1,0 +1,106 @@
+"""Randomised differential check of UserHistoryEncoder (forward, input gradient, every parameter gradient) against the
+CPU oracle's full attention stack (oracle/cpu_ref.history_encoder_forward, every position of every layer, row 0 taken
+at the end): random width, history length, head count, layer count (1 = only the collapsed last layer, 2 = collapsed
+last + handed-over context, >= 3 adds folded layer boundaries), positional table on / off, batch sizes around the
+32-row tiles, and -- every third case -- gradients accumulated over two backward passes (the weight-gradient products
+then run on the main stream: .grad is not None).  A mismatch is re-examined against the oracle evaluated in float64:
+the report then says how far each side is from it.     python tools/fuzz_encoder.py [seconds] [seed] [only-this-case]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import two_tower_models_amd as A
+from oracle import cpu_ref as R
+
+DEV = "cuda:0"
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None
+rng = np.random.default_rng(seed)
+t0, n, bad = time.time(), 0, 0
+while time.time() - t0 < budget:
+    heads = int(rng.choice([1, 2, 4, 4, 4, 8, 16]))
+    hd = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 32]))
+    D = heads * hd
+    if D > 256:
+        continue
+    H = int(rng.choice([1, 2, 3, 8, 20, 31, 32, 33, 50, 55, 56, 64, 65, 100, 128]))
+    L = int(rng.choice([1, 2, 3, 3, 3, 4, 6]))
+    B = int(rng.choice([1, 2, 3, 31, 32, 33, 64, 100, 257, 512]))
+    pe = bool(rng.integers(0, 2))
+    twice = n % 3 == 2
+    what = f"case {n}: D={D} heads={heads} H={H} L={L} B={B} pe={pe} accumulate={twice}"
+    if only is not None and n != only:
+        n += 1
+        if n > only:
+            break
+        continue
+    try:
+        torch.manual_seed(5000 + n)
+        enc = A.UserHistoryEncoder(D, H, heads, L, pe)
+        with torch.no_grad():
+            for name, p in enc.named_parameters():
+                if name.endswith("bias"):
+                    p.normal_(0, 0.1)  # the reference initialises them to zero; make every bias gradient path visible
+        params = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+        enc = enc.to(DEV)
+        g = torch.Generator().manual_seed(9 + n)
+        x = torch.randn(B, H, D, generator=g)
+        cot = torch.randn(B, 2, D, generator=g)
+        xd = x.to(DEV).requires_grad_(True)
+        reps = 2 if twice else 1
+        for _ in range(reps):
+            y = enc(xd)
+            (y * cot.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        leaves = {k: v.clone().requires_grad_(True) for k, v in params.items() }
+        xl = x.clone().requires_grad_(True)
+        table = enc.positional_embeddings.cpu() if pe else None
+        want = R.history_encoder_forward(xl, R.encoder_layers_from_params(leaves, prefix=""), heads, table)
+        (want * cot).sum().backward()
+        msgs = []
+        l64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
+        x64 = x.double().requires_grad_(True)
+
+        def in_float64():
+            if x64.grad is None:
+                w64 = R.history_encoder_forward(x64, R.encoder_layers_from_params(l64, prefix=""), heads,
+                                                table.double() if pe else None)
+                (w64 * cot.double()).sum().backward()
+            return {"x": x64.grad, **{k: v.grad for k, v in l64.items()}}
+
+        if not torch.allclose(y.detach().cpu(), want.detach(), atol=1e-5, rtol=1e-5):
+            msgs.append(f"output: max err {float((y.detach().cpu() - want.detach()).abs().max()):.3e}")
+
+        def cmp(got, gw, name):
+            gw = gw * reps
+            tol = max(1e-5 * float(gw.abs().max()), 1e-7) + 2e-4 * gw.abs()
+            if name.endswith("in_proj_bias"):  # K third: analytically zero (softmax shift invariance)
+                tol = tol + 1e-6 * max(1.0, float(gw.abs().max()))
+            out = int(((got - gw).abs() > tol).sum())
+            if out:
+                g64 = in_float64()[name] * reps
+                bad_at = (got - gw).abs() > tol
+                msgs.append(f"grad {name}: {out} elements, max err {float((got - gw).abs().max()):.3e} (max |g| {float(gw.abs().max()):.3e}); "
+                            f"there, vs float64: GPU {float((got.double() - g64)[bad_at].abs().max()):.3e}, "
+                            f"fp32 oracle {float((gw.double() - g64)[bad_at].abs().max()):.3e}")
+
+        cmp(xd.grad.cpu(), xl.grad, "x")
+        for name, p in enc.named_parameters():
+            if name not in leaves:
+                continue
+            gw = leaves[name].grad if leaves[name].grad is not None else torch.zeros_like(leaves[name])
+            cmp(p.grad.cpu() if p.grad is not None else torch.zeros_like(gw), gw, name)
+        if msgs:
+            bad += 1
+            print("MISMATCH", what, "|", "; ".join(msgs), flush=True)
+    except Exception as e:  # a crash is a finding too
+        bad += 1
+        print("ERROR", what, "|", type(e).__name__, str(e)[:300], flush=True)
+    n += 1
+print(f"{n} cases, {bad} findings in {time.time() - t0:.0f} s")

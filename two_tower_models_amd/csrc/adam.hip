@@ -25,7 +25,7 @@ constexpr int SWEEP_MAX_TABLES_DECL = 4;  // = SWEEP_MAX_TABLES (tables per mult
 constexpr int SWEEP_DEFAULT_PERSIST = 3;
 
 struct AdamConst {
-  float one_minus_b1, b2, one_minus_b2, eps, neg_step_size, bc2_sqrt;
+  float one_minus_b1, b2, one_minus_b2, eps, neg_step_size, inv_bc2_sqrt;
 };
 
 __device__ __forceinline__ AdamConst load_hyper(const double* __restrict__ h) {
@@ -35,24 +35,35 @@ __device__ __forceinline__ AdamConst load_hyper(const double* __restrict__ h) {
   c.one_minus_b2 = (float)(1.0 - h[2]);
   c.eps = (float)h[3];
   c.neg_step_size = (float)(-h[5]);
-  c.bc2_sqrt = (float)h[6];
+  c.inv_bc2_sqrt = (float)(1.0 / h[6]);
   return c;
 }
 
 // Every fused multiply-add is spelled out: left to -ffp-contract the compiler picks a different
 // pairing in different kernels (fma(t, g, v*b2) in one, fma(v, b2, t*g) in another), and the
 // schedules (serial / overlapped / deferred) must agree to the bit.
+//
+// m / (sqrt(v) / c + eps) is ONE function shared by every kernel and schedule (so they keep agreeing to the bit) and it is
+// built from the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32 and the reciprocal of c prepared per step: 5 VALU issues, two
+// of them quarter-rate, instead of an IEEE square root and two IEEE divisions (~30).  The dense sweep is HBM-bound and
+// does not notice; the deferred schedule's replay (pure VALU work) is what gets cheaper.  Error: a few ulp of an update
+// that is itself <= lr in size, i.e. orders of magnitude below the rounding of p += ... -- the trajectory tests against
+// the reference fixture hold at their old tolerances.  v_sqrt_f32 takes a denormal v as 0: sqrt(v) < 1.1e-19 there,
+// invisible next to any eps in use (torch's default is 1e-8); the floor keeps eps = 0 with v = 0 from producing
+// 0 * inf (torch itself returns NaN there: 0 / 0).
+__device__ __forceinline__ float adam_ratio(float m, float v, const AdamConst& c) {
+  const float denom = fmaxf(fmaf(__builtin_amdgcn_sqrtf(v), c.inv_bc2_sqrt, c.eps), 1e-30f);
+  return m * __builtin_amdgcn_rcpf(denom);
+}
 __device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float g, const AdamConst& c) {
   m = fmaf(c.one_minus_b1, g - m, m);
   v = fmaf(c.one_minus_b2 * g, g, v * c.b2);
-  const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
-  p = fmaf(c.neg_step_size, m / denom, p);
+  p = fmaf(c.neg_step_size, adam_ratio(m, v, c), p);
 }
 __device__ __forceinline__ void adam_elem_zero_grad(float& p, float& m, float& v, const AdamConst& c) {
   m = fmaf(c.one_minus_b1, -m, m);
   v = v * c.b2;
-  const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
-  p = fmaf(c.neg_step_size, m / denom, p);
+  p = fmaf(c.neg_step_size, adam_ratio(m, v, c), p);
 }
 
 // step-dependent constants exactly as load_hyper() hands them to the kernels
@@ -62,7 +73,7 @@ __device__ __forceinline__ void step_consts_from_doubles(double lr, double b1, d
   h6 = sqrt(1.0 - pow(b2, step));
 }
 // tab (optional): per-step constants for the deferred schedule, tab[2j] = (float)(-h5_j),
-// tab[2j+1] = (float)h6_j -- the values every dense kernel of step j saw
+// tab[2j+1] = (float)(1 / h6_j) -- the values every dense kernel of step j saw
 __global__ void adam_advance_kernel(double* h, float* tab, int64_t tab_cap) {
   const double step = h[4] + 1.0;
   h[4] = step;
@@ -70,7 +81,7 @@ __global__ void adam_advance_kernel(double* h, float* tab, int64_t tab_cap) {
   const int64_t j = (int64_t)step;
   if (tab && j < tab_cap) {
     tab[2 * j] = (float)(-h[5]);
-    tab[2 * j + 1] = (float)h[6];
+    tab[2 * j + 1] = (float)(1.0 / h[6]);
   }
 }
 
@@ -210,7 +221,7 @@ __global__ __launch_bounds__(256) void adam_begin_ids_kernel(const StashJobs job
       const int64_t j = (int64_t)step;
       if (tab && j < tab_cap) {
         tab[2 * j] = (float)(-h[5]);
-        tab[2 * j + 1] = (float)h[6];
+        tab[2 * j + 1] = (float)(1.0 / h[6]);
       }
     }
     return;
@@ -511,17 +522,17 @@ __device__ __forceinline__ void replay_consts(AdamConst& c, const double* __rest
                                               int64_t cap, int64_t j) {
   if (j < cap) {
     c.neg_step_size = tab[2 * j];
-    c.bc2_sqrt = tab[2 * j + 1];
+    c.inv_bc2_sqrt = tab[2 * j + 1];
   } else {  // beyond the table: the same double arithmetic adam_advance_kernel performs
     double h5, h6;
     step_consts_from_doubles(h[0], h[1], h[2], (double)j, h5, h6);
     c.neg_step_size = (float)(-h5);
-    c.bc2_sqrt = (float)h6;
+    c.inv_bc2_sqrt = (float)(1.0 / h6);
   }
 }
 
 // one wavefront replays steps from+1 .. to of one row (zero gradient), Q elements per lane and
-// chunk of 64*Q columns.  The replay is pure VALU work (IEEE sqrt and two divisions per element
+// chunk of 64*Q columns.  The replay is pure VALU work (adam_ratio: 7 VALU issues per element
 // and step), so Q is matched to the row width -- no lane computes padding.
 template <int Q>
 __device__ __forceinline__ void replay_row_q(float* __restrict__ W, float* __restrict__ M, float* __restrict__ V,

@@ -113,8 +113,9 @@ def run_on_side(dev: torch.device, fn, hold: Sequence[Optional[torch.Tensor]] = 
 
 def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, M: int, Nn: int, K: int,
          bias: Optional[torch.Tensor] = None, epilogue: int = N.TT_EPI_NONE,
-         aux: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
-    """out[M,N] (+)= op(A) op(B) (+bias) -- see tt_gemm_f32.  A/B/out may be strided row views."""
+         aux: Optional[torch.Tensor] = None, accumulate: bool = False, slot: str = "ws") -> torch.Tensor:
+    """out[M,N] (+)= op(A) op(B) (+bias) -- see tt_gemm_f32.  A/B/out may be strided row views.
+    slot: which scratch buffer a split-K plan may use (calls queued on the side stream must not share the main one's)."""
     dev = N.require_device(A, B, out, bias, aux)
     lib = N.load()
     pa, _, _, lda = _f32_2d(A, "A")
@@ -123,7 +124,7 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, M: in
     paux, ldaux = (None, 0)
     if aux is not None:
         paux, _, _, ldaux = _f32_2d(aux, "aux")
-    wsp, wsn = _ws(dev, lib.tt_gemm_workspace_bytes(layout, M, Nn, K))
+    wsp, wsn = _ws(dev, lib.tt_gemm_workspace_bytes(layout, M, Nn, K), slot)
     N.check(lib.tt_gemm_f32(layout, M, Nn, K, pa, lda, pb, ldb, pc, ldc, N.ptr(bias), epilogue, paux, ldaux,
                             1 if accumulate else 0, wsp, wsn, N.stream()), "tt_gemm_f32")
     return out
@@ -1153,8 +1154,6 @@ class HistoryEncoder(_LookupFunction):
                 #   dW_o = W_in^T G                      db_o = W_in^T s                  d_c = dQKV W_eff  (the data path)
                 w_po, b_po = layer_params[4 * (l - 1) + 2], layer_params[4 * (l - 1) + 3]
                 w_eff = ctx.folded[l]
-                dx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
-                gemm(N.TT_GEMM_NN, d_qkv, w_eff, dx, B * H, D, 3 * D)
                 G = torch.empty(3 * D, D, dtype=torch.float32, device=dev)
                 db_in = torch.empty(3 * D, dtype=torch.float32, device=dev)
                 dW_po = torch.empty(D, D, dtype=torch.float32, device=dev)
@@ -1162,13 +1161,16 @@ class HistoryEncoder(_LookupFunction):
 
                 def folded_weights(d_qkv=d_qkv, x=x, G=G, db_in=db_in, dW_in=dW_in, dW_po=dW_po, db_po=db_po, w_po=w_po, b_po=b_po, w_in=w_in):
                     gemm_tn_colsum(d_qkv, x, G, db=db_in, slot="ws_side_i")
-                    gemm(N.TT_GEMM_NT, G, w_po, dW_in, 3 * D, D, D)
-                    gemm(N.TT_GEMM_NT, db_in.view(3 * D, 1), b_po.view(D, 1), dW_in, 3 * D, D, 1, accumulate=True)
-                    gemm(N.TT_GEMM_TN, w_in, G, dW_po, D, D, 3 * D)
-                    gemm(N.TT_GEMM_NN, db_in.view(1, 3 * D), w_in, db_po.view(1, D), 1, D, 3 * D)
+                    gemm(N.TT_GEMM_NT, G, w_po, dW_in, 3 * D, D, D, slot="ws_side_g")
+                    gemm(N.TT_GEMM_NT, db_in.view(3 * D, 1), b_po.view(D, 1), dW_in, 3 * D, D, 1, accumulate=True, slot="ws_side_g")
+                    gemm(N.TT_GEMM_TN, w_in, G, dW_po, D, D, 3 * D, slot="ws_side_g")
+                    gemm(N.TT_GEMM_NN, db_in.view(1, 3 * D), w_in, db_po.view(1, D), 1, D, 3 * D, slot="ws_side_g")
 
+                # queued BEFORE the data-path product below: the side stream starts where the main one stands now
                 run_on_side(dev, folded_weights, hold=(d_qkv, x, G, w_po, b_po, w_in, w_eff),
                             leaves=list(leaf_params[4 * l: 4 * l + 2]) + list(leaf_params[4 * (l - 1) + 2: 4 * (l - 1) + 4]))
+                dx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
+                gemm(N.TT_GEMM_NN, d_qkv, w_eff, dx, B * H, D, 3 * D)
                 prev_out_grads = (dW_po, db_po)
             else:
                 db_in = wgrad(d_qkv, x, dW_in, "i", l)
