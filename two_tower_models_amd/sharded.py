@@ -138,6 +138,14 @@ def reduce_scatter_rows(x: torch.Tensor) -> torch.Tensor:
 # 4.237 vs 4.246 ms per step; not the default.
 _UTOWER_EARLY = os.environ.get("TT_SHARDED_EARLY_UTOWER") is not None
 _LOSS_KERNELS = os.environ.get("TT_SHARDED_TORCH_LOSS") is None  # A/B: the value-weight tail as two kernels
+# Opt-in (TT_SHARDED_PLAN_ASIDE=1): the NEXT batch's route plan (owner histogram + scan per lookup, the MAX all-reduce
+# of the bucket sizes, their copy to the host) on the library's third stream at the very top of the step instead of on
+# the main stream after the lookups -- eight small launches leave the critical path: emulated W = 8 step 4.09 -> 4.05 ms
+# (three A/B pairs on one box).  It has to be the EXISTING third stream (ops.run_on_side: a new HIP stream may share the
+# sweep's hardware queue, which is what made the first attempt slower).  Not the default: it issues that all-reduce
+# from a second stream while the lookups' exchanges are in flight on the first, a pattern no multi-GPU run has
+# exercised yet, and 1 % is not worth a surprise there.
+_PLAN_ASIDE = os.environ.get("TT_SHARDED_PLAN_ASIDE") is not None
 
 
 # Per-exchange timing (bench.py's multi-rank line: `comm_ms`): None = off.  When a list, every exchange appends
@@ -1111,6 +1119,16 @@ class ShardedTrainer:
         self._planned_next = None
         if routes is None or routes.key != self._route_key(batch):
             routes = self.plan_routes(batch)
+        elif routes.event is not None:
+            torch.cuda.current_stream().wait_event(routes.event)  # (planned on the third stream)
+        aside = next_batch is not None and _PLAN_ASIDE and self.device.type == "cuda" and hasattr(be, "N")
+        if aside:
+            aux = be.N.aux_stream(self.device)
+            ready = torch.cuda.Event()
+            ready.record()  # whatever produced next_batch was queued on this stream before the call
+            aux.wait_event(ready)
+            with torch.cuda.stream(aux):
+                self._planned_next = self.plan_routes(next_batch)
         caps = routes.caps()
         # 1. each owner is sent the ids it holds (cap slots per peer), and returns the rows in the same slots
         lks: List[_RoutedLookup] = []
@@ -1125,10 +1143,7 @@ class ShardedTrainer:
             lk.rows_p = all_to_all_rows_start(be.gather_owned(lk.table.weight, lk.local, lk.n_local), tag="lookup_rows_alltoall")
         lk_u, lk_i = lks[0], lks[-1]
         lk_h = lks[1] if self.hist else None
-        if next_batch is not None:
-            # (on the step's own stream, here: planned on a side stream -- at the top of the step, or underneath the logits
-            # kernels -- the plan's event arrived LATER, the host waits for it at the top of the next step, and the emulated
-            # W = 8 step went from 4.23 to 5.9 - 6.1 ms; round 4, measured and dropped)
+        if next_batch is not None and not aside:
             self._planned_next = self.plan_routes(next_batch)
         item_local = torch.cat([lk_h.local, lk_i.local]) if self.hist else lk_i.local
         # the tables' old rows have been read: plan, park the looked-up rows, and start the
