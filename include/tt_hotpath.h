@@ -189,6 +189,24 @@ int tt_inbatch_ce_bwd_kept(const float* U, int64_t ldu, int64_t M, int64_t N, in
                            const float* row_lse, const float* coef, const float* logits, int64_t logits_bytes,
                            float* dI, int64_t lddi, void* ws, int64_t ws_bytes, tt_stream_t stream);
 
+/* EXPLORATORY, opt-in (the sharded trainer takes it with TT_CE_F16X2=1; nothing takes it by default): the kept-logits pair
+ * above on the 16-bit matrix pipe at fp32-grade accuracy (csrc/ce_f16x2.hip).  Every fp32 operand is cut into two fp16
+ * terms after a power-of-two scale (11 + 11 significant bits) and every product runs as three v_mfma_f32_32x32x16_f16
+ * into one fp32 accumulator: element-wise error at the level of an fp32 fma chain (tools/f16x2_logits_probe.hip), a
+ * fifth of the matrix-pipe cycles.  Same arguments, meaning and outputs as tt_inbatch_ce_fwd_du_keep /
+ * tt_inbatch_ce_bwd_kept -- same reference lines: ref:src/two_tower_base_retrieval.py:287-312 -- except: `logits`
+ * is [M][N] fp32 (M * N * 4 bytes), the workspace is tt_ce16_workspace_bytes, and the shapes are D = 128,
+ * M % 128 == 0, N % 1024 == 0 (tt_ce16_supported; TT_E_UNSUPPORTED otherwise).  |coef| <= 1 is assumed (example
+ * weights normalised by their maximum: ref:...base_retrieval.py:334-343). */
+int tt_ce16_supported(int64_t M, int64_t N, int64_t D);
+int64_t tt_ce16_workspace_bytes(int64_t M, int64_t N, int64_t D);
+int tt_ce16_fwd_du_keep(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N, int64_t D,
+                        int64_t diag_offset, float* row_lse, float* row_ce, float* du_unit, int64_t ld_du, float* logits,
+                        int64_t logits_bytes, void* ws, int64_t ws_bytes, tt_stream_t stream);
+int tt_ce16_bwd_kept(const float* U, int64_t ldu, int64_t M, int64_t N, int64_t D, int64_t diag_offset,
+                     const float* row_lse, const float* coef, const float* logits, int64_t logits_bytes, float* dI,
+                     int64_t lddi, void* ws, int64_t ws_bytes, tt_stream_t stream);
+
 /* dU[i, :] = du_unit[i, :] * coef[i]: the chain-rule step that turns tt_inbatch_ce_fwd_du's unit gradient into the
  * user-side gradient once dL/dce is known (autograd of ref:...base_retrieval.py:287-312,342). */
 int tt_scale_rows(const float* x, int64_t ldx, const float* coef, int64_t rows, int64_t D, float* out, int64_t ldo,

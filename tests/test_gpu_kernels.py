@@ -254,6 +254,70 @@ def test_inbatch_ce_kept_logits_backward(T, M, Nn, D, off, scale):
                                          du2.data_ptr(), D, Z.data_ptr(), zn - 4, wsp, wsn, N.stream()) != 0
 
 
+@pytest.mark.parametrize("M,Nn,off,scale", [(128, 1024, 0, 0.5), (256, 2048, 1536, 0.35), (384, 1024, 640, 3.0),
+                                             (1024, 8192, 4096, 0.3)])
+def test_split_fp16_ce_pair_vs_float64(T, M, Nn, off, scale):
+    """tt_ce16_fwd_du_keep / tt_ce16_bwd_kept (csrc/ce_f16x2.hip, exploratory and opt-in): the kept-logits pair with every
+    product as three fp16 MFMA products of two-term splits.  Against float64: logits, lse, ce, unit user gradient, item
+    gradient -- each also next to the fp32-MFMA pair's error on the same inputs (the split form must stay within 4x of it
+    plus a floor: 'fp32-grade'), non-zero diagonal offset, saturated softmax rows (scale 3), and the shapes it refuses."""
+    ops, N = T
+    lib = N.load()
+    D = 128
+    assert lib.tt_ce16_supported(M, Nn, D) == 1
+    assert lib.tt_ce16_supported(M, Nn + 8, D) == 0 and lib.tt_ce16_supported(M + 1, Nn, D) == 0 and lib.tt_ce16_supported(M, Nn, 64) == 0
+    U = (g((M, D), 181) * scale).to(DEV)
+    I = (g((Nn, D), 182) * scale).to(DEV)
+    coef = (g((M,), 183).abs().clamp(max=3.0) / (3.0 * M)).to(DEV)
+    e = lambda *shape: torch.full(shape, float("nan"), device=DEV)
+    wsn = lib.tt_ce16_workspace_bytes(M, Nn, D)
+    ws = torch.empty(wsn, dtype=torch.uint8, device=DEV)
+    lse, ce, du, Z, dI = e(M), e(M), e(M, D), e(M, Nn), e(Nn, D)
+    for _ in range(2):  # twice: nothing in the workspace may carry over
+        N.check(lib.tt_ce16_fwd_du_keep(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, off, lse.data_ptr(), ce.data_ptr(), du.data_ptr(), D,
+                                        Z.data_ptr(), M * Nn * 4, ws.data_ptr(), wsn, N.stream()), "ce16 fwd")
+        N.check(lib.tt_ce16_bwd_kept(U.data_ptr(), D, M, Nn, D, off, lse.data_ptr(), coef.data_ptr(), Z.data_ptr(), M * Nn * 4,
+                                     dI.data_ptr(), D, ws.data_ptr(), wsn, N.stream()), "ce16 bwd")
+    # the fp32-MFMA pair on the same inputs
+    wsp, wsn32 = ops._ws(torch.device(DEV), lib.tt_inbatch_ce_workspace_bytes(M, Nn, D), "ce_test")
+    lse32, ce32, du32, dI32 = e(M), e(M), e(M, D), e(Nn, D)
+    zn = lib.tt_inbatch_ce_logits_bytes(M, Nn)
+    Z32 = torch.empty(zn // 4, device=DEV)
+    N.check(lib.tt_inbatch_ce_fwd_du_keep(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, off, lse32.data_ptr(), ce32.data_ptr(),
+                                          du32.data_ptr(), D, Z32.data_ptr(), zn, wsp, wsn32, N.stream()), "fwd_du_keep")
+    N.check(lib.tt_inbatch_ce_bwd_kept(U.data_ptr(), D, M, Nn, D, off, lse32.data_ptr(), coef.data_ptr(), Z32.data_ptr(), zn,
+                                       dI32.data_ptr(), D, wsp, wsn32, N.stream()), "bwd_kept")
+    Ud, Id, cd = U.cpu().double(), I.cpu().double(), coef.cpu().double()
+    S = Ud @ Id.t()
+    rows = torch.arange(M)
+    ref_lse = torch.logsumexp(S, dim=1)
+    ref_ce = ref_lse - S[rows, rows + off]
+    P = torch.softmax(S, dim=1)
+    ref_du = P @ Id - Id[rows + off]
+    P[rows, rows + off] -= 1.0
+    ref_dI = (P * cd.unsqueeze(1)).t() @ Ud
+
+    def err(got, ref):
+        return float((got.cpu().double() - ref).abs().max())
+
+    smax = max(1.0, float(S.abs().max()))
+    assert err(Z, S * 1.4426950408889634) <= 2e-6 * smax  # log2-domain logits, every element
+    assert err(lse, ref_lse) <= 2e-6 * max(1.0, float(ref_lse.abs().max()))  # (row_lse's convention is each pair's own business)
+    for name, got, got32, ref in (("ce", ce, ce32, ref_ce), ("du_unit", du, du32, ref_du), ("dI", dI, dI32, ref_dI)):
+        e16, e32 = err(got, ref), err(got32, ref)
+        floor = 2e-6 * max(float(ref.abs().max()), 1e-30)
+        assert e16 <= 4 * e32 + floor, (name, e16, e32, float(ref.abs().max()))
+    loss = float((ref_ce * cd).sum())
+    assert abs(float((ce.double().cpu() * cd).sum()) - loss) < 1e-6 * max(1.0, abs(loss))  # the loss: far inside 1e-4
+    # refused, not overrun
+    assert lib.tt_ce16_fwd_du_keep(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, off, lse.data_ptr(), ce.data_ptr(), du.data_ptr(), D,
+                                   Z.data_ptr(), M * Nn * 4 - 4, ws.data_ptr(), wsn, N.stream()) != 0
+    assert lib.tt_ce16_fwd_du_keep(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, off, lse.data_ptr(), ce.data_ptr(), du.data_ptr(), D,
+                                   Z.data_ptr(), M * Nn * 4, ws.data_ptr(), wsn - 256, N.stream()) == N.TT_E_WORKSPACE
+    assert lib.tt_ce16_fwd_du_keep(U.data_ptr(), D, I.data_ptr(), D, M, Nn - 8, D, 0, lse.data_ptr(), ce.data_ptr(), du.data_ptr(), D,
+                                   Z.data_ptr(), M * Nn * 4, ws.data_ptr(), wsn, N.stream()) == N.TT_E_UNSUPPORTED
+
+
 def test_inbatch_ce_op_keep_logits_matches_default(T):
     """ops.InBatchSoftmaxCE(keep_logits=True) == the default path through autograd, and the default
     switches itself on for wide negative sets only."""

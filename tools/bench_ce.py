@@ -53,14 +53,37 @@ for M, Nn in shapes:
         N.check(lib.tt_inbatch_ce_bwd_kept(U.data_ptr(), D, M, Nn, D, 0, lse.data_ptr(), coef.data_ptr(), Z.data_ptr(), zn,
                                            dI2.data_ptr(), D, ws.data_ptr(), wsn, N.stream()), "bwd_kept")
 
+    have16 = bool(lib.tt_ce16_supported(M, Nn, D))
+    if have16:  # the split-fp16 pair (csrc/ce_f16x2.hip, exploratory)
+        ws16n = lib.tt_ce16_workspace_bytes(M, Nn, D)
+        ws16 = torch.empty(ws16n, dtype=torch.uint8, device=dev)
+        Z16 = torch.empty(M * Nn, device=dev)
+        dI16, du16, lse16, ce16 = torch.empty(Nn, D, device=dev), torch.empty(M, D, device=dev), torch.empty(M, device=dev), torch.empty(M, device=dev)
+
+        def fwd_du_keep_f16x2():
+            N.check(lib.tt_ce16_fwd_du_keep(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, 0, lse16.data_ptr(), ce16.data_ptr(),
+                                            du16.data_ptr(), D, Z16.data_ptr(), M * Nn * 4, ws16.data_ptr(), ws16n, N.stream()), "ce16 fwd")
+
+        def bwd_kept_f16x2():
+            N.check(lib.tt_ce16_bwd_kept(U.data_ptr(), D, M, Nn, D, 0, lse16.data_ptr(), coef.data_ptr(), Z16.data_ptr(), M * Nn * 4,
+                                         dI16.data_ptr(), D, ws16.data_ptr(), ws16n, N.stream()), "ce16 bwd")
+
     fwd_du(); bwd_items(); fwd_du_keep(); bwd_kept()
     torch.cuda.synchronize()
+    if have16:
+        fwd_du_keep_f16x2(); bwd_kept_f16x2()
+        torch.cuda.synchronize()
+        print(f"M={M} N={Nn}: split-fp16 pair vs the fp32-MFMA pair: lse {float((lse16 - lse).abs().max()):.2e} abs, "
+              f"du_unit {float((du16 - du_unit).abs().max() / du_unit.abs().max()):.2e}, "
+              f"dI {float((dI16 - dI2).abs().max() / dI2.abs().max()):.2e} (rel to max)", flush=True)
     err = (dI2 - dI).abs().max().item() / max(dI.abs().max().item(), 1e-30)
     print(f"M={M} N={Nn}: kept-logits dI vs recomputed dI: max rel-to-max error {err:.2e}", flush=True)
 
-    for name, fn, flops in (("fwd", fwd, 2.0 * M * Nn * D), ("bwd", bwd, 8.0 * M * Nn * D),
-                            ("fwd_du", fwd_du, 4.0 * M * Nn * D), ("bwd_items", bwd_items, 4.0 * M * Nn * D),
-                            ("fwd_du_keep", fwd_du_keep, 4.0 * M * Nn * D), ("bwd_kept", bwd_kept, 2.0 * M * Nn * D)):
+    for name, fn, flops in ((("fwd", fwd, 2.0 * M * Nn * D), ("bwd", bwd, 8.0 * M * Nn * D),
+                             ("fwd_du", fwd_du, 4.0 * M * Nn * D), ("bwd_items", bwd_items, 4.0 * M * Nn * D),
+                             ("fwd_du_keep", fwd_du_keep, 4.0 * M * Nn * D), ("bwd_kept", bwd_kept, 2.0 * M * Nn * D))
+                            + ((("fwd_du_keep_f16x2", fwd_du_keep_f16x2, 4.0 * M * Nn * D),
+                                ("bwd_kept_f16x2", bwd_kept_f16x2, 2.0 * M * Nn * D)) if have16 else ())):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()

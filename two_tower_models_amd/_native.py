@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("TT_HOTPATH_LIB") or os.path.join(_PKG, "lib", "libtt_
 TT_GEMM_NT, TT_GEMM_NN, TT_GEMM_TN = 0, 1, 2
 TT_EPI_NONE, TT_EPI_RELU, TT_EPI_RELU_MASK = 0, 1, 2
 TT_F32, TT_BF16 = 0, 1
+TT_E_BADARG, TT_E_WORKSPACE, TT_E_UNSUPPORTED = -1, -2, -3
 TT_DEBIAS_COMBINED, TT_DEBIAS_POSITION, TT_DEBIAS_USER = 0, 1, 2
 TT_COMM_ID_BYTES = 128
 TT_COMM_F32, TT_COMM_I32, TT_COMM_I64, TT_COMM_U8 = 0, 1, 2, 3
@@ -101,6 +102,10 @@ SIGNATURES = {
     "tt_inbatch_ce_fwd_du_keep": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64,
                                          _vp, _i64, _vp]),
     "tt_inbatch_ce_bwd_kept": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "tt_ce16_supported": (_int, [_i64, _i64, _i64]),
+    "tt_ce16_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "tt_ce16_fwd_du_keep": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "tt_ce16_bwd_kept": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "tt_scale_rows": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "tt_weighted_mean_loss": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tt_value_weights": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),

@@ -1,0 +1,570 @@
+// Exploratory, opt-in (TT_CE_F16X2=1 in the sharded trainer; never the default): the wide-negatives in-batch CE pair
+// (tt_inbatch_ce_fwd_du_keep / tt_inbatch_ce_bwd_kept, ref:src/two_tower_base_retrieval.py:287-312) on the 16-bit
+// matrix pipe at fp32-grade accuracy.
+//
+// Every fp32 operand x of a product is cut into TWO fp16 terms, x * s = h + l (s = a power of two that brings the
+// operand's largest magnitude to the top of fp16's range; h = fp16(x s), l = fp16(x s - h): 11 + 11 significant
+// bits), and a product runs as THREE v_mfma_f32_32x32x16_f16 into one fp32 accumulator -- ah bh + ah bl + al bh; the
+// dropped al bl is <= 2^-24 of |a||b|.  Measured element-wise error against float64: rms 4.9e-8 of sum |a_k b_k|
+// (an fp32 fma chain: 2.8e-8; tools/f16x2_logits_probe.hip).  96 matrix-pipe cycles per 16 k instead of the 512 of
+// eight v_mfma_f32_32x32x2_f32.
+//
+//   ce16_split_kernel      fp32 [R][128] -> four fp16 images: h, l row-major (operand of products that reduce over d)
+//                         and th, tl = [R/16][128][16] blocks (operand of products that reduce over ROWS: the lane that
+//                         owns column d reads its 8 rows of a 16-row k-step as one 16-B chunk, in the row order the
+//                         MFMA result layout hands the other operand over in -- no transposing LDS read anywhere)
+//   ce16_fwd_kernel       users stationary (B fragments of both terms in registers, 32 per wave), item tiles by LDS-DMA;
+//                         per 32 x 32 tile: logits (24 MFMAs), online softmax per lane (= per user), the probabilities
+//                         re-split in registers and E[u] += P I (24 MFMAs, the tile's th / tl image), log2-domain
+//                         logits stored for the backward; per (split, user) partials
+//   ce16_merge_kernel     splits -> lse, ce (diagonal logit as an fp32 dot product), unit user gradient E/sum - I_diag
+//   ce16_bwd_items_kernel items stationary (accumulators only); per 32-user tile the kept logits come straight from
+//                         HBM (lane = item, register = user: 128 contiguous bytes per half-wave and user row), the
+//                         gradient tile G = coef (p - 1[diag]) is split in registers, dI += G^T U (24 MFMAs, U's th / tl)
+//
+// Shapes: D = 128, M and N multiples of 128, |coef| <= 1 (the trainer's example weights are normalised by their maximum).
+#include "common.hpp"
+
+namespace tt {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int C16_D = 128;
+constexpr int C16_TILE = 32;                 // streamed rows per ring stage
+constexpr int C16_ROW_B = C16_D * 2;         // bytes of one fp16 row
+constexpr int C16_RM_B = C16_TILE * C16_ROW_B;   // one term, row-major image of a stage: 8 KiB
+constexpr int C16_TR_B = C16_TILE * C16_ROW_B;   // one term, transposed image of a stage (2 blocks of 4 KiB)
+constexpr float C16_PSCALE = 32768.f;        // probabilities / gradients are in [-1, 1]: 2^15 brings them to fp16's top
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+__device__ __forceinline__ int brow(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
+
+struct Images {
+  _Float16 *h, *l, *th, *tl;
+};
+
+// the power of two that brings `absmax` into [2^14, 2^15)
+__device__ __forceinline__ float scale_for(unsigned absmax_bits) {
+  const float mx = __uint_as_float(absmax_bits);
+  if (!(mx > 0.f) || !(mx < 3.0e38f)) return 1.f;
+  int e;
+  frexpf(mx, &e);  // mx = f 2^e, f in [0.5, 1)
+  return ldexpf(1.f, 15 - e);
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------- split
+__global__ void ce16_absmax_kernel(const float* __restrict__ X, int64_t ld, int64_t rows, unsigned* __restrict__ out) {
+  float m = 0.f;
+  const int64_t n4 = rows * (C16_D / 4);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = *reinterpret_cast<const float4*>(X + (i >> 5) * ld + (i & 31) * 4);
+    m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fmaxf(fabsf(v.z), fabsf(v.w)), m));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order like their bit patterns
+}
+
+// one workgroup per 16-row block: row-major terms (thread = row, 8 columns) and the block's transposed image
+// (thread = column d and lane half hh: slots q = 0..7 <-> rows (q & 3) + 8 (q >> 2) + 4 hh)
+__global__ __launch_bounds__(256) void ce16_split_kernel(const float* __restrict__ X, int64_t ld, int64_t rows, const unsigned* __restrict__ absmax,
+                                                      Images im) {
+  __shared__ float xs[16][C16_D + 4];
+  const float s = scale_for(*absmax);
+  const int64_t blk = blockIdx.x;
+  const int t = threadIdx.x;
+  {
+    const int r = t >> 4, c = (t & 15) * 8;
+    const int64_t row = blk * 16 + r;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = 0.f;
+    if (row < rows) {
+      const float4 a = *reinterpret_cast<const float4*>(X + row * ld + c), b = *reinterpret_cast<const float4*>(X + row * ld + c + 4);
+      v[0] = a.x * s; v[1] = a.y * s; v[2] = a.z * s; v[3] = a.w * s; v[4] = b.x * s; v[5] = b.y * s; v[6] = b.z * s; v[7] = b.w * s;
+    }
+    f16x8 hh, ll;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      xs[r][c + k] = v[k];
+      const _Float16 q = (_Float16)v[k];
+      hh[k] = q;
+      ll[k] = (_Float16)(v[k] - (float)q);
+    }
+    *reinterpret_cast<f16x8*>(im.h + row * C16_D + c) = hh;
+    *reinterpret_cast<f16x8*>(im.l + row * C16_D + c) = ll;
+  }
+  __syncthreads();
+  {
+    const int d = t >> 1, hh = t & 1;
+    f16x8 a, b;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float v = xs[(q & 3) + 8 * (q >> 2) + 4 * hh][d];
+      const _Float16 x = (_Float16)v;
+      a[q] = x;
+      b[q] = (_Float16)(v - (float)x);
+    }
+    const int64_t at = (blk * C16_D + d) * 16 + hh * 8;
+    *reinterpret_cast<f16x8*>(im.th + at) = a;
+    *reinterpret_cast<f16x8*>(im.tl + at) = b;
+  }
+}
+
+namespace {
+// ---------------------------------------------------------------------------------------------------- tile DMA
+// row-major image of C16_TILE rows, one term: every wave instruction lands 1 KiB = 4 rows; XOR swizzle of the 16-B chunks
+__device__ __forceinline__ void dma_rowmajor(const _Float16* __restrict__ base, char* dst, int wave, int lane) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(base), 0, C16_RM_B, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {  // 8 instructions per term, 2 per wave
+    const int rbase = (wave * 2 + i) * 4;
+    const int row = rbase + (lane >> 4);
+    const int c = (lane & 15) ^ (row & 15);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + rbase * C16_ROW_B), 16,
+                                             row * C16_ROW_B + 16 * c, 0, 0, 0);
+  }
+}
+// transposed image of C16_TILE rows (2 blocks), one term: already in fragment order, a linear copy
+__device__ __forceinline__ void dma_linear(const _Float16* __restrict__ base, char* dst, int wave, int lane) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(base), 0, C16_TR_B, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int off = (wave * 2 + i) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + off), 16, off + lane * 16, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
+  f16x8 r;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r[k] = (_Float16)v[k];
+  return __builtin_bit_cast(u32x4, r);
+}
+// v (already scaled into fp16's range) -> its two terms, 8 at a time
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+  f16x8 a, b;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const _Float16 x = (_Float16)v[k];
+    a[k] = x;
+    b[k] = (_Float16)(v[k] - (float)x);
+  }
+  hi = __builtin_bit_cast(u32x4, a);
+  lo = __builtin_bit_cast(u32x4, b);
+}
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0)
+
+// ---------------------------------------------------------------------------------------------------- forward
+struct FwdArgs {
+  Images u, it;                 // users (h, l used), items (all four)
+  const unsigned* absmax;       // [0] users, [1] items
+  int64_t M, N;
+  float* logits;                // [M][N] log2-domain
+  float *pmax, *psum, *pe;      // [splits][M], [splits][M], [splits][M][128]
+  int n_splits;
+};
+
+struct FwdStage {  // LDS image of one item tile
+  char rm_h[C16_RM_B], rm_l[C16_RM_B], tr_h[C16_TR_B], tr_l[C16_TR_B];
+};
+
+__device__ __forceinline__ void fwd_stage_dma(const FwdArgs& p, int64_t item0, FwdStage* st, int wave, int lane) {
+  dma_rowmajor(p.it.h + item0 * C16_D, st->rm_h, wave, lane);
+  dma_rowmajor(p.it.l + item0 * C16_D, st->rm_l, wave, lane);
+  dma_linear(p.it.th + item0 * C16_D, st->tr_h, wave, lane);
+  dma_linear(p.it.tl + item0 * C16_D, st->tr_l, wave, lane);
+}
+
+// one tile against the wave's 32 stationary users
+__device__ __forceinline__ void fwd_tile(const FwdStage* st, const u32x4 (&uh)[8], const u32x4 (&ul)[8], f32x16 (&E)[4], float& mx, float& sm,
+                                         float out_scale, float* __restrict__ logit_row, int64_t item0, int r, int h) {
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const char* rowh = st->rm_h + r * C16_ROW_B;
+  const char* rowl = st->rm_l + r * C16_ROW_B;
+  u32x4 ih[2], il[2];
+  {
+    const int off = (h ^ (r & 15)) * 16;
+    ih[0] = *reinterpret_cast<const u32x4*>(rowh + off);
+    il[0] = *reinterpret_cast<const u32x4*>(rowl + off);
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t + 1 < 8) {
+      const int off = ((2 * (t + 1) + h) ^ (r & 15)) * 16;
+      ih[(t + 1) & 1] = *reinterpret_cast<const u32x4*>(rowh + off);
+      il[(t + 1) & 1] = *reinterpret_cast<const u32x4*>(rowl + off);
+    }
+    acc = MFMA16(ih[t & 1], uh[t], acc);
+    acc = MFMA16(ih[t & 1], ul[t], acc);
+    acc = MFMA16(il[t & 1], uh[t], acc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // lane (user r, half h) holds the logits of items item0 + brow(e, h); both halves must use ONE reference maximum
+  // (the E product below sums over the items of both)
+  float v[16];
+  float tmax = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    v[e] = acc[e] * out_scale;
+    tmax = fmaxf(tmax, v[e]);
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(logit_row + item0 + 8 * g + 4 * h) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+  tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+  if (tmax > mx) {  // (lane-divergent, rare after the first tiles)
+    const float f = __builtin_amdgcn_exp2f(mx - tmax);
+    sm *= f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) E[b][e] *= f;
+    mx = tmax;
+  }
+  u32x4 ph[2], pl[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    float pv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float pr = __builtin_amdgcn_exp2f(v[8 * s + q] - mx);
+      sm += pr;
+      pv[q] = pr * C16_PSCALE;
+    }
+    split8(pv, ph[s], pl[s]);
+  }
+  // E^T[d][user] += I^T[d][item] P[item][user]: A = the tile's transposed image, B = the probabilities just formed
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int at = s * 4096 + (b * 32 + r) * 32 + h * 16;
+      const u32x4 th = *reinterpret_cast<const u32x4*>(st->tr_h + at);
+      const u32x4 tl = *reinterpret_cast<const u32x4*>(st->tr_l + at);
+      E[b] = MFMA16(th, ph[s], E[b]);
+      E[b] = MFMA16(th, pl[s], E[b]);
+      E[b] = MFMA16(tl, ph[s], E[b]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void ce16_fwd_kernel(const FwdArgs p) {
+  __shared__ __attribute__((aligned(1024))) FwdStage ring0;
+  __shared__ __attribute__((aligned(1024))) FwdStage ring1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int64_t user = (int64_t)blockIdx.x * 128 + wave * 32 + r;
+  const int split = blockIdx.y;
+  const int64_t per = p.N / p.n_splits;  // a multiple of C16_TILE (host)
+  const int64_t n0 = split * per;
+  const int n_tiles = (int)(per / C16_TILE);
+  const float out_scale = LOG2E / (scale_for(p.absmax[0]) * scale_for(p.absmax[1]));
+
+  u32x4 uh[8], ul[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    uh[t] = *reinterpret_cast<const u32x4*>(p.u.h + user * C16_D + 16 * t + 8 * h);
+    ul[t] = *reinterpret_cast<const u32x4*>(p.u.l + user * C16_D + 16 * t + 8 * h);
+  }
+  f32x16 E[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) E[b][e] = 0.f;
+  float mx = -INFINITY, sm = 0.f;
+  float* logit_row = p.logits + user * p.N;
+
+  fwd_stage_dma(p, n0, &ring0, wave, lane);
+  for (int tile = 0; tile < n_tiles; tile += 2) {  // two NAMED stages, unrolled by two (distinct LDS objects carry alias scopes)
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the tile has landed (and the logits stores of the previous one have left)
+    __builtin_amdgcn_s_barrier();
+    if (tile + 1 < n_tiles) fwd_stage_dma(p, n0 + (int64_t)(tile + 1) * C16_TILE, &ring1, wave, lane);
+    fwd_tile(&ring0, uh, ul, E, mx, sm, out_scale, logit_row, n0 + (int64_t)tile * C16_TILE, r, h);
+    if (tile + 1 >= n_tiles) break;
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __builtin_amdgcn_s_barrier();
+    if (tile + 2 < n_tiles) fwd_stage_dma(p, n0 + (int64_t)(tile + 2) * C16_TILE, &ring0, wave, lane);
+    fwd_tile(&ring1, uh, ul, E, mx, sm, out_scale, logit_row, n0 + (int64_t)(tile + 1) * C16_TILE, r, h);
+  }
+  sm += __shfl_xor(sm, 32);
+  const int64_t at = (int64_t)split * p.M + user;
+  if (h == 0) {
+    p.pmax[at] = mx;
+    p.psum[at] = sm;
+  }
+  float* pe = p.pe + at * C16_D;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(pe + b * 32 + 8 * g + 4 * h) = make_float4(E[b][4 * g], E[b][4 * g + 1], E[b][4 * g + 2], E[b][4 * g + 3]);
+}
+
+// one wavefront per user: splits -> lse, ce, unit gradient
+__global__ __launch_bounds__(256) void ce16_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, const float* __restrict__ pe,
+                                                         int n_splits, int64_t M, const unsigned* __restrict__ absmax,
+                                                         const float* __restrict__ U, int64_t ldu, const float* __restrict__ I, int64_t ldi,
+                                                         int64_t diag_off, float* __restrict__ row_lse, float* __restrict__ row_ce,
+                                                         float* __restrict__ du_unit, int64_t ld_du) {
+  const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= M) return;
+  const int lane = threadIdx.x & 63;
+  float m = -INFINITY;
+  for (int s = 0; s < n_splits; ++s) m = fmaxf(m, pmax[(int64_t)s * M + u]);
+  float tot = 0.f, e0 = 0.f, e1 = 0.f;
+  for (int s = 0; s < n_splits; ++s) {
+    const float f = exp2f(pmax[(int64_t)s * M + u] - m);
+    tot += psum[(int64_t)s * M + u] * f;
+    const float2 v = *reinterpret_cast<const float2*>(pe + ((int64_t)s * M + u) * C16_D + 2 * lane);
+    e0 = fmaf(v.x, f, e0);
+    e1 = fmaf(v.y, f, e1);
+  }
+  const float inv = 1.f / (tot * C16_PSCALE * scale_for(absmax[1]));
+  const float2 iv = *reinterpret_cast<const float2*>(I + (u + diag_off) * ldi + 2 * lane);
+  const float2 uv = *reinterpret_cast<const float2*>(U + u * ldu + 2 * lane);
+  *reinterpret_cast<float2*>(du_unit + u * ld_du + 2 * lane) = make_float2(e0 * inv - iv.x, e1 * inv - iv.y);
+  const float diag = wave_sum(fmaf(uv.x, iv.x, uv.y * iv.y));
+  if (lane == 0) {
+    const float lse = (m + log2f(tot)) * LN2;
+    row_lse[u] = lse;
+    row_ce[u] = lse - diag;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- backward, item side
+namespace {
+struct BwdArgs {
+  Images u;                     // users: th, tl used
+  const float* logits;          // [M][N] log2-domain
+  const float *row_lse, *coef;  // [M]
+  int64_t M, N, diag_off;
+  float* dI;
+  int64_t lddi;
+  const unsigned* absmax;       // [0] users
+};
+struct BwdStage {
+  char tr_h[C16_TR_B], tr_l[C16_TR_B];
+};
+// buffer loads: tile base in a scalar resource descriptor, row offset in a scalar register, ONE 32-bit per-lane offset
+// (global loads would carry a 64-bit VGPR address each: 32 registers and 32 VALU adds per tile).  The row stride is made
+// opaque so the 16 row offsets are a scalar multiply per tile, not 16 hoisted scalar registers (csrc/inbatch_ce.hip).
+__device__ __forceinline__ void bwd_fetch(const BwdArgs& p, int64_t user0, int lane_off, int wave, int lane, float (&s)[16], float& stat) {
+  int n = (int)p.N;
+  asm volatile("" : "+s"(n));
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.logits + user0 * p.N), 0, -1, 0x00020000);
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+    s[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane_off, ((e & 3) + 8 * (e >> 2)) * n * 4, 0));
+  // the tile's 32 (lse, coef) pairs: one value per lane of wave 0, handed to everybody through LDS (every lane needs 16 of
+  // each; fetched per lane they would be twice the logits' load traffic and 64 registers of double buffer)
+  if (wave == 0) stat = (lane < 32 ? p.row_lse : p.coef)[user0 + (lane & 31)];
+}
+__device__ __forceinline__ void bwd_tile(const BwdStage* st, const float* stat, const float (&s)[16], f32x16 (&acc)[4],
+                                         int64_t user0, int64_t diag_user, int r, int h) {
+  float lse[16], cf[16];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {  // users 8 g + 4 h + (0..3) = brow(4 g + k, h)
+    const float4 a = *reinterpret_cast<const float4*>(stat + 8 * g + 4 * h);
+    const float4 b = *reinterpret_cast<const float4*>(stat + 32 + 8 * g + 4 * h);
+    lse[4 * g] = a.x; lse[4 * g + 1] = a.y; lse[4 * g + 2] = a.z; lse[4 * g + 3] = a.w;
+    cf[4 * g] = b.x; cf[4 * g + 1] = b.y; cf[4 * g + 2] = b.z; cf[4 * g + 3] = b.w;
+  }
+  u32x4 gh[2], gl[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float gv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = 8 * k + q;
+      float pr = __builtin_amdgcn_exp2f(s[e] - lse[e] * LOG2E);
+      if (user0 + brow(e, h) == diag_user) pr -= 1.f;
+      gv[q] = pr * cf[e] * C16_PSCALE;
+    }
+    split8(gv, gh[k], gl[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int at = k * 4096 + (b * 32 + r) * 32 + h * 16;
+      const u32x4 th = *reinterpret_cast<const u32x4*>(st->tr_h + at);
+      const u32x4 tl = *reinterpret_cast<const u32x4*>(st->tr_l + at);
+      acc[b] = MFMA16(th, gh[k], acc[b]);
+      acc[b] = MFMA16(th, gl[k], acc[b]);
+      acc[b] = MFMA16(tl, gh[k], acc[b]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void ce16_bwd_items_kernel(const BwdArgs p) {
+  __shared__ __attribute__((aligned(1024))) BwdStage ring0;
+  __shared__ __attribute__((aligned(1024))) BwdStage ring1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int64_t item = (int64_t)blockIdx.x * 128 + wave * 32 + r;
+  const int64_t diag_user = item - p.diag_off;  // the user whose positive this item is (outside [0, M): none)
+  const int n_tiles = (int)(p.M / C16_TILE);
+  const int lane_off = (int)((4 * h * p.N + item) * 4);  // bytes from the tile's first logit to this lane's column, rows 4 h ..
+  f32x16 acc[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+  __shared__ __attribute__((aligned(16))) float stat0[64];
+  __shared__ __attribute__((aligned(16))) float stat1[64];
+  float s0[16], s1[16];
+  float sv0 = 0.f, sv1 = 0.f;
+  dma_linear(p.u.th, ring0.tr_h, wave, lane);
+  dma_linear(p.u.tl, ring0.tr_l, wave, lane);
+  bwd_fetch(p, 0, lane_off, wave, lane, s0, sv0);
+  for (int tile = 0; tile < n_tiles; tile += 2) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    if (wave == 0) stat0[lane] = sv0;
+    __syncthreads();
+    if (tile + 1 < n_tiles) {
+      const int64_t u1 = (int64_t)(tile + 1) * C16_TILE;
+      dma_linear(p.u.th + u1 * C16_D, ring1.tr_h, wave, lane);
+      dma_linear(p.u.tl + u1 * C16_D, ring1.tr_l, wave, lane);
+      bwd_fetch(p, u1, lane_off, wave, lane, s1, sv1);
+    }
+    bwd_tile(&ring0, stat0, s0, acc, (int64_t)tile * C16_TILE, diag_user, r, h);
+    if (tile + 1 >= n_tiles) break;
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    if (wave == 0) stat1[lane] = sv1;
+    __syncthreads();
+    if (tile + 2 < n_tiles) {
+      const int64_t u2 = (int64_t)(tile + 2) * C16_TILE;
+      dma_linear(p.u.th + u2 * C16_D, ring0.tr_h, wave, lane);
+      dma_linear(p.u.tl + u2 * C16_D, ring0.tr_l, wave, lane);
+      bwd_fetch(p, u2, lane_off, wave, lane, s0, sv0);
+    }
+    bwd_tile(&ring1, stat1, s1, acc, (int64_t)(tile + 1) * C16_TILE, diag_user, r, h);
+  }
+  const float inv = 1.f / (C16_PSCALE * scale_for(p.absmax[0]));
+  float* out = p.dI + item * p.lddi;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(out + b * 32 + 8 * g + 4 * h) =
+          make_float4(acc[b][4 * g] * inv, acc[b][4 * g + 1] * inv, acc[b][4 * g + 2] * inv, acc[b][4 * g + 3] * inv);
+}
+
+// ---------------------------------------------------------------------------------------------------- host
+namespace {
+constexpr int C16_SPLITS = 8;
+
+struct Ws {
+  unsigned* absmax;
+  Images u, it;
+  float *pmax, *psum, *pe;
+};
+int64_t carve(void* base, int64_t M, int64_t N, Ws* w) {
+  Carver c(base);
+  unsigned* am = c.take<unsigned>(64);
+  Images u, it;
+  u.h = c.take<_Float16>(M * C16_D); u.l = c.take<_Float16>(M * C16_D); u.th = c.take<_Float16>(M * C16_D); u.tl = c.take<_Float16>(M * C16_D);
+  it.h = c.take<_Float16>(N * C16_D); it.l = c.take<_Float16>(N * C16_D); it.th = c.take<_Float16>(N * C16_D); it.tl = c.take<_Float16>(N * C16_D);
+  float* pmax = c.take<float>((int64_t)C16_SPLITS * M);
+  float* psum = c.take<float>((int64_t)C16_SPLITS * M);
+  float* pe = c.take<float>((int64_t)C16_SPLITS * M * C16_D);
+  if (w) { w->absmax = am; w->u = u; w->it = it; w->pmax = pmax; w->psum = psum; w->pe = pe; }
+  return c.off;
+}
+int split_matrix(const float* X, int64_t ld, int64_t rows, unsigned* absmax, const Images& im, hipStream_t st) {
+  const int64_t n4 = rows * (C16_D / 4);
+  int blocks = (int)(n4 / 256 < 1024 ? (n4 + 255) / 256 : 1024);
+  hipLaunchKernelGGL(ce16_absmax_kernel, dim3(blocks), dim3(256), 0, st, X, ld, rows, absmax);
+  if (int rc = check_launch("ce16_absmax_kernel")) return rc;
+  hipLaunchKernelGGL(ce16_split_kernel, dim3((unsigned)(rows / 16)), dim3(256), 0, st, X, ld, rows, absmax, im);
+  return check_launch("ce16_split_kernel");
+}
+}  // namespace
+}  // namespace tt
+
+using namespace tt;
+
+extern "C" int tt_ce16_supported(int64_t M, int64_t N, int64_t D) {
+  return (D == C16_D && M > 0 && N > 0 && M % 128 == 0 && N % (128 * C16_SPLITS) == 0) ? 1 : 0;
+}
+
+extern "C" int64_t tt_ce16_workspace_bytes(int64_t M, int64_t N, int64_t D) {
+  if (!tt_ce16_supported(M, N, D)) return 0;
+  return carve(nullptr, M, N, nullptr);
+}
+
+extern "C" int tt_ce16_fwd_du_keep(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N, int64_t D,
+                                   int64_t diag_offset, float* row_lse, float* row_ce, float* du_unit, int64_t ld_du, float* logits,
+                                   int64_t logits_bytes, void* ws, int64_t ws_bytes, tt_stream_t stream) {
+  if (!U || !I || !row_lse || !row_ce || !du_unit || !logits || !ws) return fail_arg("tt_ce16_fwd_du_keep: null pointer");
+  if (!tt_ce16_supported(M, N, D)) {
+    set_error("tt_ce16_fwd_du_keep: needs D = 128, M %% 128 == 0, N %% 1024 == 0");
+    return TT_E_UNSUPPORTED;
+  }
+  if (ldu < D || ldi < D || ld_du < D || (ldu | ldi | ld_du) % 4 || ((uintptr_t)U | (uintptr_t)I | (uintptr_t)du_unit) % 16)
+    return fail_arg("tt_ce16_fwd_du_keep: rows must be 16-byte aligned");
+  if (diag_offset < 0 || diag_offset + M > N) return fail_arg("tt_ce16_fwd_du_keep: diagonal outside the item range");
+  if (logits_bytes < M * N * (int64_t)sizeof(float)) return fail_arg("tt_ce16_fwd_du_keep: logits buffer");
+  if (ws_bytes < tt_ce16_workspace_bytes(M, N, D)) {
+    set_error("tt_ce16_fwd_du_keep: workspace");
+    return TT_E_WORKSPACE;
+  }
+  hipStream_t st = S(stream);
+  Ws w;
+  carve(ws, M, N, &w);
+  if (hipMemsetAsync(w.absmax, 0, 256, st) != hipSuccess) return check_launch("hipMemsetAsync");
+  if (int rc = split_matrix(U, ldu, M, w.absmax, w.u, st)) return rc;
+  if (int rc = split_matrix(I, ldi, N, w.absmax + 1, w.it, st)) return rc;
+  FwdArgs a;
+  a.u = w.u; a.it = w.it; a.absmax = w.absmax; a.M = M; a.N = N; a.logits = logits;
+  a.pmax = w.pmax; a.psum = w.psum; a.pe = w.pe; a.n_splits = C16_SPLITS;
+  {
+    ProfScope prof("ce_fwd_kernel", st);
+    hipLaunchKernelGGL(ce16_fwd_kernel, dim3((unsigned)(M / 128), C16_SPLITS), dim3(256), 0, st, a);
+  }
+  if (int rc = check_launch("ce16_fwd_kernel")) return rc;
+  hipLaunchKernelGGL(ce16_merge_kernel, dim3((unsigned)ceil_div(M, 4)), dim3(256), 0, st, w.pmax, w.psum, w.pe, C16_SPLITS, M, w.absmax, U, ldu, I,
+                     ldi, diag_offset, row_lse, row_ce, du_unit, ld_du);
+  return check_launch("ce16_merge_kernel");
+}
+
+extern "C" int tt_ce16_bwd_kept(const float* U, int64_t ldu, int64_t M, int64_t N, int64_t D, int64_t diag_offset, const float* row_lse,
+                                const float* coef, const float* logits, int64_t logits_bytes, float* dI, int64_t lddi, void* ws,
+                                int64_t ws_bytes, tt_stream_t stream) {
+  if (!U || !row_lse || !coef || !logits || !dI || !ws) return fail_arg("tt_ce16_bwd_kept: null pointer");
+  if (!tt_ce16_supported(M, N, D)) {
+    set_error("tt_ce16_bwd_kept: needs D = 128, M %% 128 == 0, N %% 1024 == 0");
+    return TT_E_UNSUPPORTED;
+  }
+  if (ldu < D || lddi < D || (ldu | lddi) % 4 || ((uintptr_t)U | (uintptr_t)dI) % 16) return fail_arg("tt_ce16_bwd_kept: rows must be 16-byte aligned");
+  if (logits_bytes < M * N * (int64_t)sizeof(float)) return fail_arg("tt_ce16_bwd_kept: logits buffer");
+  if (ws_bytes < tt_ce16_workspace_bytes(M, N, D)) {
+    set_error("tt_ce16_bwd_kept: workspace");
+    return TT_E_WORKSPACE;
+  }
+  hipStream_t st = S(stream);
+  Ws w;
+  carve(ws, M, N, &w);
+  // the user images are formed again (two small launches) instead of being trusted to have survived in a shared workspace
+  if (hipMemsetAsync(w.absmax, 0, 256, st) != hipSuccess) return check_launch("hipMemsetAsync");
+  if (int rc = split_matrix(U, ldu, M, w.absmax, w.u, st)) return rc;
+  BwdArgs a;
+  a.u = w.u; a.logits = logits; a.row_lse = row_lse; a.coef = coef; a.M = M; a.N = N; a.diag_off = diag_offset; a.dI = dI; a.lddi = lddi;
+  a.absmax = w.absmax;
+  {
+    ProfScope prof("ce_bwd_kernel", st);
+    hipLaunchKernelGGL(ce16_bwd_items_kernel, dim3((unsigned)(N / 128)), dim3(256), 0, st, a);
+  }
+  return check_launch("ce16_bwd_items_kernel");
+}

@@ -138,6 +138,7 @@ def reduce_scatter_rows(x: torch.Tensor) -> torch.Tensor:
 # 4.237 vs 4.246 ms per step; not the default.
 _UTOWER_EARLY = os.environ.get("TT_SHARDED_EARLY_UTOWER") is not None
 _LOSS_KERNELS = os.environ.get("TT_SHARDED_TORCH_LOSS") is None  # A/B: the value-weight tail as two kernels
+_CE_F16X2 = os.environ.get("TT_CE_F16X2") is not None  # exploratory: split-fp16 logits kernels (HipBackend.ce_fwd)
 # Opt-in (TT_SHARDED_PLAN_ASIDE=1): the NEXT batch's route plan (owner histogram + scan per lookup, the MAX all-reduce
 # of the bucket sizes, their copy to the host) on the library's third stream at the very top of the step instead of on
 # the main stream after the lookups -- eight small launches leave the critical path: emulated W = 8 step 4.09 -> 4.05 ms
@@ -346,7 +347,7 @@ class HipBackend:
         self.device = device
         self._sides = {}
         self._du_unit = None
-        self._kept = None
+        self._kept = self._kept16 = None
         self.keep_logits = False  # set by the trainer when the logits dominate the step
         self._side_stream = None
         self._sweep_done = None
@@ -518,7 +519,16 @@ class HipBackend:
         # forward fused with the user-side gradient (kept for ce_bwd): with global negatives the
         # logits are the step at 8 GPUs, and this removes one of their five passes
         self._du_unit = self.empty(M, D)
-        self._kept = None
+        self._kept = self._kept16 = None
+        if _CE_F16X2 and lib.tt_ce16_supported(M, Nn, D) and U.is_contiguous() and I_all.is_contiguous():
+            # EXPLORATORY (TT_CE_F16X2=1): the same pair on the 16-bit matrix pipe, every product as three fp16 MFMA products
+            # of two-term splits -- fp32-grade results (csrc/ce_f16x2.hip), about half the time of the fp32-MFMA pair
+            w16p, w16n = ops._ws(self.device, lib.tt_ce16_workspace_bytes(M, Nn, D), "ce16")
+            self._kept16 = torch.empty(M * Nn, dtype=torch.float32, device=self.device)
+            N.check(lib.tt_ce16_fwd_du_keep(U.data_ptr(), D, I_all.data_ptr(), D, M, Nn, D, off, lse.data_ptr(), ce.data_ptr(),
+                                            self._du_unit.data_ptr(), D, self._kept16.data_ptr(), M * Nn * 4, w16p, w16n,
+                                            N.stream()), "tt_ce16_fwd_du_keep")
+            return ce, lse
         if self.keep_logits and ops.kept_logits_supported(U, I_all):
             # wide negative sets: the logits are written out once and read back by the item-side
             # backward instead of being recomputed (3 instead of 4 logit-sized products per step)
@@ -548,6 +558,12 @@ class HipBackend:
         Nn = I_all.shape[0]
         dI = self.empty(Nn, D)
         dU = self.ce_du(coef) if want_du else None
+        if self._kept16 is not None:
+            w16p, w16n = ops._ws(self.device, lib.tt_ce16_workspace_bytes(M, Nn, D), "ce16")
+            N.check(lib.tt_ce16_bwd_kept(U.data_ptr(), D, M, Nn, D, off, lse.data_ptr(), coef.data_ptr(), self._kept16.data_ptr(),
+                                         M * Nn * 4, dI.data_ptr(), D, w16p, w16n, N.stream()), "tt_ce16_bwd_kept")
+            self._kept16 = None
+            return dU, dI
         wsp, wsn = ops._ws(self.device, lib.tt_inbatch_ce_workspace_bytes(M, Nn, D))
         if self._kept is not None:
             N.check(lib.tt_inbatch_ce_bwd_kept(U.data_ptr(), D, M, Nn, D, off, lse.data_ptr(), coef.data_ptr(),
