@@ -435,6 +435,13 @@ def secondary(device, lib, N):
         sec["emulated_W8"] = {"error": f"{type(e).__name__}: {e}"}
     torch.cuda.empty_cache()
     try:
+        # EXPLORATORY, reported separately like P_lazy: the same emulated step with the logits pair as
+        # split-fp16 products (csrc/ce_f16x2.hip, TT_CE_F16X2) -- fp32-grade results at about half the logits time
+        sec["emulated_W8_f16x2"] = _emu.emulated(8, "P", steps=30, warmup=25, device=device, split16=True)
+    except Exception as e:
+        sec["emulated_W8_f16x2"] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
+    try:
         # the drop-in training script end to end (ref:train/train.py:138-183): dataset generated in HBM, device-side
         # shuffle + batch slicing, 1-D [B] labels, 40 steps per epoch at the headline shapes; 2nd epoch reported
         import argparse as _ap

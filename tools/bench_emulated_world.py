@@ -63,15 +63,22 @@ def _time_steps(trainer, batches, steps):
     return host, (time.perf_counter() - t0) / steps * 1e3
 
 
-def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False):
-    """One rank's kernels of the W-GPU step (stand-in collectives), as a record for bench.py's `secondary`."""
+MFMA_F16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak
+
+
+def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False, split16=None):
+    """One rank's kernels of the W-GPU step (stand-in collectives), as a record for bench.py's `secondary`.
+    split16: run the logits pair as split-fp16 products (csrc/ce_f16x2.hip, exploratory; default: what TT_CE_F16X2 says)."""
     import bench
     from two_tower_models_amd import _native as N
     from two_tower_models_amd import sharded
     device = device or torch.device("cuda:0")
     lib = N.load()
-    real_dist = sharded.dist
+    real_dist, real_split = sharded.dist, sharded._CE_F16X2
     sharded.dist = _fake_dist(W)
+    if split16 is not None:
+        sharded._CE_F16X2 = bool(split16)
+    split = sharded._CE_F16X2
     try:
         cfg = dict(bench.WORKLOADS[workload])
         # (1) the host's own cost of enqueueing a step -- Python + ~150 launches -- measured where the GPU can never
@@ -142,7 +149,8 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False)
         # the same two kernels with the GPU to themselves (no sweep next to them, nothing else in the queue): what the
         # kernels reach vs what the step gets out of them
         alone = {}
-        if kept:
+        split = split and bool(lib.tt_ce16_supported(M, Nn, D))
+        if kept and not split:
             U = torch.randn(M, D, device=device) * 0.3
             I = torch.randn(Nn, D, device=device) * 0.3
             coef = torch.rand(M, device=device) / M
@@ -174,10 +182,18 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False)
                 alone[key] = t.value / max(c.value, 1)
             del U, I, Z, ws, dI, du
         roof = []
-        for kname, fl, key in (("ce_fwd_du_kernel", fl_fwd, "ce_fwd_kernel"),
-                               ("ce_bwd_kept_kernel" if kept else "ce_bwd_kernel", fl_bwd, "ce_bwd_kernel")):
+        for kname, fl, key in (("ce16_fwd_kernel" if split else "ce_fwd_du_kernel", fl_fwd, "ce_fwd_kernel"),
+                               ("ce16_bwd_items_kernel" if split else "ce_bwd_kept_kernel" if kept else "ce_bwd_kernel",
+                                2.0 * M * Nn * D if split else fl_bwd, "ce_bwd_kernel")):
             avg_ms, launches = prof[key]
-            if launches:
+            if launches and split:
+                # every logit-sized product runs as THREE fp16 MFMA products: priced against the fp16 matrix-pipe peak on the
+                # flops the pipe actually executes, next to the fp32-equivalent rate
+                tf = 3.0 * fl / (avg_ms * 1e-3) / 1e12
+                roof.append({"bound": "mfma", "kernel": kname, "achieved": round(tf, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
+                             "frac": round(tf / MFMA_F16_PEAK_TF, 4), "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+                             "algorithmic_flops_per_launch": 3.0 * fl, "fp32_equivalent_TFLOPs": round(tf / 3.0, 1)})
+            elif launches:
                 tf = fl / (avg_ms * 1e-3) / 1e12
                 roof.append({"bound": "mfma", "kernel": kname, "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                              "frac": round(tf / MFMA_F32_PEAK_TF, 4), "avg_launch_ms": round(avg_ms, 4), "launches": launches,
@@ -191,6 +207,10 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False)
                     "negatives per user, routed lookups; torch.distributed replaced by stand-ins that return tensors of the right "
                     "shape without moving data -- NOT a training run, the collectives' time comes on top",
             "workload": workload, "world": W, "routing": trainer.routing, "kept_logits": kept,
+            "dtype": "f32 (fp16x2 split: every logits product as three fp16 MFMA products of two-term splits, fp32 accumulate)" if split else "f32",
+            **({"EXPLORATORY": "TT_CE_F16X2 -- not the default path, not the headline; parity: tests/test_gpu_kernels.py::"
+                               "test_split_fp16_ce_pair_vs_float64, tests/test_gpu_sharded.py::test_world1_split_fp16_logits_match_oracle_at_unchanged_tolerances"}
+               if split else {}),
             "ms_per_step_per_rank": round(ms, 4),
             "pairs_per_s_if_collectives_were_free": round(B * W / ms * 1e3, 1),
             "host_enqueue_ms_per_step": round(host_ms, 4),
@@ -212,12 +232,12 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False)
             print(f"emulated W={W} workload={workload} routing={trainer.routing}: {ms:.3f} ms/step per rank (no collectives) -> "
                   f"{B * W / ms * 1e3 / 1e6:.2f} M pairs/s if the collectives were free")
             for r in roof:
-                print(f"  {r['kernel']}: {r['avg_launch_ms']:.3f} ms = {r['achieved']} TFLOP/s = {r['frac']:.3f} of the fp32 MFMA peak"
+                print(f"  {r['kernel']}: {r['avg_launch_ms']:.3f} ms = {r['achieved']} TFLOP/s = {r['frac']:.3f} of the {'fp16' if r['peak'] > 1000 else 'fp32'} MFMA peak"
                       + (f" (alone: {r['alone_avg_launch_ms']:.3f} ms = {r['alone_frac']:.3f})" if "alone_frac" in r else ""))
             print(f"  bytes this rank would send per step: {trainer.comm_bytes} = {sum(trainer.comm_bytes.values()) / 1e6:.1f} MB")
         return out
     finally:
-        sharded.dist = real_dist
+        sharded.dist, sharded._CE_F16X2 = real_dist, real_split
 
 
 if __name__ == "__main__":

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Measurement variants of the split-fp16 logits pair (ce_f16x2.hip -DTT_CE16_EXP=k) next to the product library, timed with
+# tools/bench_ce.py at the W = 8 shape.  Variant results are WRONG by design.
+#   1 no logits stores   2 no E product (forward)   8 tile wait leaves the four logits stores in flight   32 backward without logits loads
+#   tools/ce16_variants.sh build   (here)        tools/ce16_variants.sh run   (on the GPU box)
+set -e
+cd "$(dirname "$0")/.."
+P=two_tower_models_amd
+mkdir -p $P/lib/exp
+if [ "$1" = build ]; then
+  python -m $P.build >/dev/null
+  for k in ${VARIANTS:-1 2 3 8 32}; do
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DTT_CE16_EXP=$k -Iinclude -I$P/csrc -x hip -c $P/csrc/ce_f16x2.hip -o $P/lib/exp/ce16_e$k.o &
+  done
+  wait
+  for k in ${VARIANTS:-1 2 3 8 32}; do
+    objs=$(ls $P/csrc/_obj/*.o | grep -v "/ce_f16x2.o")
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/lib/exp/libtt_hotpath_c$k.so $objs $P/lib/exp/ce16_e$k.o
+  done
+  ls $P/lib/exp/*_c*.so
+else
+  for rep in 1 2; do
+    python tools/bench_ce.py 8192 65536 2>&1 | grep f16x2 | grep -v pair | sed -e 's/^/product : /'
+    for f in $P/lib/exp/libtt_hotpath_c*.so; do
+      TT_HOTPATH_LIB=$PWD/$f python tools/bench_ce.py 8192 65536 2>&1 | grep f16x2 | grep -v pair | sed -e "s#^#$(basename $f .so | sed s/libtt_hotpath_//) : #"
+    done
+  done
+fi

@@ -22,8 +22,14 @@
 //                         HBM (lane = item, register = user: 128 contiguous bytes per half-wave and user row), the
 //                         gradient tile G = coef (p - 1[diag]) is split in registers, dI += G^T U (24 MFMAs, U's th / tl)
 //
-// Shapes: D = 128, M and N multiples of 128, |coef| <= 1 (the trainer's example weights are normalised by their maximum).
+// Shapes: D = 128, M a multiple of 256, N of 1024, |coef| <= 1 (the trainer's example weights are normalised by their maximum).
 #include "common.hpp"
+
+// measurement variants (tools/ce16_variants.sh; results are WRONG by design): 1 no logits stores, 2 no E product,
+// 8 the tile wait leaves four vector-memory instructions (the logits stores) in flight, 32 backward without the logits loads
+#ifndef TT_CE16_EXP
+#define TT_CE16_EXP 0
+#endif
 
 namespace tt {
 namespace {
@@ -34,6 +40,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int C16_D = 128;
 constexpr int C16_TILE = 32;                 // streamed rows per ring stage
+constexpr int C16_NW = 8;                    // waves per workgroup: ONE workgroup per CU, its eight waves share one tile ring
+                                             // (two 4-wave workgroups per CU fetched every tile twice: the L1 path -- tile
+                                             // DMA + logits stores -- was as busy as the matrix pipe)
+constexpr int C16_ROWS_WG = 32 * C16_NW;     // stationary rows per workgroup
 constexpr int C16_ROW_B = C16_D * 2;         // bytes of one fp16 row
 constexpr int C16_RM_B = C16_TILE * C16_ROW_B;   // one term, row-major image of a stage: 8 KiB
 constexpr int C16_TR_B = C16_TILE * C16_ROW_B;   // one term, transposed image of a stage (2 blocks of 4 KiB)
@@ -121,8 +131,8 @@ namespace {
 __device__ __forceinline__ void dma_rowmajor(const _Float16* __restrict__ base, char* dst, int wave, int lane) {
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(base), 0, C16_RM_B, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {  // 8 instructions per term, 2 per wave
-    const int rbase = (wave * 2 + i) * 4;
+  for (int i = 0; i < 8 / C16_NW; ++i) {  // 8 instructions per term
+    const int rbase = (wave * (8 / C16_NW) + i) * 4;
     const int row = rbase + (lane >> 4);
     const int c = (lane & 15) ^ (row & 15);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + rbase * C16_ROW_B), 16,
@@ -133,8 +143,8 @@ __device__ __forceinline__ void dma_rowmajor(const _Float16* __restrict__ base, 
 __device__ __forceinline__ void dma_linear(const _Float16* __restrict__ base, char* dst, int wave, int lane) {
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(base), 0, C16_TR_B, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int off = (wave * 2 + i) * 1024;
+  for (int i = 0; i < 8 / C16_NW; ++i) {
+    const int off = (wave * (8 / C16_NW) + i) * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + off), 16, off + lane * 16, 0, 0, 0);
   }
 }
@@ -216,9 +226,13 @@ __device__ __forceinline__ void fwd_tile(const FwdStage* st, const u32x4 (&uh)[8
     v[e] = acc[e] * out_scale;
     tmax = fmaxf(tmax, v[e]);
   }
+#if !(TT_CE16_EXP & 1)
+  {  // the wave's 32 x 32 tile is one contiguous 4 KiB block of the logits buffer, row-major inside (see tt_hotpath.h)
+    float* tile = logit_row + (item0 >> 5) * 1024 + 8 * 0 + 4 * h;
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
-    *reinterpret_cast<float4*>(logit_row + item0 + 8 * g + 4 * h) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(tile + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+  }
+#endif
   tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
   if (tmax > mx) {  // (lane-divergent, rare after the first tiles)
     const float f = __builtin_amdgcn_exp2f(mx - tmax);
@@ -242,6 +256,10 @@ __device__ __forceinline__ void fwd_tile(const FwdStage* st, const u32x4 (&uh)[8
     split8(pv, ph[s], pl[s]);
   }
   // E^T[d][user] += I^T[d][item] P[item][user]: A = the tile's transposed image, B = the probabilities just formed
+#if TT_CE16_EXP & 2
+  E[0][0] += __builtin_bit_cast(float, ph[0][0] ^ pl[1][3]);
+  return;
+#endif
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -259,11 +277,16 @@ __device__ __forceinline__ void fwd_tile(const FwdStage* st, const u32x4 (&uh)[8
 
 }  // namespace
 
-__global__ __launch_bounds__(256, 2) void ce16_fwd_kernel(const FwdArgs p) {
+#if TT_CE16_EXP & 8
+#define C16_FWD_WAIT 0x0f74
+#else
+#define C16_FWD_WAIT 0x0f70
+#endif
+__global__ __launch_bounds__(64 * C16_NW, 2) void ce16_fwd_kernel(const FwdArgs p) {
   __shared__ __attribute__((aligned(1024))) FwdStage ring0;
   __shared__ __attribute__((aligned(1024))) FwdStage ring1;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const int64_t user = (int64_t)blockIdx.x * 128 + wave * 32 + r;
+  const int64_t user = (int64_t)blockIdx.x * C16_ROWS_WG + wave * 32 + r;
   const int split = blockIdx.y;
   const int64_t per = p.N / p.n_splits;  // a multiple of C16_TILE (host)
   const int64_t n0 = split * per;
@@ -282,16 +305,19 @@ __global__ __launch_bounds__(256, 2) void ce16_fwd_kernel(const FwdArgs p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) E[b][e] = 0.f;
   float mx = -INFINITY, sm = 0.f;
-  float* logit_row = p.logits + user * p.N;
+  // logits layout: [M / 32][N / 32] tiles of 32 users x 32 items, each 4 KiB contiguous and row-major inside -- the
+  // forward writes whole tiles (row-major [M][N] meant 32-byte pieces in 32 rows 4 N bytes apart per store: 0.33 of the
+  // kernel's 1.19 ms at N = 65536), the backward reads every tile as 16 coalesced 128-byte rows
+  float* logit_row = p.logits + ((user >> 5) * (p.N >> 5)) * 1024 + (user & 31) * 32;
 
   fwd_stage_dma(p, n0, &ring0, wave, lane);
   for (int tile = 0; tile < n_tiles; tile += 2) {  // two NAMED stages, unrolled by two (distinct LDS objects carry alias scopes)
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the tile has landed (and the logits stores of the previous one have left)
+    __builtin_amdgcn_s_waitcnt(C16_FWD_WAIT);  // vmcnt(0): the tile has landed (and the logits stores of the previous one have left)
     __builtin_amdgcn_s_barrier();
     if (tile + 1 < n_tiles) fwd_stage_dma(p, n0 + (int64_t)(tile + 1) * C16_TILE, &ring1, wave, lane);
     fwd_tile(&ring0, uh, ul, E, mx, sm, out_scale, logit_row, n0 + (int64_t)tile * C16_TILE, r, h);
     if (tile + 1 >= n_tiles) break;
-    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __builtin_amdgcn_s_waitcnt(C16_FWD_WAIT);
     __builtin_amdgcn_s_barrier();
     if (tile + 2 < n_tiles) fwd_stage_dma(p, n0 + (int64_t)(tile + 2) * C16_TILE, &ring0, wave, lane);
     fwd_tile(&ring1, uh, ul, E, mx, sm, out_scale, logit_row, n0 + (int64_t)(tile + 1) * C16_TILE, r, h);
@@ -358,13 +384,18 @@ struct BwdStage {
 // buffer loads: tile base in a scalar resource descriptor, row offset in a scalar register, ONE 32-bit per-lane offset
 // (global loads would carry a 64-bit VGPR address each: 32 registers and 32 VALU adds per tile).  The row stride is made
 // opaque so the 16 row offsets are a scalar multiply per tile, not 16 hoisted scalar registers (csrc/inbatch_ce.hip).
-__device__ __forceinline__ void bwd_fetch(const BwdArgs& p, int64_t user0, int lane_off, int wave, int lane, float (&s)[16], float& stat) {
-  int n = (int)p.N;
-  asm volatile("" : "+s"(n));
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.logits + user0 * p.N), 0, -1, 0x00020000);
+__device__ __forceinline__ void bwd_fetch(const BwdArgs& p, int64_t user0, int64_t item_blk, int lane_off, int wave, int lane, float (&s)[16], float& stat) {
+  // buffer loads: tile base in a scalar resource descriptor, row offset an immediate, ONE 32-bit per-lane offset
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.logits + ((user0 >> 5) * (p.N >> 5) + item_blk) * 1024), 0, 4096, 0x00020000);
+#if TT_CE16_EXP & 32
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s[e] = (float)(lane_off + e) * 1e-9f;
+#else
 #pragma unroll
   for (int e = 0; e < 16; ++e)
-    s[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane_off, ((e & 3) + 8 * (e >> 2)) * n * 4, 0));
+    s[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane_off, ((e & 3) + 8 * (e >> 2)) * 128, 0));
+#endif
   // the tile's 32 (lse, coef) pairs: one value per lane of wave 0, handed to everybody through LDS (every lane needs 16 of
   // each; fetched per lane they would be twice the logits' load traffic and 64 registers of double buffer)
   if (wave == 0) stat = (lane < 32 ? p.row_lse : p.coef)[user0 + (lane & 31)];
@@ -408,14 +439,15 @@ __device__ __forceinline__ void bwd_tile(const BwdStage* st, const float* stat, 
 }
 }  // namespace
 
-__global__ __launch_bounds__(256, 2) void ce16_bwd_items_kernel(const BwdArgs p) {
+__global__ __launch_bounds__(64 * C16_NW, 2) void ce16_bwd_items_kernel(const BwdArgs p) {
   __shared__ __attribute__((aligned(1024))) BwdStage ring0;
   __shared__ __attribute__((aligned(1024))) BwdStage ring1;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const int64_t item = (int64_t)blockIdx.x * 128 + wave * 32 + r;
+  const int64_t item = (int64_t)blockIdx.x * C16_ROWS_WG + wave * 32 + r;
   const int64_t diag_user = item - p.diag_off;  // the user whose positive this item is (outside [0, M): none)
   const int n_tiles = (int)(p.M / C16_TILE);
-  const int lane_off = (int)((4 * h * p.N + item) * 4);  // bytes from the tile's first logit to this lane's column, rows 4 h ..
+  const int lane_off = (4 * h * 32 + r) * 4;  // bytes from the tile's first logit to this lane's column, rows 4 h ..
+  const int64_t item_blk = (int64_t)blockIdx.x * C16_NW + __builtin_amdgcn_readfirstlane(wave);  // (wave-uniform: scalar descriptor)
   f32x16 acc[4];
 #pragma unroll
   for (int b = 0; b < 4; ++b)
@@ -427,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void ce16_bwd_items_kernel(const BwdArgs p)
   float sv0 = 0.f, sv1 = 0.f;
   dma_linear(p.u.th, ring0.tr_h, wave, lane);
   dma_linear(p.u.tl, ring0.tr_l, wave, lane);
-  bwd_fetch(p, 0, lane_off, wave, lane, s0, sv0);
+  bwd_fetch(p, 0, item_blk, lane_off, wave, lane, s0, sv0);
   for (int tile = 0; tile < n_tiles; tile += 2) {
     __builtin_amdgcn_s_waitcnt(0x0f70);
     if (wave == 0) stat0[lane] = sv0;
@@ -436,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void ce16_bwd_items_kernel(const BwdArgs p)
       const int64_t u1 = (int64_t)(tile + 1) * C16_TILE;
       dma_linear(p.u.th + u1 * C16_D, ring1.tr_h, wave, lane);
       dma_linear(p.u.tl + u1 * C16_D, ring1.tr_l, wave, lane);
-      bwd_fetch(p, u1, lane_off, wave, lane, s1, sv1);
+      bwd_fetch(p, u1, item_blk, lane_off, wave, lane, s1, sv1);
     }
     bwd_tile(&ring0, stat0, s0, acc, (int64_t)tile * C16_TILE, diag_user, r, h);
     if (tile + 1 >= n_tiles) break;
@@ -447,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void ce16_bwd_items_kernel(const BwdArgs p)
       const int64_t u2 = (int64_t)(tile + 2) * C16_TILE;
       dma_linear(p.u.th + u2 * C16_D, ring0.tr_h, wave, lane);
       dma_linear(p.u.tl + u2 * C16_D, ring0.tr_l, wave, lane);
-      bwd_fetch(p, u2, lane_off, wave, lane, s0, sv0);
+      bwd_fetch(p, u2, item_blk, lane_off, wave, lane, s0, sv0);
     }
     bwd_tile(&ring1, stat1, s1, acc, (int64_t)(tile + 1) * C16_TILE, diag_user, r, h);
   }
@@ -463,7 +495,13 @@ __global__ __launch_bounds__(256, 2) void ce16_bwd_items_kernel(const BwdArgs p)
 
 // ---------------------------------------------------------------------------------------------------- host
 namespace {
-constexpr int C16_SPLITS = 8;
+// item splits of the forward: enough workgroups for the 256 CUs, N / splits a multiple of the tile
+int pick_splits(int64_t M, int64_t N) {
+  int want = 8;
+  while (want < 32 && (M / C16_ROWS_WG) * want < 256) want *= 2;
+  while (want > 1 && N % ((int64_t)want * 128)) want /= 2;
+  return want;
+}
 
 struct Ws {
   unsigned* absmax;
@@ -472,13 +510,14 @@ struct Ws {
 };
 int64_t carve(void* base, int64_t M, int64_t N, Ws* w) {
   Carver c(base);
+  const int splits = pick_splits(M, N);
   unsigned* am = c.take<unsigned>(64);
   Images u, it;
   u.h = c.take<_Float16>(M * C16_D); u.l = c.take<_Float16>(M * C16_D); u.th = c.take<_Float16>(M * C16_D); u.tl = c.take<_Float16>(M * C16_D);
   it.h = c.take<_Float16>(N * C16_D); it.l = c.take<_Float16>(N * C16_D); it.th = c.take<_Float16>(N * C16_D); it.tl = c.take<_Float16>(N * C16_D);
-  float* pmax = c.take<float>((int64_t)C16_SPLITS * M);
-  float* psum = c.take<float>((int64_t)C16_SPLITS * M);
-  float* pe = c.take<float>((int64_t)C16_SPLITS * M * C16_D);
+  float* pmax = c.take<float>((int64_t)splits * M);
+  float* psum = c.take<float>((int64_t)splits * M);
+  float* pe = c.take<float>((int64_t)splits * M * C16_D);
   if (w) { w->absmax = am; w->u = u; w->it = it; w->pmax = pmax; w->psum = psum; w->pe = pe; }
   return c.off;
 }
@@ -496,7 +535,7 @@ int split_matrix(const float* X, int64_t ld, int64_t rows, unsigned* absmax, con
 using namespace tt;
 
 extern "C" int tt_ce16_supported(int64_t M, int64_t N, int64_t D) {
-  return (D == C16_D && M > 0 && N > 0 && M % 128 == 0 && N % (128 * C16_SPLITS) == 0) ? 1 : 0;
+  return (D == C16_D && M > 0 && N > 0 && M % C16_ROWS_WG == 0 && N % 1024 == 0) ? 1 : 0;
 }
 
 extern "C" int64_t tt_ce16_workspace_bytes(int64_t M, int64_t N, int64_t D) {
@@ -509,7 +548,7 @@ extern "C" int tt_ce16_fwd_du_keep(const float* U, int64_t ldu, const float* I, 
                                    int64_t logits_bytes, void* ws, int64_t ws_bytes, tt_stream_t stream) {
   if (!U || !I || !row_lse || !row_ce || !du_unit || !logits || !ws) return fail_arg("tt_ce16_fwd_du_keep: null pointer");
   if (!tt_ce16_supported(M, N, D)) {
-    set_error("tt_ce16_fwd_du_keep: needs D = 128, M %% 128 == 0, N %% 1024 == 0");
+    set_error("tt_ce16_fwd_du_keep: needs D = 128, M %% 256 == 0, N %% 1024 == 0");
     return TT_E_UNSUPPORTED;
   }
   if (ldu < D || ldi < D || ld_du < D || (ldu | ldi | ld_du) % 4 || ((uintptr_t)U | (uintptr_t)I | (uintptr_t)du_unit) % 16)
@@ -528,13 +567,14 @@ extern "C" int tt_ce16_fwd_du_keep(const float* U, int64_t ldu, const float* I, 
   if (int rc = split_matrix(I, ldi, N, w.absmax + 1, w.it, st)) return rc;
   FwdArgs a;
   a.u = w.u; a.it = w.it; a.absmax = w.absmax; a.M = M; a.N = N; a.logits = logits;
-  a.pmax = w.pmax; a.psum = w.psum; a.pe = w.pe; a.n_splits = C16_SPLITS;
+  const int splits = pick_splits(M, N);
+  a.pmax = w.pmax; a.psum = w.psum; a.pe = w.pe; a.n_splits = splits;
   {
     ProfScope prof("ce_fwd_kernel", st);
-    hipLaunchKernelGGL(ce16_fwd_kernel, dim3((unsigned)(M / 128), C16_SPLITS), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(ce16_fwd_kernel, dim3((unsigned)(M / C16_ROWS_WG), splits), dim3(64 * C16_NW), 0, st, a);
   }
   if (int rc = check_launch("ce16_fwd_kernel")) return rc;
-  hipLaunchKernelGGL(ce16_merge_kernel, dim3((unsigned)ceil_div(M, 4)), dim3(256), 0, st, w.pmax, w.psum, w.pe, C16_SPLITS, M, w.absmax, U, ldu, I,
+  hipLaunchKernelGGL(ce16_merge_kernel, dim3((unsigned)ceil_div(M, 4)), dim3(256), 0, st, w.pmax, w.psum, w.pe, splits, M, w.absmax, U, ldu, I,
                      ldi, diag_offset, row_lse, row_ce, du_unit, ld_du);
   return check_launch("ce16_merge_kernel");
 }
@@ -544,7 +584,7 @@ extern "C" int tt_ce16_bwd_kept(const float* U, int64_t ldu, int64_t M, int64_t 
                                 int64_t ws_bytes, tt_stream_t stream) {
   if (!U || !row_lse || !coef || !logits || !dI || !ws) return fail_arg("tt_ce16_bwd_kept: null pointer");
   if (!tt_ce16_supported(M, N, D)) {
-    set_error("tt_ce16_bwd_kept: needs D = 128, M %% 128 == 0, N %% 1024 == 0");
+    set_error("tt_ce16_bwd_kept: needs D = 128, M %% 256 == 0, N %% 1024 == 0");
     return TT_E_UNSUPPORTED;
   }
   if (ldu < D || lddi < D || (ldu | lddi) % 4 || ((uintptr_t)U | (uintptr_t)dI) % 16) return fail_arg("tt_ce16_bwd_kept: rows must be 16-byte aligned");
@@ -564,7 +604,7 @@ extern "C" int tt_ce16_bwd_kept(const float* U, int64_t ldu, int64_t M, int64_t 
   a.absmax = w.absmax;
   {
     ProfScope prof("ce_bwd_kernel", st);
-    hipLaunchKernelGGL(ce16_bwd_items_kernel, dim3((unsigned)(N / 128)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(ce16_bwd_items_kernel, dim3((unsigned)(N / C16_ROWS_WG)), dim3(64 * C16_NW), 0, st, a);
   }
   return check_launch("ce16_bwd_items_kernel");
 }
