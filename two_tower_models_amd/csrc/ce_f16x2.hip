@@ -10,7 +10,7 @@
 // eight v_mfma_f32_32x32x2_f32.
 //
 //   ce16_split_kernel      fp32 [R][128] -> four fp16 images: h, l row-major (operand of products that reduce over d)
-//                         and th, tl = [R/16][128][16] blocks (operand of products that reduce over ROWS: the lane that
+//                         and th, tl = [R/16][2][128][8] blocks (operand of products that reduce over ROWS: the lane that
 //                         owns column d reads its 8 rows of a 16-row k-step as one 16-B chunk, in the row order the
 //                         MFMA result layout hands the other operand over in -- no transposing LDS read anywhere)
 //   ce16_fwd_kernel       users stationary (B fragments of both terms in registers, 32 per wave), item tiles by LDS-DMA;
@@ -25,7 +25,8 @@
 // Shapes: D = 128, M a multiple of 256, N of 1024, |coef| <= 1 (the trainer's example weights are normalised by their maximum).
 #include "common.hpp"
 
-// measurement variants (tools/ce16_variants.sh; results are WRONG by design): 1 no logits stores, 2 no E product,
+// measurement variants (tools/ce16_variants.sh; results are WRONG by design): 1 no logits stores, 2 no E product, 4 non-temporal
+// logits stores [correct],
 // 8 the tile wait leaves four vector-memory instructions (the logits stores) in flight, 32 backward without the logits loads
 #ifndef TT_CE16_EXP
 #define TT_CE16_EXP 0
@@ -80,7 +81,9 @@ __global__ void ce16_absmax_kernel(const float* __restrict__ X, int64_t ld, int6
 }
 
 // one workgroup per 16-row block: row-major terms (thread = row, 8 columns) and the block's transposed image
-// (thread = column d and lane half hh: slots q = 0..7 <-> rows (q & 3) + 8 (q >> 2) + 4 hh)
+// (thread = column d and lane half hh: slots q = 0..7 <-> rows (q & 3) + 8 (q >> 2) + 4 hh; [half][d][slot] so that the
+// 16 lanes of a ds_read_b128 lane group -- all of one half -- cover 16 consecutive-modulo-16 chunks: no bank conflict;
+// [d][half][slot] was a 2-way conflict on every read)
 __global__ __launch_bounds__(256) void ce16_split_kernel(const float* __restrict__ X, int64_t ld, int64_t rows, const unsigned* __restrict__ absmax,
                                                       Images im) {
   __shared__ float xs[16][C16_D + 4];
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256) void ce16_split_kernel(const float* __restrict
       a[q] = x;
       b[q] = (_Float16)(v - (float)x);
     }
-    const int64_t at = (blk * C16_D + d) * 16 + hh * 8;
+    const int64_t at = blk * (C16_D * 16) + (hh * C16_D + d) * 8;  // [block][lane half][d][8 slots]
     *reinterpret_cast<f16x8*>(im.th + at) = a;
     *reinterpret_cast<f16x8*>(im.tl + at) = b;
   }
@@ -230,7 +233,17 @@ __device__ __forceinline__ void fwd_tile(const FwdStage* st, const u32x4 (&uh)[8
   {  // the wave's 32 x 32 tile is one contiguous 4 KiB block of the logits buffer, row-major inside (see tt_hotpath.h)
     float* tile = logit_row + (item0 >> 5) * 1024 + 8 * 0 + 4 * h;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(tile + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+    for (int g = 0; g < 4; ++g) {
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const f32x4 q = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+#if TT_CE16_EXP & 4
+      __builtin_nontemporal_store(q, reinterpret_cast<f32x4*>(tile + 8 * g));
+#else
+      // (plain stores: non-temporal ones were measured 25 % slower here -- 1.30 vs 1.04 ms, WRITE_SIZE 3.1 GB for 2.15 GB of
+      // logits: the 32-byte pieces of a line no longer merge in L2)
+      *reinterpret_cast<f32x4*>(tile + 8 * g) = q;
+#endif
+    }
   }
 #endif
   tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
@@ -264,7 +277,7 @@ __device__ __forceinline__ void fwd_tile(const FwdStage* st, const u32x4 (&uh)[8
   for (int s = 0; s < 2; ++s) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const int at = s * 4096 + (b * 32 + r) * 32 + h * 16;
+      const int at = s * 4096 + h * 2048 + (b * 32 + r) * 16;
       const u32x4 th = *reinterpret_cast<const u32x4*>(st->tr_h + at);
       const u32x4 tl = *reinterpret_cast<const u32x4*>(st->tr_l + at);
       E[b] = MFMA16(th, ph[s], E[b]);
@@ -427,7 +440,7 @@ __device__ __forceinline__ void bwd_tile(const BwdStage* st, const float* stat, 
   for (int k = 0; k < 2; ++k) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const int at = k * 4096 + (b * 32 + r) * 32 + h * 16;
+      const int at = k * 4096 + h * 2048 + (b * 32 + r) * 16;
       const u32x4 th = *reinterpret_cast<const u32x4*>(st->tr_h + at);
       const u32x4 tl = *reinterpret_cast<const u32x4*>(st->tr_l + at);
       acc[b] = MFMA16(th, gh[k], acc[b]);
