@@ -17,7 +17,7 @@
 //                         per 32 x 32 tile: logits (24 MFMAs), online softmax per lane (= per user), the probabilities
 //                         re-split in registers and E[u] += P I (24 MFMAs, the tile's th / tl image), log2-domain
 //                         logits stored for the backward; per (split, user) partials
-//   ce16_merge_kernel     splits -> lse, ce (diagonal logit as an fp32 dot product), unit user gradient E/sum - I_diag
+//   ce16_merge_kernel     splits -> lse (log2 domain), ce (diagonal logit as an fp32 dot product), unit user gradient E/sum - I_diag
 //   ce16_bwd_items_kernel items stationary (accumulators only); per 32-user tile the kept logits come straight from
 //                         HBM (lane = item, register = user: 128 contiguous bytes per half-wave and user row), the
 //                         gradient tile G = coef (p - 1[diag]) is split in registers, dI += G^T U (24 MFMAs, U's th / tl)
@@ -374,9 +374,11 @@ __global__ __launch_bounds__(256) void ce16_merge_kernel(const float* __restrict
   *reinterpret_cast<float2*>(du_unit + u * ld_du + 2 * lane) = make_float2(e0 * inv - iv.x, e1 * inv - iv.y);
   const float diag = wave_sum(fmaf(uv.x, iv.x, uv.y * iv.y));
   if (lane == 0) {
-    const float lse = (m + log2f(tot)) * LN2;
-    row_lse[u] = lse;
-    row_ce[u] = lse - diag;
+    // row_lse stays in the log2 domain, like the fp32 pair's: the backward subtracts it from log2-domain logits, and
+    // a round trip through the natural logarithm costs an ulp of |lse| -- 1e-3 on saturated rows with logits of 1e4
+    const float lse2 = m + log2f(tot);
+    row_lse[u] = lse2;
+    row_ce[u] = lse2 * LN2 - diag;
   }
 }
 
@@ -430,7 +432,7 @@ __device__ __forceinline__ void bwd_tile(const BwdStage* st, const float* stat, 
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int e = 8 * k + q;
-      float pr = __builtin_amdgcn_exp2f(s[e] - lse[e] * LOG2E);
+      float pr = __builtin_amdgcn_exp2f(s[e] - lse[e]);
       if (user0 + brow(e, h) == diag_user) pr -= 1.f;
       gv[q] = pr * cf[e] * C16_PSCALE;
     }
