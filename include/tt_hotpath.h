@@ -579,6 +579,7 @@ int tt_comm_broadcast(tt_comm_t comm, void* buf, int64_t count, int dtype, int32
  * (both stored as bf16, fp32 accumulate -- BASELINE config 5). */
 #define TT_F32 0
 #define TT_BF16 1
+#define TT_F16X2 2 /* EXPLORATORY: both operands as two-term fp16 splits of fp32 rows, see tt_mips_split_rows */
 int64_t tt_mips_workspace_bytes(int64_t B, int64_t C, int64_t D, int64_t K, int dtype);
 int tt_mips_topk(const void* query, const void* corpus, int dtype, int64_t B, int64_t C,
                  int64_t D, int64_t K, int64_t* idx_out, float* score_out, void* ws,
@@ -590,6 +591,18 @@ int64_t tt_mips_merge_workspace_bytes(int64_t B, int64_t n_cand);
 int tt_mips_merge(const float* scores, const int64_t* idx, int64_t B, int64_t n_cand, int64_t K,
                   int64_t* idx_out, float* score_out, void* ws, int64_t ws_bytes, tt_stream_t stream);
 int tt_f32_to_bf16(const float* in, uint16_t* out, int64_t n, tt_stream_t stream);
+
+/* EXPLORATORY: fp32-grade MIPS scores on the fp16 matrix pipe (dtype TT_F16X2; D = 128 only).  tt_mips_split_rows turns
+ * fp32 rows into [rows][D x fp16 h | D x fp16 l] (x * scale = h + l, scale[0] = the power of two that brings the
+ * matrix' largest magnitude to the top of fp16's range; 4 D bytes per row, the fp32 row's size; ws: 256 bytes) -- once
+ * for a corpus, per call for the queries.  tt_mips_topk(query_split, corpus_split, TT_F16X2, ...) then scores every pair
+ * as three fp16 MFMA products per 16-wide k-step (element-wise error at an fp32 fma chain's level, csrc/ce_f16x2.hip)
+ * and returns scores times scale_q * scale_c; tt_mips_unscale divides that out (powers of two: exact, order untouched).
+ * Same contract as the fp32 path otherwise -- (score desc, index asc), bit-exact indices and scores on exact-arithmetic
+ * corpora; ref:src/baseline_mips_module.py:57-61. */
+int tt_mips_split_rows(const float* X, int64_t rows, int64_t D, uint16_t* out, float* scale, void* ws, int64_t ws_bytes,
+                       tt_stream_t stream);
+int tt_mips_unscale(float* scores, int64_t n, const float* scale_a, const float* scale_b, tt_stream_t stream);
 int tt_gather_rows_bf16(const uint16_t* table, int64_t n_rows, int64_t dim, const int64_t* ids,
                         int64_t n_ids, float* out, int64_t ld_out, int32_t* oob_flag,
                         tt_stream_t stream);

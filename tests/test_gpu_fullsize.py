@@ -551,6 +551,51 @@ def test_mips_10m_exact_arithmetic_corpus_bit_exact_order(T, bf16, B):
     assert torch.equal(idx.cpu(), want_idx)
 
 
+@pytest.mark.parametrize("B", [8, 72, 300])
+def test_mips_split_fp16_scoring_exact_arithmetic_and_random(T, B):
+    """EXPLORATORY TT_F16X2 scoring (BaselineMIPSModule.use_split_fp16_scoring: fp32 corpus + its two-term fp16 split, three
+    fp16 MFMA products per product).  (1) exact-arithmetic corpus of 3 M rows: indices AND scores bit for bit equal to the CPU
+    oracle's (score desc, index asc) order, ties included -- the fp32 path's contract (B = 8: shared-query pass 1, 72 /
+    300: the throughput forms); (2) random corpus: every picked score against a float64 checker at the fp32 path's
+    tolerance, k-th-score optimality, overlap with the float64 top-K."""
+    import two_tower_models_amd as A
+    from oracle import cpu_ref as R
+    C_, D, K = 3_000_000, 128, 500
+    g = torch.Generator(device=DEV).manual_seed(19)
+    corpus = torch.randint(-1, 2, (C_, D), device=DEV, generator=g, dtype=torch.int8).float()
+    i = torch.arange(C_, device=DEV)
+    corpus[:, D - 3] = ((i & 63) - 32).float()
+    corpus[:, D - 2] = (((i >> 6) & 63) - 32).float()
+    corpus[:, D - 1] = (((i >> 12) & 15) - 8).float()
+    q = torch.randint(-1, 2, (B, D), device=DEV, generator=g, dtype=torch.int8).float()
+    q[:, D - 3], q[:, D - 2], q[:, D - 1] = 2.0 ** -6, 2.0 ** -12, 2.0 ** -16
+    m = A.BaselineMIPSModule(corpus_size=8, embedding_dim=D)
+    m.corpus, m.corpus_size = corpus, C_
+    m.use_split_fp16_scoring()
+    idx, sc = m.search(q, K)
+    nq = min(B, 16)  # the oracle is a CPU matmul: a sample of the queries
+    want_idx, want_sc, _ = R.mips_topk(q[:nq].cpu(), corpus.cpu(), K, chunk=2)
+    assert torch.equal(sc[:nq].cpu(), want_sc)
+    assert torch.equal(idx[:nq].cpu(), want_idx)
+    idx32, sc32 = A.BaselineMIPSModule.search(m.use_split_fp16_scoring(False), q, K)  # and the fp32-MFMA path agrees
+    assert torch.equal(idx32, idx) and torch.equal(sc32, sc)
+    # random data
+    corpus = torch.randn(C_, D, device=DEV, generator=g)
+    q = torch.randn(B, D, device=DEV, generator=g)
+    m.corpus = corpus
+    m.use_split_fp16_scoring()
+    idx, sc = m.search(q, K)
+    assert bool((sc[:, 1:] <= sc[:, :-1]).all()) and bool(((idx >= 0) & (idx < C_)).all())
+    assert all(len(set(r.tolist())) == K for r in idx[:8].cpu())
+    full = _fp64_scores(q[:32], corpus)
+    picked = torch.gather(full, 1, idx[:32])
+    assert torch.allclose(picked, sc[:32].double(), atol=5e-5)  # (the fp32 path's test allows 5e-4)
+    ref = torch.topk(full, K, dim=1)
+    assert bool((picked.min(1).values >= ref.values[:, -1] - 5e-5).all())
+    overlap = np.mean([len(set(a.tolist()) & set(b.tolist())) / K for a, b in zip(idx[:32].cpu(), ref.indices.cpu())])
+    assert overlap > 0.999
+
+
 def test_table_beyond_2_31_elements_gather_and_adam(T):
     """A table with more than 2^31 ELEMENTS (20 M x 128 = 2.56 G floats, 10.2 GB; 30.7 GB with both moments -- what
     one rank of BASELINE config 4 holds at N = 8 is 12.5 M rows): gather, the row plan and two dense-exact Adam

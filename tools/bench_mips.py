@@ -24,8 +24,12 @@ m = A.BaselineMIPSModule(corpus_size=8, embedding_dim=D)
 m.corpus = torch.randn(Cn, D, device=dev, generator=g)
 m.corpus_size = Cn
 q = torch.randn(B, D, device=dev, generator=g)
-for name in ("fp32", "bf16"):
+for name in ("fp32", "fp32_split16", "bf16"):
+    if name == "fp32_split16":  # EXPLORATORY: fp32 corpus scored as two-term fp16 splits (three fp16 MFMA products per product)
+        ref_idx, ref_sc = idx, sc
+        m.use_split_fp16_scoring()
     if name == "bf16":
+        m.use_split_fp16_scoring(False)
         m.use_bf16_storage()
     idx, sc = m.search(q, K)  # warm-up (allocates the workspace)
     torch.cuda.synchronize()
@@ -45,3 +49,7 @@ for name in ("fp32", "bf16"):
           f"score GEMM pass {gemm_ms:.2f} ms = {flops / gemm_ms / 1e9:.0f} TFLOP/s "
           f"({cnt.value // reps} passes/call), corpus stream {Cn * D * (2 if name == 'bf16' else 4) / 1e9:.2f} GB",
           flush=True)
+    if name == "fp32_split16":
+        same = float((idx == ref_idx).float().mean())
+        print(f"  fp32_split16 vs fp32: {same:.5f} of the returned indices identical position by position, "
+              f"max |score difference| {float((sc - ref_sc).abs().max()):.2e} (scores ~ {float(ref_sc.abs().mean()):.1f})", flush=True)

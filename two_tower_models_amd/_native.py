@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("TT_HOTPATH_LIB") or os.path.join(_PKG, "lib", "libtt_
 
 TT_GEMM_NT, TT_GEMM_NN, TT_GEMM_TN = 0, 1, 2
 TT_EPI_NONE, TT_EPI_RELU, TT_EPI_RELU_MASK = 0, 1, 2
-TT_F32, TT_BF16 = 0, 1
+TT_F32, TT_BF16, TT_F16X2 = 0, 1, 2
 TT_E_BADARG, TT_E_WORKSPACE, TT_E_UNSUPPORTED = -1, -2, -3
 TT_DEBIAS_COMBINED, TT_DEBIAS_POSITION, TT_DEBIAS_USER = 0, 1, 2
 TT_COMM_ID_BYTES = 128
@@ -169,6 +169,8 @@ SIGNATURES = {
     "tt_mips_merge_workspace_bytes": (_i64, [_i64, _i64]),
     "tt_mips_merge": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
     "tt_f32_to_bf16": (_int, [_vp, _vp, _i64, _vp]),
+    "tt_mips_split_rows": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "tt_mips_unscale": (_int, [_vp, _i64, _vp, _vp, _vp]),
     "tt_gather_rows_bf16": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
 }
 

@@ -44,6 +44,7 @@
 namespace tt {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 
@@ -248,6 +249,44 @@ struct Op<TT_BF16, DPX> {
   }
 };
 
+// EXPLORATORY (TT_F16X2): fp32-grade scores on the fp16 matrix pipe.  A row is the two-term split of an fp32 row after a
+// power-of-two scale (csrc/ce_f16x2.hip explains the arithmetic): [D x fp16 h | D x fp16 l] -- 4 D bytes, the fp32 row's
+// size, so staging, tile DMA and the LDS image are the fp32 path's, byte for byte.  A score is the sum over 16-wide
+// k-steps of yh qh + yh ql + yl qh, three v_mfma_f32_32x32x16_f16 into one accumulator -- the SAME sequence in pass 1
+// and in the sparse re-scoring pass, so their scores agree bit for bit, as the selection requires.  DPX = D / 8.
+template <int DPX>
+struct Op<TT_F16X2, DPX> : Op<TT_F32, DPX> {
+  static constexpr int KS = DPX / 2;  // k-steps of 16
+  static constexpr int DP = DPX * 8;
+  struct Frag { uint4 h[KS], l[KS]; };
+  static __device__ __forceinline__ void load_queries(Frag& f, const void* Q, int64_t row, int64_t nrows, int64_t D, int hh, bool) {
+    const uint16_t* X = reinterpret_cast<const uint16_t*>(Q);
+#pragma unroll
+    for (int g = 0; g < KS; ++g) {
+      f.h[g] = (row < nrows) ? *reinterpret_cast<const uint4*>(X + row * 2 * D + 16 * g + 8 * hh) : make_uint4(0, 0, 0, 0);
+      f.l[g] = (row < nrows) ? *reinterpret_cast<const uint4*>(X + row * 2 * D + D + 16 * g + 8 * hh) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  // yrow -> this lane's A-operand row (LDS or global), already advanced by 16*h bytes
+  static __device__ __forceinline__ f32x16 tile_at(const char* yrow, const Frag& q) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int g = 0; g < KS; ++g) {
+      const uint4 yh = *reinterpret_cast<const uint4*>(yrow + 32 * g);
+      const uint4 yl = *reinterpret_cast<const uint4*>(yrow + 2 * DP + 32 * g);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, yh), __builtin_bit_cast(f16x8, q.h[g]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, yh), __builtin_bit_cast(f16x8, q.l[g]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, yl), __builtin_bit_cast(f16x8, q.h[g]), acc, 0, 0, 0);
+    }
+    return acc;
+  }
+  static __device__ __forceinline__ f32x16 tile(const char* Ys, const Frag& q, int jt, int r, int h) {
+    return tile_at(Ys + (jt * 32 + r) * Op<TT_F32, DPX>::LDB + 16 * h, q);
+  }
+};
+
 // ---------------------------------------------------------------- the dense GEMM pass
 // PASS 1: group maxima.  PASS 2 (fallback for ragged D / tiny corpora): candidates.
 template <int DT, int DPX, int PASS>
@@ -396,6 +435,34 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // Without it three of the four waves multiply zero queries (B = 16 at C = 10 M: 3.0 -> 0.9 ms).
 // SF = 2 (33..64 queries): two pairs of waves, each pair holds 32 queries and its two waves take
 // sub-tile 0 / sub-tile 1 of every 64-row tile (alternating 16-row blocks of each group).
+// TT_F16X2 scores of one 32-row sub-tile of the swizzled LDS tile (fp32 image: 32 DPX bytes per row, chunks 0 .. 2 KS - 1
+// the h term, 2 KS .. 4 KS - 1 the l term; the swizzle flips the low four chunk bits only, so the halves stay apart):
+// the MFMA sequence of Op<TT_F16X2>::tile_at, operand reads one k-step ahead
+template <int DPX>
+__device__ __forceinline__ f32x16 score_tile_f16x2(const float* ys, const typename Op<TT_F16X2, DPX>::Frag& q, int jt, int r, int h) {
+  using TM = TileMap<DPX, true>;
+  constexpr int KS = DPX / 2;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const int row = jt * 32 + r;
+  uint4 yh[2], yl[2];
+  yh[0] = *reinterpret_cast<const uint4*>(ys + TM::chunk(row, h));
+  yl[0] = *reinterpret_cast<const uint4*>(ys + TM::chunk(row, 2 * KS + h));
+#pragma unroll
+  for (int g = 0; g < KS; ++g) {
+    if (g + 1 < KS) {
+      yh[(g + 1) & 1] = *reinterpret_cast<const uint4*>(ys + TM::chunk(row, 2 * (g + 1) + h));
+      yl[(g + 1) & 1] = *reinterpret_cast<const uint4*>(ys + TM::chunk(row, 2 * KS + 2 * (g + 1) + h));
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, yh[g & 1]), __builtin_bit_cast(f16x8, q.h[g]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, yh[g & 1]), __builtin_bit_cast(f16x8, q.l[g]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, yl[g & 1]), __builtin_bit_cast(f16x8, q.h[g]), acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return acc;
+}
+
 template <int DT, int DPX, int NQ, int STAGES, int SF>
 __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p) {
   constexpr bool SHARE = SF != 0;
@@ -514,6 +581,8 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
       f32x16 acc[NQ];
       if constexpr (DT == TT_F32) {
         acc[0] = score_tile<DPX, true>(ys, qf[0].v, jt, r, h);
+      } else if constexpr (DT == TT_F16X2) {
+        acc[0] = score_tile_f16x2<DPX>(ys, qf[0], jt, r, h);
       } else {
 #pragma unroll
         for (int n = 0; n < NQ; ++n)
@@ -1337,6 +1406,8 @@ static bool plan_mips(int64_t B, int64_t C, int64_t D, int64_t K, int dtype, Mip
     if (D <= 32) pl.dpx = 4; else if (D <= 64) pl.dpx = 8; else if (D <= 128) pl.dpx = 16; else pl.dpx = 0;  // 0: generic form
   } else if (dtype == TT_BF16) {
     if (D <= 32) pl.dpx = 2; else if (D <= 64) pl.dpx = 4; else if (D <= 128) pl.dpx = 8; else pl.dpx = 0;
+  } else if (dtype == TT_F16X2 && D == 128) {
+    pl.dpx = 16;
   } else {
     return false;
   }
@@ -1344,7 +1415,7 @@ static bool plan_mips(int64_t B, int64_t C, int64_t D, int64_t K, int dtype, Mip
   pl.n_groups = 2 * pl.n_chunks;
   const int64_t sel = K < pl.n_groups ? K : pl.n_groups;
   pl.cap = sel * GROUP;
-  if (dtype == TT_BF16 || (dtype == TT_F32 && D >= 32)) {  // the LDS-DMA pass may use 128-row groups: room for K whole groups of those
+  if (dtype == TT_BF16 || dtype == TT_F16X2 || (dtype == TT_F32 && D >= 32)) {  // the LDS-DMA pass may use 128-row groups: room for K whole groups of those
     const int64_t n7 = 2 * ceil_div(C, 2 * CHUNK), sel7 = K < n7 ? K : n7;
     if (sel7 * 2 * GROUP > pl.cap) pl.cap = sel7 * 2 * GROUP;
   }
@@ -1377,6 +1448,7 @@ static int dispatch_score(int dtype, int dpx, const MipsArgs& a, dim3 grid, hipS
     if (dpx == 8) return launch_score<TT_F32, 8, PASS>(a, grid, st);
     return launch_score<TT_F32, 16, PASS>(a, grid, st);
   }
+  if (dtype == TT_F16X2) return launch_score<TT_F16X2, 16, PASS>(a, grid, st);
   if (dpx == 2) return launch_score<TT_BF16, 2, PASS>(a, grid, st);
   if (dpx == 4) return launch_score<TT_BF16, 4, PASS>(a, grid, st);
   return launch_score<TT_BF16, 8, PASS>(a, grid, st);
@@ -1417,6 +1489,8 @@ static int dispatch_pass1_dma(int dtype, int dpx, const MipsArgs& a, int64_t spl
     if (dpx == 8) return sf == 4 ? launch_pass1_dma<TT_F32, 8, 1, 4>(a, splits, st) : sf == 2 ? launch_pass1_dma<TT_F32, 8, 1, 2>(a, splits, st) : launch_pass1_dma<TT_F32, 8, 1>(a, splits, st);
     return sf == 4 ? launch_pass1_dma<TT_F32, 16, 1, 4>(a, splits, st) : sf == 2 ? launch_pass1_dma<TT_F32, 16, 1, 2>(a, splits, st) : launch_pass1_dma<TT_F32, 16, 1>(a, splits, st);
   }
+  if (dtype == TT_F16X2)
+    return sf == 4 ? launch_pass1_dma<TT_F16X2, 16, 1, 4>(a, splits, st) : sf == 2 ? launch_pass1_dma<TT_F16X2, 16, 1, 2>(a, splits, st) : launch_pass1_dma<TT_F16X2, 16, 1>(a, splits, st);
   if (sf) {
     if (dpx == 4) return sf == 4 ? launch_pass1_dma<TT_BF16, 4, 1, 4>(a, splits, st) : launch_pass1_dma<TT_BF16, 4, 1, 2>(a, splits, st);
     if (dpx == 8) return sf == 4 ? launch_pass1_dma<TT_BF16, 8, 1, 4>(a, splits, st) : launch_pass1_dma<TT_BF16, 8, 1, 2>(a, splits, st);
@@ -1447,6 +1521,7 @@ static int dispatch_sparse(int dtype, int dpx, const MipsArgs& a, dim3 grid, hip
     if (dpx == 8) return launch_sparse<TT_F32, 8>(a, grid, st);
     return launch_sparse<TT_F32, 16>(a, grid, st);
   }
+  if (dtype == TT_F16X2) return launch_sparse<TT_F16X2, 16>(a, grid, st);
   if (dpx == 2) return launch_sparse<TT_BF16, 2>(a, grid, st);
   if (dpx == 4) return launch_sparse<TT_BF16, 4>(a, grid, st);
   return launch_sparse<TT_BF16, 8>(a, grid, st);
@@ -1501,7 +1576,7 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
   const bool wide = pl.dpx == 0;
   void* wide_ws = reinterpret_cast<char*>(ws) + cv.off;
   const int64_t wide_bytes = ws_bytes - cv.off;
-  const int esz = dtype == TT_F32 ? 4 : 2;
+  const int esz = dtype == TT_BF16 ? 2 : 4;  // (a TT_F16X2 row: two fp16 terms per element)
   const bool vec = ((reinterpret_cast<uintptr_t>(query) | reinterpret_cast<uintptr_t>(corpus)) & 15) == 0 &&
                    (D * esz) % 16 == 0;
   hipError_t he = hipMemsetAsync(status, 0, 4, st);
@@ -1521,7 +1596,7 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
     if ((rc = check_launch("mips_zero_kernel"))) return rc;
     // sparse pass 2 reads the corpus rows as MFMA fragments straight from global memory
     static const bool no_sparse = getenv("TT_MIPS_NO_SPARSE") != nullptr;
-    const int dp = pl.dpx * (dtype == TT_F32 ? 8 : 16);
+    const int dp = pl.dpx * (dtype == TT_BF16 ? 16 : 8);
     const bool sparse = pl.n_groups > K && vec && D == dp && !no_sparse && !wide;
     static const bool no_dma = getenv("TT_MIPS_NO_DMA") != nullptr;
     static const bool no_g128 = getenv("TT_MIPS_NO_G128") != nullptr;  // A/B: 64-row groups for bf16 too
@@ -1597,6 +1672,77 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
     if ((rc = check_launch("mips_sort_emit_kernel"))) return rc;
   }
   return 0;
+}
+
+// ---------------------------------------------------------------- TT_F16X2 operands
+// scale[0] = the power of two that brings the matrix' largest magnitude into [2^14, 2^15) (1 for an all-zero matrix)
+__global__ void mips_absmax_kernel(const float* __restrict__ X, int64_t n4, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(X)[i];
+    m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fmaxf(fabsf(v.z), fabsf(v.w)), m));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+__global__ void mips_scale_from_absmax_kernel(const unsigned* __restrict__ absmax, float* __restrict__ scale) {
+  const float mx = __uint_as_float(*absmax);
+  float s = 1.f;
+  if (mx > 0.f && mx < 3.0e38f) {
+    int e;
+    frexpf(mx, &e);
+    s = ldexpf(1.f, 15 - e);
+  }
+  *scale = s;
+}
+// one thread per 8 elements: [rows][D] fp32 -> [rows][D h | D l] fp16
+__global__ __launch_bounds__(256) void mips_split_rows_kernel(const float* __restrict__ X, int64_t rows, int64_t D,
+                                                              const float* __restrict__ scale, uint16_t* __restrict__ out) {
+  const int64_t per_row = D / 8;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * per_row) return;
+  const int64_t row = i / per_row, c = (i % per_row) * 8;
+  const float s = *scale;
+  const float4 a = *reinterpret_cast<const float4*>(X + row * D + c), b = *reinterpret_cast<const float4*>(X + row * D + c + 4);
+  const float v[8] = {a.x * s, a.y * s, a.z * s, a.w * s, b.x * s, b.y * s, b.z * s, b.w * s};
+  f16x8 hh, ll;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const _Float16 q = (_Float16)v[k];
+    hh[k] = q;
+    ll[k] = (_Float16)(v[k] - (float)q);
+  }
+  *reinterpret_cast<f16x8*>(out + row * 2 * D + c) = hh;
+  *reinterpret_cast<f16x8*>(out + row * 2 * D + D + c) = ll;
+}
+__global__ void mips_unscale_kernel(float* __restrict__ scores, int64_t n, const float* __restrict__ sa, const float* __restrict__ sb) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) scores[i] *= 1.f / (*sa * *sb);  // powers of two: exact
+}
+
+extern "C" int tt_mips_split_rows(const float* X, int64_t rows, int64_t D, uint16_t* out, float* scale, void* ws, int64_t ws_bytes,
+                                  tt_stream_t stream) {
+  if (!X || !out || !scale || !ws) return fail_arg("tt_mips_split_rows: null pointer");
+  if (rows <= 0 || D <= 0 || D % 8 || ((uintptr_t)X | (uintptr_t)out) % 16) return fail_arg("tt_mips_split_rows: D % 8 == 0, 16-byte aligned rows");
+  if (ws_bytes < 256) { set_error("tt_mips_split_rows: workspace (256 bytes)"); return TT_E_WORKSPACE; }
+  hipStream_t st = S(stream);
+  unsigned* am = reinterpret_cast<unsigned*>(ws);
+  if (hipMemsetAsync(am, 0, 4, st) != hipSuccess) return check_launch("hipMemsetAsync");
+  const int64_t n4 = rows * D / 4;
+  const int blocks = (int)(n4 / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  mips_absmax_kernel<<<blocks, 256, 0, st>>>(X, n4, am);
+  if (int rc = check_launch("mips_absmax_kernel")) return rc;
+  mips_scale_from_absmax_kernel<<<1, 1, 0, st>>>(am, scale);
+  if (int rc = check_launch("mips_scale_from_absmax_kernel")) return rc;
+  mips_split_rows_kernel<<<(unsigned)ceil_div(rows * (D / 8), 256), 256, 0, st>>>(X, rows, D, scale, out);
+  return check_launch("mips_split_rows_kernel");
+}
+
+extern "C" int tt_mips_unscale(float* scores, int64_t n, const float* scale_a, const float* scale_b, tt_stream_t stream) {
+  if (!scores || !scale_a || !scale_b) return fail_arg("tt_mips_unscale: null pointer");
+  if (n <= 0) return 0;
+  mips_unscale_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, S(stream)>>>(scores, n, scale_a, scale_b);
+  return check_launch("mips_unscale_kernel");
 }
 
 extern "C" int64_t tt_mips_merge_workspace_bytes(int64_t B, int64_t n_cand) {

@@ -1192,11 +1192,44 @@ class HistoryEncoder(_LookupFunction):
 
 
 # ----------------------------------------------------------------- MIPS
-def mips_topk(query: torch.Tensor, corpus: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+def mips_split_rows(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """fp32 [R, 128] -> ([R, 256] fp16 = the two-term split [h | l] of x * scale, scale [1]): the operand form of the
+    EXPLORATORY TT_F16X2 scoring (tt_mips_split_rows; csrc/mips.hip, csrc/ce_f16x2.hip)."""
+    dev = N.require_device(x)
+    lib = N.load()
+    x = x.detach().contiguous()
+    if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != 128:
+        raise TypeError("split-fp16 scoring takes float32 [rows, 128]")
+    out = torch.empty(x.shape[0], 2 * x.shape[1], dtype=torch.float16, device=dev)
+    scale = torch.empty(1, dtype=torch.float32, device=dev)
+    wsp, wsn = _ws(dev, 256, "mips_split")
+    N.check(lib.tt_mips_split_rows(x.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), scale.data_ptr(), wsp, wsn, N.stream()),
+            "tt_mips_split_rows")
+    return out, scale
+
+
+def mips_topk(query: torch.Tensor, corpus: torch.Tensor, k: int,
+              split16: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """torch.topk(query @ corpus.T, k) with (score desc, index asc) order
-    (ref:src/baseline_mips_module.py:57-61).  corpus fp32 or bf16 [C, D]; query fp32 [B, D]."""
+    (ref:src/baseline_mips_module.py:57-61).  corpus fp32 or bf16 [C, D]; query fp32 [B, D].
+    split16 = mips_split_rows(corpus) (EXPLORATORY, fp32 corpus with D = 128): score on the fp16 matrix pipe from two-term
+    splits of both operands -- fp32-grade scores, the fp32 path's contract, about 2.5x its speed."""
     dev = N.require_device(query, corpus)
     lib = N.load()
+    if split16 is not None and corpus.dtype == torch.float32 and corpus.shape[1] == 128 and query.dtype == torch.float32 \
+            and query.dim() == 2 and query.shape[1] == 128 and 0 < k <= corpus.shape[0]:
+        c16, c_scale = split16
+        if c16.shape != (corpus.shape[0], 256) or c16.dtype != torch.float16:
+            raise ValueError("split16 does not belong to this corpus")
+        q16, q_scale = mips_split_rows(query)
+        B, Cn = query.shape[0], corpus.shape[0]
+        idx = torch.empty(B, k, dtype=torch.int64, device=dev)
+        scores = torch.empty(B, k, dtype=torch.float32, device=dev)
+        wsp, wsn = _ws(dev, lib.tt_mips_workspace_bytes(B, Cn, 128, k, N.TT_F16X2), "mips")
+        N.check(lib.tt_mips_topk(q16.data_ptr(), c16.data_ptr(), N.TT_F16X2, B, Cn, 128, k, idx.data_ptr(), scores.data_ptr(),
+                                 wsp, wsn, N.stream()), "tt_mips_topk")
+        N.check(lib.tt_mips_unscale(scores.data_ptr(), B * k, q_scale.data_ptr(), c_scale.data_ptr(), N.stream()), "tt_mips_unscale")
+        return idx, scores
     query = query.detach()
     if query.dtype != torch.float32 or query.dim() != 2:
         raise TypeError("query_embedding must be a 2-D float32 tensor")
