@@ -356,8 +356,13 @@ def _timed_mips(device, lib, N, Cn=10_000_000, B=1024, K=1000, D=128, reps=3):
         out["cpu_baseline"] = cpu_baseline_mips(m.corpus.cpu(), K)
     except Exception as e:
         out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
-    for name, peak in (("fp32", MFMA_F32_PEAK_TF), ("bf16", MFMA_BF16_PEAK_TF)):
+    for name, peak in (("fp32", MFMA_F32_PEAK_TF), ("fp32_split16", MFMA_BF16_PEAK_TF), ("bf16", MFMA_BF16_PEAK_TF)):
+        if name == "fp32_split16":
+            # EXPLORATORY, reported separately (never instead of "fp32"): the fp32 corpus scored from its two-term fp16 split,
+            # three fp16 MFMA products per product (csrc/mips.hip TT_F16X2) -- same contract, fp32-grade scores
+            m.use_split_fp16_scoring()
         if name == "bf16":
+            m.use_split_fp16_scoring(False)
             m.use_bf16_storage()
         m.search(q, K)  # warm-up: allocates the workspace
         torch.cuda.synchronize()
@@ -370,12 +375,18 @@ def _timed_mips(device, lib, N, Cn=10_000_000, B=1024, K=1000, D=128, reps=3):
         ms, cnt = C.c_double(0), C.c_int64(0)
         N.check(lib.tt_profile_read(b"mips_score_kernel", C.byref(ms), C.byref(cnt)), "tt_profile_read")
         lib.tt_profile_enable(0)
-        tf = 2.0 * B * Cn * D * cnt.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else None
+        products = 3.0 if name == "fp32_split16" else 1.0  # MFMA products the pipe executes per product of the algorithm
+        tf = products * 2.0 * B * Cn * D * cnt.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else None
         out[name] = {"queries_per_s": round(B / dt, 1), "ms_per_call": round(dt * 1e3, 3), "C": Cn, "B": B, "K": K, "D": D,
                      "roofline": {"bound": "mfma", "kernel": "mips_pass1_dma_kernel", "achieved": round(tf, 1) if tf else None,
                                   "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4) if tf else None,
                                   "avg_launch_ms": round(ms.value / max(cnt.value, 1), 4), "launches": cnt.value,
-                                  "algorithmic_flops_per_launch": 2.0 * B * Cn * D}}
+                                  "algorithmic_flops_per_launch": products * 2.0 * B * Cn * D}}
+        if name == "fp32_split16":
+            out[name]["EXPLORATORY"] = ("dtype f32 (fp16x2 split): opt-in BaselineMIPSModule.use_split_fp16_scoring(); roofline priced on "
+                                        "the 3 fp16 MFMA products per product against the fp16 pipe's peak; fp32-equivalent "
+                                        f"{round(tf / 3.0, 1) if tf else None} TFLOP/s; parity: tests/test_gpu_fullsize.py::"
+                                        "test_mips_split_fp16_scoring_exact_arithmetic_and_random")
         # serving-size batch: back-to-back calls of 16 queries (the pass is the corpus stream there, not the matrix cores)
         q16 = q[:16].contiguous()
         m.search(q16, K)

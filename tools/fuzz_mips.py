@@ -23,6 +23,7 @@ while time.time() - t0 < budget:
     C = int(rng.integers(200, 60000))
     K = int(rng.integers(1, min(C, 1500)))
     bf16 = bool(rng.integers(0, 2))
+    split16 = (not bf16) and D == 128 and bool(rng.integers(0, 2))  # EXPLORATORY: fp32 corpus scored from its fp16 split
     spread = int(rng.choice([3, 5, 9]))
     corpus = torch.from_numpy((fg.hashed_u64((C, D), 100 + n) % np.uint64(spread)).astype(np.float32) - spread // 2)
     q = torch.from_numpy((fg.hashed_u64((B, D), 900 + n) % np.uint64(3)).astype(np.float32) - 1.0)
@@ -31,12 +32,14 @@ while time.time() - t0 < budget:
     m = m.to("cuda:0")
     if bf16:
         m.use_bf16_storage()
+    if split16:
+        m.use_split_fp16_scoring()
     idx, sc = m.search(q.to("cuda:0"), K)
     want_idx, want_sc, _ = R.mips_topk(q, corpus, K)
     ok = torch.equal(idx.cpu(), want_idx) and torch.equal(sc.cpu(), want_sc)
     n += 1
     if not ok:
         bad += 1
-        print(f"MISMATCH B={B} C={C} D={D} K={K} bf16={bf16} spread={spread} case={n - 1}", flush=True)
+        print(f"MISMATCH B={B} C={C} D={D} K={K} bf16={bf16} split16={split16} spread={spread} case={n - 1}", flush=True)
 print(f"{n} cases, {bad} mismatches in {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
