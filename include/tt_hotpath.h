@@ -198,8 +198,7 @@ int tt_inbatch_ce_bwd_kept(const float* U, int64_t ldu, int64_t M, int64_t N, in
  * is M * N * 4 bytes holding [M / 32][N / 32] tiles of 32 users x 32 items, each tile 4 KiB contiguous and row-major
  * inside (log2-domain logits), row_lse is in the log2 domain as well (only the backward consumes it), the workspace is
  * tt_ce16_workspace_bytes, and the shapes are D = 128,
- * M % 256 == 0, N % 1024 == 0 (tt_ce16_supported; TT_E_UNSUPPORTED otherwise).  |coef| <= 1 is assumed (example
- * weights normalised by their maximum: ref:...base_retrieval.py:334-343). */
+ * M % 256 == 0, N % 1024 == 0 (tt_ce16_supported; TT_E_UNSUPPORTED otherwise). */
 int tt_ce16_supported(int64_t M, int64_t N, int64_t D);
 int64_t tt_ce16_workspace_bytes(int64_t M, int64_t N, int64_t D);
 int tt_ce16_fwd_du_keep(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N, int64_t D,

@@ -44,7 +44,7 @@ while time.time() - t0 < budget:
         I[torch.rand(Nn, generator=g) < 0.01] = 0.0
         if zero_op:
             U.zero_()
-        coef = torch.rand(M, generator=g) / M
+        coef = torch.rand(M, generator=g) / M * float(rng.choice([1.0, 1.0, 1e3, 1e-3, -5.0]))
         coef[torch.rand(M, generator=g) < 0.05] = 0.0
         coef[torch.rand(M, generator=g) < 0.05] *= 1e-6
         Ug, Ig, cg = U.to(DEV), I.to(DEV), coef.to(DEV)
