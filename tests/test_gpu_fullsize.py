@@ -579,11 +579,14 @@ def test_mips_split_fp16_scoring_exact_arithmetic_and_random(T, B):
     assert torch.equal(idx[:nq].cpu(), want_idx)
     idx32, sc32 = A.BaselineMIPSModule.search(m.use_split_fp16_scoring(False), q, K)  # and the fp32-MFMA path agrees
     assert torch.equal(idx32, idx) and torch.equal(sc32, sc)
-    # random data
+    # random data: the corpus is REPLACED and then refilled in place -- the split must follow it both times
     corpus = torch.randn(C_, D, device=DEV, generator=g)
     q = torch.randn(B, D, device=DEV, generator=g)
-    m.corpus = corpus
     m.use_split_fp16_scoring()
+    m.search(q[:4], 5)
+    m.corpus = torch.zeros_like(corpus)
+    m.search(q[:4], 5)
+    m.corpus.copy_(corpus)
     idx, sc = m.search(q, K)
     assert bool((sc[:, 1:] <= sc[:, :-1]).all()) and bool(((idx >= 0) & (idx < C_)).all())
     assert all(len(set(r.tolist())) == K for r in idx[:8].cpu())

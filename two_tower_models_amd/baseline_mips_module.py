@@ -44,8 +44,13 @@ class BaselineMIPSModule(nn.Module):
         """EXPLORATORY: keep the fp32 corpus and ALSO its two-term fp16 split (same size again); searches then score
         on the fp16 matrix pipe at fp32-grade accuracy (three fp16 MFMA products per fp32 product) -- same contract
         as the fp32 path, about 2.5x faster.  D = 128, fp32 corpus.  Call again after the corpus changes."""
-        self._split16 = ops.mips_split_rows(self.corpus) if on else None
+        self._split16_on = bool(on)
+        self._split16 = self._split16_key = None  # built by the next search (and again whenever the corpus has changed)
         return self
+
+    def _corpus_key(self):
+        c = self.corpus
+        return (c.data_ptr(), c._version, tuple(c.shape), c.dtype, c.device)
 
     def set_corpus(self, embeddings: torch.Tensor, bf16: bool = False) -> "BaselineMIPSModule":
         """Replace the random corpus (ref :29-30) by real item embeddings [C, DI]."""
@@ -57,10 +62,15 @@ class BaselineMIPSModule(nn.Module):
 
     def search(self, query_embedding: torch.Tensor, num_items: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """(indices int64 [B, K], scores fp32 [B, K]) without gathering the rows."""
-        split = getattr(self, "_split16", None)
-        if split is not None and (self.corpus.dtype != torch.float32 or split[0].shape[0] != self.corpus.shape[0]
-                                  or split[0].device != self.corpus.device):
-            split = self._split16 = None  # the corpus was replaced / converted / moved: the split no longer belongs to it
+        split = None
+        if getattr(self, "_split16_on", False) and self.corpus.dtype == torch.float32 and self.corpus.shape[1] == 128 \
+                and self.corpus.is_cuda:
+            # the split belongs to ONE state of the corpus: storage, in-place version, shape (a corpus that was assigned,
+            # refilled in place, converted or moved since gets a new one -- 2 ms at 10 M rows)
+            key = self._corpus_key()
+            if getattr(self, "_split16_key", None) != key:
+                self._split16, self._split16_key = ops.mips_split_rows(self.corpus), key
+            split = self._split16
         return ops.mips_topk(query_embedding, self.corpus, num_items, split16=split)
 
     def forward(
