@@ -341,6 +341,38 @@ def test_inbatch_ce_op_keep_logits_matches_default(T):
     assert torch.isfinite(I.grad).all()
 
 
+def test_inbatch_ce_op_through_split_fp16_pair(T, monkeypatch):
+    """ops.InBatchSoftmaxCE with TT_CE_F16X2 (EXPLORATORY): the autograd op takes the split-fp16 pair where its shapes allow
+    and lands on the fp32-MFMA path's values to within the pair's error (test_split_fp16_ce_pair_vs_float64); unsupported
+    shapes and no-grad calls keep the fp32 path bit for bit."""
+    ops, N = T
+    M, Nn, D, off = 512, 2048, 128, 1024
+    U0, I0 = g((M, D), 191) * 0.5, g((Nn, D), 192) * 0.5
+    coef = (g((M,), 193).abs() / M).to(DEV)
+    res = []
+    for split in (False, True):
+        monkeypatch.setattr(ops, "_CE_F16X2", split)
+        assert ops.ce16_usable(U0.to(DEV), I0.to(DEV)) == split
+        U, I = U0.to(DEV).requires_grad_(True), I0.to(DEV).requires_grad_(True)
+        ce = ops.InBatchSoftmaxCE.apply(U, I, off)
+        (ce * coef).sum().backward()
+        res.append((ce.detach(), U.grad, I.grad))
+    assert not torch.equal(res[0][0], res[1][0])  # a different kernel did run
+    for a, b in zip(res[0], res[1]):
+        assert torch.allclose(a, b, atol=3e-6 * float(a.abs().max()), rtol=1e-5)
+    # shapes the pair does not take (M = 300; in-batch N = M, where its backward would leave most CUs idle) and inference
+    # calls: the fp32 path, untouched by the switch
+    monkeypatch.setattr(ops, "_CE_F16X2", True)
+    U, I = (g((300, D), 194)).to(DEV), (g((2048, D), 195)).to(DEV)
+    assert not ops.ce16_usable(U, I) and not ops.ce16_usable(I[:1024], I[:1024])
+    with torch.no_grad():
+        ce_a = ops.InBatchSoftmaxCE.apply(U0.to(DEV), I0.to(DEV), off)
+    monkeypatch.setattr(ops, "_CE_F16X2", False)
+    with torch.no_grad():
+        ce_b = ops.InBatchSoftmaxCE.apply(U0.to(DEV), I0.to(DEV), off)
+    assert torch.equal(ce_a, ce_b)
+
+
 @pytest.mark.parametrize("B,Tn,DI,case", [(64, 1, 128, "plain"), (1000, 3, 40, "plain"), (8192, 1, 128, "plain"),
                                           (300, 1, 64, "all_zero_labels"), (257, 2, 32, "clamped_priors"), (1, 1, 8, "plain")])
 def test_debias_loss_head_matches_torch_expressions(T, B, Tn, DI, case):

@@ -666,7 +666,16 @@ class InBatchSoftmaxCE(torch.autograd.Function):
         pu, _, _, ldu = _f32_2d(U, "U")
         pi, _, _, ldi = _f32_2d(I, "I")
         ctx.diag_offset = diag_offset
-        ctx.kept = None
+        ctx.kept = ctx.kept16 = None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and _FUSED_DU and ldu == D and ldi == D and ce16_usable(U, I) \
+                and 0 <= diag_offset <= Nn - M:
+            du_unit = torch.empty(M, D, dtype=torch.float32, device=dev)
+            w16p, w16n = _ws(dev, lib.tt_ce16_workspace_bytes(M, Nn, D), "ce16")
+            ctx.kept16 = torch.empty(M * Nn, dtype=torch.float32, device=dev)
+            N.check(lib.tt_ce16_fwd_du_keep(pu, D, pi, D, M, Nn, D, diag_offset, lse.data_ptr(), ce.data_ptr(), du_unit.data_ptr(), D,
+                                            ctx.kept16.data_ptr(), M * Nn * 4, w16p, w16n, N.stream()), "tt_ce16_fwd_du_keep")
+            ctx.save_for_backward(U, I, lse, du_unit)
+            return ce
         if ctx.needs_input_grad[0] and _FUSED_DU:
             # training: the forward also accumulates E[i] = sum_j p_ij I_j, which IS the user-side
             # gradient up to the row factor -- the backward then only runs the item-side kernel
@@ -714,6 +723,12 @@ class InBatchSoftmaxCE(torch.autograd.Function):
         wsp, wsn = _ws(dev, lib.tt_inbatch_ce_workspace_bytes(M, Nn, D))
         pu, _, _, ldu = _f32_2d(U, "U")
         pi, _, _, ldi = _f32_2d(I, "I")
+        if ctx.kept16 is not None:  # the split-fp16 pair's backward
+            w16p, w16n = _ws(dev, lib.tt_ce16_workspace_bytes(M, Nn, D), "ce16")
+            N.check(lib.tt_ce16_bwd_kept(pu, D, M, Nn, D, ctx.diag_offset, lse.data_ptr(), coef.data_ptr(), ctx.kept16.data_ptr(),
+                                         M * Nn * 4, dI.data_ptr(), D, w16p, w16n, N.stream()), "tt_ce16_bwd_kept")
+            ctx.kept16 = None
+            return dU, dI, None, None
         if ctx.kept is not None:  # item side from the logits the forward kept
             N.check(lib.tt_inbatch_ce_bwd_kept(pu, ldu, M, Nn, D, ctx.diag_offset, lse.data_ptr(), coef.data_ptr(),
                                                ctx.kept.data_ptr(), ctx.kept.numel(), dI.data_ptr(), D, wsp, wsn,
@@ -775,11 +790,24 @@ class WeightedMeanLoss(torch.autograd.Function):
 
 
 _FUSED_LOSS = os.environ.get("TT_CE_NO_FUSED_LOSS") is None  # A/B switch
+# EXPLORATORY: InBatchSoftmaxCE through the split-fp16 pair (csrc/ce_f16x2.hip) where its shapes allow
+# (D = 128, M % 256 == 0, N % 1024 == 0, contiguous rows) -- fp32-grade results on the fp16 matrix pipe.  Never the default.
+_CE_F16X2 = os.environ.get("TT_CE_F16X2") is not None
+
+
+def ce16_usable(U: torch.Tensor, I: torch.Tensor) -> bool:
+    # wide negative sets only (N >= 4 M, the sharded step's shape seen from one rank): the pair's item-side backward has
+    # one workgroup per 256 items and no split over users -- at N = M = 8192 that is 32 workgroups on 256 CUs, and the op
+    # measured SLOWER than the fp32 pair there (deferred-Adam P step 1.42 vs 1.19 ms)
+    return bool(_CE_F16X2 and U.is_cuda and U.dim() == 2 and I.dim() == 2 and U.dtype == torch.float32 and I.dtype == torch.float32
+                and I.shape[0] >= 4 * U.shape[0] and N.load().tt_ce16_supported(U.shape[0], I.shape[0], U.shape[1]))
 
 
 def fused_loss_supported(U: torch.Tensor, I: torch.Tensor, labels: Optional[torch.Tensor], uvw: torch.Tensor) -> bool:
     """InBatchSoftmaxWeightedLoss: a training forward (U needs a gradient) with in-batch negatives only (N < 4 M: the wide
     form keeps its logits and has its own forward), float32 everywhere, one label row per user row."""
+    if ce16_usable(U, I):
+        return False  # the split-fp16 pair is a two-op path: InBatchSoftmaxCE + WeightedMeanLoss
     return bool(_FUSED_LOSS and _FUSED_DU and U.is_cuda and U.requires_grad and torch.is_grad_enabled() and U.dim() == 2 and I.dim() == 2
                 and U.dtype == torch.float32 and I.dtype == torch.float32 and uvw.dtype == torch.float32
                 and I.shape[0] < 4 * U.shape[0]
