@@ -387,6 +387,12 @@ typedef struct {
 int tt_adam_begin_ids(double* hyper, float* tab, int64_t tab_steps, const tt_adam_stash_job* jobs, int32_t n_jobs,
                       tt_stream_t stream);
 int tt_adam_tables_finish(const tt_adam_finish_job* jobs, int32_t n_jobs, const double* hyper, tt_stream_t stream);
+/* tt_adam_begin_ids in two halves, for steps whose lookups are large (the history model parks 217 K rows: 0.67 GB): `planes`
+ * is a mask of 1 = p (+ the step-count advance), 2 = m, 4 = v.  The forward's lookups read the parked p plane only, so a
+ * caller runs planes = 1 on its own stream and planes = 6 on the sweep's stream in front of the sweep -- the moments leave
+ * the step's critical path.  planes = 7 is tt_adam_begin_ids.  At most 4 tables. */
+int tt_adam_begin_ids_planes(double* hyper, float* tab, int64_t tab_steps, const tt_adam_stash_job* jobs, int32_t n_jobs,
+                             int32_t planes, tt_stream_t stream);
 
 /* A HIP stream of the device's least priority (hipStreamCreateWithPriority) for
  * tt_adam_table_sweep, so the backward pass on the caller's stream is dispatched first. */

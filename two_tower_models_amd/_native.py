@@ -82,6 +82,7 @@ SIGNATURES = {
     "tt_tower_bwd_weights": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _i64, _vp]),
     "tt_adam_begin_ids": (_int, [_vp, _vp, _i64, C.POINTER(AdamStashJob), _i32, _vp]),
+    "tt_adam_begin_ids_planes": (_int, [_vp, _vp, _i64, C.POINTER(AdamStashJob), _i32, _i32, _vp]),
     "tt_adam_tables_finish": (_int, [C.POINTER(AdamFinishJob), _i32, _vp, _vp]),
     "tt_inbatch_ce_fwd_du_loss": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                          _vp, _vp, _i64, _vp]),

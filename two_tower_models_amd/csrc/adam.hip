@@ -161,10 +161,12 @@ __global__ __launch_bounds__(256) void adam_stash_kernel(const float* __restrict
 // the same values several times; the finish uses the first).  Needs nothing but the ids, so the
 // sweep can start a few microseconds into the step while the sort runs underneath it.  Ids
 // outside [0, n_rows) (another rank's rows, or invalid input that the plan will flag) park zeros.
+// planes: bit 0 = p, bit 1 = m, bit 2 = v (tt_adam_begin_ids_planes: the p plane is all the forward's lookups need, the
+// moments can be parked on the sweep's own stream in front of it)
 __device__ __forceinline__ void adam_stash_ids_body(const float* __restrict__ W, const float* __restrict__ M,
                                                     const float* __restrict__ V, int64_t n_rows, int64_t dim,
                                                     const int64_t* __restrict__ ids, int64_t n_ids, float* __restrict__ side,
-                                                    int64_t block) {
+                                                    int64_t block, int planes = 7) {
   const int64_t i = block * 4 + (threadIdx.x >> 6);
   if (i >= n_ids) return;
   const int lane = threadIdx.x & 63;
@@ -177,15 +179,15 @@ __device__ __forceinline__ void adam_stash_ids_body(const float* __restrict__ W,
                             reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(side)) & 15) == 0) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t d = 4 * lane; d < dim; d += 256) {
-      *reinterpret_cast<float4*>(sp + d) = ok ? *reinterpret_cast<const float4*>(W + row * dim + d) : z;
-      *reinterpret_cast<float4*>(sm + d) = ok ? *reinterpret_cast<const float4*>(M + row * dim + d) : z;
-      *reinterpret_cast<float4*>(sv + d) = ok ? *reinterpret_cast<const float4*>(V + row * dim + d) : z;
+      if (planes & 1) *reinterpret_cast<float4*>(sp + d) = ok ? *reinterpret_cast<const float4*>(W + row * dim + d) : z;
+      if (planes & 2) *reinterpret_cast<float4*>(sm + d) = ok ? *reinterpret_cast<const float4*>(M + row * dim + d) : z;
+      if (planes & 4) *reinterpret_cast<float4*>(sv + d) = ok ? *reinterpret_cast<const float4*>(V + row * dim + d) : z;
     }
   } else {
     for (int64_t d = lane; d < dim; d += 64) {
-      sp[d] = ok ? W[row * dim + d] : 0.f;
-      sm[d] = ok ? M[row * dim + d] : 0.f;
-      sv[d] = ok ? V[row * dim + d] : 0.f;
+      if (planes & 1) sp[d] = ok ? W[row * dim + d] : 0.f;
+      if (planes & 2) sm[d] = ok ? M[row * dim + d] : 0.f;
+      if (planes & 4) sv[d] = ok ? V[row * dim + d] : 0.f;
     }
   }
 }
@@ -211,10 +213,11 @@ struct StashJobs {
   unsigned first_block[SWEEP_MAX_TABLES_DECL + 1];
   int n;
 };
-__global__ __launch_bounds__(256) void adam_begin_ids_kernel(const StashJobs jobs, double* h, float* tab, int64_t tab_cap) {
+__global__ __launch_bounds__(256) void adam_begin_ids_kernel(const StashJobs jobs, double* h, float* tab, int64_t tab_cap, int planes,
+                                                             int advance) {
   const unsigned n_stash = jobs.first_block[jobs.n];
   if (blockIdx.x == n_stash) {
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && advance) {
       const double step = h[4] + 1.0;
       h[4] = step;
       step_consts_from_doubles(h[0], h[1], h[2], step, h[5], h[6]);
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256) void adam_begin_ids_kernel(const StashJobs job
   for (int q = 1; q < SWEEP_MAX_TABLES_DECL; ++q)
     if (q < jobs.n && blockIdx.x >= jobs.first_block[q]) t = q;
   adam_stash_ids_body(jobs.W[t], jobs.M[t], jobs.V[t], jobs.n_rows[t], jobs.dim[t], jobs.ids[t], jobs.n_ids[t], jobs.side[t],
-                      blockIdx.x - jobs.first_block[t]);
+                      blockIdx.x - jobs.first_block[t], planes);
 }
 
 __global__ __launch_bounds__(256) void adam_writeback_kernel(float* __restrict__ W, float* __restrict__ M,
@@ -789,8 +792,24 @@ extern "C" int tt_adam_table_stash_ids(const float* W, const float* M, const flo
   return check_launch("adam_stash_ids_kernel");
 }
 
+static int begin_ids_impl(double* hyper, float* tab, int64_t tab_steps, const tt_adam_stash_job* jobs, int32_t n_jobs, int planes,
+                          tt_stream_t stream);
+
 extern "C" int tt_adam_begin_ids(double* hyper, float* tab, int64_t tab_steps, const tt_adam_stash_job* jobs, int32_t n_jobs,
                                  tt_stream_t stream) {
+  return begin_ids_impl(hyper, tab, tab_steps, jobs, n_jobs, 7, stream);
+}
+
+extern "C" int tt_adam_begin_ids_planes(double* hyper, float* tab, int64_t tab_steps, const tt_adam_stash_job* jobs, int32_t n_jobs,
+                                        int32_t planes, tt_stream_t stream) {
+  if (planes <= 0 || planes > 7) return fail_arg("tt_adam_begin_ids_planes: planes is a mask of 1 (p), 2 (m), 4 (v)");
+  if (n_jobs > SWEEP_MAX_TABLES) return fail_arg("tt_adam_begin_ids_planes: at most 4 tables");
+  return begin_ids_impl(hyper, tab, tab_steps, jobs, n_jobs, planes, stream);
+}
+
+// planes & 1: the step-count advance rides along (it belongs to the launch that parks the p plane)
+static int begin_ids_impl(double* hyper, float* tab, int64_t tab_steps, const tt_adam_stash_job* jobs, int32_t n_jobs, int planes,
+                          tt_stream_t stream) {
   if (!hyper || (n_jobs > 0 && !jobs) || n_jobs < 0) return fail_arg("tt_adam_begin_ids: null pointer");
   if (tab && tab_steps <= 0) return fail_arg("tt_adam_begin_ids: sizes");
   hipStream_t st = S(stream);
@@ -815,7 +834,7 @@ extern "C" int tt_adam_begin_ids(double* hyper, float* tab, int64_t tab_steps, c
     blocks += (unsigned)ceil_div(j.n_ids, 4);
   }
   for (int i = n_jobs; i <= SWEEP_MAX_TABLES; ++i) a.first_block[i] = blocks;
-  adam_begin_ids_kernel<<<blocks + 1, 256, 0, st>>>(a, hyper, tab, tab ? tab_steps : 0);
+  adam_begin_ids_kernel<<<blocks + 1, 256, 0, st>>>(a, hyper, tab, tab ? tab_steps : 0, planes, planes & 1);
   return check_launch("adam_begin_ids_kernel");
 }
 

@@ -61,6 +61,8 @@ import torch
 from . import _native as N
 from . import ops
 
+_SPLIT_STASH = os.environ.get("TT_ADAM_ONE_STASH") is None  # A/B: park p | m | v of large lookups in one launch on the main stream
+
 
 class _TableStep:
     """State of one table between the overlapped begin (in zero_grad) and finish (in step)."""
@@ -319,11 +321,24 @@ class DenseExactAdam(torch.optim.Optimizer):
             for i, j in enumerate(stash_jobs):
                 (jobs[i].W, jobs[i].M, jobs[i].V, jobs[i].n_rows, jobs[i].dim, jobs[i].ids, jobs[i].n_ids, jobs[i].side,
                  jobs[i].side_bytes) = j
-            N.check(lib.tt_adam_begin_ids(hyper, None, 0, jobs, len(stash_jobs), N.stream()), "tt_adam_begin_ids")
+            # Many looked-up rows (history model: 217 K, 0.67 GB of p / m / v to park): only the p plane is needed before the
+            # forward can start -- the moments are parked on the sweep's stream, in front of the sweep (C3: 0.15 ms at the
+            # head of the step become 0.05).  Small lookups keep the single launch.
+            n_stashed = sum(j[6] for j in stash_jobs)
+            split_planes = _SPLIT_STASH and not capturing and 0 < len(stash_jobs) <= 4 and n_stashed >= 65536
+            if split_planes:
+                N.check(lib.tt_adam_begin_ids_planes(hyper, None, 0, jobs, len(stash_jobs), 1, N.stream()), "tt_adam_begin_ids_planes")
+            else:
+                N.check(lib.tt_adam_begin_ids(hyper, None, 0, jobs, len(stash_jobs), N.stream()), "tt_adam_begin_ids")
+        else:
+            split_planes = False
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(main)  # lookups (or none yet, forward mode) + stashes are complete here
         self._side_stream.wait_event(ready)
+        if split_planes:
+            N.check(lib.tt_adam_begin_ids_planes(hyper, None, 0, jobs, len(stash_jobs), 6, self._side_stream.cuda_stream),
+                    "tt_adam_begin_ids_planes")
         ev_s0 = None
         if not capturing:
             ev_s0 = torch.cuda.Event(enable_timing=True)
