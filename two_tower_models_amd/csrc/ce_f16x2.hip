@@ -399,6 +399,8 @@ struct BwdArgs {
   float* dI;
   int64_t lddi;
   const unsigned* absmax;       // [0] users, [2] dL/dce
+  float* part;                  // [n_splits][N][128] partial item gradients when the users are split (else unused)
+  int n_splits;                 // blockIdx.y: user ranges, so that narrow item sets (N < 65536) still fill the chip
 };
 struct BwdStage {
   char tr_h[C16_TR_B], tr_l[C16_TR_B];
@@ -461,13 +463,17 @@ __device__ __forceinline__ void bwd_tile(const BwdStage* st, const float* stat, 
 }
 }  // namespace
 
+// SPLIT: the users are cut into p.n_splits ranges (blockIdx.y), partial results; otherwise one workgroup streams all of them
+template <bool SPLIT>
 __global__ __launch_bounds__(64 * C16_NW, 2) void ce16_bwd_items_kernel(const BwdArgs p) {
   __shared__ __attribute__((aligned(1024))) BwdStage ring0;
   __shared__ __attribute__((aligned(1024))) BwdStage ring1;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const int64_t item = (int64_t)blockIdx.x * C16_ROWS_WG + wave * 32 + r;
   const int64_t diag_user = item - p.diag_off;  // the user whose positive this item is (outside [0, M): none)
-  const int n_tiles = (int)(p.M / C16_TILE);
+  const int tiles_all = (int)(p.M / C16_TILE), per = SPLIT ? (tiles_all + p.n_splits - 1) / p.n_splits : tiles_all;
+  const int tile0 = SPLIT ? blockIdx.y * per : 0;
+  const int n_tiles = SPLIT ? (tile0 + per < tiles_all ? tile0 + per : tiles_all) - tile0 : tiles_all;  // (SPLIT: may be <= 0)
   const float gscale = scale_for(p.absmax[2]);  // from max |coef|
   const int lane_off = (4 * h * 32 + r) * 4;  // bytes from the tile's first logit to this lane's column, rows 4 h ..
   const int64_t item_blk = (int64_t)blockIdx.x * C16_NW + __builtin_amdgcn_readfirstlane(wave);  // (wave-uniform: scalar descriptor)
@@ -480,34 +486,39 @@ __global__ __launch_bounds__(64 * C16_NW, 2) void ce16_bwd_items_kernel(const Bw
   __shared__ __attribute__((aligned(16))) float stat1[64];
   float s0[16], s1[16];
   float sv0 = 0.f, sv1 = 0.f;
-  dma_linear(p.u.th, ring0.tr_h, wave, lane);
-  dma_linear(p.u.tl, ring0.tr_l, wave, lane);
-  bwd_fetch(p, 0, item_blk, lane_off, wave, lane, s0, sv0);
+  const int64_t ubase = (int64_t)tile0 * C16_TILE;  // this split's first user
+  if (n_tiles > 0) {
+    dma_linear(p.u.th + ubase * C16_D, ring0.tr_h, wave, lane);
+    dma_linear(p.u.tl + ubase * C16_D, ring0.tr_l, wave, lane);
+    bwd_fetch(p, ubase, item_blk, lane_off, wave, lane, s0, sv0);
+  }
   for (int tile = 0; tile < n_tiles; tile += 2) {
     __builtin_amdgcn_s_waitcnt(0x0f70);
     if (wave == 0) stat0[lane] = sv0;
     __syncthreads();
     if (tile + 1 < n_tiles) {
-      const int64_t u1 = (int64_t)(tile + 1) * C16_TILE;
+      const int64_t u1 = ubase + (int64_t)(tile + 1) * C16_TILE;
       dma_linear(p.u.th + u1 * C16_D, ring1.tr_h, wave, lane);
       dma_linear(p.u.tl + u1 * C16_D, ring1.tr_l, wave, lane);
       bwd_fetch(p, u1, item_blk, lane_off, wave, lane, s1, sv1);
     }
-    bwd_tile(&ring0, stat0, s0, acc, (int64_t)tile * C16_TILE, diag_user, gscale, r, h);
+    bwd_tile(&ring0, stat0, s0, acc, ubase + (int64_t)tile * C16_TILE, diag_user, gscale, r, h);
     if (tile + 1 >= n_tiles) break;
     __builtin_amdgcn_s_waitcnt(0x0f70);
     if (wave == 0) stat1[lane] = sv1;
     __syncthreads();
     if (tile + 2 < n_tiles) {
-      const int64_t u2 = (int64_t)(tile + 2) * C16_TILE;
+      const int64_t u2 = ubase + (int64_t)(tile + 2) * C16_TILE;
       dma_linear(p.u.th + u2 * C16_D, ring0.tr_h, wave, lane);
       dma_linear(p.u.tl + u2 * C16_D, ring0.tr_l, wave, lane);
       bwd_fetch(p, u2, item_blk, lane_off, wave, lane, s0, sv0);
     }
-    bwd_tile(&ring1, stat1, s1, acc, (int64_t)(tile + 1) * C16_TILE, diag_user, gscale, r, h);
+    bwd_tile(&ring1, stat1, s1, acc, ubase + (int64_t)(tile + 1) * C16_TILE, diag_user, gscale, r, h);
   }
   const float inv = 1.f / (gscale * scale_for(p.absmax[0]));
-  float* out = p.dI + item * p.lddi;
+  float* out = SPLIT ? p.part + ((int64_t)blockIdx.y * p.N + item) * C16_D : p.dI + item * p.lddi;
+  const int64_t ldo = SPLIT ? C16_D : p.lddi;
+  (void)ldo;
 #pragma unroll
   for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -516,8 +527,29 @@ __global__ __launch_bounds__(64 * C16_NW, 2) void ce16_bwd_items_kernel(const Bw
           make_float4(acc[b][4 * g] * inv, acc[b][4 * g + 1] * inv, acc[b][4 * g + 2] * inv, acc[b][4 * g + 3] * inv);
 }
 
+// dI[i][:] = sum over user splits of part[s][i][:], in split order (deterministic)
+__global__ __launch_bounds__(256) void ce16_bwd_reduce_kernel(const float* __restrict__ part, int n_splits, int64_t N, float* __restrict__ dI,
+                                                              int64_t lddi) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4
+  if (i >= N * (C16_D / 4)) return;
+  const int64_t row = i >> 5, c = (i & 31) * 4;
+  float4 a = *reinterpret_cast<const float4*>(part + row * C16_D + c);
+  for (int s = 1; s < n_splits; ++s) {
+    const float4 b = *reinterpret_cast<const float4*>(part + ((int64_t)s * N + row) * C16_D + c);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  *reinterpret_cast<float4*>(dI + row * lddi + c) = a;
+}
+
 // ---------------------------------------------------------------------------------------------------- host
 namespace {
+// user splits of the backward: one workgroup per 256 items is enough from N = 65536 on; narrower item sets split the users
+int pick_bwd_splits(int64_t M, int64_t N) {
+  int want = 1;
+  while (want < 16 && (N / C16_ROWS_WG) * want < 256 && (M / C16_TILE) / (2 * want) >= 8) want *= 2;
+  return want;
+}
+
 // item splits of the forward: enough workgroups for the 256 CUs, N / splits a multiple of the tile
 int pick_splits(int64_t M, int64_t N) {
   int want = 8;
@@ -529,7 +561,7 @@ int pick_splits(int64_t M, int64_t N) {
 struct Ws {
   unsigned* absmax;
   Images u, it;
-  float *pmax, *psum, *pe;
+  float *pmax, *psum, *pe, *part;
 };
 int64_t carve(void* base, int64_t M, int64_t N, Ws* w) {
   Carver c(base);
@@ -541,7 +573,9 @@ int64_t carve(void* base, int64_t M, int64_t N, Ws* w) {
   float* pmax = c.take<float>((int64_t)splits * M);
   float* psum = c.take<float>((int64_t)splits * M);
   float* pe = c.take<float>((int64_t)splits * M * C16_D);
-  if (w) { w->absmax = am; w->u = u; w->it = it; w->pmax = pmax; w->psum = psum; w->pe = pe; }
+  const int bs = pick_bwd_splits(M, N);
+  float* part = c.take<float>(bs > 1 ? (int64_t)bs * N * C16_D : 0);
+  if (w) { w->absmax = am; w->u = u; w->it = it; w->pmax = pmax; w->psum = psum; w->pe = pe; w->part = part; }
   return c.off;
 }
 int split_matrix(const float* X, int64_t ld, int64_t rows, unsigned* absmax, const Images& im, hipStream_t st) {
@@ -627,9 +661,17 @@ extern "C" int tt_ce16_bwd_kept(const float* U, int64_t ldu, int64_t M, int64_t 
   BwdArgs a;
   a.u = w.u; a.logits = logits; a.row_lse = row_lse; a.coef = coef; a.M = M; a.N = N; a.diag_off = diag_offset; a.dI = dI; a.lddi = lddi;
   a.absmax = w.absmax;
+  a.n_splits = pick_bwd_splits(M, N);
+  a.part = w.part;
   {
     ProfScope prof("ce_bwd_kernel", st);
-    hipLaunchKernelGGL(ce16_bwd_items_kernel, dim3((unsigned)(N / C16_ROWS_WG)), dim3(64 * C16_NW), 0, st, a);
+    if (a.n_splits > 1) hipLaunchKernelGGL(ce16_bwd_items_kernel<true>, dim3((unsigned)(N / C16_ROWS_WG), (unsigned)a.n_splits), dim3(64 * C16_NW), 0, st, a);
+    else hipLaunchKernelGGL(ce16_bwd_items_kernel<false>, dim3((unsigned)(N / C16_ROWS_WG)), dim3(64 * C16_NW), 0, st, a);
   }
-  return check_launch("ce16_bwd_items_kernel");
+  if (int rc = check_launch("ce16_bwd_items_kernel")) return rc;
+  if (a.n_splits > 1) {
+    hipLaunchKernelGGL(ce16_bwd_reduce_kernel, dim3((unsigned)ceil_div(N * (C16_D / 4), 256)), dim3(256), 0, st, w.part, a.n_splits, N, dI, lddi);
+    return check_launch("ce16_bwd_reduce_kernel");
+  }
+  return 0;
 }

@@ -796,11 +796,8 @@ _CE_F16X2 = os.environ.get("TT_CE_F16X2") is not None
 
 
 def ce16_usable(U: torch.Tensor, I: torch.Tensor) -> bool:
-    # wide negative sets only (N >= 4 M, the sharded step's shape seen from one rank): the pair's item-side backward has
-    # one workgroup per 256 items and no split over users -- at N = M = 8192 that is 32 workgroups on 256 CUs, and the op
-    # measured SLOWER than the fp32 pair there (deferred-Adam P step 1.42 vs 1.19 ms)
     return bool(_CE_F16X2 and U.is_cuda and U.dim() == 2 and I.dim() == 2 and U.dtype == torch.float32 and I.dtype == torch.float32
-                and I.shape[0] >= 4 * U.shape[0] and N.load().tt_ce16_supported(U.shape[0], I.shape[0], U.shape[1]))
+                and N.load().tt_ce16_supported(U.shape[0], I.shape[0], U.shape[1]))
 
 
 def fused_loss_supported(U: torch.Tensor, I: torch.Tensor, labels: Optional[torch.Tensor], uvw: torch.Tensor) -> bool:
