@@ -448,6 +448,20 @@ def secondary(device, lib, N):
         sec["emulated_W8"] = {"error": f"{type(e).__name__}: {e}"}
     torch.cuda.empty_cache()
     try:
+        # EXPLORATORY x deferred schedule: P_lazy with the in-batch logits as split-fp16 products (TT_CE_F16X2 on the module path)
+        from two_tower_models_amd import ops as _ops
+        _was = _ops._CE_F16X2
+        _ops._CE_F16X2 = True
+        try:
+            sec["P_lazy_f16x2"] = _timed_train("P", device, 20, 3, lazy=True)
+            sec["P_lazy_f16x2"]["EXPLORATORY"] = ("dtype f32 (fp16x2 split logits: csrc/ce_f16x2.hip) on top of the value-exact deferred Adam "
+                                                 "schedule; compare with P_lazy, never with the headline")
+        finally:
+            _ops._CE_F16X2 = _was
+    except Exception as e:
+        sec["P_lazy_f16x2"] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
+    try:
         # EXPLORATORY, reported separately like P_lazy: the same emulated step with the logits pair as
         # split-fp16 products (csrc/ce_f16x2.hip, TT_CE_F16X2) -- fp32-grade results at about half the logits time
         sec["emulated_W8_f16x2"] = _emu.emulated(8, "P", steps=30, warmup=25, device=device, split16=True)
