@@ -44,6 +44,9 @@ class BaselineMIPSModule(nn.Module):
         """EXPLORATORY: keep the fp32 corpus and ALSO its two-term fp16 split (same size again); searches then score
         on the fp16 matrix pipe at fp32-grade accuracy (three fp16 MFMA products per fp32 product) -- same contract
         as the fp32 path, about 2.5x faster.  D = 128, fp32 corpus.  Call again after the corpus changes."""
+        if on and (self.corpus.dtype != torch.float32 or self.corpus.shape[1] != 128):
+            raise ValueError("split-fp16 scoring takes a float32 corpus with embedding_dim 128 "
+                             f"(got {self.corpus.dtype}, D = {self.corpus.shape[1]})")
         self._split16_on = bool(on)
         self._split16 = self._split16_key = None  # built by the next search (and again whenever the corpus has changed)
         return self
