@@ -159,12 +159,6 @@ __device__ __forceinline__ void dma_linear(const _Float16* __restrict__ base, ch
   }
 }
 
-__device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
-  f16x8 r;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) r[k] = (_Float16)v[k];
-  return __builtin_bit_cast(u32x4, r);
-}
 // v (already scaled into fp16's range) -> its two terms, 8 at a time
 __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
   f16x8 a, b;

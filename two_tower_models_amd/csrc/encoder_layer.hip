@@ -369,12 +369,19 @@ extern "C" int tt_enc_layer_fwd(const float* x, int64_t B, int64_t H, int64_t D,
   if (al & 15) return fail_arg("tt_enc_layer_fwd: x, w_in, b_in, w_out, qkv must be 16-byte aligned");
   if (rows0_only ? ld_y < D : ld_y != D) return fail_arg("tt_enc_layer_fwd: ld_y");
   if (B == 0) return 0;
+  // Phase skipping / per-phase clocks exist in measurement builds only (-DTT_ENC_FWD_MEASURE; DESIGN section 4 quotes what
+  // they found): the product library allocates nothing and prints nothing.
+#ifdef TT_ENC_FWD_MEASURE
   static const int dbg = [] { const char* e = getenv("TT_ENC_FWD_DBG"); return e ? atoi(e) : 0; }();
   static long long* trace = [] {
     long long* t = nullptr;
     if (getenv("TT_ENC_FWD_TRACE") && hipMalloc(&t, 4 * 64 * 8 * sizeof(long long)) != hipSuccess) t = nullptr;
     return t;
   }();
+#else
+  constexpr int dbg = 0;
+  long long* const trace = nullptr;
+#endif
   EncLayerArgs a{x, w_in, b_in, w_out, b_out, y, qkv, ctx, lse, B, ld_y, (int)H, rows0_only ? 1 : 0, trace, dbg};
   hipStream_t st = S(stream);
   static const int wgs = [] { const char* e = getenv("TT_ENC_FWD_WGS"); return e ? atoi(e) : 256; }();
@@ -382,6 +389,7 @@ extern "C" int tt_enc_layer_fwd(const float* x, int64_t B, int64_t H, int64_t D,
   ProfScope prof("enc_layer_fwd_kernel", st);
   if (rows0_only) enc_layer_fwd_kernel<true><<<grid, 256, 0, st>>>(a);
   else enc_layer_fwd_kernel<false><<<grid, 256, 0, st>>>(a);
+#ifdef TT_ENC_FWD_MEASURE
   if (trace) {  // measurement only: phase boundaries of workgroup 0's first samples, cycles relative to the first mark
     static int printed = 0;
     if (printed++ == 3) {
@@ -399,5 +407,6 @@ extern "C" int tt_enc_layer_fwd(const float* x, int64_t B, int64_t H, int64_t D,
       }
     }
   }
+#endif
   return check_launch("enc_layer_fwd_kernel");
 }
