@@ -438,13 +438,15 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // TT_F16X2 scores of one 32-row sub-tile of the swizzled LDS tile (fp32 image: 32 DPX bytes per row, chunks 0 .. 2 KS - 1
 // the h term, 2 KS .. 4 KS - 1 the l term; the swizzle flips the low four chunk bits only, so the halves stay apart):
 // the MFMA sequence of Op<TT_F16X2>::tile_at, operand reads one k-step ahead
-template <int DPX>
-__device__ __forceinline__ f32x16 score_tile_f16x2(const float* ys, const typename Op<TT_F16X2, DPX>::Frag& q, int jt, int r, int h) {
+template <int DPX, int NQ>
+__device__ __forceinline__ void score_tile_f16x2(const float* ys, const typename Op<TT_F16X2, DPX>::Frag (&q)[NQ], f32x16 (&acc)[NQ], int jt,
+                                                 int r, int h) {
   using TM = TileMap<DPX, true>;
   constexpr int KS = DPX / 2;
-  f32x16 acc;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int n = 0; n < NQ; ++n)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
   const int row = jt * 32 + r;
   uint4 yh[2], yl[2];
   yh[0] = *reinterpret_cast<const uint4*>(ys + TM::chunk(row, h));
@@ -455,12 +457,19 @@ __device__ __forceinline__ f32x16 score_tile_f16x2(const float* ys, const typena
       yh[(g + 1) & 1] = *reinterpret_cast<const uint4*>(ys + TM::chunk(row, 2 * (g + 1) + h));
       yl[(g + 1) & 1] = *reinterpret_cast<const uint4*>(ys + TM::chunk(row, 2 * KS + 2 * (g + 1) + h));
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, yh[g & 1]), __builtin_bit_cast(f16x8, q.h[g]), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, yh[g & 1]), __builtin_bit_cast(f16x8, q.l[g]), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, yl[g & 1]), __builtin_bit_cast(f16x8, q.h[g]), acc, 0, 0, 0);
+    // per query fragment the SAME three products in the same order as Op<TT_F16X2>::tile_at (bit-identical scores); the
+    // fragments' chains interleave, and one pair of operand reads feeds all of them
+#pragma unroll
+    for (int n = 0; n < NQ; ++n)
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, yh[g & 1]), __builtin_bit_cast(f16x8, q[n].h[g]), acc[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NQ; ++n)
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, yh[g & 1]), __builtin_bit_cast(f16x8, q[n].l[g]), acc[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NQ; ++n)
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, yl[g & 1]), __builtin_bit_cast(f16x8, q[n].h[g]), acc[n], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
-  return acc;
 }
 
 template <int DT, int DPX, int NQ, int STAGES, int SF>
@@ -474,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
   static_assert(SF == 0 || SF == 2 || SF == 4, "shared-query form: waves per query block");
   using O = Op<DT, DPX>;
   using TM = TileMap<DPX, true>;  // row bytes = 32 * DPX for both dtypes
-  static_assert(DT == TT_BF16 || NQ == 1, "two query fragments only for bf16");
+  static_assert(DT == TT_BF16 || NQ == 1 || (DT == TT_F16X2 && NQ == 2), "several query fragments only for the 16-bit forms");
   static_assert(!SHARE || NQ == 1, "shared queries: one fragment");
   constexpr int TILE_FLOATS = CT * TM::DP;
   // The ring's stages are separately NAMED LDS arrays and the tile loop is unrolled by STAGES: only
@@ -582,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void mips_pass1_dma_kernel(const MipsArgs p
       if constexpr (DT == TT_F32) {
         acc[0] = score_tile<DPX, true>(ys, qf[0].v, jt, r, h);
       } else if constexpr (DT == TT_F16X2) {
-        acc[0] = score_tile_f16x2<DPX>(ys, qf[0], jt, r, h);
+        score_tile_f16x2<DPX, NQ>(ys, qf, acc, jt, r, h);
       } else {
 #pragma unroll
         for (int n = 0; n < NQ; ++n)
@@ -1489,8 +1498,13 @@ static int dispatch_pass1_dma(int dtype, int dpx, const MipsArgs& a, int64_t spl
     if (dpx == 8) return sf == 4 ? launch_pass1_dma<TT_F32, 8, 1, 4>(a, splits, st) : sf == 2 ? launch_pass1_dma<TT_F32, 8, 1, 2>(a, splits, st) : launch_pass1_dma<TT_F32, 8, 1>(a, splits, st);
     return sf == 4 ? launch_pass1_dma<TT_F32, 16, 1, 4>(a, splits, st) : sf == 2 ? launch_pass1_dma<TT_F32, 16, 1, 2>(a, splits, st) : launch_pass1_dma<TT_F32, 16, 1>(a, splits, st);
   }
-  if (dtype == TT_F16X2)
-    return sf == 4 ? launch_pass1_dma<TT_F16X2, 16, 1, 4>(a, splits, st) : sf == 2 ? launch_pass1_dma<TT_F16X2, 16, 1, 2>(a, splits, st) : launch_pass1_dma<TT_F16X2, 16, 1>(a, splits, st);
+  if (dtype == TT_F16X2) {
+    if (sf) return sf == 4 ? launch_pass1_dma<TT_F16X2, 16, 1, 4>(a, splits, st) : launch_pass1_dma<TT_F16X2, 16, 1, 2>(a, splits, st);
+    // two query fragments per wave (64 queries) from 256 queries on: one pair of operand reads feeds six MFMAs
+    static const int f16_nq = getenv("TT_MIPS_F16X2_NQ") ? atoi(getenv("TT_MIPS_F16X2_NQ")) : 0;
+    const int nq2 = f16_nq ? f16_nq == 2 : a.nq > 2 * QB_WG;
+    return nq2 ? launch_pass1_dma<TT_F16X2, 16, 2>(a, splits, st) : launch_pass1_dma<TT_F16X2, 16, 1>(a, splits, st);
+  }
   if (sf) {
     if (dpx == 4) return sf == 4 ? launch_pass1_dma<TT_BF16, 4, 1, 4>(a, splits, st) : launch_pass1_dma<TT_BF16, 4, 1, 2>(a, splits, st);
     if (dpx == 8) return sf == 4 ? launch_pass1_dma<TT_BF16, 8, 1, 4>(a, splits, st) : launch_pass1_dma<TT_BF16, 8, 1, 2>(a, splits, st);
