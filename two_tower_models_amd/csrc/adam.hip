@@ -177,12 +177,27 @@ __device__ __forceinline__ void adam_stash_ids_body(const float* __restrict__ W,
   float* sv = sm + n_ids * dim;
   if (((dim & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(M) |
                             reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(side)) & 15) == 0) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (the load is unconditional, from row 0 for an id that is not ours, and masked afterwards: `ok ? *ptr : zero` on a
+    // float4 is a select between two ADDRESSES -- the zero lands in scratch memory, 32 bytes per lane of it)
+    const int64_t src = (ok ? row : 0) * dim;
     for (int64_t d = 4 * lane; d < dim; d += 256) {
-      if (planes & 1) *reinterpret_cast<float4*>(sp + d) = ok ? *reinterpret_cast<const float4*>(W + row * dim + d) : z;
-      if (planes & 2) *reinterpret_cast<float4*>(sm + d) = ok ? *reinterpret_cast<const float4*>(M + row * dim + d) : z;
-      if (planes & 4) *reinterpret_cast<float4*>(sv + d) = ok ? *reinterpret_cast<const float4*>(V + row * dim + d) : z;
+      if (planes & 1) {
+        float4 v = *reinterpret_cast<const float4*>(W + src + d);
+        if (!ok) v.x = v.y = v.z = v.w = 0.f;
+        *reinterpret_cast<float4*>(sp + d) = v;
+      }
+      if (planes & 2) {
+        float4 v = *reinterpret_cast<const float4*>(M + src + d);
+        if (!ok) v.x = v.y = v.z = v.w = 0.f;
+        *reinterpret_cast<float4*>(sm + d) = v;
+      }
+      if (planes & 4) {
+        float4 v = *reinterpret_cast<const float4*>(V + src + d);
+        if (!ok) v.x = v.y = v.z = v.w = 0.f;
+        *reinterpret_cast<float4*>(sv + d) = v;
+      }
     }
+
   } else {
     for (int64_t d = lane; d < dim; d += 64) {
       if (planes & 1) sp[d] = ok ? W[row * dim + d] : 0.f;
