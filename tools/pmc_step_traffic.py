@@ -1,6 +1,6 @@
 """Per-step HBM traffic of a whole train step from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 usage: python tools/pmc_step_traffic.py <fetch_dir> <write_dir> <out_json> [algorithmic_GB]
-Steps are delimited by adam_advance_kernel (or adam_begin_ids_kernel) dispatches; per kernel name the counters are summed over the complete steps
+Steps are delimited by adam_advance_kernel (or the first adam_begin_ids_kernel after a sweep) dispatches; per kernel name the counters are summed over the complete steps
 and divided by their number.  bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 for kernels that stream 16-B / lane
 (MI355X_MICROARCH.md, HBM section: FETCH_SIZE counts 64 B per 128-B request on gfx950) -- reported next to the
 uncorrected (FETCH_SIZE + WRITE_SIZE) * 1024 so both bounds are on the page."""
@@ -19,7 +19,15 @@ def per_kernel(d, counter):
             if r["Counter_Name"] == counter:
                 rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"])))
     rows.sort()
-    marks = [i for i, r in enumerate(rows) if "adam_advance_kernel" in r[1] or "adam_begin_ids_kernel" in r[1]]
+    # a step begins at adam_advance_kernel / adam_begin_ids_kernel; large lookups launch adam_begin_ids_kernel TWICE per step
+    # (p plane, then m and v on the sweep's stream), so a begin kernel opens a step only if a sweep ran since the last one
+    marks, swept = [], True
+    for i, r in enumerate(rows):
+        if "adam_sweep" in r[1]:
+            swept = True
+        elif ("adam_advance_kernel" in r[1] or "adam_begin_ids_kernel" in r[1]) and swept:
+            marks.append(i)
+            swept = False
     if len(marks) < 3:
         raise SystemExit(f"{d}: need >= 3 steps")
     a, b = marks[1], marks[-1]  # skip the first step (allocations, first-use set-up)

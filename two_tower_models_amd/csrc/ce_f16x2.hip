@@ -69,22 +69,31 @@ __device__ __forceinline__ float scale_for(unsigned absmax_bits) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------- split
-__global__ void ce16_absmax_kernel(const float* __restrict__ X, int64_t ld, int64_t rows, unsigned* __restrict__ out) {
+// ONE atomic per workgroup (256 threads): with one per wavefront the 4096 same-address atomics of a 1024-block launch
+// serialised in L2 and a 4 MB matrix took 50 us to scan (profiles/r04_timeline_emulated_W8_f16x2.txt, first version)
+__device__ __forceinline__ void block_atomic_max(float m, unsigned* out) {
+  __shared__ float part[4];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(out, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));  // non-negative floats order like their bit patterns
+}
+
+__global__ __launch_bounds__(256) void ce16_absmax_kernel(const float* __restrict__ X, int64_t ld, int64_t rows, unsigned* __restrict__ out) {
   float m = 0.f;
   const int64_t n4 = rows * (C16_D / 4);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const float4 v = *reinterpret_cast<const float4*>(X + (i >> 5) * ld + (i & 31) * 4);
     m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fmaxf(fabsf(v.z), fabsf(v.w)), m));
   }
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order like their bit patterns
+  block_atomic_max(m, out);
 }
 
-__global__ void ce16_absmax_vec_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
+__global__ __launch_bounds__(256) void ce16_absmax_vec_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
   float m = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+  block_atomic_max(m, out);
 }
 
 // one workgroup per 16-row block: row-major terms (thread = row, 8 columns) and the block's transposed image
@@ -574,7 +583,7 @@ int64_t carve(void* base, int64_t M, int64_t N, Ws* w) {
 }
 int split_matrix(const float* X, int64_t ld, int64_t rows, unsigned* absmax, const Images& im, hipStream_t st) {
   const int64_t n4 = rows * (C16_D / 4);
-  int blocks = (int)(n4 / 256 < 1024 ? (n4 + 255) / 256 : 1024);
+  int blocks = (int)(n4 / 256 < 256 ? (n4 + 255) / 256 : 256);
   hipLaunchKernelGGL(ce16_absmax_kernel, dim3(blocks), dim3(256), 0, st, X, ld, rows, absmax);
   if (int rc = check_launch("ce16_absmax_kernel")) return rc;
   hipLaunchKernelGGL(ce16_split_kernel, dim3((unsigned)(rows / 16)), dim3(256), 0, st, X, ld, rows, absmax, im);

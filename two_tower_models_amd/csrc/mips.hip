@@ -1690,14 +1690,17 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
 
 // ---------------------------------------------------------------- TT_F16X2 operands
 // scale[0] = the power of two that brings the matrix' largest magnitude into [2^14, 2^15) (1 for an all-zero matrix)
-__global__ void mips_absmax_kernel(const float* __restrict__ X, int64_t n4, unsigned* __restrict__ out) {
+__global__ __launch_bounds__(256) void mips_absmax_kernel(const float* __restrict__ X, int64_t n4, unsigned* __restrict__ out) {
   float m = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const float4 v = reinterpret_cast<const float4*>(X)[i];
     m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fmaxf(fabsf(v.z), fabsf(v.w)), m));
   }
+  __shared__ float part[4];  // one atomic per workgroup, not per wavefront (same-address atomics serialise)
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
 }
 __global__ void mips_scale_from_absmax_kernel(const unsigned* __restrict__ absmax, float* __restrict__ scale) {
   const float mx = __uint_as_float(*absmax);
@@ -1743,7 +1746,7 @@ extern "C" int tt_mips_split_rows(const float* X, int64_t rows, int64_t D, uint1
   unsigned* am = reinterpret_cast<unsigned*>(ws);
   if (hipMemsetAsync(am, 0, 4, st) != hipSuccess) return check_launch("hipMemsetAsync");
   const int64_t n4 = rows * D / 4;
-  const int blocks = (int)(n4 / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  const int blocks = (int)(n4 / 256 < 1024 ? (n4 + 255) / 256 : 1024);
   mips_absmax_kernel<<<blocks, 256, 0, st>>>(X, n4, am);
   if (int rc = check_launch("mips_absmax_kernel")) return rc;
   mips_scale_from_absmax_kernel<<<1, 1, 0, st>>>(am, scale);
