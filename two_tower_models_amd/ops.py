@@ -635,6 +635,7 @@ _ENC_LAST_COLLAPSED = os.environ.get("TT_ENC_NO_COLLAPSED_LAST") is None  # last
 # the three launches it replaces (one wave per SIMD, rows padded 50 -> 64), and no better next to the sweep; opt-in
 _ENC_FUSED_FWD = os.environ.get("TT_ENC_FUSED_FWD") is not None
 _ENC_FOLD_OUT = os.environ.get("TT_ENC_NO_FOLDED_OUT") is None  # out-projection of layer l composed with the in-projection of l + 1
+_ENC_FOLD_TAIL = os.environ.get("TT_ENC_FOLD_INLINE") is None  # A/B: the composed boundaries' small weight-gradient products at the end of backward
 _ENC_COLLAPSE_PREV = os.environ.get("TT_ENC_NO_COLLAPSED_PREV") is None  # second-to-last layer's out-projection folded into the last
 
 
@@ -1099,6 +1100,7 @@ class HistoryEncoder(_LookupFunction):
         grads: List[Optional[torch.Tensor]] = [None] * (4 * L)
         dx = None  # gradient wrt the current layer's OUTPUT x_{l+1}, [B*H, D]
         prev_out_grads = None
+        tail_jobs = []  # (fn, ran on the side stream, hold, leaves): small weight-gradient products deferred to the end
         leaf_params = ctx.layer_leaves
 
         def wgrad(dy, xin, dW, tag, l):  # off the critical path: see run_on_side
@@ -1184,16 +1186,28 @@ class HistoryEncoder(_LookupFunction):
                 dW_po = torch.empty(D, D, dtype=torch.float32, device=dev)
                 db_po = torch.empty(D, dtype=torch.float32, device=dev)
 
-                def folded_weights(d_qkv=d_qkv, x=x, G=G, db_in=db_in, dW_in=dW_in, dW_po=dW_po, db_po=db_po, w_po=w_po, b_po=b_po, w_in=w_in):
+                def folded_G(d_qkv=d_qkv, x=x, G=G, db_in=db_in):
                     gemm_tn_colsum(d_qkv, x, G, db=db_in, slot="ws_side_i")
+
+                def folded_weights(G=G, db_in=db_in, dW_in=dW_in, dW_po=dW_po, db_po=db_po, w_po=w_po, b_po=b_po, w_in=w_in):
                     gemm(N.TT_GEMM_NT, G, w_po, dW_in, 3 * D, D, D, slot="ws_side_g")
                     gemm(N.TT_GEMM_NT, db_in.view(3 * D, 1), b_po.view(D, 1), dW_in, 3 * D, D, 1, accumulate=True, slot="ws_side_g")
                     gemm(N.TT_GEMM_TN, w_in, G, dW_po, D, D, 3 * D, slot="ws_side_g")
                     gemm(N.TT_GEMM_NN, db_in.view(1, 3 * D), w_in, db_po.view(1, D), 1, D, 3 * D, slot="ws_side_g")
 
-                # queued BEFORE the data-path product below: the side stream starts where the main one stands now
-                run_on_side(dev, folded_weights, hold=(d_qkv, x, G, w_po, b_po, w_in, w_eff),
-                            leaves=list(leaf_params[4 * l: 4 * l + 2]) + list(leaf_params[4 * (l - 1) + 2: 4 * (l - 1) + 4]))
+                # the streaming product G is queued BEFORE the data-path product below (the side stream starts where the main
+                # one stands now); the four small products that turn G into weight gradients wait until the END of this
+                # backward -- in line they sat on the side stream between this layer's G and the next one's, next to the
+                # data path's heaviest kernels, 245 us for 60 us of work, and the side stream finished 250 us after the main one
+                hold_f = (d_qkv, x, G, db_in, w_po, b_po, w_in, w_eff)
+                leaves_f = list(leaf_params[4 * l: 4 * l + 2]) + list(leaf_params[4 * (l - 1) + 2: 4 * (l - 1) + 4])
+                aside = run_on_side(dev, folded_G, hold=hold_f, leaves=leaves_f)
+                if _ENC_FOLD_TAIL:
+                    tail_jobs.append((folded_weights, aside, hold_f, leaves_f))
+                elif aside:
+                    run_on_side(dev, folded_weights, hold=hold_f, leaves=leaves_f)
+                else:
+                    folded_weights()
                 dx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
                 gemm(N.TT_GEMM_NN, d_qkv, w_eff, dx, B * H, D, 3 * D)
                 prev_out_grads = (dW_po, db_po)
@@ -1202,6 +1216,11 @@ class HistoryEncoder(_LookupFunction):
                 dx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
                 gemm(N.TT_GEMM_NN, d_qkv, w_in, dx, B * H, D, 3 * D)
             grads[4 * l: 4 * l + 4] = [dW_in, db_in, dW_out, db_out]
+        for fn, aside, hold_f, leaves_f in tail_jobs:
+            if aside:
+                run_on_side(dev, fn, hold=hold_f, leaves=leaves_f)
+            else:
+                fn()
         if dx is None:  # L == 0: slot 0 is row 0 of (x + pe)
             dx = torch.zeros(B * H, D, dtype=torch.float32, device=dev)
             dx.view(B, H, D)[:, 0, :].copy_(d_recent)
