@@ -453,6 +453,14 @@ int tt_adam_dense(const tt_adam_tensor* tensors /*host*/, int32_t n_tensors, con
 int tt_hist_embed_pool(const float* table, int64_t n_rows, int64_t dim, const int64_t* ids,
                        int64_t B, int64_t H, const float* pe, float* x, float* pooled,
                        int64_t ld_pooled, int32_t* oob_flag, tt_stream_t stream);
+/* The first encoder layer's input gradient and the mean pool's backward in ONE pass:
+ * dx[b, h, :] = dqkv[b, h, :] . w_in + d_pooled[b, :] / H   (dqkv [B*H, 3D], w_in [3D, D]; autograd of
+ * ref:src/user_history_encoder.py:103-116: the in-projection's input gradient plus the mean over H) -- the row-group term
+ * rides in the product's epilogue, so dx is written once and never read back (tt_gemm_f32 + tt_hist_pool_bwd otherwise).
+ * D = 128, B*H >= 16384, 16-byte aligned operands; TT_E_UNSUPPORTED otherwise. */
+int tt_hist_dx_pool_bwd(const float* dqkv, const float* w_in, int64_t B, int64_t H, int64_t D, const float* d_pooled,
+                        int64_t ld_pooled, float* dx, tt_stream_t stream);
+
 /* backward of the mean pool (ref:...encoder.py:89): dx[b,h,:] += d_pooled[b,:] / H */
 int tt_hist_pool_bwd(float* dx, int64_t B, int64_t H, int64_t dim, const float* d_pooled,
                      int64_t ld_pooled, tt_stream_t stream);

@@ -341,6 +341,22 @@ def test_inbatch_ce_op_keep_logits_matches_default(T):
     assert torch.isfinite(I.grad).all()
 
 
+def test_dx_product_with_pool_backward_epilogue(T):
+    """tt_hist_dx_pool_bwd: dx = dQKV W_in + d_pooled / H in one pass (the POOL form of gemm_ws16_kernel) against float64,
+    strided d_pooled rows (slot 1 of the [B, 2, D] cotangent), a ragged last stage; small problems are refused."""
+    ops, N = T
+    lib = N.load()
+    B, H, D = 700, 29, 128  # B * H = 20 300 rows: not a multiple of the 32-row stage
+    dqkv, w_in = g((B * H, 3 * D), 411) * 0.3, g((3 * D, D), 412) / math.sqrt(D)
+    cot = g((B, 2 * D), 413)
+    dq, w, c = dqkv.to(DEV), w_in.to(DEV), cot.to(DEV)
+    dx = torch.full((B * H, D), float("nan"), device=DEV)
+    N.check(lib.tt_hist_dx_pool_bwd(dq.data_ptr(), w.data_ptr(), B, H, D, c[:, D:].data_ptr(), 2 * D, dx.data_ptr(), N.stream()), "dx_pool")
+    want = dqkv.double() @ w_in.double() + (cot[:, D:].double() / H).repeat_interleave(H, dim=0)
+    assert float((dx.cpu().double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    assert lib.tt_hist_dx_pool_bwd(dq.data_ptr(), w.data_ptr(), 4, H, D, c[:, D:].data_ptr(), 2 * D, dx.data_ptr(), N.stream()) == N.TT_E_UNSUPPORTED
+
+
 def test_inbatch_ce_op_through_split_fp16_pair(T, monkeypatch):
     """ops.InBatchSoftmaxCE with TT_CE_F16X2 (EXPLORATORY): the autograd op takes the split-fp16 pair where its shapes allow
     and lands on the fp32-MFMA path's values to within the pair's error (test_split_fp16_ce_pair_vs_float64); unsupported

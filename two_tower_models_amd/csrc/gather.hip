@@ -212,6 +212,23 @@ extern "C" int tt_hist_embed_pool(const float* table, int64_t n_rows, int64_t di
   return check_launch("hist_embed_pool_kernel");
 }
 
+namespace tt {
+int gemm_ws16_pool_try(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
+                       const float* pool, int64_t ld_pool, int64_t group, float scale, hipStream_t st);
+}
+
+extern "C" int tt_hist_dx_pool_bwd(const float* dqkv, const float* w_in, int64_t B, int64_t H, int64_t D, const float* d_pooled,
+                                   int64_t ld_pooled, float* dx, tt_stream_t stream) {
+  if (!dqkv || !w_in || !d_pooled || !dx) return fail_arg("tt_hist_dx_pool_bwd: null pointer");
+  if (B <= 0 || H <= 0 || D <= 0 || ld_pooled < D) return fail_arg("tt_hist_dx_pool_bwd: sizes");
+  const int rc = gemm_ws16_pool_try(B * H, D, 3 * D, dqkv, 3 * D, w_in, D, dx, D, d_pooled, ld_pooled, H, 1.0f / (float)H, S(stream));
+  if (rc == -100) {
+    set_error("tt_hist_dx_pool_bwd: takes D = 128, B * H >= 16384, 16-byte aligned operands");
+    return TT_E_UNSUPPORTED;
+  }
+  return rc;
+}
+
 extern "C" int tt_hist_pool_bwd(float* dx, int64_t B, int64_t H, int64_t dim, const float* d_pooled,
                                 int64_t ld_pooled, tt_stream_t stream) {
   if (!dx || !d_pooled) return fail_arg("tt_hist_pool_bwd: null pointer");

@@ -29,6 +29,11 @@ struct Ws16Args {
   const float* bias;
   float* C;
   int64_t M, lda, ldw, ldc;
+  // POOL form only: C[m][:] += pool_scale * pool[m / group][:] (the mean pool's backward folded into the dx product)
+  const float* pool;
+  int64_t ld_pool;
+  uint32_t group;
+  float pool_scale;
 };
 
 template <int KB, int NB>  // K = 128 * KB, N = 128 * NB
@@ -71,7 +76,7 @@ __device__ __forceinline__ void ws16_issue(const Ws16Args& p, float* stage, int6
   }
 }
 
-template <int KB, int NB, bool W_TRANS>  // K = 128 KB reduction columns, N = 128 NB output columns; KB * NB <= 3
+template <int KB, int NB, bool W_TRANS, bool POOL = false>  // K = 128 KB reduction columns, N = 128 NB output columns; KB * NB <= 3
 __global__ __launch_bounds__(512, 2) void gemm_ws16_kernel(const Ws16Args p) {
   using Cf = Ws16Cfg<KB, NB>;
   constexpr int K = Cf::K, TILES = Cf::TILES, PPW = Cf::PPW;
@@ -111,6 +116,22 @@ __global__ __launch_bounds__(512, 2) void gemm_ws16_kernel(const Ws16Args p) {
   const int64_t nst = (p.M + Cf::ROWS - 1) / Cf::ROWS;
   const int64_t t0 = nst * blockIdx.x / gridDim.x, t1 = nst * (blockIdx.x + 1) / gridDim.x;
 
+  // POOL: the row-group term of a stage's rows is fetched BEFORE the next stage's DMA is issued (see WS16_STEP): the
+  // compiler's wait for it then allows the DMA pieces issued after it to stay in flight
+  f32x4 pool4[POOL ? TILES : 1][NB];
+  auto fetch_pool = [&](int64_t t) {
+    if constexpr (POOL) {
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) {
+        int64_t m = t * Cf::ROWS + tl + 16 * i;
+        if (m >= p.M) m = p.M - 1;
+        const uint32_t b = (uint32_t)m / p.group;  // (M < 2^32, host-checked)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) pool4[i][j] = *reinterpret_cast<const f32x4*>(p.pool + (int64_t)b * p.ld_pool + n0 + 16 * j + 4 * q4);
+      }
+    }
+  };
+
   auto compute = [&](const float* stg, int64_t t) {
     f32x4 acc[TILES][NB];
 #pragma unroll
@@ -140,7 +161,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ws16_kernel(const Ws16Args p) {
       // after it, so the store count the waits below assume holds wherever it matters)
       if (m < p.M) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) *reinterpret_cast<f32x4*>(p.C + m * p.ldc + n0 + 16 * j + 4 * q4) = acc[i][j] + bias4[j];
+        for (int j = 0; j < NB; ++j) {
+          f32x4 v = acc[i][j] + bias4[j];
+          if constexpr (POOL) v += pool4[i][j] * p.pool_scale;
+          *reinterpret_cast<f32x4*>(p.C + m * p.ldc + n0 + 16 * j + 4 * q4) = v;
+        }
       }
     }
   };
@@ -155,6 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws16_kernel(const Ws16Args p) {
     first = false;                                                                         \
     __builtin_amdgcn_s_barrier();                                                          \
     asm volatile("" ::: "memory");                                                         \
+    fetch_pool(T);                                                                         \
     ws16_issue<KB, NB>(p, NXT, (T) + 2, t1, wave, lane);                                       \
     compute(CUR, (T));                                                                     \
   } while (0)
@@ -170,6 +196,24 @@ __global__ __launch_bounds__(512, 2) void gemm_ws16_kernel(const Ws16Args p) {
     ws16_wait_vmcnt<0>();
   }
 #undef WS16_STEP
+}
+
+// dx[m][:] = A[m][:] W + scale * pool[m / group][:] for the history encoder's first layer (K = 384, N = 128, NN): the mean
+// pool's backward (ref:src/user_history_encoder.py:115-116, autograd of the mean over H) rides in the dx product's
+// epilogue instead of a read-modify-write pass over dx.  -100 = shape not taken.
+int gemm_ws16_pool_try(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
+                       const float* pool, int64_t ld_pool, int64_t group, float scale, hipStream_t st) {
+  static const bool off = getenv("TT_GEMM_NO_WS16") != nullptr;
+  if (off || M < 16384 || M >= ((int64_t)1 << 32) || N != 128 || K != 384 || group <= 0 || group >= ((int64_t)1 << 31)) return -100;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(C) |
+                       reinterpret_cast<uintptr_t>(pool);
+  if ((al & 15) || lda % 4 || ldw % 4 || ldc % 4 || ld_pool % 4 || lda > (1 << 20)) return -100;
+  Ws16Args a{A, W, nullptr, C, M, lda, ldw, ldc, pool, ld_pool, (uint32_t)group, scale};
+  const int64_t nst = ceil_div(a.M, Ws16Cfg<3, 1>::ROWS);
+  const unsigned grid = (unsigned)(nst < 256 ? nst : 256);
+  ProfScope prof("gemm_ws16_kernel", st);
+  gemm_ws16_kernel<3, 1, true, true><<<grid, 512, 0, st>>>(a);
+  return check_launch("gemm_ws16_kernel");
 }
 
 template <int KB, int NB, bool WT>
@@ -190,7 +234,7 @@ int gemm_ws16_try(int layout, int64_t M, int64_t N, int64_t K, const float* A, i
   const uintptr_t al = reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(C) |
                        reinterpret_cast<uintptr_t>(bias);
   if ((al & 15) || lda % 4 || ldw % 4 || ldc % 4 || lda > (1 << 20)) return -100;  // 32-bit byte offsets within a stage
-  Ws16Args a{A, W, bias, C, M, lda, ldw, ldc};
+  Ws16Args a{A, W, bias, C, M, lda, ldw, ldc, nullptr, 0, 1u, 0.f};
   const bool wt = layout == TT_GEMM_NN;
   const int kb = (int)(K / 128), nb = (int)(N / 128);
 #define WS16_CASE(KBv, NBv) \

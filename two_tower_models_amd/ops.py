@@ -635,6 +635,7 @@ _ENC_LAST_COLLAPSED = os.environ.get("TT_ENC_NO_COLLAPSED_LAST") is None  # last
 # the three launches it replaces (one wave per SIMD, rows padded 50 -> 64), and no better next to the sweep; opt-in
 _ENC_FUSED_FWD = os.environ.get("TT_ENC_FUSED_FWD") is not None
 _ENC_FOLD_OUT = os.environ.get("TT_ENC_NO_FOLDED_OUT") is None  # out-projection of layer l composed with the in-projection of l + 1
+_ENC_POOL_EPILOGUE = os.environ.get("TT_ENC_NO_POOL_EPILOGUE") is None  # A/B: mean-pool backward as a separate pass over dx
 _ENC_FOLD_TAIL = os.environ.get("TT_ENC_FOLD_INLINE") is None  # A/B: the composed boundaries' small weight-gradient products at the end of backward
 _ENC_COLLAPSE_PREV = os.environ.get("TT_ENC_NO_COLLAPSED_PREV") is None  # second-to-last layer's out-projection folded into the last
 
@@ -1101,6 +1102,7 @@ class HistoryEncoder(_LookupFunction):
         dx = None  # gradient wrt the current layer's OUTPUT x_{l+1}, [B*H, D]
         prev_out_grads = None
         tail_jobs = []  # (fn, ran on the side stream, hold, leaves): small weight-gradient products deferred to the end
+        pool_done = False
         leaf_params = ctx.layer_leaves
 
         def wgrad(dy, xin, dW, tag, l):  # off the critical path: see run_on_side
@@ -1214,7 +1216,16 @@ class HistoryEncoder(_LookupFunction):
             else:
                 db_in = wgrad(d_qkv, x, dW_in, "i", l)
                 dx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
-                gemm(N.TT_GEMM_NN, d_qkv, w_in, dx, B * H, D, 3 * D)
+                rc = N.TT_E_UNSUPPORTED
+                if l == 0 and _ENC_POOL_EPILOGUE and w_in.is_contiguous():
+                    rc = lib.tt_hist_dx_pool_bwd(d_qkv.data_ptr(), w_in.data_ptr(), B, H, D, d_pooled.data_ptr(), 2 * D, dx.data_ptr(),
+                                                 N.stream())
+                if rc == 0:
+                    pool_done = True  # the mean pool's backward rode in this product's epilogue (csrc/gemm_ws16.hip, POOL)
+                elif rc == N.TT_E_UNSUPPORTED:  # shape not taken: the product, then a read-modify-write pass over dx
+                    gemm(N.TT_GEMM_NN, d_qkv, w_in, dx, B * H, D, 3 * D)
+                else:
+                    N.check(rc, "tt_hist_dx_pool_bwd")
             grads[4 * l: 4 * l + 4] = [dW_in, db_in, dW_out, db_out]
         for fn, aside, hold_f, leaves_f in tail_jobs:
             if aside:
@@ -1224,8 +1235,9 @@ class HistoryEncoder(_LookupFunction):
         if dx is None:  # L == 0: slot 0 is row 0 of (x + pe)
             dx = torch.zeros(B * H, D, dtype=torch.float32, device=dev)
             dx.view(B, H, D)[:, 0, :].copy_(d_recent)
-        N.check(lib.tt_hist_pool_bwd(dx.data_ptr(), B, H, D, d_pooled.data_ptr(), 2 * D, N.stream()),
-                "tt_hist_pool_bwd")
+        if not pool_done:
+            N.check(lib.tt_hist_pool_bwd(dx.data_ptr(), B, H, D, d_pooled.data_ptr(), 2 * D, N.stream()),
+                    "tt_hist_pool_bwd")
         d_source = None
         if ctx.needs_input_grad[0]:
             if ctx.has_ids:
