@@ -138,6 +138,7 @@ def reduce_scatter_rows(x: torch.Tensor) -> torch.Tensor:
 # 4.237 vs 4.246 ms per step; not the default.
 _UTOWER_EARLY = os.environ.get("TT_SHARDED_EARLY_UTOWER") is not None
 _LOSS_KERNELS = os.environ.get("TT_SHARDED_TORCH_LOSS") is None  # A/B: the value-weight tail as two kernels
+_WGRAD_ASIDE = os.environ.get("TT_SHARDED_WGRAD_MAIN") is None  # A/B: tower weight gradients on the third stream
 _CE_F16X2 = os.environ.get("TT_CE_F16X2") is not None  # exploratory: split-fp16 logits kernels (HipBackend.ce_fwd)
 # Opt-in (TT_SHARDED_PLAN_ASIDE=1): the NEXT batch's route plan (owner histogram + scan per lookup, the MAX all-reduce
 # of the bucket sizes, their copy to the host) on the library's third stream at the very top of the step instead of on
@@ -348,6 +349,7 @@ class HipBackend:
         self._sides = {}
         self._du_unit = None
         self._kept = self._kept16 = None
+        self._side_done, self._side_hold = None, []
         self.keep_logits = False  # set by the trainer when the logits dominate the step
         self._side_stream = None
         self._sweep_done = None
@@ -474,7 +476,21 @@ class HipBackend:
             N.check(self.lib.tt_tower_bwd_data_x(d_out.data_ptr(), d_out.stride(0), B, De, Hd, W2.data_ptr(), W3.data_ptr(),
                                                  h.data_ptr(), d_emb.data_ptr(), De, d_f.data_ptr(), dh.data_ptr(),
                                                  N.ptr(d_extra), E, E, N.stream()), "tt_tower_bwd_data_x")
-            ops.tower_weight_grads(d_out, f, d_f, h, dh, feats.contiguous(), out=(gW1, gb1, gW2, gb2, gW3, gb3), extra=extra)
+            feats_c = feats.contiguous()
+            if _WGRAD_ASIDE and self.device.type == "cuda":
+                # the six weight gradients feed nothing but the dense all-reduce at the end of the step: they run on the third
+                # stream underneath the other tower's backward and the row-gradient exchanges, joined by join_side()
+                aux = N.aux_stream(self.device)
+                ev = torch.cuda.Event()
+                ev.record()
+                aux.wait_event(ev)
+                with torch.cuda.stream(aux):
+                    ops.tower_weight_grads(d_out, f, d_f, h, dh, feats_c, out=(gW1, gb1, gW2, gb2, gW3, gb3), extra=extra)
+                    self._side_done = torch.cuda.Event()
+                    self._side_done.record()
+                self._side_hold += [d_out, f, d_f, h, dh, feats_c, extra]  # (allocated on the main stream: alive until the join)
+            else:
+                ops.tower_weight_grads(d_out, f, d_f, h, dh, feats_c, out=(gW1, gb1, gW2, gb2, gW3, gb3), extra=extra)
             return d_emb, d_extra
         ops.gemm_tn_colsum(d_out, emb, gW3[:, :De], db=gb3)
         ops.gemm(N.TT_GEMM_TN, d_out, f, gW3[:, De:De + Dm], Do, Dm, B)
@@ -492,6 +508,13 @@ class HipBackend:
         ops.gemm(N.TT_GEMM_NN, d_f, W2, dh, B, Hd, Dm, epilogue=N.TT_EPI_RELU_MASK, aux=h)
         ops.gemm_tn_colsum(dh, feats, gW1, db=gb1)
         return d_emb, d_extra
+
+    def join_side(self) -> None:
+        """The main stream waits for the tower weight gradients queued on the third stream (tower_bwd)."""
+        if self._side_done is not None:
+            torch.cuda.current_stream().wait_event(self._side_done)
+            self._side_done = None
+        self._side_hold = []
 
     # history encoder (ref:src/user_history_encoder.py:80-121) through the product's autograd function
     def encoder_fwd(self, x: torch.Tensor, pe: Optional[torch.Tensor], heads: int, layer_params: Sequence[torch.Tensor]):
@@ -1238,6 +1261,8 @@ class ShardedTrainer:
             g_h_p = all_to_all_rows_start(be.gather_rows(d_hrows, lk_h.src_of), tag="rowgrad_alltoall")
         d_irows, _ = be.tower_bwd(dI_p.wait(), i_emb, i_h, i_f, item_feat, pi, self._tower_grads("item"))
         g_i_p = all_to_all_rows_start(be.gather_rows(d_irows, lk_i.src_of), tag="rowgrad_alltoall")
+        if hasattr(be, "join_side"):
+            be.join_side()
         flat_p = all_reduce_start_(self.flat_g, tag="dense_grad_allreduce")  # every dense gradient has been written by now
         g_u, g_i = g_u_p.wait(), g_i_p.wait()
         if self.hist:  # aligned with item_local = [history ids | item ids]
@@ -1341,6 +1366,8 @@ class ShardedTrainer:
             g_h_p = all_gather_rows_start(d_hrows)
         d_irows, _ = be.tower_bwd(dI_p.wait(), i_emb, i_h, i_f, item_feat, pi, self._tower_grads("item"))
         g_i_p = all_gather_rows_start(d_irows)
+        if hasattr(be, "join_side"):
+            be.join_side()
         flat_p = all_reduce_start_(self.flat_g)  # every dense gradient has been written by now
         g_u, g_i = g_u_p.wait(), g_i_p.wait()
         if self.hist:  # aligned with item_local = [history ids | item ids]
