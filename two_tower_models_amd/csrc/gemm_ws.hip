@@ -124,7 +124,9 @@ __global__ __launch_bounds__(256, ((GLDS && DP8 <= 16) ? 2 : 1)) void gemm_ws_ke
   // LDS-DMA completion is waited on, so a store issued right before that wait would stall the
   // wave for a full HBM write latency: sub-tile 1's stores are DEFERRED into the next iteration
   // (after the next DMA issue), and sub-tile 0's are followed by sub-tile 1's 64 MFMAs.
-  auto emit = [&](const f32x16& acc, int64_t m) {
+  // always_inline: the run-time (WS_GENERIC) body is large enough that hipcc left it a FUNCTION with three call sites, and
+  // everything it captures by reference (bias_e, the pending tile) then lived in scratch: 384 B per lane
+  auto emit = [&](const f32x16& acc, int64_t m) __attribute__((always_inline)) {
     if constexpr (MODE != WS_GENERIC) {
       if (m < p.M && nw < p.N) {
         float* crow = p.C + ((int)m * (int)p.ldc + (int)nw + 4 * h);  // 32-bit offsets (host-checked)
