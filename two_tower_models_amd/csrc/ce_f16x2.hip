@@ -225,6 +225,10 @@ __device__ __forceinline__ void fwd_tile(const FwdStage* st, const u32x4 (&uh)[8
       ih[(t + 1) & 1] = *reinterpret_cast<const u32x4*>(rowh + off);
       il[(t + 1) & 1] = *reinterpret_cast<const u32x4*>(rowl + off);
     }
+#if !(TT_CE16_EXP & 128)
+    __builtin_amdgcn_sched_barrier(0);  // the reads of step t + 1 go out BEFORE step t's MFMAs (else hipcc reuses ih's registers
+                                        // and issues the read one MFMA ahead of its use: an LDS latency per k-step)
+#endif
     acc = MFMA16(ih[t & 1], uh[t], acc);
     acc = MFMA16(ih[t & 1], ul[t], acc);
     acc = MFMA16(il[t & 1], uh[t], acc);
@@ -283,6 +287,7 @@ __device__ __forceinline__ void fwd_tile(const FwdStage* st, const u32x4 (&uh)[8
   E[0][0] += __builtin_bit_cast(float, ph[0][0] ^ pl[1][3]);
   return;
 #endif
+#if TT_CE16_EXP & 128
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -296,6 +301,29 @@ __device__ __forceinline__ void fwd_tile(const FwdStage* st, const u32x4 (&uh)[8
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+#else
+  // the eight (s, b) fragment pairs, each read one pair ahead of its three MFMAs
+  u32x4 th[2], tl[2];
+  {
+    const int at = h * 2048 + r * 16;
+    th[0] = *reinterpret_cast<const u32x4*>(st->tr_h + at);
+    tl[0] = *reinterpret_cast<const u32x4*>(st->tr_l + at);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int s = i >> 2, b = i & 3;
+    if (i + 1 < 8) {
+      const int at = ((i + 1) >> 2) * 4096 + h * 2048 + (((i + 1) & 3) * 32 + r) * 16;
+      th[(i + 1) & 1] = *reinterpret_cast<const u32x4*>(st->tr_h + at);
+      tl[(i + 1) & 1] = *reinterpret_cast<const u32x4*>(st->tr_l + at);
+    }
+    __builtin_amdgcn_sched_barrier(0x6);  // (VALU / SALU may cross: the second half's exp2 + split still slide under these MFMAs)
+    E[b] = MFMA16(th[i & 1], ph[s], E[b]);
+    E[b] = MFMA16(th[i & 1], pl[s], E[b]);
+    E[b] = MFMA16(tl[i & 1], ph[s], E[b]);
+    __builtin_amdgcn_sched_barrier(0x6);
+  }
+#endif
 }
 
 }  // namespace
