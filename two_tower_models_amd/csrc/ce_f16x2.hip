@@ -255,7 +255,11 @@ __device__ __forceinline__ void fwd_tile(const FwdStage* st, const u32x4 (&uh)[8
 #else
       // (plain stores: non-temporal ones were measured 25 % slower here -- 1.30 vs 1.04 ms, WRITE_SIZE 3.1 GB for 2.15 GB of
       // logits: the 32-byte pieces of a line no longer merge in L2)
+#if TT_CE16_EXP & 16  // (measurement: the same bytes as four fully coalesced 1-KiB stores, WRONG layout)
+      *reinterpret_cast<f32x4*>(logit_row - r * 32 + (item0 >> 5) * 1024 + g * 256 + (h * 32 + r) * 4) = q;
+#else
       *reinterpret_cast<f32x4*>(tile + 8 * g) = q;
+#endif
 #endif
     }
   }
