@@ -3,6 +3,7 @@
 # tools/bench_ce.py at the W = 8 shape.  Variant results are WRONG by design.
 #   1 no logits stores   2 no E product (forward)   4 non-temporal logits stores   8 tile wait leaves the four logits stores in flight   32 backward without logits loads
 #   16 logits stores as four fully coalesced 1-KiB pieces per tile (wrong layout: what the 32-byte-per-row pattern costs)
+#   256 logits stores straight from the score registers (32 bytes into each of 32 rows per instruction) instead of through the LDS transpose
 #   128 forward operand reads where hipcc puts them (one MFMA ahead of their use) instead of a whole k-step / fragment pair ahead
 #   tools/ce16_variants.sh build   (here)        tools/ce16_variants.sh run   (on the GPU box)
 set -e

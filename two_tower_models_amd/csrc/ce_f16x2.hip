@@ -206,7 +206,7 @@ __device__ __forceinline__ void fwd_stage_dma(const FwdArgs& p, int64_t item0, F
 
 // one tile against the wave's 32 stationary users
 __device__ __forceinline__ void fwd_tile(const FwdStage* st, const u32x4 (&uh)[8], const u32x4 (&ul)[8], f32x16 (&E)[4], float& mx, float& sm,
-                                         float out_scale, float* __restrict__ logit_row, int64_t item0, int r, int h) {
+                                         float out_scale, float* __restrict__ logit_row, int64_t item0, int r, int h, char* xp) {
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -244,6 +244,7 @@ __device__ __forceinline__ void fwd_tile(const FwdStage* st, const u32x4 (&uh)[8
     tmax = fmaxf(tmax, v[e]);
   }
 #if !(TT_CE16_EXP & 1)
+#if TT_CE16_EXP & (4 | 16 | 256)
   {  // the wave's 32 x 32 tile is one contiguous 4 KiB block of the logits buffer, row-major inside (see tt_hotpath.h)
     float* tile = logit_row + (item0 >> 5) * 1024 + 8 * 0 + 4 * h;
 #pragma unroll
@@ -263,6 +264,26 @@ __device__ __forceinline__ void fwd_tile(const FwdStage* st, const u32x4 (&uh)[8
 #endif
     }
   }
+#else
+  {  // The wave's 32 x 32 tile is one contiguous 4 KiB block of the logits buffer, row-major inside (see tt_hotpath.h).  Straight
+     // from the score registers (lane = user) a store instruction would write 32 bytes into each of 32 rows -- 8.5 % of the kernel
+     // (variant 16) -- so the tile is turned through the wave's own 4-KiB LDS slice: written as [user][item] with the 16-byte
+     // chunks of a row XOR-swizzled by the row (conflict-free both ways), read back 8 lanes per row, stored as four fully
+     // coalesced 1-KiB pieces.  One wave, LDS in order: no barrier.
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = h * 32 + r;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 q = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};  // items 8 g + 4 h + (0..3) = chunk 2 g + h of row r
+      *reinterpret_cast<f32x4*>(xp + r * 128 + (((2 * g + h) ^ (r & 7)) * 16)) = q;
+    }
+    float* tile = logit_row - r * 32 + (item0 >> 5) * 1024 + lane * 4;
+    const char* src = xp + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) * 16);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)  // rows 8 g + (lane >> 3), chunk lane & 7
+      *reinterpret_cast<f32x4*>(tile + g * 256) = *reinterpret_cast<const f32x4*>(src + g * 1024);
+  }
+#endif
 #endif
   tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
   if (tmax > mx) {  // (lane-divergent, rare after the first tiles)
@@ -340,7 +361,9 @@ __device__ __forceinline__ void fwd_tile(const FwdStage* st, const u32x4 (&uh)[8
 __global__ __launch_bounds__(64 * C16_NW, 2) void ce16_fwd_kernel(const FwdArgs p) {
   __shared__ __attribute__((aligned(1024))) FwdStage ring0;
   __shared__ __attribute__((aligned(1024))) FwdStage ring1;
+  __shared__ __attribute__((aligned(1024))) char xpose[C16_NW][4096];  // per wave: the logits tile on its way to memory (fwd_tile)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  char* xp = xpose[wave];
   const int64_t user = (int64_t)blockIdx.x * C16_ROWS_WG + wave * 32 + r;
   const int split = blockIdx.y;
   const int64_t per = p.N / p.n_splits;  // a multiple of C16_TILE (host)
@@ -370,12 +393,12 @@ __global__ __launch_bounds__(64 * C16_NW, 2) void ce16_fwd_kernel(const FwdArgs 
     __builtin_amdgcn_s_waitcnt(C16_FWD_WAIT);  // vmcnt(0): the tile has landed (and the logits stores of the previous one have left)
     __builtin_amdgcn_s_barrier();
     if (tile + 1 < n_tiles) fwd_stage_dma(p, n0 + (int64_t)(tile + 1) * C16_TILE, &ring1, wave, lane);
-    fwd_tile(&ring0, uh, ul, E, mx, sm, out_scale, logit_row, n0 + (int64_t)tile * C16_TILE, r, h);
+    fwd_tile(&ring0, uh, ul, E, mx, sm, out_scale, logit_row, n0 + (int64_t)tile * C16_TILE, r, h, xp);
     if (tile + 1 >= n_tiles) break;
     __builtin_amdgcn_s_waitcnt(C16_FWD_WAIT);
     __builtin_amdgcn_s_barrier();
     if (tile + 2 < n_tiles) fwd_stage_dma(p, n0 + (int64_t)(tile + 2) * C16_TILE, &ring0, wave, lane);
-    fwd_tile(&ring1, uh, ul, E, mx, sm, out_scale, logit_row, n0 + (int64_t)(tile + 1) * C16_TILE, r, h);
+    fwd_tile(&ring1, uh, ul, E, mx, sm, out_scale, logit_row, n0 + (int64_t)(tile + 1) * C16_TILE, r, h, xp);
   }
   sm += __shfl_xor(sm, 32);
   const int64_t at = (int64_t)split * p.M + user;
