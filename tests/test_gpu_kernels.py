@@ -278,6 +278,17 @@ def test_split_fp16_ce_pair_vs_float64(T, M, Nn, off, scale):
                                         Z.data_ptr(), M * Nn * 4, ws.data_ptr(), wsn, N.stream()), "ce16 fwd")
         N.check(lib.tt_ce16_bwd_kept(U.data_ptr(), D, M, Nn, D, off, lse.data_ptr(), coef.data_ptr(), Z.data_ptr(), M * Nn * 4,
                                      dI.data_ptr(), D, ws.data_ptr(), wsn, N.stream()), "ce16 bwd")
+    # the recomputing form: no logits buffer at all; once trusting the forward's images in the workspace, once forming them again
+    lse_r, ce_r, du_r, dI_r, dI_r2 = e(M), e(M), e(M, D), e(Nn, D), e(Nn, D)
+    N.check(lib.tt_ce16_fwd_du_keep(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, off, lse_r.data_ptr(), ce_r.data_ptr(), du_r.data_ptr(), D,
+                                    None, 0, ws.data_ptr(), wsn, N.stream()), "ce16 fwd (no logits)")
+    N.check(lib.tt_ce16_bwd_recompute(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, off, lse_r.data_ptr(), coef.data_ptr(), dI_r.data_ptr(), D,
+                                      ws.data_ptr(), wsn, 1, N.stream()), "ce16 bwd recompute (reuse)")
+    ws.fill_(0xA5)
+    N.check(lib.tt_ce16_bwd_recompute(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, off, lse_r.data_ptr(), coef.data_ptr(), dI_r2.data_ptr(), D,
+                                      ws.data_ptr(), wsn, 0, N.stream()), "ce16 bwd recompute")
+    assert torch.equal(lse_r, lse) and torch.equal(ce_r, ce) and torch.equal(du_r, du)  # the forward's results do not depend on keeping
+    assert torch.equal(dI_r, dI_r2)
     # the fp32-MFMA pair on the same inputs
     wsp, wsn32 = ops._ws(torch.device(DEV), lib.tt_inbatch_ce_workspace_bytes(M, Nn, D), "ce_test")
     lse32, ce32, du32, dI32 = e(M), e(M), e(M, D), e(Nn, D)
@@ -304,7 +315,8 @@ def test_split_fp16_ce_pair_vs_float64(T, M, Nn, off, scale):
     Zrm = Z.view(M // 32, Nn // 32, 32, 32).permute(0, 2, 1, 3).reshape(M, Nn)  # tiles of 32 x 32, row-major inside
     assert err(Zrm, S * 1.4426950408889634) <= 2e-6 * smax  # log2-domain logits, every element
     assert err(lse * 0.6931471805599453, ref_lse) <= 2e-6 * max(1.0, float(ref_lse.abs().max()))  # row_lse: log2 domain, like the fp32 pair's
-    for name, got, got32, ref in (("ce", ce, ce32, ref_ce), ("du_unit", du, du32, ref_du), ("dI", dI, dI32, ref_dI)):
+    for name, got, got32, ref in (("ce", ce, ce32, ref_ce), ("du_unit", du, du32, ref_du), ("dI", dI, dI32, ref_dI),
+                                  ("dI (recomputed logits)", dI_r, dI32, ref_dI)):
         e16, e32 = err(got, ref), err(got32, ref)
         floor = 2e-6 * max(float(ref.abs().max()), 1e-30)
         assert e16 <= 4 * e32 + floor, (name, e16, e32, float(ref.abs().max()))

@@ -71,8 +71,8 @@ def test_world1_split_fp16_logits_match_oracle_at_unchanged_tolerances(monkeypat
         dense = _dense_init(cfg)
         tr = sharded.ShardedTrainer(cfg, dev, negatives="global", user_value_weights=(0.7,), dense_init=dense)
         calls = []
-        real = tr.be.lib.tt_ce16_bwd_kept
-        monkeypatch.setattr(tr.be.lib, "tt_ce16_bwd_kept", lambda *a: (calls.append(1), real(*a))[1])
+        real = tr.be.lib.tt_ce16_bwd_recompute  # (the pair's default form keeps no logits; TT_CE16_KEEP = its first form)
+        monkeypatch.setattr(tr.be.lib, "tt_ce16_bwd_recompute", lambda *a: (calls.append(1), real(*a))[1])
         params = dict(_dense_init(cfg))
         params["user_id_embedding_arch.weight"] = tr.users.weight.cpu().clone()
         params["item_id_embedding_arch.weight"] = tr.items.weight.cpu().clone()

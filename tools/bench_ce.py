@@ -68,11 +68,23 @@ for M, Nn in shapes:
             N.check(lib.tt_ce16_bwd_kept(U.data_ptr(), D, M, Nn, D, 0, lse16.data_ptr(), coef.data_ptr(), Z16.data_ptr(), M * Nn * 4,
                                          dI16.data_ptr(), D, ws16.data_ptr(), ws16n, N.stream()), "ce16 bwd")
 
+        dI16r = torch.empty(Nn, D, device=dev)
+
+        def fwd_du_nokeep_f16x2():  # the same forward, no logits written
+            N.check(lib.tt_ce16_fwd_du_keep(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, 0, lse16.data_ptr(), ce16.data_ptr(),
+                                            du16.data_ptr(), D, None, 0, ws16.data_ptr(), ws16n, N.stream()), "ce16 fwd")
+
+        def bwd_recompute_f16x2():  # logits tiles formed again on the fp16 pipe (images of the forward reused)
+            N.check(lib.tt_ce16_bwd_recompute(U.data_ptr(), D, I.data_ptr(), D, M, Nn, D, 0, lse16.data_ptr(), coef.data_ptr(),
+                                              dI16r.data_ptr(), D, ws16.data_ptr(), ws16n, 1, N.stream()), "ce16 bwd rc")
+
     fwd_du(); bwd_items(); fwd_du_keep(); bwd_kept()
     torch.cuda.synchronize()
     if have16:
         fwd_du_keep_f16x2(); bwd_kept_f16x2()
+        fwd_du_nokeep_f16x2(); bwd_recompute_f16x2()
         torch.cuda.synchronize()
+        print(f"M={M} N={Nn}: split-fp16 dI with recomputed logits vs with kept logits: {float((dI16r - dI16).abs().max() / dI16.abs().max()):.2e} (rel to max)", flush=True)
         print(f"M={M} N={Nn}: split-fp16 pair vs the fp32-MFMA pair: lse {float((lse16 - lse).abs().max()):.2e} abs, "
               f"du_unit {float((du16 - du_unit).abs().max() / du_unit.abs().max()):.2e}, "
               f"dI {float((dI16 - dI2).abs().max() / dI2.abs().max()):.2e} (rel to max)", flush=True)
@@ -83,7 +95,9 @@ for M, Nn in shapes:
                              ("fwd_du", fwd_du, 4.0 * M * Nn * D), ("bwd_items", bwd_items, 4.0 * M * Nn * D),
                              ("fwd_du_keep", fwd_du_keep, 4.0 * M * Nn * D), ("bwd_kept", bwd_kept, 2.0 * M * Nn * D))
                             + ((("fwd_du_keep_f16x2", fwd_du_keep_f16x2, 4.0 * M * Nn * D),
-                                ("bwd_kept_f16x2", bwd_kept_f16x2, 2.0 * M * Nn * D)) if have16 else ())):
+                                ("bwd_kept_f16x2", bwd_kept_f16x2, 2.0 * M * Nn * D),
+                                ("fwd_du_nokeep_f16x2", fwd_du_nokeep_f16x2, 4.0 * M * Nn * D),
+                                ("bwd_recompute_f16x2", bwd_recompute_f16x2, 4.0 * M * Nn * D)) if have16 else ())):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()

@@ -183,8 +183,9 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False,
             del U, I, Z, ws, dI, du
         roof = []
         for kname, fl, key in (("ce16_fwd_kernel" if split else "ce_fwd_du_kernel", fl_fwd, "ce_fwd_kernel"),
-                               ("ce16_bwd_items_kernel" if split else "ce_bwd_kept_kernel" if kept else "ce_bwd_kernel",
-                                2.0 * M * Nn * D if split else fl_bwd, "ce_bwd_kernel")):
+                               (("ce16_bwd_items_kernel" if sharded._CE16_KEEP else "ce16_bwd_items_rc_kernel") if split
+                                else "ce_bwd_kept_kernel" if kept else "ce_bwd_kernel",
+                                (2.0 if sharded._CE16_KEEP else 4.0) * M * Nn * D if split else fl_bwd, "ce_bwd_kernel")):
             avg_ms, launches = prof[key]
             if launches and split:
                 # every logit-sized product runs as THREE fp16 MFMA products: priced against the fp16 matrix-pipe peak on the
@@ -206,7 +207,7 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False,
             "what": f"ONE rank's kernels of the row-sharded step at W = {W} on one GPU: tables 1/{W} as thick, {W}x{B} in-batch "
                     "negatives per user, routed lookups; torch.distributed replaced by stand-ins that return tensors of the right "
                     "shape without moving data -- NOT a training run, the collectives' time comes on top",
-            "workload": workload, "world": W, "routing": trainer.routing, "kept_logits": kept,
+            "workload": workload, "world": W, "routing": trainer.routing, "kept_logits": (sharded._CE16_KEEP if split else kept),
             "dtype": "f32 (fp16x2 split: every logits product as three fp16 MFMA products of two-term splits, fp32 accumulate)" if split else "f32",
             **({"EXPLORATORY": "TT_CE_F16X2 -- not the default path, not the headline; parity: tests/test_gpu_kernels.py::"
                                "test_split_fp16_ce_pair_vs_float64, tests/test_gpu_sharded.py::test_world1_split_fp16_logits_match_oracle_at_unchanged_tolerances"}

@@ -56,6 +56,11 @@ while time.time() - t0 < budget:
                                         Z.data_ptr(), M * Nn * 4, ws.data_ptr(), wsn, N.stream()), "ce16 fwd")
         N.check(lib.tt_ce16_bwd_kept(Ug.data_ptr(), D, M, Nn, D, off, lse.data_ptr(), cg.data_ptr(), Z.data_ptr(), M * Nn * 4,
                                      dI.data_ptr(), D, ws.data_ptr(), wsn, N.stream()), "ce16 bwd")
+        dIr = e(Nn, D)  # the recomputing backward (no logits buffer), alternately trusting / re-forming the workspace images
+        N.check(lib.tt_ce16_fwd_du_keep(Ug.data_ptr(), D, Ig.data_ptr(), D, M, Nn, D, off, lse.data_ptr(), ce.data_ptr(), du.data_ptr(), D,
+                                        None, 0, ws.data_ptr(), wsn, N.stream()), "ce16 fwd (no logits)")
+        N.check(lib.tt_ce16_bwd_recompute(Ug.data_ptr(), D, Ig.data_ptr(), D, M, Nn, D, off, lse.data_ptr(), cg.data_ptr(), dIr.data_ptr(), D,
+                                          ws.data_ptr(), wsn, n % 2, N.stream()), "ce16 bwd recompute")
         wsp, wsn32 = ops._ws(DEV, lib.tt_inbatch_ce_workspace_bytes(M, Nn, D), "fuzz")
         lse32, ce32, du32, dI32 = e(M), e(M), e(M, D), e(Nn, D)
         zn = lib.tt_inbatch_ce_logits_bytes(M, Nn)
@@ -81,7 +86,7 @@ while time.time() - t0 < budget:
             msgs.append(f"logits {err(Zrm, S * 1.4426950408889634):.2e} (max |S| {smax:.2e})")
         if err(lse * 0.6931471805599453, ref_lse) > 2e-6 * max(1.0, float(ref_lse.abs().max())):
             msgs.append(f"lse {err(lse * 0.6931471805599453, ref_lse):.2e}")
-        for name, got, got32, ref in (("ce", ce, ce32, ref_ce), ("du_unit", du, du32, ref_du), ("dI", dI, dI32, ref_dI)):
+        for name, got, got32, ref in (("ce", ce, ce32, ref_ce), ("du_unit", du, du32, ref_du), ("dI", dI, dI32, ref_dI), ("dI recomputed", dIr, dI32, ref_dI)):
             e16, e32 = err(got, ref), err(got32, ref)
             if not e16 <= (16 if scale > 10 else 4) * e32 + 2e-6 * max(float(ref.abs().max()), 1e-30):
                 msgs.append(f"{name}: {e16:.2e} vs the fp32 pair's {e32:.2e} (max |ref| {float(ref.abs().max()):.2e})")

@@ -49,13 +49,13 @@ def hip_course(cfg, dense, batches, split, marks):
         init[TABLES[0]] = tr.users.weight.cpu().clone()
         init[TABLES[1]] = tr.items.weight.cpu().clone()
         losses, snaps, calls = [], {}, []
-        real = tr.be.lib.tt_ce16_bwd_kept
-        tr.be.lib.tt_ce16_bwd_kept = lambda *a: (calls.append(1), real(*a))[1]
+        real = tr.be.lib.tt_ce16_bwd_recompute
+        tr.be.lib.tt_ce16_bwd_recompute = lambda *a: (calls.append(1), real(*a))[1]
         for i, b in enumerate(batches(tr)):
             losses.append(float(tr.step(b)))
             if i + 1 in marks:
                 snaps[i + 1] = {TABLES[0]: tr.users.weight.cpu().double(), TABLES[1]: tr.items.weight.cpu().double()}
-        tr.be.lib.tt_ce16_bwd_kept = real
+        tr.be.lib.tt_ce16_bwd_recompute = real
         return init, losses, snaps, len(calls)
     finally:
         dist.destroy_process_group()

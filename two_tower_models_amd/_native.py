@@ -107,6 +107,7 @@ SIGNATURES = {
     "tt_ce16_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "tt_ce16_fwd_du_keep": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "tt_ce16_bwd_kept": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "tt_ce16_bwd_recompute": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _int, _vp]),
     "tt_scale_rows": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "tt_weighted_mean_loss": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tt_value_weights": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),

@@ -244,6 +244,7 @@ __device__ __forceinline__ void fwd_tile(const FwdStage* st, const u32x4 (&uh)[8
     tmax = fmaxf(tmax, v[e]);
   }
 #if !(TT_CE16_EXP & 1)
+  if (logit_row)  // (wave-uniform: null = the caller keeps no logits, tt_ce16_bwd_recompute forms them again)
 #if TT_CE16_EXP & (4 | 16 | 256)
   {  // the wave's 32 x 32 tile is one contiguous 4 KiB block of the logits buffer, row-major inside (see tt_hotpath.h)
     float* tile = logit_row + (item0 >> 5) * 1024 + 8 * 0 + 4 * h;
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(64 * C16_NW, 2) void ce16_fwd_kernel(const FwdArgs 
   // logits layout: [M / 32][N / 32] tiles of 32 users x 32 items, each 4 KiB contiguous and row-major inside -- the
   // forward writes whole tiles (row-major [M][N] meant 32-byte pieces in 32 rows 4 N bytes apart per store: 0.33 of the
   // kernel's 1.19 ms at N = 65536), the backward reads every tile as 16 coalesced 128-byte rows
-  float* logit_row = p.logits + ((user >> 5) * (p.N >> 5)) * 1024 + (user & 31) * 32;
+  float* logit_row = p.logits ? p.logits + ((user >> 5) * (p.N >> 5)) * 1024 + (user & 31) * 32 : nullptr;
 
   fwd_stage_dma(p, n0, &ring0, wave, lane);
   for (int tile = 0; tile < n_tiles; tile += 2) {  // two NAMED stages, unrolled by two (distinct LDS objects carry alias scopes)
@@ -450,8 +451,9 @@ __global__ __launch_bounds__(256) void ce16_merge_kernel(const float* __restrict
 // ---------------------------------------------------------------------------------------------------- backward, item side
 namespace {
 struct BwdArgs {
-  Images u;                     // users: th, tl used
-  const float* logits;          // [M][N] log2-domain
+  Images u;                     // users: th, tl used (recomputing form: h, l too)
+  Images it;                    // items: h, l (recomputing form only)
+  const float* logits;          // [M][N] log2-domain (kept form only)
   const float *row_lse, *coef;  // [M]
   int64_t M, N, diag_off;
   float* dI;
@@ -519,6 +521,73 @@ __device__ __forceinline__ void bwd_tile(const BwdStage* st, const float* stat, 
     __builtin_amdgcn_sched_barrier(0);
   }
 }
+
+// ---- the same tile WITHOUT kept logits: the 32 x 32 logits are formed again on the fp16 pipe -- 24 matrix instructions, the
+// user tile's row-major terms (a second pair of LDS images per stage) against the wave's items held as B fragments -- in the
+// register layout the kept form loads them in (lane = item, register e = user brow(e, h)).  At W = 8 the step with the split
+// pair is HBM-bound: 2.1 GB less written by the forward and 2.1 GB less read here.
+__device__ __forceinline__ void bwd_tile_rc(const FwdStage* st, const float* stat, const unsigned (&koff)[8], unsigned tbase, const u32x4 (&ih)[8],
+                                            const char* ilp, f32x16 (&acc)[4], float out_scale, int64_t user0, int64_t diag_user,
+                                            float gscale, int h) {
+  f32x16 sacc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const u32x4 ah = *reinterpret_cast<const u32x4*>(st->rm_h + koff[t]);
+    const u32x4 al = *reinterpret_cast<const u32x4*>(st->rm_l + koff[t]);
+    const u32x4 ilt = *reinterpret_cast<const u32x4*>(ilp + t * 1024);  // (the items' low terms live in the wave's LDS slice: 32 registers)
+    // rows = the tile's users (LDS), columns = this wave's items.  The three products in the FORWARD's order (item high x user
+    // high, item high x user low, item low x user high): the tile must come out bit for bit as the forward saw it -- the row's
+    // lse was formed from those values, and at logits of 1e4 a last-bit difference is 1e-3 in the exponent
+    sacc = MFMA16(ah, ih[t], sacc);
+    sacc = MFMA16(al, ih[t], sacc);
+    sacc = MFMA16(ah, ilt, sacc);
+  }
+  u32x4 gh[2], gl[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float lse[8], cf[8];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {  // users 8 (2 k + g) + 4 h + (0..3) = brow(8 k + 4 g + (0..3), h)
+      const float4 a = *reinterpret_cast<const float4*>(stat + 8 * (2 * k + g) + 4 * h);
+      const float4 b = *reinterpret_cast<const float4*>(stat + 32 + 8 * (2 * k + g) + 4 * h);
+      lse[4 * g] = a.x; lse[4 * g + 1] = a.y; lse[4 * g + 2] = a.z; lse[4 * g + 3] = a.w;
+      cf[4 * g] = b.x; cf[4 * g + 1] = b.y; cf[4 * g + 2] = b.z; cf[4 * g + 3] = b.w;
+    }
+    float gv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = 8 * k + q;
+      // the product ROUNDED, then the difference -- not one fma: the row's lse was formed from the rounded logits, and at
+      // logits of 1e4 the unrounded product is up to 1e-3 away from what the forward saw (tools/fuzz_ce16.py, scale 30)
+      float lg = sacc[e] * out_scale;
+      asm volatile("" : "+v"(lg));  // (keeps hipcc from contracting product and difference into one v_fma: __fmul_rn does not)
+      float pr = __builtin_amdgcn_exp2f(lg - lse[q]);
+      if (user0 + brow(e, h) == diag_user) pr -= 1.f;
+      gv[q] = pr * (cf[q] * gscale);
+    }
+    split8(gv, gh[k], gl[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const u32x4 th = *reinterpret_cast<const u32x4*>(st->tr_h + tbase + (k * 4096 + b * 512));
+      const u32x4 tl = *reinterpret_cast<const u32x4*>(st->tr_l + tbase + (k * 4096 + b * 512));
+      acc[b] = MFMA16(th, gh[k], acc[b]);
+      acc[b] = MFMA16(th, gl[k], acc[b]);
+      acc[b] = MFMA16(tl, gh[k], acc[b]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+__device__ __forceinline__ void bwd_stage_dma_rc(const BwdArgs& p, int64_t user0, FwdStage* st, int wave, int lane) {
+  dma_rowmajor(p.u.h + user0 * C16_D, st->rm_h, wave, lane);
+  dma_rowmajor(p.u.l + user0 * C16_D, st->rm_l, wave, lane);
+  dma_linear(p.u.th + user0 * C16_D, st->tr_h, wave, lane);
+  dma_linear(p.u.tl + user0 * C16_D, st->tr_l, wave, lane);
+}
 }  // namespace
 
 // SPLIT: the users are cut into p.n_splits ranges (blockIdx.y), partial results; otherwise one workgroup streams all of them
@@ -584,6 +653,77 @@ __global__ __launch_bounds__(64 * C16_NW, 2) void ce16_bwd_items_kernel(const Bw
       *reinterpret_cast<float4*>(out + b * 32 + 8 * g + 4 * h) =
           make_float4(acc[b][4 * g] * inv, acc[b][4 * g + 1] * inv, acc[b][4 * g + 2] * inv, acc[b][4 * g + 3] * inv);
 }
+
+template <bool SPLIT>
+__global__ __launch_bounds__(64 * C16_NW, 2) void ce16_bwd_items_rc_kernel(const BwdArgs p) {
+  __shared__ __attribute__((aligned(1024))) FwdStage ring0;
+  __shared__ __attribute__((aligned(1024))) FwdStage ring1;
+  __shared__ __attribute__((aligned(16))) float stat0[64];
+  __shared__ __attribute__((aligned(16))) float stat1[64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int64_t item = (int64_t)blockIdx.x * C16_ROWS_WG + wave * 32 + r;
+  const int64_t diag_user = item - p.diag_off;
+  const int tiles_all = (int)(p.M / C16_TILE), per = SPLIT ? (tiles_all + p.n_splits - 1) / p.n_splits : tiles_all;
+  const int tile0 = SPLIT ? blockIdx.y * per : 0;
+  const int n_tiles = SPLIT ? (tile0 + per < tiles_all ? tile0 + per : tiles_all) - tile0 : tiles_all;
+  const float gscale = scale_for(p.absmax[2]);
+  const float out_scale = LOG2E / (scale_for(p.absmax[0]) * scale_for(p.absmax[1]));
+  unsigned koff[8];  // the lane's LDS offsets inside a stage, computed once (else hipcc keeps a set per stage)
+#pragma unroll
+  for (int t = 0; t < 8; ++t) koff[t] = (unsigned)(r * C16_ROW_B + ((2 * t + h) ^ (r & 15)) * 16);
+  const unsigned tbase = (unsigned)(h * 2048 + r * 16);
+  // this lane's item as B fragments (8 consecutive d per k-group): the high terms in registers, the low terms in the wave's own
+  // 8-KiB LDS slice (acc + both terms = 192 registers left no room for the tile's work: spills inside the loop)
+  __shared__ __attribute__((aligned(1024))) char ilfrag[C16_NW][8192];
+  char* ilp = ilfrag[wave] + lane * 16;
+  u32x4 ih[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    ih[t] = *reinterpret_cast<const u32x4*>(p.it.h + item * C16_D + 16 * t + 8 * h);
+    *reinterpret_cast<u32x4*>(ilp + t * 1024) = *reinterpret_cast<const u32x4*>(p.it.l + item * C16_D + 16 * t + 8 * h);
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+  float sv0 = 0.f, sv1 = 0.f;
+  const int64_t ubase = (int64_t)tile0 * C16_TILE;
+  if (n_tiles > 0) {
+    bwd_stage_dma_rc(p, ubase, &ring0, wave, lane);
+    if (wave == 0) sv0 = (lane < 32 ? p.row_lse : p.coef)[ubase + (lane & 31)];
+  }
+  for (int tile = 0; tile < n_tiles; tile += 2) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    if (wave == 0) stat0[lane] = sv0;
+    __syncthreads();
+    if (tile + 1 < n_tiles) {
+      const int64_t u1 = ubase + (int64_t)(tile + 1) * C16_TILE;
+      bwd_stage_dma_rc(p, u1, &ring1, wave, lane);
+      if (wave == 0) sv1 = (lane < 32 ? p.row_lse : p.coef)[u1 + (lane & 31)];
+    }
+    bwd_tile_rc(&ring0, stat0, koff, tbase, ih, ilp, acc, out_scale, ubase + (int64_t)tile * C16_TILE, diag_user, gscale, h);
+    if (tile + 1 >= n_tiles) break;
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    if (wave == 0) stat1[lane] = sv1;
+    __syncthreads();
+    if (tile + 2 < n_tiles) {
+      const int64_t u2 = ubase + (int64_t)(tile + 2) * C16_TILE;
+      bwd_stage_dma_rc(p, u2, &ring0, wave, lane);
+      if (wave == 0) sv0 = (lane < 32 ? p.row_lse : p.coef)[u2 + (lane & 31)];
+    }
+    bwd_tile_rc(&ring1, stat1, koff, tbase, ih, ilp, acc, out_scale, ubase + (int64_t)(tile + 1) * C16_TILE, diag_user, gscale, h);
+  }
+  const float inv = 1.f / (gscale * scale_for(p.absmax[0]));
+  float* out = SPLIT ? p.part + ((int64_t)blockIdx.y * p.N + item) * C16_D : p.dI + item * p.lddi;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(out + b * 32 + 8 * g + 4 * h) =
+          make_float4(acc[b][4 * g] * inv, acc[b][4 * g + 1] * inv, acc[b][4 * g + 2] * inv, acc[b][4 * g + 3] * inv);
+}
+
 
 // dI[i][:] = sum over user splits of part[s][i][:], in split order (deterministic)
 __global__ __launch_bounds__(256) void ce16_bwd_reduce_kernel(const float* __restrict__ part, int n_splits, int64_t N, float* __restrict__ dI,
@@ -661,7 +801,7 @@ extern "C" int64_t tt_ce16_workspace_bytes(int64_t M, int64_t N, int64_t D) {
 extern "C" int tt_ce16_fwd_du_keep(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N, int64_t D,
                                    int64_t diag_offset, float* row_lse, float* row_ce, float* du_unit, int64_t ld_du, float* logits,
                                    int64_t logits_bytes, void* ws, int64_t ws_bytes, tt_stream_t stream) {
-  if (!U || !I || !row_lse || !row_ce || !du_unit || !logits || !ws) return fail_arg("tt_ce16_fwd_du_keep: null pointer");
+  if (!U || !I || !row_lse || !row_ce || !du_unit || !ws) return fail_arg("tt_ce16_fwd_du_keep: null pointer");
   if (!tt_ce16_supported(M, N, D)) {
     set_error("tt_ce16_fwd_du_keep: needs D = 128, M %% 256 == 0, N %% 1024 == 0");
     return TT_E_UNSUPPORTED;
@@ -669,7 +809,7 @@ extern "C" int tt_ce16_fwd_du_keep(const float* U, int64_t ldu, const float* I, 
   if (ldu < D || ldi < D || ld_du < D || (ldu | ldi | ld_du) % 4 || ((uintptr_t)U | (uintptr_t)I | (uintptr_t)du_unit) % 16)
     return fail_arg("tt_ce16_fwd_du_keep: rows must be 16-byte aligned");
   if (diag_offset < 0 || diag_offset + M > N) return fail_arg("tt_ce16_fwd_du_keep: diagonal outside the item range");
-  if (logits_bytes < M * N * (int64_t)sizeof(float)) return fail_arg("tt_ce16_fwd_du_keep: logits buffer");
+  if (logits && logits_bytes < M * N * (int64_t)sizeof(float)) return fail_arg("tt_ce16_fwd_du_keep: logits buffer");
   if (ws_bytes < tt_ce16_workspace_bytes(M, N, D)) {
     set_error("tt_ce16_fwd_du_keep: workspace");
     return TT_E_WORKSPACE;
@@ -727,6 +867,50 @@ extern "C" int tt_ce16_bwd_kept(const float* U, int64_t ldu, int64_t M, int64_t 
     else hipLaunchKernelGGL(ce16_bwd_items_kernel<false>, dim3((unsigned)(N / C16_ROWS_WG)), dim3(64 * C16_NW), 0, st, a);
   }
   if (int rc = check_launch("ce16_bwd_items_kernel")) return rc;
+  if (a.n_splits > 1) {
+    hipLaunchKernelGGL(ce16_bwd_reduce_kernel, dim3((unsigned)ceil_div(N * (C16_D / 4), 256)), dim3(256), 0, st, w.part, a.n_splits, N, dI, lddi);
+    return check_launch("ce16_bwd_reduce_kernel");
+  }
+  return 0;
+}
+
+extern "C" int tt_ce16_bwd_recompute(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N, int64_t D,
+                                     int64_t diag_offset, const float* row_lse, const float* coef, float* dI, int64_t lddi, void* ws,
+                                     int64_t ws_bytes, int reuse_images, tt_stream_t stream) {
+  if (!U || !I || !row_lse || !coef || !dI || !ws) return fail_arg("tt_ce16_bwd_recompute: null pointer");
+  if (!tt_ce16_supported(M, N, D)) {
+    set_error("tt_ce16_bwd_recompute: needs D = 128, M %% 256 == 0, N %% 1024 == 0");
+    return TT_E_UNSUPPORTED;
+  }
+  if (ldu < D || ldi < D || lddi < D || (ldu | ldi | lddi) % 4 || ((uintptr_t)U | (uintptr_t)I | (uintptr_t)dI) % 16)
+    return fail_arg("tt_ce16_bwd_recompute: rows must be 16-byte aligned");
+  if (ws_bytes < tt_ce16_workspace_bytes(M, N, D)) {
+    set_error("tt_ce16_bwd_recompute: workspace");
+    return TT_E_WORKSPACE;
+  }
+  hipStream_t st = S(stream);
+  Ws w;
+  carve(ws, M, N, &w);
+  if (reuse_images) {  // the workspace still holds the forward's images and scales of THESE operands (the caller's promise)
+    if (hipMemsetAsync(w.absmax + 2, 0, 4, st) != hipSuccess) return check_launch("hipMemsetAsync");
+  } else {
+    if (hipMemsetAsync(w.absmax, 0, 256, st) != hipSuccess) return check_launch("hipMemsetAsync");
+    if (int rc = split_matrix(U, ldu, M, w.absmax, w.u, st)) return rc;
+    if (int rc = split_matrix(I, ldi, N, w.absmax + 1, w.it, st)) return rc;
+  }
+  hipLaunchKernelGGL(ce16_absmax_vec_kernel, dim3((unsigned)(M / 256 < 64 ? ceil_div(M, 256) : 64)), dim3(256), 0, st, coef, M, w.absmax + 2);
+  if (int rc = check_launch("ce16_absmax_vec_kernel")) return rc;
+  BwdArgs a;
+  a.u = w.u; a.it = w.it; a.logits = nullptr; a.row_lse = row_lse; a.coef = coef; a.M = M; a.N = N; a.diag_off = diag_offset; a.dI = dI; a.lddi = lddi;
+  a.absmax = w.absmax;
+  a.n_splits = pick_bwd_splits(M, N);
+  a.part = w.part;
+  {
+    ProfScope prof("ce_bwd_kernel", st);
+    if (a.n_splits > 1) hipLaunchKernelGGL(ce16_bwd_items_rc_kernel<true>, dim3((unsigned)(N / C16_ROWS_WG), (unsigned)a.n_splits), dim3(64 * C16_NW), 0, st, a);
+    else hipLaunchKernelGGL(ce16_bwd_items_rc_kernel<false>, dim3((unsigned)(N / C16_ROWS_WG)), dim3(64 * C16_NW), 0, st, a);
+  }
+  if (int rc = check_launch("ce16_bwd_items_rc_kernel")) return rc;
   if (a.n_splits > 1) {
     hipLaunchKernelGGL(ce16_bwd_reduce_kernel, dim3((unsigned)ceil_div(N * (C16_D / 4), 256)), dim3(256), 0, st, w.part, a.n_splits, N, dI, lddi);
     return check_launch("ce16_bwd_reduce_kernel");

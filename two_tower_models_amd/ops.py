@@ -673,9 +673,11 @@ class InBatchSoftmaxCE(torch.autograd.Function):
                 and 0 <= diag_offset <= Nn - M:
             du_unit = torch.empty(M, D, dtype=torch.float32, device=dev)
             w16p, w16n = _ws(dev, lib.tt_ce16_workspace_bytes(M, Nn, D), "ce16")
-            ctx.kept16 = torch.empty(M * Nn, dtype=torch.float32, device=dev)
+            # no logits buffer unless asked for (TT_CE16_KEEP, the pair's first form): the backward forms the tiles again
+            ctx.kept16 = torch.empty(M * Nn, dtype=torch.float32, device=dev) if _CE16_KEEP else True
             N.check(lib.tt_ce16_fwd_du_keep(pu, D, pi, D, M, Nn, D, diag_offset, lse.data_ptr(), ce.data_ptr(), du_unit.data_ptr(), D,
-                                            ctx.kept16.data_ptr(), M * Nn * 4, w16p, w16n, N.stream()), "tt_ce16_fwd_du_keep")
+                                            ctx.kept16.data_ptr() if _CE16_KEEP else None, M * Nn * 4 if _CE16_KEEP else 0, w16p, w16n,
+                                            N.stream()), "tt_ce16_fwd_du_keep")
             ctx.save_for_backward(U, I, lse, du_unit)
             return ce
         if ctx.needs_input_grad[0] and _FUSED_DU:
@@ -727,8 +729,12 @@ class InBatchSoftmaxCE(torch.autograd.Function):
         pi, _, _, ldi = _f32_2d(I, "I")
         if ctx.kept16 is not None:  # the split-fp16 pair's backward
             w16p, w16n = _ws(dev, lib.tt_ce16_workspace_bytes(M, Nn, D), "ce16")
-            N.check(lib.tt_ce16_bwd_kept(pu, D, M, Nn, D, ctx.diag_offset, lse.data_ptr(), coef.data_ptr(), ctx.kept16.data_ptr(),
-                                         M * Nn * 4, dI.data_ptr(), D, w16p, w16n, N.stream()), "tt_ce16_bwd_kept")
+            if ctx.kept16 is True:  # (images formed again: other products may have used the workspace slot since the forward)
+                N.check(lib.tt_ce16_bwd_recompute(pu, D, pi, D, M, Nn, D, ctx.diag_offset, lse.data_ptr(), coef.data_ptr(), dI.data_ptr(), D,
+                                                  w16p, w16n, 0, N.stream()), "tt_ce16_bwd_recompute")
+            else:
+                N.check(lib.tt_ce16_bwd_kept(pu, D, M, Nn, D, ctx.diag_offset, lse.data_ptr(), coef.data_ptr(), ctx.kept16.data_ptr(),
+                                             M * Nn * 4, dI.data_ptr(), D, w16p, w16n, N.stream()), "tt_ce16_bwd_kept")
             ctx.kept16 = None
             return dU, dI, None, None
         if ctx.kept is not None:  # item side from the logits the forward kept
@@ -794,6 +800,7 @@ class WeightedMeanLoss(torch.autograd.Function):
 _FUSED_LOSS = os.environ.get("TT_CE_NO_FUSED_LOSS") is None  # A/B switch
 # EXPLORATORY: InBatchSoftmaxCE through the split-fp16 pair (csrc/ce_f16x2.hip) where its shapes allow
 # (D = 128, M % 256 == 0, N % 1024 == 0, contiguous rows) -- fp32-grade results on the fp16 matrix pipe.  Never the default.
+_CE16_KEEP = os.environ.get("TT_CE16_KEEP") is not None  # A/B: the split-fp16 pair with kept logits (its first form)
 _CE_F16X2 = os.environ.get("TT_CE_F16X2") is not None
 
 

@@ -140,6 +140,7 @@ _UTOWER_EARLY = os.environ.get("TT_SHARDED_EARLY_UTOWER") is not None
 _LOSS_KERNELS = os.environ.get("TT_SHARDED_TORCH_LOSS") is None  # A/B: the value-weight tail as two kernels
 _WGRAD_ASIDE = os.environ.get("TT_SHARDED_WGRAD_MAIN") is None  # A/B: tower weight gradients on the third stream
 _CE_F16X2 = os.environ.get("TT_CE_F16X2") is not None  # exploratory: split-fp16 logits kernels (HipBackend.ce_fwd)
+_CE16_KEEP = os.environ.get("TT_CE16_KEEP") is not None  # A/B: that pair with kept logits (its first form) instead of recomputed ones
 # Opt-in (TT_SHARDED_PLAN_ASIDE=1): the NEXT batch's route plan (owner histogram + scan per lookup, the MAX all-reduce
 # of the bucket sizes, their copy to the host) on the library's third stream at the very top of the step instead of on
 # the main stream after the lookups -- eight small launches leave the critical path: emulated W = 8 step 4.09 -> 4.05 ms
@@ -547,10 +548,16 @@ class HipBackend:
             # EXPLORATORY (TT_CE_F16X2=1): the same pair on the 16-bit matrix pipe, every product as three fp16 MFMA products
             # of two-term splits -- fp32-grade results (csrc/ce_f16x2.hip), about half the time of the fp32-MFMA pair
             w16p, w16n = ops._ws(self.device, lib.tt_ce16_workspace_bytes(M, Nn, D), "ce16")
-            self._kept16 = torch.empty(M * Nn, dtype=torch.float32, device=self.device)
+            if _CE16_KEEP:
+                self._kept16 = torch.empty(M * Nn, dtype=torch.float32, device=self.device)
+                zp, zn = self._kept16.data_ptr(), M * Nn * 4
+            else:
+                # no logits buffer: on the fp16 pipe forming a tile again is cheaper than 8 bytes of HBM traffic per logit,
+                # and the step with this pair is HBM-bound.  The backward reuses the images this call
+                # leaves in the "ce16" workspace slot -- nothing else in the step touches that slot.
+                self._kept16, zp, zn = (w16p, w16n), None, 0
             N.check(lib.tt_ce16_fwd_du_keep(U.data_ptr(), D, I_all.data_ptr(), D, M, Nn, D, off, lse.data_ptr(), ce.data_ptr(),
-                                            self._du_unit.data_ptr(), D, self._kept16.data_ptr(), M * Nn * 4, w16p, w16n,
-                                            N.stream()), "tt_ce16_fwd_du_keep")
+                                            self._du_unit.data_ptr(), D, zp, zn, w16p, w16n, N.stream()), "tt_ce16_fwd_du_keep")
             return ce, lse
         if self.keep_logits and ops.kept_logits_supported(U, I_all):
             # wide negative sets: the logits are written out once and read back by the item-side
@@ -583,8 +590,13 @@ class HipBackend:
         dU = self.ce_du(coef) if want_du else None
         if self._kept16 is not None:
             w16p, w16n = ops._ws(self.device, lib.tt_ce16_workspace_bytes(M, Nn, D), "ce16")
-            N.check(lib.tt_ce16_bwd_kept(U.data_ptr(), D, M, Nn, D, off, lse.data_ptr(), coef.data_ptr(), self._kept16.data_ptr(),
-                                         M * Nn * 4, dI.data_ptr(), D, w16p, w16n, N.stream()), "tt_ce16_bwd_kept")
+            if isinstance(self._kept16, tuple):
+                same = self._kept16 == (w16p, w16n)  # (the slot was not re-allocated in between: the forward's images are there)
+                N.check(lib.tt_ce16_bwd_recompute(U.data_ptr(), D, I_all.data_ptr(), D, M, Nn, D, off, lse.data_ptr(), coef.data_ptr(),
+                                                  dI.data_ptr(), D, w16p, w16n, 1 if same else 0, N.stream()), "tt_ce16_bwd_recompute")
+            else:
+                N.check(lib.tt_ce16_bwd_kept(U.data_ptr(), D, M, Nn, D, off, lse.data_ptr(), coef.data_ptr(), self._kept16.data_ptr(),
+                                             M * Nn * 4, dI.data_ptr(), D, w16p, w16n, N.stream()), "tt_ce16_bwd_kept")
             self._kept16 = None
             return dU, dI
         wsp, wsn = ops._ws(self.device, lib.tt_inbatch_ce_workspace_bytes(M, Nn, D))
