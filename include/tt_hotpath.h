@@ -209,7 +209,7 @@ int tt_ce16_bwd_kept(const float* U, int64_t ldu, int64_t M, int64_t N, int64_t 
                      int64_t lddi, void* ws, int64_t ws_bytes, tt_stream_t stream);
 /* The same backward WITHOUT kept logits: tt_ce16_fwd_du_keep accepts logits = NULL (nothing is written), and this call
  * forms every 32 x 32 logits tile again on the fp16 pipe (24 more matrix instructions per tile) instead of reading it
- * back -- 2 * 4 * M * N bytes of HBM traffic less per step, which is what the W = 8 step with this pair is bound by
+ * back -- 2 * 4 * M * N bytes of HBM traffic less per step, half of what the W = 8 step with this pair moved
  * (DESIGN section 5).  Needs the item rows as well.  reuse_images != 0: `ws` still holds the images and scales the
  * forward call formed from THESE U and I (nothing else touched it) -- they are not formed again. */
 int tt_ce16_bwd_recompute(const float* U, int64_t ldu, const float* I, int64_t ldi, int64_t M, int64_t N, int64_t D,

@@ -525,7 +525,7 @@ __device__ __forceinline__ void bwd_tile(const BwdStage* st, const float* stat, 
 // ---- the same tile WITHOUT kept logits: the 32 x 32 logits are formed again on the fp16 pipe -- 24 matrix instructions, the
 // user tile's row-major terms (a second pair of LDS images per stage) against the wave's items held as B fragments -- in the
 // register layout the kept form loads them in (lane = item, register e = user brow(e, h)).  At W = 8 the step with the split
-// pair is HBM-bound: 2.1 GB less written by the forward and 2.1 GB less read here.
+// pair moved half of its HBM bytes as kept logits: 2.1 GB less written by the forward, 2.1 GB less read here.
 __device__ __forceinline__ void bwd_tile_rc(const FwdStage* st, const float* stat, const unsigned (&koff)[8], unsigned tbase, const u32x4 (&ih)[8],
                                             const char* ilp, f32x16 (&acc)[4], float out_scale, int64_t user0, int64_t diag_user,
                                             float gscale, int h) {

@@ -553,7 +553,7 @@ class HipBackend:
                 zp, zn = self._kept16.data_ptr(), M * Nn * 4
             else:
                 # no logits buffer: on the fp16 pipe forming a tile again is cheaper than 8 bytes of HBM traffic per logit,
-                # and the step with this pair is HBM-bound.  The backward reuses the images this call
+                # and half of this step's HBM traffic was the logits going out and coming back.  The backward reuses the images this call
                 # leaves in the "ce16" workspace slot -- nothing else in the step touches that slot.
                 self._kept16, zp, zn = (w16p, w16n), None, 0
             N.check(lib.tt_ce16_fwd_du_keep(U.data_ptr(), D, I_all.data_ptr(), D, M, Nn, D, off, lse.data_ptr(), ce.data_ptr(),
