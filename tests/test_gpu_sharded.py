@@ -52,27 +52,29 @@ def test_world1_hip_backend_matches_oracle(cfg):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("split", [False, True, "kept"])
 def test_world1_split_fp16_logits_match_oracle_at_unchanged_tolerances(monkeypatch, split):
     """TT_CE_F16X2 (exploratory): the trainer with the split-fp16 logits pair (csrc/ce_f16x2.hip) against the oracle's train
     steps at the SAME criterion as the fp32-MFMA pair (split = False runs that one through the identical assertions) --
     loss 1e-4, tables and dense parameters 5e-6 after three Adam steps -- at a shape the pair takes (B = 1024, D = 128),
-    and the pair is what ran."""
+    and the pair is what ran (split = True: its default form, no logits buffer; "kept": its first form, TT_CE16_KEEP)."""
     import torch.distributed as dist
     from oracle import cpu_ref as R
     from test_sharded_cpu import _dense_init
     from two_tower_models_amd import sharded
     cfg = dict(n_users=3000, n_items=5000, D=128, F=8, B=1024, H=2)
     dev = torch.device("cuda:0")
-    monkeypatch.setattr(sharded, "_CE_F16X2", split)
+    monkeypatch.setattr(sharded, "_CE_F16X2", bool(split))
+    monkeypatch.setattr(sharded, "_CE16_KEEP", split == "kept")
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
                             device_id=dev)
     try:
         dense = _dense_init(cfg)
         tr = sharded.ShardedTrainer(cfg, dev, negatives="global", user_value_weights=(0.7,), dense_init=dense)
         calls = []
-        real = tr.be.lib.tt_ce16_bwd_recompute  # (the pair's default form keeps no logits; TT_CE16_KEEP = its first form)
-        monkeypatch.setattr(tr.be.lib, "tt_ce16_bwd_recompute", lambda *a: (calls.append(1), real(*a))[1])
+        which = "tt_ce16_bwd_kept" if split == "kept" else "tt_ce16_bwd_recompute"
+        real = getattr(tr.be.lib, which)
+        monkeypatch.setattr(tr.be.lib, which, lambda *a: (calls.append(1), real(*a))[1])
         params = dict(_dense_init(cfg))
         params["user_id_embedding_arch.weight"] = tr.users.weight.cpu().clone()
         params["item_id_embedding_arch.weight"] = tr.items.weight.cpu().clone()
