@@ -71,9 +71,9 @@ def make_batches(cfg, n, device, seed=1234):
     return out
 
 
-def build_model(cfg, device):
+def build_model(cfg, device, seed=0):
     import two_tower_models_amd as A
-    torch.manual_seed(0)
+    torch.manual_seed(seed)
     with torch.device(device):  # initialise the 5.6 GB of tables directly in HBM
         mips = A.BaselineMIPSModule(corpus_size=1024, embedding_dim=cfg["D"])
         kw = dict(num_items=10, user_id_hash_size=cfg["n_users"], user_id_embedding_dim=cfg["D"],
@@ -229,11 +229,87 @@ def cpu_baseline_mips(corpus_cpu, K, n_queries=64):
                       f"{threads} threads, {dt:.1f} s"}
 
 
+def build_sharded(cfg, device, rank):
+    """The workload's model as THIS rank's member of a row-sharded group (parallel.row_sharded: each table's block is
+    born on its owner, never whole) + its optimiser; replicated parameters are rank 0's."""
+    import two_tower_models_amd as A
+    from two_tower_models_amd import parallel
+    with parallel.row_sharded():
+        model = build_model(cfg, device, seed=1000 + rank)  # (different rows on every rank; dense: broadcast below)
+    parallel.shard_model_(model)
+    opt = A.DenseExactAdam(model.parameters(), lr=1e-3)  # row-sharded tables: the forward-announced dense-exact schedule
+    return model, opt
+
+
+def sharded_step_fn(model, opt, total_loss, watchdog=None):
+    """The reference loop body (ref:train/train.py:112-125) + the announcement of the NEXT batch's lookups."""
+    from two_tower_models_amd import parallel
+
+    def step(batch, nxt=None):
+        loss = model.train_forward(*batch)
+        if nxt is not None:  # the next batch's routes are planned underneath this step (no host wait)
+            parallel.plan_ahead(model._lookup_plan(nxt[0], nxt[2], nxt[3]))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        total_loss.add_(loss.detach())
+        if watchdog is not None:
+            watchdog.mark()
+
+    return step
+
+
+def sharded_check(device, rank, world, steps=3):
+    """`--check`: the first contact of a new node with the sharded path, made boring.  Every rank builds the SAME small
+    model (seeded), keeps its row blocks, and runs `steps` train steps on its own batch; rank 0 then repeats the steps on
+    the CONCATENATED batches through the single-process module path (the path tests/ pin to the oracle).  The W-rank losses
+    must equal the 1-rank losses to 1e-4 (the north star's loss tolerance)."""
+    import two_tower_models_amd as A
+    from two_tower_models_amd import parallel
+    cfg = dict(n_users=4096, n_items=8192, D=128, F=8, B=256, H=4, model="base")
+
+    def whole():
+        model = build_model(cfg, "cpu", seed=7)
+        with torch.no_grad():  # logits O(1): differences show up in the loss, not in saturation
+            for n, p in model.named_parameters():
+                p.mul_(0.5 if n.endswith("embedding_arch.weight") else 0.5 if n.endswith("tower_arch.weight") else 1.0)
+        return model.to(device)
+
+    per_rank = [make_batches(cfg, steps, "cpu", seed=77 + 1000 * r) for r in range(world)]
+    model = parallel.shard_model_(whole())
+    opt = A.DenseExactAdam(model.parameters(), lr=1e-3)
+    got = []
+    for s_ in range(steps):
+        loss = model.train_forward(*[t.to(device) for t in per_rank[rank][s_]])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        got.append(float(loss))
+    del model, opt
+    out = {"ok": True, "steps": steps, "shape": cfg, "sharded_losses": got}
+    if rank == 0:
+        single = whole()
+        opt1 = A.DenseExactAdam(single.parameters(), lr=1e-3)
+        want = []
+        for s_ in range(steps):
+            cat = [torch.cat([per_rank[r][s_][k] for r in range(world)]).to(device) for k in range(7)]
+            loss = single.train_forward(*cat)
+            opt1.zero_grad()
+            loss.backward()
+            opt1.step()
+            want.append(float(loss))
+        err = max(abs(a - b) for a, b in zip(got, want))
+        out.update(single_process_losses=want, max_abs_diff=err, ok=bool(err < 1e-4))
+    flag = torch.tensor([1.0 if out["ok"] else 0.0], device=device)
+    parallel.C.broadcast_(flag, src=0)
+    out["ok"] = bool(flag.item() > 0.5)
+    return out
+
+
 def _timed_sharded_w1(device, steps=20, warmup=5):
-    """The row-sharded trainer at W = 1 over RCCL (`bench.py --sharded --gpus 1`) at the P shapes: the N = 1 point the
-    scaling curve starts from must equal the module-path headline (tests/test_gpu_bench_contract.py holds it to 3 %)."""
+    """The row-sharded module path at W = 1 over RCCL (`bench.py --sharded --gpus 1`) at the P shapes: the N = 1 point the
+    scaling curve starts from must equal the single-GPU headline (tests/test_gpu_bench_contract.py holds it to 3 %)."""
     import torch.distributed as dist
-    from two_tower_models_amd import sharded
     if dist.is_initialized():
         raise RuntimeError("a process group is already up")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -242,20 +318,23 @@ def _timed_sharded_w1(device, steps=20, warmup=5):
     dist.init_process_group("nccl", device_id=device)
     try:
         cfg = dict(WORKLOADS["P"])
-        trainer = sharded.ShardedTrainer(cfg, device)
-        batches = trainer.make_batches(16)
+        model, opt = build_sharded(cfg, device, 0)
+        batches = make_batches(cfg, 16, device)
+        total = torch.zeros((), device=device)
+        step = sharded_step_fn(model, opt, total)
         for i in range(warmup):
-            trainer.step(batches[i % 16], batches[(i + 1) % 16])
+            step(batches[i % 16], batches[(i + 1) % 16])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            trainer.step(batches[(warmup + i) % 16], batches[(warmup + i + 1) % 16])
+            step(batches[(warmup + i) % 16], batches[(warmup + i + 1) % 16])
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        out = {"workload": "P through ShardedTrainer, world size 1, RCCL process group (the N = 1 point of the scaling curve)",
+        out = {"workload": "P through the row-sharded MODULE path (parallel.row_sharded + TwoTowerBaseRetrieval + DenseExactAdam), "
+                           "world size 1, RCCL process group (the N = 1 point of the scaling curve)",
                "pairs_per_s": round(cfg["B"] * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
-               "warmup": warmup, "routing": trainer.routing, "transport": trainer.transport}
-        del trainer, batches
+               "warmup": warmup}
+        del model, opt, batches, step
     finally:
         dist.destroy_process_group()
     return out
@@ -536,15 +615,18 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` object (C2 / C3 / deferred-Adam train steps, config 5 MIPS) the default "
                          "single-GPU P run appends")
-    ap.add_argument("--negatives", default="global", choices=["global", "local"])
     ap.add_argument("--overlap", default="forward", choices=["forward", "zero_grad", "off"],
                     help="when DenseExactAdam starts the table sweep (optim.py); all three are bit-identical")
-    ap.add_argument("--sharded", action="store_true", help="use the row-sharded trainer even at --gpus 1")
-    ap.add_argument("--routing", default=None, choices=["alltoall", "allgather"],
-                    help="sharded lookups: padded all-to-all to the owning ranks (default) or round 1's all-gather scheme")
-    ap.add_argument("--transport", default=None, choices=["torch", "native"],
+    ap.add_argument("--sharded", action="store_true", help="use the row-sharded module path even at --gpus 1")
+    ap.add_argument("--transport", default="torch", choices=["torch", "native"],
                     help="sharded collectives through torch.distributed's process group (default) or the C ABI's "
                          "tt_comm_* (RCCL bound by libtt_hotpath.so)")
+    ap.add_argument("--check", action="store_true",
+                    help="sharded runs: before the timed run, 3 steps at a small shape on all ranks; rank 0 repeats them on "
+                         "the concatenated batch through the single-process module path and the losses must agree (1e-4)")
+    ap.add_argument("--watchdog", type=float, default=30.0,
+                    help="sharded runs: seconds without a completed step before the run is ended with the list of "
+                         "exchanges in flight (0 = off)")
     ap.add_argument("--fresh-ids", action="store_true",
                     help="draw new uniform user / item ids on the device every step instead of cycling 16 batches "
                          "(the deferred schedule's steady state: every lookup hits rows that idled for ~N/B steps)")
@@ -582,9 +664,10 @@ def main():
     n_ranks, dist_backend_seen = 1, None
     if use_sharded and (args.adam != "dense" or args.fresh_ids or args.phase != "step"):
         raise SystemExit("--adam lazy / --fresh-ids / --phase apply to the single-GPU module path")
+    check = watchdog = None
     if use_sharded:
         import torch.distributed as dist
-        from two_tower_models_amd import sharded
+        from two_tower_models_amd import collectives, parallel
         if "MASTER_ADDR" not in os.environ:  # plain `python bench.py --sharded`
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         if dist_backend == "nccl":
@@ -592,12 +675,23 @@ def main():
         else:
             dist.init_process_group(dist_backend)
         n_ranks, dist_backend_seen = dist.get_world_size(), dist.get_backend()
-        trainer = sharded.ShardedTrainer(cfg, device, negatives=args.negatives, routing=args.routing,
-                                         transport=args.transport)  # cfg['model'] selects base / hist
-        batches = trainer.make_batches(16)
-
-        def step(batch, nxt=None):  # the next batch's routes are planned underneath this step (no host wait)
-            trainer.step(batch, nxt)
+        if args.transport == "native" and (world > 1 or os.environ.get("TT_COMM_FORCE_ASYNC")):
+            if dist_backend != "nccl":
+                raise SystemExit("--transport native needs one GPU per rank (RCCL); this group runs over " + dist_backend)
+            from two_tower_models_amd.comm import NativeComm
+            collectives.use_native_transport(NativeComm.from_torch_distributed(device))
+        if args.watchdog > 0:
+            watchdog = collectives.Watchdog(args.watchdog)
+        if args.check:
+            check = sharded_check(device, rank, world)
+            if rank == 0 and not check["ok"]:
+                print(json.dumps({"metric": "bench.py --check FAILED", "check": check}), flush=True)
+            if not check["ok"]:
+                raise SystemExit(3)
+        model, opt = build_sharded(cfg, device, rank)  # cfg['model'] selects base / hist / debias
+        batches = make_batches(cfg, 16, device, seed=1234 + 1000 * rank)
+        total_loss = torch.zeros((), device=device)
+        step = sharded_step_fn(model, opt, total_loss, watchdog)
     else:
         model = build_model(cfg, device)
         opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep=args.overlap, lazy=args.adam == "lazy")

@@ -447,6 +447,10 @@ typedef struct tt_adam_tensor_s {
 } tt_adam_tensor;
 int tt_adam_dense(const tt_adam_tensor* tensors /*host*/, int32_t n_tensors, const double* hyper,
                   tt_stream_t stream);
+/* Row-sharded training: copy each replicated parameter's gradient (`g`, n floats) into its slice
+ * (`p`) of ONE flat buffer -- the operand of the single dense-gradient all-reduce; m, v are ignored.  One launch per 64
+ * tensors.  The reference has no counterpart (single process, ref:train/train.py:123-125). */
+int tt_pack_grads(const tt_adam_tensor* tensors /*host*/, int32_t n_tensors, tt_stream_t stream);
 
 /* ---------------------------------------------------------------- K4 history encoder pieces
  * tt_hist_embed_pool: x[b,h,:] = table[ids[b,h],:] (+ pe[h,:]);  pooled[b,:] = mean_h table[ids[b,h],:]

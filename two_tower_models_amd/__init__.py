@@ -1,5 +1,6 @@
 """MI355X-native hot path of gauravchak/two_tower_models: the reference's nn.Module
 API over hand-written gfx950 HIP kernels (libtt_hotpath.so, C ABI in include/)."""
+from . import parallel
 from .baseline_mips_module import BaselineMIPSModule
 from .graphs import GraphedTrainStep
 from .optim import DenseExactAdam
@@ -13,5 +14,5 @@ from .user_history_encoder import UserHistoryEncoder
 __all__ = [
     "BaselineMIPSModule", "DenseExactAdam", "GraphedTrainStep", "TwoTowerBaseRetrieval", "TwoTowerWithDebiasing",
     "TwoTowerWithPositionDebiasedWeights", "TwoTowerWithUserDebiasedWeights", "TwoTowerWithUserHistoryEncoder",
-    "UserHistoryEncoder",
+    "UserHistoryEncoder", "parallel",
 ]

@@ -139,6 +139,7 @@ SIGNATURES = {
     "tt_stream_create_cu_mask": (_int, [C.POINTER(C.c_uint32), _i32, C.POINTER(_vp)]),
     "tt_stream_destroy": (_int, [_vp]),
     "tt_adam_dense": (_int, [C.POINTER(AdamTensor), _i32, _vp, _vp]),
+    "tt_pack_grads": (_int, [C.POINTER(AdamTensor), _i32, _vp]),
     "tt_hist_embed_pool": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp]),
     "tt_hist_dx_pool_bwd": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
     "tt_hist_pool_bwd": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),

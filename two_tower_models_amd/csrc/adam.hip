@@ -667,6 +667,14 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(const AdamBatch ts, con
   }
 }
 
+// row-sharded training: every replicated parameter's gradient into its slice of ONE flat buffer (the operand of the single
+// dense-gradient all-reduce): t.p = destination slice, t.g = the gradient autograd produced, t.n elements
+__global__ __launch_bounds__(256) void pack_grads_kernel(const AdamBatch ts) {
+  const tt_adam_tensor t = ts.t[blockIdx.y];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < t.n; i += stride) t.p[i] = t.g[i];
+}
+
 // dense gradient for torch.optim users: dense[row,:] = sum of that row's gradient rows
 __global__ __launch_bounds__(256) void rowgrad_dense_kernel(const tt_grad_sources src, int64_t n_rows, int64_t dim,
                                                             const int32_t* __restrict__ sorted_ids,
@@ -1079,6 +1087,26 @@ extern "C" int tt_adam_dense(const tt_adam_tensor* tensors, int32_t n_tensors, c
     const int64_t bx = ceil_div(max_n, 1024) < 1024 ? ceil_div(max_n, 1024) : 1024;
     adam_dense_kernel<<<dim3((unsigned)bx, (unsigned)cnt), 256, 0, S(stream)>>>(b, hyper);
     const int rc = check_launch("adam_dense_kernel");
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int tt_pack_grads(const tt_adam_tensor* tensors, int32_t n_tensors, tt_stream_t stream) {
+  if (!tensors) return fail_arg("tt_pack_grads: null pointer");
+  if (n_tensors <= 0) return fail_arg("tt_pack_grads: sizes");
+  for (int32_t base = 0; base < n_tensors; base += ADAM_BATCH) {
+    const int32_t cnt = (n_tensors - base < ADAM_BATCH) ? n_tensors - base : ADAM_BATCH;
+    AdamBatch b;
+    int64_t max_n = 1;
+    for (int32_t i = 0; i < cnt; ++i) {
+      b.t[i] = tensors[base + i];
+      if (!b.t[i].p || !b.t[i].g || b.t[i].n < 0) return fail_arg("tt_pack_grads: descriptor");
+      if (b.t[i].n > max_n) max_n = b.t[i].n;
+    }
+    const int64_t bx = ceil_div(max_n, 1024) < 1024 ? ceil_div(max_n, 1024) : 1024;
+    pack_grads_kernel<<<dim3((unsigned)bx, (unsigned)cnt), 256, 0, S(stream)>>>(b);
+    const int rc = check_launch("pack_grads_kernel");
     if (rc) return rc;
   }
   return 0;

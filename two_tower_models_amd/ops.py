@@ -303,6 +303,11 @@ class ActiveStash:
 def lookup_source(weight: torch.Tensor, ids: torch.Tensor, recording: bool):
     """-> (rows_table [n, D], row_ids int64 [numel], lookup_index).  Registers the lookup with the
     table's optimiser when the forward is being recorded."""
+    if getattr(weight, "_tt_shard", None) is not None:
+        # row-sharded table: the rows arrive from their owners (parallel.py); the "table" the consuming kernel gathers
+        # from is the receive buffer, the "ids" are the slots in it
+        from . import parallel
+        return parallel.routed_source(weight, ids, recording)
     lazy = getattr(weight, "_tt_lazy", None)
     if lazy is not None:  # deferred Adam: the rows must be current before anyone reads them
         lazy.catch_up(ids)
@@ -329,11 +334,21 @@ def _route_table_grad(weight: torch.Tensor, ids: torch.Tensor, rows: torch.Tenso
     """Embedding backward.  If the optimiser that owns `weight` consumes row gradients
     (two_tower_models_amd.optim.DenseExactAdam sets `_tt_rowgrads`), park them there and
     return no dense gradient; otherwise build the dense gradient torch.optim needs."""
+    if getattr(weight, "_tt_shard", None) is not None and index is not None:
+        from . import parallel
+        return parallel.route_grad_rows(weight, rows, index)  # back through the lookup's slots to the owning ranks
     stash = getattr(weight, "_tt_rowgrads", None)
     if stash is not None:
         stash.append(RowGrad(ids, rows, index))
         return None
     return dense_grad_from_rows([RowGrad(ids, rows)], weight.shape[0], weight.shape[1])
+
+
+def _resolve_pending(g: torch.Tensor) -> None:
+    """Row-sharded training: an incoming tower gradient may be the result of a reduce-scatter that was only STARTED
+    (parallel.AllGatherRows.backward); the current stream waits for it here, at its first use."""
+    from . import parallel
+    parallel.resolve_pending(g)
 
 
 # ----------------------------------------------------------------- autograd Functions
@@ -396,6 +411,7 @@ class Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
+        _resolve_pending(dy)
         dy = _rowmajor(dy)
         M, K = x.shape
         Nn = W.shape[0]
@@ -555,6 +571,7 @@ class FusedTower(_LookupFunction):
         E = 0 if extra is None else extra.shape[1]
         w = ctx.weight
         dev = dy.device
+        _resolve_pending(dy)
         dy = dy.contiguous()
         B, F = feats.shape
         D, Hd = w.shape[1], h.shape[1]

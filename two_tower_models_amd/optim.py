@@ -105,6 +105,18 @@ class DenseExactAdam(torch.optim.Optimizer):
             p._tt_optimizer = weakref.ref(self)
         if overlap_sweep not in (True, False, "forward"):
             raise ValueError('overlap_sweep must be True, False or "forward"')
+        # Row-sharded tables (parallel.py): this rank's Parameter is its row block, the state below its moments.  The
+        # looked-up rows are known to their OWNER only through the lookup exchange, which train_forward starts -- so the
+        # forward-announced schedule is the one that applies; the replicated parameters' gradients are all-reduced (SUM,
+        # one flat buffer) in step().
+        self._sharded = [p for p in self._tables if getattr(p, "_tt_shard", None) is not None]
+        if self._sharded:
+            if len(self._sharded) != len(self._tables):
+                raise ValueError("either every embedding table of the model is row-sharded or none is")
+            if lazy:
+                raise ValueError("the deferred (lazy) schedule is a single-GPU schedule; row-sharded tables use the dense-exact sweep")
+            overlap_sweep = "forward"
+        self._flat_g: Optional[torch.Tensor] = None
         self.lazy = bool(lazy)
         self.overlap_sweep = False if self.lazy else overlap_sweep  # no sweep to overlap
         self._last_step: Dict[int, torch.Tensor] = {}
@@ -300,16 +312,24 @@ class DenseExactAdam(torch.optim.Optimizer):
             if not blocks:
                 continue
             n_rows, dim = p.shape
+            shard = getattr(p, "_tt_shard", None)
+            if shard is not None:
+                # this rank's block: `blocks` are the local ids the lookup exchange delivered, with the sentinel n_local
+                # for padding slots -- the plan sorts it last (n_rows + 1 "rows") and the Adam kernels skip its run
+                n_rows = shard.n_local
+                if n_rows <= 0:  # fewer rows than ranks: nothing to park, sweep or finish on this rank
+                    continue
             st = self.state[p]
             # forward mode: the ids alone are enough to park the rows (slot = occurrence), so the
             # sort is deferred until the sweep is running
-            plan = ops.RowPlan(blocks, n_rows, slot=f"plan{id(p)}", defer=announced is not None)
+            plan = ops.RowPlan(blocks, n_rows + (1 if shard is not None else 0), slot=f"plan{id(p)}", defer=announced is not None)
             side = self._side(p, lib.tt_adam_table_workspace_bytes(plan.n, dim))
             if announced is not None:
                 stash_jobs.append((p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), n_rows, dim,
                                    plan.ids.data_ptr(), plan.n, side.data_ptr(), side.numel()))
-                p_plane = side[: plan.n * dim * 4].view(torch.float32).view(plan.n, dim)
-                p._tt_active = ops.ActiveStash(p_plane, plan.block_sizes)
+                if shard is None:  # (a sharded table's lookups were served from the table before this point: parallel.begin_lookups)
+                    p_plane = side[: plan.n * dim * 4].view(torch.float32).view(plan.n, dim)
+                    p._tt_active = ops.ActiveStash(p_plane, plan.block_sizes)
             else:
                 N.check(lib.tt_adam_table_stash(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                                 n_rows, dim, plan.n, plan.sorted_ids.data_ptr(), plan.perm.data_ptr(),
@@ -348,7 +368,9 @@ class DenseExactAdam(torch.optim.Optimizer):
             for i, p in enumerate(begun):
                 st = self.state[p]
                 descs[i].p, descs[i].g = p.data_ptr(), None
-                descs[i].m, descs[i].v, descs[i].n = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+                shard = getattr(p, "_tt_shard", None)
+                descs[i].m, descs[i].v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                descs[i].n = p.numel() if shard is None else shard.n_local * p.shape[1]
             N.check(lib.tt_adam_tables_sweep(descs, len(begun), hyper, self._sweep_wgs, self._side_stream.cuda_stream),
                     "tt_adam_tables_sweep")
         # forward mode: the stable sort of the ids is needed only by finish (in step()).  It is NOT enqueued here: its
@@ -467,6 +489,50 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._begin_overlapped({id(p): [b.reshape(-1) for b in blocks] for p, blocks in lookups.items() if id(p) in mine})
         return True
 
+    # ------------------------------------------------------------------ replicated parameters of a row-sharded model
+    def _start_dense_allreduce(self):
+        """Every replicated parameter's gradient into ONE flat buffer (tt_pack_grads, one launch) and its all-reduce (SUM:
+        each rank holds the gradient of ITS rows' share of the global-batch mean) started -- it travels underneath the
+        table finish.  A parameter without a gradient on this rank contributes zeros (its slice is cleared)."""
+        from . import parallel
+        lib = N.load()
+        total = sum(p.numel() for p in self._dense)
+        if total == 0:
+            return None
+        dev = self._dense[0].device
+        if self._flat_g is None or self._flat_g.numel() != total:
+            self._flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        descs = (N.AdamTensor * len(self._dense))()
+        n, off, missing = 0, 0, []
+        keep = []
+        for p in self._dense:
+            if p.grad is not None:
+                gr = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                keep.append(gr)
+                descs[n].p, descs[n].g, descs[n].n = self._flat_g.data_ptr() + 4 * off, gr.data_ptr(), p.numel()
+                n += 1
+            else:
+                missing.append((off, p.numel()))
+            off += p.numel()
+        for o, k in missing:
+            self._flat_g[o:o + k].zero_()
+        if n:
+            N.check(lib.tt_pack_grads(descs, n, N.stream()), "tt_pack_grads")
+        return parallel.all_reduce_dense_start(self._flat_g), keep
+
+    def _finish_dense_allreduce(self, reduce, lib, hyper) -> None:
+        pending, _keep = reduce
+        flat = pending.wait()
+        descs = (N.AdamTensor * len(self._dense))()
+        off = 0
+        for i, p in enumerate(self._dense):
+            st = self.state[p]
+            descs[i].p, descs[i].g = p.data_ptr(), flat.data_ptr() + 4 * off
+            descs[i].m, descs[i].v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            descs[i].n = p.numel()
+            off += p.numel()
+        N.check(lib.tt_adam_dense(descs, len(self._dense), hyper, N.stream()), "tt_adam_dense")
+
     def zero_grad(self, set_to_none: bool = True) -> None:
         for p in self._tables:
             p._tt_rowgrads.clear()
@@ -496,6 +562,10 @@ class DenseExactAdam(torch.optim.Optimizer):
             self._init_state()
         lib = N.load()
         hyper = self._hyper.data_ptr()
+        reduce = self._start_dense_allreduce() if self._sharded else None
+        if self._sharded and self._begun is None:
+            raise RuntimeError("row-sharded tables: step() without a train_forward that announced its lookups (the models' "
+                               "train_forward does; a custom forward must call model._announce_lookups first)")
         if self._begun is not None:
             # overlapped schedule: hyper already advanced, tables already swept on the side stream
             self._launch_plans(side=False)  # nobody called zero_grad() after the forward: sort now, in line
@@ -510,7 +580,9 @@ class DenseExactAdam(torch.optim.Optimizer):
                     ts.plan.attach(self._ordered_rows(p))
                     j = jobs[i]
                     j.W, j.M, j.V = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-                    j.n_rows, j.dim, j.src, j.n_ids = p.shape[0], p.shape[1], C.pointer(ts.plan.sources), ts.plan.n
+                    shard = getattr(p, "_tt_shard", None)
+                    j.n_rows = p.shape[0] if shard is None else shard.n_local
+                    j.dim, j.src, j.n_ids = p.shape[1], C.pointer(ts.plan.sources), ts.plan.n
                     j.sorted_ids, j.perm = ts.plan.sorted_ids.data_ptr(), ts.plan.perm.data_ptr()
                     j.seg_begin, j.n_unique = ts.plan.seg_begin.data_ptr(), ts.plan.n_unique.data_ptr()
                     j.side, j.side_bytes = ts.side.data_ptr(), ts.side.numel()
@@ -569,10 +641,15 @@ class DenseExactAdam(torch.optim.Optimizer):
                                               N.stream()), "tt_adam_table")
                 # a table with no lookups this step has grad None: torch.optim skips it too
         for p in self._tables:
+            for b in p._tt_rowgrads:  # (a sharded table this rank owns no row of: its exchanges still have to be waited for)
+                b.rows
             p._tt_lookups.clear()
             p._tt_rowgrads.clear()
             p._tt_active = None
 
+        if reduce is not None:
+            self._finish_dense_allreduce(reduce, lib, hyper)
+            return None
         live = [p for p in self._dense if p.grad is not None]
         if live:
             descs = (N.AdamTensor * len(live))()

@@ -1,0 +1,651 @@
+"""Row-sharded multi-GPU training BEHIND the drop-in module API (one process per GPU, RCCL over xGMI).
+
+The reference has no parallelism of any kind; this is new design, constrained only by parity:
+W ranks with B rows each compute exactly the reference's loss and update on the CONCATENATED batch of W*B rows
+("global in-batch negatives").  Nothing here is a second trainer: the user still builds `TwoTowerBaseRetrieval` /
+`TwoTowerWithUserHistoryEncoder` / `TwoTowerWithDebiasing` (or a subclass with its own hooks), a `DenseExactAdam` over
+`model.parameters()`, and runs the reference loop (ref:train/train.py:112-125)
+
+    loss = model.train_forward(...); optimizer.zero_grad(); loss.backward(); optimizer.step()
+
+on every rank.  What changes is where the embedding rows live:
+
+    with parallel.row_sharded():                  # tables created inside own only this rank's row block
+        model = TwoTowerBaseRetrieval(...)
+    parallel.shard_model_(model)                  # (or: build the full model anywhere, then slice it) + broadcast dense
+
+Partitioning
+  * every embedding table is split into W contiguous row blocks; a rank's `nn.Embedding.weight` IS its block
+    (`weight._tt_shard` says which), its Adam moments are the optimiser's state for that Parameter, and the optimiser
+    sweeps only that block (the HBM-bound part scales 1/W with no communication);
+  * the batch is split by rank; dense MLP / tower / encoder / debias-head parameters are replicated.
+Exchanges per step, every size known to the host before the step starts:
+  1. lookups (`ops.lookup_source` -> `routed_source`): padded fixed-capacity all-to-all.  A rank's ids are bucketed by
+     owner in one stable counting pass (csrc/route.hip); each owner is sent only ITS ids, `cap` slots per peer, and
+     returns the rows in the same slots:   ids all_to_all [W, cap] int64,  rows all_to_all [W, cap, D].
+     `cap` = the largest (requester, owner) bucket over all ranks, rounded up to 64 -- exact, no overflow path.  It is
+     all-reduced (MAX) ONE STEP AHEAD from the next batch's ids (`plan_ahead`), so the host never waits for it;
+     a batch that was not announced synchronises once on those few ints.  `train_forward` starts ALL of a step's
+     lookups before the first tower (`begin_lookups`), so the exchanges overlap each other and the towers.
+  2. item embeddings                         all_gather      [B, D] -> [W*B, D]        (`AllGatherRows`, forward)
+  3. max of the value weights, loss          all_reduce      scalars                   (`GlobalWeightedMeanLoss`)
+  4. partial dI over the gathered items      reduce_scatter  [W*B, D] -> [B, D]        (`AllGatherRows`, backward)
+  5. embedding-row gradients: back through the lookup's slots   all_to_all [W, cap, D] (`route_grad_rows`)
+  6. dense-parameter gradients, ONE flat buffer  all_reduce  ~0.5-1.5 MB               (`DenseExactAdam.step`)
+Loss heads that are not the plain weighted mean (debias heads, user-overridden hooks) are evaluated REPLICATED on the
+gathered [W*B]-sized head inputs with the model's own single-device code and scaled 1/W in the backward
+(`ReplicatedLoss`): every cross-row term of the reference (the batch maximum, upstream's [B,1]-vs-[B] broadcast inside
+the position loss) is then the reference's own expression on the concatenated batch.
+
+The arithmetic is libtt_hotpath.so throughout; tests/ inject a CPU restatement of the four routing kernels
+(`set_route_kernels_for_tests`) to exercise this file's exchange logic under gloo without a GPU.
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import collectives as C
+
+
+# ----------------------------------------------------------------- who owns which rows
+class RowShard:
+    """Contiguous row block [lo, hi) of a [n_rows, dim] table, attached to the block's Parameter as `_tt_shard`."""
+
+    __slots__ = ("n_rows", "dim", "world", "rank", "rows_per_rank", "lo", "hi", "n_local")
+
+    def __init__(self, n_rows: int, dim: int, world: int, rank: int):
+        self.n_rows, self.dim, self.world, self.rank = int(n_rows), int(dim), int(world), int(rank)
+        self.rows_per_rank, self.lo, self.hi = block_range(n_rows, rank, world)
+        self.n_local = self.hi - self.lo
+
+    def __repr__(self):
+        return f"RowShard(rows [{self.lo}, {self.hi}) of {self.n_rows}, rank {self.rank}/{self.world})"
+
+
+def block_range(n_rows: int, rank: int, world: int) -> Tuple[int, int, int]:
+    per = (n_rows + world - 1) // world
+    lo = min(rank * per, n_rows)
+    return per, lo, min(lo + per, n_rows)
+
+
+def shard_of(weight) -> Optional[RowShard]:
+    return getattr(weight, "_tt_shard", None)
+
+
+def _group() -> Tuple[int, int]:
+    if not dist.is_initialized():
+        raise RuntimeError("row-sharded tables need torch.distributed to be initialised (one process per GPU)")
+    return dist.get_world_size(), dist.get_rank()
+
+
+_BUILDING = [False]
+
+
+@contextlib.contextmanager
+def row_sharded():
+    """Inside, the models' constructors create each embedding table as THIS rank's row block only (a 100 M-row table
+    never exists in one piece).  Follow with `shard_model_(model)` (broadcasts the replicated parameters)."""
+    _group()
+    prev, _BUILDING[0] = _BUILDING[0], True
+    try:
+        yield
+    finally:
+        _BUILDING[0] = prev
+
+
+def embedding(num_embeddings: int, embedding_dim: int) -> nn.Embedding:
+    """nn.Embedding(num_embeddings, embedding_dim) (ref:src/two_tower_base_retrieval.py:70,97) -- under
+    `row_sharded()` only this rank's rows of it, N(0, 1) like the whole."""
+    if not _BUILDING[0]:
+        return nn.Embedding(num_embeddings, embedding_dim)
+    world, rank = _group()
+    sh = RowShard(num_embeddings, embedding_dim, world, rank)
+    emb = nn.Embedding(max(sh.n_local, 1), embedding_dim)
+    emb.weight._tt_shard = sh
+    return emb
+
+
+def _tables(model: nn.Module) -> List[Tuple[str, nn.Parameter]]:
+    return [(n, p) for n, p in model.named_parameters() if getattr(p, "_tt_is_table", False)]
+
+
+@torch.no_grad()
+def shard_model_(model: nn.Module, broadcast_dense: bool = True) -> nn.Module:
+    """Make `model` this rank's member of a row-sharded group: every embedding table still whole is cut down to this
+    rank's row block (same Parameter object, so optimisers / hooks created later see the block), and the replicated
+    parameters are broadcast from rank 0 so that the replicas start bit-identical.  Call it BEFORE building the
+    optimiser."""
+    world, rank = _group()
+    for _, p in _tables(model):
+        if shard_of(p) is None:
+            sh = RowShard(p.shape[0], p.shape[1], world, rank)
+            block = torch.zeros(max(sh.n_local, 1), sh.dim, dtype=p.dtype, device=p.device)
+            block[: sh.n_local].copy_(p.data[sh.lo:sh.hi])
+            p.data = block
+            p._tt_shard = sh
+    if broadcast_dense and world > 1:
+        dense = [p for p in model.parameters() if not getattr(p, "_tt_is_table", False)]
+        flat = torch.cat([p.data.reshape(-1) for p in dense]) if dense else None
+        if flat is not None:
+            C.broadcast_(flat, src=0)
+            off = 0
+            for p in dense:
+                p.data.copy_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+    # the random MIPS corpus (ref:src/baseline_mips_module.py:29-30) is per-process state of an inference helper: untouched
+    return model
+
+
+def is_sharded(model: nn.Module) -> bool:
+    return any(shard_of(p) is not None for _, p in _tables(model))
+
+
+def full_state_dict(model: nn.Module) -> Dict[str, torch.Tensor]:
+    """The reference-format state_dict (whole tables under the reference's Parameter names),
+    assembled on every rank: loads into the single-device modules (either implementation) unchanged."""
+    out = {}
+    for k, v in model.state_dict().items():
+        out[k] = v.detach().clone()
+    for name, p in _tables(model):
+        sh = shard_of(p)
+        if sh is None:
+            continue
+        block = p.data.new_zeros(sh.rows_per_rank, sh.dim)
+        block[: sh.n_local] = p.data[: sh.n_local]
+        full = C.all_gather_rows(block) if sh.world > 1 else block
+        out[name] = full[: sh.n_rows].clone()
+    return out
+
+
+@torch.no_grad()
+def load_full_state_dict(model: nn.Module, state: Dict[str, torch.Tensor]) -> None:
+    """Scatter a reference-format state_dict into the row blocks / replicated parameters."""
+    own = model.state_dict()
+    tables = dict(_tables(model))
+    for k, v in own.items():
+        p = tables.get(k)
+        sh = shard_of(p) if p is not None else None
+        if sh is None:
+            v.copy_(state[k].to(v.device))
+            continue
+        full = state[k]
+        if tuple(full.shape) != (sh.n_rows, sh.dim):
+            raise ValueError(f"{k}: expected {(sh.n_rows, sh.dim)}, got {tuple(full.shape)}")
+        p.data[: sh.n_local].copy_(full[sh.lo:sh.hi].to(p.device))
+
+
+# ----------------------------------------------------------------- routing kernels (csrc/route.hip, csrc/gather.hip)
+class _HipRouteKernels:
+    """Owner bucketing / slot assignment / owner-side localisation / row gathers on libtt_hotpath.so."""
+
+    def __init__(self, device: torch.device):
+        from . import _native
+        self.N, self.lib, self.device = _native, _native.load(), device
+
+    def route_plan(self, ids: torch.Tensor, n_rows: int, rows_per_rank: int, world: int, max_out: torch.Tensor):
+        """Count this rank's ids per owner (one stable counting pass, no sort); the largest bucket is atomicMax'ed into
+        the int32 scalar view `max_out`.  Ids outside [0, n_rows) raise the device-side out-of-range flag (IndexError at
+        the next poll, like the single-GPU lookups)."""
+        N, lib = self.N, self.lib
+        n = ids.numel()
+        ws = torch.empty(lib.tt_route_workspace_bytes(n, world), dtype=torch.uint8, device=self.device)
+        counts = torch.empty(world, dtype=torch.int32, device=self.device)
+        N.check(lib.tt_route_count(ids.data_ptr(), n, n_rows, rows_per_rank, world, counts.data_ptr(), max_out.data_ptr(),
+                                   N.oob.flag(self.device).data_ptr(), ws.data_ptr(), ws.numel(), N.stream()), "tt_route_count")
+        return ids, n_rows, ws, counts
+
+    def route_build(self, planned, rows_per_rank: int, world: int, cap: int):
+        N, lib = self.N, self.lib
+        ids, n_rows, ws, _counts = planned
+        n = ids.numel()
+        send_ids = torch.empty(world * cap, dtype=torch.int64, device=self.device)
+        src_of = torch.empty(world * cap, dtype=torch.int64, device=self.device)
+        slot_of = torch.empty(n, dtype=torch.int64, device=self.device)
+        N.check(lib.tt_route_build(ids.data_ptr(), n, n_rows, rows_per_rank, world, cap, ws.data_ptr(), ws.numel(),
+                                   send_ids.data_ptr(), slot_of.data_ptr(), src_of.data_ptr(),
+                                   N.oob.flag(self.device).data_ptr(), N.stream()), "tt_route_build")
+        return send_ids, slot_of, src_of
+
+    def localize(self, ids: torch.Tensor, lo: int, n_local: int) -> torch.Tensor:
+        out = torch.empty_like(ids)
+        self.N.check(self.lib.tt_route_localize(ids.data_ptr(), ids.numel(), lo, n_local, out.data_ptr(), self.N.stream()),
+                     "tt_route_localize")
+        return out
+
+    def gather_owned(self, table: torch.Tensor, local: torch.Tensor, n_local: int) -> torch.Tensor:
+        """out[i] = table[local[i]] for local[i] < n_local, a zero row for the sentinel / padding."""
+        out = torch.empty(local.numel(), table.shape[1], dtype=torch.float32, device=self.device)
+        if n_local <= 0:  # a rank that owns no row of this table (fewer rows than ranks): every id is the sentinel
+            return out.zero_()
+        N = self.N
+        N.check(self.lib.tt_gather_rows(table.data_ptr(), n_local, table.shape[1], local.data_ptr(), local.numel(),
+                                        out.data_ptr(), table.shape[1], None, N.stream()), "tt_gather_rows")
+        return out
+
+
+_ROUTE_KERNELS = {}
+_ROUTE_KERNELS_TEST = [None]
+
+
+def set_route_kernels_for_tests(obj) -> None:
+    """tests/ only: a CPU restatement of the four routing kernels, so this file's exchange logic runs under gloo on a
+    box without a GPU.  The product never calls this."""
+    _ROUTE_KERNELS_TEST[0] = obj
+
+
+def _kernels(device: torch.device):
+    if _ROUTE_KERNELS_TEST[0] is not None:
+        return _ROUTE_KERNELS_TEST[0]
+    if device.type != "cuda":
+        raise RuntimeError("row-sharded lookups run on MI355X only: got a CPU tensor (there is no CPU path)")
+    k = _ROUTE_KERNELS.get(device.index)
+    if k is None:
+        k = _ROUTE_KERNELS[device.index] = _HipRouteKernels(device)
+    return k
+
+
+# ----------------------------------------------------------------- routed lookups
+class _PlannedRoutes:
+    """The routing of one step's lookups as far as it can be prepared without knowing `cap`: per lookup the counted
+    owner buckets, and the all-reduced bucket maxima on their way to the host."""
+
+    __slots__ = ("key", "planned", "counts_host", "event", "keep")
+
+    def __init__(self, key, planned, counts_host, event, keep):
+        self.key, self.planned, self.counts_host, self.event, self.keep = key, planned, counts_host, event, keep
+
+    def caps(self) -> List[int]:
+        if self.event is not None:
+            self.event.synchronize()  # planned a step ahead: long complete, no wait
+        return [max(64, (int(c) + 63) // 64 * 64) for c in self.counts_host.tolist()]
+
+
+class _RoutedLookup:
+    """One lookup in flight: requester side (slot_of, src_of) and owner side (local ids, sentinel n_local)."""
+
+    __slots__ = ("shard", "n", "cap", "slot_of", "src_of", "ids_p", "rows_p", "local")
+
+    def __init__(self, shard, n, cap, slot_of, src_of, ids_p):
+        self.shard, self.n, self.cap, self.slot_of, self.src_of, self.ids_p = shard, n, cap, slot_of, src_of, ids_p
+        self.rows_p, self.local = None, None
+
+
+class PendingRowGrad:
+    """ops.RowGrad whose rows are still travelling to their owner (all-to-all started in the backward pass); the
+    optimiser's `step()` reads `.rows`, which waits for the exchange on the current stream."""
+
+    __slots__ = ("ids", "index", "_pending", "_rows")
+
+    def __init__(self, ids: torch.Tensor, pending, index: Optional[int]):
+        self.ids, self.index, self._pending, self._rows = ids, index, pending, None
+
+    @property
+    def rows(self) -> torch.Tensor:
+        if self._rows is None:
+            self._rows = self._pending.wait()
+            self._pending = None
+        return self._rows
+
+
+_planned_next: List[Optional[_PlannedRoutes]] = [None]
+comm_bytes: Dict[str, int] = {}  # bytes this rank SENT to other ranks during the last step, by exchange
+
+
+def _sent(tag: str, nbytes: int) -> None:
+    comm_bytes[tag] = comm_bytes.get(tag, 0) + int(nbytes)
+
+
+def _route_key(specs) -> tuple:
+    # storage, size AND torch's in-place version counter: a static input buffer refilled with copy_() between the
+    # announcement and the step keeps its address but not its version, and is planned again
+    return tuple((id(p), t.data_ptr(), t.numel(), t._version) for p, t in specs)
+
+
+def _specs(plan: Dict[nn.Parameter, Sequence[torch.Tensor]]):
+    return [(p, ids) for p, blocks in plan.items() if shard_of(p) is not None for ids in blocks]
+
+
+def plan_routes(specs) -> _PlannedRoutes:
+    """Count each lookup's ids by owner and start the all-reduce (MAX) of the bucket maxima + its copy to the host."""
+    dev = specs[0][1].device
+    K = _kernels(dev)
+    counts = torch.zeros(len(specs), dtype=torch.int32, device=dev)
+    planned, keep = [], []
+    for k, (p, ids) in enumerate(specs):
+        sh = shard_of(p)
+        # a private copy: route_build ranks THESE ids against the bucket offsets counted here, whatever happens to the
+        # caller's tensor in between (a writer torch does not see -- a prefetcher's raw memcpy -- would otherwise put two
+        # ids into one send slot without tripping the overflow flag)
+        flat = ids.reshape(-1)
+        flat = flat.clone() if (flat.dtype == torch.int64 and flat.is_contiguous()) else flat.to(torch.int64).contiguous()
+        keep.append(flat)
+        planned.append(K.route_plan(flat, sh.n_rows, sh.rows_per_rank, sh.world, counts[k:k + 1]))
+    if dist.get_world_size() > 1:
+        C.all_reduce_start_(counts, op=dist.ReduceOp.MAX, tag="route_caps_allreduce").wait()
+    if counts.is_cuda:
+        host = torch.empty(len(specs), dtype=torch.int32).pin_memory()
+        host.copy_(counts, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        keep.append(counts)
+    else:
+        host, event = counts, None
+    return _PlannedRoutes(_route_key(specs), planned, host, event, keep)
+
+
+def plan_ahead(plan: Dict[nn.Parameter, Sequence[torch.Tensor]]) -> None:
+    """Announce the NEXT step's lookups (`model._lookup_plan(user_id, user_history, item_id)` of the next batch): their
+    routes are counted and the bucket capacity all-reduced underneath the current step, which removes the step's only
+    host wait.  Purely a scheduling hint; results do not depend on it.  Every rank must call it (or none)."""
+    specs = _specs(plan)
+    _planned_next[0] = plan_routes(specs) if specs else None
+
+
+def _start_lookups(specs, routes: _PlannedRoutes) -> List[Tuple[nn.Parameter, _RoutedLookup]]:
+    """ids to their owners, rows back: every exchange of `specs` is in flight when this returns."""
+    dev = specs[0][1].device
+    K = _kernels(dev)
+    caps = routes.caps()
+    lks: List[Tuple[nn.Parameter, _RoutedLookup]] = []
+    for (p, ids), planned, cap in zip(specs, routes.planned, caps):
+        sh = shard_of(p)
+        send_ids, slot_of, src_of = K.route_build(planned, sh.rows_per_rank, sh.world, cap)
+        lks.append((p, _RoutedLookup(sh, ids.numel(), cap, slot_of, src_of,
+                                     C.all_to_all_rows_start(send_ids, tag="lookup_ids_alltoall"))))
+        _sent("lookup_ids_alltoall", (sh.world - 1) * cap * 8)
+    for p, lk in lks:
+        sh = lk.shard
+        lk.local = K.localize(lk.ids_p.wait(), sh.lo, sh.n_local)  # sentinel n_local for padding
+        lk.ids_p = None
+        lk.rows_p = C.all_to_all_rows_start(K.gather_owned(p.data, lk.local, sh.n_local), tag="lookup_rows_alltoall")
+        _sent("lookup_rows_alltoall", (sh.world - 1) * lk.cap * sh.dim * 4)
+    return lks
+
+
+def begin_lookups(plan: Dict[nn.Parameter, Sequence[torch.Tensor]]) -> Dict[nn.Parameter, List[torch.Tensor]]:
+    """Start the routed exchange of EVERY lookup of a step (tables in `plan` order, blocks in forward order) and queue
+    the results on their tables for `routed_source` to hand out.  Returns the plan as the OWNERS see it -- per sharded
+    table the received local-id blocks (sentinel n_local for padding and for other ranks' rows) -- which is what
+    `DenseExactAdam.begin_step` plans the table step from; tables that are not sharded pass through unchanged."""
+    specs = _specs(plan)
+    if not specs:
+        return dict(plan)
+    comm_bytes.clear()
+    dev = specs[0][1].device
+    for p, _ in specs:
+        p._tt_routed = []
+    routes, _planned_next[0] = _planned_next[0], None
+    if routes is None or routes.key != _route_key(specs):
+        routes = plan_routes(specs)
+    elif routes.event is not None and dev.type == "cuda":
+        torch.cuda.current_stream().wait_event(routes.event)
+    out: Dict[nn.Parameter, List[torch.Tensor]] = {p: list(b) for p, b in plan.items() if shard_of(p) is None}
+    for p, lk in _start_lookups(specs, routes):
+        p._tt_routed.append(lk)
+        out.setdefault(p, []).append(lk.local)
+    return out
+
+
+_LOCAL_ROWS = [False]
+
+
+@contextlib.contextmanager
+def local_rows():
+    """Inside, lookups of a sharded table read THIS rank's block directly and the ids are local row numbers (corpus
+    export: a rank runs the item tower over its own rows, no exchange)."""
+    prev, _LOCAL_ROWS[0] = _LOCAL_ROWS[0], True
+    try:
+        yield
+    finally:
+        _LOCAL_ROWS[0] = prev
+
+
+def routed_source(weight: nn.Parameter, ids: torch.Tensor, recording: bool):
+    """ops.lookup_source for a sharded table -> (rows [W*cap, D] as received from the owners, slot of each id in it,
+    lookup index).  The consuming kernel gathers by slot, so the rows are never re-ordered in HBM."""
+    from . import ops
+    sh = shard_of(weight)
+    if _LOCAL_ROWS[0]:
+        return weight, ids.reshape(-1), None
+    q = getattr(weight, "_tt_routed", None)
+    if q:
+        lk = q.pop(0)
+        if lk.n != ids.numel():
+            raise RuntimeError("forward performed a lookup that differs from the one train_forward announced "
+                               f"({ids.numel()} ids, announced {lk.n})")
+    else:  # not announced (inference, a hook's own lookup): route it now, one host wait for the bucket capacity
+        specs = [(weight, ids)]
+        lk = _start_lookups(specs, plan_routes(specs))[0][1]
+    rows = lk.rows_p.wait()
+    idx = ops.register_lookup(weight, lk.local) if recording else None
+    if recording:
+        if idx is None:
+            raise RuntimeError("training through a row-sharded table needs DenseExactAdam built over the model's parameters "
+                               "(its table step consumes the routed row gradients); none is attached to this table")
+        live = getattr(weight, "_tt_routed_live", None)
+        if live is None:
+            live = weight._tt_routed_live = {}
+        live[idx] = lk
+    return rows, lk.slot_of, idx
+
+
+def route_grad_rows(weight: nn.Parameter, grad_rows: torch.Tensor, index: Optional[int]) -> None:
+    """Embedding backward for a sharded table: the gradient rows go back through the lookup's slots to the owners
+    (started here, waited for by the optimiser's step), where they arrive aligned with the local ids the owner served."""
+    live = getattr(weight, "_tt_routed_live", None)
+    lk = live.pop(index, None) if (live is not None and index is not None) else None
+    if lk is None:
+        raise RuntimeError("backward through a row-sharded lookup that was not recorded by a training forward")
+    sh = lk.shard
+    K = _kernels(grad_rows.device)
+    if not grad_rows.is_contiguous():
+        grad_rows = grad_rows.contiguous()
+    send = K.gather_owned(grad_rows, lk.src_of, grad_rows.shape[0])  # [W*cap, D]; zero rows in the padding slots
+    pend = C.all_to_all_rows_start(send, tag="rowgrad_alltoall")
+    _sent("rowgrad_alltoall", (sh.world - 1) * lk.cap * sh.dim * 4)
+    weight._tt_rowgrads.append(PendingRowGrad(lk.local, pend, index))
+    return None
+
+
+# ----------------------------------------------------------------- autograd collectives
+_DEFERRED: Dict[int, "C._Pending"] = {}  # data_ptr of a reduce-scatter result that has not been waited for yet
+
+
+def resolve_pending(t: Optional[torch.Tensor]) -> None:
+    """Called by the backward of this package's tower Functions on their incoming gradient: if it is the result of a
+    reduce-scatter that is still in flight (AllGatherRows.backward, `defer`), the current stream waits for it now."""
+    if _DEFERRED and t is not None:
+        p = _DEFERRED.pop(t.data_ptr(), None)
+        if p is not None:
+            p.wait()
+
+
+_DEFER_SAFE_PRODUCERS = ("FusedTowerBackward", "LinearBackward")
+
+
+class AllGatherRows(torch.autograd.Function):
+    """[B, ...] per rank -> [W*B, ...] on every rank (rank order); backward: reduce-scatter (SUM) of the gradient.
+    SURVEY.md 8e exchanges 3 and 5 (item embeddings / partial dI).  When the tensor gathered was produced by one of this
+    package's tower Functions, the backward only STARTS the reduce-scatter: that Function's backward waits for it when
+    it runs (`resolve_pending`), and whatever autograd schedules in between -- the user tower's backward -- overlaps it."""
+
+    @staticmethod
+    def forward(ctx, x, tag: str = "item_emb_allgather", defer_ok: bool = False):
+        """`defer_ok`: the caller vouches that `x` has no other consumer (autograd would otherwise SUM the deferred
+        gradient with the other one on the main stream, before anyone waited for the exchange)."""
+        ctx.tag = tag
+        ctx.defer = bool(defer_ok) and x.grad_fn is not None and type(x.grad_fn).__name__ in _DEFER_SAFE_PRODUCERS
+        ctx.world = dist.get_world_size()
+        if ctx.world == 1 and not C._force_async():
+            return x.view_as(x)
+        _sent(tag, (ctx.world - 1) * x.numel() * x.element_size())
+        return C.all_gather_rows_start(x.contiguous(), tag=tag).wait()
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.world == 1 and not C._force_async():
+            return g, None, None
+        back = {"item_emb_allgather": "dI_reduce_scatter"}.get(ctx.tag, ctx.tag + "_grad_reduce_scatter")
+        _sent(back, (ctx.world - 1) * (g.numel() // ctx.world) * g.element_size())
+        pend = C.reduce_scatter_rows_start(g.contiguous(), tag=back)
+        if ctx.defer and pend.work is not None:
+            _DEFERRED[pend.out.data_ptr()] = pend
+            return pend.out, None, None
+        return pend.wait(), None, None
+
+
+def gather_no_grad(x: torch.Tensor, tag: str = "head_inputs_allgather") -> torch.Tensor:
+    if dist.get_world_size() == 1:
+        return x
+    _sent(tag, (dist.get_world_size() - 1) * x.numel() * x.element_size())
+    return C.all_gather_rows_start(x.contiguous(), tag=tag).wait()
+
+
+class ReplicatedLoss(torch.autograd.Function):
+    """A scalar every rank computed identically from gathered inputs: value unchanged, gradient scaled 1/W -- the
+    gathers' reduce-scatters and the dense all-reduce (both SUMs) then add the W copies back up to exactly one."""
+
+    @staticmethod
+    def forward(ctx, loss):
+        ctx.scale = 1.0 / dist.get_world_size()
+        return loss.view_as(loss)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.scale
+
+
+_ONES: Dict[tuple, torch.Tensor] = {}
+
+
+def _ones(n: int, device: torch.device) -> torch.Tensor:
+    key = (device.index, n)
+    if key not in _ONES:
+        _ONES[key] = torch.ones(n, dtype=torch.float32, device=device)
+    return _ONES[key]
+
+
+class GlobalWeightedMeanLoss(torch.autograd.Function):
+    """ops.WeightedMeanLoss over the GLOBAL batch: mean over W*B rows of row_ce * w, w = clamp(labels . uvw, 1e-6) /
+    max over ALL ranks (ref:src/two_tower_base_retrieval.py:322,334-343 on the concatenated batch).  Two launches around
+    two scalar all-reduces (tt_value_weights, tt_weighted_loss_global); labels None: w = 1 (train.py's [B] labels).
+    Returns the global loss on every rank; the backward hands each rank the coefficients of ITS rows."""
+
+    @staticmethod
+    def forward(ctx, row_ce, labels, uvw):
+        from . import _native as N
+        from . import ops
+        dev = N.require_device(row_ce, labels, uvw)
+        lib = N.load()
+        row_ce = row_ce.contiguous()
+        B = row_ce.numel()
+        W = dist.get_world_size()
+        if labels is not None:
+            labels = ops._labels_f32(labels, "GlobalWeightedMeanLoss")
+            nuv = torch.empty(B, dtype=torch.float32, device=dev)
+            mx = torch.empty(1, dtype=torch.float32, device=dev)
+            N.check(lib.tt_value_weights(labels.data_ptr(), B, labels.shape[1], uvw.contiguous().data_ptr(), nuv.data_ptr(),
+                                         mx.data_ptr(), N.stream()), "tt_value_weights")
+            if W > 1:
+                C._timed_sync("scalars", C.all_reduce_, mx, op=dist.ReduceOp.MAX)
+        else:
+            nuv, mx = _ones(B, dev), _ones(1, dev)
+        coef = torch.empty(B, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        N.check(lib.tt_weighted_loss_global(nuv.data_ptr(), mx.data_ptr(), row_ce.data_ptr(), B, float(B * W), coef.data_ptr(),
+                                            loss.data_ptr(), N.stream()), "tt_weighted_loss_global")
+        if W > 1:
+            C._timed_sync("scalars", C.all_reduce_, loss)
+            _sent("scalars", 3 * 4 * (W - 1))
+        ctx.save_for_backward(coef)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (coef,) = ctx.saved_tensors
+        return coef * g, None, None
+
+
+def all_reduce_dense_start(flat: torch.Tensor):
+    _sent("dense_grad_allreduce", int(2 * (dist.get_world_size() - 1) / dist.get_world_size() * flat.numel() * 4))
+    return C.all_reduce_start_(flat, tag="dense_grad_allreduce")
+
+
+# ----------------------------------------------------------------- sharded MIPS (BASELINE config 5)
+class ShardedMIPS:
+    """Brute-force MIPS over a corpus whose rows are split into W contiguous blocks
+    (ref:src/baseline_mips_module.py:32-72 on one shard per GPU).  Every rank brings its own B queries; per call:
+        all_gather queries                         [B, D] -> [W*B, D]
+        local exact top-K of ALL queries on this rank's block (tt_mips_topk)
+        all_to_all of the (score, global index) lists   [W, B, K] <-> [W, B, K]   (fixed size)
+        exact merge of the W*K candidates per own query (tt_mips_merge)
+    The global top-K is a subset of the union of the per-block top-Ks and every stage uses the (score desc, index asc)
+    order, so the result equals the single-device answer.  `kernels` (tests only): an object with mips_topk / mips_merge."""
+
+    def __init__(self, corpus_block: torch.Tensor, row_offset: int, kernels=None):
+        if not dist.is_initialized():
+            raise RuntimeError("ShardedMIPS needs torch.distributed to be initialised")
+        self.corpus, self.row_offset = corpus_block, int(row_offset)
+        self.W = dist.get_world_size()
+        if kernels is None:
+            from . import ops
+            kernels = ops
+        self.k = kernels
+
+    @staticmethod
+    def block_range(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
+        return block_range(n_rows, rank, world)[1:]
+
+    def search(self, query: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        W, B = self.W, query.shape[0]
+        q_all = C.all_gather_rows(query) if W > 1 else query
+        n_local = self.corpus.shape[0]
+        k_loc = min(k, n_local)
+        if k_loc > 0:
+            idx, sc = self.k.mips_topk(q_all, self.corpus, k_loc)  # [W*B, k_loc], local row numbers
+            idx = idx + self.row_offset
+        else:  # this rank's block is empty (fewer corpus rows than ranks x rows per rank): "no candidate" only
+            idx = torch.empty(q_all.shape[0], 0, dtype=torch.int64, device=q_all.device)
+            sc = torch.empty(q_all.shape[0], 0, dtype=torch.float32, device=q_all.device)
+        if k_loc < k:  # a block smaller than K: pad with "no candidate"
+            pad = k - k_loc
+            idx = torch.cat([idx, idx.new_full((idx.shape[0], pad), -1)], dim=1)
+            sc = torch.cat([sc, sc.new_zeros((sc.shape[0], pad))], dim=1)
+        if W > 1:
+            ridx, rsc = C.all_to_all_rows(idx), C.all_to_all_rows(sc)  # chunk r of the send = rank r's queries
+            # received layout [W (source shard), B, k] -> per own query the W*k candidates
+            idx = ridx.view(W, B, k).permute(1, 0, 2).reshape(B, W * k)
+            sc = rsc.view(W, B, k).permute(1, 0, 2).reshape(B, W * k)
+        return self.k.mips_merge(sc, idx, k)
+
+
+@torch.no_grad()
+def index_corpus_sharded(model: nn.Module, item_features_block: torch.Tensor) -> ShardedMIPS:
+    """Serve what was trained (upstream searches a random corpus,
+    ref:src/baseline_mips_module.py:29-30): the item tower over THIS rank's rows of the catalogue -- item r is row r of
+    the item table, `item_features_block` [hi - lo, II] the features of rows [lo, hi) -- installed as this rank's block of
+    a ShardedMIPS.  Its search() equals TwoTowerBaseRetrieval.index_corpus + forward on one device with
+    `full_state_dict(model)`."""
+    w = model.item_id_embedding_arch.weight
+    sh = shard_of(w)
+    if sh is None:
+        raise ValueError("index_corpus_sharded: the model's item table is not row-sharded")
+    feats = item_features_block.to(w.device, torch.float32)
+    if feats.shape[0] != sh.n_local:
+        raise ValueError(f"item_features_block: expected {sh.n_local} rows (this rank's item rows), got {feats.shape[0]}")
+    if sh.n_local > 0:
+        with local_rows():
+            corpus = model.compute_item_embeddings(torch.arange(sh.n_local, device=w.device), feats)
+    else:  # a rank that owns no item row
+        corpus = torch.empty(0, sh.dim, dtype=torch.float32, device=w.device)
+    return ShardedMIPS(corpus, sh.lo)
+
+
+def env_world_size() -> int:
+    return int(os.environ.get("WORLD_SIZE", "1"))

@@ -10,17 +10,27 @@ differ, both because the upstream pipeline caps at ~46 K samples/s
   * the optimiser is DenseExactAdam (same update as optim.Adam, row-form embedding grads).
 ``python -m two_tower_models_amd.train --model hist`` selects the history-encoder model
 (upstream's script only ever builds the base model).
+
+Multi-GPU: the SAME loop, one process per GPU --
+
+    torchrun --nproc_per_node N --master-addr 127.0.0.1 -m two_tower_models_amd.train --world_size N ...
+
+-- every rank builds the model under ``parallel.row_sharded()`` (each table's rows split N ways, replicated dense
+parameters), draws its own ``num_samples / N`` records and runs ``train_one_epoch`` unchanged; ``--batch_size`` is per
+rank and the loss is the reference's on the concatenated batch of N x batch_size rows (global in-batch negatives).
 """
 from __future__ import annotations
 
 import argparse
+import contextlib
+import os
 import time
 from typing import Optional
 
 import torch
 
 from . import BaselineMIPSModule, DenseExactAdam, TwoTowerBaseRetrieval, TwoTowerWithDebiasing, \
-    TwoTowerWithUserHistoryEncoder
+    TwoTowerWithUserHistoryEncoder, parallel
 
 
 class DummyRecDataset:
@@ -77,13 +87,21 @@ class DeviceBatches:
 
 def train_one_epoch(model, dataloader, optimizer, device):
     """ref:train/train.py:85-135: forward -> zero_grad -> backward -> step per batch; returns
-    the mean loss.  The per-step ``.item()`` of upstream is replaced by one at the end."""
+    the mean loss.  The per-step ``.item()`` of upstream is replaced by one at the end.
+    Row-sharded model: the NEXT batch's lookups are announced underneath the current step (parallel.plan_ahead), which
+    is what lets the host run ahead of the GPU; purely a scheduling hint."""
     model.train()
     total_loss = None
-    for batch in dataloader:
+    sharded = parallel.is_sharded(model)
+    batches = iter(dataloader)
+    batch = next(batches, None)
+    while batch is not None:
         user_ids, user_features, user_history, item_ids, item_features, positions, labels = (t.to(device) for t in batch)
         batch_loss = model.train_forward(user_ids, user_features, user_history, item_ids, item_features,
                                          positions, labels)
+        batch = next(batches, None)
+        if sharded and batch is not None:
+            parallel.plan_ahead(model._lookup_plan(batch[0], batch[2], batch[3]))
         optimizer.zero_grad()
         batch_loss.backward()
         optimizer.step()
@@ -94,11 +112,38 @@ def train_one_epoch(model, dataloader, optimizer, device):
 MODELS = {"base": TwoTowerBaseRetrieval, "hist": TwoTowerWithUserHistoryEncoder, "debias": TwoTowerWithDebiasing}
 
 
+def _init_distributed(world: int):
+    """One process per GPU over RCCL (torch.distributed backend "nccl").  TT_DIST_BACKEND=gloo: test hook -- every rank
+    on cuda:0, exchanging through gloo (RCCL refuses two ranks on one device)."""
+    import torch.distributed as dist
+    if "RANK" not in os.environ:
+        raise SystemExit(f"--world_size {world}: launch one process per GPU, e.g.\n  torchrun --nproc_per_node {world} "
+                         f"--master-addr 127.0.0.1 -m two_tower_models_amd.train --world_size {world} ...")
+    if int(os.environ.get("WORLD_SIZE", "1")) != world:
+        raise SystemExit(f"--world_size {world} but the launcher started {os.environ.get('WORLD_SIZE')} ranks")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC
+    backend = os.environ.get("TT_DIST_BACKEND", "nccl")
+    device = torch.device(f"cuda:{int(os.environ.get('LOCAL_RANK', '0')) if backend == 'nccl' else 0}")
+    torch.cuda.set_device(device)
+    if not dist.is_initialized():
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    return device, dist.get_rank()
+
+
 def main(args):
     if not torch.cuda.is_available():
         raise SystemExit("two_tower_models_amd.train needs an MI355X (ROCm) device; there is no CPU path")
-    device = torch.device("cuda")
-    print(f"Running on device: {device}")
+    world = int(getattr(args, "world_size", 0) or os.environ.get("WORLD_SIZE", "1"))
+    rank = 0
+    if world > 1:
+        device, rank = _init_distributed(world)
+    else:
+        device = torch.device("cuda")
+    say = print if rank == 0 else (lambda *a, **k: None)
+    say(f"Running on device: {device}" + (f" (x{world}, row-sharded tables)" if world > 1 else ""))
     # tables and the (random, upstream-style) MIPS corpus are initialised directly in HBM
     with torch.device(device):
         mips_module = BaselineMIPSModule(corpus_size=args.num_items, embedding_dim=args.embedding_dim)
@@ -108,11 +153,15 @@ def main(args):
               item_features_size=args.feature_dim, user_value_weights=[1.0], mips_module=mips_module)
     if args.model != "base":
         kw["user_history_seqlen"] = args.user_history_seqlen
-    with torch.device(device):
+    with torch.device(device), (parallel.row_sharded() if world > 1 else contextlib.nullcontext()):
         model = MODELS[args.model](**kw)
     model = model.to(device)
-    dataset = DummyRecDataset(num_samples=args.num_samples, num_users=args.num_users, num_items=args.num_items,
-                              feature_dim=args.feature_dim, user_history_seqlen=args.user_history_seqlen, device=device)
+    if world > 1:
+        parallel.shard_model_(model)
+    # every rank draws its own records (a different stream per rank: the ranks' default generators start identical)
+    dataset = DummyRecDataset(num_samples=max(args.num_samples // world, 1), num_users=args.num_users, num_items=args.num_items,
+                              feature_dim=args.feature_dim, user_history_seqlen=args.user_history_seqlen, device=device,
+                              seed=(20240 + rank) if world > 1 else None)
     dataloader = DeviceBatches(dataset, batch_size=args.batch_size, shuffle=True)
     # the loop below is exactly train_forward -> zero_grad -> backward -> step, which is what the
     # forward-announced sweep start assumes (optim.py)
@@ -124,12 +173,16 @@ def main(args):
         t0 = time.perf_counter()
         avg_loss = train_one_epoch(model, dataloader, optimizer, device)  # ends with .item(): the device has drained
         dt = time.perf_counter() - t0
-        print(f"Epoch [{epoch + 1}/{args.num_epochs}] - Loss: {avg_loss:.4f}")
-        stats.append({"epoch": epoch + 1, "loss": avg_loss, "seconds": dt, "pairs_per_s": len(dataset) / dt})
+        say(f"Epoch [{epoch + 1}/{args.num_epochs}] - Loss: {avg_loss:.4f}")
+        stats.append({"epoch": epoch + 1, "loss": avg_loss, "seconds": dt, "pairs_per_s": len(dataset) * world / dt})
         if getattr(args, "report_throughput", False):
-            print(f"  {len(dataset) / dt:,.0f} user-item pairs/s end to end (shuffle + batch slicing + step), "
-                  f"{dt / len(dataloader) * 1e3:.3f} ms/step")
+            say(f"  {len(dataset) * world / dt:,.0f} user-item pairs/s end to end (shuffle + batch slicing + step), "
+                f"{dt / len(dataloader) * 1e3:.3f} ms/step")
     optimizer.flush()  # deferred schedule: the tables are complete again from here on
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     return stats
 
 
@@ -152,6 +205,9 @@ def build_parser() -> argparse.ArgumentParser:
         p.add_argument(flag, type=typ, default=default, help=hlp)
     p.add_argument("--model", choices=sorted(MODELS), default="base", help="model variant (upstream: base only)")
     p.add_argument("--report_throughput", action="store_true", help="print end-to-end pairs/s per epoch")
+    p.add_argument("--world_size", type=int, default=0,
+                   help="row-shard the tables over this many GPUs (one process per GPU under torchrun; default: WORLD_SIZE "
+                        "from the launcher, else 1); --batch_size and the printed loss are per rank / of the global batch")
     p.add_argument("--lazy_adam", action="store_true",
                    help="value-exact deferred Adam: replay a row's zero-gradient steps when it is next needed")
     return p

@@ -7,6 +7,12 @@ submodules created in ``__init__`` (nn.Embedding / nn.Sequential / nn.Linear)
 are parameter CONTAINERS only: they give the reference's state_dict keys and
 its default initialisation (same RNG draws in the same order), and are never
 called.  All arithmetic runs in libtt_hotpath.so through ``ops``.
+
+Multi-GPU: the same class, built under ``parallel.row_sharded()`` or passed through
+``parallel.shard_model_``, holds only this rank's row block of each table.  ``train_forward`` then computes the
+reference's loss on the CONCATENATED batch of all ranks (routed lookups, global in-batch negatives, group-wide
+value-weight maximum) and ``loss.backward()`` / ``DenseExactAdam.step()`` apply the reference's update; every hook
+below stays overridable.
 """
 from __future__ import annotations
 
@@ -17,6 +23,7 @@ import torch.nn as nn
 
 from . import _native as N
 from . import ops
+from . import parallel
 from .baseline_mips_module import BaselineMIPSModule
 
 _FEATURE_HIDDEN = 256  # ref:src/two_tower_base_retrieval.py:76-80
@@ -54,10 +61,10 @@ class TwoTowerBaseRetrieval(nn.Module):
         self.user_value_weights = torch.tensor(user_value_weights)
         self.mips_module = mips_module
         # creation order == reference order (:70-110) so a seeded init is bit-identical
-        self.user_id_embedding_arch = nn.Embedding(user_id_hash_size, user_id_embedding_dim)
+        self.user_id_embedding_arch = parallel.embedding(user_id_hash_size, user_id_embedding_dim)
         self.user_features_arch = _feature_mlp(user_features_size, user_id_embedding_dim)
         self.user_tower_arch = nn.Linear(2 * user_id_embedding_dim, item_id_embedding_dim)
-        self.item_id_embedding_arch = nn.Embedding(item_id_hash_size, item_id_embedding_dim)
+        self.item_id_embedding_arch = parallel.embedding(item_id_hash_size, item_id_embedding_dim)
         self.item_features_arch = _feature_mlp(item_features_size, item_id_embedding_dim)
         self.item_tower_arch = nn.Linear(2 * item_id_embedding_dim, item_id_embedding_dim)
         mark_table(self.user_id_embedding_arch.weight)
@@ -164,6 +171,8 @@ class TwoTowerBaseRetrieval(nn.Module):
     ) -> torch.Tensor:
         """In-batch softmax loss weighted by normalised net user value (ref :279-347).
         The [B, B] logits are never materialised."""
+        if self._sharded():
+            return self._sharded_training_loss(user_embedding, item_embeddings, position, labels)
         hook_is_identity = type(self).debias_net_user_value is TwoTowerBaseRetrieval.debias_net_user_value
         T = self.user_value_weights.numel()
         B = user_embedding.shape[0]
@@ -179,9 +188,12 @@ class TwoTowerBaseRetrieval(nn.Module):
             row_ce = ops.InBatchSoftmaxCE.apply(user_embedding, item_embeddings, 0)  # [B]
             return ops.WeightedMeanLoss.apply(row_ce, lab, self.user_value_weights)
         row_ce = ops.InBatchSoftmaxCE.apply(user_embedding, item_embeddings, 0)  # [B]
-        # General path: exactly the reference's expressions on [B]-sized tensors, so every
-        # broadcasting quirk (1-D labels collapsing to a scalar weight, SURVEY.md 3.1;
-        # debias heads that differentiate through the weights) behaves identically.
+        return self._loss_head(row_ce, labels, position, user_embedding)
+
+    def _loss_head(self, row_ce, labels, position, user_embedding) -> torch.Tensor:
+        """General loss head: exactly the reference's expressions on [B]-sized tensors (ref :322-345), so every
+        broadcasting quirk (1-D labels collapsing to a scalar weight; debias heads that differentiate
+        through the weights) behaves identically.  Subclasses with a fused head override this."""
         net_user_value = torch.sum(labels * self.user_value_weights, dim=-1)
         net_user_value, additional_loss = self.debias_net_user_value(
             net_user_value=net_user_value, position=position, user_embedding=user_embedding
@@ -190,17 +202,51 @@ class TwoTowerBaseRetrieval(nn.Module):
         net_user_value = net_user_value / torch.max(net_user_value)
         return torch.mean(row_ce * net_user_value) + additional_loss
 
+    # ------------------------------------------------------------------ row-sharded tables (parallel.py)
+    def _sharded(self) -> bool:
+        return parallel.shard_of(self.item_id_embedding_arch.weight) is not None
+
+    def _sharded_training_loss(self, user_embedding, item_embeddings, position, labels) -> torch.Tensor:
+        """The same loss on the CONCATENATED batch of all W ranks (SURVEY.md 8e "parity definition"): every user row is
+        scored against all W*B item embeddings (all-gather; its backward is the reduce-scatter of the partial dI), the
+        positives sit at column rank*B + i.  Identity hook: the value weights' maximum and the mean are group-wide scalars
+        (two all-reduces).  Any other head -- a fused debias head or an overridden hook -- is evaluated on the gathered
+        head inputs by the single-device code, identically on every rank, and scaled 1/W in the backward."""
+        world, rank = parallel.dist.get_world_size(), parallel.dist.get_rank()
+        B = user_embedding.shape[0]
+        single_use = getattr(self, "_tt_item_emb_single_use", False)  # set by the un-overridden train_forward
+        items_all = parallel.AllGatherRows.apply(item_embeddings, "item_emb_allgather", single_use)
+        row_ce = ops.InBatchSoftmaxCE.apply(user_embedding, items_all, rank * B)  # [B], this rank's users
+        hook_is_identity = type(self).debias_net_user_value is TwoTowerBaseRetrieval.debias_net_user_value
+        T = self.user_value_weights.numel()
+        plain_mean = labels.dim() == 1 and labels.shape[0] == B and T == 1
+        weighted = labels.dim() == 2 and labels.shape[1] == T and labels.shape[0] == B
+        if hook_is_identity and ops.labels_fusable(labels) and (weighted or plain_mean):
+            return parallel.GlobalWeightedMeanLoss.apply(row_ce, labels if weighted else None, self.user_value_weights)
+        if world == 1:
+            return self._loss_head(row_ce, labels, position, user_embedding)
+        loss = self._loss_head(parallel.AllGatherRows.apply(row_ce, "head_row_ce_allgather"),
+                               parallel.gather_no_grad(labels), parallel.gather_no_grad(position),
+                               parallel.AllGatherRows.apply(user_embedding, "head_user_emb_allgather"))
+        return parallel.ReplicatedLoss.apply(loss)
+
     def _lookup_plan(self, user_id, user_history, item_id):
         """{table: [id blocks in the order this model's forward looks them up]}."""
         return {self.user_id_embedding_arch.weight: [user_id], self.item_id_embedding_arch.weight: [item_id]}
 
     def _announce_lookups(self, user_id, user_history, item_id) -> None:
-        """DenseExactAdam(overlap_sweep="forward"): tell the optimiser which rows this step reads
-        so its table sweep can start before the forward's gathers (optim.py)."""
+        """DenseExactAdam(overlap_sweep="forward"): tell the optimiser which rows this step reads so its table sweep can
+        start before the forward's gathers (optim.py).  Row-sharded tables: first start every lookup's exchange with the
+        owning ranks (parallel.begin_lookups) -- the optimiser is then told the rows THIS rank serves."""
+        if not user_id.is_cuda:
+            return
+        plan = self._lookup_plan(user_id, user_history, item_id)
+        if self._sharded():
+            plan = parallel.begin_lookups(plan)
         ref = getattr(self.item_id_embedding_arch.weight, "_tt_optimizer", None)
         opt = ref() if ref is not None else None
-        if opt is not None and user_id.is_cuda:
-            opt.begin_step(self._lookup_plan(user_id, user_history, item_id))
+        if opt is not None:
+            opt.begin_step(plan)
 
     def train_forward(
         self,
@@ -214,8 +260,15 @@ class TwoTowerBaseRetrieval(nn.Module):
     ) -> torch.Tensor:
         """Scalar training loss with an autograd graph (ref :349-394)."""
         self._announce_lookups(user_id, user_history, item_id)
-        user_embedding = self.compute_user_embedding(user_id, user_features, user_history)
-        item_embeddings = self.compute_item_embeddings(item_id, item_features)
+        if self._sharded():
+            # the item tower FIRST (the towers are independent): autograd then runs the user tower's backward before the
+            # item tower's, i.e. underneath the reduce-scatter of dI that the item tower's backward has to wait for
+            self._tt_item_emb_single_use = type(self).compute_item_embeddings is TwoTowerBaseRetrieval.compute_item_embeddings
+            item_embeddings = self.compute_item_embeddings(item_id, item_features)
+            user_embedding = self.compute_user_embedding(user_id, user_features, user_history)
+        else:
+            user_embedding = self.compute_user_embedding(user_id, user_features, user_history)
+            item_embeddings = self.compute_item_embeddings(item_id, item_features)
         return self.compute_training_loss(
             user_embedding=user_embedding, item_embeddings=item_embeddings, position=position, labels=labels
         )

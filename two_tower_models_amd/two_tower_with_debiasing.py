@@ -46,16 +46,16 @@ class TwoTowerWithDebiasing(TwoTowerWithUserHistoryEncoder):
             + F.mse_loss(pos_prior, net_user_value, reduction="sum")
         return net_user_value / torch.clamp(user_prior, min=1e-3), aux
 
-    def compute_training_loss(self, user_embedding: torch.Tensor, item_embeddings: torch.Tensor,
-                              position: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
-        """The base loss with this class's debias head, fused: one op instead of
-        ~15 elementwise launches and a [B, B] temporary.  A subclass that overrides the hook, or labels
-        of another rank, take the reference's expressions (the base class's general path)."""
+    def _loss_head(self, row_ce: torch.Tensor, labels: torch.Tensor, position: torch.Tensor,
+                   user_embedding: torch.Tensor) -> torch.Tensor:
+        """The base loss head with this class's debias hook, fused: one op instead of ~15
+        elementwise launches and a [B, B] temporary.  A subclass that overrides the hook, or labels the kernel does not
+        take, get the reference's expressions (the base class's head).  Row-sharded training calls this on the
+        gathered batch (TwoTowerBaseRetrieval._sharded_training_loss)."""
         hook_is_mine = type(self).debias_net_user_value is TwoTowerWithDebiasing.debias_net_user_value
         if not (_FUSED_HEAD and hook_is_mine and labels.dim() == 2 and labels.shape[1] == self.user_value_weights.numel()
                 and ops.labels_fusable(labels) and user_embedding.is_cuda):
-            return super().compute_training_loss(user_embedding, item_embeddings, position, labels)
-        row_ce = ops.InBatchSoftmaxCE.apply(user_embedding, item_embeddings, 0)  # [B]
+            return super()._loss_head(row_ce, labels, position, user_embedding)
         lin = self.user_debias_net_user_value[0]
         return ops.DebiasedWeightedLoss.apply(row_ce, labels, self.user_value_weights, position, user_embedding,
                                               self.position_bias_net_user_value.weight, lin.weight, lin.bias)

@@ -40,12 +40,11 @@ class TwoTowerWithPositionDebiasedWeights(TwoTowerWithUserHistoryEncoder):
         aux = torch.sum((prior - net_user_value) ** 2)
         return net_user_value / prior.clamp(min=1e-3), aux
 
-    def compute_training_loss(self, user_embedding: torch.Tensor, item_embeddings: torch.Tensor,
-                              position: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    def _loss_head(self, row_ce: torch.Tensor, labels: torch.Tensor, position: torch.Tensor,
+                   user_embedding: torch.Tensor) -> torch.Tensor:
         hook_is_mine = type(self).debias_net_user_value is TwoTowerWithPositionDebiasedWeights.debias_net_user_value
         if not (_FUSED_HEAD and hook_is_mine and labels.dim() == 2 and labels.shape[1] == self.user_value_weights.numel()
                 and ops.labels_fusable(labels) and user_embedding.is_cuda):
-            return super().compute_training_loss(user_embedding, item_embeddings, position, labels)
-        row_ce = ops.InBatchSoftmaxCE.apply(user_embedding, item_embeddings, 0)  # [B]
+            return super()._loss_head(row_ce, labels, position, user_embedding)
         return ops.DebiasedWeightedLoss.apply(row_ce, labels, self.user_value_weights, position, user_embedding,
                                               self.position_bias_net_user_value.weight, None, None, N.TT_DEBIAS_POSITION)

@@ -69,6 +69,7 @@ class TwoTowerWithUserHistoryEncoder(TwoTowerBaseRetrieval):
         return super().compute_user_embedding(user_id, user_features, user_history)
 
     def _lookup_plan(self, user_id, user_history, item_id):
-        # forward order: history rows (encoder), then the user row, then the item row
-        return {self.user_id_embedding_arch.weight: [user_id],
-                self.item_id_embedding_arch.weight: [user_history, item_id]}
+        # forward order: history rows (encoder), then the user row, then the item row; row-sharded tables: the item
+        # tower runs first (TwoTowerBaseRetrieval.train_forward), so the item row is the item table's first lookup
+        item_blocks = [item_id, user_history] if self._sharded() else [user_history, item_id]
+        return {self.user_id_embedding_arch.weight: [user_id], self.item_id_embedding_arch.weight: item_blocks}
