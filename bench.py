@@ -662,8 +662,8 @@ def main():
 
     use_sharded = world > 1 or args.sharded
     n_ranks, dist_backend_seen = 1, None
-    if use_sharded and (args.adam != "dense" or args.fresh_ids or args.phase != "step"):
-        raise SystemExit("--adam lazy / --fresh-ids / --phase apply to the single-GPU module path")
+    if use_sharded and (args.adam != "dense" or args.fresh_ids or args.phase != "step" or args.graph):
+        raise SystemExit("--adam lazy / --fresh-ids / --phase / --graph apply to the single-GPU module path")
     check = watchdog = None
     if use_sharded:
         import torch.distributed as dist
@@ -767,7 +767,7 @@ def main():
     barrier()
     lib.tt_profile_enable(1)
     if use_sharded:
-        sharded.comm_timing(True)  # per-exchange events over the timed steps -> `comm.ms_per_step` below
+        collectives.comm_timing(True)  # per-exchange events over the timed steps -> `comm.ms_per_step` below
     import gc
     gc.collect()
     gc.disable()  # no cyclic-GC pause inside the timed region (the loop allocates no cycles that would need it)
@@ -780,13 +780,17 @@ def main():
     dt = time.perf_counter() - t0
     gc.enable()
     comm_ms = None
+    rank_ms = None
     if use_sharded:
-        comm_ms = sharded.comm_timing_summary(args.steps)
-        sharded.comm_timing(False)
+        comm_ms = collectives.comm_timing_summary(args.steps)
+        collectives.comm_timing(False)
+        if watchdog is not None:
+            watchdog.close()
     if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        sharded.all_reduce_(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
+        mine = torch.tensor([dt], device=device, dtype=torch.float64)
+        every = collectives.all_gather_rows(mine)
+        rank_ms = {"min": round(float(every.min()) / args.steps * 1e3, 4), "max": round(float(every.max()) / args.steps * 1e3, 4)}
+        dt = float(every.max())
 
     if main_ctx is not None:
         main_ctx.__exit__(None, None, None)
@@ -831,10 +835,10 @@ def main():
             # With the tables sharded over many GPUs the sweep shrinks 1/N while the global-negative
             # logits grow N-fold: report whichever kernel family actually dominates the step.
             if ce_cnt.value > 0 and ce_ms.value > ms.value:
-                n_neg = B * world if (use_sharded and args.negatives == "global") else B
+                n_neg = B * world if use_sharded else B
                 # one gradient product per launch (dI); ce_bwd_kernel also recomputes its logits tile,
-                # ce_bwd_kept_kernel reads the logits the forward kept (sharded trainer, wide negative sets)
-                kept = use_sharded and getattr(trainer.be, "keep_logits", False)
+                # ce_bwd_kept_kernel reads the logits the forward kept (wide negative sets: N >= 4 M, ops.InBatchSoftmaxCE)
+                kept = use_sharded and world >= 4
                 flops = 2.0 * B * n_neg * cfg["D"]
                 tf = flops * ce_cnt.value / (ce_ms.value * 1e-3) / 1e12
                 roof = {"bound": "mfma", "kernel": "ce_bwd_kept_kernel" if kept else "ce_bwd_kernel",
@@ -855,7 +859,7 @@ def main():
                                    + (", debias loss head" if cfg['model'] == 'debias' else ""),
                        "global_batch": B * world,
                        "parallelism": ("single GPU" + (", whole-step hipGraph" if args.graph else "")) if not use_sharded else
-                       f"row-sharded tables x{world}, {args.negatives} in-batch negatives, "
+                       f"row-sharded tables x{world} behind the module API (parallel.py), global in-batch negatives, "
                        + ("RCCL" if dist_backend == "nccl" else dist_backend)},
             "roofline": roof,
             # what the collective library itself reports (1 when no process group was needed)
@@ -864,16 +868,19 @@ def main():
         # tuned kernels that did NOT run for this shape, each with the constraint that ruled it out ({} = all taken)
         from two_tower_models_amd import ops as _ops
         out["generic_paths"] = dict(_ops.generic_paths)
-        if use_sharded:  # bytes each rank sends to its peers per step, by exchange (sharded.py)
-            out["comm"] = {"routing": trainer.routing, "transport": trainer.transport, "bytes_sent_per_rank_per_step": dict(trainer.comm_bytes),
-                           "total_MB": round(sum(trainer.comm_bytes.values()) / 1e6, 2),
+        if use_sharded:  # bytes each rank sends to its peers per step, by exchange (parallel.py)
+            out["comm"] = {"transport": args.transport, "bytes_sent_per_rank_per_step": dict(parallel.comm_bytes),
+                           "total_MB": round(sum(parallel.comm_bytes.values()) / 1e6, 2),
                            # rank 0, HIP events around every exchange of the timed steps, ms per step:  span = issue -> result
                            # usable (the cost if nothing overlapped it), exposed = how long the compute stream stood still
                            # at the wait (what the exchange actually adds to the step), wire = the collective alone (native
                            # transport only).  A bad 1 -> 8 curve is read off `exposed_ms` by exchange.
                            "ms_per_step": comm_ms,
                            "exposed_ms_per_step_total": round(sum(v["exposed_ms"] for v in (comm_ms or {}).values()), 4),
-                           "schedule": getattr(trainer, "schedule_note", lambda: None)()}
+                           "schedule": {"table_sweep": "forward-announced (starts once the owners have served the step's lookups)",
+                                        "sweep_workgroups": opt._sweep_wgs or 768, "sweep_level_decided_by": opt.sweep_level_note()}}
+            out["rank_ms_per_step"] = rank_ms  # slowest / fastest rank's own clock over the timed steps (null at N = 1)
+            out["check"] = check
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         else:
@@ -889,6 +896,7 @@ def main():
             out["secondary"] = secondary(device, lib, N)
         result = json.dumps(out)
     if use_sharded:
+        collectives.use_native_transport(None)
         torch.distributed.destroy_process_group()
     if rank == 0:
         # RCCL prints its version banner through C stdio; flush that first so the JSON line

@@ -104,3 +104,16 @@ def test_bench_roofline_traffic_key_resolves():
     flat = os.path.join(os.environ.get("TMPDIR", "/tmp"), "pmc_flat_test.json")
     json.dump(json.load(open(path))["P_gpus1"], open(flat, "w"))
     assert bench.pmc_traffic_bytes(flat, "P", 1) == got
+
+
+def test_reference_package_name_resolves_to_this_implementation():
+    """`from src.<module> import <Class>` (the reference's layout, ref:tests/conftest.py:1-6) gives this package's classes."""
+    import two_tower_models_amd as A
+    from src.baseline_mips_module import BaselineMIPSModule
+    from src.two_tower_base_retrieval import TwoTowerBaseRetrieval
+    from src.two_tower_with_debiasing import TwoTowerWithDebiasing
+    from src.two_tower_with_user_history_encoder import TwoTowerWithUserHistoryEncoder
+    from src.user_history_encoder import UserHistoryEncoder
+    assert TwoTowerBaseRetrieval is A.TwoTowerBaseRetrieval and BaselineMIPSModule is A.BaselineMIPSModule
+    assert TwoTowerWithDebiasing is A.TwoTowerWithDebiasing and UserHistoryEncoder is A.UserHistoryEncoder
+    assert TwoTowerWithUserHistoryEncoder is A.TwoTowerWithUserHistoryEncoder

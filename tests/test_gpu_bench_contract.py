@@ -75,8 +75,8 @@ def test_self_launch_needs_no_env():
     assert out["dist_backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")
 
 
-def test_sharded_trainer_at_world1_matches_the_module_path_headline():
-    """`bench.py --sharded --gpus 1` (ShardedTrainer over an RCCL group of one: the N = 1 point a scaling run starts
+def test_sharded_module_path_at_world1_matches_the_single_gpu_headline():
+    """`bench.py --sharded --gpus 1` (the row-sharded module path over an RCCL group of one: the N = 1 point a scaling run starts
     from) against the module-path headline `bench.py` on the same box, same P shapes, back to back: within 5 %
     (round-4 measurements: 0.97-1.03 on five boxes; the two paths launch the same sweep / logits / tower kernels and
     differ in the routing kernels of the sharded lookups).  The multi-rank line's `comm` record carries per-exchange

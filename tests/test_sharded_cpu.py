@@ -1,7 +1,12 @@
-"""Multi-rank path on CPU: world_size 2 and 3 under gloo, compute supplied by the oracle
-test double.  Checks that W row-sharded ranks reproduce the single-process reference
-semantics on the CONCATENATED batch (global in-batch negatives): same loss trajectory, same
-updated tables (touched and untouched rows) and dense parameters."""
+"""The multi-rank exchange logic of two_tower_models_amd.parallel on CPU: world sizes 2-4 under gloo, the four routing
+kernels supplied by the torch restatement in tests/sharded_cpu_backend.py, the towers / logits / loss by the oracle's
+torch expressions.  What runs from the PRODUCT is everything that decides who is sent what: `begin_lookups` /
+`plan_ahead` / `routed_source` / `route_grad_rows` (through `ops.lookup_source` and `ops._route_table_grad`, the calls
+the HIP autograd Functions make), `AllGatherRows` (all-gather forward, reduce-scatter backward), `ReplicatedLoss`, the
+flat dense all-reduce, `shard_model_` / `full_state_dict` / `load_full_state_dict`, `ShardedMIPS`.
+
+Checked against the oracle on the CONCATENATED batch: the loss, the gradient every OWNER receives for
+its row block (ids + rows, summed), the all-reduced dense gradients."""
 import os
 import socket
 import sys
@@ -14,7 +19,7 @@ import torch.multiprocessing as mp
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-CFG = dict(n_users=53, n_items=71, D=16, F=4, B=8, H=2)
+CFG = dict(n_users=53, n_items=71, D=16, F=4, B=8, H=3)
 STEPS = 3
 
 
@@ -26,231 +31,206 @@ def _free_port():
     return p
 
 
-def _dense_init(cfg):
+def _paths():
+    for p in (ROOT, HERE, os.path.join(HERE, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _params(cfg, hist):
     g = torch.Generator().manual_seed(5)
     D, F = cfg["D"], cfg["F"]
-    out = {}
+    out = {"user_id_embedding_arch.weight": 0.5 * torch.randn(cfg["n_users"], D, generator=g),
+           "item_id_embedding_arch.weight": 0.5 * torch.randn(cfg["n_items"], D, generator=g)}
     for side in ("user", "item"):
         out[f"{side}_features_arch.0.weight"] = torch.randn(256, F, generator=g) * 0.3
         out[f"{side}_features_arch.0.bias"] = torch.randn(256, generator=g) * 0.1
         out[f"{side}_features_arch.2.weight"] = torch.randn(D, 256, generator=g) * 0.06
         out[f"{side}_features_arch.2.bias"] = torch.randn(D, generator=g) * 0.1
-        out[f"{side}_tower_arch.weight"] = torch.randn(D, 2 * D, generator=g) * 0.2
+        wide = 4 * D if (hist and side == "user") else 2 * D
+        out[f"{side}_tower_arch.weight"] = torch.randn(D, wide, generator=g) * 0.2
         out[f"{side}_tower_arch.bias"] = torch.randn(D, generator=g) * 0.1
+    if hist:
+        for l in range(3):
+            base = f"user_history_encoder.multihead_attn_layers.{l}."
+            out[base + "in_proj_weight"] = torch.randn(3 * D, D, generator=g) * 0.2
+            out[base + "in_proj_bias"] = torch.randn(3 * D, generator=g) * 0.05
+            out[base + "out_proj.weight"] = torch.randn(D, D, generator=g) * 0.2
+            out[base + "out_proj.bias"] = torch.randn(D, generator=g) * 0.05
     return out
 
 
-def _tables(cfg):
-    g = torch.Generator().manual_seed(6)
-    return torch.randn(cfg["n_users"], cfg["D"], generator=g), torch.randn(cfg["n_items"], cfg["D"], generator=g)
+def _batches(cfg, rank, n, seed=99):
+    gen = torch.Generator().manual_seed(seed + 1000 * rank)
+    B, F = cfg["B"], cfg["F"]
+    return [(torch.randint(0, cfg["n_users"], (B,), generator=gen), torch.randn(B, F, generator=gen),
+             torch.randint(0, cfg["n_items"], (B, cfg["H"]), generator=gen),
+             torch.randint(0, cfg["n_items"], (B,), generator=gen), torch.randn(B, F, generator=gen),
+             torch.randint(0, 10, (B,), generator=gen), torch.randint(0, 2, (B, 1), generator=gen).float())
+            for _ in range(n)]
 
 
-def _worker(rank, world, port, outdir, negatives, routing="alltoall"):
-    for p in (ROOT, HERE, os.path.join(HERE, "golden")):
-        if p not in sys.path:
-            sys.path.insert(0, p)
+class _Lookup(torch.autograd.Function):
+    """What every HIP Function that reads a table does (ops.EmbeddingLookup): lookup_source in the forward,
+    _route_table_grad in the backward -- with the gather itself in torch."""
+
+    @staticmethod
+    def forward(ctx, weight, ids):
+        from two_tower_models_amd import ops
+        src, row_ids, ctx.index = ops.lookup_source(weight, ids, True)
+        ctx.weight, ctx.ids = weight, ids
+        return src[row_ids].view(*ids.shape, weight.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        from two_tower_models_amd import ops
+        w = ctx.weight
+        return ops._route_table_grad(w, ctx.ids.reshape(-1), g.reshape(-1, w.shape[1]), ctx.index), None
+
+
+def _worker(rank, world, port, outdir, cfg, hist):
+    _paths()
     import torch.distributed as dist
-    from sharded_cpu_backend import OracleBackend
-    from two_tower_models_amd import sharded
+    from oracle import cpu_ref as R
+    from sharded_cpu_backend import OracleRouteKernels
+    from two_tower_models_amd import parallel
     torch.set_num_threads(1)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    parallel.set_route_kernels_for_tests(OracleRouteKernels())
     try:
-        tr = sharded.ShardedTrainer(CFG, torch.device("cpu"), negatives=negatives, backend=OracleBackend(),
-                                    user_value_weights=(0.7,), dense_init=_dense_init(CFG), routing=routing)
-        ut, it = _tables(CFG)
-        tr.users.weight.copy_(ut[tr.users.lo:tr.users.hi])
-        tr.items.weight.copy_(it[tr.items.lo:tr.items.hi])
-        # checkpoint adaptor: a reference-format state_dict round-trips through the shards
-        full = dict(_dense_init(CFG))
-        full["user_id_embedding_arch.weight"], full["item_id_embedding_arch.weight"] = ut, it
-        tr.load_state_dict(full)
-        back = tr.state_dict()
-        assert all(torch.equal(back[k], full[k]) for k in full), "state_dict round trip"
-        batches = tr.make_batches(STEPS, seed=99)
-        if routing == "alltoall":  # every id of step 1 on ONE owner: the most lopsided buckets there are
+        full = _params(cfg, hist)
+        # a module with the reference's two table names: shard_model_ cuts the blocks, full_state_dict reassembles them
+        holder = torch.nn.Module()
+        holder.user_id_embedding_arch = torch.nn.Embedding(cfg["n_users"], cfg["D"])
+        holder.item_id_embedding_arch = torch.nn.Embedding(cfg["n_items"], cfg["D"])
+        holder.dense = torch.nn.ParameterDict({k.replace(".", "/"): torch.nn.Parameter(v.clone()) for k, v in full.items()
+                                               if "embedding_arch" not in k})
+        for name in ("user", "item"):
+            w = getattr(holder, f"{name}_id_embedding_arch").weight
+            w.data.copy_(full[f"{name}_id_embedding_arch.weight"])
+            w._tt_is_table = True
+        if rank != 0:  # replicas must come out of shard_model_ as rank 0's
+            with torch.no_grad():
+                for p in holder.dense.values():
+                    p.add_(1.0)
+        parallel.shard_model_(holder)
+        back = parallel.full_state_dict(holder)
+        assert all(torch.equal(back[f"{n}_id_embedding_arch.weight"], full[f"{n}_id_embedding_arch.weight"]) for n in ("user", "item"))
+        assert all(torch.equal(p.data, full[k.replace("/", ".")]) for k, p in holder.dense.items()), "dense broadcast"
+        parallel.load_full_state_dict(holder, back)  # round trip
+        tables = {"user": holder.user_id_embedding_arch.weight, "item": holder.item_id_embedding_arch.weight}
+        for w in tables.values():  # what DenseExactAdam attaches
+            w._tt_rowgrads, w._tt_lookups = [], []
+        dense = {k.replace("/", "."): p for k, p in holder.dense.items()}
+        pe = R.positional_table(cfg["H"], cfg["D"]) if hist else None
+        batches = _batches(cfg, rank, STEPS)
+        if world == 2:  # every user id of step 1 on ONE owner: the most lopsided buckets there are
             batches[1][0].fill_(int(batches[1][0][0]))
-            batches[1][3].copy_(batches[1][3] % max(tr.items.rows_per_rank, 1))
-        # routes of the next batch are planned one step ahead, except for the last one (planned on the spot)
-        losses = []
-        for i, b in enumerate(batches):
-            losses.append(float(tr.step(b, batches[i + 1] if i + 2 < len(batches) else None)))
-            if i == 0 and routing == "alltoall":
-                # a static input buffer REFILLED IN PLACE after it was announced: same storage, new ids.  The
-                # planned routes must not be applied to them (they were counted for the old ids).
-                batches[1][0].copy_(torch.roll(batches[1][0], 3) if rank else batches[1][0].flip(0))
-                batches[1][3].copy_((batches[1][3] * 7 + 3) % CFG["n_items"])
-        # serve the trained item table: this rank's catalogue block -> item tower -> ShardedMIPS
-        gq = torch.Generator().manual_seed(31)
-        cat_feats = torch.randn(CFG["n_items"], CFG["F"], generator=gq)
-        queries = torch.randn(4 * world, CFG["D"], generator=gq)[rank * 4:(rank + 1) * 4]
-        served = tr.index_corpus(cat_feats[tr.items.lo:tr.items.hi]).search(queries, 9)
-        torch.save({"losses": losses, "users": tr.users.weight.clone(), "items": tr.items.weight.clone(),
-                    "served": served, "cat_feats": cat_feats, "queries": queries,
-                    "lo_hi": (tr.users.lo, tr.users.hi, tr.items.lo, tr.items.hi),
-                    "dense": {k: v.clone() for k, v in tr.params.items()}, "comm": dict(tr.comm_bytes),
-                    "batches": [tuple(t.clone() for t in b) for b in batches]},
-                   os.path.join(outdir, f"rank{rank}.pt"))
+        out = []
+        uvw = torch.tensor([0.7])
+        for s, (uid, uf, hid, iid, itf, pos, lab) in enumerate(batches):
+            for w in tables.values():
+                w._tt_rowgrads.clear()
+                w._tt_lookups.clear()
+            for p in dense.values():
+                p.grad = None
+            plan = {tables["user"]: [uid], tables["item"]: ([iid, hid] if hist else [iid])}
+            owner_plan = parallel.begin_lookups(plan)
+            # the owners' view: one local-id block per lookup, sentinel n_local where the slot is padding
+            for w, blocks in owner_plan.items():
+                sh = parallel.shard_of(w)
+                assert len(blocks) == len(plan[w]) and all(int(b.max()) <= sh.n_local and int(b.min()) >= 0 for b in blocks)
+            if s == 0:
+                # batch 1 announced a step ahead, then REFILLED IN PLACE (same storage, new ids): the planned routes must
+                # not be applied to it (they were counted for the old ids)
+                nb = batches[1]
+                parallel.plan_ahead({tables["user"]: [nb[0]], tables["item"]: ([nb[3], nb[2]] if hist else [nb[3]])})
+                nb[3].copy_((nb[3] * 7 + 3) % cfg["n_items"])
+            i_emb = _Lookup.apply(tables["item"], iid)
+            p_all = dict(dense)
+            p_item = {k: v for k, v in p_all.items()}
+            f_i = R.feature_mlp(itf, p_item, "item_features_arch.")
+            I = torch.cat([i_emb, f_i], dim=1) @ dense["item_tower_arch.weight"].t() + dense["item_tower_arch.bias"]
+            pieces = []
+            if hist:
+                h_rows = _Lookup.apply(tables["item"], hid)  # [B, H, D]
+                layers = R.encoder_layers_from_params(p_all)
+                pieces = [R.history_encoder_forward(h_rows, layers, 4, pe).reshape(uid.shape[0], -1)]
+            u_emb = _Lookup.apply(tables["user"], uid)
+            f_u = R.feature_mlp(uf, p_all, "user_features_arch.")
+            U = torch.cat([u_emb, f_u] + pieces, dim=1) @ dense["user_tower_arch.weight"].t() + dense["user_tower_arch.bias"]
+            # global negatives + the replicated loss head on the gathered [W*B] inputs
+            I_all = parallel.AllGatherRows.apply(I, "item_emb_allgather", True)
+            ce = R.inbatch_rowwise_ce(U, I_all, diag_offset=rank * uid.shape[0])
+            ce_g = parallel.AllGatherRows.apply(ce, "head_row_ce_allgather")
+            nuv = R.normalise_value_weights(R.net_user_value(parallel.gather_no_grad(lab), uvw))
+            loss = parallel.ReplicatedLoss.apply((ce_g * nuv).sum() / ce_g.shape[0])
+            loss.backward()
+            names = list(dense)
+            flat = torch.cat([dense[k].grad.reshape(-1) for k in names])
+            flat = parallel.all_reduce_dense_start(flat).wait()
+            got_tab = {}
+            for name, w in tables.items():
+                sh = parallel.shard_of(w)
+                g = torch.zeros(sh.n_local + 1, sh.dim)
+                assert len(w._tt_rowgrads) == len(plan[w]) and sorted(b.index for b in w._tt_rowgrads) == list(range(len(plan[w])))
+                for b in w._tt_rowgrads:
+                    g.index_add_(0, b.ids, b.rows)  # sentinel rows land in the extra row
+                got_tab[name] = (sh.lo, sh.hi, g[: sh.n_local].clone())
+            off, got_dense = 0, {}
+            for k in names:
+                got_dense[k] = flat[off:off + dense[k].numel()].view_as(dense[k]).clone()
+                off += dense[k].numel()
+            out.append({"loss": float(loss), "tables": got_tab, "dense": got_dense, "comm": dict(parallel.comm_bytes)})
+        torch.save({"steps": out, "batches": batches}, os.path.join(outdir, f"rank{rank}.pt"))
     finally:
+        parallel.set_route_kernels_for_tests(None)
         dist.destroy_process_group()
 
 
-def _run(world, negatives, routing="alltoall"):
-    outdir = tempfile.mkdtemp()
-    mp.spawn(_worker, args=(world, _free_port(), outdir, negatives, routing), nprocs=world, join=True)
-    return [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(world)]
-
-
-@pytest.mark.parametrize("world,routing", [(2, "alltoall"), (3, "alltoall"), (2, "allgather"), (3, "allgather")])
-def test_global_negatives_equal_reference_on_concatenated_batch(world, routing):
-    """`alltoall`: owners are sent only their own ids (padded fixed-capacity all-to-all, capacity all-reduced
-    one step ahead); `allgather`: round 1's fixed-size scheme.  Same reference semantics either way."""
+@pytest.mark.parametrize("world,hist,cfg", [(2, False, CFG), (3, False, CFG), (2, True, CFG), (3, True, dict(CFG, H=5, B=6)),
+                                            # fewer item rows than ranks x rows-per-rank: the last rank owns NO item row
+                                            (4, False, dict(CFG, n_items=9, B=5))])
+def test_exchanges_deliver_the_reference_gradients_of_the_concatenated_batch(world, hist, cfg):
+    _paths()
     from oracle import cpu_ref as R
-    res = _run(world, "global", routing)
-    assert ("lookup_rows_alltoall" in res[0]["comm"]) == (routing == "alltoall")
-    ut, it = _tables(CFG)
-    params = dict(_dense_init(CFG))
-    params["user_id_embedding_arch.weight"] = ut.clone()
-    params["item_id_embedding_arch.weight"] = it.clone()
-    state = R.AdamState(params)
-    uvw = torch.tensor([0.7])
-    want_losses = []
+    outdir = tempfile.mkdtemp()
+    mp.spawn(_worker, args=(world, _free_port(), outdir, cfg, hist), nprocs=world, join=True)
+    res = [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(world)]
+    params = _params(cfg, hist)
+    kw = dict(with_history=True, heads=4, pos_table=R.positional_table(cfg["H"], cfg["D"])) if hist else {}
     for s in range(STEPS):
         cat = [torch.cat([res[r]["batches"][s][k] for r in range(world)]) for k in range(7)]
-        want_losses.append(R.train_step(params, state, cat, uvw))
-    # the catalogue served from the shards == exact top-K over the item tower applied to the trained reference table.
-    # (The two item-side biases carry +-lr steps of noise -- zero true gradient -- which shifts EVERY item embedding by
-    # the same vector: each query's scores move by one constant, the ranking does not.)
-    corpus = R.item_embeddings(params, torch.arange(CFG["n_items"]), res[0]["cat_feats"])
-    for r in range(world):
-        want_idx, want_sc, _ = R.mips_topk(res[r]["queries"], corpus, 9)
-        got_idx, got_sc = res[r]["served"]
-        shift = (got_sc - want_sc)
-        assert float((shift - shift[:, :1]).abs().max()) < 1e-4 and float((got_idx == want_idx).float().mean()) > 0.95
-    for r in range(world):
-        assert np.allclose(res[r]["losses"], want_losses, atol=1e-5), (res[r]["losses"], want_losses)
-        ulo, uhi, ilo, ihi = res[r]["lo_hi"]
-        assert torch.allclose(res[r]["users"][: uhi - ulo], params["user_id_embedding_arch.weight"][ulo:uhi], atol=2e-6)
-        assert torch.allclose(res[r]["items"][: ihi - ilo], params["item_id_embedding_arch.weight"][ilo:ihi], atol=2e-6)
-        for k, v in res[r]["dense"].items():
-            noise_only = k in ("item_tower_arch.bias", "item_features_arch.2.bias")  # zero true gradient
-            assert torch.allclose(v, params[k], atol=STEPS * 2.2e-3 if noise_only else 3e-6), k
+        leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+        want = R.train_forward(leaves, cat, torch.tensor([0.7]), **kw)
+        grads = dict(zip(leaves, torch.autograd.grad(want, list(leaves.values()))))
+        for r in range(world):
+            st = res[r]["steps"][s]
+            assert abs(st["loss"] - float(want)) < 1e-5, (s, r, st["loss"], float(want))
+            for name, (lo, hi, g) in st["tables"].items():
+                assert torch.allclose(g, grads[f"{name}_id_embedding_arch.weight"][lo:hi], atol=2e-6), (s, r, name)
+            for k, g in st["dense"].items():
+                assert torch.allclose(g, grads[k], atol=3e-6), (s, r, k, float((g - grads[k]).abs().max()))
+            assert {"lookup_ids_alltoall", "lookup_rows_alltoall", "rowgrad_alltoall", "item_emb_allgather",
+                    "dI_reduce_scatter", "dense_grad_allreduce"} <= set(st["comm"])
     # the shards tile the tables exactly
-    assert sum(r["lo_hi"][1] - r["lo_hi"][0] for r in res) == CFG["n_users"]
-    assert sum(r["lo_hi"][3] - r["lo_hi"][2] for r in res) == CFG["n_items"]
-
-
-def test_local_negatives_is_mean_of_per_rank_losses():
-    from oracle import cpu_ref as R
-    world = 2
-    res = _run(world, "local")
-    ut, it = _tables(CFG)
-    params = dict(_dense_init(CFG))
-    params["user_id_embedding_arch.weight"] = ut
-    params["item_id_embedding_arch.weight"] = it
-    per_rank = [float(R.train_forward(params, res[r]["batches"][0], torch.tensor([0.7]))) for r in range(world)]
-    assert abs(res[0]["losses"][0] - sum(per_rank) / world) < 1e-5
-    assert res[0]["losses"] == res[1]["losses"]
-
-
-# ---------------------------------------------------------------- history model
-HCFG = dict(n_users=37, n_items=61, D=16, F=4, B=6, H=5, model="hist")
-
-
-def _hist_dense_init(cfg):
-    g = torch.Generator().manual_seed(15)
-    D = cfg["D"]
-    out = {k: v for k, v in _dense_init(cfg).items() if k != "user_tower_arch.weight"}
-    out["user_tower_arch.weight"] = torch.randn(D, 4 * D, generator=g) * 0.15
-    for l in range(3):
-        base = f"user_history_encoder.multihead_attn_layers.{l}."
-        out[base + "in_proj_weight"] = torch.randn(3 * D, D, generator=g) * 0.2
-        out[base + "in_proj_bias"] = torch.randn(3 * D, generator=g) * 0.05
-        out[base + "out_proj.weight"] = torch.randn(D, D, generator=g) * 0.2
-        out[base + "out_proj.bias"] = torch.randn(D, generator=g) * 0.05
-    return out
-
-
-def _hist_worker(rank, world, port, outdir):
-    for p in (ROOT, HERE, os.path.join(HERE, "golden")):
-        if p not in sys.path:
-            sys.path.insert(0, p)
-    import torch.distributed as dist
-    from sharded_cpu_backend import OracleBackend
-    from two_tower_models_amd import sharded
-    torch.set_num_threads(1)
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    try:
-        tr = sharded.ShardedTrainer(HCFG, torch.device("cpu"), backend=OracleBackend(), user_value_weights=(0.7,),
-                                    dense_init=_hist_dense_init(HCFG))
-        ut, it = _tables(HCFG)
-        tr.users.weight[: tr.users.hi - tr.users.lo].copy_(0.5 * ut[tr.users.lo:tr.users.hi])
-        tr.items.weight[: tr.items.hi - tr.items.lo].copy_(0.5 * it[tr.items.lo:tr.items.hi])
-        batches = tr.make_batches(STEPS, seed=41)
-        losses = [float(tr.step(b)) for b in batches]
-        # serve the trained item table (SURVEY 8f-4): this rank's catalogue block -> item tower -> ShardedMIPS
-        gq = torch.Generator().manual_seed(31)
-        cat_feats = torch.randn(CFG["n_items"], CFG["F"], generator=gq)
-        queries = torch.randn(4 * world, CFG["D"], generator=gq)[rank * 4:(rank + 1) * 4]
-        served = tr.index_corpus(cat_feats[tr.items.lo:tr.items.hi]).search(queries, 9)
-        torch.save({"losses": losses, "users": tr.users.weight.clone(), "items": tr.items.weight.clone(),
-                    "served": served, "cat_feats": cat_feats, "queries": queries,
-                    "lo_hi": (tr.users.lo, tr.users.hi, tr.items.lo, tr.items.hi),
-                    "dense": {k: v.clone() for k, v in tr.params.items()},
-                    "batches": [tuple(t.clone() for t in b) for b in batches]},
-                   os.path.join(outdir, f"hist{rank}.pt"))
-    finally:
-        dist.destroy_process_group()
-
-
-def test_history_model_equals_reference_on_concatenated_batch():
-    """TwoTowerWithUserHistoryEncoder on 2 ranks: B*H history rows fetched from the sharded item table,
-    encoder replicated, item-table gradients from both the id and the history lookups."""
-    from oracle import cpu_ref as R
-    world = 2
-    outdir = tempfile.mkdtemp()
-    mp.spawn(_hist_worker, args=(world, _free_port(), outdir), nprocs=world, join=True)
-    res = [torch.load(os.path.join(outdir, f"hist{r}.pt")) for r in range(world)]
-    ut, it = _tables(HCFG)
-    params = dict(_hist_dense_init(HCFG))
-    params["user_id_embedding_arch.weight"] = 0.5 * ut
-    params["item_id_embedding_arch.weight"] = 0.5 * it
-    state = R.AdamState(params)
-    pe = R.positional_table(HCFG["H"], HCFG["D"])
-    want = []
-    for s in range(STEPS):
-        cat = [torch.cat([res[r]["batches"][s][k] for r in range(world)]) for k in range(7)]
-        want.append(R.train_step(params, state, cat, torch.tensor([0.7]), with_history=True, heads=4, pos_table=pe))
-    for r in range(world):
-        assert np.allclose(res[r]["losses"], want, atol=1e-5), (res[r]["losses"], want)
-        ulo, uhi, ilo, ihi = res[r]["lo_hi"]
-        named = [("users", res[r]["users"][: uhi - ulo], params["user_id_embedding_arch.weight"][ulo:uhi]),
-                 ("items", res[r]["items"][: ihi - ilo], params["item_id_embedding_arch.weight"][ilo:ihi])]
-        named += [(k, v, params[k]) for k, v in res[r]["dense"].items()]
-        for name, got, ref in named:
-            err = (got - ref).abs()
-            assert float(err.max()) <= 2.2e-3 * STEPS, (name, float(err.max()))
-            # zero true gradient (Adam only sees rounding noise): the two item-side biases, and the K third
-            # of every in_proj_bias (a key bias shifts all scores of a query equally: softmax-invariant)
-            noise_only = name in ("item_tower_arch.bias", "item_features_arch.2.bias") or name.endswith("in_proj_bias")
-            if not noise_only:
-                assert float((err > 5e-6).float().mean()) <= 5e-3, (name, float((err > 5e-6).float().mean()))
+    for name, n in (("user", cfg["n_users"]), ("item", cfg["n_items"])):
+        assert sum(r["steps"][0]["tables"][name][1] - r["steps"][0]["tables"][name][0] for r in res) == n
 
 
 # ---------------------------------------------------------------- sharded MIPS
 def _mips_worker(rank, world, port, outdir, C, K):
-    for p in (ROOT, HERE, os.path.join(HERE, "golden")):
-        if p not in sys.path:
-            sys.path.insert(0, p)
+    _paths()
     import torch.distributed as dist
     import fixture_gen as fg
-    from sharded_cpu_backend import OracleBackend
-    from two_tower_models_amd import sharded
+    from sharded_cpu_backend import OracleMipsKernels
+    from two_tower_models_amd import parallel
     torch.set_num_threads(1)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         corpus = torch.from_numpy(fg.exact_mips_corpus(C, 32))
-        lo, hi = sharded.ShardedMIPS.block_range(C, rank, world)
-        m = sharded.ShardedMIPS(corpus[lo:hi].clone(), lo, backend=OracleBackend())
+        lo, hi = parallel.ShardedMIPS.block_range(C, rank, world)
+        m = parallel.ShardedMIPS(corpus[lo:hi].clone(), lo, kernels=OracleMipsKernels())
         q = torch.from_numpy(fg.exact_mips_queries(5 * world, 32))[rank * 5:(rank + 1) * 5]
         idx, sc = m.search(q, K)
         torch.save({"idx": idx, "sc": sc}, os.path.join(outdir, f"mips{rank}.pt"))
@@ -258,9 +238,10 @@ def _mips_worker(rank, world, port, outdir, C, K):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,C,K", [(2, 700, 20), (3, 100, 40)])
+@pytest.mark.parametrize("world,C,K", [(2, 700, 20), (3, 100, 40), (4, 5, 3)])
 def test_sharded_mips_equals_single_device(world, C, K):
-    """Row-sharded corpus (incl. a block smaller than K) == the unsharded exact top-K."""
+    """Row-sharded corpus (incl. a block smaller than K, and an empty block) == the unsharded exact top-K."""
+    _paths()
     import fixture_gen as fg
     from oracle import cpu_ref as R
     outdir = tempfile.mkdtemp()
@@ -272,3 +253,38 @@ def test_sharded_mips_equals_single_device(world, C, K):
         got = torch.load(os.path.join(outdir, f"mips{r}.pt"))
         assert torch.equal(got["idx"], want_idx[r * 5:(r + 1) * 5])
         assert torch.equal(got["sc"], want_sc[r * 5:(r + 1) * 5])
+
+
+# ---------------------------------------------------------------- watchdog
+class _StubEvent:
+    def __init__(self, done):
+        self.done = done
+
+    def query(self):
+        return self.done
+
+
+def test_watchdog_names_the_exchange_a_step_is_stuck_in():
+    """collectives.Watchdog: steps that complete are retired; a step that does not complete within the limit produces a
+    report that lists the exchanges issued since the last completed step, oldest first (stub events: no GPU needed)."""
+    import time
+    _paths()
+    from two_tower_models_amd import collectives
+    fired = []
+    wd = collectives.Watchdog(seconds=0.3, on_timeout=fired.append, poll=0.05)
+    try:
+        collectives.note_exchange("lookup_ids_alltoall", torch.zeros(16, dtype=torch.int64))
+        wd.mark(_StubEvent(True))
+        time.sleep(0.2)
+        assert not fired and wd._done_step == 1
+        collectives.note_exchange("item_emb_allgather", torch.zeros(8, 4))
+        collectives.note_exchange("dI_reduce_scatter", torch.zeros(32, 4))
+        wd.mark(_StubEvent(False))  # never completes
+        time.sleep(0.8)
+        assert len(fired) == 1 and wd.fired
+        text = fired[0]
+        assert "last completed step 1" in text
+        assert text.index("item_emb_allgather (128 bytes)") < text.index("dI_reduce_scatter (512 bytes)")
+        assert "lookup_ids_alltoall" not in text  # issued before the step that completed
+    finally:
+        wd.close()

@@ -4,7 +4,7 @@ data between processes (all_gather = W copies of the local block, reduce_scatter
 all_reduce = identity).  The numbers are NOT a training run -- they show what one rank's kernels cost
 once the tables are W times thinner and the in-batch negatives W times wider, i.e. the step time at
 W GPUs minus the collectives.  bench.py puts `emulated(8, "P")` into the default line's `secondary`.
-Usage: python tools/bench_emulated_world.py [W] [workload]   (TT_ROUTE=alltoall|allgather)"""
+Usage: python tools/bench_emulated_world.py [W] [workload]"""
 import ctypes as C
 import os
 import sys
@@ -51,13 +51,13 @@ def _fake_dist(W):
         broadcast=lambda x, src=0: None, ReduceOp=torch.distributed.ReduceOp, barrier=lambda: None)
 
 
-def _time_steps(trainer, batches, steps):
+def _time_steps(step, batches, steps):
     """-> (ms to ENQUEUE a step, ms per step): wall clock around the enqueue loop, then around the drain."""
     n = len(batches)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        trainer.step(batches[i % n], batches[(i + 1) % n])
+        step(batches[i % n], batches[(i + 1) % n])
     host = (time.perf_counter() - t0) / steps * 1e3
     torch.cuda.synchronize()
     return host, (time.perf_counter() - t0) / steps * 1e3
@@ -67,38 +67,41 @@ MFMA_F16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak
 
 
 def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False, split16=None):
-    """One rank's kernels of the W-GPU step (stand-in collectives), as a record for bench.py's `secondary`.
+    """One rank's kernels of the W-GPU step (stand-in collectives) THROUGH THE MODULE PATH (parallel.row_sharded +
+    TwoTower* + DenseExactAdam -- the code `bench.py --gpus W` runs), as a record for bench.py's `secondary`.
     split16: run the logits pair as split-fp16 products (csrc/ce_f16x2.hip, exploratory; default: what TT_CE_F16X2 says)."""
     import bench
     from two_tower_models_amd import _native as N
-    from two_tower_models_amd import sharded
+    from two_tower_models_amd import collectives, ops, parallel
     device = device or torch.device("cuda:0")
     lib = N.load()
-    real_dist, real_split = sharded.dist, sharded._CE_F16X2
-    sharded.dist = _fake_dist(W)
+    real = (collectives.dist, parallel.dist, ops._CE_F16X2)
+    collectives.dist = parallel.dist = _fake_dist(W)
     if split16 is not None:
-        sharded._CE_F16X2 = bool(split16)
-    split = sharded._CE_F16X2
+        ops._CE_F16X2 = bool(split16)
+    split = ops._CE_F16X2
     try:
         cfg = dict(bench.WORKLOADS[workload])
-        # (1) the host's own cost of enqueueing a step -- Python + ~150 launches -- measured where the GPU can never
+        # (1) the host's own cost of enqueueing a step -- Python + ~100 launches -- measured where the GPU can never
         # be what the enqueue loop waits for: the SAME step on tables and batches 64 times smaller (every kernel of
         # the full-size step is launched, each finishes in microseconds, the queue never fills)
         tiny_cfg = dict(cfg, n_users=max(cfg["n_users"] // 64, 1024), n_items=max(cfg["n_items"] // 64, 1024), B=128)
-        tiny = sharded.ShardedTrainer(tiny_cfg, device, negatives="global")
-        tb = tiny.make_batches(8)
+        model, opt = bench.build_sharded(tiny_cfg, device, 0)
+        tb = bench.make_batches(tiny_cfg, 8, device)
+        tstep = bench.sharded_step_fn(model, opt, torch.zeros((), device=device))
         for i in range(warmup):
-            tiny.step(tb[i % 8], tb[(i + 1) % 8])
-        host_only_ms, _ = _time_steps(tiny, tb, steps)
-        del tiny, tb
+            tstep(tb[i % 8], tb[(i + 1) % 8])
+        host_only_ms, _ = _time_steps(tstep, tb, steps)
+        del model, opt, tb, tstep
         torch.cuda.empty_cache()
 
-        trainer = sharded.ShardedTrainer(cfg, device, negatives="global")
-        batches = trainer.make_batches(8)
-        for i in range(warmup):
-            trainer.step(batches[i % 8], batches[(i + 1) % 8])
+        model, opt = bench.build_sharded(cfg, device, 0)
+        batches = bench.make_batches(cfg, 8, device)
+        step = bench.sharded_step_fn(model, opt, torch.zeros((), device=device))
+        for i in range(max(warmup, 45)):  # covers the optimiser's group-wide sweep-level scan (optim._tune_sweep_group)
+            step(batches[i % 8], batches[(i + 1) % 8])
         lib.tt_profile_enable(1)
-        host_ms, ms = _time_steps(trainer, batches, steps)
+        host_ms, ms = _time_steps(step, batches, steps)
         prof = {}
         for name in (b"ce_fwd_kernel", b"ce_bwd_kernel", b"adam_sweep_kernel"):
             t, c = C.c_double(0.0), C.c_int64(0)
@@ -106,7 +109,7 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False,
             prof[name.decode()] = (t.value / max(c.value, 1), c.value)
         lib.tt_profile_enable(0)
 
-        # where the time goes: events on the main stream around the two logits kernels
+        # where the time goes: events on the main stream around the two logits Functions
         marks = []
 
         def _ev():
@@ -114,8 +117,7 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False,
             e.record()
             marks.append(e)
 
-        be = trainer.be
-        _fwd, _bwd = be.ce_fwd, be.ce_bwd
+        _fwd, _bwd = ops.InBatchSoftmaxCE.forward, ops.InBatchSoftmaxCE.backward
 
         def ce_fwd(*a, **k):
             _ev()
@@ -129,20 +131,22 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False,
             _ev()
             return out
 
-        be.ce_fwd, be.ce_bwd = ce_fwd, ce_bwd
+        ops.InBatchSoftmaxCE.forward, ops.InBatchSoftmaxCE.backward = staticmethod(ce_fwd), staticmethod(ce_bwd)
         acc = [0.0] * 5
-        for i in range(10):
-            marks.clear()
-            _ev()
-            trainer.step(batches[i % 8], batches[(i + 1) % 8])
-            _ev()
-            torch.cuda.synchronize()
-            for k in range(5):
-                acc[k] += marks[k].elapsed_time(marks[k + 1]) / 10
-        be.ce_fwd, be.ce_bwd = _fwd, _bwd
+        try:
+            for i in range(10):
+                marks.clear()
+                _ev()
+                step(batches[i % 8], batches[(i + 1) % 8])
+                _ev()
+                torch.cuda.synchronize()
+                for k in range(5):
+                    acc[k] += marks[k].elapsed_time(marks[k + 1]) / 10
+        finally:
+            ops.InBatchSoftmaxCE.forward, ops.InBatchSoftmaxCE.backward = staticmethod(_fwd), staticmethod(_bwd)
         B, D = cfg["B"], cfg["D"]
         M, Nn = B, B * W
-        kept = bool(getattr(trainer.be, "keep_logits", False))
+        kept = Nn >= 4 * M and not split  # ops.InBatchSoftmaxCE: wide negative sets keep their logits for the backward
         # logit-sized products: forward S = U.I^T and E = P.I (2), backward dI = G^T.U from the kept logits (1) or
         # with S recomputed (2); 2*M*N*D flops each
         fl_fwd, fl_bwd = 4.0 * M * Nn * D, (2.0 if kept else 4.0) * M * Nn * D
@@ -183,9 +187,9 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False,
             del U, I, Z, ws, dI, du
         roof = []
         for kname, fl, key in (("ce16_fwd_kernel" if split else "ce_fwd_du_kernel", fl_fwd, "ce_fwd_kernel"),
-                               (("ce16_bwd_items_kernel" if sharded._CE16_KEEP else "ce16_bwd_items_rc_kernel") if split
+                               (("ce16_bwd_items_kernel" if ops._CE16_KEEP else "ce16_bwd_items_rc_kernel") if split
                                 else "ce_bwd_kept_kernel" if kept else "ce_bwd_kernel",
-                                (2.0 if sharded._CE16_KEEP else 4.0) * M * Nn * D if split else fl_bwd, "ce_bwd_kernel")):
+                                (2.0 if ops._CE16_KEEP else 4.0) * M * Nn * D if split else fl_bwd, "ce_bwd_kernel")):
             avg_ms, launches = prof[key]
             if launches and split:
                 # every logit-sized product runs as THREE fp16 MFMA products: priced against the fp16 matrix-pipe peak on the
@@ -207,10 +211,11 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False,
             "what": f"ONE rank's kernels of the row-sharded step at W = {W} on one GPU: tables 1/{W} as thick, {W}x{B} in-batch "
                     "negatives per user, routed lookups; torch.distributed replaced by stand-ins that return tensors of the right "
                     "shape without moving data -- NOT a training run, the collectives' time comes on top",
-            "workload": workload, "world": W, "routing": trainer.routing, "kept_logits": (sharded._CE16_KEEP if split else kept),
+            "workload": workload, "world": W, "path": "module classes + DenseExactAdam over parallel.row_sharded tables",
+            "kept_logits": (ops._CE16_KEEP if split else kept),
             "dtype": "f32 (fp16x2 split: every logits product as three fp16 MFMA products of two-term splits, fp32 accumulate)" if split else "f32",
             **({"EXPLORATORY": "TT_CE_F16X2 -- not the default path, not the headline; parity: tests/test_gpu_kernels.py::"
-                               "test_split_fp16_ce_pair_vs_float64, tests/test_gpu_sharded.py::test_world1_split_fp16_logits_match_oracle_at_unchanged_tolerances"}
+                               "test_split_fp16_ce_pair_vs_float64, tests/test_gpu_fullsize.py::test_split_fp16_ce_pair_8_rank_shape"}
                if split else {}),
             "ms_per_step_per_rank": round(ms, 4),
             "pairs_per_s_if_collectives_were_free": round(B * W / ms * 1e3, 1),
@@ -222,23 +227,24 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False,
                                       "logits_bwd_dI": round(acc[3], 3), "towers_bwd_row_adam": round(acc[4], 3)},
             "roofline": roof,
             "sweep_avg_launch_ms": round(prof["adam_sweep_kernel"][0], 4),
-            "bytes_this_rank_would_send_per_step": dict(trainer.comm_bytes),
-            "total_MB_sent": round(sum(trainer.comm_bytes.values()) / 1e6, 2),
+            "sweep_level": opt.sweep_level_note(),
+            "bytes_this_rank_would_send_per_step": dict(parallel.comm_bytes),
+            "total_MB_sent": round(sum(parallel.comm_bytes.values()) / 1e6, 2),
             "steps": steps, "warmup": warmup,
         }
         if verbose:
             print(f"  host enqueue time {host_ms:.3f} ms/step (host only, GPU never the wait: {host_only_ms:.3f})")
             print("  main-stream phases (ms): lookups+towers %.3f | logits fwd + dU %.3f | weights/loss %.3f | logits bwd (dI) %.3f | "
                   "towers bwd + row Adam %.3f" % tuple(acc))
-            print(f"emulated W={W} workload={workload} routing={trainer.routing}: {ms:.3f} ms/step per rank (no collectives) -> "
+            print(f"emulated W={W} workload={workload}: {ms:.3f} ms/step per rank (no collectives) -> "
                   f"{B * W / ms * 1e3 / 1e6:.2f} M pairs/s if the collectives were free")
             for r in roof:
                 print(f"  {r['kernel']}: {r['avg_launch_ms']:.3f} ms = {r['achieved']} TFLOP/s = {r['frac']:.3f} of the {'fp16' if r['peak'] > 1000 else 'fp32'} MFMA peak"
                       + (f" (alone: {r['alone_avg_launch_ms']:.3f} ms = {r['alone_frac']:.3f})" if "alone_frac" in r else ""))
-            print(f"  bytes this rank would send per step: {trainer.comm_bytes} = {sum(trainer.comm_bytes.values()) / 1e6:.1f} MB")
+            print(f"  bytes this rank would send per step: {parallel.comm_bytes} = {sum(parallel.comm_bytes.values()) / 1e6:.1f} MB")
         return out
     finally:
-        sharded.dist, sharded._CE_F16X2 = real_dist, real_split
+        collectives.dist, parallel.dist, ops._CE_F16X2 = real
 
 
 if __name__ == "__main__":

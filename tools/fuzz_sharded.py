@@ -1,15 +1,13 @@
-"""Randomised check of the row-sharded trainer with the PRODUCT backend at world sizes 2-4 on ONE GPU (ranks as
-processes sharing cuda:0, gloo transport -- RCCL refuses two ranks on a device): random table sizes, widths, batch
-sizes, model kind and routing; every rank's losses, table blocks and dense replicas against the oracle's train steps
-on the concatenated batch (the assertions of tests/test_gpu_sharded.py, with 0.5 % instead of 0.2 % of a tensor's
+"""Randomised check of row-sharded training THROUGH THE MODULE CLASSES at world sizes 2-4 on ONE GPU (ranks as processes
+sharing cuda:0, gloo transport -- RCCL refuses two ranks on a device): random table sizes, widths, batch sizes and model
+kind (base / hist / debias); every rank's losses, reassembled tables and dense replicas against the oracle's train steps
+on the concatenated batch (the assertions of tests/test_gpu_parallel.py, with 0.5 % instead of 0.2 % of a tensor's
 elements allowed beyond 5e-6).  Per-rank batches of 8 and more: with a global batch of 2-6 samples most gradient
 elements are rounding noise around zero, Adam's first steps turn their SIGN into +-lr, and any two fp32 implementations
 -- the CPU port run as 2 ranks included -- then differ in tens of elements per tensor and by 1e-4 in the next loss.
 Three or more item features, for a related reason: with one or two, many units of the item MLP's first layer are active
-for EVERY sample of the batch, and for those the bias gradient is W^T . sum_j dL/d(item_emb_j) = 0 analytically (the
-in-batch softmax is invariant to a common shift of the item embeddings) -- noise again.
-First run (seed 2): one real finding in 146 cases -- a rank that owns no row of a table (9 item rows on 4 ranks) had
-its lookups and its table Adam rejected with "sizes"; fixed, tests/test_gpu_sharded.py "empty_block".
+for EVERY sample of the batch, and for those the bias gradient is analytically zero (the in-batch softmax is invariant to
+a common shift of the item embeddings) -- noise again.
     python tools/fuzz_sharded.py [seconds] [seed]"""
 import json
 import os
@@ -21,26 +19,24 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
     sys.path.insert(0, p)
-import test_gpu_sharded as T  # noqa: E402
+import test_gpu_parallel as T  # noqa: E402
 
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     t0, n, bad = time.time(), 0, 0
     while time.time() - t0 < budget:
-        hist = rng.random() < 0.35
+        kind = str(rng.choice(["base", "base", "hist", "debias"]))
+        hist = kind != "base"
         cfg = dict(n_users=int(rng.integers(3, 700)), n_items=int(rng.integers(3, 700)),
                    D=int(rng.choice([32, 64, 128])) if hist else int(rng.choice([8, 24, 40, 64, 128, 160])),
                    F=int(rng.integers(3, 24)), B=int(rng.choice([8, 16, 33, 64, 100])),
                    H=int(rng.choice([1, 4, 9, 50])) if hist else 2)
-        if hist:
-            cfg["model"] = "hist"
         world = int(rng.choice([2, 3, 4]))
-        routing = str(rng.choice(["alltoall", "allgather"]))
-        what = f"case {n}: W={world} routing={routing} {cfg}"
+        what = f"case {n}: W={world} {kind} {cfg}"
         try:
-            T.test_multi_rank_hip_backend_equals_reference_on_concatenated_batch(world, "json:" + json.dumps(cfg), "gloo",
-                                                                                  routing, "torch", outlier_frac=5e-3)
+            T.test_sharded_modules_equal_reference_on_concatenated_batch(world, "json:" + json.dumps([kind, cfg]), "gloo", "torch",
+                                                                          bool(rng.integers(0, 2)), outlier_frac=5e-3)
         except BaseException as e:  # noqa: BLE001 -- assertion failures and crashed ranks are both findings
             bad += 1
             print("FINDING", what, "|", type(e).__name__, str(e)[:400], flush=True)

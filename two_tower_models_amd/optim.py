@@ -402,9 +402,80 @@ class DenseExactAdam(torch.optim.Optimizer):
     _SCAN_BLOCK = 6  # steps per level; the first one of a block overlaps the previous level's tail and is not counted
     _RESCAN_STEPS = 4000
 
+    def sweep_level_note(self) -> str:
+        """How the sweep's width was chosen (bench.py prints it)."""
+        ts = self._tune_state
+        if os.environ.get("TT_SWEEP_WGS") is not None:
+            return "fixed by TT_SWEEP_WGS"
+        if ts is None:
+            return "not measured yet"
+        return ts.get("why", ts["phase"])
+
+    # Row-sharded group: the steps of all ranks are synchronised by the collectives, so the best level is a property of
+    # the GROUP, and ranks that locked different levels on local timing noise would drag each other.  Same probe / scan /
+    # decide as below, but every decision is taken at a step number all ranks reach, from the MAX over the ranks of each
+    # level's best step time (two host waits per scan, i.e. per 4000 steps).
+    def _tune_sweep_group(self) -> None:
+        import torch.distributed as dist
+        from . import collectives
+        levels = self._SWEEP_LEVELS
+        step = self._host_steps + 1  # the step about to be enqueued
+        ts = self._tune_state
+        if ts is None:
+            ts = self._tune_state = {"phase": "probe", "t0": step, "since": 0}
+
+        def collect():
+            obs = {}
+            for got in self._tune_done:
+                got[3].synchronize()
+                if got[5] < ts["t0"] + 4 or got[5] in ts.get("skip", ()):
+                    continue
+                obs.setdefault(got[4], []).append((got[0].elapsed_time(got[3]), got[1].elapsed_time(got[2])))
+            self._tune_done.clear()
+            return obs
+
+        def group(values, op):
+            t = torch.tensor(values, dtype=torch.float32, device=self._hyper.device)
+            collectives.all_reduce_(t, op=op)
+            return [float(v) for v in t.cpu()]
+
+        if ts["phase"] == "probe":
+            self._sweep_wgs = levels[0]
+            if step == ts["t0"] + 8:
+                seen = collect().get(0, [])
+                mine = 1.0 if (len(seen) >= 2 and all(sweep > 0.9 * st for st, sweep in seen[-2:])) else 0.0
+                if group([mine], dist.ReduceOp.MIN)[0] > 0.5:
+                    self._lock_sweep(ts, 0, "the sweep is the step on every rank")
+                else:
+                    plan, skip, nxt = [], set(), step
+                    for lv in levels[1:]:
+                        skip.add(nxt)
+                        plan += [lv] * self._SCAN_BLOCK
+                        nxt += self._SCAN_BLOCK
+                    skip.add(nxt)
+                    ts.update(phase="scan", plan=plan, skip=skip, scan_start=step)
+        if ts["phase"] == "scan":
+            k = step - ts["scan_start"]
+            self._sweep_wgs = ts["plan"][k] if k < len(ts["plan"]) else levels[0]
+            if k == len(ts["plan"]) + 3:
+                obs = collect()
+                local = [min((st for st, _ in obs.get(lv, [])), default=1.0e9) if len(obs.get(lv, [])) >= 2 else 1.0e9
+                         for lv in levels]
+                worst = group(local, dist.ReduceOp.MAX)
+                best = min(range(len(levels)), key=lambda i: (worst[i], i))
+                self._lock_sweep(ts, levels[best], "group (max over ranks of each level's best step time): "
+                                 + str({(lv or 768): round(v, 3) for lv, v in zip(levels, worst) if v < 1.0e8}))
+        elif ts["phase"] == "locked":
+            self._tune_done.clear()
+            ts["since"] += 1
+            if ts["since"] >= self._RESCAN_STEPS:
+                self._tune_state = {"phase": "probe", "t0": step, "since": 0}
+
     def _tune_sweep(self) -> None:
         if os.environ.get("TT_SWEEP_WGS") is not None:
             return
+        if self._sharded and self._sharded[0]._tt_shard.world > 1:
+            return self._tune_sweep_group()
         ts = self._tune_state
         if ts is None:
             ts = self._tune_state = {"phase": "probe", "obs": {}, "plan": [], "skip": set(), "last": 0, "since": 0}
@@ -448,7 +519,7 @@ class DenseExactAdam(torch.optim.Optimizer):
 
     def _lock_sweep(self, ts: dict, level: int, why: str) -> None:
         self._sweep_wgs = level
-        ts.update(phase="locked", obs={}, plan=[], skip=set(), since=0)
+        ts.update(phase="locked", obs={}, plan=[], skip=set(), since=0, why=f"{level or 768} workgroups: {why}")
         if os.environ.get("TT_TUNE_DEBUG"):
             print(f"[tt] sweep level: {level or 768} workgroups ({why})", file=sys.stderr)
 
