@@ -61,9 +61,8 @@ def note_generic(path: str, why: str) -> None:
 # gradients by ordinary stream order.  Operands are held until then.  Not used while a hipGraph is being captured.
 # (The third stream, not a new one: ROCm multiplexes HIP streams onto a handful of hardware queues in creation order, and
 # one more stream can land on the sweep's queue -- measured in sharded.py, round 4.)
-_SIDE_GRADS = os.environ.get("TT_WGRAD_MAIN") is None
-_TOWER_WGRAD_SIDE = os.environ.get("TT_TOWER_WGRAD_SIDE") is not None
-_side_state = {"held": [], "armed": False, "dev": None, "encoder": False}  # "encoder": a HistoryEncoder forward ran since the last join
+_SIDE_GRADS = os.environ.get("TT_WGRAD_MAIN") is None  # TT_WGRAD_MAIN=1: everything in line (the safe mode under DDP-style reducers)
+_side_state = {"held": [], "armed": False, "dev": None, "encoder": False, "leaves": set()}  # "encoder": a HistoryEncoder forward ran since the last join
 
 
 def _join_side_grads() -> None:
@@ -73,27 +72,39 @@ def _join_side_grads() -> None:
         done.record(N.aux_stream(st["dev"]))
         torch.cuda.current_stream(st["dev"]).wait_event(done)
     st["held"].clear()
+    st["leaves"].clear()
     st["armed"], st["dev"], st["encoder"] = False, None, False
 
 
+def _deferrable(t: Optional[torch.Tensor]) -> bool:
+    """May the gradient of `t` be handed to autograd before the side stream has written it?  Only if NOTHING reads it
+    before the end-of-backward join: a leaf whose `.grad` is None (AccumulateGrad then steals the returned tensor without
+    launching anything; a defined `.grad` means an in-place add on the main stream at once), dense contiguous layout
+    (otherwise AccumulateGrad clones), and no tensor / post-accumulate hooks (hook-based reducers and clipping read the
+    gradient inside the backward pass).  Hooks registered on the AccumulateGrad NODE itself (torch's DDP) cannot be seen
+    from here: run with TT_WGRAD_MAIN=1 under such wrappers."""
+    return (t is not None and t.is_leaf and t.grad is None and t.is_contiguous() and not t._backward_hooks
+            and not getattr(t, "_post_accumulate_grad_hooks", None))
+
+
 def run_on_side(dev: torch.device, fn, hold: Sequence[Optional[torch.Tensor]] = (),
-                leaves: Sequence[Optional[torch.Tensor]] = ()) -> bool:
+                leaves: Sequence[Optional[torch.Tensor]] = (), again: bool = False) -> bool:
     """Run fn() on the third stream, after everything queued so far on the current one; -> False (and fn() runs in
     place) when side execution is off, the device is not a GPU, a graph is being captured, or no backward pass is running.
     `hold`: the INPUTS of fn (kept alive until the join) -- never its outputs: autograd's AccumulateGrad takes a returned
     gradient over as `.grad` without launching anything only if nobody else references it; a held output would be CLONED
     on the main stream, at once, before the side kernel has written it.  `leaves`: the tensors the gradients are for; the
-    work is deferred only if each of them is a leaf whose `.grad` is None (then AccumulateGrad steals) -- a defined
-    `.grad` (zero_grad(set_to_none=False)) means an in-place add on the main stream right after backward() returns its
-    outputs, and a non-leaf means an arbitrary consumer: both get completed gradients instead."""
+    work is deferred only if each of them is `_deferrable` AND has not been deferred by another node of this backward pass
+    (a Parameter that feeds two Functions: autograd SUMS the two gradients on the main stream as soon as both exist).
+    `again`: a continuation of work this node already deferred for the same leaves (must stay behind it on the side stream)."""
     if not (_SIDE_GRADS and dev.type == "cuda") or torch.cuda.is_current_stream_capturing() or torch.is_grad_enabled():
         fn()
         return False
+    st = _side_state
     for t in leaves:
-        if t is None or not (t.is_leaf and t.grad is None):
+        if not _deferrable(t) or (not again and id(t) in st["leaves"]):
             fn()
             return False
-    st = _side_state
     if not st["armed"]:
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_join_side_grads)
@@ -108,6 +119,7 @@ def run_on_side(dev: torch.device, fn, hold: Sequence[Optional[torch.Tensor]] = 
     with torch.cuda.stream(side):
         fn()
     st["held"].extend(t for t in hold if t is not None)
+    st["leaves"].update(id(t) for t in leaves)
     return True
 
 
@@ -589,8 +601,8 @@ class FusedTower(_LookupFunction):
         # (the towers' weight gradients go to the third stream only in a step that also runs the history encoder -- there
         # they are worth 0.1 ms of the 4.3 ms C3 step, underneath the encoder's backward; in the sweep-bound base model the
         # extra stream hop COSTS 0.06 ms of the 1.15 ms C2 step)
-        if _TOWER_WGRAD_SIDE or _side_state["encoder"]:
-            run_on_side(dev, lambda: tower_weight_grads(dy, tin, d_f, h, dh, feats, out=outs, extra=extra),
+        if _side_state["encoder"]:
+            run_on_side(dev, lambda: tower_weight_grads(dy, tin, d_f, h, dh, feats, out=outs, extra=extra, side=True),
                         hold=(dy, tin, d_f, h, dh, feats, extra), leaves=ctx.tower_leaves)
         else:
             tower_weight_grads(dy, tin, d_f, h, dh, feats, out=outs, extra=extra)
@@ -604,11 +616,13 @@ class FusedTower(_LookupFunction):
 _TOWER_WGRAD = os.environ.get("TT_TOWER_NO_WGRAD") is None  # A/B switch
 
 
-def tower_weight_grads(dy, tin, d_f, h, dh, feats, out=None, extra=None):
+def tower_weight_grads(dy, tin, d_f, h, dh, feats, out=None, extra=None, side=False):
     """(dW1, db1, dW2, db2, dW3, db3) of one tower: dW3 = dy^T [tin | extra], dW2 = d_f^T h, dW1 = dh^T feats and the
     bias sums, one product launch + one reduce (tt_tower_bwd_weights_x) instead of three tt_gemm_tn_colsum_f32 calls.
     `out`: the six tensors to write into (contiguous), else they are allocated.  `extra` [B, 2D]: the third block of
-    the tower input (history model), dW3 is then [D, 4D]."""
+    the tower input (history model), dW3 is then [D, 4D].  `side`: the call is queued on the third stream -- it then uses
+    scratch slots of its own (the main stream's products use "ws" / "tower_wgrad" concurrently)."""
+    slot_fused, slot_gemm = ("tower_wgrad_side", "ws_side_t") if side else ("tower_wgrad", "ws")
     dev = dy.device
     B, D = dy.shape
     Hd, F = h.shape[1], feats.shape[1]
@@ -627,34 +641,29 @@ def tower_weight_grads(dy, tin, d_f, h, dh, feats, out=None, extra=None):
             and all(t.is_contiguous() for t in (tin, d_f, h, dh, dW1, db1, dW2, db2, dW3, db3))
             and all(t.data_ptr() % 16 == 0 for t in (dy, tin, d_f, h, dh))
             and (extra is None or (extra.stride(1) == 1 and extra.stride(0) % 4 == 0 and extra.data_ptr() % 16 == 0))):
-        wsp, wsn = _ws(dev, lib.tt_tower_bwd_weights_x_workspace_bytes(B, D, F, Hd, E), "tower_wgrad")
+        wsp, wsn = _ws(dev, lib.tt_tower_bwd_weights_x_workspace_bytes(B, D, F, Hd, E), slot_fused)
         N.check(lib.tt_tower_bwd_weights_x(dy.data_ptr(), dy.stride(0), tin.data_ptr(), d_f.data_ptr(), h.data_ptr(), dh.data_ptr(),
                                            feats.data_ptr(), feats.stride(0), N.ptr(extra), extra.stride(0) if E else 0, E,
                                            B, D, F, Hd, dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(),
                                            dW3.data_ptr(), db3.data_ptr(), wsp, wsn, N.stream()), "tt_tower_bwd_weights_x")
         return dW1, db1, dW2, db2, dW3, db3
     if extra is not None:
-        gemm_tn_colsum(dy, tin, dW3[:, :2 * D], db=db3)
-        gemm(N.TT_GEMM_TN, dy, extra, dW3[:, 2 * D:], D, E, B)
-        gemm_tn_colsum(d_f, h, dW2, db=db2)
-        gemm_tn_colsum(dh, feats, dW1, db=db1)
+        gemm_tn_colsum(dy, tin, dW3[:, :2 * D], db=db3, slot=slot_gemm)
+        gemm(N.TT_GEMM_TN, dy, extra, dW3[:, 2 * D:], D, E, B, slot=slot_gemm)
+        gemm_tn_colsum(d_f, h, dW2, db=db2, slot=slot_gemm)
+        gemm_tn_colsum(dh, feats, dW1, db=db1, slot=slot_gemm)
         return dW1, db1, dW2, db2, dW3, db3
-    gemm_tn_colsum(dy, tin, dW3, db=db3)
-    gemm_tn_colsum(d_f, h, dW2, db=db2)
-    gemm_tn_colsum(dh, feats, dW1, db=db1)
+    gemm_tn_colsum(dy, tin, dW3, db=db3, slot=slot_gemm)
+    gemm_tn_colsum(d_f, h, dW2, db=db2, slot=slot_gemm)
+    gemm_tn_colsum(dh, feats, dW1, db=db1, slot=slot_gemm)
     return dW1, db1, dW2, db2, dW3, db3
 
 
 _FUSED_DU = os.environ.get("TT_CE_NO_FUSED_DU") is None  # A/B switches
-_ROW0_LAST = os.environ.get("TT_ENC_FULL_LAST_LAYER") is None
-_ENC_LAST_COLLAPSED = os.environ.get("TT_ENC_NO_COLLAPSED_LAST") is None  # last layer without K / V projections (encoder_last.hip)
-# whole-layer forward in one launch (encoder_layer.hip): measured round 4 -- 440 us per layer alone against 375-390 us for
-# the three launches it replaces (one wave per SIMD, rows padded 50 -> 64), and no better next to the sweep; opt-in
-_ENC_FUSED_FWD = os.environ.get("TT_ENC_FUSED_FWD") is not None
-_ENC_FOLD_OUT = os.environ.get("TT_ENC_NO_FOLDED_OUT") is None  # out-projection of layer l composed with the in-projection of l + 1
-_ENC_POOL_EPILOGUE = os.environ.get("TT_ENC_NO_POOL_EPILOGUE") is None  # A/B: mean-pool backward as a separate pass over dx
-_ENC_FOLD_TAIL = os.environ.get("TT_ENC_FOLD_INLINE") is None  # A/B: the composed boundaries' small weight-gradient products at the end of backward
-_ENC_COLLAPSE_PREV = os.environ.get("TT_ENC_NO_COLLAPSED_PREV") is None  # second-to-last layer's out-projection folded into the last
+# TT_ENC_GENERIC=1 (tests): the history encoder's plain composition -- every layer in full (in-projection, attention,
+# out-projection; the last one's out-projection for row 0 only) -- instead of the algebraic shortcuts below; it is
+# also what shapes outside the shortcut kernels' limits run, so it has to stay correct
+_ENC_GENERIC = os.environ.get("TT_ENC_GENERIC") is not None
 
 
 def kept_logits_supported(U: torch.Tensor, I: torch.Tensor) -> bool:
@@ -1000,21 +1009,21 @@ class HistoryEncoder(_LookupFunction):
                                        pooled.data_ptr(), 2 * D, N.oob.flag(dev).data_ptr(), N.stream()),
                 "tt_hist_embed_pool")
         saved: List[torch.Tensor] = []
-        row0_last = L > 0 and H <= 64 and D // heads <= 64 and _ROW0_LAST
-        collapsed_last = (row0_last and _ENC_LAST_COLLAPSED and bool(lib.tt_enc_last_supported(H, D, heads))
-                          and x.data_ptr() % 16 == 0)
-        collapse_prev = collapsed_last and L >= 2 and _ENC_COLLAPSE_PREV and lib.tt_enc_last_supported(H, D, heads) >= 2
-        fused_layer = (_ENC_FUSED_FWD and L > 0 and bool(lib.tt_enc_layer_fwd_supported(H, D, heads))
-                       and x.data_ptr() % 16 == 0)
+        # the last layer is consumed at row 0 only: one query per (sample, head), K / V projections folded into two D-wide
+        # vectors per (sample, head) (csrc/encoder_last.hip)
+        collapsed_last = (L > 0 and not _ENC_GENERIC and H <= 64 and D // heads <= 64
+                          and bool(lib.tt_enc_last_supported(H, D, heads)) and x.data_ptr() % 16 == 0)
+        # ... and with it the second-to-last layer's out-projection (the last layer then reads that layer's CONTEXT)
+        collapse_prev = collapsed_last and L >= 2 and lib.tt_enc_last_supported(H, D, heads) >= 2
         dh = D // max(heads, 1)
         if L > 0 and (H > 64 or dh not in (16, 32, 64) or D % 4):
             note_generic("history-encoder attention",
                          f"the matrix-core kernels take H <= 64 and head width in {{16, 32, 64}}; got H = {H}, head width = {dh}: "
-                         "VALU attention" + ("" if row0_last else ", last layer computed for every position"))
-        fold = _ENC_FOLD_OUT and not fused_layer
+                         "VALU attention" + ("" if collapsed_last else ", last layer computed for every position"))
+        fold = not _ENC_GENERIC  # out-projection of layer l composed with the in-projection of layer l + 1
 
         def folded_in(l):  # layer l (a full layer, not the first) reads the previous layer's context through composed weights
-            return fold and 1 <= l < L and not (l == L - 1 and row0_last)
+            return fold and 1 <= l < L and not (l == L - 1 and collapsed_last)
 
         folded_w = {}
         for l in range(L):
@@ -1042,38 +1051,7 @@ class HistoryEncoder(_LookupFunction):
                                             N.stream()), "tt_enc_last_fwd")
                 saved += [x, q0, tq, probs, xbar, ctx0] + extra
                 continue
-            if l == L - 1 and row0_last:
-                # the last layer is consumed at row 0 only: K, V for every position, Q for position 0,
-                # one query per (sample, head) -- 1/H of the attention, 2/3 of the in-projection
-                kv = torch.empty(B * H, 2 * D, dtype=torch.float32, device=dev)
-                gemm(N.TT_GEMM_NT, x, w_in[D:], kv, B * H, 2 * D, D, bias=b_in[D:])
-                x0 = x.view(B, H * D)[:, :D]  # rows b*H + 0
-                q0 = torch.empty(B, D, dtype=torch.float32, device=dev)
-                gemm(N.TT_GEMM_NT, x0, w_in[:D], q0, B, D, D, bias=b_in[:D])
-                ctx0 = torch.empty(B, D, dtype=torch.float32, device=dev)
-                probs = torch.empty(B, heads, H, dtype=torch.float32, device=dev)
-                N.check(lib.tt_attn_row0_fwd(q0.data_ptr(), D, kv.data_ptr(), 2 * D, B, H, D, heads, ctx0.data_ptr(),
-                                             probs.data_ptr(), N.stream()), "tt_attn_row0_fwd")
-                gemm(N.TT_GEMM_NT, ctx0, w_out, out[:, 0, :], B, D, D, bias=b_out)
-                saved += [x, kv, q0, ctx0, probs]
-                continue
             qkv = torch.empty(B * H, 3 * D, dtype=torch.float32, device=dev)
-            if fused_layer:
-                # in-projection + attention + out-projection of one sample per workgroup (csrc/encoder_layer.hip): qkv /
-                # ctx / lse are written for the backward, never read back here
-                ctx_t = torch.empty(B * H, D, dtype=torch.float32, device=dev)
-                lse = torch.empty(B, heads, H, dtype=torch.float32, device=dev)
-                last = l + 1 == L
-                y = out if last else torch.empty(B * H, D, dtype=torch.float32, device=dev)
-                N.check(lib.tt_enc_layer_fwd(x.data_ptr(), B, H, D, heads, w_in.contiguous().data_ptr(),
-                                             b_in.contiguous().data_ptr(), w_out.contiguous().data_ptr(),
-                                             b_out.contiguous().data_ptr(), y.data_ptr(), 2 * D if last else D,
-                                             1 if last else 0, qkv.data_ptr(), ctx_t.data_ptr(), lse.data_ptr(),
-                                             N.stream()), "tt_enc_layer_fwd")
-                saved += [x, qkv, ctx_t, lse]
-                if not last:
-                    x = y
-                continue
             if folded_in(l):
                 # x is the previous layer's CONTEXT c: x_l = c W_o^T + b_o never exists, the two Linear maps are composed --
                 #   qkv = c (W_in W_o)^T + (W_in b_o + b_in)          ([3D, D] x [D, D]: 12.6 MFLOP instead of a [B*H, D] x [D, D]
@@ -1099,7 +1077,6 @@ class HistoryEncoder(_LookupFunction):
         if L == 0:
             out[:, 0, :].copy_(x.view(B, H, D)[:, 0, :])
         ctx.dims = (B, H, D, L, heads)
-        ctx.row0_last = row0_last
         ctx.collapsed_last = collapsed_last
         ctx.collapse_prev = collapse_prev
         ctx.folded = {l: w for l, w in folded_w.items()}  # layer -> its composed in-projection weight W_in W_o(prev)
@@ -1161,27 +1138,6 @@ class HistoryEncoder(_LookupFunction):
                 if ctx.collapse_prev:
                     prev_out_grads = (dW_pa, db_pa)  # dx is then the gradient of the previous layer's CONTEXT
                 continue
-            if l == L - 1 and ctx.row0_last:
-                x, kv, q0, ctx0, probs = saved[4 * l: 4 * l + 5]
-                dW_out = torch.empty(D, D, dtype=torch.float32, device=dev)
-                _, db_out = gemm_tn_colsum(d_recent, ctx0, dW_out)
-                d_ctx0 = torch.empty(B, D, dtype=torch.float32, device=dev)
-                gemm(N.TT_GEMM_NN, d_recent, w_out, d_ctx0, B, D, D)
-                d_q0 = torch.empty(B, D, dtype=torch.float32, device=dev)
-                d_kv = torch.empty(B * H, 2 * D, dtype=torch.float32, device=dev)
-                N.check(lib.tt_attn_row0_bwd(q0.data_ptr(), D, kv.data_ptr(), 2 * D, probs.data_ptr(), d_ctx0.data_ptr(),
-                                             B, H, D, heads, d_q0.data_ptr(), d_kv.data_ptr(), 2 * D, N.stream()),
-                        "tt_attn_row0_bwd")
-                x0 = x.view(B, H * D)[:, :D]
-                dW_in = torch.empty(3 * D, D, dtype=torch.float32, device=dev)
-                db_in = torch.empty(3 * D, dtype=torch.float32, device=dev)
-                gemm_tn_colsum(d_q0, x0, dW_in[:D], db=db_in[:D])
-                gemm_tn_colsum(d_kv, x, dW_in[D:], db=db_in[D:])
-                dx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
-                gemm(N.TT_GEMM_NN, d_kv, w_in[D:], dx, B * H, D, 2 * D)
-                gemm(N.TT_GEMM_NN, d_q0, w_in[:D], dx.view(B, H * D)[:, :D], B, D, D, accumulate=True)
-                grads[4 * l: 4 * l + 4] = [dW_in, db_in, dW_out, db_out]
-                continue
             x, qkv, ctx_t, lse = saved[4 * l: 4 * l + 4]
             dW_out = torch.empty(D, D, dtype=torch.float32, device=dev)
             if prev_out_grads is not None:  # the layer after this one took the context: its backward produced these
@@ -1225,15 +1181,12 @@ class HistoryEncoder(_LookupFunction):
                 # one stands now); the four small products that turn G into weight gradients wait until the END of this
                 # backward -- in line they sat on the side stream between this layer's G and the next one's, next to the
                 # data path's heaviest kernels, 245 us for 60 us of work, and the side stream finished 250 us after the main one
-                hold_f = (d_qkv, x, G, db_in, w_po, b_po, w_in, w_eff)
+                # (held: INPUTS and the private G only -- never db_in, which is returned as in_proj_bias's gradient: a held
+                # output is CLONED by AccumulateGrad on the main stream before the side stream has written it)
+                hold_f = (d_qkv, x, G, w_po, b_po, w_in, w_eff)
                 leaves_f = list(leaf_params[4 * l: 4 * l + 2]) + list(leaf_params[4 * (l - 1) + 2: 4 * (l - 1) + 4])
                 aside = run_on_side(dev, folded_G, hold=hold_f, leaves=leaves_f)
-                if _ENC_FOLD_TAIL:
-                    tail_jobs.append((folded_weights, aside, hold_f, leaves_f))
-                elif aside:
-                    run_on_side(dev, folded_weights, hold=hold_f, leaves=leaves_f)
-                else:
-                    folded_weights()
+                tail_jobs.append((folded_weights, aside, hold_f, leaves_f))
                 dx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
                 gemm(N.TT_GEMM_NN, d_qkv, w_eff, dx, B * H, D, 3 * D)
                 prev_out_grads = (dW_po, db_po)
@@ -1241,7 +1194,7 @@ class HistoryEncoder(_LookupFunction):
                 db_in = wgrad(d_qkv, x, dW_in, "i", l)
                 dx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
                 rc = N.TT_E_UNSUPPORTED
-                if l == 0 and _ENC_POOL_EPILOGUE and w_in.is_contiguous():
+                if l == 0 and not _ENC_GENERIC and w_in.is_contiguous():
                     rc = lib.tt_hist_dx_pool_bwd(d_qkv.data_ptr(), w_in.data_ptr(), B, H, D, d_pooled.data_ptr(), 2 * D, dx.data_ptr(),
                                                  N.stream())
                 if rc == 0:
@@ -1253,7 +1206,7 @@ class HistoryEncoder(_LookupFunction):
             grads[4 * l: 4 * l + 4] = [dW_in, db_in, dW_out, db_out]
         for fn, aside, hold_f, leaves_f in tail_jobs:
             if aside:
-                run_on_side(dev, fn, hold=hold_f, leaves=leaves_f)
+                run_on_side(dev, fn, hold=hold_f, leaves=leaves_f, again=True)
             else:
                 fn()
         if dx is None:  # L == 0: slot 0 is row 0 of (x + pe)
