@@ -580,7 +580,7 @@ def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: re-exec this script as N ranks under
     torch.distributed.run (one rank per GPU, RCCL) on a free local port, pass the ranks' output through
     and print rank 0's JSON line LAST.  On a box with fewer than N devices (the 1-GPU test boxes) the
-    ranks share cuda:0 and exchange through gloo -- bench.py's TT_BENCH_DIST_BACKEND test hook -- and
+    ranks share cuda:0 and exchange through gloo -- bench.py's TT_DIST_BACKEND test hook -- and
     the JSON line says so in config.parallelism."""
     import socket
     import subprocess
@@ -589,9 +589,9 @@ def self_launch(n: int) -> int:
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ)
-    if "TT_BENCH_DIST_BACKEND" not in env and torch.cuda.device_count() < n:
+    if "TT_DIST_BACKEND" not in env and torch.cuda.device_count() < n:
         sys.stderr.write(f"bench.py: {torch.cuda.device_count()} device(s) < --gpus {n}: ranks share cuda:0 over gloo\n")
-        env["TT_BENCH_DIST_BACKEND"] = "gloo"
+        env["TT_DIST_BACKEND"] = "gloo"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, stdin=subprocess.DEVNULL)
@@ -648,9 +648,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # TT_BENCH_DIST_BACKEND=gloo: test hook -- all ranks share cuda:0 and exchange through gloo (RCCL
+    # TT_DIST_BACKEND=gloo: test hook -- all ranks share cuda:0 and exchange through gloo (RCCL
     # refuses two ranks on one device), so the N > 1 code path can be exercised on a 1-GPU box.
-    dist_backend = os.environ.get("TT_BENCH_DIST_BACKEND", "nccl")
+    dist_backend = os.environ.get("TT_DIST_BACKEND", "nccl")
     device = torch.device(f"cuda:{local_rank if dist_backend == 'nccl' else 0}")
     torch.cuda.set_device(device)
     cfg = dict(WORKLOADS[args.workload])
@@ -755,13 +755,6 @@ def main():
         else:
             step(batches[i % len(batches)])
 
-    main_ctx = None
-    k_sweep = int(os.environ.get("TT_SWEEP_CUS", "0"))
-    if 0 < k_sweep < 8 and not use_sharded:  # A/B: forward / backward on the CUs the sweep's stream does not use
-        comp = N.cu_masked_stream(device, lambda i: i % 8 >= k_sweep)
-        comp.wait_stream(torch.cuda.current_stream())
-        main_ctx = torch.cuda.stream(comp)
-        main_ctx.__enter__()
     for i in range(args.warmup):
         run(i)
     barrier()
@@ -792,8 +785,6 @@ def main():
         rank_ms = {"min": round(float(every.min()) / args.steps * 1e3, 4), "max": round(float(every.max()) / args.steps * 1e3, 4)}
         dt = float(every.max())
 
-    if main_ctx is not None:
-        main_ctx.__exit__(None, None, None)
     import ctypes as C
     ms, cnt = C.c_double(0.0), C.c_int64(0)
     prof_kernel = b"adam_flush_kernel" if args.adam == "lazy" else b"adam_sweep_kernel"
@@ -821,9 +812,7 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             traffic = pmc_traffic_bytes(tpath, args.workload, world)
             # the name rocprofv3 reports for it (profiles/r01_kernel_stats_P_1gpu_final.csv)
-            sweep_name = ("adam_sweep_bounded_kernel" if os.environ.get("TT_SWEEP_PERSIST") == "0"
-                          else "adam_sweep_persistent_kernel" if os.environ.get("TT_SWEEP_ONE_LAUNCH") == "0"
-                          else "adam_sweep_tables_kernel")
+            sweep_name = "adam_sweep_tables_kernel"
             roof = {"bound": "hbm", "kernel": sweep_name, "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic,

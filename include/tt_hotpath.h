@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 1
+#define TT_ABI_VERSION 2
 
 #define TT_E_BADARG (-1)      /* null pointer / negative size / unsupported shape */
 #define TT_E_WORKSPACE (-2)   /* ws_bytes smaller than tt_*_workspace_bytes()     */
@@ -405,9 +405,6 @@ int tt_adam_begin_ids_planes(double* hyper, float* tab, int64_t tab_steps, const
 /* A HIP stream of the device's least priority (hipStreamCreateWithPriority) for
  * tt_adam_table_sweep, so the backward pass on the caller's stream is dispatched first. */
 int tt_stream_create_low_priority(void** out_stream);
-/* A stream whose kernels run only on the CUs whose bit is set in `mask` (host array, 32 CUs per word;
- * hipExtStreamCreateWithCUMask): the sweep and the forward / backward kernels can be given disjoint CUs. */
-int tt_stream_create_cu_mask(const uint32_t* mask /*host*/, int32_t n_words, void** out_stream);
 int tt_stream_destroy(void* stream);
 
 /* Deferred ("lazy") schedule of the SAME dense Adam -- value-exact, reported separately from the
@@ -480,26 +477,8 @@ int tt_attn_fwd(const float* qkv, int64_t B, int64_t H, int64_t D, int64_t heads
                 float* lse, tt_stream_t stream);
 int tt_attn_bwd(const float* qkv, const float* ctx, const float* lse, const float* d_ctx,
                 int64_t B, int64_t H, int64_t D, int64_t heads, float* d_qkv, tt_stream_t stream);
-/* The encoder's LAST layer is consumed at row 0 only (ref:...encoder.py:113): one query per sample.
- *   q0 [B, D] (row stride ldq) = projected query of history position 0; kv [B*H, 2D] (row stride
- *   ldkv) = [K | V] of every position; ctx0 [B, D]; probs [B, heads, H] (saved for the backward).
- *   H <= 64.  The backward writes every row of d_kv [B*H, 2D] and d_q0 [B, D]. */
-int tt_attn_row0_fwd(const float* q0, int64_t ldq, const float* kv, int64_t ldkv, int64_t B, int64_t H,
-                     int64_t D, int64_t heads, float* ctx0, float* probs, tt_stream_t stream);
-int tt_attn_row0_bwd(const float* q0, int64_t ldq, const float* kv, int64_t ldkv, const float* probs,
-                     const float* d_ctx0, int64_t B, int64_t H, int64_t D, int64_t heads, float* d_q0,
-                     float* d_kv, int64_t ld_dkv, tt_stream_t stream);
-/* One WHOLE attention layer of the encoder in one launch (round 4; ref:src/user_history_encoder.py:103-108 =
- * nn.MultiheadAttention(x, x, x)[0]): y = (softmax((x Wq^T + bq)(x Wk^T + bk)^T / sqrt(dh)) (x Wv^T + bv)) Wo^T + bo per
- * sample, one sample per workgroup, the packed projection and the context held in LDS.  x [B*H, D]; y [B*H, D]
- * (ld_y = D) or, rows0_only != 0, row 0 of every sample into y [B, ld_y].  qkv [B*H, 3D], ctx [B*H, D], lse
- * [B, heads, H] may each be NULL; when given they receive what tt_gemm_f32 + tt_attn_fwd would have produced (the
- * backward's inputs).  Shape class: D = 128, heads = 4, H <= 55 (tt_enc_layer_fwd_supported), 16-byte aligned. */
-int tt_enc_layer_fwd_supported(int64_t H, int64_t D, int64_t heads);
-int tt_enc_layer_fwd(const float* x, int64_t B, int64_t H, int64_t D, int64_t heads, const float* w_in,
-                     const float* b_in, const float* w_out, const float* b_out, float* y, int64_t ld_y,
-                     int rows0_only, float* qkv, float* ctx, float* lse, tt_stream_t stream);
-/* The same layer WITHOUT projecting K and V (round 4; ref:src/user_history_encoder.py:103-116 with only row 0 of
+/* The encoder's LAST layer is consumed at row 0 only (ref:src/user_history_encoder.py:103-116): it runs WITHOUT
+ * projecting K and V. ref:src/user_history_encoder.py:103-116 with only row 0 of
  * the last nn.MultiheadAttention consumed).  x [B*H, D] is the layer's input, w_in [3D, D] / b_in [3D] / w_out [D, D] /
  * b_out [D] its packed parameters.  With q0 = W_q x[b,0] + b_q:  score_h[j] = scale (W_k,h^T q0_h) . x[b,j]  (the K bias
  * shifts every score of a head alike and drops out of the softmax) and ctx0_h = W_v,h (sum_j p_h[j] x[b,j]) + b_v,h,

@@ -46,7 +46,7 @@ def test_single_gpu_line():
 
 
 def test_two_rank_launch_line():
-    env = dict(os.environ, TT_BENCH_DIST_BACKEND="gloo")
+    env = dict(os.environ, TT_DIST_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2",
                         "--workload", "tiny", "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env,
@@ -64,7 +64,7 @@ def test_self_launch_needs_no_env():
     (RCCL with one device per rank when the box has them, otherwise both on cuda:0 over gloo) and still prints
     ONE JSON line last."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR",
-                                                            "MASTER_PORT", "TT_BENCH_DIST_BACKEND")}
+                                                            "MASTER_PORT", "TT_DIST_BACKEND")}
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "tiny", "--steps", "3", "--warmup", "1"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900, stdin=subprocess.DEVNULL)
     assert r.returncode == 0, r.stderr[-3000:]

@@ -522,36 +522,6 @@ def test_single_term_debias_heads_match_torch_expressions(T, B, Tn, DI, case, mo
     assert torch.equal(got2, got) and all(a.grad is None or torch.equal(a.grad, b.grad) for a, b in zip(leaves, leaves2))
 
 
-@pytest.mark.parametrize("B,H,D,heads", [(9, 50, 128, 4), (5, 64, 64, 4), (3, 1, 32, 2), (70, 7, 48, 3)])
-def test_single_query_attention_matches_full_attention_row0(T, B, H, D, heads):
-    """tt_attn_row0_fwd / _bwd (the encoder's last layer: only history position 0 is consumed) against
-    torch autograd on the same algebra: context of query 0, and the gradients it sends to q0, K, V."""
-    ops, N = T
-    lib = N.load()
-    dh = D // heads
-    q0 = g((B, D), 71).requires_grad_(True)
-    kv = g((B * H, 2 * D), 72).requires_grad_(True)
-    K = kv[:, :D].reshape(B, H, heads, dh).permute(0, 2, 1, 3)
-    V = kv[:, D:].reshape(B, H, heads, dh).permute(0, 2, 1, 3)
-    sc = torch.einsum("bhd,bhjd->bhj", q0.reshape(B, heads, dh) / math.sqrt(dh), K)
-    P = torch.softmax(sc, dim=-1)
-    ref = torch.einsum("bhj,bhjd->bhd", P, V).reshape(B, D)
-    d_ctx = g((B, D), 73)
-    ref.backward(d_ctx)
-    q0d, kvd = q0.detach().to(DEV), kv.detach().to(DEV)
-    ctx0, probs = torch.empty(B, D, device=DEV), torch.empty(B, heads, H, device=DEV)
-    N.check(lib.tt_attn_row0_fwd(q0d.data_ptr(), D, kvd.data_ptr(), 2 * D, B, H, D, heads, ctx0.data_ptr(),
-                                 probs.data_ptr(), N.stream()), "row0 fwd")
-    assert torch.allclose(ctx0.cpu(), ref.detach(), atol=2e-6, rtol=1e-5)
-    assert torch.allclose(probs.cpu(), P.detach(), atol=1e-6, rtol=1e-5)
-    d_q0, d_kv = torch.empty(B, D, device=DEV), torch.empty(B * H, 2 * D, device=DEV)
-    dcd = d_ctx.to(DEV)
-    N.check(lib.tt_attn_row0_bwd(q0d.data_ptr(), D, kvd.data_ptr(), 2 * D, probs.data_ptr(), dcd.data_ptr(), B, H, D,
-                                 heads, d_q0.data_ptr(), d_kv.data_ptr(), 2 * D, N.stream()), "row0 bwd")
-    assert torch.allclose(d_q0.cpu(), q0.grad, atol=2e-6 * float(q0.grad.abs().max()) + 1e-9, rtol=1e-4)
-    assert torch.allclose(d_kv.cpu(), kv.grad, atol=2e-6 * float(kv.grad.abs().max()) + 1e-9, rtol=1e-4)
-
-
 def test_weighted_mean_loss(T):
     ops, N = T
     B, Tn = 777, 3
@@ -817,57 +787,6 @@ def test_encoder_last_layer_without_kv_projection(T, B, H, D, heads, prev):
     if prev:
         close(dWp, w_pa.grad, "dW_prev_out")
         close(dbp, b_pa.grad, "db_prev_out")
-
-
-@pytest.mark.parametrize("B,H", [(1, 50), (5, 50), (300, 50), (7, 1), (3, 55), (258, 7), (513, 33)])
-@pytest.mark.parametrize("rows0", [False, True])
-def test_fused_encoder_layer_forward(T, B, H, rows0):
-    """tt_enc_layer_fwd (csrc/encoder_layer.hip: in-projection + attention + out-projection of one sample per
-    workgroup, D = 128, 4 heads) against the oracle's layer (oracle/cpu_ref.self_attention_layer) -- the output and the
-    three by-products the backward consumes (packed projection, context, row log-sum-exp)."""
-    ops, N = T
-    lib = N.load()
-    D, heads = 128, 4
-    assert lib.tt_enc_layer_fwd_supported(H, D, heads)
-    x = g((B, H, D), 401)
-    w_in = g((3 * D, D), 402) * (1.0 / math.sqrt(D))
-    b_in = g((3 * D,), 403) * 0.1
-    w_out = g((D, D), 404) * (1.0 / math.sqrt(D))
-    b_out = g((D,), 405) * 0.1
-    want = R.self_attention_layer(x, w_in, b_in, w_out, b_out, heads)
-    qkv_w = x.reshape(B * H, D) @ w_in.t() + b_in
-    dh = D // heads
-    q, k, v = (t_.reshape(B, H, heads, dh).permute(0, 2, 1, 3) for t_ in (qkv_w[:, :D], qkv_w[:, D:2 * D], qkv_w[:, 2 * D:]))
-    sc = (q / math.sqrt(dh)) @ k.transpose(-1, -2)
-    ctx_w = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B * H, D)
-    lse_w = torch.logsumexp(sc, -1)
-    xd = x.reshape(B * H, D).to(DEV)
-    wi, bi, wo, bo = (t_.to(DEV) for t_ in (w_in, b_in, w_out, b_out))
-    qkv = torch.full((B * H, 3 * D), float("nan"), device=DEV)
-    ctx = torch.full((B * H, D), float("nan"), device=DEV)
-    lse = torch.full((B, heads, H), float("nan"), device=DEV)
-    if rows0:
-        y = torch.zeros(B, 2 * D, device=DEV)
-        ld = 2 * D
-    else:
-        y = torch.full((B * H, D), float("nan"), device=DEV)
-        ld = D
-    N.check(lib.tt_enc_layer_fwd(xd.data_ptr(), B, H, D, heads, wi.data_ptr(), bi.data_ptr(), wo.data_ptr(), bo.data_ptr(),
-                                 y.data_ptr(), ld, 1 if rows0 else 0, qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(),
-                                 N.stream()), "enc_layer_fwd")
-    assert torch.allclose(qkv.cpu(), qkv_w, atol=3e-6, rtol=1e-5)
-    assert torch.allclose(ctx.cpu(), ctx_w, atol=3e-6, rtol=1e-5)
-    assert torch.allclose(lse.cpu(), lse_w, atol=1e-5)
-    if rows0:
-        assert torch.allclose(y[:, :D].cpu(), want[:, 0, :], atol=3e-6, rtol=1e-5)
-        assert float(y[:, D:].abs().max()) == 0.0
-    else:
-        assert torch.allclose(y.cpu().reshape(B, H, D), want, atol=3e-6, rtol=1e-5)
-    # without the by-products (inference): same output
-    y2 = torch.zeros_like(y) if rows0 else torch.full_like(y, float("nan"))
-    N.check(lib.tt_enc_layer_fwd(xd.data_ptr(), B, H, D, heads, wi.data_ptr(), bi.data_ptr(), wo.data_ptr(), bo.data_ptr(),
-                                 y2.data_ptr(), ld, 1 if rows0 else 0, None, None, None, N.stream()), "enc_layer_fwd")
-    assert torch.equal(y2, y)
 
 
 @pytest.mark.parametrize("D,H,B", [(128, 50, 9), (50, 7, 4)])

@@ -278,6 +278,64 @@ def test_encoder_matches_reference(golden, name):
     check_grads(enc, g)
 
 
+@pytest.mark.parametrize("name", ["g3_encoder_d128", "g3_encoder_odd"])
+def test_encoder_plain_composition_matches_reference(golden, name, monkeypatch):
+    """TT_ENC_GENERIC: every layer in full (in-projection, attention, out-projection; no folded out-projections, no
+    collapsed last layer, no pool epilogue) -- the composition shapes outside the shortcut kernels' limits run -- against
+    the same goldens as the default path."""
+    from two_tower_models_amd import ops
+    monkeypatch.setattr(ops, "_ENC_GENERIC", True)
+    test_encoder_matches_reference(golden, name)
+
+
+def _encoder_grads(g, main_only=False, hook=False, shared=False):
+    """Weight gradients of the g3 encoder through loss.backward() (the side-stream deferral only arms inside a backward
+    pass); `hook`: a tensor hook on one in_proj_bias; `shared`: the SAME encoder applied to two inputs in one graph."""
+    import two_tower_models_amd as A
+    from two_tower_models_amd import ops
+    D, H, heads, L, B, pe = (int(v) for v in g["cfg"])
+    enc = A.UserHistoryEncoder(D, H, heads, L, bool(pe))
+    enc.load_state_dict(state_of(g))
+    enc = enc.to(DEV)
+    seen = []
+    if hook:
+        enc.multihead_attn_layers[1].in_proj_bias.register_hook(lambda gr: seen.append(gr.clone()))
+    old = ops._SIDE_GRADS
+    ops._SIDE_GRADS = not main_only
+    try:
+        x = T(g["x"]).to(DEV)
+        y = enc(x)
+        loss = (y * T(g["cot"]).to(DEV)).sum()
+        if shared:
+            loss = loss + (enc(x.flip(0)) * T(g["cot"]).to(DEV)).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops._SIDE_GRADS = old
+    return {n: p.grad.clone() for n, p in enc.named_parameters()}, seen
+
+
+def test_side_stream_weight_gradients_equal_inline_ones(golden):
+    """ops.run_on_side: weight gradients queued on the third stream are the in-line ones bit for bit --
+    including in_proj_bias of a folded layer, whose buffer must be STOLEN by AccumulateGrad (never held: a held output
+    is cloned on the main stream before the side stream wrote it); a hooked Parameter and a Parameter that feeds two
+    nodes of one backward pass get completed gradients (run in line)."""
+    g = golden("g3_encoder_d128")
+    want, _ = _encoder_grads(g, main_only=True)
+    for kw in (dict(), dict(hook=True)):
+        for _ in range(3):  # a race would not show every time
+            got, seen = _encoder_grads(g, **kw)
+            for n in want:
+                assert torch.equal(got[n], want[n]), (n, kw)
+            if kw.get("hook"):
+                assert len(seen) == 1 and torch.equal(seen[0], want["multihead_attn_layers.1.in_proj_bias"])
+    want2, _ = _encoder_grads(g, main_only=True, shared=True)
+    for _ in range(3):
+        got2, _ = _encoder_grads(g, shared=True)
+        for n in want2:
+            assert torch.equal(got2[n], want2[n]), (n, "shared")
+
+
 @pytest.mark.parametrize("name", ["g4_hist_d128", "g4_hist_tiny"])
 def test_history_model_matches_reference(golden, name):
     g = golden(name)

@@ -24,7 +24,7 @@ TT_COMM_ID_BYTES = 128
 TT_COMM_F32, TT_COMM_I32, TT_COMM_I64, TT_COMM_U8 = 0, 1, 2, 3
 TT_COMM_SUM, TT_COMM_MAX = 0, 1
 TT_MAX_GRAD_SOURCES = 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp, _i64, _i32, _int = C.c_void_p, C.c_int64, C.c_int32, C.c_int
 
@@ -136,7 +136,6 @@ SIGNATURES = {
                                   _vp, _i64, _vp, _vp, _i64, _vp]),
     "tt_adam_table_flush": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
     "tt_stream_create_low_priority": (_int, [C.POINTER(_vp)]),
-    "tt_stream_create_cu_mask": (_int, [C.POINTER(C.c_uint32), _i32, C.POINTER(_vp)]),
     "tt_stream_destroy": (_int, [_vp]),
     "tt_adam_dense": (_int, [C.POINTER(AdamTensor), _i32, _vp, _vp]),
     "tt_pack_grads": (_int, [C.POINTER(AdamTensor), _i32, _vp]),
@@ -145,10 +144,6 @@ SIGNATURES = {
     "tt_hist_pool_bwd": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "tt_attn_fwd": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "tt_attn_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
-    "tt_attn_row0_fwd": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
-    "tt_attn_row0_bwd": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp]),
-    "tt_enc_layer_fwd_supported": (_int, [_i64, _i64, _i64]),
-    "tt_enc_layer_fwd": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
     "tt_enc_last_supported": (_int, [_i64, _i64, _i64]),
     "tt_enc_last_fwd": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp]),
@@ -272,19 +267,6 @@ def aux_stream(device: torch.device) -> torch.cuda.Stream:
     if key not in _streams:
         _streams[key] = torch.cuda.Stream(device=device)
     return _streams[key]
-
-
-def cu_masked_stream(device: torch.device, keep, n_cus: int = 256) -> torch.cuda.Stream:
-    """Stream restricted to the CUs i for which keep(i) is true (tt_stream_create_cu_mask)."""
-    words = (n_cus + 31) // 32
-    mask = (C.c_uint32 * words)()
-    for i in range(n_cus):
-        if keep(i):
-            mask[i // 32] |= 1 << (i % 32)
-    with torch.cuda.device(device):
-        raw = _vp()
-        check(load().tt_stream_create_cu_mask(mask, words, C.byref(raw)), "tt_stream_create_cu_mask")
-    return torch.cuda.ExternalStream(raw.value, device=device)
 
 
 # ----------------------------------------------------------------- scratch

@@ -356,39 +356,12 @@ __global__ __launch_bounds__(256) void adam_finish_tables_kernel(const FinishJob
                         blockIdx.x - jobs.first_block[t]);
 }
 
-// The roofline kernel: 3 x 16-B loads + 3 x 16-B stores per lane per float4, nothing else.
-// (Non-temporal loads/stores and a plain grid-stride loop were A/B'd on hardware and lose 3-5 %;
-// see DESIGN.md.)
-// One-shot bounded-work form (TT_SWEEP_PERSIST=0): each workgroup streams SWEEP_ITERS x 256
-// float4 triples and exits.  Kept as the A/B partner of the persistent kernel below: the
-// dispatcher refills every freed slot with another of these small workgroups, so the big
-// forward / backward workgroups starve until the grid is exhausted (sweep + compute in series).
-constexpr int SWEEP_ITERS = 8;
-__global__ __launch_bounds__(256) void adam_sweep_bounded_kernel(float4* __restrict__ W, float4* __restrict__ M,
-                                                                 float4* __restrict__ V, int64_t n4,
-                                                                 const double* __restrict__ hyper) {
-  const AdamConst c = load_hyper(hyper);
-  const int64_t base = (int64_t)blockIdx.x * (256 * SWEEP_ITERS) + threadIdx.x;
-#pragma unroll 2
-  for (int k = 0; k < SWEEP_ITERS; ++k) {
-    const int64_t i = base + (int64_t)k * 256;
-    if (i >= n4) break;
-    float4 p = W[i], m = M[i], v = V[i];
-    adam_elem_zero_grad(p.x, m.x, v.x, c);
-    adam_elem_zero_grad(p.y, m.y, v.y, c);
-    adam_elem_zero_grad(p.z, m.z, v.z, c);
-    adam_elem_zero_grad(p.w, m.w, v.w, c);
-    W[i] = p; M[i] = m; V[i] = v;
-  }
-}
-
-// Persistent form of the same chunking: gridDim.x = (#CUs x workgroups-per-CU) workgroups take
-// 256 x ITERS-float4 chunks in order, so neighbouring workgroups stream neighbouring chunks
-// (the DRAM page pattern of the bounded kernel) while the sweep's footprint on every CU stays
-// FIXED: a few light waves per SIMD, no LDS.  That leaves registers, LDS and wave slots for
-// the forward / backward kernels' big workgroups for the whole 5 ms the sweep lasts -- with the
-// one-shot grid above the dispatcher refills every freed slot with another small sweep
-// workgroup and a 256-VGPR / 64-KiB workgroup never finds a whole CU's worth of room.
+// The roofline kernel: 3 x 16-B loads + 3 x 16-B stores per lane per float4, nothing else.  Persistent: gridDim.x =
+// (#CUs x workgroups-per-CU) workgroups take 256 x ITERS-float4 chunks in order, so neighbouring workgroups stream
+// neighbouring chunks while the sweep's footprint on every CU stays FIXED: a few light waves per SIMD, no LDS.  That
+// leaves registers, LDS and wave slots for the forward / backward kernels' big workgroups for the whole 5 ms the sweep
+// lasts (a one-shot grid lets the dispatcher refill every freed slot with another small sweep workgroup, and a
+// 256-VGPR / 64-KiB workgroup never finds a whole CU's worth of room: sweep + compute in series).
 typedef float vf4 __attribute__((ext_vector_type(4)));
 template <bool NT>
 __device__ __forceinline__ float4 sweep_load(const float4* p) {
@@ -724,25 +697,16 @@ static int launch_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t di
   if (n4 > 0) {
     float4 *w4 = reinterpret_cast<float4*>(W), *m4 = reinterpret_cast<float4*>(M), *v4 = reinterpret_cast<float4*>(V);
     ProfScope prof("adam_sweep_kernel", st);
-    // Persistent, dynamically chunked sweep with TT_SWEEP_PERSIST workgroups per CU (default 3 =
-    // 3 waves per SIMD, ~12 16-byte loads in flight per lane: HBM-saturating on its own and small
-    // enough that a 256-VGPR / 64-KiB forward / backward workgroup still fits next to it; from 5
-    // per CU upwards it no longer does and the overlapped step degrades to sweep + compute in
-    // series -- measured, profiles/README.md).  TT_SWEEP_PERSIST=0 selects the one-shot bounded
-    // grid instead (the A/B partner).
-    static const int persist = getenv("TT_SWEEP_PERSIST") ? atoi(getenv("TT_SWEEP_PERSIST")) : SWEEP_DEFAULT_PERSIST;
-    if (persist > 0) {
-      // hyper[7] is the library's scratch slot: two 32-bit chunk counters, zero between launches
-      unsigned* ctr = reinterpret_cast<unsigned*>(const_cast<double*>(hyper) + 7);
-      unsigned grid = (unsigned)(device_cu_count() * persist);
-      if (n_wgs > 0 && (unsigned)n_wgs < grid) grid = (unsigned)n_wgs;
-      static const bool nt = !(getenv("TT_SWEEP_NT") && atoi(getenv("TT_SWEEP_NT")) == 0);  // A/B switch, default on
-      static const int prio = getenv("TT_SWEEP_PRIO") ? atoi(getenv("TT_SWEEP_PRIO")) : 0;
-      if (nt) adam_sweep_persistent_kernel<4, 4, true><<<grid, 256, 0, st>>>(w4, m4, v4, n4, hyper, ctr, prio);
-      else adam_sweep_persistent_kernel<4, 4, false><<<grid, 256, 0, st>>>(w4, m4, v4, n4, hyper, ctr, prio);
-    } else {
-      adam_sweep_bounded_kernel<<<(unsigned)ceil_div(n4, 256 * SWEEP_ITERS), 256, 0, st>>>(w4, m4, v4, n4, hyper);
-    }
+    // Persistent, dynamically chunked sweep with SWEEP_DEFAULT_PERSIST = 3 workgroups per CU (3 waves per SIMD, ~12
+    // 16-byte loads in flight per lane: HBM-saturating on its own and small enough that a 256-VGPR / 64-KiB forward /
+    // backward workgroup still fits next to it; from 5 per CU upwards it no longer does and the overlapped step degrades
+    // to sweep + compute in series), non-temporal loads / stores.  The one-shot bounded grid, the temporal form and the
+    // raised-priority form lost their A/Bs (profiles/HISTORY.md) and are gone.
+    // hyper[7] is the library's scratch slot: two 32-bit chunk counters, zero between launches
+    unsigned* ctr = reinterpret_cast<unsigned*>(const_cast<double*>(hyper) + 7);
+    unsigned grid = (unsigned)(device_cu_count() * SWEEP_DEFAULT_PERSIST);
+    if (n_wgs > 0 && (unsigned)n_wgs < grid) grid = (unsigned)n_wgs;
+    adam_sweep_persistent_kernel<4, 4, true><<<grid, 256, 0, st>>>(w4, m4, v4, n4, hyper, ctr, 0);
     if ((rc = check_launch("adam_sweep_kernel"))) return rc;
   }
   if (n4 * 4 < total) {
@@ -873,11 +837,7 @@ extern "C" int tt_adam_tables_sweep(const tt_adam_tensor* tables, int32_t n_tabl
   if (!tables || !hyper) return fail_arg("tt_adam_tables_sweep: null pointer");
   if (n_tables <= 0 || n_tables > SWEEP_MAX_TABLES) return fail_arg("tt_adam_tables_sweep: 1..4 tables");
   hipStream_t st = S(stream);
-  static const int persist = getenv("TT_SWEEP_PERSIST") ? atoi(getenv("TT_SWEEP_PERSIST")) : SWEEP_DEFAULT_PERSIST;
-  static const bool nt = !(getenv("TT_SWEEP_NT") && atoi(getenv("TT_SWEEP_NT")) == 0);
-  static const int prio = getenv("TT_SWEEP_PRIO") ? atoi(getenv("TT_SWEEP_PRIO")) : 0;
-  static const bool one_launch = !(getenv("TT_SWEEP_ONE_LAUNCH") && atoi(getenv("TT_SWEEP_ONE_LAUNCH")) == 0);
-  bool fused = persist > 0 && one_launch && n_tables > 1;
+  bool fused = n_tables > 1;
   SweepTables tabs{};
   unsigned chunks = 0;
   for (int t = 0; t < n_tables; ++t) {
@@ -904,11 +864,10 @@ extern "C" int tt_adam_tables_sweep(const tt_adam_tensor* tables, int32_t n_tabl
     return 0;
   }
   unsigned* ctr = reinterpret_cast<unsigned*>(const_cast<double*>(hyper) + 7);
-  unsigned grid = (unsigned)(device_cu_count() * persist);
+  unsigned grid = (unsigned)(device_cu_count() * SWEEP_DEFAULT_PERSIST);
   if (want > 0 && (unsigned)want < grid) grid = (unsigned)want;
   ProfScope prof("adam_sweep_kernel", st);
-  if (nt) adam_sweep_tables_kernel<4, 4, true><<<grid, 256, 0, st>>>(tabs, hyper, ctr, prio);
-  else adam_sweep_tables_kernel<4, 4, false><<<grid, 256, 0, st>>>(tabs, hyper, ctr, prio);
+  adam_sweep_tables_kernel<4, 4, true><<<grid, 256, 0, st>>>(tabs, hyper, ctr, 0);
   return check_launch("adam_sweep_tables_kernel");
 }
 
@@ -922,17 +881,6 @@ extern "C" int tt_stream_create_low_priority(void** out) {
   hipStream_t s;
   e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least);
   if (e != hipSuccess) { set_error("hipStreamCreateWithPriority: %s", hipGetErrorString(e)); return (int)e; }
-  *out = reinterpret_cast<void*>(s);
-  return 0;
-}
-// A stream restricted to a subset of the CUs (hipExtStreamCreateWithCUMask): `mask` holds one bit per CU, 32 per
-// word.  Lets the HBM-bound sweep and the MFMA / latency-bound forward / backward kernels run on DISJOINT CUs, so
-// neither takes wave slots, LDS or issue cycles from the other (they still share HBM and L2).
-extern "C" int tt_stream_create_cu_mask(const uint32_t* mask, int32_t n_words, void** out) {
-  if (!mask || !out || n_words <= 0) return fail_arg("tt_stream_create_cu_mask: null pointer / size");
-  hipStream_t s;
-  hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask);
-  if (e != hipSuccess) { set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e)); return (int)e; }
   *out = reinterpret_cast<void*>(s);
   return 0;
 }

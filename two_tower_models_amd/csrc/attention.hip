@@ -160,114 +160,6 @@ static int opt_in(K kernel, size_t lds, const char* name) {
 }
 
 
-// ------------------------------------------------------------------ single-query attention
-// The encoder consumes only ROW 0 of its last layer (ref:src/user_history_encoder.py:113), so
-// that layer needs one query per sample: 1/H of the score / context work, no Q projection for the
-// other rows, and a backward that touches K and V once.  One wavefront per (sample, head), H <= 64:
-// lane j owns key j for the scores, lane d owns column d for the context.
-//   fwd: s_j = scale * q . K_j ; p = softmax(s) ; ctx = sum_j p_j V_j        probs saved [B, heads, H]
-//   bwd: dP_j = d_ctx . V_j ; delta = sum_j p_j dP_j ; dS_j = p_j (dP_j - delta)
-//        dq = scale * sum_j dS_j K_j ; dK_j = scale * dS_j q ; dV_j = p_j d_ctx
-// one head slice [H][dh] (K or V) of a (sample, head) -> the wave's LDS image [64][dh+1], coalesced;
-// rows >= H are never read.  Only the matrix that is consumed "one row per lane" is staged; the
-// one consumed "one column per lane" is read from global memory directly (already coalesced).
-__device__ __forceinline__ void stage_slice(float* Xs, const float* __restrict__ Xb, int64_t ldkv, int H, int dh, int lane) {
-  const int ld = dh + 1;
-  for (int i = lane; i < H * dh; i += 64) Xs[(i / dh) * ld + (i % dh)] = Xb[(int64_t)(i / dh) * ldkv + (i % dh)];
-}
-
-__global__ __launch_bounds__(256) void attn_row0_fwd_kernel(const float* __restrict__ q0, int64_t ldq,
-                                                            const float* __restrict__ kv, int64_t ldkv, int64_t n_pairs,
-                                                            int H, int D, int heads, float* __restrict__ ctx0,
-                                                            float* __restrict__ probs) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t pair = (int64_t)blockIdx.x * 4 + wave;
-  if (pair >= n_pairs) return;
-  const int dh = D / heads, ld = dh + 1;
-  float* Ks = reinterpret_cast<float*>(smem_raw) + wave * (64 * ld + 128);
-  float* qs = Ks + 64 * ld;  // [dh] scaled query
-  float* ps = qs + 64;       // [64] probabilities
-  const int64_t b = pair / heads, hd = pair % heads;
-  const float scale = 1.0f / sqrtf((float)dh);
-  const float* Kb = kv + b * H * ldkv + hd * dh;
-  const float* Vb = Kb + D;
-  stage_slice(Ks, Kb, ldkv, H, dh, lane);
-  if (lane < dh) qs[lane] = q0[b * ldq + hd * dh + lane] * scale;
-  __builtin_amdgcn_wave_barrier();
-  float sc = -3.0e38f;
-  if (lane < H) {
-    float acc = 0.f;
-    for (int d = 0; d < dh; ++d) acc = fmaf(qs[d], Ks[lane * ld + d], acc);
-    sc = acc;
-  }
-  const float mx = wave_max(sc);
-  const float e = (lane < H) ? __expf(sc - mx) : 0.f;
-  const float l = wave_sum(e);
-  const float pj = e / l;
-  if (lane < H) probs[pair * H + lane] = pj;
-  ps[lane] = pj;
-  __builtin_amdgcn_wave_barrier();
-  if (lane < dh) {  // column `lane` of V, rows in sequence: 128-B coalesced per row, loads independent
-    float acc = 0.f;
-#pragma unroll 8
-    for (int j = 0; j < H; ++j) acc = fmaf(ps[j], Vb[(int64_t)j * ldkv + lane], acc);
-    ctx0[b * D + hd * dh + lane] = acc;
-  }
-}
-
-__global__ __launch_bounds__(256) void attn_row0_bwd_kernel(const float* __restrict__ q0, int64_t ldq,
-                                                            const float* __restrict__ kv, int64_t ldkv,
-                                                            const float* __restrict__ probs,
-                                                            const float* __restrict__ d_ctx0, int64_t n_pairs, int H,
-                                                            int D, int heads, float* __restrict__ d_q0,
-                                                            float* __restrict__ d_kv, int64_t ld_dkv) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t pair = (int64_t)blockIdx.x * 4 + wave;
-  if (pair >= n_pairs) return;
-  const int dh = D / heads, ld = dh + 1;
-  float* Vs = reinterpret_cast<float*>(smem_raw) + wave * (64 * ld + 256);
-  float* qs = Vs + 64 * ld;  // [dh] query (unscaled)
-  float* dcs = qs + 64;      // [dh] d_ctx0
-  float* gs = dcs + 64;      // [64] scale * dS_j
-  float* pss = gs + 64;      // [64] p_j
-  const int64_t b = pair / heads, hd = pair % heads;
-  const float scale = 1.0f / sqrtf((float)dh);
-  const float* Kb = kv + b * H * ldkv + hd * dh;
-  const float* Vb = Kb + D;
-  stage_slice(Vs, Vb, ldkv, H, dh, lane);
-  if (lane < dh) {
-    qs[lane] = q0[b * ldq + hd * dh + lane];
-    dcs[lane] = d_ctx0[b * D + hd * dh + lane];
-  }
-  __builtin_amdgcn_wave_barrier();
-  float pj = 0.f, dp = 0.f;
-  if (lane < H) {
-    pj = probs[pair * H + lane];
-    for (int d = 0; d < dh; ++d) dp = fmaf(dcs[d], Vs[lane * ld + d], dp);
-  }
-  const float delta = wave_sum(pj * dp);
-  const float dS = pj * (dp - delta);
-  gs[lane] = scale * dS;
-  pss[lane] = pj;
-  __builtin_amdgcn_wave_barrier();
-  // dK_j = (scale dS_j) q, dV_j = p_j d_ctx0: consecutive lanes on consecutive columns
-  float* dKb = d_kv + b * H * ld_dkv + hd * dh;
-  for (int i = lane; i < H * dh; i += 64) {
-    const int row = i / dh, d = i % dh;
-    float* dst = dKb + (int64_t)row * ld_dkv + d;
-    dst[0] = gs[row] * qs[d];
-    dst[D] = pss[row] * dcs[d];
-  }
-  if (lane < dh) {  // dq = scale * sum_j dS_j K_j: column `lane` of K, rows in sequence
-    float acc = 0.f;
-#pragma unroll 8
-    for (int j = 0; j < H; ++j) acc = fmaf(gs[j], Kb[(int64_t)j * ldkv + lane], acc);
-    d_q0[b * D + hd * dh + lane] = acc;
-  }
-}
-
 }  // namespace tt
 
 using namespace tt;
@@ -314,35 +206,4 @@ extern "C" int tt_attn_bwd(const float* qkv, const float* ctx, const float* lse,
   if (dhp == 4) { TT_BWD(4) } else if (dhp == 16) { TT_BWD(16) } else if (dhp == 32) { TT_BWD(32) } else if (dhp == 64) { TT_BWD(64) } else { TT_BWD(128) }
 #undef TT_BWD
   return check_launch("attn_bwd_kernel");
-}
-
-extern "C" int tt_attn_row0_fwd(const float* q0, int64_t ldq, const float* kv, int64_t ldkv, int64_t B, int64_t H,
-                                int64_t D, int64_t heads, float* ctx0, float* probs, tt_stream_t stream) {
-  if (!q0 || !kv || !ctx0 || !probs) return fail_arg("tt_attn_row0_fwd: null pointer");
-  if (B < 0 || H <= 0 || H > 64 || D <= 0 || heads <= 0 || D % heads != 0 || ldq < D || ldkv < 2 * D)
-    return fail_arg("tt_attn_row0_fwd: sizes (H <= 64)");
-  if (B == 0) return 0;
-  const int64_t n = B * heads, dh = D / heads;
-  if (dh > 64) { set_error("tt_attn_row0_fwd: head dim %lld > 64 not implemented", (long long)dh); return TT_E_UNSUPPORTED; }
-  const size_t lds = 4 * (64 * (size_t)(dh + 1) + 128) * sizeof(float);
-  int rc = opt_in(attn_row0_fwd_kernel, lds, "attn_row0_fwd_kernel");
-  if (rc) return rc;
-  attn_row0_fwd_kernel<<<(unsigned)ceil_div(n, 4), 256, lds, S(stream)>>>(q0, ldq, kv, ldkv, n, (int)H, (int)D, (int)heads, ctx0, probs);
-  return check_launch("attn_row0_fwd_kernel");
-}
-
-extern "C" int tt_attn_row0_bwd(const float* q0, int64_t ldq, const float* kv, int64_t ldkv, const float* probs,
-                                const float* d_ctx0, int64_t B, int64_t H, int64_t D, int64_t heads, float* d_q0,
-                                float* d_kv, int64_t ld_dkv, tt_stream_t stream) {
-  if (!q0 || !kv || !probs || !d_ctx0 || !d_q0 || !d_kv) return fail_arg("tt_attn_row0_bwd: null pointer");
-  if (B < 0 || H <= 0 || H > 64 || D <= 0 || heads <= 0 || D % heads != 0 || ldq < D || ldkv < 2 * D || ld_dkv < 2 * D)
-    return fail_arg("tt_attn_row0_bwd: sizes (H <= 64)");
-  if (B == 0) return 0;
-  const int64_t n = B * heads, dh = D / heads;
-  if (dh > 64) { set_error("tt_attn_row0_bwd: head dim %lld > 64 not implemented", (long long)dh); return TT_E_UNSUPPORTED; }
-  const size_t lds = 4 * (64 * (size_t)(dh + 1) + 256) * sizeof(float);
-  int rc = opt_in(attn_row0_bwd_kernel, lds, "attn_row0_bwd_kernel");
-  if (rc) return rc;
-  attn_row0_bwd_kernel<<<(unsigned)ceil_div(n, 4), 256, lds, S(stream)>>>(q0, ldq, kv, ldkv, probs, d_ctx0, n, (int)H, (int)D, (int)heads, d_q0, d_kv, ld_dkv);
-  return check_launch("attn_row0_bwd_kernel");
 }

@@ -361,9 +361,8 @@ static int launch_bwd(const float* qkv, const float* lse, const float* d_ctx, in
 }
 
 bool attn_mfma_supported(const void* a, const void* b, int64_t H, int64_t D, int64_t dh) {
-  static const bool off = getenv("TT_ATTN_NO_MFMA") != nullptr;
   const bool al = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
-  return !off && al && H <= HP && (dh == 16 || dh == 32 || dh == 64) && D % 4 == 0;
+  return al && H <= HP && (dh == 16 || dh == 32 || dh == 64) && D % 4 == 0;
 }
 
 int attn_fwd_mfma(const float* qkv, int64_t B, int64_t H, int64_t D, int64_t heads, float* ctx, float* lse, hipStream_t st) {

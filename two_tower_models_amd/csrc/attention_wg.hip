@@ -319,10 +319,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_wg_kernel(const AttnWgArgs p)
 
 bool attn_bwd_wg_supported(const void* qkv, const void* ctx, const void* d_ctx, const void* d_qkv, int64_t H, int64_t D,
                            int64_t heads) {
-  static const bool off = getenv("TT_ATTN_NO_WG") != nullptr;
   const uintptr_t al = reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(ctx) | reinterpret_cast<uintptr_t>(d_ctx) |
                        reinterpret_cast<uintptr_t>(d_qkv);
-  return !off && (al & 15) == 0 && heads == awg::HEADS && D == awg::D && H >= 1 && H <= 50;  // 50: the loaders' staging split
+  return (al & 15) == 0 && heads == awg::HEADS && D == awg::D && H >= 1 && H <= 50;  // 50: the loaders' staging split
 }
 
 int attn_bwd_wg(const float* qkv, const float* ctx, const float* lse, const float* d_ctx, int64_t B, int64_t H, float* d_qkv,

@@ -349,11 +349,6 @@ static GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
     if (splits > 256) splits = 256;
     if (splits < 1) splits = 1;
   }
-  if (const char* e = getenv("TT_GEMM_SPLITS")) {  // tuning hook
-    splits = atoi(e);
-    if (splits < 1) splits = 1;
-    if (splits > ktiles) splits = ktiles;
-  }
   p.k_per_split = ceil_div(ktiles, splits) * BK;
   p.splits = (int)ceil_div(K, p.k_per_split);
   return p;

@@ -275,9 +275,8 @@ static int tns_launch(const TnsArgs& a, int nwg, float* C, int64_t ldc, int accu
 // Called by tt_gemm_f32 / tt_gemm_tn_colsum_f32 (gemm.hip) for TN products.  -100 = shape not for this kernel.
 int gemm_tn_stream_try(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                        float* C, int64_t ldc, int accumulate, float* a_colsum, void* ws, int64_t ws_bytes, hipStream_t st) {
-  static const bool off = getenv("TT_GEMM_NO_TN_STREAM") != nullptr;
   const int64_t need = gemm_tn_stream_ws_floats(M, N, K) * (int64_t)sizeof(float);
-  if (off || need == 0) return -100;
+  if (need == 0) return -100;
   const uintptr_t al = reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B);
   if ((al & 15) || lda % 4 || ldb % 4 || lda < M || ldb < N) return -100;
   if (lda >= ((int64_t)1 << 22) || ldb >= ((int64_t)1 << 22)) return -100;  // 32-bit byte offsets within a stage

@@ -261,8 +261,7 @@ static int ws_launch_one(int layout, int64_t M, int64_t N, int64_t K, const floa
 int gemm_ws_try(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W,
                 int64_t ldw, float* C, int64_t ldc, const float* bias, int epilogue, const float* aux,
                 int64_t ldaux, int accumulate, hipStream_t st) {
-  static const bool off = getenv("TT_GEMM_NO_WS") != nullptr;
-  if (off || layout == TT_GEMM_TN || K > 512 || K < 1 || M < 16384) return -100;
+  if (layout == TT_GEMM_TN || K > 512 || K < 1 || M < 16384) return -100;
   if (M * ldc >= ((int64_t)1 << 31) || (aux && M * ldaux >= ((int64_t)1 << 31))) return -100;  // 32-bit offsets inside
   if (K <= 256)
     return ws_launch_one(layout, M, N, K, A, lda, W, ldw, C, ldc, bias, epilogue, aux, ldaux, accumulate, 0, st);

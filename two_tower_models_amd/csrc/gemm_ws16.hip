@@ -203,8 +203,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws16_kernel(const Ws16Args p) {
 // epilogue instead of a read-modify-write pass over dx.  -100 = shape not taken.
 int gemm_ws16_pool_try(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
                        const float* pool, int64_t ld_pool, int64_t group, float scale, hipStream_t st) {
-  static const bool off = getenv("TT_GEMM_NO_WS16") != nullptr;
-  if (off || M < 16384 || M >= ((int64_t)1 << 32) || N != 128 || K != 384 || group <= 0 || group >= ((int64_t)1 << 31)) return -100;
+  if (M < 16384 || M >= ((int64_t)1 << 32) || N != 128 || K != 384 || group <= 0 || group >= ((int64_t)1 << 31)) return -100;
   const uintptr_t al = reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(C) |
                        reinterpret_cast<uintptr_t>(pool);
   if ((al & 15) || lda % 4 || ldw % 4 || ldc % 4 || ld_pool % 4 || lda > (1 << 20)) return -100;
@@ -228,8 +227,7 @@ static int ws16_launch(const Ws16Args& a, hipStream_t st) {
 // Called by tt_gemm_f32 (gemm.hip) ahead of gemm_ws_try.  -100 = shape not for this kernel.
 int gemm_ws16_try(int layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* W, int64_t ldw,
                   float* C, int64_t ldc, const float* bias, int epilogue, int accumulate, hipStream_t st) {
-  static const bool off = getenv("TT_GEMM_NO_WS16") != nullptr;
-  if (off || layout == TT_GEMM_TN || M < 16384 || N % 128 || K % 128 || N < 128 || K < 128 || (N / 128) * (K / 128) > 3) return -100;
+  if (layout == TT_GEMM_TN || M < 16384 || N % 128 || K % 128 || N < 128 || K < 128 || (N / 128) * (K / 128) > 3) return -100;
   if (epilogue != TT_EPI_NONE || accumulate) return -100;
   const uintptr_t al = reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(C) |
                        reinterpret_cast<uintptr_t>(bias);

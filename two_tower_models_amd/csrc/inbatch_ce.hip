@@ -888,11 +888,9 @@ static bool plan_ce(int64_t RX, int64_t RY, int64_t D, CePlan& pl) {
   // 512 workgroups = one resident round (2 per CU).  Long streams are cut finer, up to 1024 units of
   // >= 16 tiles: when the Adam sweep is resident only ONE of these 256-VGPR workgroups fits per CU, and
   // with a single static round the late starters set the kernel time (8192 x 65536 under the sweep:
-  // 3.5 ms with 512 units, 2.3 ms with 1024; alone 2.18 ms either way).  TT_CE_UNITS overrides.
-  static const int64_t units_env = getenv("TT_CE_UNITS") ? atoll(getenv("TT_CE_UNITS")) : 0;
-  int64_t splits = ceil_div(units_env > 0 ? units_env : 512, rowblocks);
-  if (units_env <= 0)
-    while (rowblocks * splits < 1024 && tiles >= 32 * splits) splits *= 2;
+  // 3.5 ms with 512 units, 2.3 ms with 1024; alone 2.18 ms either way).
+  int64_t splits = ceil_div(512, rowblocks);
+  while (rowblocks * splits < 1024 && tiles >= 32 * splits) splits *= 2;
   if (splits > ceil_div(tiles, 4)) splits = ceil_div(tiles, 4);
   if (splits > 64) splits = 64;
   if (splits < 1) splits = 1;
@@ -923,33 +921,16 @@ static int dispatch_fwd(int dp8, bool dma, const CeArgs& a, dim3 grid, hipStream
   if (dma) return dp8 == 4 ? launch_fwd<4, true>(a, grid, st) : dp8 == 8 ? launch_fwd<8, true>(a, grid, st) : launch_fwd<16, true>(a, grid, st);
   return dp8 == 4 ? launch_fwd<4, false>(a, grid, st) : dp8 == 8 ? launch_fwd<8, false>(a, grid, st) : launch_fwd<16, false>(a, grid, st);
 }
-// TT_CE_LDS_PAD=bytes (experiment): unused dynamic LDS on top of the static tile buffers, so that only ONE workgroup of
-// the wide-negatives kernels fits a CU and the other half of its register file is free for the Adam sweep's waves
-static int ce_lds_pad() {
-  static const int pad = [] { const char* e = getenv("TT_CE_LDS_PAD"); return e ? atoi(e) : 0; }();
-  return pad;
-}
-template <typename K>
-static int ce_allow_lds(K kernel, int pad) {
-  if (pad <= 0) return 0;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pad);
-  if (e != hipSuccess) { set_error("in-batch CE: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-  return 0;
-}
 template <int DP8, bool GLDS, bool KEEP = false>
 static int launch_fwd_du(const CeArgs& a, dim3 grid, hipStream_t st) {
   ProfScope prof("ce_fwd_kernel", st);
-  const int pad = KEEP ? ce_lds_pad() : 0;
-  if (int rc = ce_allow_lds(ce_fwd_du_kernel<DP8, GLDS, KEEP>, pad)) return rc;
-  ce_fwd_du_kernel<DP8, GLDS, KEEP><<<grid, 256, pad, st>>>(a);  // LDS is static: two named tile buffers
+  ce_fwd_du_kernel<DP8, GLDS, KEEP><<<grid, 256, 0, st>>>(a);  // LDS is static: two named tile buffers
   return check_launch("ce_fwd_du_kernel");
 }
 template <int DP8>
 static int launch_bwd_kept(const CeArgs& a, dim3 grid, hipStream_t st) {
   ProfScope prof("ce_bwd_kernel", st);
-  const int pad = ce_lds_pad();
-  if (int rc = ce_allow_lds(ce_bwd_kept_kernel<DP8>, pad)) return rc;
-  ce_bwd_kept_kernel<DP8><<<grid, 256, pad, st>>>(a);  // LDS is static: two named tile buffers
+  ce_bwd_kept_kernel<DP8><<<grid, 256, 0, st>>>(a);  // LDS is static: two named tile buffers
   return check_launch("ce_bwd_kept_kernel");
 }
 static int dispatch_fwd_du_keep(int dp8, const CeArgs& a, dim3 grid, hipStream_t st) {  // LDS-DMA form only

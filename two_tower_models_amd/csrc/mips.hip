@@ -1490,9 +1490,8 @@ static int launch_pass1_dma(MipsArgs a, int64_t, hipStream_t st) {
 }
 // -1: shape not covered by the DMA form
 static int dispatch_pass1_dma(int dtype, int dpx, const MipsArgs& a, int64_t splits, hipStream_t st) {
-  static const bool no_share = getenv("TT_MIPS_NO_SHARE") != nullptr;
   // small query batch: waves share queries and split the corpus instead (4 waves x 32, 2 pairs x 32)
-  const int sf = no_share ? 0 : a.nq <= 32 ? 4 : a.nq <= 64 ? 2 : 0;
+  const int sf = a.nq <= 32 ? 4 : a.nq <= 64 ? 2 : 0;
   if (dtype == TT_F32) {
     if (dpx == 4) return sf == 4 ? launch_pass1_dma<TT_F32, 4, 1, 4>(a, splits, st) : sf == 2 ? launch_pass1_dma<TT_F32, 4, 1, 2>(a, splits, st) : launch_pass1_dma<TT_F32, 4, 1>(a, splits, st);
     if (dpx == 8) return sf == 4 ? launch_pass1_dma<TT_F32, 8, 1, 4>(a, splits, st) : sf == 2 ? launch_pass1_dma<TT_F32, 8, 1, 2>(a, splits, st) : launch_pass1_dma<TT_F32, 8, 1>(a, splits, st);
@@ -1501,8 +1500,7 @@ static int dispatch_pass1_dma(int dtype, int dpx, const MipsArgs& a, int64_t spl
   if (dtype == TT_F16X2) {
     if (sf) return sf == 4 ? launch_pass1_dma<TT_F16X2, 16, 1, 4>(a, splits, st) : launch_pass1_dma<TT_F16X2, 16, 1, 2>(a, splits, st);
     // two query fragments per wave (64 queries) from 256 queries on: one pair of operand reads feeds six MFMAs
-    static const int f16_nq = getenv("TT_MIPS_F16X2_NQ") ? atoi(getenv("TT_MIPS_F16X2_NQ")) : 0;
-    const int nq2 = f16_nq ? f16_nq == 2 : a.nq > 2 * QB_WG;
+    const int nq2 = a.nq > 2 * QB_WG;
     return nq2 ? launch_pass1_dma<TT_F16X2, 16, 2>(a, splits, st) : launch_pass1_dma<TT_F16X2, 16, 1>(a, splits, st);
   }
   if (sf) {
@@ -1510,8 +1508,7 @@ static int dispatch_pass1_dma(int dtype, int dpx, const MipsArgs& a, int64_t spl
     if (dpx == 8) return sf == 4 ? launch_pass1_dma<TT_BF16, 8, 1, 4>(a, splits, st) : launch_pass1_dma<TT_BF16, 8, 1, 2>(a, splits, st);
     return -1;
   }
-  static const int force_nq = getenv("TT_MIPS_NQ") ? atoi(getenv("TT_MIPS_NQ")) : 0;
-  const int nqf = force_nq ? force_nq : (a.nq > 2 * QB_WG ? 4 : a.nq > QB_WG ? 2 : 1);
+  const int nqf = a.nq > 2 * QB_WG ? 4 : a.nq > QB_WG ? 2 : 1;
   if (dpx == 4) {
     if (nqf == 4) return launch_pass1_dma<TT_BF16, 4, 4>(a, splits, st);
     return nqf == 2 ? launch_pass1_dma<TT_BF16, 4, 2>(a, splits, st) : launch_pass1_dma<TT_BF16, 4, 1>(a, splits, st);
@@ -1612,7 +1609,7 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
     static const bool no_sparse = getenv("TT_MIPS_NO_SPARSE") != nullptr;
     const int dp = pl.dpx * (dtype == TT_BF16 ? 16 : 8);
     const bool sparse = pl.n_groups > K && vec && D == dp && !no_sparse && !wide;
-    static const bool no_dma = getenv("TT_MIPS_NO_DMA") != nullptr;
+    const bool no_dma = false;
     static const bool no_g128 = getenv("TT_MIPS_NO_G128") != nullptr;  // A/B: 64-row groups for bf16 too
     // the LDS-DMA pass 1 (not its shared-query forms) with the sparse pass 2: 256-row chunks, i.e. 128-row
     // groups -- half the result bytes of pass 1 and half the groups for the selection, which reads gmax three times
@@ -1649,8 +1646,8 @@ extern "C" int tt_mips_topk(const void* query, const void* corpus, int dtype, in
       const int64_t qblocks = ceil_div(nq, SEL_Q);
       int64_t slices = ceil_div(2048, qblocks);
       // every slice adds its bins to the same few global counters of a query (in the first pass nearly all keys share
-      // one bin), and same-address atomics serialise: cap the slices of small batches (A/B: TT_MIPS_SEL_SLICES)
-      static const int64_t max_slices = getenv("TT_MIPS_SEL_SLICES") ? atoll(getenv("TT_MIPS_SEL_SLICES")) : 512;
+      // one bin), and same-address atomics serialise: cap the slices of small batches
+      const int64_t max_slices = 512;
       if (slices > max_slices) slices = max_slices;
       if (slices > ceil_div(n_groups, 64)) slices = ceil_div(n_groups, 64);
       if (slices < 1) slices = 1;

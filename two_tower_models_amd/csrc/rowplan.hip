@@ -360,8 +360,7 @@ extern "C" int tt_rowgrad_plan(const int64_t* ids, int64_t n_ids, int64_t n_rows
     return fail_arg("tt_rowgrad_plan: sizes");
   if (ws_bytes < tt_rowgrad_workspace_bytes(n_ids)) { set_error("tt_rowgrad_plan: workspace"); return TT_E_WORKSPACE; }
   hipStream_t st = S(stream);
-  static const bool no_small = getenv("TT_PLAN_NO_SMALL") != nullptr;  // A/B switch
-  if (n_ids <= PS_MAX && !no_small) {
+  if (n_ids <= PS_MAX) {
     int bits = 1;
     while (bits < 31 && ((int64_t)1 << bits) < n_rows) ++bits;
     const int kpt = (int)ceil_div(n_ids, PS_THREADS);

@@ -450,8 +450,6 @@ __global__ __launch_bounds__(1024) void tower_wgrad_reduce_kernel(const float* _
 // CU) had come and gone -- 1.5 ms late, the step's tail 0.1 ms longer at the headline shape.  Below B = 4096 the 32-row
 // form halves the towers' latency (B = 4096: 64 -> 128 workgroups; C2 step 1.216 -> 1.202 ms).
 static int tower_row_tiles(int64_t B) {
-  static const int forced = [] { const char* e = getenv("TT_TOWER_ROW_TILES"); return e ? atoi(e) : 0; }();  // A/B switch
-  if (forced == 1 || forced == 2) return forced;
   return B <= 4096 ? 1 : 2;
 }
 static bool tower_shape_ok(int64_t D, int64_t F, int64_t hidden, int64_t d_out) {

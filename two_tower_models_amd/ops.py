@@ -517,13 +517,12 @@ class TowerInput(_LookupFunction):
         return dweight, None, None, dW1, db1, dW2, db2
 
 
-_FUSED_TOWER = os.environ.get("TT_NO_FUSED_TOWER") is None  # A/B switch
 
 
 def fused_tower_supported(weight, feats, W1, W2, W3, extra_width: int = 0) -> bool:
     """tt_tower_fwd(_x) / tt_tower_bwd_data(_x): hidden = 256, D = d_out in {32, 64, 128}, F <= 64; a third input
     block (`extra_width` columns: the history model's [recent | mean] summary) must be 2D wide."""
-    if not (_FUSED_TOWER and weight.is_cuda and feats.dim() == 2 and feats.dtype == torch.float32):
+    if not (weight.is_cuda and feats.dim() == 2 and feats.dtype == torch.float32):
         return False
     ok = (W3.shape[1] == 2 * weight.shape[1] + extra_width and W2.shape[0] == weight.shape[1]
           and bool(N.load().tt_tower_x_supported(weight.shape[1], feats.shape[1], W1.shape[0], W3.shape[0], extra_width)))
@@ -613,7 +612,6 @@ class FusedTower(_LookupFunction):
         return dweight, None, None, dW1, db1, dW2, db2, dW3, db3, d_extra
 
 
-_TOWER_WGRAD = os.environ.get("TT_TOWER_NO_WGRAD") is None  # A/B switch
 
 
 def tower_weight_grads(dy, tin, d_f, h, dh, feats, out=None, extra=None, side=False):
@@ -637,7 +635,7 @@ def tower_weight_grads(dy, tin, d_f, h, dh, feats, out=None, extra=None, side=Fa
         db2 = torch.empty(D, dtype=torch.float32, device=dev)
         db1 = torch.empty(Hd, dtype=torch.float32, device=dev)
     lib = N.load()
-    if (_TOWER_WGRAD and lib.tt_tower_x_supported(D, F, Hd, D, E) and dy.stride(1) == 1 and dy.stride(0) % 4 == 0 and feats.stride(1) == 1
+    if (lib.tt_tower_x_supported(D, F, Hd, D, E) and dy.stride(1) == 1 and dy.stride(0) % 4 == 0 and feats.stride(1) == 1
             and all(t.is_contiguous() for t in (tin, d_f, h, dh, dW1, db1, dW2, db2, dW3, db3))
             and all(t.data_ptr() % 16 == 0 for t in (dy, tin, d_f, h, dh))
             and (extra is None or (extra.stride(1) == 1 and extra.stride(0) % 4 == 0 and extra.data_ptr() % 16 == 0))):
@@ -659,7 +657,6 @@ def tower_weight_grads(dy, tin, d_f, h, dh, feats, out=None, extra=None, side=Fa
     return dW1, db1, dW2, db2, dW3, db3
 
 
-_FUSED_DU = os.environ.get("TT_CE_NO_FUSED_DU") is None  # A/B switches
 # TT_ENC_GENERIC=1 (tests): the history encoder's plain composition -- every layer in full (in-projection, attention,
 # out-projection; the last one's out-projection for row 0 only) -- instead of the algebraic shortcuts below; it is
 # also what shapes outside the shortcut kernels' limits run, so it has to stay correct
@@ -695,7 +692,7 @@ class InBatchSoftmaxCE(torch.autograd.Function):
         pi, _, _, ldi = _f32_2d(I, "I")
         ctx.diag_offset = diag_offset
         ctx.kept = ctx.kept16 = None
-        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and _FUSED_DU and ldu == D and ldi == D and ce16_usable(U, I) \
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and ldu == D and ldi == D and ce16_usable(U, I) \
                 and 0 <= diag_offset <= Nn - M:
             du_unit = torch.empty(M, D, dtype=torch.float32, device=dev)
             w16p, w16n = _ws(dev, lib.tt_ce16_workspace_bytes(M, Nn, D), "ce16")
@@ -706,7 +703,7 @@ class InBatchSoftmaxCE(torch.autograd.Function):
                                             N.stream()), "tt_ce16_fwd_du_keep")
             ctx.save_for_backward(U, I, lse, du_unit)
             return ce
-        if ctx.needs_input_grad[0] and _FUSED_DU:
+        if ctx.needs_input_grad[0]:
             # training: the forward also accumulates E[i] = sum_j p_ij I_j, which IS the user-side
             # gradient up to the row factor -- the backward then only runs the item-side kernel
             du_unit = torch.empty(M, D, dtype=torch.float32, device=dev)
@@ -823,7 +820,6 @@ class WeightedMeanLoss(torch.autograd.Function):
         return coef * g, None, None
 
 
-_FUSED_LOSS = os.environ.get("TT_CE_NO_FUSED_LOSS") is None  # A/B switch
 # EXPLORATORY: InBatchSoftmaxCE through the split-fp16 pair (csrc/ce_f16x2.hip) where its shapes allow
 # (D = 128, M % 256 == 0, N % 1024 == 0, contiguous rows) -- fp32-grade results on the fp16 matrix pipe.  Never the default.
 _CE16_KEEP = os.environ.get("TT_CE16_KEEP") is not None  # A/B: the split-fp16 pair with kept logits (its first form)
@@ -840,7 +836,7 @@ def fused_loss_supported(U: torch.Tensor, I: torch.Tensor, labels: Optional[torc
     form keeps its logits and has its own forward), float32 everywhere, one label row per user row."""
     if ce16_usable(U, I):
         return False  # the split-fp16 pair is a two-op path: InBatchSoftmaxCE + WeightedMeanLoss
-    return bool(_FUSED_LOSS and _FUSED_DU and U.is_cuda and U.requires_grad and torch.is_grad_enabled() and U.dim() == 2 and I.dim() == 2
+    return bool(U.is_cuda and U.requires_grad and torch.is_grad_enabled() and U.dim() == 2 and I.dim() == 2
                 and U.dtype == torch.float32 and I.dtype == torch.float32 and uvw.dtype == torch.float32
                 and I.shape[0] < 4 * U.shape[0]
                 and (labels is None or (labels.dim() == 2 and labels.shape[0] == U.shape[0] and labels.shape[1] == uvw.numel()

@@ -61,8 +61,6 @@ import torch
 from . import _native as N
 from . import ops
 
-_SPLIT_STASH = os.environ.get("TT_ADAM_ONE_STASH") is None  # A/B: park p | m | v of large lookups in one launch on the main stream
-
 
 class _TableStep:
     """State of one table between the overlapped begin (in zero_grad) and finish (in step)."""
@@ -158,10 +156,7 @@ class DenseExactAdam(torch.optim.Optimizer):
             for key in ("exp_avg", "exp_avg_sq"):  # a loaded checkpoint already supplied them
                 if key not in st or st[key].shape != p.shape or st[key].device != p.device:
                     st[key] = torch.zeros_like(p) if key not in st else st[key].to(p.device, torch.float32).contiguous()
-        # TT_SWEEP_CUS=k (A/B): the sweep's stream is restricted to k of every 8 CUs; the caller may
-        # run the step itself on the complementary CUs (bench.py --cu-split)
-        k = int(os.environ.get("TT_SWEEP_CUS", "0"))
-        self._side_stream = N.cu_masked_stream(dev, lambda i: i % 8 < k) if 0 < k < 8 else N.low_priority_stream(dev)
+        self._side_stream = N.low_priority_stream(dev)
         start = int(self._resume_step)
         self._hyper[4] = float(start)  # [5], [6] are recomputed from the step by every advance
         self._host_steps = start
@@ -345,7 +340,7 @@ class DenseExactAdam(torch.optim.Optimizer):
             # forward can start -- the moments are parked on the sweep's stream, in front of the sweep (C3: 0.15 ms at the
             # head of the step become 0.05).  Small lookups keep the single launch.
             n_stashed = sum(j[6] for j in stash_jobs)
-            split_planes = _SPLIT_STASH and not capturing and 0 < len(stash_jobs) <= 4 and n_stashed >= 65536
+            split_planes = not capturing and 0 < len(stash_jobs) <= 4 and n_stashed >= 65536
             if split_planes:
                 N.check(lib.tt_adam_begin_ids_planes(hyper, None, 0, jobs, len(stash_jobs), 1, N.stream()), "tt_adam_begin_ids_planes")
             else:
