@@ -346,7 +346,32 @@ def _expected_idle(t, r):
     return r * (1.0 - x * math.exp(-x) / (1.0 - math.exp(-x)))
 
 
-def _timed_train(name, device, steps, warmup, lazy=False, fresh_ids=False, steady=False):
+def _tower_flops_fwd(B, D, F, tower_in):
+    return 2.0 * B * (F * 256 + 256 * D) + 2.0 * B * tower_in * D
+
+
+def step_flops(cfg):
+    """Dense-contraction flops of one train step, two ways:
+      executed -- what this build's kernels actually multiply after its algebraic work removal: towers x3 (fwd, data
+                  grad, weight grad), FOUR logit-sized products (fwd S and E = P.I; bwd S again and dI), and for the
+                  history model 2 full attention layers (the last layer is consumed at row 0 only and runs collapsed;
+                  out-projections are folded into the next in-projection) with an attention backward of 5 H^2 products;
+      survey   -- SURVEY.md's count: 3 x the reference's forward contractions (+ nothing recomputed)."""
+    B, D, F, H = cfg["B"], cfg["D"], cfg["F"], cfg["H"]
+    hist = cfg["model"] != "base"
+    logits = 2.0 * B * B * D
+    towers = _tower_flops_fwd(B, D, F, 4 * D if hist else 2 * D) + _tower_flops_fwd(B, D, F, 2 * D)
+    executed, survey = 3.0 * towers + 4.0 * logits, 3.0 * (towers + logits)
+    if hist:
+        L = 3
+        inproj, attn, outproj = 2.0 * B * H * D * 3 * D, 4.0 * B * H * H * D, 2.0 * B * H * D * D
+        last_fwd = 4.0 * B * H * D * 4 + 8.0 * B * D * D
+        executed += (L - 1) * (inproj + attn) + last_fwd + (L - 1) * (2.0 * inproj + 2.5 * attn) + 2.0 * last_fwd
+        survey += 3.0 * L * (inproj + attn + outproj)
+    return executed, survey
+
+
+def _timed_train(name, device, steps, warmup, lazy=False, fresh_ids=False, steady=False, graph=False):
     """One module-path train workload, timed like the headline (batches resident, K steps between syncs).
     `fresh_ids`: every step looks up NEW uniform ids (generated on the device outside nothing -- inside the timed
     region, 3 randint launches per step) instead of cycling 8 batches: the steady state of the deferred schedule,
@@ -381,9 +406,19 @@ def _timed_train(name, device, steps, warmup, lazy=False, fresh_ids=False, stead
         opt.step()
         total.add_(loss.detach())
 
+    if graph:  # the whole step as ONE hipGraph launch (graphs.GraphedTrainStep: the ~90 launches of a step become one)
+        graphed = A.GraphedTrainStep(model, opt, batches[0], warmup=3)
+
+        def step(i):  # noqa: F811
+            total.add_(graphed(*batch_at(i)))
+
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
+    import ctypes as C
+    from two_tower_models_amd import _native as N
+    lib = N.load()
+    lib.tt_profile_enable(1)
     import gc
     gc.collect()
     gc.disable()  # a cyclic-GC pause inside a 25 ms timed window of a host-bound loop is a 30 % error (seen: 1.38 vs 1.75 ms)
@@ -403,11 +438,45 @@ def _timed_train(name, device, steps, warmup, lazy=False, fresh_ids=False, stead
             flush_s = time.perf_counter() - t1
     finally:
         gc.enable()
+    sw_ms, sw_cnt = C.c_double(0.0), C.c_int64(0)
+    N.check(lib.tt_profile_read(b"adam_sweep_kernel", C.byref(sw_ms), C.byref(sw_cnt)), "tt_profile_read")
+    lib.tt_profile_enable(0)
+    executed, survey = step_flops(cfg)
+    ms_step = dt / steps * 1e3
+    if lazy:
+        # no table sweep: what bounds the step is its matrix work; the HBM side is the touched rows only (7 x 4 x D
+        # bytes per looked-up row -- reported separately, never mixed with the dense-exact figure)
+        n_rows = cfg["B"] * (2 + (cfg["H"] if cfg["model"] != "base" else 0))
+        roof = {"bound": "mfma", "kernel": "whole step (no sweep: logits + towers" + (" + encoder" if cfg["model"] != "base" else "") + ")",
+                "achieved": round(executed / (ms_step * 1e-3) / 1e12, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(executed / (ms_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
+                "executed_flops_per_step": executed, "survey_flops_per_step": survey,
+                "touched_rows_bytes_per_step": 28.0 * cfg["D"] * n_rows,
+                "touched_rows_GBps": round(28.0 * cfg["D"] * n_rows / (ms_step * 1e-3) / 1e9, 1)}
+    elif cfg["model"] != "base":
+        # history model: SURVEY 8d's bound is the fp32 matrix pipe (the encoder), priced on executed AND on the survey's flops
+        roof = {"bound": "mfma", "kernel": "whole step (encoder + towers + logits; the sweep runs underneath)",
+                "achieved": round(executed / (ms_step * 1e-3) / 1e12, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(executed / (ms_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
+                "executed_flops_per_step": executed, "survey_flops_per_step": survey,
+                "frac_on_survey_flops": round(survey / (ms_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)}
+    else:
+        # base model: the dense-exact table sweep (24 B per table element), per launch and per step
+        nbytes = algorithmic_sweep_bytes(cfg, 1)
+        launch_ms = sw_ms.value / sw_cnt.value if sw_cnt.value else None
+        roof = {"bound": "hbm", "kernel": "adam_sweep_tables_kernel", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "achieved": round(nbytes / (launch_ms * 1e-3) / 1e9, 1) if launch_ms else None,
+                "frac": round(nbytes / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if launch_ms else None,
+                "avg_launch_ms": round(launch_ms, 4) if launch_ms else None, "launches": sw_cnt.value,
+                "algorithmic_bytes_per_launch": nbytes, "traffic": None,
+                "step_achieved": round(nbytes / (ms_step * 1e-3) / 1e9, 1),
+                "step_frac": round(nbytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     return {"workload": name + (" [value-exact DEFERRED Adam, K steps + flush: not the headline schedule]" if lazy else "")
+                        + (" [whole step replayed as ONE hipGraph]" if graph else "")
                         + (" [fresh uniform ids every step]" if fresh_ids else (" [8 batches cycled: every row recurs after 8 steps]" if lazy else "")),
             "pairs_per_s": round(cfg["B"] * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
             "steps": steps, "warmup": warmup, "B": cfg["B"], "n_items": cfg["n_items"],
-            "H": cfg["H"] if cfg["model"] != "base" else None,
+            "H": cfg["H"] if cfg["model"] != "base" else None, "roofline": roof,
             **({} if lazy else {"sweep_workgroups": opt._sweep_wgs or 768}),  # where the level scan of the optimizer settled
             **({"note": f"STEADY STATE of the deferred schedule: {warmup} untimed steps of fresh uniform ids first (N_i / B = "
                         f"{cfg['n_items'] // cfg['B']} = r; a looked-up item row then carries moments with probability "
@@ -494,14 +563,19 @@ def secondary(device, lib, N):
     # (dense-exact workloads: 80 warm-up steps, the sweep-level scan of DenseExactAdam._tune_sweep settles inside them)
     for key, name, steps, lazy, fresh in (("C2", "C2", 40, False, False), ("C3", "C3", 20, False, False),
                                           ("P_lazy", "P", 20, True, False),
+                                          # the same schedule with the step replayed as one hipGraph: the eager loop is bound by
+                                          # the HOST's ~90 launches per step, the GPU work is ~0.5 ms of MFMA
+                                          ("P_lazy_graphed", "P", 40, True, "graph"),
                                           # the deferred schedule's STEADY STATE next to -- not instead of -- the recurring-ids
                                           # figure: new uniform ids every step, pre-aged (see below)
                                           ("P_lazy_fresh_ids", "P", 300, True, True)):
         try:
             # fresh ids: pre-aged over 4 N_i / B untimed steps, so the figure IS the steady state to within 10 % of the replay
             # work per lookup (the 200-step window flattered it 2.7x); see the note for the exact fractions
+            graph = fresh == "graph"
+            fresh = fresh is True
             sec[key] = _timed_train(name, device, steps, (5000 if fresh else 3) if lazy else 80, lazy=lazy, fresh_ids=fresh,
-                                    steady=fresh)
+                                    steady=fresh, graph=graph)
             if not lazy:
                 sec[key]["cpu_baseline"] = cpu_baseline_small(name)
         except Exception as e:  # a secondary figure must never take the headline line down with it

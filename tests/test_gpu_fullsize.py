@@ -91,6 +91,95 @@ def test_inbatch_ce_8_rank_shape_kept_logits(T):
     assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-12
 
 
+@pytest.mark.parametrize("keep", [False, True])
+def test_split_fp16_ce_pair_8_rank_shape(T, keep, monkeypatch):
+    """EXPLORATORY path, full size: the split-fp16 logits pair (csrc/ce_f16x2.hip, TT_CE_F16X2) through
+    ops.InBatchSoftmaxCE at one rank's 8-GPU shape -- 8192 users x 65 536 items, positives at 3*B -- in its default form
+    (no logits buffer, `keep` False) and its kept-logits form, with the SAME sampled-float64 assertions and tolerances as
+    the fp32-MFMA pair (test_inbatch_ce_8_rank_shape_kept_logits above)."""
+    ops, N = T
+    B, D, W = 8192, 128, 8
+    assert N.load().tt_ce16_supported(B, W * B, D) == 1
+    monkeypatch.setattr(ops, "_CE_F16X2", True)
+    monkeypatch.setattr(ops, "_CE16_KEEP", bool(keep))
+    calls = []
+    lib = N.load()
+    which = "tt_ce16_bwd_kept" if keep else "tt_ce16_bwd_recompute"
+    real = getattr(lib, which)
+    monkeypatch.setattr(lib, which, lambda *a: (calls.append(1), real(*a))[1])
+    g = torch.Generator(device="cpu").manual_seed(5)
+    U = torch.randn(B, D, generator=g) * 0.3
+    I_all = torch.randn(W * B, D, generator=g) * 0.3
+    coef = torch.rand(B, generator=g) / (W * B)
+    Ud, Id = U.to(DEV).requires_grad_(True), I_all.to(DEV).requires_grad_(True)
+    ce = ops.InBatchSoftmaxCE.apply(Ud, Id, 3 * B)
+    (ce * coef.to(DEV)).sum().backward()
+    assert calls == [1]  # the pair is what ran
+    ce, dU, dI = ce.detach(), Ud.grad, Id.grad
+    assert float(dI.sum(0).abs().max()) < 1e-6  # softmax rows sum to one
+    rows = torch.arange(0, B, 257)
+    S = U[rows].double() @ I_all.double().t()
+    lse = torch.logsumexp(S, 1)
+    assert torch.allclose(ce.cpu()[rows].double(), lse - S[torch.arange(len(rows)), rows + 3 * B], atol=2e-5)
+    # user gradient on the sampled rows: dU_i = coef_i (sum_j p_ij I_j - I_{i + 3B})
+    P = torch.softmax(S, dim=1)
+    dU_ref = coef[rows].double()[:, None] * (P @ I_all.double() - I_all[rows + 3 * B].double())
+    assert torch.allclose(dU.cpu()[rows].double(), dU_ref, atol=1e-9, rtol=2e-4)
+    # sampled item rows: dI[j] = sum_i coef_i (p_ij - [j == i + 3B]) U_i needs every user -> fp64 on the GPU
+    items = torch.tensor([0, 12345, 3 * B, 3 * B + 4097, 4 * B - 1, W * B - 1])
+    Sd = U.to(DEV).double() @ I_all[items].to(DEV).double().t()
+    lse_all = torch.logsumexp(U.to(DEV).double() @ I_all.to(DEV).double().t(), 1)
+    G = torch.exp(Sd - lse_all[:, None])
+    for k, j in enumerate(items.tolist()):
+        if 3 * B <= j < 4 * B:
+            G[j - 3 * B, k] -= 1.0
+    ref = (G * coef.to(DEV).double()[:, None]).t() @ U.to(DEV).double()
+    got = dI[items.to(DEV)].double()
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-12
+
+
+def test_split_fp16_p_shape_whole_step_vs_oracle(T, monkeypatch):
+    """EXPLORATORY path: one whole P-shape train step (B = 8192, D = 128, tables shrunk to what the CPU oracle sweeps in
+    seconds) with TT_CE_F16X2 through the MODULE path against oracle/cpu_ref.py: loss 1e-4 (the north star's tolerance), the
+    looked-up rows and the dense parameters at the fp32 path's criteria."""
+    import two_tower_models_amd as A
+    from oracle import cpu_ref as R
+    ops, N = T
+    monkeypatch.setattr(ops, "_CE_F16X2", True)
+    n_users, n_items, D, F, B = 50_000, 100_000, 128, 8, 8192
+    torch.manual_seed(0)
+    model = A.TwoTowerBaseRetrieval(10, n_users, D, F, n_items, D, F, [1.0], A.BaselineMIPSModule(64, D))
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("embedding_arch.weight") or n.endswith("tower_arch.weight"):
+                p.mul_(0.5)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    opt = A.DenseExactAdam(model.parameters(), lr=1e-3)
+    gen = torch.Generator().manual_seed(3)
+    batch = (torch.randint(0, n_users, (B,), generator=gen), torch.randn(B, F, generator=gen), torch.randint(0, n_items, (B, 2), generator=gen),
+             torch.randint(0, n_items, (B,), generator=gen), torch.randn(B, F, generator=gen), torch.randint(0, 10, (B,), generator=gen),
+             torch.randint(0, 2, (B, 1), generator=gen).float())
+    calls = []
+    lib = N.load()
+    real = lib.tt_ce16_bwd_recompute
+    monkeypatch.setattr(lib, "tt_ce16_bwd_recompute", lambda *a: (calls.append(1), real(*a))[1])
+    loss = model.train_forward(*[t.to(DEV) for t in batch])
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    assert calls == [1]
+    state = R.AdamState(params)
+    want = R.train_step(params, state, batch, torch.tensor([1.0]))
+    assert abs(float(loss) - want) < 1e-4, (float(loss), want)
+    for k, v in model.state_dict().items():
+        err = (v.cpu() - params[k]).abs()
+        noise_only = k in ("item_tower_arch.bias", "item_features_arch.2.bias")
+        assert float(err.max()) <= 2.2e-3, (k, float(err.max()))
+        if not noise_only:
+            assert float((err > 5e-6).float().mean()) <= 2e-3, (k, float((err > 5e-6).float().mean()))
+
+
 def test_row_plan_420k_ids_over_10m_rows(T):
     ops, N = T
     n, n_rows = 8192 * 51, 10_000_000

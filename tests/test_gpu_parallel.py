@@ -211,6 +211,7 @@ def oracle_run(case, res, world):
 
 def check_against_oracle(case, res, world, outlier_frac=2e-3):
     want, params = oracle_run(case, res, world)
+    bad = []
     for r in range(world):
         assert np.allclose(res[r]["losses"], want, atol=1e-4), (res[r]["losses"], want)
         # Adam's early updates are lr * g / (|g| + eps)-like: the few elements whose gradient happens to be ~1e-4 of the
@@ -226,11 +227,11 @@ def check_against_oracle(case, res, world, outlier_frac=2e-3):
             assert float(err.max()) <= 2.2e-3 * STEPS, (name, r, float(err.max()))
             # zero true gradient, noise only: the item-side biases and the key third of every in_proj_bias
             noise_only = name in ("item_tower_arch.bias", "item_features_arch.2.bias") or name.endswith("in_proj_bias")
-            if not noise_only:
-                assert int((err > 5e-6).sum()) <= max(2, int(outlier_frac * err.numel())), \
-                    (name, r, int((err > 5e-6).sum()), err.numel(), float(err.max()))
+            if not noise_only and int((err > 5e-6).sum()) > max(2, int(outlier_frac * err.numel())):
+                bad.append((name, r, int((err > 5e-6).sum()), err.numel(), float(err.max())))
         # replicas stay bit-identical, and every rank assembled the same whole tables
         assert all(torch.equal(v, res[0]["sd"][k]) for k, v in res[r]["sd"].items())
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("world,case,backend,transport,sharded_init", [

@@ -89,8 +89,9 @@ def _deferrable(t: Optional[torch.Tensor]) -> bool:
 
 def run_on_side(dev: torch.device, fn, hold: Sequence[Optional[torch.Tensor]] = (),
                 leaves: Sequence[Optional[torch.Tensor]] = (), again: bool = False) -> bool:
-    """Run fn() on the third stream, after everything queued so far on the current one; -> False (and fn() runs in
-    place) when side execution is off, the device is not a GPU, a graph is being captured, or no backward pass is running.
+    """Run fn(True) on the third stream, after everything queued so far on the current one; -> False (and fn(False) runs in
+    place, on the current stream -- `fn` picks its scratch slots by that flag: the two streams never share one) when side
+    execution is off, the device is not a GPU, a graph is being captured, or no backward pass is running.
     `hold`: the INPUTS of fn (kept alive until the join) -- never its outputs: autograd's AccumulateGrad takes a returned
     gradient over as `.grad` without launching anything only if nobody else references it; a held output would be CLONED
     on the main stream, at once, before the side kernel has written it.  `leaves`: the tensors the gradients are for; the
@@ -98,18 +99,18 @@ def run_on_side(dev: torch.device, fn, hold: Sequence[Optional[torch.Tensor]] = 
     (a Parameter that feeds two Functions: autograd SUMS the two gradients on the main stream as soon as both exist).
     `again`: a continuation of work this node already deferred for the same leaves (must stay behind it on the side stream)."""
     if not (_SIDE_GRADS and dev.type == "cuda") or torch.cuda.is_current_stream_capturing() or torch.is_grad_enabled():
-        fn()
+        fn(False)
         return False
     st = _side_state
     for t in leaves:
         if not _deferrable(t) or (not again and id(t) in st["leaves"]):
-            fn()
+            fn(False)
             return False
     if not st["armed"]:
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_join_side_grads)
         except RuntimeError:  # not inside a backward pass: nobody would join
-            fn()
+            fn(False)
             return False
         st["armed"], st["dev"] = True, dev
     side = N.aux_stream(dev)
@@ -117,7 +118,7 @@ def run_on_side(dev: torch.device, fn, hold: Sequence[Optional[torch.Tensor]] = 
     ev.record()
     side.wait_event(ev)
     with torch.cuda.stream(side):
-        fn()
+        fn(True)
     st["held"].extend(t for t in hold if t is not None)
     st["leaves"].update(id(t) for t in leaves)
     return True
@@ -601,7 +602,7 @@ class FusedTower(_LookupFunction):
         # they are worth 0.1 ms of the 4.3 ms C3 step, underneath the encoder's backward; in the sweep-bound base model the
         # extra stream hop COSTS 0.06 ms of the 1.15 ms C2 step)
         if _side_state["encoder"]:
-            run_on_side(dev, lambda: tower_weight_grads(dy, tin, d_f, h, dh, feats, out=outs, extra=extra, side=True),
+            run_on_side(dev, lambda on_side: tower_weight_grads(dy, tin, d_f, h, dh, feats, out=outs, extra=extra, side=on_side),
                         hold=(dy, tin, d_f, h, dh, feats, extra), leaves=ctx.tower_leaves)
         else:
             tower_weight_grads(dy, tin, d_f, h, dh, feats, out=outs, extra=extra)
@@ -1104,8 +1105,9 @@ class HistoryEncoder(_LookupFunction):
 
         def wgrad(dy, xin, dW, tag, l):  # off the critical path: see run_on_side
             db = torch.empty(dW.shape[0], dtype=torch.float32, device=dev)
-            run_on_side(dev, lambda: gemm_tn_colsum(dy, xin, dW, db=db, slot="ws_side_" + tag), hold=(dy, xin),
-                        leaves=leaf_params[4 * l: 4 * l + 4])
+            k = 4 * l + (0 if tag == "i" else 2)  # the (weight, bias) pair this product is the gradient of
+            run_on_side(dev, lambda on_side: gemm_tn_colsum(dy, xin, dW, db=db, slot=("ws_side_" + tag) if on_side else "ws"),
+                        hold=(dy, xin), leaves=leaf_params[k: k + 2])
             return db
 
         for l in reversed(range(L)):
@@ -1164,14 +1166,15 @@ class HistoryEncoder(_LookupFunction):
                 dW_po = torch.empty(D, D, dtype=torch.float32, device=dev)
                 db_po = torch.empty(D, dtype=torch.float32, device=dev)
 
-                def folded_G(d_qkv=d_qkv, x=x, G=G, db_in=db_in):
-                    gemm_tn_colsum(d_qkv, x, G, db=db_in, slot="ws_side_i")
+                def folded_G(on_side, d_qkv=d_qkv, x=x, G=G, db_in=db_in):
+                    gemm_tn_colsum(d_qkv, x, G, db=db_in, slot="ws_side_i" if on_side else "ws")
 
-                def folded_weights(G=G, db_in=db_in, dW_in=dW_in, dW_po=dW_po, db_po=db_po, w_po=w_po, b_po=b_po, w_in=w_in):
-                    gemm(N.TT_GEMM_NT, G, w_po, dW_in, 3 * D, D, D, slot="ws_side_g")
-                    gemm(N.TT_GEMM_NT, db_in.view(3 * D, 1), b_po.view(D, 1), dW_in, 3 * D, D, 1, accumulate=True, slot="ws_side_g")
-                    gemm(N.TT_GEMM_TN, w_in, G, dW_po, D, D, 3 * D, slot="ws_side_g")
-                    gemm(N.TT_GEMM_NN, db_in.view(1, 3 * D), w_in, db_po.view(1, D), 1, D, 3 * D, slot="ws_side_g")
+                def folded_weights(on_side, G=G, db_in=db_in, dW_in=dW_in, dW_po=dW_po, db_po=db_po, w_po=w_po, b_po=b_po, w_in=w_in):
+                    slot = "ws_side_g" if on_side else "ws"
+                    gemm(N.TT_GEMM_NT, G, w_po, dW_in, 3 * D, D, D, slot=slot)
+                    gemm(N.TT_GEMM_NT, db_in.view(3 * D, 1), b_po.view(D, 1), dW_in, 3 * D, D, 1, accumulate=True, slot=slot)
+                    gemm(N.TT_GEMM_TN, w_in, G, dW_po, D, D, 3 * D, slot=slot)
+                    gemm(N.TT_GEMM_NN, db_in.view(1, 3 * D), w_in, db_po.view(1, D), 1, D, 3 * D, slot=slot)
 
                 # the streaming product G is queued BEFORE the data-path product below (the side stream starts where the main
                 # one stands now); the four small products that turn G into weight gradients wait until the END of this
@@ -1204,7 +1207,7 @@ class HistoryEncoder(_LookupFunction):
             if aside:
                 run_on_side(dev, fn, hold=hold_f, leaves=leaves_f, again=True)
             else:
-                fn()
+                fn(False)
         if dx is None:  # L == 0: slot 0 is row 0 of (x + pe)
             dx = torch.zeros(B * H, D, dtype=torch.float32, device=dev)
             dx.view(B, H, D)[:, 0, :].copy_(d_recent)

@@ -476,28 +476,40 @@ class AllGatherRows(torch.autograd.Function):
     it runs (`resolve_pending`), and whatever autograd schedules in between -- the user tower's backward -- overlaps it."""
 
     @staticmethod
-    def forward(ctx, x, tag: str = "item_emb_allgather", defer_ok: bool = False):
+    def forward(ctx, x, tag: str = "item_emb_allgather", defer_ok: bool = False, started=None):
         """`defer_ok`: the caller vouches that `x` has no other consumer (autograd would otherwise SUM the deferred
-        gradient with the other one on the main stream, before anyone waited for the exchange)."""
+        gradient with the other one on the main stream, before anyone waited for the exchange).  `started`: the
+        all-gather of `x` was already started (`start_all_gather`) -- whatever was queued since overlapped it."""
         ctx.tag = tag
         ctx.defer = bool(defer_ok) and x.grad_fn is not None and type(x.grad_fn).__name__ in _DEFER_SAFE_PRODUCERS
         ctx.world = dist.get_world_size()
         if ctx.world == 1 and not C._force_async():
             return x.view_as(x)
+        if started is not None:
+            return started.wait()
         _sent(tag, (ctx.world - 1) * x.numel() * x.element_size())
         return C.all_gather_rows_start(x.contiguous(), tag=tag).wait()
 
     @staticmethod
     def backward(ctx, g):
         if ctx.world == 1 and not C._force_async():
-            return g, None, None
+            return g, None, None, None
         back = {"item_emb_allgather": "dI_reduce_scatter"}.get(ctx.tag, ctx.tag + "_grad_reduce_scatter")
         _sent(back, (ctx.world - 1) * (g.numel() // ctx.world) * g.element_size())
         pend = C.reduce_scatter_rows_start(g.contiguous(), tag=back)
         if ctx.defer and pend.work is not None:
             _DEFERRED[pend.out.data_ptr()] = pend
-            return pend.out, None, None
-        return pend.wait(), None, None
+            return pend.out, None, None, None
+        return pend.wait(), None, None, None
+
+
+def start_all_gather(x: torch.Tensor, tag: str = "item_emb_allgather"):
+    """Start the all-gather of `x` now (no autograd): hand the result to `AllGatherRows.apply(x, tag, defer_ok, started)`
+    once the kernels that should overlap it have been queued.  None at world size 1."""
+    if dist.get_world_size() == 1 and not C._force_async():
+        return None
+    _sent(tag, (dist.get_world_size() - 1) * x.numel() * x.element_size())
+    return C.all_gather_rows_start(x.detach().contiguous(), tag=tag)
 
 
 def gather_no_grad(x: torch.Tensor, tag: str = "head_inputs_allgather") -> torch.Tensor:

@@ -215,7 +215,9 @@ class TwoTowerBaseRetrieval(nn.Module):
         world, rank = parallel.dist.get_world_size(), parallel.dist.get_rank()
         B = user_embedding.shape[0]
         single_use = getattr(self, "_tt_item_emb_single_use", False)  # set by the un-overridden train_forward
-        items_all = parallel.AllGatherRows.apply(item_embeddings, "item_emb_allgather", single_use)
+        started, self._tt_item_gather = getattr(self, "_tt_item_gather", None), None
+        started = started[1] if (started is not None and started[0] is item_embeddings) else None
+        items_all = parallel.AllGatherRows.apply(item_embeddings, "item_emb_allgather", single_use, started)
         row_ce = ops.InBatchSoftmaxCE.apply(user_embedding, items_all, rank * B)  # [B], this rank's users
         hook_is_identity = type(self).debias_net_user_value is TwoTowerBaseRetrieval.debias_net_user_value
         T = self.user_value_weights.numel()
@@ -265,6 +267,8 @@ class TwoTowerBaseRetrieval(nn.Module):
             # item tower's, i.e. underneath the reduce-scatter of dI that the item tower's backward has to wait for
             self._tt_item_emb_single_use = type(self).compute_item_embeddings is TwoTowerBaseRetrieval.compute_item_embeddings
             item_embeddings = self.compute_item_embeddings(item_id, item_features)
+            # ... and its all-gather (every rank scores against every rank's items) travels underneath the user tower
+            self._tt_item_gather = (item_embeddings, parallel.start_all_gather(item_embeddings))
             user_embedding = self.compute_user_embedding(user_id, user_features, user_history)
         else:
             user_embedding = self.compute_user_embedding(user_id, user_features, user_history)
