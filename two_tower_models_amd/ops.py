@@ -1005,6 +1005,12 @@ class HistoryEncoder(_LookupFunction):
                                        N.ptr(pe), x.data_ptr(),
                                        pooled.data_ptr(), 2 * D, N.oob.flag(dev).data_ptr(), N.stream()),
                 "tt_hist_embed_pool")
+        if ids is not None:
+            # the step's big gather is queued: a table sweep the optimiser held back for it may start now (optim.py)
+            ref = getattr(source, "_tt_optimizer", None)
+            opt = ref() if ref is not None else None
+            if opt is not None:
+                opt.release_sweep()
         saved: List[torch.Tensor] = []
         # the last layer is consumed at row 0 only: one query per (sample, head), K / V projections folded into two D-wide
         # vectors per (sample, head) (csrc/encoder_last.hip)

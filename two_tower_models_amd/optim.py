@@ -350,24 +350,47 @@ class DenseExactAdam(torch.optim.Optimizer):
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(main)  # lookups (or none yet, forward mode) + stashes are complete here
-        self._side_stream.wait_event(ready)
-        if split_planes:
-            N.check(lib.tt_adam_begin_ids_planes(hyper, None, 0, jobs, len(stash_jobs), 6, self._side_stream.cuda_stream),
-                    "tt_adam_begin_ids_planes")
-        ev_s0 = None
-        if not capturing:
-            ev_s0 = torch.cuda.Event(enable_timing=True)
-            ev_s0.record(self._side_stream)
-        if begun:  # ONE launch for all tables: no gap and a single tail between the user and the item table
-            descs = (N.AdamTensor * len(begun))()
-            for i, p in enumerate(begun):
-                st = self.state[p]
-                descs[i].p, descs[i].g = p.data_ptr(), None
-                shard = getattr(p, "_tt_shard", None)
-                descs[i].m, descs[i].v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-                descs[i].n = p.numel() if shard is None else shard.n_local * p.shape[1]
-            N.check(lib.tt_adam_tables_sweep(descs, len(begun), hyper, self._sweep_wgs, self._side_stream.cuda_stream),
-                    "tt_adam_tables_sweep")
+
+        def launch_sweep(held_back=False, ready=ready, begun=begun, split_planes=split_planes, capturing=capturing):
+            self._side_stream.wait_event(ready)
+            if held_back:  # ... and after what was queued since (the big gather this was held back for)
+                later = torch.cuda.Event()
+                later.record(torch.cuda.current_stream())
+                self._side_stream.wait_event(later)
+            if split_planes:
+                N.check(lib.tt_adam_begin_ids_planes(hyper, None, 0, jobs, len(stash_jobs), 6, self._side_stream.cuda_stream),
+                        "tt_adam_begin_ids_planes")
+            ev_s0 = None
+            if not capturing:
+                ev_s0 = torch.cuda.Event(enable_timing=True)
+                ev_s0.record(self._side_stream)
+            if begun:  # ONE launch for all tables: no gap and a single tail between the user and the item table
+                descs = (N.AdamTensor * len(begun))()
+                for i, p in enumerate(begun):
+                    st = self.state[p]
+                    descs[i].p, descs[i].g = p.data_ptr(), None
+                    shard = getattr(p, "_tt_shard", None)
+                    descs[i].m, descs[i].v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                    descs[i].n = p.numel() if shard is None else shard.n_local * p.shape[1]
+                N.check(lib.tt_adam_tables_sweep(descs, len(begun), hyper, self._sweep_wgs, self._side_stream.cuda_stream),
+                        "tt_adam_tables_sweep")
+            self._sweep_done = torch.cuda.Event(enable_timing=not capturing)
+            self._sweep_done.record(self._side_stream)
+            if self._tune is not None:
+                self._tune[1], self._tune[2] = ev_s0, self._sweep_done
+
+        # A step that gathers MANY rows right after this point (history model: B*H = 205 K random 512-B rows) lets that
+        # gather run BEFORE the sweep starts saturating HBM: next to the sweep it took 281 us instead of 105 (round 4
+        # profile), on the critical path.  The gather's Function calls release_sweep() once it is queued; zero_grad() /
+        # step() do if nobody did.  The sweep is a third of such a step: starting it 0.1 ms later costs nothing.
+        self._tune = None if capturing else [ev_begin, None, None, None, self._sweep_wgs, self._host_steps]
+        self._sweep_done = None
+        n_announced = sum(ts.plan.n for ts in begun.values()) if announced is not None else 0
+        if announced is not None and not capturing and n_announced >= 65536 and not self._sharded:
+            self._sweep_pending = launch_sweep
+        else:
+            self._sweep_pending = None
+            launch_sweep()
         # forward mode: the stable sort of the ids is needed only by finish (in step()).  It is NOT enqueued here: its
         # ~30 short launches would sit in front of the forward's kernels on the HOST (0.25 ms of enqueue time per step
         # -- at C2 the main stream idled that long before its first forward kernel).  zero_grad() -- after the forward
@@ -375,10 +398,13 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._plan_done = None
         self._plans_pending = announced is not None and bool(begun)
         self._plan_ready = ready if self._plans_pending else None
-        self._sweep_done = torch.cuda.Event(enable_timing=not capturing)
-        self._sweep_done.record(self._side_stream)
-        self._tune = None if capturing else [ev_begin, ev_s0, self._sweep_done, None, self._sweep_wgs, self._host_steps]
         self._begun = begun
+
+    def release_sweep(self) -> None:
+        """Start the table sweep a forward-announced step held back (see _begin_overlapped); no-op otherwise."""
+        pending, self._sweep_pending = getattr(self, "_sweep_pending", None), None
+        if pending is not None:
+            pending(True)
 
     # The sweep saturates HBM for as long as it lasts, and everything that runs next to it is stretched 2-3x.  When the
     # sweep IS the step (headline shape: 5.0 of 5.3 ms) that is free; when the forward/backward chain is as long as the
@@ -603,6 +629,7 @@ class DenseExactAdam(torch.optim.Optimizer):
         for p in self._tables:
             p._tt_rowgrads.clear()
         super().zero_grad(set_to_none=set_to_none)
+        self.release_sweep()
         if self._begun is not None and not torch.cuda.is_current_stream_capturing():
             self._launch_plans(side=True)
         if (self.overlap_sweep and self._begun is None and any(p._tt_lookups for p in self._tables)
@@ -632,6 +659,7 @@ class DenseExactAdam(torch.optim.Optimizer):
         if self._sharded and self._begun is None:
             raise RuntimeError("row-sharded tables: step() without a train_forward that announced its lookups (the models' "
                                "train_forward does; a custom forward must call model._announce_lookups first)")
+        self.release_sweep()
         if self._begun is not None:
             # overlapped schedule: hyper already advanced, tables already swept on the side stream
             self._launch_plans(side=False)  # nobody called zero_grad() after the forward: sort now, in line
