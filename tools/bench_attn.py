@@ -1,5 +1,5 @@
 """Time the encoder's attention kernels alone at the BASELINE shape (B = 4096, H = 50, 4 heads x 32) on MI355X.
-TT_ATTN_NO_WG=1 selects the wave-per-(sample, head) kernels of attention_mfma.hip for the backward."""
+The backward takes attention_wg.hip (one sample per workgroup) at the BASELINE shape."""
 import os
 import sys
 
@@ -28,7 +28,7 @@ def bwd():
                             N.stream()), "tt_attn_bwd")
 
 
-for name, fn, mf in (("fwd", fwd, 128), ("bwd", bwd, 312 if os.environ.get("TT_ATTN_NO_WG") is None else 448)):
+for name, fn, mf in (("fwd", fwd, 128), ("bwd", bwd, 312)):
     for _ in range(20):
         fn()
     torch.cuda.synchronize()

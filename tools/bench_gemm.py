@@ -1,4 +1,4 @@
-"""Time tt_gemm_f32 on the encoder-projection shapes (MI355X); run twice with TT_GEMM_NO_WS=1 to compare."""
+"""Time tt_gemm_f32 on the encoder-projection shapes (MI355X)."""
 import os
 import sys
 
@@ -35,4 +35,4 @@ for name, layout, M, Nn, K in cases:
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 100
     print(f"{name} M={M} N={Nn} K={K}: {ms * 1e3:8.1f} us  {2.0 * M * Nn * K / ms / 1e9:6.1f} TFLOP/s "
-          f"(ws={'off' if os.environ.get('TT_GEMM_NO_WS') else 'on'})", flush=True)
+          , flush=True)

@@ -24,4 +24,4 @@ for n, n_rows in cases:
         torch.cuda.synchronize()
         ts.append(a.elapsed_time(b) / 20)
     print(f"n={n} n_rows={n_rows}: {sorted(ts)[2] * 1e3:.1f} us per plan "
-          f"(small={'off' if os.environ.get('TT_PLAN_NO_SMALL') else 'on'})", flush=True)
+          , flush=True)

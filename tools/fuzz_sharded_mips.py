@@ -1,6 +1,6 @@
 """Randomised check of the row-sharded MIPS (per-rank top-K, all-to-all of the candidates, tt_mips_merge) with the
 product backend at world sizes 2-4 on one GPU (gloo): random corpus sizes (down to fewer rows than ranks x K) and K,
-indices and scores against the unsharded exact order (tests/test_gpu_sharded.py's assertion).
+indices and scores against the unsharded exact order (tests/test_gpu_parallel.py's assertion).
     python tools/fuzz_sharded_mips.py [seconds] [seed]"""
 import os
 import sys
@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
     sys.path.insert(0, p)
-import test_gpu_sharded as T  # noqa: E402
+import test_gpu_parallel as T  # noqa: E402
 
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
@@ -22,7 +22,7 @@ if __name__ == "__main__":
         C = int(rng.choice([world, world + 1, 17, 100, 999, 5000, 20000, 70001]))
         K = int(rng.integers(1, min(C, 600) + 1))
         try:
-            T.test_multi_rank_sharded_mips_hip_backend(world, C, K, "gloo")
+            T.test_multi_rank_sharded_mips(world, C, K, "gloo")
         except BaseException as e:  # noqa: BLE001
             bad += 1
             print(f"FINDING case {n}: W={world} C={C} K={K} | {type(e).__name__} {str(e)[:400]}", flush=True)

@@ -62,6 +62,9 @@ from . import _native as N
 from . import ops
 
 
+_HOLD_SWEEP = True  # (tools/ab_c3.py flips it: the held-back sweep start against the immediate one, same process, same box)
+
+
 class _TableStep:
     """State of one table between the overlapped begin (in zero_grad) and finish (in step)."""
 
@@ -386,7 +389,7 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._tune = None if capturing else [ev_begin, None, None, None, self._sweep_wgs, self._host_steps]
         self._sweep_done = None
         n_announced = sum(ts.plan.n for ts in begun.values()) if announced is not None else 0
-        if announced is not None and not capturing and n_announced >= 65536 and not self._sharded:
+        if _HOLD_SWEEP and announced is not None and not capturing and n_announced >= 65536 and not self._sharded:
             self._sweep_pending = launch_sweep
         else:
             self._sweep_pending = None
