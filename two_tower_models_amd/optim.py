@@ -286,7 +286,7 @@ class DenseExactAdam(torch.optim.Optimizer):
         return buf
 
     # ------------------------------------------------------------------ overlapped begin
-    def _begin_overlapped(self, announced: Optional[Dict[int, Sequence[torch.Tensor]]] = None) -> None:
+    def _begin_overlapped(self, announced: Optional[Dict[int, Sequence[torch.Tensor]]] = None, hold_sweep: bool = False) -> None:
         """Plan + park the old rows on the main stream, then launch the sweep on the side stream.
         `announced` (forward mode): the id blocks each table WILL be looked up with, in lookup
         order; otherwise the blocks the forward already registered."""
@@ -389,7 +389,11 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._tune = None if capturing else [ev_begin, None, None, None, self._sweep_wgs, self._host_steps]
         self._sweep_done = None
         n_announced = sum(ts.plan.n for ts in begun.values()) if announced is not None else 0
-        if _HOLD_SWEEP and announced is not None and not capturing and n_announced >= 65536 and not self._sharded:
+        # ... and a caller whose logits kernels ARE the step (row-sharded tables from W = 4: thin row blocks, W*B negatives
+        # per user) asks for the sweep to start with the BACKWARD logits kernel (zero_grad() releases it): the forward
+        # logits kernel then runs at 0.81 instead of 0.73 of the matrix pipe, the backward one -- which streams the kept
+        # logits from HBM anyway -- loses less than that (round 4: 4.10 vs 4.26 ms per emulated W = 8 step)
+        if _HOLD_SWEEP and announced is not None and not capturing and ((n_announced >= 65536 and not self._sharded) or hold_sweep):
             self._sweep_pending = launch_sweep
         else:
             self._sweep_pending = None
@@ -565,7 +569,7 @@ class DenseExactAdam(torch.optim.Optimizer):
             self._plan_done = torch.cuda.Event()
             self._plan_done.record(self._plan_stream)
 
-    def begin_step(self, lookups: Dict[torch.nn.Parameter, Sequence[torch.Tensor]]) -> bool:
+    def begin_step(self, lookups: Dict[torch.nn.Parameter, Sequence[torch.Tensor]], hold_sweep: bool = False) -> bool:
         """Forward-mode entry (called by the models' train_forward before any lookup): announce
         the id blocks per table, in the order the forward will look them up.  Returns False
         (and does nothing) unless ``overlap_sweep == "forward"`` applies."""
@@ -581,7 +585,8 @@ class DenseExactAdam(torch.optim.Optimizer):
             p._tt_lookups.clear()
             p._tt_rowgrads.clear()
         mine = {id(p) for p in self._tables}
-        self._begin_overlapped({id(p): [b.reshape(-1) for b in blocks] for p, blocks in lookups.items() if id(p) in mine})
+        self._begin_overlapped({id(p): [b.reshape(-1) for b in blocks] for p, blocks in lookups.items() if id(p) in mine},
+                               hold_sweep=hold_sweep)
         return True
 
     # ------------------------------------------------------------------ replicated parameters of a row-sharded model

@@ -243,12 +243,19 @@ class TwoTowerBaseRetrieval(nn.Module):
         if not user_id.is_cuda:
             return
         plan = self._lookup_plan(user_id, user_history, item_id)
+        hold = False
         if self._sharded():
+            # thin row blocks and W*B negatives per user: the logits kernels are the step, the sweep starts with the backward
+            # one (optim._begin_overlapped); ~6 TB/s of sweep against ~125 TF/s of logits decide which regime this is
+            B, tables = user_id.shape[0], [t for t in plan if parallel.shard_of(t) is not None]
+            world = parallel.shard_of(tables[0]).world
+            sweep_ms = sum(parallel.shard_of(t).n_local * t.shape[1] for t in tables) * 24.0 / 6.0e9
+            hold = sweep_ms < 0.75 * (8.0 * B * B * world * self.item_id_embedding_arch.weight.shape[1] / 125.0e9)
             plan = parallel.begin_lookups(plan)
         ref = getattr(self.item_id_embedding_arch.weight, "_tt_optimizer", None)
         opt = ref() if ref is not None else None
         if opt is not None:
-            opt.begin_step(plan)
+            opt.begin_step(plan, hold_sweep=hold)
 
     def train_forward(
         self,
