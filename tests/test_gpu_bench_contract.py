@@ -49,7 +49,7 @@ def test_two_rank_launch_line():
     env = dict(os.environ, TT_DIST_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2",
-                        "--workload", "tiny", "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env,
+                        "--workload", "tiny", "--steps", "3", "--warmup", "1", "--check"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=900, stdin=subprocess.DEVNULL)
     assert r.returncode == 0, r.stderr[-3000:]
     out = _last_json(r.stdout)
@@ -57,6 +57,16 @@ def test_two_rank_launch_line():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 256 and out["scaling"] == "weak"
     assert out["cpu_baseline"] is None  # rank 0 at N = 1 only
     assert out["value"] > 0 and out["roofline"]["launches"] == 3
+    # first-contact instrumentation: the pre-flight check against the single-process module path, the
+    # slowest / fastest rank's own clock, per-exchange exposed time, the schedule the group picked
+    chk = out["check"]
+    assert chk["ok"] and chk["max_abs_diff"] < 1e-4 and len(chk["sharded_losses"]) == 3
+    assert out["rank_ms_per_step"]["max"] >= out["rank_ms_per_step"]["min"] > 0
+    comm = out["comm"]
+    assert {"lookup_ids_alltoall", "lookup_rows_alltoall", "rowgrad_alltoall", "item_emb_allgather", "dI_reduce_scatter",
+            "dense_grad_allreduce"} <= set(comm["ms_per_step"])
+    assert all("exposed_ms" in v for v in comm["ms_per_step"].values()) and comm["exposed_ms_per_step_total"] >= 0
+    assert comm["schedule"]["sweep_workgroups"] > 0 and "parallel.py" in out["config"]["parallelism"]
 
 
 def test_self_launch_needs_no_env():

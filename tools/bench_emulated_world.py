@@ -236,6 +236,7 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False,
             print(f"  host enqueue time {host_ms:.3f} ms/step (host only, GPU never the wait: {host_only_ms:.3f})")
             print("  main-stream phases (ms): lookups+towers %.3f | logits fwd + dU %.3f | weights/loss %.3f | logits bwd (dI) %.3f | "
                   "towers bwd + row Adam %.3f" % tuple(acc))
+            print(f"  sweep level: {opt.sweep_level_note()}")
             print(f"emulated W={W} workload={workload}: {ms:.3f} ms/step per rank (no collectives) -> "
                   f"{B * W / ms * 1e3 / 1e6:.2f} M pairs/s if the collectives were free")
             for r in roof:
