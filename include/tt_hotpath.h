@@ -448,6 +448,10 @@ int tt_adam_dense(const tt_adam_tensor* tensors /*host*/, int32_t n_tensors, con
  * (`p`) of ONE flat buffer -- the operand of the single dense-gradient all-reduce; m, v are ignored.  One launch per 64
  * tensors.  The reference has no counterpart (single process, ref:train/train.py:123-125). */
 int tt_pack_grads(const tt_adam_tensor* tensors /*host*/, int32_t n_tensors, tt_stream_t stream);
+/* Whole-step hipGraph (graphs.GraphedTrainStep): copy a new batch's input tensors into the captured static buffers in ONE
+ * launch -- `p` = destination, `g` = source, `n` = BYTES (any dtype), m / v ignored.  Replaces the seven `.to(device)` /
+ * copy_ calls of ref:train/train.py:91-99 per step. */
+int tt_copy_buffers(const tt_adam_tensor* buffers /*host*/, int32_t n_buffers, tt_stream_t stream);
 
 /* ---------------------------------------------------------------- K4 history encoder pieces
  * tt_hist_embed_pool: x[b,h,:] = table[ids[b,h],:] (+ pe[h,:]);  pooled[b,:] = mean_h table[ids[b,h],:]
@@ -477,37 +481,29 @@ int tt_attn_fwd(const float* qkv, int64_t B, int64_t H, int64_t D, int64_t heads
                 float* lse, tt_stream_t stream);
 int tt_attn_bwd(const float* qkv, const float* ctx, const float* lse, const float* d_ctx,
                 int64_t B, int64_t H, int64_t D, int64_t heads, float* d_qkv, tt_stream_t stream);
-/* The encoder's LAST layer is consumed at row 0 only (ref:src/user_history_encoder.py:103-116): it runs WITHOUT
- * projecting K and V. ref:src/user_history_encoder.py:103-116 with only row 0 of
- * the last nn.MultiheadAttention consumed).  x [B*H, D] is the layer's input, w_in [3D, D] / b_in [3D] / w_out [D, D] /
- * b_out [D] its packed parameters.  With q0 = W_q x[b,0] + b_q:  score_h[j] = scale (W_k,h^T q0_h) . x[b,j]  (the K bias
- * shifts every score of a head alike and drops out of the softmax) and ctx0_h = W_v,h (sum_j p_h[j] x[b,j]) + b_v,h,
- * so each sample's rows are read once and the [B*H, 2D] projection never exists.  Forward writes recent [B, D] (row
- * stride ld_recent) = W_out ctx0 + b_out and, for the backward, q0 [B, D], t [B, heads, D] (= W_k,h^T q0_h), probs
- * [B, heads, H], xbar [B, heads, D], ctx0 [B, D].  Backward writes dx [B*H, D] (every row), dW_in [3D, D], db_in [3D]
- * (the K third exactly zero), dW_out [D, D], db_out [D]; weight gradients are per-workgroup partial sums added in a
- * fixed order (deterministic).
- * w_prev_out / b_prev_out != NULL: the layer in FRONT of this one (ref:...encoder.py:103-108, second to last iteration of
- * the loop) hands over its attention CONTEXT c [B*H, D] in `x` instead of its output c W_prev_out^T + b_prev_out --
- * every use of that output here is linear in it, so its out-projection, the d_ctx product and the weight-gradient
- * product of that layer ([B*H, D] x [D, D] each) are replaced by [B (1 + 2 heads), D] x [D, D] ones.  Then the forward
- * also saves tp, cbar [B, heads, D] and x0 [B, D] (row 0 of the output that is never formed); the backward's dx is the
- * gradient of c, and dW_prev_out [D, D] / db_prev_out [D] are that layer's out-projection gradients.
- * Shapes: H <= 64, D <= 128, D % 4 == 0, D % heads == 0, (D / heads) % 4 == 0, heads <= 16 (tt_enc_last_supported
- * returns 1; 2 when the w_prev_out form is taken as well: 32 (D + 4) (2 + heads) floats of LDS); x, dx, d_recent, the
- * weights, t, tp, xbar, cbar and ws 16-byte aligned. */
+/* The encoder's LAST layer is consumed at row 0 only (ref:src/user_history_encoder.py:103-116: only row 0 of the last
+ * nn.MultiheadAttention's output is used): it runs WITHOUT projecting K and V.  x [B*H, D] is the layer's input, w_in
+ * [3D, D] / b_in [3D] / w_out [D, D] / b_out [D] its packed parameters.  With q0 = W_q x[b,0] + b_q:
+ * score_h[j] = scale (W_k,h^T q0_h) . x[b,j]  (the K bias shifts every score of a head alike and drops out of the softmax)
+ * and ctx0_h = W_v,h (sum_j p_h[j] x[b,j]) + b_v,h, so each sample's rows are read once and the [B*H, 2D] projection
+ * never exists.  Forward writes recent [B, D] (row stride ld_recent) = W_out ctx0 + b_out and, for the backward, q0
+ * [B, D], t [B, heads, D] (= W_k,h^T q0_h), probs [B, heads, H], xbar [B, heads, D], ctx0 [B, D].  Backward writes dx
+ * [B*H, D] (every row), dW_in [3D, D], db_in [3D] (the K third exactly zero), dW_out [D, D], db_out [D]; weight gradients
+ * are per-workgroup partial sums added in a fixed order (deterministic).
+ * A caller whose PREVIOUS layer hands over its attention context c instead of its output c W_o^T + b_o passes x = c with
+ * the composed parameters w_in = W_in W_o, b_in = W_in b_o + b_in (q, k, v are linear in the never-formed output) and maps
+ * dW_in / db_in back itself (ops.HistoryEncoder).
+ * Shapes: H <= 64, D <= 128, D % 4 == 0, D % heads == 0, (D / heads) % 4 == 0, heads <= 16 (tt_enc_last_supported);
+ * x, dx, d_recent, the weights, t, xbar and ws 16-byte aligned. */
 int tt_enc_last_supported(int64_t H, int64_t D, int64_t heads);
 int tt_enc_last_fwd(const float* x, int64_t B, int64_t H, int64_t D, int64_t heads, const float* w_in,
-                    const float* b_in, const float* w_out, const float* b_out, const float* w_prev_out,
-                    const float* b_prev_out, float* recent, int64_t ld_recent, float* q0, float* t, float* probs,
-                    float* xbar, float* ctx0, float* tp, float* cbar, float* x0, tt_stream_t stream);
+                    const float* b_in, const float* w_out, const float* b_out, float* recent, int64_t ld_recent,
+                    float* q0, float* t, float* probs, float* xbar, float* ctx0, tt_stream_t stream);
 int64_t tt_enc_last_bwd_workspace_bytes(int64_t B, int64_t H, int64_t D, int64_t heads);
 int tt_enc_last_bwd(const float* x, int64_t B, int64_t H, int64_t D, int64_t heads, const float* w_in,
-                    const float* w_out, const float* w_prev_out, const float* d_recent, int64_t ld_dr, const float* q0,
-                    const float* t, const float* probs, const float* xbar, const float* ctx0, const float* tp,
-                    const float* cbar, const float* x0, float* dx, float* dW_in, float* db_in, float* dW_out,
-                    float* db_out, float* dW_prev_out, float* db_prev_out, void* ws, int64_t ws_bytes,
-                    tt_stream_t stream);
+                    const float* w_out, const float* d_recent, int64_t ld_dr, const float* q0, const float* t,
+                    const float* probs, const float* xbar, const float* ctx0, float* dx, float* dW_in, float* db_in,
+                    float* dW_out, float* db_out, void* ws, int64_t ws_bytes, tt_stream_t stream);
 
 /* ---------------------------------------------------------------- R1 owner routing (row-sharded tables)
  * New design -- the reference has no parallelism.  Tables are split into `world`

@@ -720,41 +720,33 @@ def test_attention_forward_backward(T, B, H, D, heads):
 
 @pytest.mark.parametrize("B,H,D,heads", [(9, 50, 128, 4), (5, 64, 64, 4), (3, 1, 32, 2), (70, 7, 48, 3), (4, 3, 4, 1),
                                          (300, 50, 128, 4), (33, 10, 100, 5), (2, 64, 128, 16)])
-@pytest.mark.parametrize("prev", [False, True])
-def test_encoder_last_layer_without_kv_projection(T, B, H, D, heads, prev):
+def test_encoder_last_layer_without_kv_projection(T, B, H, D, heads):
     """tt_enc_last_fwd / _bwd (csrc/encoder_last.hip): the encoder's last attention layer, consumed at row 0 only
     (ref:src/user_history_encoder.py:103-116), with K / V never projected -- against the oracle's full layer
     (oracle/cpu_ref.self_attention_layer, every position, row 0 taken) and torch autograd through it: output,
     input gradient, and all four parameter gradients (the K third of the in-projection bias: zero both ways).
-    prev: the input arrives as the previous layer's attention context c, x = c W_pa^T + b_pa is never formed, and the
-    gradients of c, W_pa, b_pa come out of the same call."""
+    (The form that reads the PREVIOUS layer's context through composed weights is the caller's arithmetic:
+    tests/test_gpu_models.py::test_encoder_matches_reference covers it at L = 3.)"""
     ops, N = T
     lib = N.load()
-    level = lib.tt_enc_last_supported(H, D, heads)
-    assert level >= 1
-    if prev and level < 2:
-        pytest.skip("the folded form needs 2 + heads LDS images")
-    c = g((B, H, D), 301).requires_grad_(True)
-    w_pa = (g((D, D), 307) * (1.0 / math.sqrt(D))).requires_grad_(True)
-    b_pa = (g((D,), 308) * 0.1).requires_grad_(True)
+    assert lib.tt_enc_last_supported(H, D, heads) == 1
+    x = g((B, H, D), 301).requires_grad_(True)
     w_in = (g((3 * D, D), 302) * (1.0 / math.sqrt(D))).requires_grad_(True)
     b_in = (g((3 * D,), 303) * 0.1).requires_grad_(True)
     w_out = (g((D, D), 304) * (1.0 / math.sqrt(D))).requires_grad_(True)
     b_out = (g((D,), 305) * 0.1).requires_grad_(True)
-    x = (c.reshape(B * H, D) @ w_pa.t() + b_pa).reshape(B, H, D) if prev else c
     ref = R.self_attention_layer(x, w_in, b_in, w_out, b_out, heads)[:, 0, :]
     cot = g((B, 2 * D), 306)[:, :D]  # strided rows, like out[:, 0, :] of the [B, 2, D] encoder output
     (ref * cot).sum().backward()
-    xd = c.detach().reshape(B * H, D).to(DEV)
-    wi, bi, wo, bo, wp, bp = (t.detach().to(DEV) for t in (w_in, b_in, w_out, b_out, w_pa, b_pa))
+    xd = x.detach().reshape(B * H, D).to(DEV)
+    wi, bi, wo, bo = (t.detach().to(DEV) for t in (w_in, b_in, w_out, b_out))
     out = torch.zeros(B, 2 * D, device=DEV)
-    q0, ctx0, x0 = torch.empty(B, D, device=DEV), torch.empty(B, D, device=DEV), torch.empty(B, D, device=DEV)
-    tq, xbar, tp, cbar = (torch.empty(B, heads, D, device=DEV) for _ in range(4))
+    q0, ctx0 = torch.empty(B, D, device=DEV), torch.empty(B, D, device=DEV)
+    tq, xbar = torch.empty(B, heads, D, device=DEV), torch.empty(B, heads, D, device=DEV)
     probs = torch.empty(B, heads, H, device=DEV)
-    P = (lambda t: t.data_ptr()) if prev else (lambda t: None)
     N.check(lib.tt_enc_last_fwd(xd.data_ptr(), B, H, D, heads, wi.data_ptr(), bi.data_ptr(), wo.data_ptr(), bo.data_ptr(),
-                                P(wp), P(bp), out.data_ptr(), 2 * D, q0.data_ptr(), tq.data_ptr(), probs.data_ptr(),
-                                xbar.data_ptr(), ctx0.data_ptr(), P(tp), P(cbar), P(x0), N.stream()), "enc_last_fwd")
+                                out.data_ptr(), 2 * D, q0.data_ptr(), tq.data_ptr(), probs.data_ptr(), xbar.data_ptr(),
+                                ctx0.data_ptr(), N.stream()), "enc_last_fwd")
     assert torch.allclose(out[:, :D].cpu(), ref.detach(), atol=4e-6, rtol=1e-5)
     assert float(out[:, D:].abs().max()) == 0.0  # the other half of each row is not touched
     assert torch.allclose(probs.sum(-1).cpu(), torch.ones(B, heads), atol=1e-5)
@@ -763,20 +755,19 @@ def test_encoder_last_layer_without_kv_projection(T, B, H, D, heads, prev):
     dx = torch.empty(B * H, D, device=DEV)
     dWi, dbi = torch.empty(3 * D, D, device=DEV), torch.empty(3 * D, device=DEV)
     dWo, dbo = torch.empty(D, D, device=DEV), torch.empty(D, device=DEV)
-    dWp, dbp = torch.empty(D, D, device=DEV), torch.empty(D, device=DEV)
     nb = lib.tt_enc_last_bwd_workspace_bytes(B, H, D, heads)
     ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
     for _ in range(2):  # twice: the partial buffers are overwritten, not accumulated into
-        N.check(lib.tt_enc_last_bwd(xd.data_ptr(), B, H, D, heads, wi.data_ptr(), wo.data_ptr(), P(wp), cd.data_ptr(), 2 * D,
+        N.check(lib.tt_enc_last_bwd(xd.data_ptr(), B, H, D, heads, wi.data_ptr(), wo.data_ptr(), cd.data_ptr(), 2 * D,
                                     q0.data_ptr(), tq.data_ptr(), probs.data_ptr(), xbar.data_ptr(), ctx0.data_ptr(),
-                                    P(tp), P(cbar), P(x0), dx.data_ptr(), dWi.data_ptr(), dbi.data_ptr(), dWo.data_ptr(),
-                                    dbo.data_ptr(), P(dWp), P(dbp), ws.data_ptr(), nb, N.stream()), "enc_last_bwd")
+                                    dx.data_ptr(), dWi.data_ptr(), dbi.data_ptr(), dWo.data_ptr(), dbo.data_ptr(),
+                                    ws.data_ptr(), nb, N.stream()), "enc_last_bwd")
 
     def close(got, want, name):
         tol = 4e-6 * float(want.abs().max()) + 1e-8
         assert torch.allclose(got.cpu().reshape(want.shape), want, atol=tol, rtol=2e-4), (name, float((got.cpu().reshape(want.shape) - want).abs().max()), tol)
 
-    close(dx, c.grad, "dx")
+    close(dx, x.grad, "dx")
     close(dWo, w_out.grad, "dW_out")
     close(dbo, b_out.grad, "db_out")
     close(dWi, w_in.grad, "dW_in")
@@ -784,9 +775,6 @@ def test_encoder_last_layer_without_kv_projection(T, B, H, D, heads, prev):
     keep = torch.ones(3 * D, dtype=torch.bool)
     keep[D:2 * D] = False
     close(dbi[keep.to(DEV)], b_in.grad[keep], "db_in")
-    if prev:
-        close(dWp, w_pa.grad, "dW_prev_out")
-        close(dbp, b_pa.grad, "db_prev_out")
 
 
 @pytest.mark.parametrize("D,H,B", [(128, 50, 9), (50, 7, 4)])

@@ -139,17 +139,17 @@ SIGNATURES = {
     "tt_stream_destroy": (_int, [_vp]),
     "tt_adam_dense": (_int, [C.POINTER(AdamTensor), _i32, _vp, _vp]),
     "tt_pack_grads": (_int, [C.POINTER(AdamTensor), _i32, _vp]),
+    "tt_copy_buffers": (_int, [C.POINTER(AdamTensor), _i32, _vp]),
     "tt_hist_embed_pool": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp]),
     "tt_hist_dx_pool_bwd": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
     "tt_hist_pool_bwd": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),
     "tt_attn_fwd": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "tt_attn_bwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "tt_enc_last_supported": (_int, [_i64, _i64, _i64]),
-    "tt_enc_last_fwd": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
-                               _vp, _vp, _vp, _vp]),
+    "tt_enc_last_fwd": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tt_enc_last_bwd_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
-    "tt_enc_last_bwd": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "tt_enc_last_bwd": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _vp, _vp, _vp, _i64, _vp]),
     "tt_route_workspace_bytes": (_i64, [_i64, _i32]),
     "tt_route_count": (_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tt_route_build": (_int, [_vp, _i64, _i64, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),

@@ -648,6 +648,19 @@ __global__ __launch_bounds__(256) void pack_grads_kernel(const AdamBatch ts) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < t.n; i += stride) t.p[i] = t.g[i];
 }
 
+// whole-step hipGraph: a new batch's seven input tensors into the captured static buffers in ONE launch
+// (t.p = destination, t.g = source, t.n = BYTES; 16-byte words where both ends are aligned, bytes otherwise)
+__global__ __launch_bounds__(256) void copy_buffers_kernel(const AdamBatch ts) {
+  const tt_adam_tensor t = ts.t[blockIdx.y];
+  char* dst = reinterpret_cast<char*>(t.p);
+  const char* src = reinterpret_cast<const char*>(t.g);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool vec = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+  const int64_t n16 = vec ? t.n / 16 : 0;
+  for (int64_t i = i0; i < n16; i += stride) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+  for (int64_t i = n16 * 16 + i0; i < t.n; i += stride) dst[i] = src[i];
+}
+
 // dense gradient for torch.optim users: dense[row,:] = sum of that row's gradient rows
 __global__ __launch_bounds__(256) void rowgrad_dense_kernel(const tt_grad_sources src, int64_t n_rows, int64_t dim,
                                                             const int32_t* __restrict__ sorted_ids,
@@ -1055,6 +1068,26 @@ extern "C" int tt_pack_grads(const tt_adam_tensor* tensors, int32_t n_tensors, t
     const int64_t bx = ceil_div(max_n, 1024) < 1024 ? ceil_div(max_n, 1024) : 1024;
     pack_grads_kernel<<<dim3((unsigned)bx, (unsigned)cnt), 256, 0, S(stream)>>>(b);
     const int rc = check_launch("pack_grads_kernel");
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int tt_copy_buffers(const tt_adam_tensor* buffers, int32_t n_buffers, tt_stream_t stream) {
+  if (!buffers) return fail_arg("tt_copy_buffers: null pointer");
+  if (n_buffers <= 0) return fail_arg("tt_copy_buffers: sizes");
+  for (int32_t base = 0; base < n_buffers; base += ADAM_BATCH) {
+    const int32_t cnt = (n_buffers - base < ADAM_BATCH) ? n_buffers - base : ADAM_BATCH;
+    AdamBatch b;
+    int64_t max_n = 16;
+    for (int32_t i = 0; i < cnt; ++i) {
+      b.t[i] = buffers[base + i];
+      if (!b.t[i].p || !b.t[i].g || b.t[i].n < 0) return fail_arg("tt_copy_buffers: descriptor");
+      if (b.t[i].n > max_n) max_n = b.t[i].n;
+    }
+    const int64_t bx = ceil_div(max_n / 16, 256) < 256 ? ceil_div(max_n / 16, 256) : 256;
+    copy_buffers_kernel<<<dim3((unsigned)(bx < 1 ? 1 : bx), (unsigned)cnt), 256, 0, S(stream)>>>(b);
+    const int rc = check_launch("copy_buffers_kernel");
     if (rc) return rc;
   }
   return 0;

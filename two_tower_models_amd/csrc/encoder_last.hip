@@ -130,85 +130,53 @@ struct ElLane {
 
 }  // namespace
 
-// Arguments shared by the four small kernels.  PREV = the layer in front of this one hands over its attention
-// CONTEXT c [B*H, D] instead of its output x = c W_oa^T + b_oa (w_pa / b_pa = that layer's out-projection): every use of
-// x in this layer is linear in it, so
-//   X0 = x[b, 0] = c[b, 0] W_oa^T + b_oa          (the only row that is ever formed)
-//   t_h . x[j]   = (W_oa^T t_h) . c[j] + const     -> the main kernels run on c with tp_h = W_oa^T t_h
-//   xbar_h       = (sum_j p_h[j] c[j]) W_oa^T + b_oa = cbar_h W_oa^T + b_oa
-// and the [B*H, D] x [D, D] out-projection of that layer, its d_ctx product and its weight-gradient product
-// (3 x 6.7 GFLOP at the BASELINE shape) shrink to [B * (1 + 2 heads), D] x [D, D] ones.
+// Arguments shared by the four small kernels.  When the layer in front of this one hands over its attention CONTEXT
+// instead of its output (x = c W_o^T + b_o never formed), the CALLER composes the weights -- W_in W_o, W_in b_o + b_in:
+// q, k, v are linear in x -- and these kernels run on c unchanged (ops.HistoryEncoder; round 4 carried W_o through the
+// kernels instead: 3.5x the matrix work here for the same result).
 struct ElArgs {
-  const float* x;      // [B*H, D]: this layer's input, or (PREV) the previous layer's context
+  const float* x;      // [B*H, D]: this layer's input (or the previous layer's context, with composed w_in / b_in)
   const float* w_in;   // [3D, D]
   const float* b_in;   // [3D]
   const float* w_out;  // [D, D]
   const float* b_out;  // [D]
-  const float* w_pa;   // PREV: previous layer's out-projection weight [D, D]
-  const float* b_pa;   // PREV: its bias [D]
   int64_t B;
   int H, D, heads;
   // saved by the forward, read by the backward
   float* q0;     // [B, D]
   float* t;      // [B, heads, D]   W_k,h^T q0_h
-  float* tp;     // PREV: [B, heads, D]   W_oa^T t_h  (else unused: the main kernels take t)
-  float* cbar;   // PREV: [B, heads, D]   sum_j p_h[j] c[j]  (else unused: the main forward writes xbar)
   float* xbar;   // [B, heads, D]
   float* ctx0;   // [B, D]
-  float* x0;     // PREV: [B, D]  row 0 of the never-formed x
   float* recent; int64_t ld_recent;            // forward output [B, D]
   const float* d_recent; int64_t ld_dr;        // backward input
-  float* d_xbar;  // backward scratch [B, heads, D]: what the main backward consumes (d_xbar, or PREV d_cbar)
-  float* dt;      // backward scratch [B, heads, D]: what the main backward produces (dt, or PREV dt')
-  float* dx;      // backward output [B*H, D] (PREV: gradient of the previous layer's context)
+  float* d_xbar;  // backward scratch [B, heads, D]: what the main backward consumes
+  float* dt;      // backward scratch [B, heads, D]: what the main backward produces
+  float* dx;      // backward output [B*H, D]
   float* part_a;  // per-workgroup partial sums, backward a
   float* part_b;  // per-workgroup partial sums, backward b
 };
 
-// floats per workgroup in the partial buffers:  a = [dW_out | dW_v | dW_pa(1) | db_out | db_v | db_pa(1)]
-//                                               b = [dW_q | dW_k | dW_pa(2+3) | db_q | db_pa(2)]
-__host__ __device__ inline int64_t el_part_a(int64_t D) { return 3 * D * D + 3 * D; }
-__host__ __device__ inline int64_t el_part_b(int64_t D) { return 3 * D * D + 2 * D; }
+// floats per workgroup in the partial buffers:  a = [dW_out | dW_v | db_out | db_v]      b = [dW_q | dW_k | db_q]
+__host__ __device__ inline int64_t el_part_a(int64_t D) { return 2 * D * D + 2 * D; }
+__host__ __device__ inline int64_t el_part_b(int64_t D) { return 2 * D * D + D; }
 
 // the [32, D] result tile `acc` of column tile ct -> LDS image (row stride ldq) and / or global rows (row stride ldg)
 #define EL_TILE_COLS(ct) const int col = 32 * (ct) + L.li, nc = col < D ? col : D - 1
 
-// ------------------------------------------------------------------ forward: q0, t (, X0, tp)
-template <bool PREV>
+// ------------------------------------------------------------------ forward: q0, t
 __global__ __launch_bounds__(256, 1) void enc_last_pre_kernel(const ElArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = p.D, H = p.H, heads = p.heads;
   const int ldq = D + 4, dh = D / heads, NT = (D + 31) / 32;
   float* qs = reinterpret_cast<float*>(smem_raw);  // [32][ldq] q0
-  float* xs = qs + EL_IMG * ldq;                  // PREV: [32][ldq] X0
-  float* ts = xs + EL_IMG * ldq;                  // PREV: [heads][32][ldq] t
   const ElLane L;
   const int64_t b0 = (int64_t)blockIdx.x * EL_ROWS;
   const int nb = (int)((p.B - b0) < EL_ROWS ? (p.B - b0) : EL_ROWS);
   const int rowA = L.li < nb ? L.li : nb - 1;
-  if constexpr (PREV) {  // X0 = c[b, 0] W_oa^T + b_oa
-    for (int ct = L.w; ct < NT; ct += 4) {
-      EL_TILE_COLS(ct);
-      f32x16 acc = zero16();
-      mma_tile<true, true>(acc, p.x + (b0 + rowA) * H * D, 0, 1.f, p.w_pa + (int64_t)nc * D, 0, 1.f, D);
-      const float bias = p.b_pa[nc];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r);
-        const float v = acc[r] + bias;
-        if (col < D) {
-          xs[row * ldq + col] = v;
-          if (row < nb) p.x0[(b0 + row) * D + col] = v;
-        }
-      }
-    }
-    __syncthreads();
-  }
   for (int ct = L.w; ct < NT; ct += 4) {  // q0 = X0 W_q^T + b_q
     EL_TILE_COLS(ct);
     f32x16 acc = zero16();
-    if constexpr (PREV) mma_tile<true, true>(acc, xs + L.li * ldq, 0, 1.f, p.w_in + (int64_t)nc * D, 0, 1.f, D);
-    else mma_tile<true, true>(acc, p.x + (b0 + rowA) * H * D, 0, 1.f, p.w_in + (int64_t)nc * D, 0, 1.f, D);
+    mma_tile<true, true>(acc, p.x + (b0 + rowA) * H * D, 0, 1.f, p.w_in + (int64_t)nc * D, 0, 1.f, D);
     const float bias = p.b_in[nc];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -229,24 +197,7 @@ __global__ __launch_bounds__(256, 1) void enc_last_pre_kernel(const ElArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = acc_row(r);
-      if (col < D) {
-        if constexpr (PREV) ts[(hh * EL_IMG + row) * ldq + col] = acc[r];
-        if (row < nb) p.t[((b0 + row) * heads + hh) * D + col] = acc[r];
-      }
-    }
-  }
-  if constexpr (PREV) {  // tp_h = t_h W_oa
-    __syncthreads();
-    for (int u = L.w; u < heads * NT; u += 4) {
-      const int hh = u / NT, ct = u % NT;
-      EL_TILE_COLS(ct);
-      f32x16 acc = zero16();
-      mma_tile<true, false>(acc, ts + (hh * EL_IMG + L.li) * ldq, 0, 1.f, p.w_pa + nc, D, 1.f, D);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r);
-        if (col < D && row < nb) p.tp[((b0 + row) * heads + hh) * D + col] = acc[r];
-      }
+      if (col < D && row < nb) p.t[((b0 + row) * heads + hh) * D + col] = acc[r];
     }
   }
 }
@@ -294,46 +245,24 @@ __global__ __launch_bounds__(256) void enc_last_main_fwd_kernel(const float* __r
   }
 }
 
-// ------------------------------------------------------------------ forward: (xbar,) ctx0, recent
-// ctx0[b, i] = W_v[i] . xbar[b, head(i)] + b_v[i] ;  recent[b] = W_out ctx0[b] + b_out ;  PREV: xbar_h = cbar_h W_oa^T + b_oa first
-template <bool PREV>
+// ------------------------------------------------------------------ forward: ctx0, recent
+// ctx0[b, i] = W_v[i] . xbar[b, head(i)] + b_v[i] ;  recent[b] = W_out ctx0[b] + b_out
 __global__ __launch_bounds__(256, 1) void enc_last_post_kernel(const ElArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = p.D, heads = p.heads;
   const int ldq = D + 4, dh = D / heads, NT = (D + 31) / 32;
   float* cs = reinterpret_cast<float*>(smem_raw);  // [32][ldq] ctx0
-  float* xb = cs + EL_IMG * ldq;                  // PREV: [heads][32][ldq] xbar
   const ElLane L;
   const int64_t b0 = (int64_t)blockIdx.x * EL_ROWS;
   const int nb = (int)((p.B - b0) < EL_ROWS ? (p.B - b0) : EL_ROWS);
   const int rowA = L.li < nb ? L.li : nb - 1;
-  if constexpr (PREV) {
-    for (int u = L.w; u < heads * NT; u += 4) {
-      const int hh = u / NT, ct = u % NT;
-      EL_TILE_COLS(ct);
-      f32x16 acc = zero16();
-      mma_tile<true, true>(acc, p.cbar + ((b0 + rowA) * heads + hh) * D, 0, 1.f, p.w_pa + (int64_t)nc * D, 0, 1.f, D);
-      const float bias = p.b_pa[nc];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r);
-        const float v = acc[r] + bias;
-        if (col < D) {
-          xb[(hh * EL_IMG + row) * ldq + col] = v;
-          if (row < nb) p.xbar[((b0 + row) * heads + hh) * D + col] = v;
-        }
-      }
-    }
-    __syncthreads();
-  }
   for (int ct = L.w; ct < NT; ct += 4) {
     EL_TILE_COLS(ct);
     const int h_lo = (32 * ct) / dh, h_hi = ((32 * ct + 31 < D ? 32 * ct + 31 : D - 1)) / dh;
     f32x16 acc = zero16();
     for (int hh = h_lo; hh <= h_hi; ++hh) {
       const float bm = nc / dh == hh ? 1.f : 0.f;
-      if constexpr (PREV) mma_tile<true, true>(acc, xb + (hh * EL_IMG + L.li) * ldq, 0, 1.f, p.w_in + (int64_t)(2 * D + nc) * D, 0, bm, D);
-      else mma_tile<true, true>(acc, p.xbar + ((b0 + rowA) * heads + hh) * D, 0, 1.f, p.w_in + (int64_t)(2 * D + nc) * D, 0, bm, D);
+      mma_tile<true, true>(acc, p.xbar + ((b0 + rowA) * heads + hh) * D, 0, 1.f, p.w_in + (int64_t)(2 * D + nc) * D, 0, bm, D);
     }
     const float bias = p.b_in[2 * D + nc];
 #pragma unroll
@@ -360,14 +289,12 @@ __global__ __launch_bounds__(256, 1) void enc_last_post_kernel(const ElArgs p) {
   }
 }
 
-// ------------------------------------------------------------------ backward a: d_ctx0, d_xbar (, d_cbar); dW_out, dW_v (, dW_pa), biases
-template <bool PREV>
+// ------------------------------------------------------------------ backward a: d_ctx0, d_xbar; dW_out, dW_v, biases
 __global__ __launch_bounds__(256, 1) void enc_last_bwd_a_kernel(const ElArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = p.D, heads = p.heads;
   const int ldq = D + 4, dh = D / heads, NT = (D + 31) / 32;
   float* dc = reinterpret_cast<float*>(smem_raw);  // [32][ldq] d_ctx0, rows past the batch = 0
-  float* dxb = dc + EL_IMG * ldq;                 // PREV: [heads][32][ldq] d_xbar, rows past the batch = 0
   const ElLane L;
   const int64_t b0 = (int64_t)blockIdx.x * EL_ROWS;
   const int nb = (int)((p.B - b0) < EL_ROWS ? (p.B - b0) : EL_ROWS);
@@ -393,28 +320,10 @@ __global__ __launch_bounds__(256, 1) void enc_last_bwd_a_kernel(const ElArgs p) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = acc_row(r);
-      if (col < D) {
-        if constexpr (PREV) dxb[(hh * EL_IMG + row) * ldq + col] = row < nb ? acc[r] : 0.f;
-        else if (row < nb) p.d_xbar[((b0 + row) * heads + hh) * D + col] = acc[r];
-      }
-    }
-  }
-  if constexpr (PREV) {  // d_cbar_h = d_xbar_h W_oa
-    __syncthreads();
-    for (int u = L.w; u < heads * NT; u += 4) {
-      const int hh = u / NT, ct = u % NT;
-      EL_TILE_COLS(ct);
-      f32x16 acc = zero16();
-      mma_tile<true, false>(acc, dxb + (hh * EL_IMG + L.li) * ldq, 0, 1.f, p.w_pa + nc, D, 1.f, D);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r);
-        if (col < D && row < nb) p.d_xbar[((b0 + row) * heads + hh) * D + col] = acc[r];
-      }
+      if (col < D && row < nb) p.d_xbar[((b0 + row) * heads + hh) * D + col] = acc[r];
     }
   }
   // dW_out[m][n] = sum_b d_recent[b][m] ctx0[b][n] ;  dW_v[m][n] = sum_b d_ctx0[b][m] xbar[b][head(m)][n]
-  // PREV: dW_pa(1)[m][n] = sum_b sum_h d_xbar[b][h][m] cbar[b][h][n]
   float* mine = p.part_a + (int64_t)blockIdx.x * el_part_a(D);
   const int64_t DD = (int64_t)D * D;
   for (int u = L.w; u < NT * NT; u += 4) {
@@ -428,32 +337,23 @@ __global__ __launch_bounds__(256, 1) void enc_last_bwd_a_kernel(const ElArgs p) 
     for (int hh = h_lo; hh <= h_hi; ++hh)
       mma_tile<false, false>(acv, dc + mc, ldq, mc / dh == hh ? 1.f : 0.f, p.xbar + (b0 * heads + hh) * D + nc,
                              (int64_t)heads * D, 1.f, nb);
-    f32x16 acp = zero16();
-    if constexpr (PREV)
-      for (int hh = 0; hh < heads; ++hh)
-        mma_tile<false, false>(acp, dxb + hh * EL_IMG * ldq + mc, ldq, 1.f, p.cbar + (b0 * heads + hh) * D + nc,
-                               (int64_t)heads * D, 1.f, nb);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = 32 * rt + acc_row(r);
       if (row < D && col < D) {
         mine[row * D + col] = acc[r];
         mine[DD + row * D + col] = acv[r];
-        if constexpr (PREV) mine[2 * DD + row * D + col] = acp[r];
       }
     }
   }
   if ((int)threadIdx.x < D) {
-    float so = 0.f, sv = 0.f, sp = 0.f;
+    float so = 0.f, sv = 0.f;
     for (int b = 0; b < nb; ++b) {
       so += p.d_recent[(b0 + b) * p.ld_dr + threadIdx.x];
       sv += dc[b * ldq + threadIdx.x];
-      if constexpr (PREV)
-        for (int hh = 0; hh < heads; ++hh) sp += dxb[(hh * EL_IMG + b) * ldq + threadIdx.x];
     }
-    mine[3 * DD + threadIdx.x] = so;
-    mine[3 * DD + D + threadIdx.x] = sv;
-    mine[3 * DD + 2 * D + threadIdx.x] = sp;
+    mine[2 * DD + threadIdx.x] = so;
+    mine[2 * DD + D + threadIdx.x] = sv;
   }
 }
 
@@ -517,33 +417,16 @@ __global__ __launch_bounds__(256) void enc_last_main_bwd_kernel(const float* __r
   }
 }
 
-// ------------------------------------------------------------------ backward b: (dt,) dq0 -> dX[0]; dW_k, dW_q (, dW_pa), biases
-template <bool PREV>
+// ------------------------------------------------------------------ backward b: dq0 -> dX[0]; dW_k, dW_q, biases
 __global__ __launch_bounds__(256, 1) void enc_last_bwd_b_kernel(const ElArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = p.D, H = p.H, heads = p.heads;
   const int ldq = D + 4, dh = D / heads, NT = (D + 31) / 32;
   float* dq = reinterpret_cast<float*>(smem_raw);  // [32][ldq] dq0, rows past the batch = 0
-  float* dxs = dq + EL_IMG * ldq;                 // PREV: [32][ldq] dX0, rows past the batch = 0
-  float* dts = dxs + EL_IMG * ldq;                // PREV: [heads][32][ldq] dt, rows past the batch = 0
   const ElLane L;
   const int64_t b0 = (int64_t)blockIdx.x * EL_ROWS;
   const int nb = (int)((p.B - b0) < EL_ROWS ? (p.B - b0) : EL_ROWS);
   const int rowA = L.li < nb ? L.li : nb - 1;
-  if constexpr (PREV) {  // dt_h = dt'_h W_oa^T   (p.dt holds dt' = sum_j ds_h[j] c[j])
-    for (int u = L.w; u < heads * NT; u += 4) {
-      const int hh = u / NT, ct = u % NT;
-      EL_TILE_COLS(ct);
-      f32x16 acc = zero16();
-      mma_tile<true, true>(acc, p.dt + ((b0 + rowA) * heads + hh) * D, 0, 1.f, p.w_pa + (int64_t)nc * D, 0, 1.f, D);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r);
-        if (col < D) dts[(hh * EL_IMG + row) * ldq + col] = row < nb ? acc[r] : 0.f;
-      }
-    }
-    __syncthreads();
-  }
   // dq0[b][n] = W_k[n] . dt[b][head(n)]
   for (int ct = L.w; ct < NT; ct += 4) {
     EL_TILE_COLS(ct);
@@ -551,8 +434,7 @@ __global__ __launch_bounds__(256, 1) void enc_last_bwd_b_kernel(const ElArgs p) 
     f32x16 acc = zero16();
     for (int hh = h_lo; hh <= h_hi; ++hh) {
       const float bm = nc / dh == hh ? 1.f : 0.f;
-      if constexpr (PREV) mma_tile<true, true>(acc, dts + (hh * EL_IMG + L.li) * ldq, 0, 1.f, p.w_in + (int64_t)(D + nc) * D, 0, bm, D);
-      else mma_tile<true, true>(acc, p.dt + ((b0 + rowA) * heads + hh) * D, 0, 1.f, p.w_in + (int64_t)(D + nc) * D, 0, bm, D);
+      mma_tile<true, true>(acc, p.dt + ((b0 + rowA) * heads + hh) * D, 0, 1.f, p.w_in + (int64_t)(D + nc) * D, 0, bm, D);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -561,7 +443,7 @@ __global__ __launch_bounds__(256, 1) void enc_last_bwd_b_kernel(const ElArgs p) 
     }
   }
   __syncthreads();
-  // dX0[b][n] = sum_k dq0[b][k] W_q[k][n]:  added to row 0 of the sample's dx, or (PREV) kept for the next product
+  // dX0[b][n] = sum_k dq0[b][k] W_q[k][n]:  added to row 0 of the sample's dx
   for (int ct = L.w; ct < NT; ct += 4) {
     EL_TILE_COLS(ct);
     f32x16 acc = zero16();
@@ -569,27 +451,10 @@ __global__ __launch_bounds__(256, 1) void enc_last_bwd_b_kernel(const ElArgs p) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = acc_row(r);
-      if (col < D) {
-        if constexpr (PREV) dxs[row * ldq + col] = row < nb ? acc[r] : 0.f;
-        else if (row < nb) p.dx[(b0 + row) * H * D + col] += acc[r];
-      }
-    }
-  }
-  if constexpr (PREV) {  // d_c[b, 0][n] += sum_k dX0[b][k] W_oa[k][n]
-    __syncthreads();
-    for (int ct = L.w; ct < NT; ct += 4) {
-      EL_TILE_COLS(ct);
-      f32x16 acc = zero16();
-      mma_tile<true, false>(acc, dxs + L.li * ldq, 0, 1.f, p.w_pa + nc, D, 1.f, D);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r);
-        if (col < D && row < nb) p.dx[(b0 + row) * H * D + col] += acc[r];
-      }
+      if (col < D && row < nb) p.dx[(b0 + row) * H * D + col] += acc[r];
     }
   }
   // dW_q[m][n] = sum_b dq0[b][m] X0[b][n] ;  dW_k[m][n] = sum_b q0[b][m] dt[b][head(m)][n]
-  // PREV: dW_pa(2+3)[m][n] = sum_b sum_h t[b][h][m] dt'[b][h][n] + sum_b dX0[b][m] c[b, 0][n]
   float* mine = p.part_b + (int64_t)blockIdx.x * el_part_b(D);
   const int64_t DD = (int64_t)D * D;
   for (int u = L.w; u < NT * NT; u += 4) {
@@ -597,21 +462,12 @@ __global__ __launch_bounds__(256, 1) void enc_last_bwd_b_kernel(const ElArgs p) 
     const int mrow = 32 * rt + L.li, mc = mrow < D ? mrow : D - 1;
     EL_TILE_COLS(ct);
     f32x16 acc = zero16();
-    if constexpr (PREV) mma_tile<false, false>(acc, dq + mc, ldq, 1.f, p.x0 + b0 * D + nc, D, 1.f, nb);
-    else mma_tile<false, false>(acc, dq + mc, ldq, 1.f, p.x + b0 * H * D + nc, (int64_t)H * D, 1.f, nb);
+    mma_tile<false, false>(acc, dq + mc, ldq, 1.f, p.x + b0 * H * D + nc, (int64_t)H * D, 1.f, nb);
     f32x16 ack = zero16();
     const int h_lo = (32 * rt) / dh, h_hi = ((32 * rt + 31 < D ? 32 * rt + 31 : D - 1)) / dh;
     for (int hh = h_lo; hh <= h_hi; ++hh) {
       const float am = mc / dh == hh ? 1.f : 0.f;
-      if constexpr (PREV) mma_tile<false, false>(ack, p.q0 + b0 * D + mc, D, am, dts + hh * EL_IMG * ldq + nc, ldq, 1.f, nb);
-      else mma_tile<false, false>(ack, p.q0 + b0 * D + mc, D, am, p.dt + (b0 * heads + hh) * D + nc, (int64_t)heads * D, 1.f, nb);
-    }
-    f32x16 acp = zero16();
-    if constexpr (PREV) {
-      for (int hh = 0; hh < heads; ++hh)
-        mma_tile<false, false>(acp, p.t + (b0 * heads + hh) * D + mc, (int64_t)heads * D, 1.f, p.dt + (b0 * heads + hh) * D + nc,
-                               (int64_t)heads * D, 1.f, nb);
-      mma_tile<false, false>(acp, dxs + mc, ldq, 1.f, p.x + b0 * H * D + nc, (int64_t)H * D, 1.f, nb);
+      mma_tile<false, false>(ack, p.q0 + b0 * D + mc, D, am, p.dt + (b0 * heads + hh) * D + nc, (int64_t)heads * D, 1.f, nb);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -619,24 +475,18 @@ __global__ __launch_bounds__(256, 1) void enc_last_bwd_b_kernel(const ElArgs p) 
       if (row < D && col < D) {
         mine[row * D + col] = acc[r];
         mine[DD + row * D + col] = ack[r];
-        if constexpr (PREV) mine[2 * DD + row * D + col] = acp[r];
       }
     }
   }
   if ((int)threadIdx.x < D) {
-    float sq = 0.f, sx = 0.f;
-    for (int b = 0; b < nb; ++b) {
-      sq += dq[b * ldq + threadIdx.x];
-      if constexpr (PREV) sx += dxs[b * ldq + threadIdx.x];
-    }
-    mine[3 * DD + threadIdx.x] = sq;
-    mine[3 * DD + D + threadIdx.x] = sx;
+    float sq = 0.f;
+    for (int b = 0; b < nb; ++b) sq += dq[b * ldq + threadIdx.x];
+    mine[2 * DD + threadIdx.x] = sq;
   }
 }
 
 // ------------------------------------------------------------------ reduce the partials (fixed order)
-// dW_in [3D, D] = [dW_q | dW_k | dW_v], db_in [3D] = [db_q | 0 | db_v], dW_out [D, D], db_out [D];
-// PREV: dW_pa [D, D] = a.dW_pa(1) + b.dW_pa(2+3), db_pa [D] = a.db_pa(1) + b.db_pa(2)
+// dW_in [3D, D] = [dW_q | dW_k | dW_v], db_in [3D] = [db_q | 0 | db_v], dW_out [D, D], db_out [D]
 __device__ __forceinline__ float el_sum_parts(const float* src, int64_t stride, int n) {
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four interleaved chains: independent loads in flight
   int w = 0;
@@ -651,11 +501,10 @@ __device__ __forceinline__ float el_sum_parts(const float* src, int64_t stride, 
 }
 __global__ __launch_bounds__(256) void enc_last_reduce_kernel(const float* __restrict__ part_a, const float* __restrict__ part_b,
                                                               int n, int D, float* __restrict__ dW_in, float* __restrict__ db_in,
-                                                              float* __restrict__ dW_out, float* __restrict__ db_out,
-                                                              float* __restrict__ dW_pa, float* __restrict__ db_pa) {
+                                                              float* __restrict__ dW_out, float* __restrict__ db_out) {
   const int DD = D * D;
   const int64_t sa = el_part_a(D), sb = el_part_b(D);
-  const int total = 5 * DD + 4 * D;
+  const int total = 4 * DD + 3 * D;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
     if (e < 2 * DD) {  // dW_q | dW_k
       dW_in[e] = el_sum_parts(part_b + e, sb, n);
@@ -663,19 +512,15 @@ __global__ __launch_bounds__(256) void enc_last_reduce_kernel(const float* __res
       dW_in[e] = el_sum_parts(part_a + DD + (e - 2 * DD), sa, n);
     } else if (e < 4 * DD) {  // dW_out
       dW_out[e - 3 * DD] = el_sum_parts(part_a + (e - 3 * DD), sa, n);
-    } else if (e < 5 * DD) {  // dW_pa
-      if (dW_pa) dW_pa[e - 4 * DD] = el_sum_parts(part_a + 2 * DD + (e - 4 * DD), sa, n) + el_sum_parts(part_b + 2 * DD + (e - 4 * DD), sb, n);
     } else {
-      const int k = e - 5 * DD, which = k / D, i = k % D;
+      const int k = e - 4 * DD, which = k / D, i = k % D;
       if (which == 0) {  // db_q, and the K third: exactly zero
-        db_in[i] = el_sum_parts(part_b + 3 * DD + i, sb, n);
+        db_in[i] = el_sum_parts(part_b + 2 * DD + i, sb, n);
         db_in[D + i] = 0.f;
       } else if (which == 1) {
-        db_in[2 * D + i] = el_sum_parts(part_a + 3 * DD + D + i, sa, n);
-      } else if (which == 2) {
-        db_out[i] = el_sum_parts(part_a + 3 * DD + i, sa, n);
-      } else if (db_pa) {
-        db_pa[i] = el_sum_parts(part_a + 3 * DD + 2 * D + i, sa, n) + el_sum_parts(part_b + 3 * DD + D + i, sb, n);
+        db_in[2 * D + i] = el_sum_parts(part_a + 2 * DD + D + i, sa, n);
+      } else {
+        db_out[i] = el_sum_parts(part_a + 2 * DD + i, sa, n);
       }
     }
   }
@@ -695,81 +540,50 @@ int64_t el_groups(int64_t B) { return ceil_div(B, EL_ROWS); }
 
 bool el_aligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// LDS of the small kernels: one [32][D+4] image, PREV: + one more and a [heads][32][D+4] one
-size_t el_small_lds(int64_t D, int64_t heads, bool prev, int plain_images) {
-  const size_t img = (size_t)EL_IMG * (D + 4) * sizeof(float);
-  return prev ? img * (plain_images + heads) : img;
-}
+// LDS of the small kernels: one [32][D+4] image
+size_t el_small_lds(int64_t D) { return (size_t)EL_IMG * (D + 4) * sizeof(float); }
 
 }  // namespace
 }  // namespace tt
 
 using namespace tt;
 
-// 0 = shape not taken; 1 = taken; 2 = taken, and so is the form with the previous layer's out-projection folded in
-// (w_prev_out != NULL: two plain and `heads` per-head [32, D + 4] LDS images)
 extern "C" int tt_enc_last_supported(int64_t H, int64_t D, int64_t heads) {
-  if (!(H >= 1 && H <= EL_MAXH && D >= 4 && D <= EL_MAXD && D % 4 == 0 && heads >= 1 && heads <= EL_MAXHEADS &&
-        D % heads == 0 && (D / heads) % 4 == 0))
-    return 0;
-  return (size_t)EL_IMG * (D + 4) * 4 * (2 + heads) <= 160 * 1024 ? 2 : 1;
+  return (H >= 1 && H <= EL_MAXH && D >= 4 && D <= EL_MAXD && D % 4 == 0 && heads >= 1 && heads <= EL_MAXHEADS &&
+          D % heads == 0 && (D / heads) % 4 == 0) ? 1 : 0;
 }
 
 extern "C" int tt_enc_last_fwd(const float* x, int64_t B, int64_t H, int64_t D, int64_t heads, const float* w_in,
-                               const float* b_in, const float* w_out, const float* b_out, const float* w_prev_out,
-                               const float* b_prev_out, float* recent, int64_t ld_recent, float* q0, float* t, float* probs,
-                               float* xbar, float* ctx0, float* tp, float* cbar, float* x0, tt_stream_t stream) {
-  const bool prev = w_prev_out != nullptr;
+                               const float* b_in, const float* w_out, const float* b_out, float* recent, int64_t ld_recent,
+                               float* q0, float* t, float* probs, float* xbar, float* ctx0, tt_stream_t stream) {
   if (!x || !w_in || !b_in || !w_out || !b_out || !recent || !q0 || !t || !probs || !xbar || !ctx0)
     return fail_arg("tt_enc_last_fwd: null pointer");
-  if (prev && (!b_prev_out || !tp || !cbar || !x0)) return fail_arg("tt_enc_last_fwd: w_prev_out needs b_prev_out, tp, cbar, x0");
-  if (prev && tt_enc_last_supported(H, D, heads) < 2) {
-    set_error("tt_enc_last_fwd: the folded previous out-projection does not fit the LDS at heads = %lld, D = %lld", (long long)heads, (long long)D);
-    return TT_E_UNSUPPORTED;
-  }
   if (B < 0 || !tt_enc_last_supported(H, D, heads) || ld_recent < D) {
     set_error("tt_enc_last_fwd: shape outside H <= 64, D <= 128, D %% 4 == 0, head width %% 4 == 0 (H = %lld, D = %lld, heads = %lld)",
               (long long)H, (long long)D, (long long)heads);
     return TT_E_UNSUPPORTED;
   }
-  if (!el_aligned(x) || !el_aligned(w_in) || !el_aligned(w_out) || !el_aligned(t) || !el_aligned(xbar) || !el_aligned(w_prev_out) ||
-      !el_aligned(tp) || !el_aligned(cbar))
-    return fail_arg("tt_enc_last_fwd: x, w_in, w_out, w_prev_out, t, tp, xbar, cbar must be 16-byte aligned");
+  if (!el_aligned(x) || !el_aligned(w_in) || !el_aligned(w_out) || !el_aligned(t) || !el_aligned(xbar))
+    return fail_arg("tt_enc_last_fwd: x, w_in, w_out, t, xbar must be 16-byte aligned");
   if (B == 0) return 0;
   hipStream_t st = S(stream);
   const unsigned G = (unsigned)el_groups(B);
   ElArgs a{};
-  a.x = x; a.w_in = w_in; a.b_in = b_in; a.w_out = w_out; a.b_out = b_out; a.w_pa = w_prev_out; a.b_pa = b_prev_out;
+  a.x = x; a.w_in = w_in; a.b_in = b_in; a.w_out = w_out; a.b_out = b_out;
   a.B = B; a.H = (int)H; a.D = (int)D; a.heads = (int)heads;
-  a.q0 = q0; a.t = t; a.tp = tp; a.cbar = cbar; a.xbar = xbar; a.ctx0 = ctx0; a.x0 = x0;
+  a.q0 = q0; a.t = t; a.xbar = xbar; a.ctx0 = ctx0;
   a.recent = recent; a.ld_recent = ld_recent;
   int rc;
-  {
-    const size_t lds = el_small_lds(D, heads, prev, 2);
-    if (prev) {
-      if ((rc = el_opt_in(enc_last_pre_kernel<true>, lds, "enc_last_pre_kernel"))) return rc;
-      enc_last_pre_kernel<true><<<G, 256, lds, st>>>(a);
-    } else {
-      enc_last_pre_kernel<false><<<G, 256, lds, st>>>(a);
-    }
-    if ((rc = check_launch("enc_last_pre_kernel"))) return rc;
-  }
+  enc_last_pre_kernel<<<G, 256, el_small_lds(D), st>>>(a);
+  if ((rc = check_launch("enc_last_pre_kernel"))) return rc;
   {
     const size_t lds = ((size_t)H * (D + 4) + heads * D) * sizeof(float);
     if ((rc = el_opt_in(enc_last_main_fwd_kernel, lds, "enc_last_main_fwd_kernel"))) return rc;
     ProfScope prof("enc_last_main_fwd_kernel", st);
-    enc_last_main_fwd_kernel<<<(unsigned)B, 256, lds, st>>>(x, (int)H, (int)D, (int)heads, prev ? tp : t, probs, prev ? cbar : xbar);
+    enc_last_main_fwd_kernel<<<(unsigned)B, 256, lds, st>>>(x, (int)H, (int)D, (int)heads, t, probs, xbar);
     if ((rc = check_launch("enc_last_main_fwd_kernel"))) return rc;
   }
-  {
-    const size_t lds = el_small_lds(D, heads, prev, 1);
-    if (prev) {
-      if ((rc = el_opt_in(enc_last_post_kernel<true>, lds, "enc_last_post_kernel"))) return rc;
-      enc_last_post_kernel<true><<<G, 256, lds, st>>>(a);
-    } else {
-      enc_last_post_kernel<false><<<G, 256, lds, st>>>(a);
-    }
-  }
+  enc_last_post_kernel<<<G, 256, el_small_lds(D), st>>>(a);
   return check_launch("enc_last_post_kernel");
 }
 
@@ -781,48 +595,35 @@ extern "C" int64_t tt_enc_last_bwd_workspace_bytes(int64_t B, int64_t H, int64_t
 }
 
 extern "C" int tt_enc_last_bwd(const float* x, int64_t B, int64_t H, int64_t D, int64_t heads, const float* w_in,
-                               const float* w_out, const float* w_prev_out, const float* d_recent, int64_t ld_dr,
-                               const float* q0, const float* t, const float* probs, const float* xbar, const float* ctx0,
-                               const float* tp, const float* cbar, const float* x0, float* dx, float* dW_in, float* db_in,
-                               float* dW_out, float* db_out, float* dW_prev_out, float* db_prev_out, void* ws,
-                               int64_t ws_bytes, tt_stream_t stream) {
-  const bool prev = w_prev_out != nullptr;
+                               const float* w_out, const float* d_recent, int64_t ld_dr, const float* q0, const float* t,
+                               const float* probs, const float* xbar, const float* ctx0, float* dx, float* dW_in, float* db_in,
+                               float* dW_out, float* db_out, void* ws, int64_t ws_bytes, tt_stream_t stream) {
   if (!x || !w_in || !w_out || !d_recent || !q0 || !t || !probs || !xbar || !ctx0 || !dx || !dW_in || !db_in || !dW_out ||
       !db_out)
     return fail_arg("tt_enc_last_bwd: null pointer");
-  if (prev && (!tp || !cbar || !x0 || !dW_prev_out || !db_prev_out))
-    return fail_arg("tt_enc_last_bwd: w_prev_out needs tp, cbar, x0, dW_prev_out, db_prev_out");
-  if (prev && tt_enc_last_supported(H, D, heads) < 2) {
-    set_error("tt_enc_last_bwd: the folded previous out-projection does not fit the LDS at heads = %lld, D = %lld", (long long)heads, (long long)D);
-    return TT_E_UNSUPPORTED;
-  }
   if (B < 0 || !tt_enc_last_supported(H, D, heads) || ld_dr < D) {
     set_error("tt_enc_last_bwd: shape outside H <= 64, D <= 128, D %% 4 == 0, head width %% 4 == 0");
     return TT_E_UNSUPPORTED;
   }
   if (!el_aligned(x) || !el_aligned(w_in) || !el_aligned(w_out) || !el_aligned(t) || !el_aligned(xbar) || !el_aligned(dx) ||
-      !el_aligned(ws) || !el_aligned(d_recent) || (ld_dr % 4) != 0 || !el_aligned(w_prev_out) || !el_aligned(tp) || !el_aligned(cbar))
-    return fail_arg("tt_enc_last_bwd: x, dx, w_in, w_out, w_prev_out, t, tp, xbar, cbar, d_recent, ws must be 16-byte aligned, ld_dr % 4 == 0");
+      !el_aligned(ws) || !el_aligned(d_recent) || (ld_dr % 4) != 0)
+    return fail_arg("tt_enc_last_bwd: x, dx, w_in, w_out, t, xbar, d_recent, ws must be 16-byte aligned, ld_dr % 4 == 0");
   hipStream_t st = S(stream);
   if (B == 0) {
     (void)hipMemsetAsync(dW_in, 0, sizeof(float) * 3 * D * D, st);
     (void)hipMemsetAsync(db_in, 0, sizeof(float) * 3 * D, st);
     (void)hipMemsetAsync(dW_out, 0, sizeof(float) * D * D, st);
     (void)hipMemsetAsync(db_out, 0, sizeof(float) * D, st);
-    if (prev) {
-      (void)hipMemsetAsync(dW_prev_out, 0, sizeof(float) * D * D, st);
-      (void)hipMemsetAsync(db_prev_out, 0, sizeof(float) * D, st);
-    }
     return 0;
   }
   if (!ws || ws_bytes < tt_enc_last_bwd_workspace_bytes(B, H, D, heads)) return fail_arg("tt_enc_last_bwd: workspace too small");
   const int64_t G = el_groups(B);
   Carver cv(ws);
   ElArgs a{};
-  a.x = x; a.w_in = w_in; a.w_out = w_out; a.w_pa = w_prev_out;
+  a.x = x; a.w_in = w_in; a.w_out = w_out;
   a.B = B; a.H = (int)H; a.D = (int)D; a.heads = (int)heads;
-  a.q0 = const_cast<float*>(q0); a.t = const_cast<float*>(t); a.tp = const_cast<float*>(tp); a.cbar = const_cast<float*>(cbar);
-  a.xbar = const_cast<float*>(xbar); a.ctx0 = const_cast<float*>(ctx0); a.x0 = const_cast<float*>(x0);
+  a.q0 = const_cast<float*>(q0); a.t = const_cast<float*>(t);
+  a.xbar = const_cast<float*>(xbar); a.ctx0 = const_cast<float*>(ctx0);
   a.d_recent = d_recent; a.ld_dr = ld_dr;
   a.d_xbar = cv.take<float>(B * heads * D);
   a.dt = cv.take<float>(B * heads * D);
@@ -830,35 +631,18 @@ extern "C" int tt_enc_last_bwd(const float* x, int64_t B, int64_t H, int64_t D, 
   a.part_b = cv.take<float>(G * el_part_b(D));
   a.dx = dx;
   int rc;
-  {
-    const size_t lds = el_small_lds(D, heads, prev, 1);
-    if (prev) {
-      if ((rc = el_opt_in(enc_last_bwd_a_kernel<true>, lds, "enc_last_bwd_a_kernel"))) return rc;
-      enc_last_bwd_a_kernel<true><<<(unsigned)G, 256, lds, st>>>(a);
-    } else {
-      enc_last_bwd_a_kernel<false><<<(unsigned)G, 256, lds, st>>>(a);
-    }
-    if ((rc = check_launch("enc_last_bwd_a_kernel"))) return rc;
-  }
+  enc_last_bwd_a_kernel<<<(unsigned)G, 256, el_small_lds(D), st>>>(a);
+  if ((rc = check_launch("enc_last_bwd_a_kernel"))) return rc;
   {
     const size_t lds = ((size_t)H * (D + 4) + 2 * heads * D + 2 * heads * 64) * sizeof(float);
     if ((rc = el_opt_in(enc_last_main_bwd_kernel, lds, "enc_last_main_bwd_kernel"))) return rc;
     ProfScope prof("enc_last_main_bwd_kernel", st);
-    enc_last_main_bwd_kernel<<<(unsigned)B, 256, lds, st>>>(x, (int)H, (int)D, (int)heads, prev ? tp : t, probs, a.d_xbar, a.dt, dx);
+    enc_last_main_bwd_kernel<<<(unsigned)B, 256, lds, st>>>(x, (int)H, (int)D, (int)heads, t, probs, a.d_xbar, a.dt, dx);
     if ((rc = check_launch("enc_last_main_bwd_kernel"))) return rc;
   }
-  {
-    const size_t lds = el_small_lds(D, heads, prev, 2);
-    if (prev) {
-      if ((rc = el_opt_in(enc_last_bwd_b_kernel<true>, lds, "enc_last_bwd_b_kernel"))) return rc;
-      enc_last_bwd_b_kernel<true><<<(unsigned)G, 256, lds, st>>>(a);
-    } else {
-      enc_last_bwd_b_kernel<false><<<(unsigned)G, 256, lds, st>>>(a);
-    }
-    if ((rc = check_launch("enc_last_bwd_b_kernel"))) return rc;
-  }
-  const int total = (int)(5 * D * D + 4 * D);
-  enc_last_reduce_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(a.part_a, a.part_b, (int)G, (int)D, dW_in, db_in, dW_out, db_out,
-                                                                     prev ? dW_prev_out : nullptr, prev ? db_prev_out : nullptr);
+  enc_last_bwd_b_kernel<<<(unsigned)G, 256, el_small_lds(D), st>>>(a);
+  if ((rc = check_launch("enc_last_bwd_b_kernel"))) return rc;
+  const int total = (int)(4 * D * D + 3 * D);
+  enc_last_reduce_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(a.part_a, a.part_b, (int)G, (int)D, dW_in, db_in, dW_out, db_out);
   return check_launch("enc_last_reduce_kernel");
 }

@@ -98,7 +98,10 @@ def run_on_side(dev: torch.device, fn, hold: Sequence[Optional[torch.Tensor]] = 
     work is deferred only if each of them is `_deferrable` AND has not been deferred by another node of this backward pass
     (a Parameter that feeds two Functions: autograd SUMS the two gradients on the main stream as soon as both exist).
     `again`: a continuation of work this node already deferred for the same leaves (must stay behind it on the side stream)."""
-    if not (_SIDE_GRADS and dev.type == "cuda") or torch.cuda.is_current_stream_capturing() or torch.is_grad_enabled():
+    if _SIDE_GRADS and dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        fn(True)  # one stream while capturing: in line, on the side slots the eager warm-up steps have already sized
+        return False
+    if not (_SIDE_GRADS and dev.type == "cuda") or torch.is_grad_enabled():
         fn(False)
         return False
     st = _side_state
@@ -1016,8 +1019,8 @@ class HistoryEncoder(_LookupFunction):
         # vectors per (sample, head) (csrc/encoder_last.hip)
         collapsed_last = (L > 0 and not _ENC_GENERIC and H <= 64 and D // heads <= 64
                           and bool(lib.tt_enc_last_supported(H, D, heads)) and x.data_ptr() % 16 == 0)
-        # ... and with it the second-to-last layer's out-projection (the last layer then reads that layer's CONTEXT)
-        collapse_prev = collapsed_last and L >= 2 and lib.tt_enc_last_supported(H, D, heads) >= 2
+        # ... run on the second-to-last layer's CONTEXT with composed weights (like every other layer boundary below)
+        fold_last = collapsed_last and L >= 2
         dh = D // max(heads, 1)
         if L > 0 and (H > 64 or dh not in (16, 32, 64) or D % 4):
             note_generic("history-encoder attention",
@@ -1039,20 +1042,22 @@ class HistoryEncoder(_LookupFunction):
                 probs = torch.empty(B, heads, H, dtype=torch.float32, device=dev)
                 xbar = torch.empty(B, heads, D, dtype=torch.float32, device=dev)
                 ctx0 = torch.empty(B, D, dtype=torch.float32, device=dev)
-                w_in_c, w_out_c = w_in.contiguous(), w_out.contiguous()
-                extra = []
-                w_pa = b_pa = None
-                if collapse_prev:  # x is the previous layer's CONTEXT; its out-projection folds into this layer
-                    w_pa, b_pa = layer_params[4 * (l - 1) + 2].contiguous(), layer_params[4 * (l - 1) + 3].contiguous()
-                    extra = [torch.empty(B, heads, D, dtype=torch.float32, device=dev),  # tp
-                             torch.empty(B, heads, D, dtype=torch.float32, device=dev),  # cbar
-                             torch.empty(B, D, dtype=torch.float32, device=dev)]         # x0
-                N.check(lib.tt_enc_last_fwd(x.data_ptr(), B, H, D, heads, w_in_c.data_ptr(), b_in.contiguous().data_ptr(),
-                                            w_out_c.data_ptr(), b_out.contiguous().data_ptr(), N.ptr(w_pa), N.ptr(b_pa),
-                                            out.data_ptr(), 2 * D, q0.data_ptr(), tq.data_ptr(), probs.data_ptr(),
-                                            xbar.data_ptr(), ctx0.data_ptr(), *(N.ptr(e) for e in (extra or [None] * 3)),
+                w_in_c, w_out_c, b_in_c = w_in.contiguous(), w_out.contiguous(), b_in.contiguous()
+                if fold_last:
+                    # x is the previous layer's CONTEXT c.  q, k, v of this layer are linear in x = c W_o^T + b_o, so the layer
+                    # runs on c with W_eff = W_in W_o, b_eff = W_in b_o + b_in -- the same kernels as for a first layer
+                    w_po, b_po = layer_params[4 * (l - 1) + 2], layer_params[4 * (l - 1) + 3]
+                    w_in_c = torch.empty(3 * D, D, dtype=torch.float32, device=dev)
+                    gemm(N.TT_GEMM_NN, w_in, w_po, w_in_c, 3 * D, D, D)
+                    b_eff = torch.empty(1, 3 * D, dtype=torch.float32, device=dev)
+                    gemm(N.TT_GEMM_NT, b_po.view(1, D), w_in, b_eff, 1, 3 * D, D, bias=b_in)
+                    b_in_c = b_eff.view(-1)
+                    folded_w[l] = w_in_c
+                N.check(lib.tt_enc_last_fwd(x.data_ptr(), B, H, D, heads, w_in_c.data_ptr(), b_in_c.data_ptr(),
+                                            w_out_c.data_ptr(), b_out.contiguous().data_ptr(), out.data_ptr(), 2 * D,
+                                            q0.data_ptr(), tq.data_ptr(), probs.data_ptr(), xbar.data_ptr(), ctx0.data_ptr(),
                                             N.stream()), "tt_enc_last_fwd")
-                saved += [x, q0, tq, probs, xbar, ctx0] + extra
+                saved += [x, q0, tq, probs, xbar, ctx0]
                 continue
             qkv = torch.empty(B * H, 3 * D, dtype=torch.float32, device=dev)
             if folded_in(l):
@@ -1070,7 +1075,7 @@ class HistoryEncoder(_LookupFunction):
                 gemm(N.TT_GEMM_NT, x, w_in, qkv, B * H, 3 * D, D, bias=b_in)
             ctx_t, lse = _attn_fwd(qkv, B, H, D, heads)
             saved += [x, qkv, ctx_t, lse]
-            if (l + 2 == L and collapse_prev) or folded_in(l + 1):
+            if (l + 2 == L and fold_last) or folded_in(l + 1):
                 x = ctx_t  # no out-projection here: the next layer takes the context (fold above / csrc/encoder_last.hip, PREV)
             elif l + 1 < L:
                 x = torch.empty(B * H, D, dtype=torch.float32, device=dev)
@@ -1081,7 +1086,6 @@ class HistoryEncoder(_LookupFunction):
             out[:, 0, :].copy_(x.view(B, H, D)[:, 0, :])
         ctx.dims = (B, H, D, L, heads)
         ctx.collapsed_last = collapsed_last
-        ctx.collapse_prev = collapse_prev
         ctx.folded = {l: w for l, w in folded_w.items()}  # layer -> its composed in-projection weight W_in W_o(prev)
         ctx.layer_leaves = tuple(layer_params)  # the Parameter objects themselves (see ops.run_on_side: `leaves`)
         if L > 0 and _caller_grad_mode[0] and any(ctx.needs_input_grad[4:]):  # (grad mode is always off in here: _recording)
@@ -1120,27 +1124,39 @@ class HistoryEncoder(_LookupFunction):
             w_in, b_in, w_out, b_out = layer_params[4 * l: 4 * l + 4]
             if l == L - 1 and ctx.collapsed_last:
                 x, q0, tq, probs, xbar, ctx0 = saved[4 * l: 4 * l + 6]
-                tp = cbar = x0 = w_pa = dW_pa = db_pa = None
-                if ctx.collapse_prev:
-                    tp, cbar, x0 = saved[4 * l + 6: 4 * l + 9]
-                    w_pa = layer_params[4 * (l - 1) + 2].contiguous()
-                    dW_pa = torch.empty(D, D, dtype=torch.float32, device=dev)
-                    db_pa = torch.empty(D, dtype=torch.float32, device=dev)
                 dx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
                 dW_in = torch.empty(3 * D, D, dtype=torch.float32, device=dev)
                 db_in = torch.empty(3 * D, dtype=torch.float32, device=dev)
                 dW_out = torch.empty(D, D, dtype=torch.float32, device=dev)
                 db_out = torch.empty(D, dtype=torch.float32, device=dev)
                 wsp, wsn = _ws(dev, lib.tt_enc_last_bwd_workspace_bytes(B, H, D, heads), "enc_last")
-                N.check(lib.tt_enc_last_bwd(x.data_ptr(), B, H, D, heads, w_in.contiguous().data_ptr(),
-                                            w_out.contiguous().data_ptr(), N.ptr(w_pa), d_recent.data_ptr(), 2 * D,
-                                            q0.data_ptr(), tq.data_ptr(), probs.data_ptr(), xbar.data_ptr(), ctx0.data_ptr(),
-                                            N.ptr(tp), N.ptr(cbar), N.ptr(x0), dx.data_ptr(), dW_in.data_ptr(),
-                                            db_in.data_ptr(), dW_out.data_ptr(), db_out.data_ptr(), N.ptr(dW_pa), N.ptr(db_pa),
+                w_used = ctx.folded.get(l, w_in)  # the composed W_in W_o(prev) when the forward ran on the previous layer's context
+                N.check(lib.tt_enc_last_bwd(x.data_ptr(), B, H, D, heads, w_used.contiguous().data_ptr(),
+                                            w_out.contiguous().data_ptr(), d_recent.data_ptr(), 2 * D, q0.data_ptr(),
+                                            tq.data_ptr(), probs.data_ptr(), xbar.data_ptr(), ctx0.data_ptr(), dx.data_ptr(),
+                                            dW_in.data_ptr(), db_in.data_ptr(), dW_out.data_ptr(), db_out.data_ptr(),
                                             wsp, wsn, N.stream()), "tt_enc_last_bwd")
+                if l in ctx.folded:
+                    # dW_in / db_in above are the gradients of (W_eff, b_eff): G and s.  Back to the two layers' own parameters
+                    # (the four small products of a composed boundary, see the full layers below):
+                    #   dW_in = G W_o^T + s (x) b_o     db_in = s     dW_o = W_in^T G     db_o = W_in^T s
+                    w_po, b_po = layer_params[4 * (l - 1) + 2], layer_params[4 * (l - 1) + 3]
+                    G, dW_in = dW_in, torch.empty(3 * D, D, dtype=torch.float32, device=dev)
+                    dW_po = torch.empty(D, D, dtype=torch.float32, device=dev)
+                    db_po = torch.empty(D, dtype=torch.float32, device=dev)
+
+                    def last_folded_weights(on_side, G=G, db_in=db_in, dW_in=dW_in, dW_po=dW_po, db_po=db_po, w_po=w_po, b_po=b_po,
+                                            w_in=w_in):
+                        slot = "ws_side_g" if on_side else "ws"
+                        gemm(N.TT_GEMM_NT, G, w_po, dW_in, 3 * D, D, D, slot=slot)
+                        gemm(N.TT_GEMM_NT, db_in.view(3 * D, 1), b_po.view(D, 1), dW_in, 3 * D, D, 1, accumulate=True, slot=slot)
+                        gemm(N.TT_GEMM_TN, w_in, G, dW_po, D, D, 3 * D, slot=slot)
+                        gemm(N.TT_GEMM_NN, db_in.view(1, 3 * D), w_in, db_po.view(1, D), 1, D, 3 * D, slot=slot)
+
+                    run_on_side(dev, last_folded_weights, hold=(G, w_po, b_po, w_in),
+                                leaves=[leaf_params[4 * l]] + list(leaf_params[4 * (l - 1) + 2: 4 * (l - 1) + 4]))
+                    prev_out_grads = (dW_po, db_po)  # dx is the gradient of the previous layer's CONTEXT
                 grads[4 * l: 4 * l + 4] = [dW_in, db_in, dW_out, db_out]
-                if ctx.collapse_prev:
-                    prev_out_grads = (dW_pa, db_pa)  # dx is then the gradient of the previous layer's CONTEXT
                 continue
             x, qkv, ctx_t, lse = saved[4 * l: 4 * l + 4]
             dW_out = torch.empty(D, D, dtype=torch.float32, device=dev)
