@@ -88,7 +88,7 @@ def _deferrable(t: Optional[torch.Tensor]) -> bool:
 
 
 def run_on_side(dev: torch.device, fn, hold: Sequence[Optional[torch.Tensor]] = (),
-                leaves: Sequence[Optional[torch.Tensor]] = (), again: bool = False) -> bool:
+                leaves: Sequence[Optional[torch.Tensor]] = ()) -> bool:
     """Run fn(True) on the third stream, after everything queued so far on the current one; -> False (and fn(False) runs in
     place, on the current stream -- `fn` picks its scratch slots by that flag: the two streams never share one) when side
     execution is off, the device is not a GPU, a graph is being captured, or no backward pass is running.
@@ -96,8 +96,7 @@ def run_on_side(dev: torch.device, fn, hold: Sequence[Optional[torch.Tensor]] = 
     gradient over as `.grad` without launching anything only if nobody else references it; a held output would be CLONED
     on the main stream, at once, before the side kernel has written it.  `leaves`: the tensors the gradients are for; the
     work is deferred only if each of them is `_deferrable` AND has not been deferred by another node of this backward pass
-    (a Parameter that feeds two Functions: autograd SUMS the two gradients on the main stream as soon as both exist).
-    `again`: a continuation of work this node already deferred for the same leaves (must stay behind it on the side stream)."""
+    (a Parameter that feeds two Functions: autograd SUMS the two gradients on the main stream as soon as both exist)."""
     if _SIDE_GRADS and dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
         fn(True)  # one stream while capturing: in line, on the side slots the eager warm-up steps have already sized
         return False
@@ -106,7 +105,7 @@ def run_on_side(dev: torch.device, fn, hold: Sequence[Optional[torch.Tensor]] = 
         return False
     st = _side_state
     for t in leaves:
-        if not _deferrable(t) or (not again and id(t) in st["leaves"]):
+        if not _deferrable(t) or id(t) in st["leaves"]:
             fn(False)
             return False
     if not st["armed"]:
@@ -965,6 +964,30 @@ class DebiasedWeightedLoss(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------- history encoder
+def fold_weights(w_in, b_in, w_po, b_po):
+    """(W_in W_o, W_in b_o + b_in): the in-projection of a layer that reads the previous layer's attention CONTEXT --
+    [3D, D] x [D, D], 12.6 MFLOP at D = 128, instead of a [B*H, D] x [D, D] out-projection (and its d_ctx / dW_out products
+    in the backward).  (One hand-written launch per direction was tried in round 5 and was 4x slower than these two small
+    library products: profiles/HISTORY.md.)"""
+    D = w_po.shape[0]
+    dev = w_in.device
+    w_eff = torch.empty(3 * D, D, dtype=torch.float32, device=dev)
+    gemm(N.TT_GEMM_NN, w_in, w_po, w_eff, 3 * D, D, D)
+    b_eff = torch.empty(1, 3 * D, dtype=torch.float32, device=dev)
+    gemm(N.TT_GEMM_NT, b_po.view(1, D), w_in, b_eff, 1, 3 * D, D, bias=b_in)
+    return w_eff, b_eff.view(-1)
+
+
+def fold_weight_grads(G, s, w_in, w_po, b_po, dW_in, dW_po, db_po) -> None:
+    """Gradients of a composed boundary (G = dL/dW_eff, s = dL/db_eff) back to the two layers' own parameters:
+    dW_in = G W_o^T + s (x) b_o,  dW_o = W_in^T G,  db_o = W_in^T s   (db_in = s)."""
+    D = w_po.shape[0]
+    gemm(N.TT_GEMM_NT, G, w_po, dW_in, 3 * D, D, D)
+    gemm(N.TT_GEMM_NT, s.view(3 * D, 1), b_po.view(D, 1), dW_in, 3 * D, D, 1, accumulate=True)
+    gemm(N.TT_GEMM_TN, w_in, G, dW_po, D, D, 3 * D)
+    gemm(N.TT_GEMM_NN, s.view(1, 3 * D), w_in, db_po.view(1, D), 1, D, 3 * D)
+
+
 def _attn_fwd(qkv, B, H, D, heads):
     ctx_t = torch.empty(B * H, D, dtype=torch.float32, device=qkv.device)
     lse = torch.empty(B, heads, H, dtype=torch.float32, device=qkv.device)
@@ -1047,11 +1070,7 @@ class HistoryEncoder(_LookupFunction):
                     # x is the previous layer's CONTEXT c.  q, k, v of this layer are linear in x = c W_o^T + b_o, so the layer
                     # runs on c with W_eff = W_in W_o, b_eff = W_in b_o + b_in -- the same kernels as for a first layer
                     w_po, b_po = layer_params[4 * (l - 1) + 2], layer_params[4 * (l - 1) + 3]
-                    w_in_c = torch.empty(3 * D, D, dtype=torch.float32, device=dev)
-                    gemm(N.TT_GEMM_NN, w_in, w_po, w_in_c, 3 * D, D, D)
-                    b_eff = torch.empty(1, 3 * D, dtype=torch.float32, device=dev)
-                    gemm(N.TT_GEMM_NT, b_po.view(1, D), w_in, b_eff, 1, 3 * D, D, bias=b_in)
-                    b_in_c = b_eff.view(-1)
+                    w_in_c, b_in_c = fold_weights(w_in, b_in, w_po, b_po)
                     folded_w[l] = w_in_c
                 N.check(lib.tt_enc_last_fwd(x.data_ptr(), B, H, D, heads, w_in_c.data_ptr(), b_in_c.data_ptr(),
                                             w_out_c.data_ptr(), b_out.contiguous().data_ptr(), out.data_ptr(), 2 * D,
@@ -1065,11 +1084,8 @@ class HistoryEncoder(_LookupFunction):
                 #   qkv = c (W_in W_o)^T + (W_in b_o + b_in)          ([3D, D] x [D, D]: 12.6 MFLOP instead of a [B*H, D] x [D, D]
                 # out-projection, and its d_ctx / dW_out products in the backward)
                 w_po, b_po = layer_params[4 * (l - 1) + 2], layer_params[4 * (l - 1) + 3]
-                w_eff = torch.empty(3 * D, D, dtype=torch.float32, device=dev)
-                gemm(N.TT_GEMM_NN, w_in, w_po, w_eff, 3 * D, D, D)
-                b_eff = torch.empty(1, 3 * D, dtype=torch.float32, device=dev)
-                gemm(N.TT_GEMM_NT, b_po.view(1, D), w_in, b_eff, 1, 3 * D, D, bias=b_in)
-                gemm(N.TT_GEMM_NT, x, w_eff, qkv, B * H, 3 * D, D, bias=b_eff.view(-1))
+                w_eff, b_eff = fold_weights(w_in, b_in, w_po, b_po)
+                gemm(N.TT_GEMM_NT, x, w_eff, qkv, B * H, 3 * D, D, bias=b_eff)
                 folded_w[l] = w_eff
             else:
                 gemm(N.TT_GEMM_NT, x, w_in, qkv, B * H, 3 * D, D, bias=b_in)
@@ -1109,7 +1125,10 @@ class HistoryEncoder(_LookupFunction):
         grads: List[Optional[torch.Tensor]] = [None] * (4 * L)
         dx = None  # gradient wrt the current layer's OUTPUT x_{l+1}, [B*H, D]
         prev_out_grads = None
-        tail_jobs = []  # (fn, ran on the side stream, hold, leaves): small weight-gradient products deferred to the end
+        # (fn, event of the side-stream product it consumes or None): the composed boundaries' small weight-gradient products.
+        # They run at the END of this backward, IN LINE on the main stream: by then the main stream has nothing left to do
+        # but wait for the side stream's streaming weight gradients, and the side stream has those still to run
+        tail_jobs = []
         pool_done = False
         leaf_params = ctx.layer_leaves
 
@@ -1147,14 +1166,11 @@ class HistoryEncoder(_LookupFunction):
 
                     def last_folded_weights(on_side, G=G, db_in=db_in, dW_in=dW_in, dW_po=dW_po, db_po=db_po, w_po=w_po, b_po=b_po,
                                             w_in=w_in):
-                        slot = "ws_side_g" if on_side else "ws"
-                        gemm(N.TT_GEMM_NT, G, w_po, dW_in, 3 * D, D, D, slot=slot)
-                        gemm(N.TT_GEMM_NT, db_in.view(3 * D, 1), b_po.view(D, 1), dW_in, 3 * D, D, 1, accumulate=True, slot=slot)
-                        gemm(N.TT_GEMM_TN, w_in, G, dW_po, D, D, 3 * D, slot=slot)
-                        gemm(N.TT_GEMM_NN, db_in.view(1, 3 * D), w_in, db_po.view(1, D), 1, D, 3 * D, slot=slot)
+                        fold_weight_grads(G, db_in, w_in, w_po, b_po, dW_in, dW_po, db_po)
 
-                    run_on_side(dev, last_folded_weights, hold=(G, w_po, b_po, w_in),
-                                leaves=[leaf_params[4 * l]] + list(leaf_params[4 * (l - 1) + 2: 4 * (l - 1) + 4]))
+                    # (issued here on the side stream, these four 10-us products sat behind the persistent attention-backward
+                    # workgroups for 0.45 ms and pushed the streaming weight gradients that much later)
+                    tail_jobs.append((last_folded_weights, None))
                     prev_out_grads = (dW_po, db_po)  # dx is the gradient of the previous layer's CONTEXT
                 grads[4 * l: 4 * l + 4] = [dW_in, db_in, dW_out, db_out]
                 continue
@@ -1192,11 +1208,7 @@ class HistoryEncoder(_LookupFunction):
                     gemm_tn_colsum(d_qkv, x, G, db=db_in, slot="ws_side_i" if on_side else "ws")
 
                 def folded_weights(on_side, G=G, db_in=db_in, dW_in=dW_in, dW_po=dW_po, db_po=db_po, w_po=w_po, b_po=b_po, w_in=w_in):
-                    slot = "ws_side_g" if on_side else "ws"
-                    gemm(N.TT_GEMM_NT, G, w_po, dW_in, 3 * D, D, D, slot=slot)
-                    gemm(N.TT_GEMM_NT, db_in.view(3 * D, 1), b_po.view(D, 1), dW_in, 3 * D, D, 1, accumulate=True, slot=slot)
-                    gemm(N.TT_GEMM_TN, w_in, G, dW_po, D, D, 3 * D, slot=slot)
-                    gemm(N.TT_GEMM_NN, db_in.view(1, 3 * D), w_in, db_po.view(1, D), 1, D, 3 * D, slot=slot)
+                    fold_weight_grads(G, db_in, w_in, w_po, b_po, dW_in, dW_po, db_po)
 
                 # the streaming product G is queued BEFORE the data-path product below (the side stream starts where the main
                 # one stands now); the four small products that turn G into weight gradients wait until the END of this
@@ -1207,7 +1219,11 @@ class HistoryEncoder(_LookupFunction):
                 hold_f = (d_qkv, x, G, w_po, b_po, w_in, w_eff)
                 leaves_f = list(leaf_params[4 * l: 4 * l + 2]) + list(leaf_params[4 * (l - 1) + 2: 4 * (l - 1) + 4])
                 aside = run_on_side(dev, folded_G, hold=hold_f, leaves=leaves_f)
-                tail_jobs.append((folded_weights, aside, hold_f, leaves_f))
+                g_done = None
+                if aside:  # G is written on the side stream: the tail job (main stream) waits for exactly that
+                    g_done = torch.cuda.Event()
+                    g_done.record(N.aux_stream(dev))
+                tail_jobs.append((folded_weights, g_done))
                 dx = torch.empty(B * H, D, dtype=torch.float32, device=dev)
                 gemm(N.TT_GEMM_NN, d_qkv, w_eff, dx, B * H, D, 3 * D)
                 prev_out_grads = (dW_po, db_po)
@@ -1225,11 +1241,10 @@ class HistoryEncoder(_LookupFunction):
                 else:
                     N.check(rc, "tt_hist_dx_pool_bwd")
             grads[4 * l: 4 * l + 4] = [dW_in, db_in, dW_out, db_out]
-        for fn, aside, hold_f, leaves_f in tail_jobs:
-            if aside:
-                run_on_side(dev, fn, hold=hold_f, leaves=leaves_f, again=True)
-            else:
-                fn(False)
+        for fn, g_done in tail_jobs:
+            if g_done is not None:
+                torch.cuda.current_stream().wait_event(g_done)
+            fn(False)
         if dx is None:  # L == 0: slot 0 is row 0 of (x + pe)
             dx = torch.zeros(B * H, D, dtype=torch.float32, device=dev)
             dx.view(B, H, D)[:, 0, :].copy_(d_recent)
