@@ -21,7 +21,7 @@ class _Ev:
 
 def _drive(step_ms_of, sweep_ms_of, lag, n_steps):
     """Run the controller for n_steps host steps; the GPU completes step k when the host is at step k + lag."""
-    me = types.SimpleNamespace(_tune_done=[], _tune_state=None, _host_steps=0, _sweep_wgs=0,
+    me = types.SimpleNamespace(_tune_done=[], _tune_state=None, _host_steps=0, _sweep_wgs=0, _sharded=[],
                                _SWEEP_LEVELS=DenseExactAdam._SWEEP_LEVELS, _SCAN_BLOCK=DenseExactAdam._SCAN_BLOCK,
                                _RESCAN_STEPS=DenseExactAdam._RESCAN_STEPS)
     me._lock_sweep = types.MethodType(DenseExactAdam._lock_sweep, me)
@@ -62,80 +62,83 @@ def test_rescan_after_the_interval():
     assert hist.count(128) == 2 * DenseExactAdam._SCAN_BLOCK and me._sweep_wgs == 512
 
 
-@pytest.mark.parametrize("lag", [0, 2, 25])
-def test_sharded_schedule_scan_runs_each_candidate_one_block_and_keeps_the_fastest(lag):
-    """sharded._ScheduleScan (where the sweep starts / how wide it runs in the row-sharded step) on stub events: the host
-    `lag` steps ahead of the GPU, every candidate exactly one block, the fastest kept from then on."""
-    from two_tower_models_amd.sharded import _ScheduleScan
-    ms = {(0, 256): 4.55, (2, 256): 4.35, (0, 0): 4.46}
-    clock = {"host": 0, "t": 0.0}
+def _drive_group(local_ms, sweep_ms, n_steps, monkeypatch):
+    """Two simulated ranks of a row-sharded group run DenseExactAdam._tune_sweep_group in lockstep (one thread each; the
+    all-reduce is a barrier + a shared mailbox).  local_ms[r][level] = rank r's step time at that sweep level."""
+    import threading
 
-    class Ev:
-        def record(self):
-            self.step, self.t = clock["host"], clock["t"]
+    import torch
+    import torch.distributed as dist
 
-        def query(self):
-            return clock["host"] >= self.step + lag
+    from two_tower_models_amd import collectives
 
-        def elapsed_time(self, other):
-            return other.t - self.t
+    world = len(local_ms)
+    barrier, mailbox = threading.Barrier(world), {}
+    rank_of = threading.local()
 
-    scan = _ScheduleScan(list(ms), block=4, skip_first=3, new_event=Ev)
-    hist = []
-    for _ in range(80):
-        cand = scan.begin()
-        clock["t"] += ms[cand]  # the step's duration on the GPU's clock
-        scan.end()
-        clock["host"] += 1
-        hist.append(cand)
-    assert scan.best == (2, 256) and all(c == (2, 256) for c in hist[-30:])
-    assert hist[:3] == [(0, 256)] * 3 and hist[3:15] == [(0, 256)] * 4 + [(2, 256)] * 4 + [(0, 0)] * 4
+    def fake_all_reduce(t, op=None):
+        mailbox[rank_of.r] = t.clone()
+        barrier.wait()
+        stacked = torch.stack([mailbox[r] for r in range(world)])
+        out = stacked.min(0).values if op == dist.ReduceOp.MIN else stacked.max(0).values
+        barrier.wait()
+        t.copy_(out)
+        return t
+
+    monkeypatch.setattr(collectives, "all_reduce_", fake_all_reduce)
+    hist, mes, errors = [[] for _ in range(world)], [None] * world, []
+
+    def run(r):
+        try:
+            rank_of.r = r
+            me = types.SimpleNamespace(_tune_done=[], _tune_state=None, _host_steps=0, _sweep_wgs=0,
+                                       _hyper=types.SimpleNamespace(device="cpu"),
+                                       _SWEEP_LEVELS=DenseExactAdam._SWEEP_LEVELS, _SCAN_BLOCK=DenseExactAdam._SCAN_BLOCK,
+                                       _RESCAN_STEPS=DenseExactAdam._RESCAN_STEPS)
+            me._lock_sweep = types.MethodType(DenseExactAdam._lock_sweep, me)
+            tune = types.MethodType(DenseExactAdam._tune_sweep_group, me)
+            mes[r] = me
+            for _ in range(n_steps):
+                tune()
+                me._host_steps += 1
+                lv = me._sweep_wgs
+                ev = lambda t: types.SimpleNamespace(t=t, synchronize=lambda: None, elapsed_time=lambda other, t=t: other.t - t)
+                me._tune_done.append([ev(0.0), ev(0.0), ev(sweep_ms), ev(local_ms[r][lv]), lv, me._host_steps])
+                hist[r].append(lv)
+        except Exception as e:  # a dead thread must not leave the other one waiting on the barrier
+            errors.append(e)
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    assert not errors, errors
+    return mes, hist
 
 
-def test_sharded_schedule_scan_group_decision_is_identical_on_every_rank():
-    """With a group reduction the schedule is chosen ONCE for the group, at the same step on every rank (ADVICE r3:
-    ranks locking different schedules on local timing noise): two simulated ranks whose local measurements favour
-    different candidates both end up on the candidate whose WORST rank is fastest, and switch at the same step."""
-    from two_tower_models_amd.sharded import _ScheduleScan
-    cands = [(0, 256), (2, 256), (0, 0)]
-    local_ms = [{(0, 256): 4.40, (2, 256): 4.45, (0, 0): 4.60},   # rank 0 would pick (0, 256)
-                {(0, 256): 4.70, (2, 256): 4.42, (0, 0): 4.50}]   # rank 1 would pick (2, 256); group: max -> (2, 256)
-    clocks = [{"t": 0.0}, {"t": 0.0}]
+def test_group_tuner_takes_the_level_whose_worst_rank_is_fastest_at_the_same_step_on_every_rank(monkeypatch):
+    """Row-sharded group (optim.py::_tune_sweep_group): the sweep level is chosen ONCE for the group, at a step number
+    every rank reaches (ranks locking different levels on local timing noise drag each other).  Two ranks whose
+    local measurements favour different levels end on the level whose MAX over ranks is smallest, and hold the same level
+    at every step, including the step the decision lands on."""
+    local_ms = [{0: 4.40, 640: 4.38, 512: 4.20, 384: 4.45, 256: 4.60, 128: 5.0},   # rank 0 alone would take 512
+                {0: 4.50, 640: 4.45, 512: 4.70, 384: 4.30, 256: 4.40, 128: 5.2}]   # rank 1 alone 384; group (max): 640
+    mes, hist = _drive_group(local_ms, 1.2, 120, monkeypatch)
+    assert hist[0] == hist[1]
+    assert mes[0]._sweep_wgs == mes[1]._sweep_wgs == 640
+    assert mes[0]._tune_state["phase"] == "locked" and "group" in mes[0]._tune_state["why"]
+    for lv in (512, 384, 256, 128):  # every level exactly one block while scanning
+        assert hist[0].count(lv) == DenseExactAdam._SCAN_BLOCK
 
-    def make_ev(r):
-        class Ev:
-            def record(self):
-                self.t = clocks[r]["t"]
 
-            def query(self):
-                return True
-
-            def synchronize(self):
-                pass
-
-            def elapsed_time(self, other):
-                return other.t - self.t
-        return Ev
-
-    mailbox = {}
-
-    def group_max_for(r):
-        def f(values):  # both ranks call in lockstep: rank 0 posts, rank 1 completes -- simulated with a shared dict
-            mailbox[r] = list(values)
-            return [max(a, b) for a, b in zip(mailbox.get(0, values), mailbox.get(1, values))]
-        return f
-
-    scans = [_ScheduleScan(cands, block=4, skip_first=3, new_event=make_ev(r), group_max=None) for r in range(2)]
-    # pre-compute what each rank will report, so the simulated all-reduce can return the true max to both
-    for r in range(2):
-        scans[r]._group_max = lambda values, r=r: [max(local_ms[0][c], local_ms[1][c]) for c in cands]
-    hist = [[], []]
-    for _ in range(40):
-        for r in range(2):
-            c = scans[r].begin()
-            clocks[r]["t"] += local_ms[r][c]
-            scans[r].end()
-            hist[r].append(c)
-    assert scans[0].best == scans[1].best == (2, 256)
-    assert hist[0] == hist[1]  # same candidate at every step, including the step the decision lands on
-    assert "group" in scans[0].decided_by
+def test_group_tuner_keeps_full_width_only_if_the_sweep_is_the_step_on_every_rank(monkeypatch):
+    sweep = 5.0
+    bound = {lv: 5.3 for lv in DenseExactAdam._SWEEP_LEVELS}
+    mes, hist = _drive_group([bound, bound], sweep, 40, monkeypatch)
+    assert set(hist[0]) == {0} and mes[0]._tune_state["phase"] == "locked"
+    # one rank whose step is much longer than its sweep: the group scans
+    chain = {0: 7.0, 640: 6.9, 512: 6.5, 384: 6.6, 256: 6.8, 128: 7.5}
+    mes, hist = _drive_group([bound, chain], sweep, 120, monkeypatch)
+    assert hist[0] == hist[1] and mes[0]._sweep_wgs == 512
