@@ -7,7 +7,12 @@ elements are rounding noise around zero, Adam's first steps turn their SIGN into
 -- the CPU port run as 2 ranks included -- then differ in tens of elements per tensor and by 1e-4 in the next loss.
 Three or more item features, for a related reason: with one or two, many units of the item MLP's first layer are active
 for EVERY sample of the batch, and for those the bias gradient is analytically zero (the in-batch softmax is invariant to
-a common shift of the item embeddings) -- noise again.
+a common shift of the item embeddings) -- noise again (round 5, seed 1: F = 3 still produced two such findings, 3-4 of 256
+elements of item_features_arch.0.bias, in 114 cases; from 4 features on none).  History length 2 or more, for the same
+reason: with ONE key the attention weights are 1 whatever Q and K are, so the gradients of the Q / K projection weights
+are analytically zero -- exactly zero in the oracle's order of operations, rounding noise (1e-12) in the kernels', and
+Adam turns the noise into steps of up to lr (one finding: 780 of 49152 in_proj_weight elements off by 1.5e-5, all in the
+Q / K rows, which cannot influence any output).
     python tools/fuzz_sharded.py [seconds] [seed]"""
 import json
 import os
@@ -30,8 +35,8 @@ if __name__ == "__main__":
         hist = kind != "base"
         cfg = dict(n_users=int(rng.integers(3, 700)), n_items=int(rng.integers(3, 700)),
                    D=int(rng.choice([32, 64, 128])) if hist else int(rng.choice([8, 24, 40, 64, 128, 160])),
-                   F=int(rng.integers(3, 24)), B=int(rng.choice([8, 16, 33, 64, 100])),
-                   H=int(rng.choice([1, 4, 9, 50])) if hist else 2)
+                   F=int(rng.integers(4, 24)), B=int(rng.choice([8, 16, 33, 64, 100])),
+                   H=int(rng.choice([2, 4, 9, 50])) if hist else 2)
         world = int(rng.choice([2, 3, 4]))
         what = f"case {n}: W={world} {kind} {cfg}"
         try:

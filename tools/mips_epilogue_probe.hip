@@ -4,6 +4,8 @@
 //   L  the A operand comes from LDS (one ds_read_b128 per k-group, issued one k-group ahead, explicit lgkmcnt waits)
 //   B  one workgroup barrier per tile
 //   D  the tile ring is filled by LDS-DMA from a global buffer (4 buffer_load ... lds per wave and tile, 3 tiles ahead)
+//   G  (instead of L / B / D) no LDS at all: every wave loads its A operand straight from global memory into registers,
+//      8 x global_load_dwordx4 per 32-row sub-tile, one sub-tile ahead (the four waves of a workgroup read the same rows)
 // Epilogue variants: 0 = none, 1 = max only (v_max3, 0.5 / score), 2 = best + runner-up + best QUAD (1.75 / score,
 // the product kernel), 3 = best + runner-up + best ROW (4 / score, the round-1/2 kernel).
 // Random bf16 operands (the clock the chip sustains depends on the data: MI355X_MICROARCH.md, DVFS).
@@ -22,7 +24,7 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 
 constexpr int NQ = 4, DPX = 8, STAGES = 4, TILE_BYTES = 64 * 256;
 
-template <int V, bool L, bool B, bool D>
+template <int V, bool L, bool B, bool D, bool G = false>
 __global__ __launch_bounds__(256, 2) void spin(float* out, const uint4* __restrict__ qsrc, const char* __restrict__ corpus,
                                                int64_t corpus_tiles, int iters) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -62,6 +64,13 @@ __global__ __launch_bounds__(256, 2) void spin(float* out, const uint4* __restri
     __syncthreads();
   }
   int cur = 0;
+  u32x4 ga[2][DPX];
+  auto gload = [&](u32x4 (&dst)[DPX], int64_t tl, int jt) {
+    const char* base = corpus + tl * TILE_BYTES + (jt * 32 + r) * 256 + h * 16;
+#pragma unroll
+    for (int g = 0; g < DPX; ++g) dst[g] = *reinterpret_cast<const u32x4*>(base + g * 32);
+  };
+  if (G) gload(ga[0], tile, 0);
   for (int i = 0; i < iters; ++i) {
     dma((cur + STAGES - 1) % STAGES);
     const char* ys = smem + cur * TILE_BYTES;
@@ -72,7 +81,19 @@ __global__ __launch_bounds__(256, 2) void spin(float* out, const uint4* __restri
       for (int n = 0; n < NQ; ++n)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
-      if (L) {
+      if (G) {
+        if (jt == 0) {
+          gload(ga[1], tile, 1);
+        } else {
+          tile = tile + 1 < corpus_tiles ? tile + 1 : 0;
+          gload(ga[0], tile, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < DPX; ++g)
+#pragma unroll
+          for (int n = 0; n < NQ; ++n)
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ga[jt][g]), __builtin_bit_cast(bf16x8, q[n][g]), acc[n], 0, 0, 0);
+      } else if (L) {
         const int row = jt * 32 + r;
         const uint32_t lrow = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)ys + (uint32_t)row * 256;
         const int sw = row & 15;
@@ -148,10 +169,10 @@ static uint4* g_q;
 static char* g_corpus;
 static int64_t g_tiles;
 
-template <int V, bool L, bool B, bool D>
+template <int V, bool L, bool B, bool D, bool G = false>
 static void run(const char* what) {
   const int blocks = 256 * 2 * 4, iters = 600;
-  auto k = spin<V, L, B, D>;
+  auto k = spin<V, L, B, D, G>;
   hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * TILE_BYTES);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -164,7 +185,7 @@ static void run(const char* what) {
   float ms;
   (void)hipEventElapsedTime(&ms, e0, e1);
   const double flops = (double)blocks * 4 * iters * 2 * 8 * 4 * (2.0 * 32 * 32 * 16);
-  printf("%-26s LDS=%d barrier=%d DMA=%d  %7.3f ms  %7.1f TFLOP/s\n", what, (int)L, (int)B, (int)D, ms, flops / ms / 1e9);
+  printf("%-26s LDS=%d barrier=%d DMA=%d global->VGPR=%d  %7.3f ms  %7.1f TFLOP/s\n", what, (int)L, (int)B, (int)D, (int)G, ms, flops / ms / 1e9);
 }
 
 template <int V>
@@ -173,6 +194,7 @@ static void run_all(const char* what) {
   run<V, true, false, false>(what);
   run<V, true, true, false>(what);
   run<V, true, true, true>(what);
+  run<V, false, false, false, true>(what);
 }
 
 int main() {
