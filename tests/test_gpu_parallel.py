@@ -228,7 +228,8 @@ def check_against_oracle(case, res, world, outlier_frac=2e-3):
             # zero true gradient, noise only: the item-side biases and the key third of every in_proj_bias
             noise_only = name in ("item_tower_arch.bias", "item_features_arch.2.bias") or name.endswith("in_proj_bias")
             if not noise_only and int((err > 5e-6).sum()) > max(2, int(outlier_frac * err.numel())):
-                bad.append((name, r, int((err > 5e-6).sum()), err.numel(), float(err.max())))
+                rows = (err.reshape(err.shape[0], -1) > 5e-6).any(1).nonzero().flatten()  # first and last offending row
+                bad.append((name, r, int((err > 5e-6).sum()), err.numel(), float(err.max()), (int(rows[0]), int(rows[-1]))))
         # replicas stay bit-identical, and every rank assembled the same whole tables
         assert all(torch.equal(v, res[0]["sd"][k]) for k, v in res[r]["sd"].items())
     assert not bad, bad
