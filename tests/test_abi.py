@@ -117,3 +117,19 @@ def test_reference_package_name_resolves_to_this_implementation():
     assert TwoTowerBaseRetrieval is A.TwoTowerBaseRetrieval and BaselineMIPSModule is A.BaselineMIPSModule
     assert TwoTowerWithDebiasing is A.TwoTowerWithDebiasing and UserHistoryEncoder is A.UserHistoryEncoder
     assert TwoTowerWithUserHistoryEncoder is A.TwoTowerWithUserHistoryEncoder
+
+
+def test_mips_corpus_assignment_drops_the_split_fp16_copy():
+    """the split-fp16 copy belongs to ONE corpus tensor; a key of (pointer, version, shape) cannot tell a
+    re-allocated corpus at the same address from the old one, so every assignment of `corpus` invalidates it."""
+    import torch
+
+    from two_tower_models_amd.baseline_mips_module import BaselineMIPSModule
+    m = BaselineMIPSModule(16, 128)
+    assert m.state_dict() == {} and tuple(m.corpus.shape) == (16, 128)  # still a plain tensor attribute (ref :29-30)
+    for assign in (lambda: setattr(m, "corpus", torch.zeros(16, 128)), lambda: m.set_corpus(torch.ones(8, 128)),
+                   lambda: m.use_bf16_storage(), lambda: m.to(torch.device("cpu"))):
+        m._split16, m._split16_key = object(), ("stale",)
+        assign()
+        assert m._split16 is None and m._split16_key is None
+    assert m.corpus.dtype == torch.bfloat16 and m.corpus_size == 8

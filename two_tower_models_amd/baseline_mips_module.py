@@ -27,6 +27,20 @@ class BaselineMIPSModule(nn.Module):
         # random corpus, plain tensor (not a Parameter / buffer: empty state_dict), ref :29-30
         self.corpus = torch.randn(corpus_size, embedding_dim)  # [C, DI]
 
+    # `corpus` is a property only so that EVERY assignment -- set_corpus, use_bf16_storage, .to(), a caller's own
+    # `module.corpus = ...` -- drops the split-fp16 copy derived from the previous one (a corpus freed and
+    # re-allocated at the same address has the same (pointer, version, shape) key).  Writes INTO the tensor through raw
+    # pointers cannot be seen here: call use_split_fp16_scoring() again after those, as its docstring says.
+    @property
+    def corpus(self) -> torch.Tensor:
+        return self._corpus
+
+    @corpus.setter
+    def corpus(self, value: torch.Tensor) -> None:
+        object.__setattr__(self, "_corpus", value)
+        object.__setattr__(self, "_split16", None)
+        object.__setattr__(self, "_split16_key", None)
+
     def _apply(self, fn, *a, **kw):
         super()._apply(fn, *a, **kw)
         moved = fn(self.corpus)
