@@ -336,6 +336,48 @@ def test_side_stream_weight_gradients_equal_inline_ones(golden):
             assert torch.equal(got2[n], want2[n]), (n, "shared")
 
 
+@pytest.mark.parametrize("kind,name", [("base", "g2_base_aligned"), ("hist", "g4_hist_d128")])
+@pytest.mark.parametrize("schedule", ["forward", "zero_grad", "serial", "lazy", "torch"])
+def test_item_tower_on_the_third_stream_is_bit_identical_to_one_stream(golden, monkeypatch, kind, name, schedule):
+    """ops.AuxFork: the item tower's forward and (by autograd's stream rule) backward kernels run on the third stream next
+    to the user tower's.  Same kernels, same operands -- so three steps end in the same bits as with one stream, under
+    every optimiser schedule; the history model looks up the ITEM table from both towers (deferred schedule: the two
+    catch-ups of one table are ordered, optim.py::_catch_up).  Repeated: a race would not show every time."""
+    import two_tower_models_amd as A
+    from two_tower_models_amd import ops
+    g = golden(name)
+    b = batch_of(g)
+    monkeypatch.setattr(ops, "_FORK_MIN_ROWS", 1)
+
+    def run(concurrent):
+        monkeypatch.setattr(ops, "_CONCURRENT_TOWERS", concurrent)
+        model = make_model(kind, g)
+        if schedule == "torch":
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        else:
+            kw = dict(forward=dict(overlap_sweep="forward"), zero_grad=dict(overlap_sweep=True), serial=dict(overlap_sweep=False),
+                      lazy=dict(overlap_sweep=False, lazy=True))[schedule]
+            opt = A.DenseExactAdam(model.parameters(), lr=1e-3, **kw)
+        losses = []
+        for _ in range(3):
+            loss = model.train_forward(*b)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+        if schedule == "lazy":
+            opt.flush()
+        torch.cuda.synchronize()
+        return losses, {k: v.clone() for k, v in model.state_dict().items()}
+
+    want_l, want = run(False)
+    for _ in range(3):
+        got_l, got = run(True)
+        assert all(torch.equal(a, c) for a, c in zip(got_l, want_l))
+        for k in want:
+            assert torch.equal(got[k], want[k]), k
+
+
 @pytest.mark.parametrize("name", ["g4_hist_d128", "g4_hist_tiny"])
 def test_history_model_matches_reference(golden, name):
     g = golden(name)

@@ -35,8 +35,95 @@ def _rowmajor(t: torch.Tensor) -> torch.Tensor:
 def _ws(dev: torch.device, nbytes: int, slot: str = "ws") -> Tuple[Optional[int], int]:
     if nbytes <= 0:
         return None, 0
+    if _aux_forks[0] and dev.type == "cuda" and torch.cuda.current_stream(dev) == N.aux_stream(dev):
+        slot += "@aux"  # work forked to the third stream (AuxFork) runs NEXT TO the main stream's: its own scratch
     buf = N.scratch.get(dev, nbytes, slot)
     return buf.data_ptr(), buf.numel()
+
+
+# ----------------------------------------------------------------- two independent chains, two streams
+# The user tower and the item tower of a step share nothing until the logits kernel, and at the 1 M-row shapes each of
+# their kernels is a few hundred small workgroups that leave most of the chip idle (tower_fwd_kernel at B = 8192: 1.1 GFLOP
+# in 56 us).  AuxFork runs one of the two chains on the library's third stream: forward kernels there, and -- autograd
+# runs a node's backward on the stream its forward ran on, and orders gradients that cross streams itself -- their
+# backward kernels too.  Memory: a tensor allocated on one stream and read on the other is safe because every use of the
+# third stream starts by waiting for the main one (here, run_on_side, the plan sorts), autograd records cross-stream
+# gradients with the allocator, and `.backward()` returns with the caller's stream ordered after both (AuxFork.joined).
+# Measured (one process, alternating blocks, tools/ab_c3.py): C2 1.12 -> 1.09 ms, history model +-0, deferred P-shape step
+# 1.36 -> 1.30 ms.  TT_TOWERS_SERIAL=1: one stream (A/B).
+_CONCURRENT_TOWERS = os.environ.get("TT_TOWERS_SERIAL") is None
+_FORK_MIN_ROWS = 2048  # (tests lower it: the golden batches are small)
+_aux_forks = [0]  # 1 from a fork point to the end of that step's backward pass (0: _ws and the deferred optimiser skip their
+                  # per-stream bookkeeping -- a few current-stream queries per launch, 0.15 ms per step at host-bound shapes)
+
+
+class AuxFork:
+    """fork = AuxFork(dev) marks the point on the current stream that the forked chain depends on; `with fork:` enqueues
+    the chain on the third stream and, on exit, makes the current stream wait for it -- whatever was enqueued on the
+    current stream between the two runs next to the chain."""
+
+    def __init__(self, dev: torch.device, rows: int = 1 << 30):
+        # `rows`: the chain's batch size.  A fork costs the host ~0.2 ms per step (events, stream switches, autograd's
+        # cross-stream bookkeeping): at the reference's default shapes (B = 256: 0.55 ms per step, host-bound) that is a
+        # loss, from a few thousand rows on the kernels are long enough.  Not inside a hipGraph capture: the capture
+        # works (tests), but a replayed graph with two branches is SLOWER on this runtime than the one-stream graph
+        # (P-shape deferred step: 1.99 vs 1.13 ms) -- hipGraphLaunch pays for every cross-branch edge.
+        self.on = _CONCURRENT_TOWERS and dev.type == "cuda" and rows >= _FORK_MIN_ROWS and not torch.cuda.is_current_stream_capturing()
+        if self.on:
+            _aux_forks[0] = 1
+            self.main, self.aux = torch.cuda.current_stream(dev), N.aux_stream(dev)
+            self.at = torch.cuda.Event()
+            self.at.record(self.main)
+
+    def __enter__(self):
+        if self.on:
+            self.aux.wait_event(self.at)
+            self.ctx = torch.cuda.stream(self.aux)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+            done = torch.cuda.Event()
+            done.record(self.aux)
+            self.main.wait_event(done)
+        return False
+
+    def joined(self, out: torch.Tensor) -> torch.Tensor:
+        """The chain's result as the rest of the forward should see it: the same values; in the backward pass the first
+        node of the chain, which arms the join of the third stream at the END of the backward pass.  (Autograd orders
+        what it knows about -- gradients that cross streams, leaf accumulations -- but a backward function that hands row
+        gradients to the optimiser's list launches nothing autograd could order the caller's stream behind.)"""
+        return _JoinAuxAfterBackward.apply(out) if self.on and out.requires_grad else out
+
+
+def _join_aux(dev: torch.device) -> None:
+    cur, aux = torch.cuda.current_stream(dev), N.aux_stream(dev)
+    if cur == aux:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        with torch.cuda.stream(aux):
+            forked = torch.cuda.is_current_stream_capturing()
+        if not forked:  # nothing of this capture is outstanding there (and a capturing stream may not wait for an outside event)
+            return
+    cur.wait_stream(aux)
+
+
+class _JoinAuxAfterBackward(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: torch.Tensor) -> torch.Tensor:
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g: torch.Tensor):
+        dev = g.device
+        def done():
+            _join_aux(dev)
+            _aux_forks[0] = 0
+
+        torch.autograd.Variable._execution_engine.queue_callback(done)
+        return g
 
 
 # ----------------------------------------------------------------- "a fast path was not taken"

@@ -145,6 +145,7 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._begun: Optional[Dict[torch.nn.Parameter, _TableStep]] = None
         self._sweep_done: Optional[torch.cuda.Event] = None
         self._side_bufs: Dict[int, torch.Tensor] = {}
+        self._catchup_last: Dict[int, tuple] = {}  # deferred schedule: table -> (event, stream) of its latest catch-up this step
 
     # state is created lazily, on the parameters' device
     def _init_state(self) -> None:
@@ -176,9 +177,15 @@ class DenseExactAdam(torch.optim.Optimizer):
         """Rows `ids` of table `p` -> current step (called by the lookups before they read)."""
         if not self._ready or self._host_steps == 0 or not p.is_cuda or ids.numel() == 0:
             return  # nothing has been deferred yet (fresh, or just loaded from a flushed checkpoint)
-        if self._prefetch_done is not None:  # never replay a row on two streams at once
-            torch.cuda.current_stream().wait_event(self._prefetch_done)
-            self._prefetch_done, self._prefetch_keep = None, None
+        cur = torch.cuda.current_stream()
+        if self._prefetch_done is not None:  # never replay a row on two streams at once (step() drops the event: a forward
+            cur.wait_event(self._prefetch_done)  # whose towers run on two streams waits on both)
+        if ops._aux_forks[0]:
+            # ... nor by two towers that look up the SAME table from different streams (ops.AuxFork: the history model's
+            # user tower and its item tower both read the item table): per table, a catch-up waits for the previous one
+            prev = self._catchup_last.get(id(p))
+            if prev is not None and prev[1] != cur:
+                cur.wait_event(prev[0])
         ids = ids.reshape(-1)
         if ids.dtype != torch.int64 or not ids.is_contiguous():
             ids = ids.to(torch.int64).contiguous()
@@ -188,6 +195,10 @@ class DenseExactAdam(torch.optim.Optimizer):
                                               self._last_step[id(p)].data_ptr(), self._hyper.data_ptr(),
                                               self._tab.data_ptr(), self._tab_steps, N.stream()),
                 "tt_adam_rows_catchup")
+        if ops._aux_forks[0]:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._catchup_last[id(p)] = (ev, cur)
 
     @torch.no_grad()
     def prefetch_rows(self, lookups: Dict[torch.nn.Parameter, Sequence[torch.Tensor]]) -> None:
@@ -701,6 +712,7 @@ class DenseExactAdam(torch.optim.Optimizer):
             if self._prefetch_done is not None:  # rows being replayed for a later batch: finish first
                 torch.cuda.current_stream().wait_event(self._prefetch_done)
                 self._prefetch_done, self._prefetch_keep = None, None
+            self._catchup_last.clear()
             self._advance_lazy()
             for p in self._tables:
                 blocks = p._tt_rowgrads

@@ -278,8 +278,13 @@ class TwoTowerBaseRetrieval(nn.Module):
             self._tt_item_gather = (item_embeddings, parallel.start_all_gather(item_embeddings))
             user_embedding = self.compute_user_embedding(user_id, user_features, user_history)
         else:
+            # the towers share nothing until the logits: the item tower's kernels (forward here, backward by autograd's
+            # stream rule) go to the third stream and run NEXT TO the user tower's (ops.AuxFork)
+            fork = ops.AuxFork(user_id.device, rows=user_id.numel())
             user_embedding = self.compute_user_embedding(user_id, user_features, user_history)
-            item_embeddings = self.compute_item_embeddings(item_id, item_features)
+            with fork:
+                item_embeddings = self.compute_item_embeddings(item_id, item_features)
+            item_embeddings = fork.joined(item_embeddings)
         return self.compute_training_loss(
             user_embedding=user_embedding, item_embeddings=item_embeddings, position=position, labels=labels
         )
