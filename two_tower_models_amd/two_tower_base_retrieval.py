@@ -280,7 +280,12 @@ class TwoTowerBaseRetrieval(nn.Module):
         else:
             # the towers share nothing until the logits: the item tower's kernels (forward here, backward by autograd's
             # stream rule) go to the third stream and run NEXT TO the user tower's (ops.AuxFork)
-            fork = ops.AuxFork(user_id.device, rows=user_id.numel())
+            # (the tuned shapes only: there the item tower is one forward and three backward kernels; the generic forms --
+            # any width, a dozen library launches -- stay on one stream)
+            mlp = self.item_features_arch
+            tuned = item_features.is_cuda and ops.fused_tower_supported(
+                self.item_id_embedding_arch.weight, item_features, mlp[0].weight, mlp[2].weight, self.item_tower_arch.weight)
+            fork = ops.AuxFork(user_id.device, rows=user_id.numel() if tuned else 0)
             user_embedding = self.compute_user_embedding(user_id, user_features, user_history)
             with fork:
                 item_embeddings = self.compute_item_embeddings(item_id, item_features)
