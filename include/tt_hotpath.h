@@ -504,6 +504,17 @@ int tt_enc_last_bwd(const float* x, int64_t B, int64_t H, int64_t D, int64_t hea
                     const float* w_out, const float* d_recent, int64_t ld_dr, const float* q0, const float* t,
                     const float* probs, const float* xbar, const float* ctx0, float* dx, float* dW_in, float* db_in,
                     float* dW_out, float* db_out, void* ws, int64_t ws_bytes, tt_stream_t stream);
+/* tt_enc_last_bwd in two halves sharing ONE workspace (same size; it must stay untouched between the two calls):
+ *   _data     dx (everything the rest of the backward pass waits for)
+ *   _weights  dW_in, db_in, dW_out, db_out from what _data left in the workspace -- feeds nothing but the optimiser, so a
+ *             caller may enqueue it on another stream, behind _data
+ * tt_enc_last_bwd = the two in a row on one stream; bit-identical results either way. */
+int tt_enc_last_bwd_data(const float* x, int64_t B, int64_t H, int64_t D, int64_t heads, const float* w_in,
+                         const float* w_out, const float* d_recent, int64_t ld_dr, const float* t, const float* probs,
+                         float* dx, void* ws, int64_t ws_bytes, tt_stream_t stream);
+int tt_enc_last_bwd_weights(const float* x, int64_t B, int64_t H, int64_t D, int64_t heads, const float* d_recent,
+                            int64_t ld_dr, const float* q0, const float* xbar, const float* ctx0, float* dW_in, float* db_in,
+                            float* dW_out, float* db_out, void* ws, int64_t ws_bytes, tt_stream_t stream);
 
 /* ---------------------------------------------------------------- R1 owner routing (row-sharded tables)
  * New design -- the reference has no parallelism.  Tables are split into `world`

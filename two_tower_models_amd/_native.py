@@ -150,6 +150,8 @@ SIGNATURES = {
     "tt_enc_last_bwd_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "tt_enc_last_bwd": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _i64, _vp]),
+    "tt_enc_last_bwd_data": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "tt_enc_last_bwd_weights": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tt_route_workspace_bytes": (_i64, [_i64, _i32]),
     "tt_route_count": (_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tt_route_build": (_int, [_vp, _i64, _i64, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),

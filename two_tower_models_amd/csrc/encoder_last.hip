@@ -16,8 +16,11 @@
 // score of a head by the same amount; autograd produces rounding noise there).
 //
 // Launches: forward  enc_last_pre (q0, t) -> enc_last_main_fwd (probs, xbar) -> enc_last_post (ctx0, recent)
-//           backward enc_last_bwd_a (d_xbar; dW_out, dW_v partials) -> enc_last_main_bwd (dt, dX)
-//                    -> enc_last_bwd_b (dX[0] += W_q^T dq0; dW_k, dW_q partials) -> enc_last_reduce
+//           backward, data path     enc_last_bwd_a (d_ctx0, d_xbar) -> enc_last_main_bwd (dt, dX)
+//                                   -> enc_last_bwd_b (dq0; dX[0] += W_q^T dq0)
+//           backward, weights       enc_last_wgrad (dW_out, dW_v | dW_q, dW_k partials) -> enc_last_reduce
+//           (tt_enc_last_bwd_data / _weights: the weight half feeds nothing but the optimiser, so the caller may
+//           run it on another stream -- it used to be the tail of kernels a and b, on the step's critical path)
 // pre / post / a / b take 32 samples per workgroup and run their [32, D] x [D, D] products (and the
 // per-head [32, dh] x [dh, D] ones) on the matrix cores, operands straight from global memory /
 // L2 (the weights are 64 KB each) and a [32, D] LDS image for the intermediate that feeds the
@@ -149,6 +152,8 @@ struct ElArgs {
   float* ctx0;   // [B, D]
   float* recent; int64_t ld_recent;            // forward output [B, D]
   const float* d_recent; int64_t ld_dr;        // backward input
+  float* d_ctx0;  // backward scratch [B, D]: kernel a's first product, read again by the weight kernel
+  float* dq0;     // backward scratch [B, D]: kernel b's first product, likewise
   float* d_xbar;  // backward scratch [B, heads, D]: what the main backward consumes
   float* dt;      // backward scratch [B, heads, D]: what the main backward produces
   float* dx;      // backward output [B*H, D]
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void enc_last_post_kernel(const ElArgs p) {
   }
 }
 
-// ------------------------------------------------------------------ backward a: d_ctx0, d_xbar; dW_out, dW_v, biases
+// ------------------------------------------------------------------ backward a: d_ctx0, d_xbar
 __global__ __launch_bounds__(256, 1) void enc_last_bwd_a_kernel(const ElArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = p.D, heads = p.heads;
@@ -308,6 +313,7 @@ __global__ __launch_bounds__(256, 1) void enc_last_bwd_a_kernel(const ElArgs p) 
     for (int r = 0; r < 16; ++r) {
       const int row = acc_row(r);
       if (col < D) dc[row * ldq + col] = row < nb ? acc[r] : 0.f;
+      if (col < D && row < nb) p.d_ctx0[(b0 + row) * D + col] = acc[r];
     }
   }
   __syncthreads();
@@ -322,38 +328,6 @@ __global__ __launch_bounds__(256, 1) void enc_last_bwd_a_kernel(const ElArgs p) 
       const int row = acc_row(r);
       if (col < D && row < nb) p.d_xbar[((b0 + row) * heads + hh) * D + col] = acc[r];
     }
-  }
-  // dW_out[m][n] = sum_b d_recent[b][m] ctx0[b][n] ;  dW_v[m][n] = sum_b d_ctx0[b][m] xbar[b][head(m)][n]
-  float* mine = p.part_a + (int64_t)blockIdx.x * el_part_a(D);
-  const int64_t DD = (int64_t)D * D;
-  for (int u = L.w; u < NT * NT; u += 4) {
-    const int rt = u / NT, ct = u % NT;
-    const int mrow = 32 * rt + L.li, mc = mrow < D ? mrow : D - 1;
-    EL_TILE_COLS(ct);
-    f32x16 acc = zero16();
-    mma_tile<false, false>(acc, p.d_recent + b0 * p.ld_dr + mc, p.ld_dr, 1.f, p.ctx0 + b0 * D + nc, D, 1.f, nb);
-    f32x16 acv = zero16();
-    const int h_lo = (32 * rt) / dh, h_hi = ((32 * rt + 31 < D ? 32 * rt + 31 : D - 1)) / dh;
-    for (int hh = h_lo; hh <= h_hi; ++hh)
-      mma_tile<false, false>(acv, dc + mc, ldq, mc / dh == hh ? 1.f : 0.f, p.xbar + (b0 * heads + hh) * D + nc,
-                             (int64_t)heads * D, 1.f, nb);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = 32 * rt + acc_row(r);
-      if (row < D && col < D) {
-        mine[row * D + col] = acc[r];
-        mine[DD + row * D + col] = acv[r];
-      }
-    }
-  }
-  if ((int)threadIdx.x < D) {
-    float so = 0.f, sv = 0.f;
-    for (int b = 0; b < nb; ++b) {
-      so += p.d_recent[(b0 + b) * p.ld_dr + threadIdx.x];
-      sv += dc[b * ldq + threadIdx.x];
-    }
-    mine[2 * DD + threadIdx.x] = so;
-    mine[2 * DD + D + threadIdx.x] = sv;
   }
 }
 
@@ -417,7 +391,7 @@ __global__ __launch_bounds__(256) void enc_last_main_bwd_kernel(const float* __r
   }
 }
 
-// ------------------------------------------------------------------ backward b: dq0 -> dX[0]; dW_k, dW_q, biases
+// ------------------------------------------------------------------ backward b: dq0 -> dX[0]
 __global__ __launch_bounds__(256, 1) void enc_last_bwd_b_kernel(const ElArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int D = p.D, H = p.H, heads = p.heads;
@@ -440,6 +414,7 @@ __global__ __launch_bounds__(256, 1) void enc_last_bwd_b_kernel(const ElArgs p) 
     for (int r = 0; r < 16; ++r) {
       const int row = acc_row(r);
       if (col < D) dq[row * ldq + col] = row < nb ? acc[r] : 0.f;
+      if (col < D && row < nb) p.dq0[(b0 + row) * D + col] = acc[r];
     }
   }
   __syncthreads();
@@ -454,34 +429,81 @@ __global__ __launch_bounds__(256, 1) void enc_last_bwd_b_kernel(const ElArgs p) 
       if (col < D && row < nb) p.dx[(b0 + row) * H * D + col] += acc[r];
     }
   }
-  // dW_q[m][n] = sum_b dq0[b][m] X0[b][n] ;  dW_k[m][n] = sum_b q0[b][m] dt[b][head(m)][n]
-  float* mine = p.part_b + (int64_t)blockIdx.x * el_part_b(D);
+}
+
+// ------------------------------------------------------------------ backward, weights: the [D, 32] x [32, D] products
+// One workgroup per 32 samples and HALF: blockIdx.y = 0 writes the partials [dW_out | dW_v | db_out | db_v], 1 writes
+// [dW_q | dW_k | db_q].  The same products in the same order as when they were the tails of kernels a and b (the
+// operands d_ctx0 / dq0 now come from the [B, D] scratch those kernels leave behind instead of their LDS images):
+// bit-identical gradients, off the data path.
+__global__ __launch_bounds__(256, 1) void enc_last_wgrad_kernel(const ElArgs p) {
+  const int D = p.D, H = p.H, heads = p.heads;
+  const int dh = D / heads, NT = (D + 31) / 32;
+  const ElLane L;
+  const int64_t b0 = (int64_t)blockIdx.x * EL_ROWS;
+  const int nb = (int)((p.B - b0) < EL_ROWS ? (p.B - b0) : EL_ROWS);
   const int64_t DD = (int64_t)D * D;
-  for (int u = L.w; u < NT * NT; u += 4) {
-    const int rt = u / NT, ct = u % NT;
-    const int mrow = 32 * rt + L.li, mc = mrow < D ? mrow : D - 1;
-    EL_TILE_COLS(ct);
-    f32x16 acc = zero16();
-    mma_tile<false, false>(acc, dq + mc, ldq, 1.f, p.x + b0 * H * D + nc, (int64_t)H * D, 1.f, nb);
-    f32x16 ack = zero16();
-    const int h_lo = (32 * rt) / dh, h_hi = ((32 * rt + 31 < D ? 32 * rt + 31 : D - 1)) / dh;
-    for (int hh = h_lo; hh <= h_hi; ++hh) {
-      const float am = mc / dh == hh ? 1.f : 0.f;
-      mma_tile<false, false>(ack, p.q0 + b0 * D + mc, D, am, p.dt + (b0 * heads + hh) * D + nc, (int64_t)heads * D, 1.f, nb);
-    }
+  if (blockIdx.y == 0) {
+    // dW_out[m][n] = sum_b d_recent[b][m] ctx0[b][n] ;  dW_v[m][n] = sum_b d_ctx0[b][m] xbar[b][head(m)][n]
+    float* mine = p.part_a + (int64_t)blockIdx.x * el_part_a(D);
+    for (int u = L.w; u < NT * NT; u += 4) {
+      const int rt = u / NT, ct = u % NT;
+      const int mrow = 32 * rt + L.li, mc = mrow < D ? mrow : D - 1;
+      EL_TILE_COLS(ct);
+      f32x16 acc = zero16();
+      mma_tile<false, false>(acc, p.d_recent + b0 * p.ld_dr + mc, p.ld_dr, 1.f, p.ctx0 + b0 * D + nc, D, 1.f, nb);
+      f32x16 acv = zero16();
+      const int h_lo = (32 * rt) / dh, h_hi = ((32 * rt + 31 < D ? 32 * rt + 31 : D - 1)) / dh;
+      for (int hh = h_lo; hh <= h_hi; ++hh)
+        mma_tile<false, false>(acv, p.d_ctx0 + b0 * D + mc, D, mc / dh == hh ? 1.f : 0.f, p.xbar + (b0 * heads + hh) * D + nc,
+                               (int64_t)heads * D, 1.f, nb);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = 32 * rt + acc_row(r);
-      if (row < D && col < D) {
-        mine[row * D + col] = acc[r];
-        mine[DD + row * D + col] = ack[r];
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * rt + acc_row(r);
+        if (row < D && col < D) {
+          mine[row * D + col] = acc[r];
+          mine[DD + row * D + col] = acv[r];
+        }
       }
     }
-  }
-  if ((int)threadIdx.x < D) {
-    float sq = 0.f;
-    for (int b = 0; b < nb; ++b) sq += dq[b * ldq + threadIdx.x];
-    mine[2 * DD + threadIdx.x] = sq;
+    if ((int)threadIdx.x < D) {
+      float so = 0.f, sv = 0.f;
+      for (int b = 0; b < nb; ++b) {
+        so += p.d_recent[(b0 + b) * p.ld_dr + threadIdx.x];
+        sv += p.d_ctx0[(b0 + b) * D + threadIdx.x];
+      }
+      mine[2 * DD + threadIdx.x] = so;
+      mine[2 * DD + D + threadIdx.x] = sv;
+    }
+  } else {
+    // dW_q[m][n] = sum_b dq0[b][m] X0[b][n] ;  dW_k[m][n] = sum_b q0[b][m] dt[b][head(m)][n]
+    float* mine = p.part_b + (int64_t)blockIdx.x * el_part_b(D);
+    for (int u = L.w; u < NT * NT; u += 4) {
+      const int rt = u / NT, ct = u % NT;
+      const int mrow = 32 * rt + L.li, mc = mrow < D ? mrow : D - 1;
+      EL_TILE_COLS(ct);
+      f32x16 acc = zero16();
+      mma_tile<false, false>(acc, p.dq0 + b0 * D + mc, D, 1.f, p.x + b0 * H * D + nc, (int64_t)H * D, 1.f, nb);
+      f32x16 ack = zero16();
+      const int h_lo = (32 * rt) / dh, h_hi = ((32 * rt + 31 < D ? 32 * rt + 31 : D - 1)) / dh;
+      for (int hh = h_lo; hh <= h_hi; ++hh) {
+        const float am = mc / dh == hh ? 1.f : 0.f;
+        mma_tile<false, false>(ack, p.q0 + b0 * D + mc, D, am, p.dt + (b0 * heads + hh) * D + nc, (int64_t)heads * D, 1.f, nb);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * rt + acc_row(r);
+        if (row < D && col < D) {
+          mine[row * D + col] = acc[r];
+          mine[DD + row * D + col] = ack[r];
+        }
+      }
+    }
+    if ((int)threadIdx.x < D) {
+      float sq = 0.f;
+      for (int b = 0; b < nb; ++b) sq += p.dq0[(b0 + b) * D + threadIdx.x];
+      mine[2 * DD + threadIdx.x] = sq;
+    }
   }
 }
 
@@ -590,45 +612,46 @@ extern "C" int tt_enc_last_fwd(const float* x, int64_t B, int64_t H, int64_t D, 
 extern "C" int64_t tt_enc_last_bwd_workspace_bytes(int64_t B, int64_t H, int64_t D, int64_t heads) {
   if (B <= 0 || !tt_enc_last_supported(H, D, heads)) return 0;
   const int64_t G = el_groups(B);
-  // d_xbar [B, heads, D] | dt [B, heads, D] | partials a | partials b
-  return round_up(B * heads * D * 4, 256) * 2 + round_up(G * el_part_a(D) * 4, 256) + round_up(G * el_part_b(D) * 4, 256);
+  // d_xbar [B, heads, D] | dt [B, heads, D] | d_ctx0 [B, D] | dq0 [B, D] | partials a | partials b
+  return round_up(B * heads * D * 4, 256) * 2 + round_up(B * D * 4, 256) * 2 + round_up(G * el_part_a(D) * 4, 256) +
+         round_up(G * el_part_b(D) * 4, 256);
 }
 
-extern "C" int tt_enc_last_bwd(const float* x, int64_t B, int64_t H, int64_t D, int64_t heads, const float* w_in,
-                               const float* w_out, const float* d_recent, int64_t ld_dr, const float* q0, const float* t,
-                               const float* probs, const float* xbar, const float* ctx0, float* dx, float* dW_in, float* db_in,
-                               float* dW_out, float* db_out, void* ws, int64_t ws_bytes, tt_stream_t stream) {
-  if (!x || !w_in || !w_out || !d_recent || !q0 || !t || !probs || !xbar || !ctx0 || !dx || !dW_in || !db_in || !dW_out ||
-      !db_out)
-    return fail_arg("tt_enc_last_bwd: null pointer");
+namespace {
+// the workspace, carved the same way by the data half and the weight half
+void el_carve(ElArgs& a, void* ws, int64_t B, int64_t D, int64_t heads) {
+  const int64_t G = el_groups(B);
+  Carver cv(ws);
+  a.d_xbar = cv.take<float>(B * heads * D);
+  a.dt = cv.take<float>(B * heads * D);
+  a.d_ctx0 = cv.take<float>(B * D);
+  a.dq0 = cv.take<float>(B * D);
+  a.part_a = cv.take<float>(G * el_part_a(D));
+  a.part_b = cv.take<float>(G * el_part_b(D));
+}
+}  // namespace
+
+extern "C" int tt_enc_last_bwd_data(const float* x, int64_t B, int64_t H, int64_t D, int64_t heads, const float* w_in,
+                                    const float* w_out, const float* d_recent, int64_t ld_dr, const float* t,
+                                    const float* probs, float* dx, void* ws, int64_t ws_bytes, tt_stream_t stream) {
+  if (!x || !w_in || !w_out || !d_recent || !t || !probs || !dx) return fail_arg("tt_enc_last_bwd_data: null pointer");
   if (B < 0 || !tt_enc_last_supported(H, D, heads) || ld_dr < D) {
     set_error("tt_enc_last_bwd: shape outside H <= 64, D <= 128, D %% 4 == 0, head width %% 4 == 0");
     return TT_E_UNSUPPORTED;
   }
-  if (!el_aligned(x) || !el_aligned(w_in) || !el_aligned(w_out) || !el_aligned(t) || !el_aligned(xbar) || !el_aligned(dx) ||
-      !el_aligned(ws) || !el_aligned(d_recent) || (ld_dr % 4) != 0)
+  if (!el_aligned(x) || !el_aligned(w_in) || !el_aligned(w_out) || !el_aligned(t) || !el_aligned(dx) || !el_aligned(ws) ||
+      !el_aligned(d_recent) || (ld_dr % 4) != 0)
     return fail_arg("tt_enc_last_bwd: x, dx, w_in, w_out, t, xbar, d_recent, ws must be 16-byte aligned, ld_dr % 4 == 0");
-  hipStream_t st = S(stream);
-  if (B == 0) {
-    (void)hipMemsetAsync(dW_in, 0, sizeof(float) * 3 * D * D, st);
-    (void)hipMemsetAsync(db_in, 0, sizeof(float) * 3 * D, st);
-    (void)hipMemsetAsync(dW_out, 0, sizeof(float) * D * D, st);
-    (void)hipMemsetAsync(db_out, 0, sizeof(float) * D, st);
-    return 0;
-  }
+  if (B == 0) return 0;
   if (!ws || ws_bytes < tt_enc_last_bwd_workspace_bytes(B, H, D, heads)) return fail_arg("tt_enc_last_bwd: workspace too small");
+  hipStream_t st = S(stream);
   const int64_t G = el_groups(B);
-  Carver cv(ws);
   ElArgs a{};
   a.x = x; a.w_in = w_in; a.w_out = w_out;
   a.B = B; a.H = (int)H; a.D = (int)D; a.heads = (int)heads;
-  a.q0 = const_cast<float*>(q0); a.t = const_cast<float*>(t);
-  a.xbar = const_cast<float*>(xbar); a.ctx0 = const_cast<float*>(ctx0);
+  a.t = const_cast<float*>(t);
   a.d_recent = d_recent; a.ld_dr = ld_dr;
-  a.d_xbar = cv.take<float>(B * heads * D);
-  a.dt = cv.take<float>(B * heads * D);
-  a.part_a = cv.take<float>(G * el_part_a(D));
-  a.part_b = cv.take<float>(G * el_part_b(D));
+  el_carve(a, ws, B, D, heads);
   a.dx = dx;
   int rc;
   enc_last_bwd_a_kernel<<<(unsigned)G, 256, el_small_lds(D), st>>>(a);
@@ -641,8 +664,52 @@ extern "C" int tt_enc_last_bwd(const float* x, int64_t B, int64_t H, int64_t D, 
     if ((rc = check_launch("enc_last_main_bwd_kernel"))) return rc;
   }
   enc_last_bwd_b_kernel<<<(unsigned)G, 256, el_small_lds(D), st>>>(a);
-  if ((rc = check_launch("enc_last_bwd_b_kernel"))) return rc;
+  return check_launch("enc_last_bwd_b_kernel");
+}
+
+extern "C" int tt_enc_last_bwd_weights(const float* x, int64_t B, int64_t H, int64_t D, int64_t heads, const float* d_recent,
+                                       int64_t ld_dr, const float* q0, const float* xbar, const float* ctx0, float* dW_in,
+                                       float* db_in, float* dW_out, float* db_out, void* ws, int64_t ws_bytes,
+                                       tt_stream_t stream) {
+  if (!x || !d_recent || !q0 || !xbar || !ctx0 || !dW_in || !db_in || !dW_out || !db_out)
+    return fail_arg("tt_enc_last_bwd_weights: null pointer");
+  if (B < 0 || !tt_enc_last_supported(H, D, heads) || ld_dr < D) {
+    set_error("tt_enc_last_bwd: shape outside H <= 64, D <= 128, D %% 4 == 0, head width %% 4 == 0");
+    return TT_E_UNSUPPORTED;
+  }
+  if (!el_aligned(x) || !el_aligned(xbar) || !el_aligned(ws) || !el_aligned(d_recent) || (ld_dr % 4) != 0)
+    return fail_arg("tt_enc_last_bwd: x, xbar, d_recent, ws must be 16-byte aligned, ld_dr % 4 == 0");
+  hipStream_t st = S(stream);
+  if (B == 0) {
+    (void)hipMemsetAsync(dW_in, 0, sizeof(float) * 3 * D * D, st);
+    (void)hipMemsetAsync(db_in, 0, sizeof(float) * 3 * D, st);
+    (void)hipMemsetAsync(dW_out, 0, sizeof(float) * D * D, st);
+    (void)hipMemsetAsync(db_out, 0, sizeof(float) * D, st);
+    return 0;
+  }
+  if (!ws || ws_bytes < tt_enc_last_bwd_workspace_bytes(B, H, D, heads)) return fail_arg("tt_enc_last_bwd: workspace too small");
+  const int64_t G = el_groups(B);
+  ElArgs a{};
+  a.x = x;
+  a.B = B; a.H = (int)H; a.D = (int)D; a.heads = (int)heads;
+  a.q0 = const_cast<float*>(q0); a.xbar = const_cast<float*>(xbar); a.ctx0 = const_cast<float*>(ctx0);
+  a.d_recent = d_recent; a.ld_dr = ld_dr;
+  el_carve(a, ws, B, D, heads);
+  int rc;
+  enc_last_wgrad_kernel<<<dim3((unsigned)G, 2), 256, 0, st>>>(a);
+  if ((rc = check_launch("enc_last_wgrad_kernel"))) return rc;
   const int total = (int)(4 * D * D + 3 * D);
   enc_last_reduce_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, st>>>(a.part_a, a.part_b, (int)G, (int)D, dW_in, db_in, dW_out, db_out);
   return check_launch("enc_last_reduce_kernel");
+}
+
+extern "C" int tt_enc_last_bwd(const float* x, int64_t B, int64_t H, int64_t D, int64_t heads, const float* w_in,
+                               const float* w_out, const float* d_recent, int64_t ld_dr, const float* q0, const float* t,
+                               const float* probs, const float* xbar, const float* ctx0, float* dx, float* dW_in, float* db_in,
+                               float* dW_out, float* db_out, void* ws, int64_t ws_bytes, tt_stream_t stream) {
+  if (!q0 || !xbar || !ctx0 || !dW_in || !db_in || !dW_out || !db_out) return fail_arg("tt_enc_last_bwd: null pointer");
+  const int rc = tt_enc_last_bwd_data(x, B, H, D, heads, w_in, w_out, d_recent, ld_dr, t, probs, dx, ws, ws_bytes, stream);
+  if (rc) return rc;
+  return tt_enc_last_bwd_weights(x, B, H, D, heads, d_recent, ld_dr, q0, xbar, ctx0, dW_in, db_in, dW_out, db_out, ws, ws_bytes,
+                                 stream);
 }

@@ -48,9 +48,11 @@ def _ws(dev: torch.device, nbytes: int, slot: str = "ws") -> Tuple[Optional[int]
 # runs a node's backward on the stream its forward ran on, and orders gradients that cross streams itself -- their
 # backward kernels too.  Memory: a tensor allocated on one stream and read on the other is safe because every use of the
 # third stream starts by waiting for the main one (here, run_on_side, the plan sorts), autograd records cross-stream
-# gradients with the allocator, and `.backward()` returns with the caller's stream ordered after both (AuxFork.joined).
+# gradients with the allocator, the chain's input tensors are recorded with it by hand (AuxFork.uses), and `.backward()`
+# returns with the caller's stream ordered after both (AuxFork.joined).
 # Measured (one process, alternating blocks, tools/ab_c3.py): C2 1.12 -> 1.09 ms, history model +-0, deferred P-shape step
 # 1.36 -> 1.30 ms.  TT_TOWERS_SERIAL=1: one stream (A/B).
+_EL_WGRAD_SIDE = True  # (tools/ab_c3.py flips it: the collapsed last layer's weight half on the third stream / in line)
 _CONCURRENT_TOWERS = os.environ.get("TT_TOWERS_SERIAL") is None
 _FORK_MIN_ROWS = 2048  # (tests lower it: the golden batches are small)
 _aux_forks = [0]  # 1 from a fork point to the end of that step's backward pass (0: _ws and the deferred optimiser skip their
@@ -89,6 +91,17 @@ class AuxFork:
             done.record(self.aux)
             self.main.wait_event(done)
         return False
+
+    def uses(self, *tensors: Optional[torch.Tensor]) -> None:
+        """The chain's INPUTS that were allocated on the caller's stream (the batch tensors): the chain's kernels -- the
+        backward ones included, long after the caller has dropped its references -- read them on the third stream, and the
+        caching allocator hands a freed block back to its own stream at once.  A training loop that moves each batch to the
+        device and forgets it (everyone's) had item_features overwritten underneath the item tower's weight-gradient kernel
+        once in ~1000 steps: dW1 wrong in 18 % of its elements (round 5: fuzz_train case 73, test_p_shape_train_step)."""
+        if self.on:
+            for t in tensors:
+                if t is not None and t.is_cuda:
+                    t.record_stream(self.aux)
 
     def joined(self, out: torch.Tensor) -> torch.Tensor:
         """The chain's result as the rest of the forward should see it: the same values; in the backward pass the first
@@ -1235,13 +1248,36 @@ class HistoryEncoder(_LookupFunction):
                 db_in = torch.empty(3 * D, dtype=torch.float32, device=dev)
                 dW_out = torch.empty(D, D, dtype=torch.float32, device=dev)
                 db_out = torch.empty(D, dtype=torch.float32, device=dev)
+                # one workspace for both halves, whichever stream the weight half runs on (the next user of the slot is the
+                # next step's backward pass, behind the end-of-backward join)
                 wsp, wsn = _ws(dev, lib.tt_enc_last_bwd_workspace_bytes(B, H, D, heads), "enc_last")
                 w_used = ctx.folded.get(l, w_in)  # the composed W_in W_o(prev) when the forward ran on the previous layer's context
-                N.check(lib.tt_enc_last_bwd(x.data_ptr(), B, H, D, heads, w_used.contiguous().data_ptr(),
-                                            w_out.contiguous().data_ptr(), d_recent.data_ptr(), 2 * D, q0.data_ptr(),
-                                            tq.data_ptr(), probs.data_ptr(), xbar.data_ptr(), ctx0.data_ptr(), dx.data_ptr(),
-                                            dW_in.data_ptr(), db_in.data_ptr(), dW_out.data_ptr(), db_out.data_ptr(),
-                                            wsp, wsn, N.stream()), "tt_enc_last_bwd")
+                N.check(lib.tt_enc_last_bwd_data(x.data_ptr(), B, H, D, heads, w_used.contiguous().data_ptr(),
+                                                 w_out.contiguous().data_ptr(), d_recent.data_ptr(), 2 * D, tq.data_ptr(),
+                                                 probs.data_ptr(), dx.data_ptr(), wsp, wsn, N.stream()), "tt_enc_last_bwd_data")
+
+                # the weight half ([D, 32] x [32, D] partial products per 32 samples + their reduction) feeds nothing but the
+                # optimiser: third stream (it was the tail of the data kernels: 0.1 ms of the step's critical path)
+                def last_weights(on_side, x=x, q0=q0, xbar=xbar, ctx0=ctx0, dW_in=dW_in, db_in=db_in, dW_out=dW_out, db_out=db_out,
+                                 wsp=wsp, wsn=wsn):
+                    N.check(lib.tt_enc_last_bwd_weights(x.data_ptr(), B, H, D, heads, d_recent.data_ptr(), 2 * D, q0.data_ptr(),
+                                                        xbar.data_ptr(), ctx0.data_ptr(), dW_in.data_ptr(), db_in.data_ptr(),
+                                                        dW_out.data_ptr(), db_out.data_ptr(), wsp, wsn, N.stream()),
+                            "tt_enc_last_bwd_weights")
+
+                # leaves: the Parameters whose gradients the side job writes -- with a composed W_in, dW_in here is the private
+                # G (turned into the two layers' gradients by a tail job on the main stream), so w_in is not among them
+                lw = list(leaf_params[4 * l + 1: 4 * l + 4]) + ([] if l in ctx.folded else [leaf_params[4 * l]])
+                w_aside = False
+                if _EL_WGRAD_SIDE:
+                    w_aside = run_on_side(dev, last_weights, hold=(x, q0, xbar, ctx0, d_out) + ((dW_in,) if l in ctx.folded else ()),
+                                          leaves=lw)
+                else:
+                    last_weights(False)
+                w_done = None
+                if w_aside and l in ctx.folded:  # the tail job below reads G on the main stream
+                    w_done = torch.cuda.Event()
+                    w_done.record(N.aux_stream(dev))
                 if l in ctx.folded:
                     # dW_in / db_in above are the gradients of (W_eff, b_eff): G and s.  Back to the two layers' own parameters
                     # (the four small products of a composed boundary, see the full layers below):
@@ -1257,7 +1293,7 @@ class HistoryEncoder(_LookupFunction):
 
                     # (issued here on the side stream, these four 10-us products sat behind the persistent attention-backward
                     # workgroups for 0.45 ms and pushed the streaming weight gradients that much later)
-                    tail_jobs.append((last_folded_weights, None))
+                    tail_jobs.append((last_folded_weights, w_done))
                     prev_out_grads = (dW_po, db_po)  # dx is the gradient of the previous layer's CONTEXT
                 grads[4 * l: 4 * l + 4] = [dW_in, db_in, dW_out, db_out]
                 continue

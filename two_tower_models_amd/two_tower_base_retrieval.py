@@ -288,6 +288,7 @@ class TwoTowerBaseRetrieval(nn.Module):
             fork = ops.AuxFork(user_id.device, rows=user_id.numel() if tuned else 0)
             user_embedding = self.compute_user_embedding(user_id, user_features, user_history)
             with fork:
+                fork.uses(item_id, item_features)
                 item_embeddings = self.compute_item_embeddings(item_id, item_features)
             item_embeddings = fork.joined(item_embeddings)
         return self.compute_training_loss(
