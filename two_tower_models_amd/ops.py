@@ -52,6 +52,7 @@ def _ws(dev: torch.device, nbytes: int, slot: str = "ws") -> Tuple[Optional[int]
 # returns with the caller's stream ordered after both (AuxFork.joined).
 # Measured (one process, alternating blocks, tools/ab_c3.py): C2 1.12 -> 1.09 ms, history model +-0, deferred P-shape step
 # 1.36 -> 1.30 ms.  TT_TOWERS_SERIAL=1: one stream (A/B).
+_FOLD_ASIDE = True  # (likewise: the composed-weight products of the encoder's forward on the third stream / between the layers)
 _EL_WGRAD_SIDE = True  # (tools/ab_c3.py flips it: the collapsed last layer's weight half on the third stream / in line)
 _CONCURRENT_TOWERS = os.environ.get("TT_TOWERS_SERIAL") is None
 _FORK_MIN_ROWS = 2048  # (tests lower it: the golden batches are small)
@@ -1064,7 +1065,7 @@ class DebiasedWeightedLoss(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------- history encoder
-def fold_weights(w_in, b_in, w_po, b_po):
+def fold_weights(w_in, b_in, w_po, b_po, slot: str = "ws"):
     """(W_in W_o, W_in b_o + b_in): the in-projection of a layer that reads the previous layer's attention CONTEXT --
     [3D, D] x [D, D], 12.6 MFLOP at D = 128, instead of a [B*H, D] x [D, D] out-projection (and its d_ctx / dW_out products
     in the backward).  (One hand-written launch per direction was tried in round 5 and was 4x slower than these two small
@@ -1072,9 +1073,9 @@ def fold_weights(w_in, b_in, w_po, b_po):
     D = w_po.shape[0]
     dev = w_in.device
     w_eff = torch.empty(3 * D, D, dtype=torch.float32, device=dev)
-    gemm(N.TT_GEMM_NN, w_in, w_po, w_eff, 3 * D, D, D)
+    gemm(N.TT_GEMM_NN, w_in, w_po, w_eff, 3 * D, D, D, slot=slot)
     b_eff = torch.empty(1, 3 * D, dtype=torch.float32, device=dev)
-    gemm(N.TT_GEMM_NT, b_po.view(1, D), w_in, b_eff, 1, 3 * D, D, bias=b_in)
+    gemm(N.TT_GEMM_NT, b_po.view(1, D), w_in, b_eff, 1, 3 * D, D, bias=b_in, slot=slot)
     return w_eff, b_eff.view(-1)
 
 
@@ -1155,6 +1156,32 @@ class HistoryEncoder(_LookupFunction):
             return fold and 1 <= l < L and not (l == L - 1 and collapsed_last)
 
         folded_w = {}
+        # The composed weights depend on nothing but the parameters: all boundaries' products (two 10-us library launches
+        # each, 20 - 25 us each next to the table sweep) are queued on the third stream HERE, underneath the history gather
+        # and the first layer, instead of between the layers on the main stream; a layer waits for its own pair's event.
+        # (Allocated on the third stream, read on the main one until the backward pass ends: every later use of the third
+        # stream starts by waiting for the main one, see AuxFork.)
+        composed = {}
+        will_fold = [l for l in range(L) if folded_in(l) or (l == L - 1 and fold_last)]
+        if will_fold and _FOLD_ASIDE and dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            top, aux_s = torch.cuda.Event(), N.aux_stream(dev)
+            top.record()
+            aux_s.wait_event(top)
+            with torch.cuda.stream(aux_s):
+                for l in will_fold:
+                    w_po, b_po = layer_params[4 * (l - 1) + 2], layer_params[4 * (l - 1) + 3]
+                    we, be = fold_weights(layer_params[4 * l], layer_params[4 * l + 1], w_po, b_po, slot="ws_side_f")
+                    ready = torch.cuda.Event()
+                    ready.record(aux_s)
+                    composed[l] = (we, be, ready)
+
+        def composed_weights(l, w_in, b_in):
+            if l in composed:
+                we, be, ready = composed.pop(l)
+                torch.cuda.current_stream(dev).wait_event(ready)
+                return we, be
+            return fold_weights(w_in, b_in, layer_params[4 * (l - 1) + 2], layer_params[4 * (l - 1) + 3])
+
         for l in range(L):
             w_in, b_in, w_out, b_out = layer_params[4 * l: 4 * l + 4]
             if l == L - 1 and collapsed_last:
@@ -1169,8 +1196,7 @@ class HistoryEncoder(_LookupFunction):
                 if fold_last:
                     # x is the previous layer's CONTEXT c.  q, k, v of this layer are linear in x = c W_o^T + b_o, so the layer
                     # runs on c with W_eff = W_in W_o, b_eff = W_in b_o + b_in -- the same kernels as for a first layer
-                    w_po, b_po = layer_params[4 * (l - 1) + 2], layer_params[4 * (l - 1) + 3]
-                    w_in_c, b_in_c = fold_weights(w_in, b_in, w_po, b_po)
+                    w_in_c, b_in_c = composed_weights(l, w_in, b_in)
                     folded_w[l] = w_in_c
                 N.check(lib.tt_enc_last_fwd(x.data_ptr(), B, H, D, heads, w_in_c.data_ptr(), b_in_c.data_ptr(),
                                             w_out_c.data_ptr(), b_out.contiguous().data_ptr(), out.data_ptr(), 2 * D,
@@ -1183,8 +1209,7 @@ class HistoryEncoder(_LookupFunction):
                 # x is the previous layer's CONTEXT c: x_l = c W_o^T + b_o never exists, the two Linear maps are composed --
                 #   qkv = c (W_in W_o)^T + (W_in b_o + b_in)          ([3D, D] x [D, D]: 12.6 MFLOP instead of a [B*H, D] x [D, D]
                 # out-projection, and its d_ctx / dW_out products in the backward)
-                w_po, b_po = layer_params[4 * (l - 1) + 2], layer_params[4 * (l - 1) + 3]
-                w_eff, b_eff = fold_weights(w_in, b_in, w_po, b_po)
+                w_eff, b_eff = composed_weights(l, w_in, b_in)
                 gemm(N.TT_GEMM_NT, x, w_eff, qkv, B * H, 3 * D, D, bias=b_eff)
                 folded_w[l] = w_eff
             else:
