@@ -561,7 +561,7 @@ def secondary(device, lib, N):
         sec["P_sharded_W1"] = {"error": f"{type(e).__name__}: {e}"}
     torch.cuda.empty_cache()
     # (dense-exact workloads: 80 warm-up steps, the sweep-level scan of DenseExactAdam._tune_sweep settles inside them)
-    for key, name, steps, lazy, fresh in (("C2", "C2", 40, False, False), ("C3", "C3", 20, False, False),
+    for key, name, steps, lazy, fresh in (("C2", "C2", 100, False, False), ("C3", "C3", 60, False, False),
                                           ("P_lazy", "P", 20, True, False),
                                           # the same schedule with the step replayed as one hipGraph: the eager loop is bound by
                                           # the HOST's ~90 launches per step, the GPU work is ~0.5 ms of MFMA
