@@ -22,7 +22,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 only = int(sys.argv[3]) if len(sys.argv) > 3 else None
 rng = np.random.default_rng(seed)
-t0, n, bad = time.time(), 0, 0
+t0, n, bad, n_notes = time.time(), 0, 0, 0
 while time.time() - t0 < budget:
     heads = int(rng.choice([1, 2, 4, 4, 4, 8, 16]))
     hd = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 32]))
@@ -63,7 +63,7 @@ while time.time() - t0 < budget:
         table = enc.positional_embeddings.cpu() if pe else None
         want = R.history_encoder_forward(xl, R.encoder_layers_from_params(leaves, prefix=""), heads, table)
         (want * cot).sum().backward()
-        msgs = []
+        msgs, notes = [], []
         l64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
         x64 = x.double().requires_grad_(True)
 
@@ -84,11 +84,16 @@ while time.time() - t0 < budget:
                 tol = tol + 1e-6 * max(1.0, float(gw.abs().max()))
             out = int(((got - gw).abs() > tol).sum())
             if out:
+                # the referee is the oracle in float64: an element where the GPU is within the tolerance of THAT and the
+                # fp32 oracle is the one that is off (deep stacks, cancelling sums: seen at L >= 4 only) is the oracle's
+                # rounding, reported as a note; an element where the GPU misses float64 as well is a finding
                 g64 = in_float64()[name] * reps
                 bad_at = (got - gw).abs() > tol
-                msgs.append(f"grad {name}: {out} elements, max err {float((got - gw).abs().max()):.3e} (max |g| {float(gw.abs().max()):.3e}); "
-                            f"there, vs float64: GPU {float((got.double() - g64)[bad_at].abs().max()):.3e}, "
-                            f"fp32 oracle {float((gw.double() - g64)[bad_at].abs().max()):.3e}")
+                gpu_off = int((((got.double() - g64).abs() > tol.double()) & bad_at).sum())
+                text = (f"grad {name}: {out} elements, max err {float((got - gw).abs().max()):.3e} (max |g| {float(gw.abs().max()):.3e}); "
+                        f"there, vs float64: GPU {float((got.double() - g64)[bad_at].abs().max()):.3e}, "
+                        f"fp32 oracle {float((gw.double() - g64)[bad_at].abs().max()):.3e}")
+                (msgs if gpu_off else notes).append(text)
 
         cmp(xd.grad.cpu(), xl.grad, "x")
         for name, p in enc.named_parameters():
@@ -98,9 +103,12 @@ while time.time() - t0 < budget:
             cmp(p.grad.cpu() if p.grad is not None else torch.zeros_like(gw), gw, name)
         if msgs:
             bad += 1
-            print("MISMATCH", what, "|", "; ".join(msgs), flush=True)
+            print("MISMATCH", what, "|", "; ".join(msgs + notes), flush=True)
+        elif notes:
+            n_notes += 1
+            print("NOTE (fp32 oracle off, GPU within tolerance of float64)", what, "|", "; ".join(notes), flush=True)
     except Exception as e:  # a crash is a finding too
         bad += 1
         print("ERROR", what, "|", type(e).__name__, str(e)[:300], flush=True)
     n += 1
-print(f"{n} cases, {bad} findings in {time.time() - t0:.0f} s")
+print(f"{n} cases, {bad} findings, {n_notes} oracle-rounding notes in {time.time() - t0:.0f} s")

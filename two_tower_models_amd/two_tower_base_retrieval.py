@@ -283,7 +283,10 @@ class TwoTowerBaseRetrieval(nn.Module):
             # (the tuned shapes only: there the item tower is one forward and three backward kernels; the generic forms --
             # any width, a dozen library launches -- stay on one stream)
             mlp = self.item_features_arch
-            tuned = item_features.is_cuda and ops.fused_tower_supported(
+            # ... and only this class's own item tower: a subclass's override may read per-batch tensors this method cannot
+            # see (and therefore cannot record on the third stream: ops.AuxFork.uses)
+            own = type(self).compute_item_embeddings is TwoTowerBaseRetrieval.compute_item_embeddings
+            tuned = own and item_features.is_cuda and ops.fused_tower_supported(
                 self.item_id_embedding_arch.weight, item_features, mlp[0].weight, mlp[2].weight, self.item_tower_arch.weight)
             fork = ops.AuxFork(user_id.device, rows=user_id.numel() if tuned else 0)
             user_embedding = self.compute_user_embedding(user_id, user_features, user_history)
