@@ -98,10 +98,33 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False,
         model, opt = bench.build_sharded(cfg, device, 0)
         batches = bench.make_batches(cfg, 8, device)
         step = bench.sharded_step_fn(model, opt, torch.zeros((), device=device))
-        for i in range(max(warmup, 45)):  # covers the optimiser's group-wide sweep-level scan (optim._tune_sweep_group)
-            step(batches[i % 8], batches[(i + 1) % 8])
+        if verbose and os.environ.get("EMU_TRACE"):  # measurement aid: wall clock per 10 steps while the controller scans
+            real_sweep, seen = lib.tt_adam_tables_sweep, []
+
+            def spy(descs, n, hyper, wgs, stream):
+                seen.append(int(wgs))
+                return real_sweep(descs, n, hyper, wgs, stream)
+
+            lib.tt_adam_tables_sweep = spy
+            for blk in range(max(warmup, 230) // 10):
+                seen.clear()
+                ms10 = _time_steps(step, batches, 10)[1]
+                print(f"  steps {10 * blk + 1}-{10 * blk + 10}: {ms10:.3f} ms/step, level {opt._sweep_wgs or 768}, phase {opt._tune_state['phase']}, "
+                      f"workgroups passed to the sweep launches: {seen}")
+            lib.tt_adam_tables_sweep = real_sweep
+        else:
+            for i in range(max(warmup, 230)):  # covers the optimiser's group-wide sweep-level scan (optim._tune_sweep_group)
+                step(batches[i % 8], batches[(i + 1) % 8])
         lib.tt_profile_enable(1)
         host_ms, ms = _time_steps(step, batches, steps)
+        if verbose and os.environ.get("EMU_FORCE_LEVELS"):  # measurement aid: the same process, the level pinned by hand
+            for lv in (int(v) for v in os.environ["EMU_FORCE_LEVELS"].split(",")):
+                opt._tune_state = {"phase": os.environ.get("EMU_FORCE_PHASE", "locked"), "since": 0, "why": f"pinned to {lv}"}
+                opt._tune_done.clear()
+                opt._sweep_wgs = lv
+                for i in range(int(os.environ.get("EMU_FORCE_WARM", "40"))):
+                    step(batches[i % 8], batches[(i + 1) % 8])
+                print(f"  pinned to {lv or 768} workgroups: " + ", ".join(f"{_time_steps(step, batches, 10)[1]:.3f}" for _ in range(5)) + " ms/step (5 x 10 steps)")
         prof = {}
         for name in (b"ce_fwd_kernel", b"ce_bwd_kernel", b"adam_sweep_kernel"):
             t, c = C.c_double(0.0), C.c_int64(0)

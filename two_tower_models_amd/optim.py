@@ -311,6 +311,8 @@ class DenseExactAdam(torch.optim.Optimizer):
             self._tune_sweep()
             ev_begin = torch.cuda.Event(enable_timing=True)
             ev_begin.record()
+            if self._tune_done and self._tune_done[-1][5] == self._host_steps and len(self._tune_done[-1]) == 6:
+                self._tune_done[-1].append(ev_begin)  # the previous step's record: its full period ends where this step begins
         if announced is None:
             N.check(lib.tt_adam_advance(hyper, N.stream()), "tt_adam_advance")
         self._host_steps += 1
@@ -439,6 +441,15 @@ class DenseExactAdam(torch.optim.Optimizer):
     # are handed out dynamically either way.
     _SWEEP_LEVELS = (0, 640, 512, 384, 256, 128)  # workgroups; 0 = library default (3 per CU = 768)
     _SCAN_BLOCK = 6  # steps per level; the first one of a block overlaps the previous level's tail and is not counted
+    # row-sharded group: every level TWICE (down the list and back up), 16-step blocks, the first 4 steps of a block not
+    # counted, the median of a level's 24 steps kept; the first scan of a process starts after 40 steps.  Pinned levels
+    # at the emulated W = 8 step (tools/bench_emulated_world.py, EMU_FORCE_LEVELS): 4.54 / 4.42 / 4.58 / 4.21 / 4.18 / 4.47
+    # ms for 768 / 512 / 384 / 256 / 192 / 128 workgroups, the same within 0.02 ms at once after every switch.  But the
+    # first ~150 steps of a process run 0.1 - 0.3 ms slower than the steady state and speed up as they go, so a one-way
+    # scan right at the start read its LAST level (128) as the best and kept it: 4.5 instead of 4.2 ms (round 5).
+    _GROUP_SCAN_BLOCK = 16
+    _GROUP_SCAN_SKIP = 4
+    _GROUP_SCAN_DELAY = 40
     _RESCAN_STEPS = 4000
 
     def sweep_level_note(self) -> str:
@@ -460,16 +471,20 @@ class DenseExactAdam(torch.optim.Optimizer):
         levels = self._SWEEP_LEVELS
         step = self._host_steps + 1  # the step about to be enqueued
         ts = self._tune_state
-        if ts is None:
-            ts = self._tune_state = {"phase": "probe", "t0": step, "since": 0}
+        if ts is None:  # (the first probe waits: see _GROUP_SCAN_DELAY)
+            ts = self._tune_state = {"phase": "probe", "t0": step + self._GROUP_SCAN_DELAY, "since": 0}
 
         def collect():
             obs = {}
             for got in self._tune_done:
-                got[3].synchronize()
+                # a step's time = begin to the NEXT step's begin where that is known: what lies between a step's end and
+                # the next one's begin (routing the next batch's lookups) waits for more or less of the sweep's tail
+                # depending on the level -- begin-to-end under-read the slowest level by 0.13 ms and picked it (round 5)
+                last = got[6] if len(got) > 6 else got[3]
+                last.synchronize()
                 if got[5] < ts["t0"] + 4 or got[5] in ts.get("skip", ()):
                     continue
-                obs.setdefault(got[4], []).append((got[0].elapsed_time(got[3]), got[1].elapsed_time(got[2])))
+                obs.setdefault(got[4], []).append((got[0].elapsed_time(last), got[1].elapsed_time(got[2])))
             self._tune_done.clear()
             return obs
 
@@ -487,10 +502,10 @@ class DenseExactAdam(torch.optim.Optimizer):
                     self._lock_sweep(ts, 0, "the sweep is the step on every rank")
                 else:
                     plan, skip, nxt = [], set(), step
-                    for lv in levels[1:]:
-                        skip.add(nxt)
-                        plan += [lv] * self._SCAN_BLOCK
-                        nxt += self._SCAN_BLOCK
+                    for lv in levels[1:] + levels[:0:-1]:  # down the levels and back up: a drift over the scan cancels
+                        skip.update(range(nxt, nxt + self._GROUP_SCAN_SKIP))  # a block's first steps are not the level's steady state
+                        plan += [lv] * self._GROUP_SCAN_BLOCK
+                        nxt += self._GROUP_SCAN_BLOCK
                     skip.add(nxt)
                     ts.update(phase="scan", plan=plan, skip=skip, scan_start=step)
         if ts["phase"] == "scan":
@@ -498,11 +513,16 @@ class DenseExactAdam(torch.optim.Optimizer):
             self._sweep_wgs = ts["plan"][k] if k < len(ts["plan"]) else levels[0]
             if k == len(ts["plan"]) + 3:
                 obs = collect()
-                local = [min((st for st, _ in obs.get(lv, [])), default=1.0e9) if len(obs.get(lv, [])) >= 2 else 1.0e9
-                         for lv in levels]
+                # the MEDIAN step of each level's block (the single-GPU controller keeps the fastest step; here one lucky step
+                # decided between levels 7 % apart in steady state: emulated W = 8, 4.19 vs 4.51 ms, round 5)
+                def median(v):
+                    v = sorted(v)
+                    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+                local = [median([st for st, _ in obs.get(lv, [])]) if len(obs.get(lv, [])) >= 3 else 1.0e9 for lv in levels]
                 worst = group(local, dist.ReduceOp.MAX)
                 best = min(range(len(levels)), key=lambda i: (worst[i], i))
-                self._lock_sweep(ts, levels[best], "group (max over ranks of each level's best step time): "
+                self._lock_sweep(ts, levels[best], "group (max over ranks of each level's median step time): "
                                  + str({(lv or 768): round(v, 3) for lv, v in zip(levels, worst) if v < 1.0e8}))
         elif ts["phase"] == "locked":
             self._tune_done.clear()
