@@ -125,7 +125,7 @@ def test_group_tuner_takes_the_level_whose_worst_rank_is_fastest_at_the_same_ste
     at every step, including the step the decision lands on."""
     local_ms = [{0: 4.40, 640: 4.38, 512: 4.20, 384: 4.45, 256: 4.60, 128: 5.0},   # rank 0 alone would take 512
                 {0: 4.50, 640: 4.45, 512: 4.70, 384: 4.30, 256: 4.40, 128: 5.2}]   # rank 1 alone 384; group (max): 640
-    mes, hist = _drive_group(local_ms, 1.2, 300, monkeypatch)
+    mes, hist = _drive_group(local_ms, 1.2, 400, monkeypatch)
     assert hist[0] == hist[1]
     assert mes[0]._sweep_wgs == mes[1]._sweep_wgs == 640
     assert mes[0]._tune_state["phase"] == "locked" and "group" in mes[0]._tune_state["why"]
@@ -136,9 +136,9 @@ def test_group_tuner_takes_the_level_whose_worst_rank_is_fastest_at_the_same_ste
 def test_group_tuner_keeps_full_width_only_if_the_sweep_is_the_step_on_every_rank(monkeypatch):
     sweep = 5.0
     bound = {lv: 5.3 for lv in DenseExactAdam._SWEEP_LEVELS}
-    mes, hist = _drive_group([bound, bound], sweep, 80, monkeypatch)
+    mes, hist = _drive_group([bound, bound], sweep, 200, monkeypatch)
     assert set(hist[0]) == {0} and mes[0]._tune_state["phase"] == "locked"
     # one rank whose step is much longer than its sweep: the group scans
     chain = {0: 7.0, 640: 6.9, 512: 6.5, 384: 6.6, 256: 6.8, 128: 7.5}
-    mes, hist = _drive_group([bound, chain], sweep, 300, monkeypatch)
+    mes, hist = _drive_group([bound, chain], sweep, 400, monkeypatch)
     assert hist[0] == hist[1] and mes[0]._sweep_wgs == 512

@@ -109,8 +109,11 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False,
             for blk in range(max(warmup, 230) // 10):
                 seen.clear()
                 ms10 = _time_steps(step, batches, 10)[1]
+                recs = [r for r in opt._tune_done[-10:] if r[2] is not None]
+                sw = sorted(r[1].elapsed_time(r[2]) for r in recs)
+                lag = sorted(r[0].elapsed_time(r[1]) for r in recs)  # step begin -> sweep start
                 print(f"  steps {10 * blk + 1}-{10 * blk + 10}: {ms10:.3f} ms/step, level {opt._sweep_wgs or 768}, phase {opt._tune_state['phase']}, "
-                      f"workgroups passed to the sweep launches: {seen}")
+                      f"sweep launches {sorted(set(seen))}, median sweep {sw[len(sw) // 2] if sw else -1:.3f} ms starting {lag[len(lag) // 2] if lag else -1:.3f} ms into the step")
             lib.tt_adam_tables_sweep = real_sweep
         else:
             for i in range(max(warmup, 230)):  # covers the optimiser's group-wide sweep-level scan (optim._tune_sweep_group)
@@ -125,6 +128,11 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False,
                 for i in range(int(os.environ.get("EMU_FORCE_WARM", "40"))):
                     step(batches[i % 8], batches[(i + 1) % 8])
                 print(f"  pinned to {lv or 768} workgroups: " + ", ".join(f"{_time_steps(step, batches, 10)[1]:.3f}" for _ in range(5)) + " ms/step (5 x 10 steps)")
+                recs = [r for r in opt._tune_done[-10:] if r[2] is not None]
+                if recs:
+                    sw = sorted(r[1].elapsed_time(r[2]) for r in recs)
+                    lag = sorted(r[0].elapsed_time(r[1]) for r in recs)
+                    print(f"    median sweep {sw[len(sw) // 2]:.3f} ms starting {lag[len(lag) // 2]:.3f} ms into the step")
         prof = {}
         for name in (b"ce_fwd_kernel", b"ce_bwd_kernel", b"adam_sweep_kernel"):
             t, c = C.c_double(0.0), C.c_int64(0)

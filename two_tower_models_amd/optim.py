@@ -442,7 +442,7 @@ class DenseExactAdam(torch.optim.Optimizer):
     _SWEEP_LEVELS = (0, 640, 512, 384, 256, 128)  # workgroups; 0 = library default (3 per CU = 768)
     _SCAN_BLOCK = 6  # steps per level; the first one of a block overlaps the previous level's tail and is not counted
     # row-sharded group: every level TWICE (down the list and back up), 16-step blocks, the first 4 steps of a block not
-    # counted, the median of a level's 24 steps kept; the first scan of a process starts after 40 steps.  Pinned levels
+    # counted, the median of a level's 24 steps kept; the first scan of an optimiser starts after 40 steps.  Pinned levels
     # at the emulated W = 8 step (tools/bench_emulated_world.py, EMU_FORCE_LEVELS): 4.54 / 4.42 / 4.58 / 4.21 / 4.18 / 4.47
     # ms for 768 / 512 / 384 / 256 / 192 / 128 workgroups, the same within 0.02 ms at once after every switch.  But the
     # first ~150 steps of a process run 0.1 - 0.3 ms slower than the steady state and speed up as they go, so a one-way
@@ -725,7 +725,7 @@ class DenseExactAdam(torch.optim.Optimizer):
                 end = torch.cuda.Event(enable_timing=True)
                 end.record()
                 self._tune[3] = end
-                if len(self._tune_done) < 256:  # never drop a PENDING measurement: when the host runs many steps ahead the
+                if len(self._tune_done) < 1024:  # never drop a PENDING measurement: when the host runs many steps ahead the
                     self._tune_done.append(self._tune)  # oldest one is the next to complete (new ones are skipped meanwhile)
                 self._tune = None
         elif self.lazy:
