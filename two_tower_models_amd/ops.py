@@ -774,6 +774,15 @@ def kept_logits_supported(U: torch.Tensor, I: torch.Tensor) -> bool:
             and U.data_ptr() % 16 == 0 and I.data_ptr() % 16 == 0 and os.environ.get("TT_CE_NO_DMA") is None)
 
 
+# optimisers whose table sweep waits for the backward logits kernel to be queued (DenseExactAdam._begin_overlapped, hold_sweep)
+held_sweeps: set = set()
+
+
+def _release_held_sweeps(before_kernel: Optional[torch.cuda.Event]) -> None:
+    for opt in list(held_sweeps):
+        opt.release_sweep(after=before_kernel)
+
+
 class InBatchSoftmaxCE(torch.autograd.Function):
     """row_ce[i] = logsumexp_j (U I^T)[i, j] - (U I^T)[i, i + diag_offset]
     (torch.matmul + F.cross_entropy(reduction="none"), ref:...base_retrieval.py:287-312)."""
@@ -854,6 +863,18 @@ class InBatchSoftmaxCE(torch.autograd.Function):
         wsp, wsn = _ws(dev, lib.tt_inbatch_ce_workspace_bytes(M, Nn, D))
         pu, _, _, ldu = _f32_2d(U, "U")
         pi, _, _, ldi = _f32_2d(I, "I")
+        before = None
+        if held_sweeps:  # a table sweep waits for this kernel to be in the queue: see DenseExactAdam._begin_overlapped
+            before = torch.cuda.Event()
+            before.record()
+        try:
+            return InBatchSoftmaxCE._item_side(ctx, lib, dev, M, Nn, D, pu, ldu, pi, ldi, lse, coef, du_unit, dU, dI, wsp, wsn)
+        finally:
+            if before is not None:
+                _release_held_sweeps(before)
+
+    @staticmethod
+    def _item_side(ctx, lib, dev, M, Nn, D, pu, ldu, pi, ldi, lse, coef, du_unit, dU, dI, wsp, wsn):
         if ctx.kept16 is not None:  # the split-fp16 pair's backward
             w16p, w16n = _ws(dev, lib.tt_ce16_workspace_bytes(M, Nn, D), "ce16")
             if ctx.kept16 is True:  # (images formed again: other products may have used the workspace slot since the forward)

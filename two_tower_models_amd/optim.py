@@ -62,6 +62,7 @@ from . import _native as N
 from . import ops
 
 
+_RELEASE_AT_LOGITS = True  # a sweep held for the backward logits kernel is released BY that kernel's Function (A/B switch)
 _HOLD_SWEEP = True  # (tools/ab_c3.py flips it: the held-back sweep start against the immediate one, same process, same box)
 
 
@@ -367,11 +368,13 @@ class DenseExactAdam(torch.optim.Optimizer):
         ready = torch.cuda.Event()
         ready.record(main)  # lookups (or none yet, forward mode) + stashes are complete here
 
-        def launch_sweep(held_back=False, ready=ready, begun=begun, split_planes=split_planes, capturing=capturing):
+        def launch_sweep(held_back=False, after=None, ready=ready, begun=begun, split_planes=split_planes, capturing=capturing):
             self._side_stream.wait_event(ready)
-            if held_back:  # ... and after what was queued since (the big gather this was held back for)
-                later = torch.cuda.Event()
-                later.record(torch.cuda.current_stream())
+            if held_back:  # ... and after what was queued since (the big gather this was held back for) / after `after`
+                later = after
+                if later is None:
+                    later = torch.cuda.Event()
+                    later.record(torch.cuda.current_stream())
                 self._side_stream.wait_event(later)
             if split_planes:
                 N.check(lib.tt_adam_begin_ids_planes(hyper, None, 0, jobs, len(stash_jobs), 6, self._side_stream.cuda_stream),
@@ -408,6 +411,16 @@ class DenseExactAdam(torch.optim.Optimizer):
         # logits from HBM anyway -- loses less than that (round 4: 4.10 vs 4.26 ms per emulated W = 8 step)
         if _HOLD_SWEEP and announced is not None and not capturing and ((n_announced >= 65536 and not self._sharded) or hold_sweep):
             self._sweep_pending = launch_sweep
+            # hold_sweep: until the BACKWARD logits kernel is in the main stream's queue (ops.InBatchSoftmaxCE.backward
+            # releases it, ordered behind an event recorded in front of that kernel): both become runnable at the same
+            # moment and the kernel, already queued on the normal-priority stream, takes its workgroup slots first.  Released
+            # by zero_grad() -- i.e. queued BEFORE the backward pass was -- the sweep's 256 workgroups were on the CUs first
+            # whenever the host ran just ahead of the GPU, and the logits kernel ran at half occupancy next to them: emulated
+            # W = 8 step 4.7 instead of 4.2 ms.  (bench.py's profiling events happened to delay the sweep the same way, which
+            # is why the bench line never showed it: round 5.)
+            self._hold_for_logits = bool(hold_sweep) and _RELEASE_AT_LOGITS
+            if self._hold_for_logits:
+                ops.held_sweeps.add(self)
         else:
             self._sweep_pending = None
             launch_sweep()
@@ -420,11 +433,14 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._plan_ready = ready if self._plans_pending else None
         self._begun = begun
 
-    def release_sweep(self) -> None:
-        """Start the table sweep a forward-announced step held back (see _begin_overlapped); no-op otherwise."""
+    def release_sweep(self, after: Optional[torch.cuda.Event] = None) -> None:
+        """Start the table sweep a forward-announced step held back (see _begin_overlapped); no-op otherwise.
+        `after`: an event on the caller's stream the sweep is ordered behind, instead of everything queued so far."""
         pending, self._sweep_pending = getattr(self, "_sweep_pending", None), None
+        self._hold_for_logits = False
+        ops.held_sweeps.discard(self)
         if pending is not None:
-            pending(True)
+            pending(True, after)
 
     # The sweep saturates HBM for as long as it lasts, and everything that runs next to it is stretched 2-3x.  When the
     # sweep IS the step (headline shape: 5.0 of 5.3 ms) that is free; when the forward/backward chain is as long as the
@@ -668,7 +684,8 @@ class DenseExactAdam(torch.optim.Optimizer):
         for p in self._tables:
             p._tt_rowgrads.clear()
         super().zero_grad(set_to_none=set_to_none)
-        self.release_sweep()
+        if not getattr(self, "_hold_for_logits", False):
+            self.release_sweep()
         if self._begun is not None and not torch.cuda.is_current_stream_capturing():
             self._launch_plans(side=True)
         if (self.overlap_sweep and self._begun is None and any(p._tt_lookups for p in self._tables)
