@@ -418,7 +418,10 @@ def _timed_train(name, device, steps, warmup, lazy=False, fresh_ids=False, stead
     import ctypes as C
     from two_tower_models_amd import _native as N
     lib = N.load()
-    lib.tt_profile_enable(1)
+    # the library's per-kernel HIP events only where the line's roofline is a KERNEL's (the base models' table sweep); the
+    # history model's is the whole step's flops, and an event pair around every attention / projection kernel of a 64-kernel
+    # step costs it 3 - 5 % (3.49 vs 3.35 ms: the events end the overlap between consecutive kernels)
+    lib.tt_profile_enable(1 if (cfg["model"] == "base" and not lazy) else 0)
     import gc
     gc.collect()
     gc.disable()  # a cyclic-GC pause inside a 25 ms timed window of a host-bound loop is a 30 % error (seen: 1.38 vs 1.75 ms)
@@ -684,6 +687,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--spinup", type=int, default=40,
+                    help="untimed steps BEFORE the --warmup ones: a process's first ~0.2 s of GPU work runs at cold clocks (the same "
+                         "sweep kernel 5.8 ms instead of 5.3 in a window that starts at step 6 of the process)")
     ap.add_argument("--workload", default="P", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
@@ -829,6 +835,8 @@ def main():
         else:
             step(batches[i % len(batches)])
 
+    for i in range(args.spinup):
+        run(i)
     for i in range(args.warmup):
         run(i)
     barrier()
@@ -913,7 +921,7 @@ def main():
             "metric": ("user-item pairs/sec (in-batch softmax train step: fwd + zero_grad + bwd + dense-exact Adam)"
                        if args.phase == "step" else f"user-item pairs/sec, {args.phase} only (secondary figure, SURVEY 8d)")
                       + (" [value-exact DEFERRED Adam: K steps + flush; not the headline schedule]" if args.adam == "lazy" else ""),
-            "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps": args.spinup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: TwoTowerBaseRetrieval train step, N_u={cfg['n_users']}, "
