@@ -421,6 +421,7 @@ def _timed_train(name, device, steps, warmup, lazy=False, fresh_ids=False, stead
     # the library's per-kernel HIP events only where the line's roofline is a KERNEL's (the base models' table sweep); the
     # history model's is the whole step's flops, and an event pair around every attention / projection kernel of a 64-kernel
     # step costs it 3 - 5 % (3.49 vs 3.35 ms: the events end the overlap between consecutive kernels)
+    lib.tt_profile_filter(b"adam_sweep_kernel")
     lib.tt_profile_enable(1 if (cfg["model"] == "base" and not lazy) else 0)
     import gc
     gc.collect()
@@ -517,6 +518,7 @@ def _timed_mips(device, lib, N, Cn=10_000_000, B=1024, K=1000, D=128, reps=3):
             m.use_bf16_storage()
         m.search(q, K)  # warm-up: allocates the workspace
         torch.cuda.synchronize()
+        lib.tt_profile_filter(b"mips_score_kernel")
         lib.tt_profile_enable(1)
         t0 = time.perf_counter()
         for _ in range(reps):
@@ -688,8 +690,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--spinup", type=int, default=40,
-                    help="untimed steps BEFORE the --warmup ones: a process's first ~0.2 s of GPU work runs at cold clocks (the same "
-                         "sweep kernel 5.8 ms instead of 5.3 in a window that starts at step 6 of the process)")
+                    help="untimed steps per spin-up block BEFORE the --warmup ones (blocks repeat until two agree to 1 %%, at most 12; "
+                         "0 = none): the first process on an idle box starts at cold clocks")
     ap.add_argument("--workload", default="P", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
@@ -835,11 +837,29 @@ def main():
         else:
             step(batches[i % len(batches)])
 
-    for i in range(args.spinup):
-        run(i)
+    # Spin-up (untimed, before the contract's warm-up): blocks of --spinup steps until two consecutive blocks agree to 1 %,
+    # at most 12 blocks.  The first process on a box that has sat idle runs its first second(s) of GPU work at a lower
+    # memory clock: the same binary measured 5.77 / 5.93 ms in a window starting 0.3 s into the process and 5.39 / 5.44
+    # ms for the same shape half a minute later in the same process (round 5).
+    spun, last = 0, None
+    while args.spinup > 0 and spun < 12 * args.spinup:
+        torch.cuda.synchronize()
+        t_blk = time.perf_counter()
+        for i in range(args.spinup):
+            run(spun + i)
+        torch.cuda.synchronize()
+        t_blk = time.perf_counter() - t_blk
+        spun += args.spinup
+        # (N > 1: every rank must run the SAME number of steps -- the collectives pair up -- so no rank-local decision: 2 blocks)
+        if (world > 1 and spun >= 2 * args.spinup) or (world == 1 and last is not None and abs(t_blk - last) <= 0.01 * last):
+            break
+        last = t_blk
     for i in range(args.warmup):
         run(i)
     barrier()
+    # HIP events around the kernels this line reports, and ONLY those (tt_profile_filter: an event pair changes what runs next
+    # to what): the sweep / the deferred flush, and the backward logits kernel that takes over the roofline when it dominates
+    lib.tt_profile_filter(b"adam_flush_kernel" if args.adam == "lazy" else b"adam_sweep_kernel,ce_bwd_kernel")
     lib.tt_profile_enable(1)
     if use_sharded:
         collectives.comm_timing(True)  # per-exchange events over the timed steps -> `comm.ms_per_step` below
@@ -921,7 +941,7 @@ def main():
             "metric": ("user-item pairs/sec (in-batch softmax train step: fwd + zero_grad + bwd + dense-exact Adam)"
                        if args.phase == "step" else f"user-item pairs/sec, {args.phase} only (secondary figure, SURVEY 8d)")
                       + (" [value-exact DEFERRED Adam: K steps + flush; not the headline schedule]" if args.adam == "lazy" else ""),
-            "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps": args.spinup,
+            "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps": spun,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: TwoTowerBaseRetrieval train step, N_u={cfg['n_users']}, "

@@ -51,6 +51,10 @@ const char* tt_last_error_string(void);
  * events and returns the summed duration and the launch count. */
 int tt_profile_enable(int on);
 int tt_profile_read(const char* kernel, double* total_ms, int64_t* launches);
+/* Bracket only the named kernels ("a,b,c"; NULL or "" = all of them again).  An event pair ends the overlap between the
+ * kernel and its neighbours on the stream and delays what follows it by a few microseconds -- enough to change which of
+ * two streams' kernels reaches the CUs first -- so a measurement brackets the kernel it reports and nothing else. */
+int tt_profile_filter(const char* kernels);
 
 /* ---------------------------------------------------------------- K1 gather
  * out[i, 0:dim] = table[ids[i], 0:dim]          (out row stride ld_out >= dim)

@@ -118,6 +118,7 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False,
         else:
             for i in range(max(warmup, 230)):  # covers the optimiser's group-wide sweep-level scan (optim._tune_sweep_group)
                 step(batches[i % 8], batches[(i + 1) % 8])
+        lib.tt_profile_filter(b"ce_fwd_kernel,ce_bwd_kernel,adam_sweep_kernel")
         lib.tt_profile_enable(0 if os.environ.get("EMU_NO_PROF") else 1)
         host_ms, ms = _time_steps(step, batches, steps)
         if verbose and os.environ.get("EMU_FORCE_LEVELS"):  # measurement aid: the same process, the level pinned by hand

@@ -16,6 +16,7 @@ struct Slot {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
 };
 bool g_on = false;
+std::string g_only;  // "" = every bracketed kernel; else ",name,name," (tt_profile_filter)
 std::vector<Slot> g_slots;
 Slot& slot_for(const char* name) {
   for (auto& s : g_slots)
@@ -32,6 +33,7 @@ void clear_all() {
 
 ProfScope::ProfScope(const char* name, hipStream_t st) : st_(st), slot_(-1), idx_(-1) {
   if (!g_on) return;
+  if (!g_only.empty() && g_only.find("," + std::string(name) + ",") == std::string::npos) return;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
   Slot& s = slot_for(name);
@@ -51,6 +53,11 @@ ProfScope::~ProfScope() {
 extern "C" int tt_profile_enable(int on) {
   tt::clear_all();
   tt::g_on = on != 0;
+  return 0;
+}
+
+extern "C" int tt_profile_filter(const char* kernels) {
+  tt::g_only = (kernels && *kernels) ? "," + std::string(kernels) + "," : std::string();
   return 0;
 }
 
