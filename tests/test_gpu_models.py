@@ -417,6 +417,41 @@ def test_forked_item_tower_keeps_its_batch_tensors_from_the_allocator(golden, mo
             assert torch.equal(got[n], want[n]), n
 
 
+def test_profile_filter_brackets_only_the_named_kernels(golden):
+    """tt_profile_filter: a measurement puts HIP events around the kernel it reports and around nothing else (an event pair
+    delays what follows it; bench.py's events once decided which of two streams' kernels reached the CUs first)."""
+    import ctypes as C
+
+    import two_tower_models_amd as A
+    from two_tower_models_amd import _native as N
+    lib = N.load()
+    g = golden("g2_base_aligned")
+    model = make_model("base", g)
+    opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep="forward")
+
+    def counts(filt):
+        lib.tt_profile_filter(filt)
+        lib.tt_profile_enable(1)
+        loss = model.train_forward(*batch_of(g))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        out = {}
+        for k in (b"adam_sweep_kernel", b"ce_bwd_kernel"):
+            ms, n = C.c_double(0.0), C.c_int64(0)
+            N.check(lib.tt_profile_read(k, C.byref(ms), C.byref(n)), "tt_profile_read")
+            out[k] = n.value
+        lib.tt_profile_enable(0)
+        lib.tt_profile_filter(None)
+        return out
+
+    only = counts(b"adam_sweep_kernel")
+    assert only[b"adam_sweep_kernel"] == 1 and only[b"ce_bwd_kernel"] == 0
+    both = counts(None)
+    assert both[b"adam_sweep_kernel"] == 1 and both[b"ce_bwd_kernel"] >= 1
+
+
 @pytest.mark.parametrize("name", ["g4_hist_d128", "g4_hist_tiny"])
 def test_history_model_matches_reference(golden, name):
     g = golden(name)
