@@ -591,6 +591,12 @@ def secondary(device, lib, N):
         sec["C1"]["cpu_baseline"] = cpu_baseline_small("tiny", n_steps=50)
     except Exception as e:
         sec["C1"] = {"error": f"{type(e).__name__}: {e}"}
+    try:  # the same shape with the whole dense-exact step replayed as ONE hipGraph: C1 is bound by the host's ~40 launches per step
+        sec["C1_graphed"] = _timed_train("tiny", device, 400, 20, graph=True)
+        sec["C1_graphed"]["note"] = ("GraphedTrainStep (forward + backward + dense-exact Adam with its side-stream sweep as a graph "
+                                     "branch), bit-identical to the eager step: tests/test_gpu_models.py::test_graphed_train_step_*")
+    except Exception as e:
+        sec["C1_graphed"] = {"error": f"{type(e).__name__}: {e}"}
     try:  # BASELINE config 4's table (100 M items, 155 GB of p, m, v) on ONE MI355X: what each of 8 ranks sweeps is 1/8 of it
         sec["C4_1gpu"] = _timed_train("C4", device, 6, 6)
     except Exception as e:
