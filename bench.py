@@ -848,7 +848,7 @@ def main():
     # memory clock: the same binary measured 5.77 / 5.93 ms in a window starting 0.3 s into the process and 5.39 / 5.44
     # ms for the same shape half a minute later in the same process (round 5).
     spun, last = 0, None
-    while args.spinup > 0 and spun < 12 * args.spinup:
+    while args.spinup > 0 and spun < int(os.environ.get('TT_BENCH_SPIN_BLOCKS', '12')) * args.spinup:
         torch.cuda.synchronize()
         t_blk = time.perf_counter()
         for i in range(args.spinup):
@@ -856,8 +856,10 @@ def main():
         torch.cuda.synchronize()
         t_blk = time.perf_counter() - t_blk
         spun += args.spinup
+        if os.environ.get("TT_BENCH_DEBUG"):
+            print(f"[bench] spin-up block ending at step {spun}: {t_blk / args.spinup * 1e3:.3f} ms/step", file=sys.stderr)
         # (N > 1: every rank must run the SAME number of steps -- the collectives pair up -- so no rank-local decision: 2 blocks)
-        if (world > 1 and spun >= 2 * args.spinup) or (world == 1 and last is not None and abs(t_blk - last) <= 0.01 * last):
+        if (world > 1 and spun >= 2 * args.spinup) or (world == 1 and last is not None and abs(t_blk - last) <= 0.01 * last and not os.environ.get('TT_BENCH_DEBUG')):
             break
         last = t_blk
     for i in range(args.warmup):
