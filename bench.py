@@ -418,11 +418,11 @@ def _timed_train(name, device, steps, warmup, lazy=False, fresh_ids=False, stead
     import ctypes as C
     from two_tower_models_amd import _native as N
     lib = N.load()
-    # the library's per-kernel HIP events only where the line's roofline is a KERNEL's (the base models' table sweep); the
-    # history model's is the whole step's flops, and an event pair around every attention / projection kernel of a 64-kernel
-    # step costs it 3 - 5 % (3.49 vs 3.35 ms: the events end the overlap between consecutive kernels)
-    lib.tt_profile_filter(b"adam_sweep_kernel")
-    lib.tt_profile_enable(1 if (cfg["model"] == "base" and not lazy) else 0)
+    # no library profiling events here: an event pair around every attention / projection kernel of a 64-kernel step costs
+    # it 3 - 5 % (3.49 vs 3.35 ms: the events end the overlap between consecutive kernels)
+    lib.tt_profile_enable(0)
+    if not lazy:
+        opt.keep_sweep_events(True)  # the sweep's launch duration from the optimiser's own event pair: no extra events
     import gc
     gc.collect()
     gc.disable()  # a cyclic-GC pause inside a 25 ms timed window of a host-bound loop is a 30 % error (seen: 1.38 vs 1.75 ms)
@@ -443,8 +443,9 @@ def _timed_train(name, device, steps, warmup, lazy=False, fresh_ids=False, stead
     finally:
         gc.enable()
     sw_ms, sw_cnt = C.c_double(0.0), C.c_int64(0)
-    N.check(lib.tt_profile_read(b"adam_sweep_kernel", C.byref(sw_ms), C.byref(sw_cnt)), "tt_profile_read")
-    lib.tt_profile_enable(0)
+    if not lazy:
+        sw_ms.value, sw_cnt.value = opt.sweep_launch_ms()
+        opt.keep_sweep_events(False)
     executed, survey = step_flops(cfg)
     ms_step = dt / steps * 1e3
     if lazy:
@@ -867,8 +868,11 @@ def main():
     barrier()
     # HIP events around the kernels this line reports, and ONLY those (tt_profile_filter: an event pair changes what runs next
     # to what): the sweep / the deferred flush, and the backward logits kernel that takes over the roofline when it dominates
-    lib.tt_profile_filter(b"adam_flush_kernel" if args.adam == "lazy" else b"adam_sweep_kernel,ce_bwd_kernel")
-    lib.tt_profile_enable(1)
+    # ... the sweep's own launch duration comes from the event pair the optimiser brackets it with anyway (keep_sweep_events)
+    lib.tt_profile_filter(b"adam_flush_kernel" if args.adam == "lazy" else b"ce_bwd_kernel")
+    lib.tt_profile_enable(1 if (args.adam == "lazy" or use_sharded) else 0)
+    if args.adam != "lazy":
+        opt.keep_sweep_events(True)
     if use_sharded:
         collectives.comm_timing(True)  # per-exchange events over the timed steps -> `comm.ms_per_step` below
     import gc
@@ -898,7 +902,11 @@ def main():
     import ctypes as C
     ms, cnt = C.c_double(0.0), C.c_int64(0)
     prof_kernel = b"adam_flush_kernel" if args.adam == "lazy" else b"adam_sweep_kernel"
-    N.check(lib.tt_profile_read(prof_kernel, C.byref(ms), C.byref(cnt)), "tt_profile_read")
+    if args.adam == "lazy":
+        N.check(lib.tt_profile_read(prof_kernel, C.byref(ms), C.byref(cnt)), "tt_profile_read")
+    else:
+        ms.value, cnt.value = opt.sweep_launch_ms()
+        opt.keep_sweep_events(False)
     ce_ms, ce_cnt = C.c_double(0.0), C.c_int64(0)
     N.check(lib.tt_profile_read(b"ce_bwd_kernel", C.byref(ce_ms), C.byref(ce_cnt)), "tt_profile_read")
     lib.tt_profile_enable(0)

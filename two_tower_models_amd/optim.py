@@ -146,6 +146,7 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._begun: Optional[Dict[torch.nn.Parameter, _TableStep]] = None
         self._sweep_done: Optional[torch.cuda.Event] = None
         self._side_bufs: Dict[int, torch.Tensor] = {}
+        self._sweep_events = None  # keep_sweep_events(): (start, end) event pairs of the table sweep launches
         self._catchup_last: Dict[int, tuple] = {}  # deferred schedule: table -> (event, stream) of its latest catch-up this step
 
     # state is created lazily, on the parameters' device
@@ -397,6 +398,8 @@ class DenseExactAdam(torch.optim.Optimizer):
             self._sweep_done.record(self._side_stream)
             if self._tune is not None:
                 self._tune[1], self._tune[2] = ev_s0, self._sweep_done
+            if self._sweep_events is not None and ev_s0 is not None and len(self._sweep_events) < 65536:
+                self._sweep_events.append((ev_s0, self._sweep_done))
 
         # A step that gathers MANY rows right after this point (history model: B*H = 205 K random 512-B rows) lets that
         # gather run BEFORE the sweep starts saturating HBM: next to the sweep it took 281 us instead of 105 (round 4
@@ -432,6 +435,21 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._plans_pending = announced is not None and bool(begun)
         self._plan_ready = ready if self._plans_pending else None
         self._begun = begun
+
+    def keep_sweep_events(self, on: bool = True) -> None:
+        """Keep the event pair every table sweep launch is bracketed by anyway (the sweep-width controller's, on the sweep's
+        own stream) so that a caller can report the sweep's launch duration WITHOUT adding events of its own -- an extra
+        pair in front of a kernel that is the step's critical path is not free (C2: 1.17 vs 1.09 ms per step)."""
+        self._sweep_events = [] if on else None
+
+    def sweep_launch_ms(self):
+        """-> (total ms, launches) over the kept events; waits for them."""
+        total, n = 0.0, 0
+        for a, b in self._sweep_events or ():
+            b.synchronize()
+            total += a.elapsed_time(b)
+            n += 1
+        return total, n
 
     def release_sweep(self, after: Optional[torch.cuda.Event] = None) -> None:
         """Start the table sweep a forward-announced step held back (see _begin_overlapped); no-op otherwise.
