@@ -450,6 +450,17 @@ def test_profile_filter_brackets_only_the_named_kernels(golden):
     assert only[b"adam_sweep_kernel"] == 1 and only[b"ce_bwd_kernel"] == 0
     both = counts(None)
     assert both[b"adam_sweep_kernel"] == 1 and both[b"ce_bwd_kernel"] >= 1
+    # ... and the optimiser's OWN event pair around every sweep launch (what bench.py reports: no events added)
+    opt.keep_sweep_events(True)
+    for _ in range(3):
+        loss = model.train_forward(*batch_of(g))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    total, n = opt.sweep_launch_ms()
+    assert n == 3 and 0.0 < total < 100.0
+    opt.keep_sweep_events(False)
+    assert opt.sweep_launch_ms() == (0.0, 0)
 
 
 @pytest.mark.parametrize("name", ["g4_hist_d128", "g4_hist_tiny"])
