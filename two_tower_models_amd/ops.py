@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 import warnings
 from typing import List, Optional, Sequence, Tuple
 
@@ -775,7 +776,7 @@ def kept_logits_supported(U: torch.Tensor, I: torch.Tensor) -> bool:
 
 
 # optimisers whose table sweep waits for the backward logits kernel to be queued (DenseExactAdam._begin_overlapped, hold_sweep)
-held_sweeps: set = set()
+held_sweeps = weakref.WeakSet()
 
 
 def _release_held_sweeps(before_kernel: Optional[torch.cuda.Event]) -> None:
