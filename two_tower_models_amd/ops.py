@@ -57,8 +57,9 @@ _FOLD_ASIDE = True  # (likewise: the composed-weight products of the encoder's f
 _EL_WGRAD_SIDE = True  # (tools/ab_c3.py flips it: the collapsed last layer's weight half on the third stream / in line)
 _CONCURRENT_TOWERS = os.environ.get("TT_TOWERS_SERIAL") is None
 _FORK_MIN_ROWS = 2048  # (tests lower it: the golden batches are small)
-_aux_forks = [0]  # 1 from a fork point to the end of that step's backward pass (0: _ws and the deferred optimiser skip their
-                  # per-stream bookkeeping -- a few current-stream queries per launch, 0.15 ms per step at host-bound shapes)
+_aux_forks = [0]  # forks whose backward pass has not ended yet (two models' steps may interleave; a forward that never gets a
+                  # backward leaves it positive: bookkeeping overhead only).  0: _ws and the deferred optimiser skip their
+                  # per-stream bookkeeping -- a few current-stream queries per launch, 0.15 ms per step at host-bound shapes
 
 
 class AuxFork:
@@ -74,7 +75,10 @@ class AuxFork:
         # (P-shape deferred step: 1.99 vs 1.13 ms) -- hipGraphLaunch pays for every cross-branch edge.
         self.on = _CONCURRENT_TOWERS and dev.type == "cuda" and rows >= _FORK_MIN_ROWS and not torch.cuda.is_current_stream_capturing()
         if self.on:
-            _aux_forks[0] = 1
+            # counted until the end of the backward pass this forward will get; a forward without one (validation loss under
+            # no_grad) keeps the bookkeeping on for the duration of the chain only
+            self.counted = torch.is_grad_enabled()
+            _aux_forks[0] += 1
             self.main, self.aux = torch.cuda.current_stream(dev), N.aux_stream(dev)
             self.at = torch.cuda.Event()
             self.at.record(self.main)
@@ -92,6 +96,8 @@ class AuxFork:
             done = torch.cuda.Event()
             done.record(self.aux)
             self.main.wait_event(done)
+            if not self.counted:
+                _aux_forks[0] = max(_aux_forks[0] - 1, 0)
         return False
 
     def uses(self, *tensors: Optional[torch.Tensor]) -> None:
@@ -135,7 +141,7 @@ class _JoinAuxAfterBackward(torch.autograd.Function):
         dev = g.device
         def done():
             _join_aux(dev)
-            _aux_forks[0] = 0
+            _aux_forks[0] = max(_aux_forks[0] - 1, 0)
 
         torch.autograd.Variable._execution_engine.queue_callback(done)
         return g
