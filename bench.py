@@ -48,7 +48,14 @@ WORKLOADS = {
     # BASELINE config 5's model in TRAINING (its loss head is SURVEY 8f item 2): C3 plus the debias head
     "C5T": dict(n_users=1_000_000, n_items=1_000_000, D=128, F=8, B=4096, H=50, model="debias"),
     "CE": dict(n_users=100_000, n_items=100_000, D=128, F=8, B=8192, H=4, model="base"),
+    # BASELINE config 5 as it is written: TwoTowerWithDebiasing.forward() -> baseline_mips_module top-K = 1000 over a 10 M-row
+    # bf16 corpus; with --gpus N the tables AND the corpus are row-sharded (C / N rows per GPU), every rank brings its own
+    # 1024 users.  An INFERENCE workload: metric = queries/s, a "step" = one model.forward() per rank
+    "C5": dict(n_users=1_000_000, n_items=10_000_000, D=128, F=8, B=1024, H=50, model="debias",
+               mips=dict(C=10_000_000, K=1000, bf16=True)),
     "tiny": dict(n_users=1024, n_items=10_000, D=32, F=8, B=128, H=4, model="base"),
+    # (tests: the C5 line's contract at a size the 1-GPU box runs as two gloo ranks in seconds)
+    "C5tiny": dict(n_users=1024, n_items=10_000, D=128, F=8, B=64, H=6, model="debias", mips=dict(C=20_000, K=100, bf16=True)),
 }
 
 
@@ -74,9 +81,12 @@ def make_batches(cfg, n, device, seed=1234):
 def build_model(cfg, device, seed=0):
     import two_tower_models_amd as A
     torch.manual_seed(seed)
+    mp = cfg.get("mips") or dict(C=1024, K=10, bf16=False)
     with torch.device(device):  # initialise the 5.6 GB of tables directly in HBM
-        mips = A.BaselineMIPSModule(corpus_size=1024, embedding_dim=cfg["D"])
-        kw = dict(num_items=10, user_id_hash_size=cfg["n_users"], user_id_embedding_dim=cfg["D"],
+        mips = A.BaselineMIPSModule(corpus_size=mp["C"], embedding_dim=cfg["D"])
+        if mp["bf16"]:
+            mips.use_bf16_storage()
+        kw = dict(num_items=mp["K"], user_id_hash_size=cfg["n_users"], user_id_embedding_dim=cfg["D"],
                   user_features_size=cfg["F"], item_id_hash_size=cfg["n_items"],
                   item_id_embedding_dim=cfg["D"], item_features_size=cfg["F"],
                   user_value_weights=[1.0], mips_module=mips)
@@ -100,6 +110,102 @@ def pmc_traffic_bytes(path, workload, world):
     if rec is None and "hbm_bytes_per_launch" in data and (workload, world) == ("P", 1):
         rec = data
     return rec.get("hbm_bytes_per_launch") if rec else None
+
+
+def sysfs_clocks():
+    """Current sclk / mclk (MHz) and board power of card 0 from the amdgpu sysfs files ('*' marks the active DPM level);
+    {} where the files are not readable.  Read before and after the timed region: a box that streams slower at the same
+    clocks is a slower box, one that dropped its memory clock is a throttling one."""
+    import glob
+    out = {}
+    for key, name in (("sclk_MHz", "pp_dpm_sclk"), ("mclk_MHz", "pp_dpm_mclk")):
+        for path in sorted(glob.glob(f"/sys/class/drm/card*/device/{name}")):
+            try:
+                for line in open(path):
+                    if "*" in line:
+                        out[key] = int(line.split(":")[1].strip().split("M")[0])
+                break
+            except (OSError, ValueError, IndexError):
+                continue
+    for path in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average")):
+        try:
+            out["power_W"] = round(int(open(path).read()) / 1e6, 1)
+            break
+        except (OSError, ValueError):
+            continue
+    return out
+
+
+def hbm_copy_calibration(lib, N, device, nbytes, launches=7):
+    """The box's own HBM streaming rate, measured in THIS process right after the timed steps: tt_stream_copy (16-byte
+    non-temporal loads / stores, the sweep's width) of a buffer as large as the sweep's footprint -- `nbytes` / 2 read and
+    `nbytes` / 2 written per launch.  Median of `launches` HIP-event pairs.  The guide quotes 6.29 TB/s for this
+    measurement; the sweep's `frac_of_copy` says how the kernel does against what this box can stream at all."""
+    half = int(nbytes // 2) // 16 * 16
+    src = torch.empty(half, dtype=torch.uint8, device=device)
+    dst = torch.empty(half, dtype=torch.uint8, device=device)
+    src.zero_()
+    dst.zero_()
+    evs = []
+    for _ in range(launches + 1):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        N.check(lib.tt_stream_copy(src.data_ptr(), dst.data_ptr(), half, 0, N.stream()), "tt_stream_copy")
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in evs[1:])
+    del src, dst
+    return {"GBps": round(2.0 * half / (ms[len(ms) // 2] * 1e-3) / 1e9, 1), "best_GBps": round(2.0 * half / (ms[0] * 1e-3) / 1e9, 1),
+            "bytes_per_launch": 2 * half, "launches": launches, "median_launch_ms": round(ms[len(ms) // 2], 4)}
+
+
+def mfma_sustained_peak(lib, N, device, dtype, iters=4000):
+    """TFLOP/s of the register-only MFMA loop (tt_mfma_probe: random operands, no LDS, no HBM, no epilogue) in THIS process:
+    what the matrix pipe sustains at this box's power budget -- the ceiling a kernel priced against the spec peak has."""
+    sink = torch.empty(512 * 256, dtype=torch.float32, device=device)
+    N.check(lib.tt_mfma_probe(dtype, 200, sink.data_ptr(), sink.numel(), N.stream()), "tt_mfma_probe")
+    best = 0.0
+    for _ in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        N.check(lib.tt_mfma_probe(dtype, iters, sink.data_ptr(), sink.numel(), N.stream()), "tt_mfma_probe")
+        b.record()
+        b.synchronize()
+        best = max(best, lib.tt_mfma_probe_flops(dtype, iters) / (a.elapsed_time(b) * 1e-3) / 1e12)
+    return round(best, 1)
+
+
+def rccl_identity(device, world):
+    """What the collective library ITSELF reports about the group this process is in (so that "RCCL saw N ranks" can be
+    read off the line): a communicator made by the C ABI's tt_comm_* over the running process group, asked for
+    ncclCommCount / ncclCommUserRank; every rank's device ordinal and PCI bus id, gathered."""
+    import ctypes
+    import torch.distributed as dist
+    from two_tower_models_amd import collectives
+    out = {}
+    try:
+        from two_tower_models_amd.comm import NativeComm
+        c = collectives._NATIVE or NativeComm.from_torch_distributed(device)
+        out["ncclCommUserRank"], out["ncclCommCount"] = c.size()
+        if c is not collectives._NATIVE:
+            c.close()
+    except Exception as e:  # noqa: BLE001
+        out["ncclCommCount"] = f"unavailable ({type(e).__name__}: {e})"
+    bus = "unknown"
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device.index or 0)) == 0:
+            bus = buf.value.decode()
+    except OSError:
+        pass
+    mine = f"rank {dist.get_rank()}: cuda:{device.index} pci {bus} pid {os.getpid()}"
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    out["ranks"] = every
+    out["distinct_pci_bus_ids"] = len({e.split(" pci ")[1].split(" pid")[0] for e in every})
+    return out
 
 
 def algorithmic_sweep_bytes(cfg, world):
@@ -494,7 +600,7 @@ def _timed_train(name, device, steps, warmup, lazy=False, fresh_ids=False, stead
                if fresh_ids else {})}
 
 
-def _timed_mips(device, lib, N, Cn=10_000_000, B=1024, K=1000, D=128, reps=3):
+def _timed_mips(device, lib, N, Cn=10_000_000, B=1024, K=1000, D=128, reps=20):
     """BASELINE config 5 on one GPU: BaselineMIPSModule top-K over a 10 M-row corpus, fp32 and bf16 storage;
     roofline of the dense scoring pass (2*B*C*D flops) from HIP events on its stream."""
     import ctypes as C
@@ -531,9 +637,13 @@ def _timed_mips(device, lib, N, Cn=10_000_000, B=1024, K=1000, D=128, reps=3):
         lib.tt_profile_enable(0)
         products = 3.0 if name == "fp32_split16" else 1.0  # MFMA products the pipe executes per product of the algorithm
         tf = products * 2.0 * B * Cn * D * cnt.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else None
+        sustained = mfma_sustained_peak(lib, N, device, N.TT_F32 if name == "fp32" else N.TT_BF16)
         out[name] = {"queries_per_s": round(B / dt, 1), "ms_per_call": round(dt * 1e3, 3), "C": Cn, "B": B, "K": K, "D": D,
                      "roofline": {"bound": "mfma", "kernel": "mips_pass1_dma_kernel", "achieved": round(tf, 1) if tf else None,
                                   "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4) if tf else None,
+                                  # the register-only MFMA loop of the same dtype, same process, right after these calls: what the
+                                  # pipe sustains at this box's power budget (fp16 ~ bf16: same pipe, same rate)
+                                  "sustained_peak": sustained, "frac_of_sustained": round(tf / sustained, 4) if (tf and sustained) else None,
                                   "avg_launch_ms": round(ms.value / max(cnt.value, 1), 4), "launches": cnt.value,
                                   "algorithmic_flops_per_launch": products * 2.0 * B * Cn * D}}
         if name == "fp32_split16":
@@ -612,6 +722,20 @@ def secondary(device, lib, N):
     except Exception as e:
         sec["emulated_W8"] = {"error": f"{type(e).__name__}: {e}"}
     torch.cuda.empty_cache()
+    for key, wl in (("emulated_W8_C3", "C3"), ("emulated_W8_C4", "C4")):
+        try:
+            # the other two sharded configs sized on the product path: config 3 (B*H = 204 800 history rows routed per rank and
+            # step) and config 4 (12.5 M item rows per rank: sweep-bound again)
+            sec[key] = _emu.emulated(8, wl, steps=20, warmup=25, device=device)
+        except Exception as e:
+            sec[key] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+    try:
+        # BASELINE config 5's 8-GPU form, one rank's kernels (C/8 corpus rows x all 8 x 1024 queries, candidate lists, merge)
+        sec["emulated_W8_mips"] = _emu.emulated_mips(8, device=device)
+    except Exception as e:
+        sec["emulated_W8_mips"] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
     try:
         # EXPLORATORY x deferred schedule: P_lazy with the in-batch logits as split-fp16 products (TT_CE_F16X2 on the module path)
         from two_tower_models_amd import ops as _ops
@@ -662,6 +786,73 @@ def secondary(device, lib, N):
     return sec
 
 
+def timed_c5(cfg, device, world, rank, steps, warmup, sharded, comm_timing=True):
+    """BASELINE config 5: `model.forward(user_id, user_features, user_history)` of TwoTowerWithDebiasing -> top-K = 1000 of a
+    10 M-row bf16 corpus, B = 1024 users per rank.  Row-sharded (`sharded`): tables and corpus in W row blocks behind the
+    same modules (parallel.row_sharded); per call one all-gather of the queries, a local top-K over C / W rows for W*B
+    queries, one all-to-all of the [W, B, K] candidate lists, tt_mips_merge.  Returns this rank's record: wall seconds for
+    `steps` calls, the dense scoring pass' HIP-event time (tt_profile), per-exchange times."""
+    import ctypes as C
+    from two_tower_models_amd import _native as N
+    from two_tower_models_amd import collectives, parallel
+    lib = N.load()
+    mp = cfg["mips"]
+    if sharded:
+        with parallel.row_sharded():
+            model = build_model(cfg, device, seed=1000 + rank)
+        parallel.shard_model_(model)
+    else:
+        model = build_model(cfg, device)
+    model.eval()
+    batches = [b[:3] for b in make_batches(cfg, 4, device, seed=1234 + 1000 * rank)]
+
+    def step(i):
+        with torch.no_grad():
+            return model(*batches[i % len(batches)])
+
+    group = parallel.dist.get_world_size() if sharded else 1  # (tools/bench_emulated_world.py swaps parallel.dist for stand-ins)
+
+    def barrier():
+        if group > 1:
+            parallel.dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(max(warmup, 1)):
+        top = step(i)
+    assert top.shape == (cfg["B"], mp["K"]) and top.dtype == torch.int64
+    barrier()
+    lib.tt_profile_filter(b"mips_score_kernel")
+    lib.tt_profile_enable(1)
+    if sharded and comm_timing:
+        collectives.comm_timing(True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    comm_ms = collectives.comm_timing_summary(steps) if (sharded and comm_timing) else None
+    collectives.comm_timing(False)
+    ms, cnt = C.c_double(0), C.c_int64(0)
+    N.check(lib.tt_profile_read(b"mips_score_kernel", C.byref(ms), C.byref(cnt)), "tt_profile_read")
+    lib.tt_profile_enable(0)
+    rows_local = model.mips_module.corpus.shape[0]
+    n_q = cfg["B"] * group  # queries this rank scores per call (all ranks' queries on its own block)
+    flops = 2.0 * n_q * rows_local * cfg["D"]
+    tf = flops * cnt.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else None
+    peak = MFMA_BF16_PEAK_TF if mp["bf16"] else MFMA_F32_PEAK_TF
+    sustained = mfma_sustained_peak(lib, N, device, N.TT_BF16 if mp["bf16"] else N.TT_F32)
+    roof = {"bound": "mfma", "kernel": "mips_pass1_dma_kernel", "achieved": round(tf, 1) if tf else None, "peak": peak,
+            "unit": "TFLOP/s", "frac": round(tf / peak, 4) if tf else None,
+            "sustained_peak": sustained, "frac_of_sustained": round(tf / sustained, 4) if (tf and sustained) else None,
+            "avg_launch_ms": round(ms.value / max(cnt.value, 1), 4), "launches": cnt.value,
+            "algorithmic_flops_per_launch": flops, "traffic": None,
+            "sustained_peak_note": "sustained_peak = tt_mfma_probe in this process (register-only MFMA loop, random operands: the "
+                                   "pipe at this box's power budget, 0.58-0.66 of the 2.5 PF spec figure on this class of box)"}
+    return {"seconds": dt, "ms_per_call": dt / steps * 1e3, "roofline": roof, "comm_ms": comm_ms,
+            "comm_bytes": dict(parallel.comm_bytes), "corpus_rows_this_rank": rows_local, "queries_scored_per_call_this_rank": n_q,
+            "corpus_dtype": str(model.mips_module.corpus.dtype).replace("torch.", ""), "model": model}
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: re-exec this script as N ranks under
     torch.distributed.run (one rank per GPU, RCCL) on a free local port, pass the ranks' output through
@@ -691,6 +882,60 @@ def self_launch(n: int) -> int:
     return r.returncode if r.returncode != 0 else (0 if js else 1)
 
 
+def main_c5(args, cfg, device, world, rank, dist_backend, use_sharded):
+    """`bench.py --workload C5 [--gpus N]`: queries/s of TwoTowerWithDebiasing.forward() -> top-1000 of a 10 M-row bf16 corpus."""
+    import torch.distributed as dist
+    from two_tower_models_amd import collectives
+    ident = None
+    if use_sharded:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", RANK="0", WORLD_SIZE="1")
+        if dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+            ident = rccl_identity(device, world)
+        else:
+            dist.init_process_group(dist_backend)
+        if args.transport == "native" and world > 1 and dist_backend == "nccl":
+            from two_tower_models_amd.comm import NativeComm
+            collectives.use_native_transport(NativeComm.from_torch_distributed(device))
+    rec = timed_c5(cfg, device, world, rank, args.steps, args.warmup, use_sharded)
+    rec.pop("model")
+    dt = rec["seconds"]
+    rank_ms = None
+    if world > 1:
+        every = collectives.all_gather_rows(torch.tensor([dt], device=device, dtype=torch.float64))
+        rank_ms = {"min": round(float(every.min()) / args.steps * 1e3, 4), "max": round(float(every.max()) / args.steps * 1e3, 4)}
+        dt = float(every.max())
+    if rank == 0:
+        mp = cfg["mips"]
+        out = {"metric": f"queries/sec (TwoTowerWithDebiasing.forward -> baseline_mips_module top-K={mp['K']} over a "
+                         f"{mp['C'] // 1_000_000} M-row {'bf16' if mp['bf16'] else 'fp32'} corpus; BASELINE config 5)",
+               "value": cfg["B"] * world * args.steps / dt, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16" if mp["bf16"] else "f32", "data": "synthetic",
+               "config": {"workload": f"C5: user tower (N_u={cfg['n_users']}, N_i={cfg['n_items']}, D={cfg['D']}, H={cfg['H']} history "
+                                      f"encoder) + MIPS top-{mp['K']} over C={mp['C']} rows, B={cfg['B']} users/GPU",
+                          "global_batch": cfg["B"] * world,
+                          "parallelism": "single GPU" if not use_sharded else
+                          f"tables and corpus row-sharded x{world} behind the module API (C/{world} = {rec['corpus_rows_this_rank']} corpus "
+                          f"rows per GPU, every GPU scores all {rec['queries_scored_per_call_this_rank']} queries on its block), "
+                          + ("RCCL" if dist_backend == "nccl" else dist_backend)},
+               "roofline": rec["roofline"], "n_ranks": world if use_sharded else 1,
+               "dist_backend": dist.get_backend() if use_sharded else None, "rccl": ident,
+               "comm": {"bytes_sent_per_rank_per_call": rec["comm_bytes"], "ms_per_call": rec["comm_ms"],
+                        "exposed_ms_per_call_total": round(sum(v["exposed_ms"] for v in (rec["comm_ms"] or {}).values()), 4)}
+               if use_sharded else None,
+               "rank_ms_per_step": rank_ms, "cpu_baseline": None}
+        result = json.dumps(out)
+    if use_sharded:
+        collectives.use_native_transport(None)
+        dist.destroy_process_group()
+    if rank == 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(result, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -699,7 +944,9 @@ def main():
     ap.add_argument("--spinup", type=int, default=40,
                     help="untimed steps per spin-up block BEFORE the --warmup ones (blocks repeat until two agree to 1 %%, at most 12; "
                          "0 = none): the first process on an idle box starts at cold clocks")
-    ap.add_argument("--workload", default="P", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="P", choices=sorted(WORKLOADS),
+                    help="P: the headline train step.  C5: BASELINE config 5's inference (queries/s of model.forward() -> top-1000 of "
+                         "a 10 M-row bf16 corpus; --gpus N row-shards tables and corpus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` object (C2 / C3 / deferred-Adam train steps, config 5 MIPS) the default "
@@ -751,6 +998,8 @@ def main():
 
     use_sharded = world > 1 or args.sharded
     n_ranks, dist_backend_seen = 1, None
+    if cfg.get("mips"):  # BASELINE config 5: an inference workload with its own metric
+        return main_c5(args, cfg, device, world, rank, dist_backend, use_sharded)
     if use_sharded and (args.adam != "dense" or args.fresh_ids or args.phase != "step" or args.graph):
         raise SystemExit("--adam lazy / --fresh-ids / --phase / --graph apply to the single-GPU module path")
     check = watchdog = None
@@ -848,8 +1097,8 @@ def main():
     # at most 12 blocks.  The first process on a box that has sat idle runs its first second(s) of GPU work at a lower
     # memory clock: the same binary measured 5.77 / 5.93 ms in a window starting 0.3 s into the process and 5.39 / 5.44
     # ms for the same shape half a minute later in the same process (round 5).
-    spun, last = 0, None
-    while args.spinup > 0 and spun < int(os.environ.get('TT_BENCH_SPIN_BLOCKS', '12')) * args.spinup:
+    spun, last, spin_blocks_ms = 0, None, []
+    while args.spinup > 0 and spun < 12 * args.spinup:
         torch.cuda.synchronize()
         t_blk = time.perf_counter()
         for i in range(args.spinup):
@@ -857,10 +1106,9 @@ def main():
         torch.cuda.synchronize()
         t_blk = time.perf_counter() - t_blk
         spun += args.spinup
-        if os.environ.get("TT_BENCH_DEBUG"):
-            print(f"[bench] spin-up block ending at step {spun}: {t_blk / args.spinup * 1e3:.3f} ms/step", file=sys.stderr)
+        spin_blocks_ms.append(round(t_blk / args.spinup * 1e3, 4))  # -> the line's `spinup_ms_per_step_by_block`
         # (N > 1: every rank must run the SAME number of steps -- the collectives pair up -- so no rank-local decision: 2 blocks)
-        if (world > 1 and spun >= 2 * args.spinup) or (world == 1 and last is not None and abs(t_blk - last) <= 0.01 * last and not os.environ.get('TT_BENCH_DEBUG')):
+        if (world > 1 and spun >= 2 * args.spinup) or (world == 1 and last is not None and abs(t_blk - last) <= 0.01 * last):
             break
         last = t_blk
     for i in range(args.warmup):
@@ -878,6 +1126,7 @@ def main():
     import gc
     gc.collect()
     gc.disable()  # no cyclic-GC pause inside the timed region (the loop allocates no cycles that would need it)
+    clocks_before = sysfs_clocks()
     t0 = time.perf_counter()
     for i in range(args.steps):
         run(args.warmup + i)
@@ -885,6 +1134,7 @@ def main():
         opt.flush()  # every deferred row update is paid for inside the timed region
     barrier()
     dt = time.perf_counter() - t0
+    clocks_after = sysfs_clocks()
     gc.enable()
     comm_ms = None
     rank_ms = None
@@ -911,6 +1161,7 @@ def main():
     N.check(lib.tt_profile_read(b"ce_bwd_kernel", C.byref(ce_ms), C.byref(ce_cnt)), "tt_profile_read")
     lib.tt_profile_enable(0)
 
+    ident = rccl_identity(device, world) if (use_sharded and dist_backend == "nccl") else None
     if rank == 0:
         B = cfg["B"]
         pairs = B * world * args.steps
@@ -939,6 +1190,18 @@ def main():
                     "launches": cnt.value,
                     "avg_launch_ms": round(ms.value / cnt.value, 4),
                     "algorithmic_bytes_per_launch": sweep_bytes_step * args.steps / cnt.value}
+            # the box's own streaming rate, measured here and now (a copy as large as the sweep's footprint, same process, same
+            # allocator state, right after the timed steps), and the clocks on both sides of the timed region: a line whose
+            # `frac` moved can be attributed -- `frac_of_copy` moves with the code, `hbm_copy_GBps` with the box
+            try:
+                cal = hbm_copy_calibration(lib, N, device, min(sweep_bytes_step, 40e9))
+                roof.update(hbm_copy_GBps=cal["GBps"], hbm_copy_best_GBps=cal["best_GBps"],
+                            frac_of_copy=round(achieved / cal["GBps"], 4), hbm_copy=cal)
+            except Exception as e:  # noqa: BLE001
+                roof["hbm_copy_GBps"] = f"unavailable ({type(e).__name__}: {e})"
+            roof["clocks"] = {"before": clocks_before, "after": clocks_after}
+            roof["sweep_workgroups"] = opt._sweep_wgs or 768
+            roof["sweep_level_decided_by"] = opt.sweep_level_note()
             # With the tables sharded over many GPUs the sweep shrinks 1/N while the global-negative
             # logits grow N-fold: report whichever kernel family actually dominates the step.
             if ce_cnt.value > 0 and ce_ms.value > ms.value:
@@ -958,6 +1221,7 @@ def main():
                        if args.phase == "step" else f"user-item pairs/sec, {args.phase} only (secondary figure, SURVEY 8d)")
                       + (" [value-exact DEFERRED Adam: K steps + flush; not the headline schedule]" if args.adam == "lazy" else ""),
             "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps": spun,
+            "spinup_ms_per_step_by_block": spin_blocks_ms,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: TwoTowerBaseRetrieval train step, N_u={cfg['n_users']}, "
@@ -970,7 +1234,7 @@ def main():
                        + ("RCCL" if dist_backend == "nccl" else dist_backend)},
             "roofline": roof,
             # what the collective library itself reports (1 when no process group was needed)
-            "n_ranks": n_ranks, "dist_backend": dist_backend_seen,
+            "n_ranks": n_ranks, "dist_backend": dist_backend_seen, "rccl": ident,
         }
         # tuned kernels that did NOT run for this shape, each with the constraint that ruled it out ({} = all taken)
         from two_tower_models_amd import ops as _ops

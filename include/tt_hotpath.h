@@ -456,6 +456,16 @@ int tt_pack_grads(const tt_adam_tensor* tensors /*host*/, int32_t n_tensors, tt_
  * launch -- `p` = destination, `g` = source, `n` = BYTES (any dtype), m / v ignored.  Replaces the seven `.to(device)` /
  * copy_ calls of ref:train/train.py:91-99 per step. */
 int tt_copy_buffers(const tt_adam_tensor* buffers /*host*/, int32_t n_buffers, tt_stream_t stream);
+/* Measurement aid (bench.py `roofline.hbm_copy_GBps`; no counterpart in the reference): the plain HBM streaming copy --
+ * 16-byte non-temporal loads and stores, `n_wgs` persistent workgroups (0 = 768, the table sweep's default width) --
+ * that calibrates what THIS box's HBM streams next to the sweep's own figure.  `bytes` are read and `bytes` written. */
+int tt_stream_copy(const void* src, void* dst, int64_t bytes, int32_t n_wgs, tt_stream_t stream);
+/* Measurement aid (bench.py `roofline.sustained_peak`): a register-only MFMA loop on random operands over the whole chip
+ * (512 workgroups x 4 waves x `iters` x 4 independent 32x32 MFMAs; dtype 0 = fp32 32x32x2, 1 = bf16 32x32x16 -- TT_F32 /
+ * TT_BF16 below) -- what the matrix pipe of THIS box sustains at its power budget, which is what a kernel priced against
+ * the spec peak can reach at most.  tt_mfma_probe_flops = the flops one launch executes; time it with events. */
+int64_t tt_mfma_probe_flops(int dtype, int32_t iters);
+int tt_mfma_probe(int dtype, int32_t iters, float* sink /* >= 131072 floats */, int64_t sink_floats, tt_stream_t stream);
 
 /* ---------------------------------------------------------------- K4 history encoder pieces
  * tt_hist_embed_pool: x[b,h,:] = table[ids[b,h],:] (+ pe[h,:]);  pooled[b,:] = mean_h table[ids[b,h],:]
@@ -618,6 +628,9 @@ int tt_f32_to_bf16(const float* in, uint16_t* out, int64_t n, tt_stream_t stream
 int tt_mips_split_rows(const float* X, int64_t rows, int64_t D, uint16_t* out, float* scale, void* ws, int64_t ws_bytes,
                        tt_stream_t stream);
 int tt_mips_unscale(float* scores, int64_t n, const float* scale_a, const float* scale_b, tt_stream_t stream);
+/* corpus[idx] for a bf16 corpus (ref:src/baseline_mips_module.py:63-69), rows widened exactly to fp32.  Ids outside
+ * [0, n_rows) produce zero rows and set *oob_flag; oob_flag may be NULL (the owner side of a row-sharded corpus: the
+ * padding slots of the fixed-size exchange carry the sentinel n_rows on purpose, like tt_gather_rows). */
 int tt_gather_rows_bf16(const uint16_t* table, int64_t n_rows, int64_t dim, const int64_t* ids,
                         int64_t n_ids, float* out, int64_t ld_out, int32_t* oob_flag,
                         tt_stream_t stream);

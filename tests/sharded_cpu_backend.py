@@ -39,7 +39,7 @@ class OracleRouteKernels:
     def gather_owned(self, table, local, n_local):
         out = torch.zeros(local.numel(), table.shape[1])
         mine = (local >= 0) & (local < n_local)
-        out[mine] = table[local[mine]]
+        out[mine] = table[local[mine]].float()
         return out
 
 

@@ -104,3 +104,35 @@ def test_sharded_module_path_at_world1_matches_the_single_gpu_headline():
     comm = sh["comm"]
     assert comm["ms_per_step"] and "lookup_rows_alltoall" in comm["ms_per_step"] and comm["schedule"]["sweep_workgroups"] > 0
     assert mod["roofline"]["traffic"] is not None  # profiles/pmc_traffic.json resolves for the default workload
+    # the line explains itself: the box's own streaming-copy rate measured in the same process, the
+    # sweep against it, the clocks on both sides of the timed region, the sweep width that ran
+    roof = mod["roofline"]
+    assert 3000 < roof["hbm_copy_GBps"] < 8000 and abs(roof["frac_of_copy"] - roof["achieved"] / roof["hbm_copy_GBps"]) < 2e-3
+    assert 0.85 < roof["frac_of_copy"] < 1.2, roof  # the sweep streams what this box can stream
+    assert set(roof["clocks"]) == {"before", "after"} and roof["sweep_workgroups"] > 0
+    # what RCCL itself says about the group
+    assert sh["rccl"]["ncclCommCount"] == 1 and len(sh["rccl"]["ranks"]) == 1 and "pci" in sh["rccl"]["ranks"][0]
+
+
+def test_config5_line_single_gpu_and_two_ranks():
+    """`bench.py --workload C5 [--gpus N]` (BASELINE config 5 as written: TwoTowerWithDebiasing.forward() -> top-K of a bf16
+    corpus, tables and corpus row-sharded with N > 1), at the test-sized twin of the workload: the driver's keys, queries/s,
+    the scoring pass' roofline with `sustained_peak`, per-exchange times for the sharded search."""
+    def run(gpus):
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", str(gpus), "--workload", "C5tiny", "--steps", "3", "--warmup", "1"],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=900, stdin=subprocess.DEVNULL)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return _last_json(r.stdout)
+    one = run(1)
+    assert KEYS <= set(one) and one["unit"] == "queries/s" and one["dtype"] == "bf16" and one["n_gpus"] == 1
+    assert abs(one["value"] - 64 * 3 / (one["ms_per_step"] * 3e-3)) < 1e-6 * one["value"]
+    roof = one["roofline"]
+    assert roof["bound"] == "mfma" and roof["launches"] == 3 and roof["sustained_peak"] > 100
+    two = run(2)
+    assert two["n_gpus"] == 2 and two["config"]["global_batch"] == 128 and "row-sharded x2" in two["config"]["parallelism"]
+    assert two["roofline"]["launches"] == 3 and two["roofline"]["algorithmic_flops_per_launch"] == 2.0 * 128 * 10_000 * 128
+    comm = two["comm"]
+    assert {"mips_queries_allgather", "mips_lists_alltoall"} <= set(comm["ms_per_call"])
+    assert {"mips_queries_allgather", "mips_lists_alltoall"} <= set(comm["bytes_sent_per_rank_per_call"])
+    assert two["rank_ms_per_step"]["max"] >= two["rank_ms_per_step"]["min"] > 0

@@ -331,7 +331,7 @@ def test_c2_whole_train_step_vs_oracle():
         noise_only = k in ("item_tower_arch.bias", "item_features_arch.2.bias")
         # Adam's first updates are lr * g / (|g| + eps): the few elements whose gradient happens to be ~1e-4 of the
         # typical size turn a 1e-7 relative summation-order difference into a ~1e-5 step difference (any two fp32
-        # implementations do; tests/test_gpu_sharded.py).  So: all but <= 0.2 % of the elements within 5e-6, every
+        # implementations do; tests/test_gpu_parallel.py).  So: all but <= 0.2 % of the elements within 5e-6, every
         # element within the steps * lr bound.
         err = (v.cpu() - params[k]).abs()
         assert float(err.max()) <= 2 * 2 * 1e-3 * 1.05, (k, float(err.max()))

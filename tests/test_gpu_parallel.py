@@ -260,28 +260,79 @@ def test_sharded_modules_equal_reference_on_concatenated_batch(world, case, back
         assert sum(r["shards"][name][1] - r["shards"][name][0] for r in res) == n
 
 
-# ------------------------------------------------------------------ sharded MIPS (BASELINE config 5) on the product kernels
-def _mips_worker(rank, world, port, outdir, C, K, backend="gloo"):
+# ------------------------------------------------------------------ sharded MIPS (BASELINE config 5) behind the drop-in API
+def _serve_model(C, D, n_users, how, dev):
+    """TwoTowerWithDebiasing (BASELINE config 5's model) whose user tower is the identity on the id embedding, so that
+    forward()'s query embeddings are EXACTLY the user table's rows (x * 1 + 0 * anything): with the exact-arithmetic
+    corpus / queries of fixture_gen the top-K then has one right answer, bit for bit."""
+    import contextlib
+    import fixture_gen as fg
+    import two_tower_models_amd as A
+    from two_tower_models_amd import parallel
+    torch.manual_seed(0)
+    ctx = parallel.row_sharded() if how == "born" else contextlib.nullcontext()
+    with ctx:
+        mips = A.BaselineMIPSModule(corpus_size=C, embedding_dim=D)
+        model = A.TwoTowerWithDebiasing(num_items=1, user_id_hash_size=n_users, user_id_embedding_dim=D, user_features_size=8,
+                                        user_history_seqlen=4, item_id_hash_size=50, item_id_embedding_dim=D, item_features_size=8,
+                                        user_value_weights=[1.0], mips_module=mips)
+    model = model.to(dev)
+    if how == "cut":  # every rank holds the whole corpus; shard_model_ keeps its block
+        model.mips_module.corpus = torch.from_numpy(fg.exact_mips_corpus(C, D)).to(dev)
+    parallel.shard_model_(model)
+    queries = torch.from_numpy(fg.exact_mips_queries(n_users, D))
+    sd = parallel.full_state_dict(model)
+    sd["user_id_embedding_arch.weight"] = queries
+    w = torch.zeros_like(sd["user_tower_arch.weight"])
+    w[:, :D] = torch.eye(D)
+    sd["user_tower_arch.weight"], sd["user_tower_arch.bias"] = w, torch.zeros(D)
+    parallel.load_full_state_dict(model, sd)
+    return model, queries
+
+
+def _mips_worker(rank, world, port, outdir, C, K, D, bf16, how, backend="gloo"):
     _paths()
     import torch.distributed as dist
     import fixture_gen as fg
     from two_tower_models_amd import parallel
     dev = init_pg(backend, rank, world, port)
     try:
-        corpus = torch.from_numpy(fg.exact_mips_corpus(C, 64))
-        lo, hi = parallel.ShardedMIPS.block_range(C, rank, world)
-        m = parallel.ShardedMIPS(corpus[lo:hi].to(dev), lo)
-        q = torch.from_numpy(fg.exact_mips_queries(6 * world, 64))[rank * 6:(rank + 1) * 6]
-        idx, sc = m.search(q.to(dev), K)
-        torch.save({"idx": idx.cpu(), "sc": sc.cpu()}, os.path.join(outdir, f"mips{rank}.pt"))
+        n_users, B = 64, 6
+        model, _ = _serve_model(C, D, n_users, how, dev)
+        m = model.mips_module
+        corpus = torch.from_numpy(fg.exact_mips_corpus(C, D))
+        _, lo, hi = parallel.block_range(C, rank, world)
+        if how == "born":
+            assert m.is_sharded() and m.corpus.shape[0] == hi - lo
+            m.set_corpus(corpus[lo:hi].to(dev), bf16=bf16)
+        elif bf16:
+            m.use_bf16_storage()
+        assert m.is_sharded() and m.corpus_size == C and m.corpus.shape[0] == hi - lo and m.corpus.is_cuda
+        assert m.corpus.dtype == (torch.bfloat16 if bf16 else torch.float32)
+        model.num_items = K
+        g = torch.Generator().manual_seed(100 + rank)
+        uid = torch.randint(0, n_users, (B,), generator=g)
+        batch = (uid.to(dev), torch.randn(B, 8, generator=g).to(dev), torch.randint(0, 50, (B, 4), generator=g).to(dev))
+        with torch.no_grad():
+            top = model(*batch)  # TwoTowerWithDebiasing.forward (ref:src/two_tower_base_retrieval.py:221-249), sharded
+            q = model.compute_user_embedding(*batch)
+            idx, sc, emb = m(query_embedding=q, num_items=K)  # the reference's call, 3-tuple
+        torch.save({"uid": uid, "top": top.cpu(), "q": q.cpu(), "idx": idx.cpu(), "sc": sc.cpu(), "emb": emb.cpu(),
+                    "comm": dict(parallel.comm_bytes)}, os.path.join(outdir, f"mips{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,C,K,backend", [(1, 5000, 100, "nccl1"), (2, 9000, 100, "gloo"), (3, 200, 80, "gloo"),
-                                               (4, 5, 3, "gloo"),  # the last rank's corpus block is empty
-                                               (2, 9000, 100, "nccl"), ("all", 9000, 100, "nccl")])
-def test_multi_rank_sharded_mips(world, C, K, backend):
+@pytest.mark.parametrize("world,C,K,D,bf16,how,backend", [
+    (1, 5000, 100, 128, False, "cut", "nccl1"), (2, 9000, 100, 128, False, "born", "gloo"),
+    (2, 9000, 100, 128, True, "cut", "gloo"),
+    (3, 200, 80, 64, True, "born", "gloo"),  # K larger than a block (67 rows), generic-width towers
+    (4, 5, 3, 128, False, "cut", "gloo"),  # the last rank's corpus block is empty
+    (2, 9000, 100, 128, True, "born", "nccl"), ("all", 9000, 100, 128, False, "cut", "nccl")])
+def test_sharded_model_forward_topk_bit_exact(world, C, K, D, bf16, how, backend):
+    """Row N2: `TwoTowerWithDebiasing.forward()` on a row-sharded model (tables AND the MIPS corpus in row blocks) returns
+    oracle.cpu_ref.mips_topk's indices over the WHOLE corpus bit for bit; BaselineMIPSModule.forward's 3-tuple: global
+    int64 indices, bit-exact scores, embeddings == corpus[idx] fetched from their owners."""
     import torch.multiprocessing as mp
     _paths()
     import fixture_gen as fg
@@ -291,14 +342,18 @@ def test_multi_rank_sharded_mips(world, C, K, backend):
     else:
         world = resolve_world(world, backend)
     outdir = tempfile.mkdtemp()
-    mp.spawn(_mips_worker, args=(world, _free_port(), outdir, C, K, backend), nprocs=world, join=True)
-    corpus = torch.from_numpy(fg.exact_mips_corpus(C, 64))
-    q = torch.from_numpy(fg.exact_mips_queries(6 * world, 64))
-    want_idx, want_sc, _ = R.mips_topk(q, corpus, K)
+    mp.spawn(_mips_worker, args=(world, _free_port(), outdir, C, K, D, bf16, how, backend), nprocs=world, join=True)
+    corpus = torch.from_numpy(fg.exact_mips_corpus(C, D))
+    queries = torch.from_numpy(fg.exact_mips_queries(64, D))
     for r in range(world):
         got = torch.load(os.path.join(outdir, f"mips{r}.pt"))
-        assert torch.equal(got["idx"], want_idx[r * 6:(r + 1) * 6])
-        assert torch.equal(got["sc"], want_sc[r * 6:(r + 1) * 6])
+        assert torch.equal(got["q"], queries[got["uid"]])  # the identity tower: queries are the table rows, exactly
+        want_idx, want_sc, want_emb = R.mips_topk(queries[got["uid"]], corpus, K)
+        assert got["top"].dtype == torch.int64 and torch.equal(got["top"], want_idx)
+        assert torch.equal(got["idx"], want_idx) and torch.equal(got["sc"], want_sc)
+        assert got["emb"].dtype == torch.float32 and torch.equal(got["emb"], want_emb)
+        if world > 1:
+            assert {"mips_queries_allgather", "mips_lists_alltoall", "mips_rows_alltoall"} <= set(got["comm"])
 
 
 def test_mips_merge_kernel_on_hand_made_shard_lists():
@@ -343,11 +398,19 @@ def _ckpt_worker(rank, world, port, outdir, backend):
             opt.step()
             losses.append(float(loss))
         sd = parallel.full_state_dict(model)  # ... and back out under the reference's Parameter names
-        # serve the trained item table: this rank's catalogue block through the item tower -> ShardedMIPS
+        # serve the trained item table: this rank's catalogue block through the item tower -> the model's own (row-sharded)
+        # mips_module, i.e. model.index_corpus(...) + model.forward(...)
         feats = torch.from_numpy(g["step0.in.item_features"])  # any [*, II] features: row r of the catalogue gets row r % B
         cat_feats = feats[torch.arange(n_items) % B]
         sh = parallel.shard_of(model.item_id_embedding_arch.weight)
         mips = parallel.index_corpus_sharded(model, cat_feats[sh.lo:sh.hi])
+        assert mips is model.mips_module and mips.is_sharded() and mips.corpus_size == n_items
+        block_local = mips.corpus.clone()
+        # ... and the general form: any ids (here the same catalogue, permuted across the ranks' blocks -> routed lookups)
+        perm = torch.arange(n_items).flip(0)
+        model.index_corpus(perm[sh.lo:sh.hi].to(dev), cat_feats[perm][sh.lo:sh.hi].to(dev), chunk=97)
+        block_routed = model.mips_module.corpus.clone()
+        parallel.index_corpus_sharded(model, cat_feats[sh.lo:sh.hi])
         torch.save({"losses": losses, "sd": {k: v.cpu() for k, v in sd.items()}}, os.path.join(outdir, f"ckpt{rank}.pt"))
         dist.barrier()
         # queries: the user embeddings of the trained model, from a single-device module fed the gathered state
@@ -362,9 +425,15 @@ def _ckpt_worker(rank, world, port, outdir, backend):
             q = single.compute_user_embedding(*users)
             # the sharded model's own inference path (un-announced routed lookups) gives the same query embeddings
             q_sharded = model.compute_user_embedding(*users)
+            top_sharded = model(*users)  # forward() of the SHARDED model: routed lookups + the sharded corpus, no other call
         assert torch.allclose(q_sharded, q, atol=1e-6)
         idx, _ = mips.search(q, 10)
-        torch.save({"idx": idx.cpu(), "want": want_top.cpu()}, os.path.join(outdir, f"serve{rank}.pt"))
+        # the routed index_corpus saw the catalogue reversed: its block r holds the embeddings of items perm[lo:hi]
+        whole = single.mips_module.corpus
+        assert torch.allclose(block_local, whole[sh.lo:sh.hi], atol=1e-6)
+        assert torch.allclose(block_routed, whole[perm[sh.lo:sh.hi].to(dev)], atol=1e-6)
+        torch.save({"idx": idx.cpu(), "want": want_top.cpu(), "top_sharded": top_sharded.cpu()},
+                   os.path.join(outdir, f"serve{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
@@ -374,7 +443,8 @@ def test_sharded_checkpoint_adaptor_and_corpus_serving(world, backend):
     """SURVEY 8f item 4 through the module path: load_full_state_dict(reference parameters of fixture g2) -> the
     reference's 3 Adam steps on its batches split by rank -> full_state_dict() equals the reference's `after.*` arrays
     (trajectory tolerances of test_gpu_models.py::test_adam_trajectory_dense_exact), and the item table trained that way,
-    served through index_corpus_sharded -> ShardedMIPS, returns the single-device model's top-K."""
+    served through model.index_corpus (both the local-rows and the routed form) -> the row-sharded mips_module ->
+    model.forward(), returns the single-device model's top-K."""
     import torch.multiprocessing as mp
     _paths()
     if world != 1:
@@ -396,6 +466,9 @@ def test_sharded_checkpoint_adaptor_and_corpus_serving(world, backend):
                 assert n_out <= max(1, int(2e-3 * err.numel())) and float(err.max()) <= 2e-4, (k, n_out, float(err.max()))
         serve = torch.load(os.path.join(outdir, f"serve{r}.pt"))
         assert torch.equal(serve["idx"], serve["want"]), r
+        # (the sharded model's own queries differ from the single-device ones by summation order: 1e-6; top-10 of 4096
+        # random rows is not margin-gated here, so allow a swap of near-ties but not a different set)
+        assert (serve["top_sharded"] == serve["want"]).float().mean() > 0.98, r
 
 
 # ------------------------------------------------------------------ routing kernels
@@ -571,9 +644,11 @@ def test_train_py_world_size_2_runs_the_reference_loop():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", str(_free_port()), "-m", "two_tower_models_amd.train", "--world_size", "2",
                         "--num_epochs", "3", "--num_samples", "2048", "--batch_size", "128", "--embedding_dim", "32",
-                        "--model", "debias", "--learning_rate", "0.01"],
+                        "--model", "debias", "--learning_rate", "0.01", "--dtype", "bf16", "--retrieve"],
                        cwd=os.path.dirname(HERE), env=env, capture_output=True, text=True, timeout=900, stdin=subprocess.DEVNULL)
     assert r.returncode == 0, r.stderr[-3000:]
     losses = [float(m) for m in re.findall(r"Epoch \[\d/3\] - Loss: ([0-9.]+)", r.stdout)]
     assert len(losses) == 3 and losses[-1] < losses[0], r.stdout[-1000:]
     assert r.stdout.count("Running on device") == 1
+    # --retrieve: model.index_corpus + model.forward() on the row-sharded model (SURVEY section 5's --dtype: bf16 corpus blocks)
+    assert "Retrieved top-10 of 1024 items for 128 users (bfloat16 corpus, 2 row blocks)" in r.stdout, r.stdout[-600:]

@@ -3,7 +3,8 @@ kernels supplied by the torch restatement in tests/sharded_cpu_backend.py, the t
 torch expressions.  What runs from the PRODUCT is everything that decides who is sent what: `begin_lookups` /
 `plan_ahead` / `routed_source` / `route_grad_rows` (through `ops.lookup_source` and `ops._route_table_grad`, the calls
 the HIP autograd Functions make), `AllGatherRows` (all-gather forward, reduce-scatter backward), `ReplicatedLoss`, the
-flat dense all-reduce, `shard_model_` / `full_state_dict` / `load_full_state_dict`, `ShardedMIPS`.
+flat dense all-reduce, `shard_model_` / `full_state_dict` / `load_full_state_dict`, the row-sharded `BaselineMIPSModule`
+(`sharded_topk`, `fetch_rows`).
 
 Checked against the oracle on the CONCATENATED batch: the loss, the gradient every OWNER receives for
 its row block (ids + rows, summed), the all-reduced dense gradients."""
@@ -218,41 +219,68 @@ def test_exchanges_deliver_the_reference_gradients_of_the_concatenated_batch(wor
         assert sum(r["steps"][0]["tables"][name][1] - r["steps"][0]["tables"][name][0] for r in res) == n
 
 
-# ---------------------------------------------------------------- sharded MIPS
-def _mips_worker(rank, world, port, outdir, C, K):
+# ---------------------------------------------------------------- sharded MIPS behind BaselineMIPSModule
+def _mips_worker(rank, world, port, outdir, C, K, bf16, how):
     _paths()
     import torch.distributed as dist
     import fixture_gen as fg
-    from sharded_cpu_backend import OracleMipsKernels
+    from sharded_cpu_backend import OracleMipsKernels, OracleRouteKernels
+    import two_tower_models_amd as A
     from two_tower_models_amd import parallel
     torch.set_num_threads(1)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    parallel.set_route_kernels_for_tests(OracleRouteKernels())
+    parallel.set_mips_kernels_for_tests(OracleMipsKernels())
     try:
         corpus = torch.from_numpy(fg.exact_mips_corpus(C, 32))
-        lo, hi = parallel.ShardedMIPS.block_range(C, rank, world)
-        m = parallel.ShardedMIPS(corpus[lo:hi].clone(), lo, kernels=OracleMipsKernels())
+        _, lo, hi = parallel.block_range(C, rank, world)
+        if how == "born":  # constructed under row_sharded(): the block is born on its owner, then filled
+            with parallel.row_sharded():
+                m = A.BaselineMIPSModule(corpus_size=C, embedding_dim=32)
+            assert m.is_sharded() and m.corpus.shape[0] == hi - lo and m.corpus_size == C
+            m.set_corpus(corpus[lo:hi].clone(), bf16=bf16)
+        else:  # every rank holds the whole corpus, shard_corpus_ keeps its block
+            m = A.BaselineMIPSModule(corpus_size=C, embedding_dim=32)
+            m.corpus = corpus.clone()
+            m.shard_corpus_()
+            if bf16:
+                m.use_bf16_storage()
+        assert m.corpus_size == C and m.corpus.shape[0] == hi - lo
+        assert m.corpus.dtype == (torch.bfloat16 if bf16 else torch.float32)
         q = torch.from_numpy(fg.exact_mips_queries(5 * world, 32))[rank * 5:(rank + 1) * 5]
-        idx, sc = m.search(q, K)
-        torch.save({"idx": idx, "sc": sc}, os.path.join(outdir, f"mips{rank}.pt"))
+        idx, sc, emb = m(query_embedding=q, num_items=K)  # the reference's call (ref:src/two_tower_base_retrieval.py:246-248)
+        comm = dict(parallel.comm_bytes)
+        idx2, sc2 = m.search(q, K)
+        assert torch.equal(idx, idx2) and torch.equal(sc, sc2)
+        with pytest.raises(RuntimeError, match="out of range"):
+            m.search(q, C + 1)
+        torch.save({"idx": idx, "sc": sc, "emb": emb, "comm": comm}, os.path.join(outdir, f"mips{rank}.pt"))
     finally:
+        parallel.set_route_kernels_for_tests(None)
+        parallel.set_mips_kernels_for_tests(None)
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,C,K", [(2, 700, 20), (3, 100, 40), (4, 5, 3)])
-def test_sharded_mips_equals_single_device(world, C, K):
-    """Row-sharded corpus (incl. a block smaller than K, and an empty block) == the unsharded exact top-K."""
+@pytest.mark.parametrize("world,C,K,bf16,how", [(2, 700, 20, False, "born"), (3, 100, 40, True, "cut"),
+                                               (4, 5, 3, False, "cut"), (2, 64, 64, True, "born")])
+def test_sharded_mips_module_equals_single_device(world, C, K, bf16, how):
+    """A row-sharded BaselineMIPSModule (incl. a block smaller than K, an empty block, K = the whole corpus, bf16 blocks)
+    returns the unsharded module's 3-tuple: exact top-K indices + scores, and embeddings == corpus[idx]."""
     _paths()
     import fixture_gen as fg
     from oracle import cpu_ref as R
     outdir = tempfile.mkdtemp()
-    mp.spawn(_mips_worker, args=(world, _free_port(), outdir, C, K), nprocs=world, join=True)
-    corpus = torch.from_numpy(fg.exact_mips_corpus(C, 32))
+    mp.spawn(_mips_worker, args=(world, _free_port(), outdir, C, K, bf16, how), nprocs=world, join=True)
+    corpus = torch.from_numpy(fg.exact_mips_corpus(C, 32))  # (small integers: its bf16 form is the same numbers)
     q = torch.from_numpy(fg.exact_mips_queries(5 * world, 32))
-    want_idx, want_sc, _ = R.mips_topk(q, corpus, K)
+    want_idx, want_sc, want_emb = R.mips_topk(R.round_to_bf16(q) if bf16 else q, corpus, K)
     for r in range(world):
         got = torch.load(os.path.join(outdir, f"mips{r}.pt"))
         assert torch.equal(got["idx"], want_idx[r * 5:(r + 1) * 5])
-        assert torch.equal(got["sc"], want_sc[r * 5:(r + 1) * 5])
+        if not bf16:  # (the CPU stand-in scores fp32 queries; the HIP path's bf16 query rounding is a -m gpu matter)
+            assert torch.equal(got["sc"], want_sc[r * 5:(r + 1) * 5])
+        assert got["emb"].dtype == torch.float32 and torch.equal(got["emb"], want_emb[r * 5:(r + 1) * 5])
+        assert {"mips_queries_allgather", "mips_lists_alltoall", "mips_rows_alltoall"} <= set(got["comm"])
 
 
 # ---------------------------------------------------------------- watchdog

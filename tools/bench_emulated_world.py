@@ -6,6 +6,7 @@ once the tables are W times thinner and the in-batch negatives W times wider, i.
 W GPUs minus the collectives.  bench.py puts `emulated(8, "P")` into the default line's `secondary`.
 Usage: python tools/bench_emulated_world.py [W] [workload]"""
 import ctypes as C
+import json
 import os
 import sys
 import time
@@ -239,6 +240,20 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False,
                                  "alone_note": "the same kernel at the same shape with the GPU to itself (10 launches back to back): the "
                                                "difference to `frac` is what sharing HBM and CUs with the Adam sweep costs it in the step"}
                                 if key in alone else {})})
+        # the table sweep of this rank's row blocks (HBM-bound; what the step is at C4's 12.5 M rows per rank)
+        sw_bytes = bench.algorithmic_sweep_bytes(cfg, W)
+        sw_ms = prof["adam_sweep_kernel"][0]
+        sweep_roof = {"bound": "hbm", "kernel": "adam_sweep_tables_kernel", "peak": bench.HBM_PEAK_GBS, "unit": "GB/s",
+                      "achieved": round(sw_bytes / (sw_ms * 1e-3) / 1e9, 1) if sw_ms > 0 else None,
+                      "frac": round(sw_bytes / (sw_ms * 1e-3) / 1e9 / bench.HBM_PEAK_GBS, 4) if sw_ms > 0 else None,
+                      "avg_launch_ms": round(sw_ms, 4), "launches": prof["adam_sweep_kernel"][1],
+                      "algorithmic_bytes_per_launch": sw_bytes, "frac_of_step": round(sw_ms / ms, 3)}
+        # padded fixed-capacity all-to-all vs the exact row bytes (SURVEY section 7 "History all-to-all volume")
+        n_lookups = B * (2 + (cfg["H"] if cfg["model"] != "base" else 0))
+        exact = (W - 1) / W * n_lookups * D * 4
+        padded = parallel.comm_bytes.get("lookup_rows_alltoall", 0)
+        pad = {"exact_bytes": int(exact), "padded_bytes": int(padded), "ratio": round(padded / exact, 3) if exact else None,
+               "note": "cap = the largest (requester, owner) bucket over all ranks, rounded up to 64; ids are uniform here"}
         out = {
             "what": f"ONE rank's kernels of the row-sharded step at W = {W} on one GPU: tables 1/{W} as thick, {W}x{B} in-batch "
                     "negatives per user, routed lookups; torch.distributed replaced by stand-ins that return tensors of the right "
@@ -259,6 +274,8 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False,
                                       "logits_bwd_dI": round(acc[3], 3), "towers_bwd_row_adam": round(acc[4], 3)},
             "roofline": roof,
             "sweep_avg_launch_ms": round(prof["adam_sweep_kernel"][0], 4),
+            "sweep_roofline": sweep_roof,
+            "lookup_rows_padding": pad,
             "sweep_level": opt.sweep_level_note(),
             "bytes_this_rank_would_send_per_step": dict(parallel.comm_bytes),
             "total_MB_sent": round(sum(parallel.comm_bytes.values()) / 1e6, 2),
@@ -280,5 +297,54 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False,
         collectives.dist, parallel.dist, ops._CE_F16X2 = real
 
 
+def emulated_mips(W=8, steps=6, warmup=2, device=None, verbose=False):
+    """ONE rank's kernels of BASELINE config 5 at W GPUs (bench.py --workload C5 --gpus W), stand-in collectives: this rank's
+    C / W corpus rows (bf16) scored against ALL W x 1024 queries, the [W, B, K] candidate lists through the stand-in
+    all-to-all, tt_mips_merge over W x K candidates per own query -- through TwoTowerWithDebiasing.forward() on a
+    row-sharded model (tables and corpus)."""
+    import bench
+    from two_tower_models_amd import collectives, parallel
+    device = device or torch.device("cuda:0")
+    real = (collectives.dist, parallel.dist)
+    collectives.dist = parallel.dist = _fake_dist(W)
+    try:
+        cfg = dict(bench.WORKLOADS["C5"])
+        rec = bench.timed_c5(cfg, device, W, 0, steps, warmup, sharded=True, comm_timing=False)
+        model = rec.pop("model")
+        mp, B = cfg["mips"], cfg["B"]
+        # the reference's full 3-tuple once (embeddings fetched through the routed exchange), timed separately: forward()
+        # of the model discards them (ref:src/two_tower_base_retrieval.py:246-248)
+        with torch.no_grad():
+            q = torch.randn(B, cfg["D"], device=device)
+            model.mips_module(query_embedding=q, num_items=mp["K"])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.mips_module(query_embedding=q, num_items=mp["K"])
+            torch.cuda.synchronize()
+            full_ms = (time.perf_counter() - t0) * 1e3
+            fetch_bytes = dict(parallel.comm_bytes)
+        out = {"what": f"ONE rank's kernels of config 5 at W = {W} on one GPU: C/{W} = {rec['corpus_rows_this_rank']} {rec['corpus_dtype']} corpus "
+                       f"rows scored against all {rec['queries_scored_per_call_this_rank']} queries, [W, B, K] candidate lists through a stand-in "
+                       "all-to-all, tt_mips_merge over W x K candidates per own query, via TwoTowerWithDebiasing.forward() on a "
+                       "row-sharded model -- NOT a serving run, the collectives' time comes on top",
+               "world": W, "B_per_rank": B, "K": mp["K"], "C": mp["C"], "ms_per_call_per_rank": round(rec["ms_per_call"], 4),
+               "queries_per_s_if_collectives_were_free": round(B * W / rec["ms_per_call"] * 1e3, 1),
+               "roofline": rec["roofline"], "bytes_this_rank_would_send_per_call": rec["comm_bytes"],
+               "total_MB_sent": round(sum(rec["comm_bytes"].values()) / 1e6, 2),
+               "module_forward_3tuple_ms": round(full_ms, 3),
+               "module_forward_3tuple_note": "BaselineMIPSModule.forward incl. the [B, K, D] embeddings fetched from their owners "
+                                             "(routed all-to-all, fp32 rows on the wire): " + str(fetch_bytes),
+               "steps": steps, "warmup": warmup}
+        if verbose:
+            print(json.dumps(out, indent=1))
+        del model
+        return out
+    finally:
+        collectives.dist, parallel.dist = real
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "C5":
+        emulated_mips(int(sys.argv[1]), verbose=True)
+        sys.exit(0)
     emulated(int(sys.argv[1]) if len(sys.argv) > 1 else 8, sys.argv[2] if len(sys.argv) > 2 else "P", verbose=True)

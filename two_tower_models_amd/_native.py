@@ -153,6 +153,9 @@ SIGNATURES = {
                                _vp, _vp, _vp, _i64, _vp]),
     "tt_enc_last_bwd_data": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tt_enc_last_bwd_weights": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "tt_stream_copy": (_int, [_vp, _vp, _i64, _i32, _vp]),
+    "tt_mfma_probe_flops": (_i64, [_int, _i32]),
+    "tt_mfma_probe": (_int, [_int, _i32, _vp, _i64, _vp]),
     "tt_route_workspace_bytes": (_i64, [_i64, _i32]),
     "tt_route_count": (_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tt_route_build": (_int, [_vp, _i64, _i64, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),

@@ -67,8 +67,8 @@ def _is_gloo() -> bool:
 
 
 def _host_staged(x: torch.Tensor) -> bool:
-    """gloo moves host memory only.  Device tensors under gloo (several ranks sharing ONE GPU, used
-    by tests/test_gpu_sharded.py to run the HIP backend at world size > 1 on a 1-GPU box) are
+    """gloo moves host memory only.  Device tensors under gloo (several ranks sharing ONE GPU: how
+    tests/test_gpu_parallel.py runs the product kernels at world size > 1 on a 1-GPU box) are
     staged through the host; under RCCL nothing is staged."""
     return _is_gloo() and x.device.type != "cpu"
 
@@ -98,24 +98,6 @@ def reduce_scatter_rows(x: torch.Tensor) -> torch.Tensor:
     else:
         dist.reduce_scatter_tensor(out, x.contiguous())
     return out
-
-
-# A/B (opt-in): user tower backward on the third stream underneath the dI logits kernel.  Measured round 4 on the emulated
-# W = 8 step: the towers' 0.1 ms leave the tail, the logits kernel they now share the chip with takes as much longer --
-# 4.237 vs 4.246 ms per step; not the default.
-_UTOWER_EARLY = os.environ.get("TT_SHARDED_EARLY_UTOWER") is not None
-_LOSS_KERNELS = os.environ.get("TT_SHARDED_TORCH_LOSS") is None  # A/B: the value-weight tail as two kernels
-_WGRAD_ASIDE = os.environ.get("TT_SHARDED_WGRAD_MAIN") is None  # A/B: tower weight gradients on the third stream
-_CE_F16X2 = os.environ.get("TT_CE_F16X2") is not None  # exploratory: split-fp16 logits kernels (HipBackend.ce_fwd)
-_CE16_KEEP = os.environ.get("TT_CE16_KEEP") is not None  # A/B: that pair with kept logits (its first form) instead of recomputed ones
-# Opt-in (TT_SHARDED_PLAN_ASIDE=1): the NEXT batch's route plan (owner histogram + scan per lookup, the MAX all-reduce
-# of the bucket sizes, their copy to the host) on the library's third stream at the very top of the step instead of on
-# the main stream after the lookups -- eight small launches leave the critical path: emulated W = 8 step 4.09 -> 4.05 ms
-# (three A/B pairs on one box).  It has to be the EXISTING third stream (ops.run_on_side: a new HIP stream may share the
-# sweep's hardware queue, which is what made the first attempt slower).  Not the default: it issues that all-reduce
-# from a second stream while the lookups' exchanges are in flight on the first, a pattern no multi-GPU run has
-# exercised yet, and 1 % is not worth a surprise there.
-_PLAN_ASIDE = os.environ.get("TT_SHARDED_PLAN_ASIDE") is not None
 
 
 # Per-exchange timing (bench.py's multi-rank line: `comm_ms`): None = off.  When a list, every exchange appends

@@ -1,9 +1,10 @@
 """tt_comm_* of the C ABI (csrc/comm.cpp: RCCL bound at run time) behind a small Python class.
 
 The reference has no communication of any kind; this is the transport a non-torch
-binder of include/tt_hotpath.h would use for the row-sharded step, and `sharded.py` can run on it
-instead of `torch.distributed`'s process group (`ShardedTrainer(..., transport="native")` /
-TT_COMM=native).  One communicator per process = per GPU.  The 128-byte RCCL id is created by rank 0
+binder of include/tt_hotpath.h would use for the row-sharded step, and the module path (parallel.py /
+collectives.py) can run on it instead of `torch.distributed`'s process group:
+`collectives.use_native_transport(NativeComm.from_torch_distributed(device))` (bench.py `--transport native`);
+`use_native_transport(None)` closes it.  One communicator per process = per GPU.  The 128-byte RCCL id is created by rank 0
 (`NativeComm.unique_id()`) and handed to the other ranks over ANY host channel; `from_torch_distributed`
 uses the already initialised process group (gloo or nccl) for exactly that one broadcast.
 """
@@ -61,8 +62,8 @@ class NativeComm:
         return cls(bytes(t.cpu().tolist()), rank, world, device)
 
     def close(self) -> None:
-        """Destroy the RCCL communicator.  Called by ShardedTrainer.close() / at interpreter exit (registered
-        by `sharded.use_native_transport`), i.e. BEFORE torch.distributed's process group goes away."""
+        """Destroy the RCCL communicator.  Called by collectives.use_native_transport(None) / at interpreter exit (registered
+        by `collectives.use_native_transport`), i.e. BEFORE torch.distributed's process group goes away."""
         if self._h is not None:
             h, self._h = self._h, None
             N.check(self.lib.tt_comm_destroy(h), "tt_comm_destroy")

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void gather_rows_bf16_kernel(const uint16_t* _
   if (i >= n_ids) return;
   const int64_t id = ids[i];
   const bool ok = (id >= 0) && (id < n_rows);
-  if (!ok && c == 0) *oob_flag = 1;
+  if (!ok && c == 0 && oob_flag) *oob_flag = 1;
   const uint16_t* src = table + (ok ? id : 0) * dim;
   for (int64_t k = c; k < dim; k += 32) out[i * ld_out + k] = ok ? bf16_to_f32(src[k]) : 0.f;
 }
@@ -175,7 +175,7 @@ extern "C" int tt_gather_rows(const float* table, int64_t n_rows, int64_t dim, c
 extern "C" int tt_gather_rows_bf16(const uint16_t* table, int64_t n_rows, int64_t dim,
                                    const int64_t* ids, int64_t n_ids, float* out, int64_t ld_out,
                                    int32_t* oob_flag, tt_stream_t stream) {
-  if (!table || !ids || !out || !oob_flag) return fail_arg("tt_gather_rows_bf16: null pointer");
+  if (!table || !ids || !out) return fail_arg("tt_gather_rows_bf16: null pointer");
   if (n_rows <= 0 || dim <= 0 || n_ids < 0 || ld_out < dim) return fail_arg("tt_gather_rows_bf16: sizes");
   if (n_ids == 0) return 0;
   gather_rows_bf16_kernel<<<ceil_div(n_ids, 8), 256, 0, S(stream)>>>(table, n_rows, dim, ids, n_ids, out, ld_out, oob_flag);

@@ -847,7 +847,7 @@ __global__ __launch_bounds__(1024) void ce_fwd_du_finish_loss_kernel(const float
   // s_waitcnt vmcnt(0) in the storing wave -> sc1 flag; reader: sc1 loads.  The wait is written out as inline assembly so it
   // does not depend on what hipcc chooses to emit for __syncthreads() (today: vmcnt(0) + s_barrier; the LLVM memory model
   // would allow a workgroup-scope barrier without it -- ADVICE r3); inline asm is invisible to the wait-count pass, so it
-  // cannot be optimised away.  TT_CE_NO_FUSED_LOSS=1 takes the two-launch form, which has no cross-workgroup hand-off.
+  // cannot be optimised away.  tt_inbatch_ce_fwd_du + tt_weighted_loss is the two-launch form, which has no cross-workgroup hand-off.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // every wave's stores (row_ce among them) have been acknowledged
   if (threadIdx.x == 0)

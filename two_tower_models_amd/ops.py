@@ -168,7 +168,7 @@ def note_generic(path: str, why: str) -> None:
 # returns) -- every consumer of `.grad` (this package's optimiser, torch.optim, user code) therefore sees completed
 # gradients by ordinary stream order.  Operands are held until then.  Not used while a hipGraph is being captured.
 # (The third stream, not a new one: ROCm multiplexes HIP streams onto a handful of hardware queues in creation order, and
-# one more stream can land on the sweep's queue -- measured in sharded.py, round 4.)
+# one more stream can land on the sweep's queue -- measured on the row-sharded step, round 4.)
 _SIDE_GRADS = os.environ.get("TT_WGRAD_MAIN") is None  # TT_WGRAD_MAIN=1: everything in line (the safe mode under DDP-style reducers)
 _side_state = {"held": [], "armed": False, "dev": None, "encoder": False, "leaves": set()}  # "encoder": a HistoryEncoder forward ran since the last join
 
@@ -816,7 +816,7 @@ class InBatchSoftmaxCE(torch.autograd.Function):
                 and 0 <= diag_offset <= Nn - M:
             du_unit = torch.empty(M, D, dtype=torch.float32, device=dev)
             w16p, w16n = _ws(dev, lib.tt_ce16_workspace_bytes(M, Nn, D), "ce16")
-            # no logits buffer unless asked for (TT_CE16_KEEP, the pair's first form): the backward forms the tiles again
+            # no logits buffer unless asked for (_CE16_KEEP, the pair's first form): the backward forms the tiles again
             ctx.kept16 = torch.empty(M * Nn, dtype=torch.float32, device=dev) if _CE16_KEEP else True
             N.check(lib.tt_ce16_fwd_du_keep(pu, D, pi, D, M, Nn, D, diag_offset, lse.data_ptr(), ce.data_ptr(), du_unit.data_ptr(), D,
                                             ctx.kept16.data_ptr() if _CE16_KEEP else None, M * Nn * 4 if _CE16_KEEP else 0, w16p, w16n,
@@ -954,7 +954,7 @@ class WeightedMeanLoss(torch.autograd.Function):
 
 # EXPLORATORY: InBatchSoftmaxCE through the split-fp16 pair (csrc/ce_f16x2.hip) where its shapes allow
 # (D = 128, M % 256 == 0, N % 1024 == 0, contiguous rows) -- fp32-grade results on the fp16 matrix pipe.  Never the default.
-_CE16_KEEP = os.environ.get("TT_CE16_KEEP") is not None  # A/B: the split-fp16 pair with kept logits (its first form)
+_CE16_KEEP = False  # A/B (tests flip it): the split-fp16 pair with kept logits (its first form) instead of recomputed ones
 _CE_F16X2 = os.environ.get("TT_CE_F16X2") is not None
 
 

@@ -658,7 +658,10 @@ class DenseExactAdam(torch.optim.Optimizer):
     def _start_dense_allreduce(self):
         """Every replicated parameter's gradient into ONE flat buffer (tt_pack_grads, one launch) and its all-reduce (SUM:
         each rank holds the gradient of ITS rows' share of the global-batch mean) started -- it travels underneath the
-        table finish.  A parameter without a gradient on this rank contributes zeros (its slice is cleared)."""
+        table finish.  A parameter whose `.grad` is None is NOT updated -- like the single-device path and
+        torch.optim.Adam -- and its slice of the buffer is cleared so that the layout stays what every rank expects.
+        (Which parameters receive gradients must be the same on every rank, as under DistributedDataParallel without
+        find_unused_parameters: it is a property of the model code, not of a rank's data.)"""
         from . import parallel
         lib = N.load()
         total = sum(p.numel() for p in self._dense)
@@ -670,6 +673,7 @@ class DenseExactAdam(torch.optim.Optimizer):
         descs = (N.AdamTensor * len(self._dense))()
         n, off, missing = 0, 0, []
         keep = []
+        self._dense_live = [p.grad is not None for p in self._dense]
         for p in self._dense:
             if p.grad is not None:
                 gr = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
@@ -689,14 +693,17 @@ class DenseExactAdam(torch.optim.Optimizer):
         pending, _keep = reduce
         flat = pending.wait()
         descs = (N.AdamTensor * len(self._dense))()
-        off = 0
-        for i, p in enumerate(self._dense):
-            st = self.state[p]
-            descs[i].p, descs[i].g = p.data_ptr(), flat.data_ptr() + 4 * off
-            descs[i].m, descs[i].v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-            descs[i].n = p.numel()
+        off, n = 0, 0
+        for p, live in zip(self._dense, self._dense_live):
+            if live:  # no gradient, no update (a frozen / unused parameter keeps its value AND its moments)
+                st = self.state[p]
+                descs[n].p, descs[n].g = p.data_ptr(), flat.data_ptr() + 4 * off
+                descs[n].m, descs[n].v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                descs[n].n = p.numel()
+                n += 1
             off += p.numel()
-        N.check(lib.tt_adam_dense(descs, len(self._dense), hyper, N.stream()), "tt_adam_dense")
+        if n:
+            N.check(lib.tt_adam_dense(descs, n, hyper, N.stream()), "tt_adam_dense")
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         for p in self._tables:
@@ -729,10 +736,10 @@ class DenseExactAdam(torch.optim.Optimizer):
             self._init_state()
         lib = N.load()
         hyper = self._hyper.data_ptr()
-        reduce = self._start_dense_allreduce() if self._sharded else None
-        if self._sharded and self._begun is None:
+        if self._sharded and self._begun is None:  # (checked BEFORE any collective is started)
             raise RuntimeError("row-sharded tables: step() without a train_forward that announced its lookups (the models' "
                                "train_forward does; a custom forward must call model._announce_lookups first)")
+        reduce = self._start_dense_allreduce() if self._sharded else None
         self.release_sweep()
         if self._begun is not None:
             # overlapped schedule: hyper already advanced, tables already swept on the side stream

@@ -107,8 +107,20 @@ def embedding(num_embeddings: int, embedding_dim: int) -> nn.Embedding:
     world, rank = _group()
     sh = RowShard(num_embeddings, embedding_dim, world, rank)
     emb = nn.Embedding(max(sh.n_local, 1), embedding_dim)
+    with torch.no_grad():
+        emb.weight.normal_(generator=block_generator(emb.weight.device, sh.lo, num_embeddings))
     emb.weight._tt_shard = sh
     return emb
+
+
+def block_generator(device: torch.device, lo: int, n_rows: int) -> torch.Generator:
+    """The RNG a rank draws ITS rows of a group-wide random tensor from: seeded by the process's seed AND the block's
+    first row, so that ranks which all called `torch.manual_seed(s)` with the same s (common practice in distributed
+    scripts) still draw different rows -- identical blocks would make rows r, r + per, r + 2 per ... of the table start
+    out equal, which is not the reference's i.i.d. N(0, 1) init (ref:src/two_tower_base_retrieval.py:70,97)."""
+    g = torch.Generator(device=device)
+    g.manual_seed((torch.initial_seed() * 1_000_003 + 7919 * (lo + 1) + n_rows) % (2 ** 63 - 1))
+    return g
 
 
 def _tables(model: nn.Module) -> List[Tuple[str, nn.Parameter]]:
@@ -138,7 +150,11 @@ def shard_model_(model: nn.Module, broadcast_dense: bool = True) -> nn.Module:
             for p in dense:
                 p.data.copy_(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
-    # the random MIPS corpus (ref:src/baseline_mips_module.py:29-30) is per-process state of an inference helper: untouched
+    # ... and the MIPS corpus (ref:src/baseline_mips_module.py:29-30): a module still holding a whole corpus keeps its own
+    # rows [lo, hi) of it -- model.forward() then searches the W blocks together (BaselineMIPSModule._sharded_*)
+    mips = getattr(model, "mips_module", None)
+    if mips is not None and hasattr(mips, "shard_corpus_"):
+        mips.shard_corpus_()
     return model
 
 
@@ -224,6 +240,10 @@ class _HipRouteKernels:
         if n_local <= 0:  # a rank that owns no row of this table (fewer rows than ranks): every id is the sentinel
             return out.zero_()
         N = self.N
+        if table.dtype == torch.bfloat16:  # a bf16 corpus block (BaselineMIPSModule.use_bf16_storage): rows widen exactly
+            N.check(self.lib.tt_gather_rows_bf16(table.data_ptr(), n_local, table.shape[1], local.data_ptr(), local.numel(),
+                                                 out.data_ptr(), table.shape[1], None, N.stream()), "tt_gather_rows_bf16")
+            return out
         N.check(self.lib.tt_gather_rows(table.data_ptr(), n_local, table.shape[1], local.data_ptr(), local.numel(),
                                         out.data_ptr(), table.shape[1], None, N.stream()), "tt_gather_rows")
         return out
@@ -255,10 +275,11 @@ class _PlannedRoutes:
     """The routing of one step's lookups as far as it can be prepared without knowing `cap`: per lookup the counted
     owner buckets, and the all-reduced bucket maxima on their way to the host."""
 
-    __slots__ = ("key", "planned", "counts_host", "event", "keep")
+    __slots__ = ("key", "planned", "counts_host", "event", "keep", "ids_ref")
 
-    def __init__(self, key, planned, counts_host, event, keep):
+    def __init__(self, key, planned, counts_host, event, keep, ids_ref=()):
         self.key, self.planned, self.counts_host, self.event, self.keep = key, planned, counts_host, event, keep
+        self.ids_ref = ids_ref  # the announced id tensors, alive as long as the plan (see _route_key)
 
     def caps(self) -> List[int]:
         if self.event is not None:
@@ -302,9 +323,13 @@ def _sent(tag: str, nbytes: int) -> None:
 
 
 def _route_key(specs) -> tuple:
-    # storage, size AND torch's in-place version counter: a static input buffer refilled with copy_() between the
-    # announcement and the step keeps its address but not its version, and is planned again
-    return tuple((id(p), t.data_ptr(), t.numel(), t._version) for p, t in specs)
+    # The announced id TENSORS themselves (a _PlannedRoutes keeps them alive in `ids_ref`, so neither the Python object
+    # nor its storage can be handed to another batch while the plan exists: an address the caching allocator recycled
+    # can no longer look like the announced batch) + torch's in-place version counter: a static input buffer refilled
+    # with copy_() between the announcement and the step keeps its identity but not its version, and is planned again.
+    # Whether a step is fed the tensors it announced is a property of the calling code, hence the same on every rank --
+    # the reuse-or-replan decision (a replan contains an all-reduce) cannot differ between ranks by allocator accident.
+    return tuple((id(p), id(t), t.data_ptr(), t.numel(), t._version) for p, t in specs)
 
 
 def _specs(plan: Dict[nn.Parameter, Sequence[torch.Tensor]]):
@@ -336,19 +361,23 @@ def plan_routes(specs) -> _PlannedRoutes:
         keep.append(counts)
     else:
         host, event = counts, None
-    return _PlannedRoutes(_route_key(specs), planned, host, event, keep)
+    return _PlannedRoutes(_route_key(specs), planned, host, event, keep, tuple(t for _, t in specs))
 
 
 def plan_ahead(plan: Dict[nn.Parameter, Sequence[torch.Tensor]]) -> None:
     """Announce the NEXT step's lookups (`model._lookup_plan(user_id, user_history, item_id)` of the next batch): their
     routes are counted and the bucket capacity all-reduced underneath the current step, which removes the step's only
-    host wait.  Purely a scheduling hint; results do not depend on it.  Every rank must call it (or none)."""
+    host wait.  A scheduling hint: the plan is used only by a step that is handed the very tensors announced here,
+    unmodified (identity + in-place version; the plan keeps them alive), any other batch is planned again -- results do
+    not depend on it.  Every rank must call it (or none)."""
     specs = _specs(plan)
     _planned_next[0] = plan_routes(specs) if specs else None
 
 
-def _start_lookups(specs, routes: _PlannedRoutes) -> List[Tuple[nn.Parameter, _RoutedLookup]]:
+def _start_lookups(specs, routes: _PlannedRoutes,
+                   tags=("lookup_ids_alltoall", "lookup_rows_alltoall")) -> List[Tuple[nn.Parameter, _RoutedLookup]]:
     """ids to their owners, rows back: every exchange of `specs` is in flight when this returns."""
+    t_ids, t_rows = tags
     dev = specs[0][1].device
     K = _kernels(dev)
     caps = routes.caps()
@@ -357,14 +386,14 @@ def _start_lookups(specs, routes: _PlannedRoutes) -> List[Tuple[nn.Parameter, _R
         sh = shard_of(p)
         send_ids, slot_of, src_of = K.route_build(planned, sh.rows_per_rank, sh.world, cap)
         lks.append((p, _RoutedLookup(sh, ids.numel(), cap, slot_of, src_of,
-                                     C.all_to_all_rows_start(send_ids, tag="lookup_ids_alltoall"))))
-        _sent("lookup_ids_alltoall", (sh.world - 1) * cap * 8)
+                                     C.all_to_all_rows_start(send_ids, tag=t_ids))))
+        _sent(t_ids, (sh.world - 1) * cap * 8)
     for p, lk in lks:
         sh = lk.shard
         lk.local = K.localize(lk.ids_p.wait(), sh.lo, sh.n_local)  # sentinel n_local for padding
         lk.ids_p = None
-        lk.rows_p = C.all_to_all_rows_start(K.gather_owned(p.data, lk.local, sh.n_local), tag="lookup_rows_alltoall")
-        _sent("lookup_rows_alltoall", (sh.world - 1) * lk.cap * sh.dim * 4)
+        lk.rows_p = C.all_to_all_rows_start(K.gather_owned(p.data, lk.local, sh.n_local), tag=t_rows)
+        _sent(t_rows, (sh.world - 1) * lk.cap * sh.dim * 4)
     return lks
 
 
@@ -377,6 +406,7 @@ def begin_lookups(plan: Dict[nn.Parameter, Sequence[torch.Tensor]]) -> Dict[nn.P
     if not specs:
         return dict(plan)
     comm_bytes.clear()
+    _DEFERRED.clear()  # a backward that aborted may have left a reduce-scatter nobody waited for: never match a later tensor
     dev = specs[0][1].device
     for p, _ in specs:
         p._tt_routed = []
@@ -590,73 +620,100 @@ def all_reduce_dense_start(flat: torch.Tensor):
 
 
 # ----------------------------------------------------------------- sharded MIPS (BASELINE config 5)
-class ShardedMIPS:
-    """Brute-force MIPS over a corpus whose rows are split into W contiguous blocks
-    (ref:src/baseline_mips_module.py:32-72 on one shard per GPU).  Every rank brings its own B queries; per call:
-        all_gather queries                         [B, D] -> [W*B, D]
-        local exact top-K of ALL queries on this rank's block (tt_mips_topk)
-        all_to_all of the (score, global index) lists   [W, B, K] <-> [W, B, K]   (fixed size)
-        exact merge of the W*K candidates per own query (tt_mips_merge)
-    The global top-K is a subset of the union of the per-block top-Ks and every stage uses the (score desc, index asc)
-    order, so the result equals the single-device answer.  `kernels` (tests only): an object with mips_topk / mips_merge."""
+# The implementation behind a row-sharded `BaselineMIPSModule` (baseline_mips_module.py): the module keeps the reference's
+# surface -- forward(query_embedding, num_items) -> (indices, scores, embeddings), ref:src/baseline_mips_module.py:32-72 --
+# and calls these two functions when its corpus is this rank's row block.
+_MIPS_KERNELS_TEST = [None]
 
-    def __init__(self, corpus_block: torch.Tensor, row_offset: int, kernels=None):
-        if not dist.is_initialized():
-            raise RuntimeError("ShardedMIPS needs torch.distributed to be initialised")
-        self.corpus, self.row_offset = corpus_block, int(row_offset)
-        self.W = dist.get_world_size()
-        if kernels is None:
-            from . import ops
-            kernels = ops
-        self.k = kernels
 
-    @staticmethod
-    def block_range(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
-        return block_range(n_rows, rank, world)[1:]
+def set_mips_kernels_for_tests(obj) -> None:
+    """tests/ only: an object with mips_topk / mips_merge (a CPU restatement), so the exchange logic below runs under
+    gloo on a box without a GPU.  The product never calls this."""
+    _MIPS_KERNELS_TEST[0] = obj
 
-    def search(self, query: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        W, B = self.W, query.shape[0]
-        q_all = C.all_gather_rows(query) if W > 1 else query
-        n_local = self.corpus.shape[0]
-        k_loc = min(k, n_local)
-        if k_loc > 0:
-            idx, sc = self.k.mips_topk(q_all, self.corpus, k_loc)  # [W*B, k_loc], local row numbers
-            idx = idx + self.row_offset
-        else:  # this rank's block is empty (fewer corpus rows than ranks x rows per rank): "no candidate" only
-            idx = torch.empty(q_all.shape[0], 0, dtype=torch.int64, device=q_all.device)
-            sc = torch.empty(q_all.shape[0], 0, dtype=torch.float32, device=q_all.device)
-        if k_loc < k:  # a block smaller than K: pad with "no candidate"
-            pad = k - k_loc
-            idx = torch.cat([idx, idx.new_full((idx.shape[0], pad), -1)], dim=1)
-            sc = torch.cat([sc, sc.new_zeros((sc.shape[0], pad))], dim=1)
-        if W > 1:
-            ridx, rsc = C.all_to_all_rows(idx), C.all_to_all_rows(sc)  # chunk r of the send = rank r's queries
-            # received layout [W (source shard), B, k] -> per own query the W*k candidates
-            idx = ridx.view(W, B, k).permute(1, 0, 2).reshape(B, W * k)
-            sc = rsc.view(W, B, k).permute(1, 0, 2).reshape(B, W * k)
-        return self.k.mips_merge(sc, idx, k)
+
+def sharded_topk(corpus_block: torch.Tensor, row_offset: int, query: torch.Tensor, k: int, topk=None):
+    """Exact top-k of every rank's own queries over a corpus whose rows are split into W contiguous blocks
+    (ref:src/baseline_mips_module.py:57-61 on one block per GPU).  Every rank brings its own B queries (the same B on
+    every rank); per call:
+        all_gather queries                                  [B, D] -> [W*B, D]
+        local exact top-k of ALL queries on this rank's block (tt_mips_topk)
+        all_to_all of the (score, global index) lists       [W, B, k] <-> [W, B, k]   (fixed size)
+        exact merge of the W*k candidates per own query     (tt_mips_merge)
+    The global top-k is a subset of the union of the per-block top-ks and every stage uses the (score desc, index asc)
+    order, so the result equals the single-device answer.  `topk(q, corpus, k)`: the local search (default
+    ops.mips_topk; the module passes its split-fp16 variant)."""
+    W = dist.get_world_size()
+    kern = _MIPS_KERNELS_TEST[0]
+    if kern is None:
+        from . import ops as kern
+    if topk is None:
+        topk = kern.mips_topk
+    B = query.shape[0]
+    comm_bytes.clear()
+    q_all = C.all_gather_rows_start(query.contiguous(), tag="mips_queries_allgather").wait() if W > 1 else query
+    _sent("mips_queries_allgather", (W - 1) * query.numel() * query.element_size())
+    n_local = corpus_block.shape[0]
+    k_loc = min(k, n_local)
+    if k_loc > 0:
+        idx, sc = topk(q_all, corpus_block, k_loc)  # [W*B, k_loc], local row numbers
+        idx = idx + row_offset
+    else:  # this rank's block is empty (fewer corpus rows than ranks x rows per rank): "no candidate" only
+        idx = torch.empty(q_all.shape[0], 0, dtype=torch.int64, device=q_all.device)
+        sc = torch.empty(q_all.shape[0], 0, dtype=torch.float32, device=q_all.device)
+    if k_loc < k:  # a block smaller than k: pad with "no candidate"
+        pad = k - k_loc
+        idx = torch.cat([idx, idx.new_full((idx.shape[0], pad), -1)], dim=1)
+        sc = torch.cat([sc, sc.new_zeros((sc.shape[0], pad))], dim=1)
+    if W > 1:
+        p_idx = C.all_to_all_rows_start(idx, tag="mips_lists_alltoall")  # chunk r of the send = rank r's queries
+        p_sc = C.all_to_all_rows_start(sc, tag="mips_lists_alltoall")
+        _sent("mips_lists_alltoall", (W - 1) * B * k * 12)
+        # received layout [W (source block), B, k] -> per own query the W*k candidates
+        idx = p_idx.wait().view(W, B, k).permute(1, 0, 2).reshape(B, W * k)
+        sc = p_sc.wait().view(W, B, k).permute(1, 0, 2).reshape(B, W * k)
+    return kern.mips_merge(sc, idx, k)
+
+
+class _Block:
+    """What the routed-lookup machinery needs of a sharded table: `.data` (this rank's rows) and `_tt_shard`."""
+
+    __slots__ = ("data", "_tt_shard", "_tt_routed", "__weakref__")
+
+    def __init__(self, data: torch.Tensor, shard: RowShard):
+        self.data, self._tt_shard, self._tt_routed = data, shard, []
+
+
+def fetch_rows(block: torch.Tensor, shard: RowShard, idx: torch.Tensor) -> torch.Tensor:
+    """block-sharded corpus[idx] -> [B, K, D] fp32 on the rank that asked (ref:src/baseline_mips_module.py:63-69): the
+    global row numbers go to their owners through the lookups' own padded all-to-all (`plan_routes` / `_start_lookups`:
+    ids out, rows back in the same slots), the rows are put in request order by one gather over the receive buffer.
+    Inference only (no autograd).  Every rank must call it, with the same number of indices."""
+    Bq, K = idx.shape
+    flat = idx.reshape(-1)
+    if shard.world == 1 and not C._force_async():
+        return _kernels(block.device).gather_owned(block, flat, shard.n_local).view(Bq, K, shard.dim)
+    tbl = _Block(block, shard)
+    specs = [(tbl, flat)]
+    lk = _start_lookups(specs, plan_routes(specs), tags=("mips_rows_ids_alltoall", "mips_rows_alltoall"))[0][1]
+    rows = lk.rows_p.wait()  # [W*cap, D] as the owners sent them
+    return _kernels(block.device).gather_owned(rows, lk.slot_of, rows.shape[0]).view(Bq, K, shard.dim)
 
 
 @torch.no_grad()
-def index_corpus_sharded(model: nn.Module, item_features_block: torch.Tensor) -> ShardedMIPS:
-    """Serve what was trained (upstream searches a random corpus,
-    ref:src/baseline_mips_module.py:29-30): the item tower over THIS rank's rows of the catalogue -- item r is row r of
-    the item table, `item_features_block` [hi - lo, II] the features of rows [lo, hi) -- installed as this rank's block of
-    a ShardedMIPS.  Its search() equals TwoTowerBaseRetrieval.index_corpus + forward on one device with
-    `full_state_dict(model)`."""
+def index_corpus_sharded(model: nn.Module, item_features_block: torch.Tensor, bf16: bool = False):
+    """Serve what was trained: `model.index_corpus` for the usual catalogue -- item r is row r of
+    the item table, `item_features_block` [hi - lo, II] the features of THIS rank's item rows [lo, hi) -- without any
+    exchange (every id is this rank's own row).  Returns the model's (row-sharded) mips_module."""
     w = model.item_id_embedding_arch.weight
     sh = shard_of(w)
     if sh is None:
         raise ValueError("index_corpus_sharded: the model's item table is not row-sharded")
-    feats = item_features_block.to(w.device, torch.float32)
-    if feats.shape[0] != sh.n_local:
-        raise ValueError(f"item_features_block: expected {sh.n_local} rows (this rank's item rows), got {feats.shape[0]}")
-    if sh.n_local > 0:
-        with local_rows():
-            corpus = model.compute_item_embeddings(torch.arange(sh.n_local, device=w.device), feats)
-    else:  # a rank that owns no item row
-        corpus = torch.empty(0, sh.dim, dtype=torch.float32, device=w.device)
-    return ShardedMIPS(corpus, sh.lo)
+    if item_features_block.shape[0] != sh.n_local:
+        raise ValueError(f"item_features_block: expected {sh.n_local} rows (this rank's item rows), got "
+                         f"{item_features_block.shape[0]}")
+    model.index_corpus(torch.arange(sh.lo, sh.hi, device=w.device), item_features_block.to(w.device, torch.float32), bf16=bf16)
+    return model.mips_module
 
 
 def env_world_size() -> int:

@@ -158,7 +158,8 @@ def main(args):
     model = model.to(device)
     if world > 1:
         parallel.shard_model_(model)
-    # every rank draws its own records (a different stream per rank: the ranks' default generators start identical)
+    # every rank draws its own records (a different seed per rank; the tables' row blocks are seeded per block by
+    # parallel.embedding, so ranks whose default generators start identical still hold different rows)
     dataset = DummyRecDataset(num_samples=max(args.num_samples // world, 1), num_users=args.num_users, num_items=args.num_items,
                               feature_dim=args.feature_dim, user_history_seqlen=args.user_history_seqlen, device=device,
                               seed=(20240 + rank) if world > 1 else None)
@@ -179,6 +180,24 @@ def main(args):
             say(f"  {len(dataset) * world / dt:,.0f} user-item pairs/s end to end (shuffle + batch slicing + step), "
                 f"{dt / len(dataloader) * 1e3:.3f} ms/step")
     optimizer.flush()  # deferred schedule: the tables are complete again from here on
+    if getattr(args, "dtype", "fp32") == "bf16" and not getattr(args, "retrieve", False):
+        model.mips_module.use_bf16_storage()
+    if getattr(args, "retrieve", False):
+        # serve what was trained: catalogue = the item table's rows; sharded: every rank indexes ITS rows
+        n_cat = args.item_id_hash_size
+        _, lo, hi = parallel.block_range(n_cat, rank, world) if world > 1 else (n_cat, 0, n_cat)
+        feats = torch.randn(hi - lo, args.feature_dim, device=device,
+                            generator=torch.Generator(device=device).manual_seed(777 + lo))
+        model.eval()
+        with torch.no_grad():
+            model.index_corpus(torch.arange(lo, hi, device=device), feats, bf16=getattr(args, "dtype", "fp32") == "bf16")
+            uid, uf, uh = (t.to(device) for t in next(iter(dataloader))[:3])
+            model.num_items = min(model.num_items, model.mips_module.corpus_size)
+            top = model(uid, uf, uh)
+        say(f"Retrieved top-{top.shape[1]} of {model.mips_module.corpus_size} items for {top.shape[0]} users "
+            f"({str(model.mips_module.corpus.dtype).replace('torch.', '')} corpus"
+            + (f", {world} row blocks" if world > 1 else "") + f"); first row: {top[0, :5].tolist()}")
+        stats.append({"retrieved": tuple(top.shape), "corpus_dtype": str(model.mips_module.corpus.dtype)})
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
@@ -208,6 +227,12 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--world_size", type=int, default=0,
                    help="row-shard the tables over this many GPUs (one process per GPU under torchrun; default: WORLD_SIZE "
                         "from the launcher, else 1); --batch_size and the printed loss are per rank / of the global batch")
+    p.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
+                   help="storage of the MIPS corpus the model serves from (BASELINE config 5: bf16).  Training arithmetic is "
+                        "IEEE fp32 either way, like the reference's")
+    p.add_argument("--retrieve", action="store_true",
+                   help="after training: index the catalogue with the trained item tower (model.index_corpus; item r = row r of "
+                        "the item table, random features) and run model.forward() on one batch -- row-sharded with --world_size N")
     p.add_argument("--lazy_adam", action="store_true",
                    help="value-exact deferred Adam: replay a row's zero-gradient steps when it is next needed")
     return p

@@ -138,7 +138,12 @@ class TwoTowerBaseRetrieval(nn.Module):
     def forward(self, user_id: torch.Tensor, user_features: torch.Tensor, user_history: torch.Tensor) -> torch.Tensor:
         """Top ``num_items`` MIPS row indices per user, [B, num_items] int64 (ref :221-249)."""
         user_embedding = self.compute_user_embedding(user_id, user_features, user_history)
-        top_items, _, _ = self.mips_module(query_embedding=user_embedding, num_items=self.num_items)
+        if type(self.mips_module).forward is BaselineMIPSModule.forward:
+            # this package's module: the reference discards the scores and the [B, K, DI] rows (ref :246-248) -- do not
+            # gather (row-sharded corpus: do not exchange) half a gigabyte of rows at B = 1024, K = 1000 to drop them
+            top_items, _ = self.mips_module.search(user_embedding, self.num_items)
+        else:  # any other mips_module (a subclass, the caller's own): the reference's call, keyword for keyword
+            top_items, _, _ = self.mips_module(query_embedding=user_embedding, num_items=self.num_items)
         N.oob.poll(user_embedding.device, blocking=True)
         return top_items
 
@@ -148,13 +153,43 @@ class TwoTowerBaseRetrieval(nn.Module):
                      bf16: bool = False) -> None:
         """Serve what was trained (upstream searches a random corpus): run the item
         tower over the catalogue (item_id [C], item_features [C, II]) in chunks and install the
-        embeddings as the MIPS corpus -- corpus row r is item item_id[r]."""
+        embeddings as the MIPS corpus -- corpus row r is item item_id[r].
+
+        Row-sharded model (collective: every rank calls): `item_id` / `item_features` are THIS RANK'S BLOCK of the
+        catalogue -- rows [lo, hi) = parallel.block_range(C, rank, world)[1:], any item ids -- and the model's
+        mips_module becomes (or stays) row-sharded with that block; `forward()` then searches all blocks together.  When
+        every rank's ids are rows it owns itself (the usual catalogue: item r = row r of the item table) no row travels."""
+        sharded = self._sharded()
+        local_only = False
+        if sharded:
+            w = self.item_id_embedding_arch.weight
+            sh = parallel.shard_of(w)
+            mine = torch.ones(1, dtype=torch.int32, device=item_id.device)
+            if item_id.numel():
+                mine = ((item_id >= sh.lo) & (item_id < sh.hi)).all().to(torch.int32).reshape(1)
+            local_only = bool(parallel.C.all_reduce_(mine, op=parallel.dist.ReduceOp.MIN).item())  # one decision for the group
+            # every rank runs the same number of chunks (routed lookups are collective); a rank whose block is shorter
+            # looks up row 0 once per surplus chunk and drops the result
+            per = torch.tensor([item_id.shape[0]], dtype=torch.int64, device=item_id.device)
+            n_chunks = -(-int(parallel.C.all_reduce_(per, op=parallel.dist.ReduceOp.MAX).item()) // chunk)
+        else:
+            n_chunks = -(-item_id.shape[0] // chunk)
         out = torch.empty(item_id.shape[0], self.item_id_embedding_arch.weight.shape[1], dtype=torch.float32,
                           device=item_id.device)
-        for lo in range(0, item_id.shape[0], chunk):
-            hi = min(lo + chunk, item_id.shape[0])
-            out[lo:hi] = self.compute_item_embeddings(item_id[lo:hi], item_features[lo:hi])
-        self.mips_module.set_corpus(out, bf16=bf16)
+        for c in range(n_chunks):
+            lo, hi = min(c * chunk, item_id.shape[0]), min((c + 1) * chunk, item_id.shape[0])
+            if local_only:
+                if hi > lo:
+                    with parallel.local_rows():
+                        out[lo:hi] = self.compute_item_embeddings(item_id[lo:hi] - sh.lo, item_features[lo:hi])
+            elif hi > lo:
+                out[lo:hi] = self.compute_item_embeddings(item_id[lo:hi], item_features[lo:hi])
+            else:
+                self.compute_item_embeddings(item_id.new_zeros(1), item_features.new_zeros(1, item_features.shape[1]))
+        if sharded:
+            self.mips_module.set_corpus(out, bf16=bf16, block=True)  # becomes (or stays) row-sharded
+        else:
+            self.mips_module.set_corpus(out, bf16=bf16)
 
     def debias_net_user_value(
         self, net_user_value: torch.Tensor, position: torch.Tensor, user_embedding: torch.Tensor
@@ -272,7 +307,12 @@ class TwoTowerBaseRetrieval(nn.Module):
         if self._sharded():
             # the item tower FIRST (the towers are independent): autograd then runs the user tower's backward before the
             # item tower's, i.e. underneath the reduce-scatter of dI that the item tower's backward has to wait for
-            self._tt_item_emb_single_use = type(self).compute_item_embeddings is TwoTowerBaseRetrieval.compute_item_embeddings
+            # (deferred reduce-scatter of dI: only while every method that can see `item_embeddings` is this package's own --
+            # a subclass's loss that ALSO uses them elsewhere would make autograd sum the in-flight result on the main stream)
+            self._tt_item_emb_single_use = (
+                type(self).compute_item_embeddings is TwoTowerBaseRetrieval.compute_item_embeddings
+                and all(getattr(type(self), m).__module__.startswith(__package__ + ".")
+                        for m in ("compute_training_loss", "_loss_head", "_sharded_training_loss")))
             item_embeddings = self.compute_item_embeddings(item_id, item_features)
             # ... and its all-gather (every rank scores against every rank's items) travels underneath the user tower
             self._tt_item_gather = (item_embeddings, parallel.start_all_gather(item_embeddings))
