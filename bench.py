@@ -138,7 +138,8 @@ def sysfs_clocks():
 
 def hbm_copy_calibration(lib, N, device, nbytes, launches=7):
     """The box's own HBM streaming rate, measured in THIS process right after the timed steps: tt_stream_copy (16-byte
-    non-temporal loads / stores, the sweep's width) of a buffer as large as the sweep's footprint -- `nbytes` / 2 read and
+    non-temporal loads / stores, one-shot grid: the fastest of the copies tools/copy_probe.hip tries) of a buffer as large as
+    the sweep's footprint -- `nbytes` / 2 read and
     `nbytes` / 2 written per launch.  Median of `launches` HIP-event pairs.  The guide quotes 6.29 TB/s for this
     measurement; the sweep's `frac_of_copy` says how the kernel does against what this box can stream at all."""
     half = int(nbytes // 2) // 16 * 16
@@ -150,7 +151,7 @@ def hbm_copy_calibration(lib, N, device, nbytes, launches=7):
     for _ in range(launches + 1):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        N.check(lib.tt_stream_copy(src.data_ptr(), dst.data_ptr(), half, 0, N.stream()), "tt_stream_copy")
+        N.check(lib.tt_stream_copy(src.data_ptr(), dst.data_ptr(), half, N.stream()), "tt_stream_copy")
         b.record()
         evs.append((a, b))
     torch.cuda.synchronize()
@@ -837,7 +838,9 @@ def timed_c5(cfg, device, world, rank, steps, warmup, sharded, comm_timing=True)
     lib.tt_profile_enable(0)
     rows_local = model.mips_module.corpus.shape[0]
     n_q = cfg["B"] * group  # queries this rank scores per call (all ranks' queries on its own block)
-    flops = 2.0 * n_q * rows_local * cfg["D"]
+    # one dense scoring launch covers at most 1024 queries (csrc/mips.hip MIPS_QBATCH): W*B queries = several launches per call
+    flops_call = 2.0 * n_q * rows_local * cfg["D"]
+    flops = flops_call * steps / max(cnt.value, 1)  # per launch
     tf = flops * cnt.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else None
     peak = MFMA_BF16_PEAK_TF if mp["bf16"] else MFMA_F32_PEAK_TF
     sustained = mfma_sustained_peak(lib, N, device, N.TT_BF16 if mp["bf16"] else N.TT_F32)
@@ -845,7 +848,8 @@ def timed_c5(cfg, device, world, rank, steps, warmup, sharded, comm_timing=True)
             "unit": "TFLOP/s", "frac": round(tf / peak, 4) if tf else None,
             "sustained_peak": sustained, "frac_of_sustained": round(tf / sustained, 4) if (tf and sustained) else None,
             "avg_launch_ms": round(ms.value / max(cnt.value, 1), 4), "launches": cnt.value,
-            "algorithmic_flops_per_launch": flops, "traffic": None,
+            "algorithmic_flops_per_launch": flops, "launches_per_call": round(cnt.value / max(steps, 1), 2),
+            "scoring_ms_per_call": round(ms.value / max(steps, 1), 4), "traffic": None,
             "sustained_peak_note": "sustained_peak = tt_mfma_probe in this process (register-only MFMA loop, random operands: the "
                                    "pipe at this box's power budget, 0.58-0.66 of the 2.5 PF spec figure on this class of box)"}
     return {"seconds": dt, "ms_per_call": dt / steps * 1e3, "roofline": roof, "comm_ms": comm_ms,

@@ -457,9 +457,9 @@ int tt_pack_grads(const tt_adam_tensor* tensors /*host*/, int32_t n_tensors, tt_
  * copy_ calls of ref:train/train.py:91-99 per step. */
 int tt_copy_buffers(const tt_adam_tensor* buffers /*host*/, int32_t n_buffers, tt_stream_t stream);
 /* Measurement aid (bench.py `roofline.hbm_copy_GBps`; no counterpart in the reference): the plain HBM streaming copy --
- * 16-byte non-temporal loads and stores, `n_wgs` persistent workgroups (0 = 768, the table sweep's default width) --
- * that calibrates what THIS box's HBM streams next to the sweep's own figure.  `bytes` are read and `bytes` written. */
-int tt_stream_copy(const void* src, void* dst, int64_t bytes, int32_t n_wgs, tt_stream_t stream);
+ * 16-byte non-temporal loads and stores, one 16 KB chunk per workgroup -- that calibrates what THIS box's HBM streams next
+ * to the sweep's own figure.  `bytes` are read and `bytes` written. */
+int tt_stream_copy(const void* src, void* dst, int64_t bytes, tt_stream_t stream);
 /* Measurement aid (bench.py `roofline.sustained_peak`): a register-only MFMA loop on random operands over the whole chip
  * (512 workgroups x 4 waves x `iters` x 4 independent 32x32 MFMAs; dtype 0 = fp32 32x32x2, 1 = bf16 32x32x16 -- TT_F32 /
  * TT_BF16 below) -- what the matrix pipe of THIS box sustains at its power budget, which is what a kernel priced against
@@ -558,6 +558,41 @@ int tt_route_build(const int64_t* ids, int64_t n_ids, int64_t n_rows, int64_t ro
                    int64_t* src_of, int32_t* overflow_flag, tt_stream_t stream);
 int tt_route_localize(const int64_t* ids, int64_t n_ids, int64_t lo, int64_t n_local, int64_t* local,
                       tt_stream_t stream);
+/* The same stages for ALL lookups of a step per launch (a step routes 2-3 id lists of a few thousand ids: 3-7 us kernels
+ * that stood 6-15 us apart).  Up to TT_ROUTE_MAX_JOBS jobs per call; host arrays of descriptors, device pointers inside.
+ *   tt_route_count_jobs  tt_route_count per job in two launches for all jobs; *max_count is WRITTEN (not atomicMax'ed:
+ *                        nothing to zero first).
+ *   tt_route_build_jobs  tt_route_build per job in ONE launch, the -1 fill of send_ids / src_of included (a slot
+ *                        o*cap + r is padding iff r >= counts[o], which the count stage left in `counts`).
+ *   tt_route_serve_jobs  owner side, ONE launch: tt_route_localize + the row gather of every received id list --
+ *                        local[i] as above, rows[i] = table[local[i]] widened to fp32 (dtype TT_F32 / TT_BF16 = the
+ *                        table's storage) or a zero row for the sentinel. */
+#define TT_ROUTE_MAX_JOBS 8
+typedef struct {
+  const int64_t* ids;    /* this rank's ids [n_ids] */
+  int64_t n_ids, n_rows, rows_per_rank;
+  int32_t* counts;       /* [world]: out of _count_jobs, in of _build_jobs */
+  int32_t* max_count;    /* [1]: out of _count_jobs */
+  void* ws;              /* tt_route_workspace_bytes(n_ids, world): written by _count_jobs, read by _build_jobs */
+  int64_t ws_bytes;
+  int64_t cap;           /* _build_jobs only (ignored by _count_jobs), with the three outputs below */
+  int64_t* send_ids;     /* [world * cap] */
+  int64_t* slot_of;      /* [n_ids] */
+  int64_t* src_of;       /* [world * cap] */
+} tt_route_job;
+typedef struct {
+  const int64_t* ids;    /* received global ids [n_ids] (-1 = padding) */
+  int64_t n_ids, lo, n_local;
+  int64_t* local;        /* out [n_ids] */
+  const void* table;     /* this rank's row block [n_local, dim], fp32 or bf16 */
+  int dtype;             /* TT_F32 / TT_BF16 */
+  int64_t dim;
+  float* rows;           /* out [n_ids, dim] */
+} tt_route_serve_job;
+int tt_route_count_jobs(const tt_route_job* jobs /*host*/, int32_t n_jobs, int32_t world, int32_t* oob_flag, tt_stream_t stream);
+int tt_route_build_jobs(const tt_route_job* jobs /*host*/, int32_t n_jobs, int32_t world, int32_t* overflow_flag,
+                        tt_stream_t stream);
+int tt_route_serve_jobs(const tt_route_serve_job* jobs /*host*/, int32_t n_jobs, tt_stream_t stream);
 
 /* ---------------------------------------------------------------- R collectives (RCCL over xGMI)
  * New design (SURVEY.md 2b R1-R4, 8b "tt_comm_*"): the reference has no communication.  One communicator per

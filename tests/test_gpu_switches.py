@@ -34,7 +34,9 @@ for s in range(4):
     loss = m.train_forward(*[t.to(dev) for t in b])
     opt.zero_grad(); loss.backward(); opt.step()
     losses.append(float(loss))
+w = m.item_id_embedding_arch.weight
 out = {"losses": losses, "side_grads": ops._SIDE_GRADS, "sweep_note": opt.sweep_level_note(),
+       "in_arena": w.untyped_storage().nbytes() > w.numel() * 4,
        "checksum": float(sum(p.double().sum() for p in m.parameters()))}
 if os.environ.get("TT_RCCL_PATH"):
     from two_tower_models_amd.comm import NativeComm
@@ -56,12 +58,14 @@ def _run(env_extra):
 
 def test_scheduling_switches_do_not_change_results():
     base, _ = _run({})
-    assert base["side_grads"] is True
+    assert base["side_grads"] is True and base["in_arena"] is True
     # weight gradients in line (the safe mode under DDP-style reducers), a fixed sweep width with the controller's debug line
     # on, RCCL loaded from an explicit path: scheduling only -> bit-identical
-    sched, err = _run({"TT_WGRAD_MAIN": "1", "TT_SWEEP_WGS": "256", "TT_TUNE_DEBUG": "1", "TT_RCCL_PATH": "/opt/rocm/lib/librccl.so.1"})
-    assert sched["side_grads"] is False and sched["sweep_note"] == "fixed by TT_SWEEP_WGS" and sched["comm_size"] == [0, 1]
+    # ... the tables and moments left where torch allocated them instead of re-homed into one arena
+    sched, err = _run({"TT_WGRAD_MAIN": "1", "TT_SWEEP_WGS": "256", "TT_TUNE_DEBUG": "1", "TT_RCCL_PATH": "/opt/rocm/lib/librccl.so.1",
+                       "TT_ADAM_NO_ARENA": "1"})
+    assert sched["in_arena"] is False and sched["side_grads"] is False and sched["sweep_note"] == "fixed by TT_SWEEP_WGS" and sched["comm_size"] == [0, 1]
     assert sched["losses"] == base["losses"] and sched["checksum"] == base["checksum"]
     # the debias head as the hook's tensor expressions instead of the fused kernels: same maths, another summation order
     unfused, _ = _run({"TT_DEBIAS_NO_FUSED": "1"})
-    assert all(abs(a - b) < 2e-5 for a, b in zip(unfused["losses"], base["losses"])), (unfused["losses"], base["losses"])
+    assert all(abs(a - b) <= 2e-6 * abs(b) for a, b in zip(unfused["losses"], base["losses"])), (unfused["losses"], base["losses"])

@@ -220,7 +220,17 @@ def test_exchanges_deliver_the_reference_gradients_of_the_concatenated_batch(wor
 
 
 # ---------------------------------------------------------------- sharded MIPS behind BaselineMIPSModule
-def _mips_worker(rank, world, port, outdir, C, K, bf16, how):
+def _corpus(C, skewed):
+    """fixture_gen's exact-arithmetic corpus; `skewed`: the first quarter of the rows doubled (exact), so that nearly every
+    query's whole top-K lies in ONE block -- the case the first-try k' of parallel.sharded_topk must detect, not assume away."""
+    import fixture_gen as fg
+    corpus = torch.from_numpy(fg.exact_mips_corpus(C, 32))
+    if skewed:
+        corpus[: C // 4] *= 2.0
+    return corpus
+
+
+def _mips_worker(rank, world, port, outdir, C, K, bf16, how, skewed=False):
     _paths()
     import torch.distributed as dist
     import fixture_gen as fg
@@ -232,7 +242,7 @@ def _mips_worker(rank, world, port, outdir, C, K, bf16, how):
     parallel.set_route_kernels_for_tests(OracleRouteKernels())
     parallel.set_mips_kernels_for_tests(OracleMipsKernels())
     try:
-        corpus = torch.from_numpy(fg.exact_mips_corpus(C, 32))
+        corpus = _corpus(C, skewed)
         _, lo, hi = parallel.block_range(C, rank, world)
         if how == "born":  # constructed under row_sharded(): the block is born on its owner, then filled
             with parallel.row_sharded():
@@ -261,17 +271,19 @@ def _mips_worker(rank, world, port, outdir, C, K, bf16, how):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,C,K,bf16,how", [(2, 700, 20, False, "born"), (3, 100, 40, True, "cut"),
-                                               (4, 5, 3, False, "cut"), (2, 64, 64, True, "born")])
-def test_sharded_mips_module_equals_single_device(world, C, K, bf16, how):
+@pytest.mark.parametrize("world,C,K,bf16,how,skewed", [(2, 700, 20, False, "born", False), (3, 100, 40, True, "cut", False),
+                                                      (4, 5, 3, False, "cut", False), (2, 64, 64, True, "born", False),
+                                                      # K large enough for the first-try k' (160 of 400): enough / not enough
+                                                      (4, 4000, 400, False, "born", False), (4, 4000, 400, False, "cut", True)])
+def test_sharded_mips_module_equals_single_device(world, C, K, bf16, how, skewed):
     """A row-sharded BaselineMIPSModule (incl. a block smaller than K, an empty block, K = the whole corpus, bf16 blocks)
     returns the unsharded module's 3-tuple: exact top-K indices + scores, and embeddings == corpus[idx]."""
     _paths()
     import fixture_gen as fg
     from oracle import cpu_ref as R
     outdir = tempfile.mkdtemp()
-    mp.spawn(_mips_worker, args=(world, _free_port(), outdir, C, K, bf16, how), nprocs=world, join=True)
-    corpus = torch.from_numpy(fg.exact_mips_corpus(C, 32))  # (small integers: its bf16 form is the same numbers)
+    mp.spawn(_mips_worker, args=(world, _free_port(), outdir, C, K, bf16, how, skewed), nprocs=world, join=True)
+    corpus = _corpus(C, skewed)  # (small integers: its bf16 form is the same numbers)
     q = torch.from_numpy(fg.exact_mips_queries(5 * world, 32))
     want_idx, want_sc, want_emb = R.mips_topk(R.round_to_bf16(q) if bf16 else q, corpus, K)
     for r in range(world):
@@ -281,6 +293,12 @@ def test_sharded_mips_module_equals_single_device(world, C, K, bf16, how):
             assert torch.equal(got["sc"], want_sc[r * 5:(r + 1) * 5])
         assert got["emb"].dtype == torch.float32 and torch.equal(got["emb"], want_emb[r * 5:(r + 1) * 5])
         assert {"mips_queries_allgather", "mips_lists_alltoall", "mips_rows_alltoall"} <= set(got["comm"])
+        from two_tower_models_amd import parallel
+        k1 = parallel.first_try_k(K, world)
+        rounds = [k1] if not skewed else [k1, K]  # the skewed corpus needs the second, full-k round -- and gets it
+        assert got["comm"]["mips_lists_alltoall"] == (world - 1) * 5 * 12 * sum(rounds), (got["comm"], k1)
+    if K == 400:
+        assert k1 == 160
 
 
 # ---------------------------------------------------------------- watchdog

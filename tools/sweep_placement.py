@@ -125,7 +125,7 @@ def main():
         for _ in range(reps):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            N.check(lib.tt_stream_copy(src.data_ptr(), dst.data_ptr(), src.numel() * 4, wgs, N.stream()), "copy")
+            N.check(lib.tt_stream_copy(src.data_ptr(), dst.data_ptr(), src.numel() * 4, N.stream()), "copy")
             b.record()
             evs.append((a, b))
         torch.cuda.synchronize()

@@ -61,6 +61,23 @@ class AdamFinishJob(C.Structure):
                 ("side_bytes", _i64)]
 
 
+TT_ROUTE_MAX_JOBS = 8
+
+
+class RouteJob(C.Structure):
+    """tt_route_job."""
+
+    _fields_ = [("ids", _vp), ("n_ids", _i64), ("n_rows", _i64), ("rows_per_rank", _i64), ("counts", _vp), ("max_count", _vp),
+                ("ws", _vp), ("ws_bytes", _i64), ("cap", _i64), ("send_ids", _vp), ("slot_of", _vp), ("src_of", _vp)]
+
+
+class RouteServeJob(C.Structure):
+    """tt_route_serve_job."""
+
+    _fields_ = [("ids", _vp), ("n_ids", _i64), ("lo", _i64), ("n_local", _i64), ("local", _vp), ("table", _vp), ("dtype", _int),
+                ("dim", _i64), ("rows", _vp)]
+
+
 # name -> (restype, argtypes); mirrors include/tt_hotpath.h declaration by declaration
 SIGNATURES = {
     "tt_abi_version": (_int, []),
@@ -153,13 +170,16 @@ SIGNATURES = {
                                _vp, _vp, _vp, _i64, _vp]),
     "tt_enc_last_bwd_data": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tt_enc_last_bwd_weights": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
-    "tt_stream_copy": (_int, [_vp, _vp, _i64, _i32, _vp]),
+    "tt_stream_copy": (_int, [_vp, _vp, _i64, _vp]),
     "tt_mfma_probe_flops": (_i64, [_int, _i32]),
     "tt_mfma_probe": (_int, [_int, _i32, _vp, _i64, _vp]),
     "tt_route_workspace_bytes": (_i64, [_i64, _i32]),
     "tt_route_count": (_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tt_route_build": (_int, [_vp, _i64, _i64, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "tt_route_localize": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "tt_route_count_jobs": (_int, [C.POINTER(RouteJob), _i32, _i32, _vp, _vp]),
+    "tt_route_build_jobs": (_int, [C.POINTER(RouteJob), _i32, _i32, _vp, _vp]),
+    "tt_route_serve_jobs": (_int, [C.POINTER(RouteServeJob), _i32, _vp]),
     "tt_comm_unique_id": (_int, [_vp]),
     "tt_comm_init": (_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
     "tt_comm_destroy": (_int, [_vp]),
@@ -211,7 +231,15 @@ def load() -> C.CDLL:
     return lib
 
 
+# tests/ only: when a list, receives -- in host order -- the name of every library call that enqueued work (`check`) and
+# "issue:<tag>" / "wait:<tag>" for every exchange of collectives.py: the ORDER in which a step issues its kernels and its
+# collectives is what decides which kernels can cover which exchange, and it can be asserted without a second GPU.
+trace: Optional[list] = None
+
+
 def check(rc: int, what: str) -> None:
+    if trace is not None:
+        trace.append(what)
     if rc != 0:
         msg = load().tt_last_error_string().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")

@@ -19,6 +19,8 @@ from typing import Dict, Optional
 import torch
 import torch.distributed as dist
 
+from . import _native as _N
+
 # ----------------------------------------------------------------- collectives
 # Two transports behind the same helpers: torch.distributed's process group (default; "nccl" = RCCL), or the
 # C ABI's own tt_comm_* (comm.NativeComm, `use_native_transport`) -- RCCL bound by libtt_hotpath.so itself.
@@ -227,8 +229,12 @@ class _Pending:
         self.tag, self.issued, self.wire = tag, issued, wire
         if tag is not None:
             note_exchange(tag, out)
+            if _N.trace is not None:
+                _N.trace.append("issue:" + tag)
 
     def wait(self) -> torch.Tensor:
+        if _N.trace is not None and self.tag is not None:
+            _N.trace.append("wait:" + self.tag)
         timing = _TIMING is not None and self.issued is not None
         w0 = _tev() if timing else None
         if self.work is not None:

@@ -1094,38 +1094,36 @@ extern "C" int tt_copy_buffers(const tt_adam_tensor* buffers, int32_t n_buffers,
 }
 
 // HBM calibration beside the sweep (bench.py `roofline.hbm_copy_GBps`): the plain streaming copy the guide's "measured
-// copy rate" refers to -- one 16-B non-temporal load + one 16-B non-temporal store per lane and float4, persistent
-// workgroups walking 4 KB-per-wave chunks like the sweep.  It moves 2 x bytes through HBM.
+// copy rate" refers to -- per lane four 16-B non-temporal loads, then four 16-B non-temporal stores; a ONE-SHOT grid, one
+// 16 KB chunk per workgroup.  Picked by measurement (tools/copy_probe.hip, profiles/r06_copy_probe.txt): 6.10 TB/s
+// against 5.0-5.6 for persistent grids of 512-4096 workgroups, 4.4 for 8 float4 per lane and 4.45 for hipMemcpyDtoD.
+// It moves 2 x bytes through HBM.
 namespace tt {
 __global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
   constexpr int ITERS = 4;
-  const int64_t n_chunks = (n4 + 256 * ITERS - 1) / (256 * ITERS);
-  for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-    const int64_t base = ch * (256 * ITERS) + threadIdx.x;
-    float4 v[ITERS];
+  const int64_t base = (int64_t)blockIdx.x * (256 * ITERS) + threadIdx.x;
+  float4 v[ITERS];
 #pragma unroll
-    for (int k = 0; k < ITERS; ++k) {
-      const int64_t i = base + (int64_t)k * 256;
-      if (i < n4) v[k] = sweep_load<true>(src + i);
-    }
+  for (int k = 0; k < ITERS; ++k) {
+    const int64_t i = base + (int64_t)k * 256;
+    if (i < n4) v[k] = sweep_load<true>(src + i);
+  }
 #pragma unroll
-    for (int k = 0; k < ITERS; ++k) {
-      const int64_t i = base + (int64_t)k * 256;
-      if (i < n4) sweep_store<true>(v[k], dst + i);
-    }
+  for (int k = 0; k < ITERS; ++k) {
+    const int64_t i = base + (int64_t)k * 256;
+    if (i < n4) sweep_store<true>(v[k], dst + i);
   }
 }
 }  // namespace tt
 
-extern "C" int tt_stream_copy(const void* src, void* dst, int64_t bytes, int32_t n_wgs, tt_stream_t stream) {
+extern "C" int tt_stream_copy(const void* src, void* dst, int64_t bytes, tt_stream_t stream) {
   if (!src || !dst) return fail_arg("tt_stream_copy: null pointer");
   if (bytes <= 0 || bytes % 16 || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15))
     return fail_arg("tt_stream_copy: 16-byte aligned buffers, a multiple of 16 bytes");
   const int64_t n4 = bytes / 16;
-  int64_t wgs = n_wgs > 0 ? n_wgs : 768;  // the sweep's default: 3 per CU
-  const int64_t chunks = ceil_div(n4, 256 * 4);
-  if (wgs > chunks) wgs = chunks;
-  stream_copy_kernel<<<(unsigned)wgs, 256, 0, S(stream)>>>(reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n4);
+  const int64_t blocks = ceil_div(n4, 256 * 4);
+  if (blocks >= (1ll << 31)) return fail_arg("tt_stream_copy: at most 32 TiB per call");
+  stream_copy_kernel<<<(unsigned)blocks, 256, 0, S(stream)>>>(reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n4);
   return check_launch("stream_copy_kernel");
 }
 

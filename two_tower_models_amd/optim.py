@@ -155,13 +155,19 @@ class DenseExactAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         self._hyper = torch.tensor([g["lr"], g["betas"][0], g["betas"][1], g["eps"], 0.0, 0.0, 0.0, 0.0],
                                    dtype=torch.float64, device=dev)
+        arena = bool(self._tables) and all(p.is_cuda for p in self._tables) and os.environ.get("TT_ADAM_NO_ARENA") is None
+        in_arena = {id(p) for p in self._tables} if arena else set()
         for p in self._params:
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise TypeError("DenseExactAdam needs contiguous fp32 parameters")
             st = self.state[p]
             for key in ("exp_avg", "exp_avg_sq"):  # a loaded checkpoint already supplied them
+                if key not in st and id(p) in in_arena:
+                    continue  # born as zeros inside the arena below
                 if key not in st or st[key].shape != p.shape or st[key].device != p.device:
                     st[key] = torch.zeros_like(p) if key not in st else st[key].to(p.device, torch.float32).contiguous()
+        if arena:
+            self._home_tables_in_one_arena()
         self._side_stream = N.low_priority_stream(dev)
         start = int(self._resume_step)
         self._hyper[4] = float(start)  # [5], [6] are recomputed from the step by every advance
@@ -173,6 +179,47 @@ class DenseExactAdam(torch.optim.Optimizer):
             self._tab_steps = max(1 << 16, 2 * (start + 2))
             self._tab = torch.zeros(2 * self._tab_steps, dtype=torch.float32, device=dev)
         self._ready = True
+
+    def _home_tables_in_one_arena(self) -> None:
+        """Every table's p, m, v in ONE device allocation, back to back on 2 MiB boundaries (the Parameter keeps its identity:
+        `p.data` becomes a view of the arena).  Measured, not aesthetic (profiles/r06_sweep_placement.txt): the sweep streams
+        the six arrays of the P tables at 6.56-6.62 TB/s from any of 40 random placements inside one allocation, and at
+        6.0-6.15 TB/s -- 7 % less -- from six allocations of torch's caching allocator IN THE SAME PROCESS on the same box;
+        which of the two a process gets from separate allocations is a lottery per process (two bench.py processes on one
+        box: 5.42 and 5.87 ms per step), and it is the 8 % "slow mode" the driver's round-5 line hit.  Costs one transient
+        copy of the tables at the first step.  A caller that saves `model.state_dict()` on its own afterwards stores the
+        arena's bytes (tables + moments); `{k: v.clone() for k, v in model.state_dict().items()}` stores the tables only."""
+        A = 2 << 20
+        sizes = [(p.numel() * 4 + A - 1) // A * A for p in self._tables]
+        try:
+            arena = torch.empty(3 * sum(sizes) + A, dtype=torch.uint8, device=self._tables[0].device)
+        except torch.OutOfMemoryError:  # no room for the transient second copy of the tables: stay where they are
+            for p in self._tables:
+                for key in ("exp_avg", "exp_avg_sq"):
+                    self.state[p].setdefault(key, torch.zeros_like(p))
+            return
+        off = (-arena.data_ptr()) % A
+
+        def take(p, size):
+            nonlocal off
+            v = arena[off:off + p.numel() * 4].view(torch.float32).view(p.shape)
+            off += size
+            return v
+
+        with torch.no_grad():
+            for p, size in zip(self._tables, sizes):
+                st = self.state[p]
+                home = take(p, size)
+                home.copy_(p.data)
+                p.data = home
+                for key in ("exp_avg", "exp_avg_sq"):
+                    v = take(p, size)
+                    if key in st:
+                        v.copy_(st[key])  # what a loaded checkpoint supplied
+                    else:
+                        v.zero_()
+                    st[key] = v
+        self._arena = arena
 
     # ------------------------------------------------------------------ deferred schedule
     def _catch_up(self, p: torch.nn.Parameter, ids: torch.Tensor) -> None:

@@ -249,6 +249,90 @@ class _HipRouteKernels:
         return out
 
 
+    # ---- all lookups of a step per launch (csrc/route.hip RouteJobs): 4 launches where the per-lookup calls above took 13
+    def route_plan_many(self, items, max_out: torch.Tensor):
+        """items: [(ids, n_rows, rows_per_rank, world)]; max_out int32 [len(items)] is WRITTEN.  -> route_plan's tuples."""
+        N, lib = self.N, self.lib
+        out = []
+        for c0 in range(0, len(items), N.TT_ROUTE_MAX_JOBS):
+            chunk = items[c0:c0 + N.TT_ROUTE_MAX_JOBS]
+            jobs = (N.RouteJob * len(chunk))()
+            world = chunk[0][3]
+            for k, (ids, n_rows, rpr, w) in enumerate(chunk):
+                ws = torch.empty(lib.tt_route_workspace_bytes(ids.numel(), w), dtype=torch.uint8, device=self.device)
+                counts = torch.empty(w, dtype=torch.int32, device=self.device)
+                j = jobs[k]
+                j.ids, j.n_ids, j.n_rows, j.rows_per_rank = ids.data_ptr(), ids.numel(), n_rows, rpr
+                j.counts, j.max_count = counts.data_ptr(), max_out[c0 + k:c0 + k + 1].data_ptr()
+                j.ws, j.ws_bytes = ws.data_ptr(), ws.numel()
+                out.append((ids, n_rows, ws, counts))
+            N.check(lib.tt_route_count_jobs(jobs, len(chunk), world, N.oob.flag(self.device).data_ptr(), N.stream()),
+                    "tt_route_count_jobs")
+        return out
+
+    def route_build_many(self, planned, rows_per_rank, world: int, caps):
+        """-> [(send_ids, slot_of, src_of)] for route_plan tuples `planned`, in one launch (the -1 fill included)."""
+        N, lib = self.N, self.lib
+        out = []
+        for c0 in range(0, len(planned), N.TT_ROUTE_MAX_JOBS):
+            chunk = planned[c0:c0 + N.TT_ROUTE_MAX_JOBS]
+            jobs = (N.RouteJob * len(chunk))()
+            for k, (ids, n_rows, ws, counts) in enumerate(chunk):
+                cap = caps[c0 + k]
+                send_ids = torch.empty(world * cap, dtype=torch.int64, device=self.device)
+                src_of = torch.empty(world * cap, dtype=torch.int64, device=self.device)
+                slot_of = torch.empty(ids.numel(), dtype=torch.int64, device=self.device)
+                j = jobs[k]
+                j.ids, j.n_ids, j.n_rows, j.rows_per_rank = ids.data_ptr(), ids.numel(), n_rows, rows_per_rank[c0 + k]
+                j.counts, j.max_count, j.ws, j.ws_bytes = counts.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel()
+                j.cap, j.send_ids, j.slot_of, j.src_of = cap, send_ids.data_ptr(), slot_of.data_ptr(), src_of.data_ptr()
+                out.append((send_ids, slot_of, src_of))
+            N.check(lib.tt_route_build_jobs(jobs, len(chunk), world, N.oob.flag(self.device).data_ptr(), N.stream()),
+                    "tt_route_build_jobs")
+        return out
+
+    def serve_many(self, items):
+        """Owner side.  items: [(table block, received ids, lo, n_local)] -> [(local ids, rows [n, D] fp32)], one launch."""
+        N, lib = self.N, self.lib
+        out = []
+        for c0 in range(0, len(items), N.TT_ROUTE_MAX_JOBS):
+            chunk = items[c0:c0 + N.TT_ROUTE_MAX_JOBS]
+            jobs = (N.RouteServeJob * len(chunk))()
+            for k, (table, ids, lo, n_local) in enumerate(chunk):
+                local = torch.empty_like(ids)
+                rows = torch.empty(ids.numel(), table.shape[1], dtype=torch.float32, device=self.device)
+                j = jobs[k]
+                j.ids, j.n_ids, j.lo, j.n_local, j.local = ids.data_ptr(), ids.numel(), lo, max(n_local, 0), local.data_ptr()
+                j.table, j.dtype = table.data_ptr(), (N.TT_BF16 if table.dtype == torch.bfloat16 else N.TT_F32)
+                j.dim, j.rows = table.shape[1], rows.data_ptr()
+                out.append((local, rows))
+            N.check(lib.tt_route_serve_jobs(jobs, len(chunk), N.stream()), "tt_route_serve_jobs")
+        return out
+
+
+def _plan_many(K, items, max_out):
+    if hasattr(K, "route_plan_many"):
+        return K.route_plan_many(items, max_out)
+    max_out.zero_()  # (the per-lookup form atomicMax'es; the tests' CPU restatement takes this path)
+    return [K.route_plan(ids, n_rows, rpr, w, max_out[k:k + 1]) for k, (ids, n_rows, rpr, w) in enumerate(items)]
+
+
+def _build_many(K, planned, rows_per_rank, world, caps):
+    if hasattr(K, "route_build_many"):
+        return K.route_build_many(planned, rows_per_rank, world, caps)
+    return [K.route_build(pl, rpr, world, cap) for pl, rpr, cap in zip(planned, rows_per_rank, caps)]
+
+
+def _serve_many(K, items):
+    if hasattr(K, "serve_many"):
+        return K.serve_many(items)
+    out = []
+    for table, ids, lo, n_local in items:
+        local = K.localize(ids, lo, n_local)
+        out.append((local, K.gather_owned(table, local, n_local)))
+    return out
+
+
 _ROUTE_KERNELS = {}
 _ROUTE_KERNELS_TEST = [None]
 
@@ -340,9 +424,9 @@ def plan_routes(specs) -> _PlannedRoutes:
     """Count each lookup's ids by owner and start the all-reduce (MAX) of the bucket maxima + its copy to the host."""
     dev = specs[0][1].device
     K = _kernels(dev)
-    counts = torch.zeros(len(specs), dtype=torch.int32, device=dev)
-    planned, keep = [], []
-    for k, (p, ids) in enumerate(specs):
+    counts = torch.empty(len(specs), dtype=torch.int32, device=dev)
+    keep, items = [], []
+    for p, ids in specs:
         sh = shard_of(p)
         # a private copy: route_build ranks THESE ids against the bucket offsets counted here, whatever happens to the
         # caller's tensor in between (a writer torch does not see -- a prefetcher's raw memcpy -- would otherwise put two
@@ -350,7 +434,8 @@ def plan_routes(specs) -> _PlannedRoutes:
         flat = ids.reshape(-1)
         flat = flat.clone() if (flat.dtype == torch.int64 and flat.is_contiguous()) else flat.to(torch.int64).contiguous()
         keep.append(flat)
-        planned.append(K.route_plan(flat, sh.n_rows, sh.rows_per_rank, sh.world, counts[k:k + 1]))
+        items.append((flat, sh.n_rows, sh.rows_per_rank, sh.world))
+    planned = _plan_many(K, items, counts)  # every lookup's owner histogram + scan: two launches
     if dist.get_world_size() > 1:
         C.all_reduce_start_(counts, op=dist.ReduceOp.MAX, tag="route_caps_allreduce").wait()
     if counts.is_cuda:
@@ -382,17 +467,18 @@ def _start_lookups(specs, routes: _PlannedRoutes,
     K = _kernels(dev)
     caps = routes.caps()
     lks: List[Tuple[nn.Parameter, _RoutedLookup]] = []
-    for (p, ids), planned, cap in zip(specs, routes.planned, caps):
-        sh = shard_of(p)
-        send_ids, slot_of, src_of = K.route_build(planned, sh.rows_per_rank, sh.world, cap)
+    shards = [shard_of(p) for p, _ in specs]
+    built = _build_many(K, routes.planned, [sh.rows_per_rank for sh in shards], shards[0].world, caps)  # ONE launch
+    for (p, ids), sh, cap, (send_ids, slot_of, src_of) in zip(specs, shards, caps, built):
         lks.append((p, _RoutedLookup(sh, ids.numel(), cap, slot_of, src_of,
                                      C.all_to_all_rows_start(send_ids, tag=t_ids))))
         _sent(t_ids, (sh.world - 1) * cap * 8)
-    for p, lk in lks:
+    # owner side, ONE launch for every lookup: received ids -> local row numbers (sentinel n_local for padding) + their rows
+    served = _serve_many(K, [(p.data, lk.ids_p.wait(), lk.shard.lo, lk.shard.n_local) for p, lk in lks])
+    for (p, lk), (local, rows) in zip(lks, served):
         sh = lk.shard
-        lk.local = K.localize(lk.ids_p.wait(), sh.lo, sh.n_local)  # sentinel n_local for padding
-        lk.ids_p = None
-        lk.rows_p = C.all_to_all_rows_start(K.gather_owned(p.data, lk.local, sh.n_local), tag=t_rows)
+        lk.local, lk.ids_p = local, None
+        lk.rows_p = C.all_to_all_rows_start(rows, tag=t_rows)
         _sent(t_rows, (sh.world - 1) * lk.cap * sh.dim * 4)
     return lks
 
@@ -632,17 +718,30 @@ def set_mips_kernels_for_tests(obj) -> None:
     _MIPS_KERNELS_TEST[0] = obj
 
 
+def first_try_k(k: int, world: int) -> int:
+    """How many candidates a block is asked for FIRST: its expected share of the global top-k plus six standard deviations
+    (k items falling into `world` equal blocks at random), rounded up to 32.  Whether that was enough is CHECKED
+    (sharded_topk), never assumed."""
+    share = k / world
+    sd = (k * (1.0 / world) * (1.0 - 1.0 / world)) ** 0.5
+    return min(k, (int(share + 6.0 * sd + 8.0) + 31) // 32 * 32)
+
+
 def sharded_topk(corpus_block: torch.Tensor, row_offset: int, query: torch.Tensor, k: int, topk=None):
     """Exact top-k of every rank's own queries over a corpus whose rows are split into W contiguous blocks
     (ref:src/baseline_mips_module.py:57-61 on one block per GPU).  Every rank brings its own B queries (the same B on
     every rank); per call:
         all_gather queries                                  [B, D] -> [W*B, D]
-        local exact top-k of ALL queries on this rank's block (tt_mips_topk)
-        all_to_all of the (score, global index) lists       [W, B, k] <-> [W, B, k]   (fixed size)
-        exact merge of the W*k candidates per own query     (tt_mips_merge)
+        local exact top-k' of ALL queries on this rank's block (tt_mips_topk)
+        all_to_all of the (score, global index) lists       [W, B, k'] <-> [W, B, k']   (fixed size)
+        exact merge of the W*k' candidates per own query    (tt_mips_merge)
     The global top-k is a subset of the union of the per-block top-ks and every stage uses the (score desc, index asc)
-    order, so the result equals the single-device answer.  `topk(q, corpus, k)`: the local search (default
-    ops.mips_topk; the module passes its split-fp16 variant)."""
+    order, so with k' = k the result equals the single-device answer.  The selection / sort stages of the local search cost
+    per (query, block, k'), i.e. W times the single-device work at k' = k, although a block holds only ~k / W of the answer.
+    So the first round asks for k' = first_try_k(k, W) and PROVES it was enough: a block can hold an unseen member of the
+    global top-k only if its LAST returned candidate sorts strictly before the merged k-th element; if that is true for any
+    (query, block) on any rank (one MAX all-reduce of a flag, one host read -- this is inference), the search is repeated
+    with k' = k.  `topk(q, corpus, k)`: the local search (default ops.mips_topk; the module passes its split-fp16 variant)."""
     W = dist.get_world_size()
     kern = _MIPS_KERNELS_TEST[0]
     if kern is None:
@@ -654,25 +753,37 @@ def sharded_topk(corpus_block: torch.Tensor, row_offset: int, query: torch.Tenso
     q_all = C.all_gather_rows_start(query.contiguous(), tag="mips_queries_allgather").wait() if W > 1 else query
     _sent("mips_queries_allgather", (W - 1) * query.numel() * query.element_size())
     n_local = corpus_block.shape[0]
-    k_loc = min(k, n_local)
-    if k_loc > 0:
-        idx, sc = topk(q_all, corpus_block, k_loc)  # [W*B, k_loc], local row numbers
-        idx = idx + row_offset
-    else:  # this rank's block is empty (fewer corpus rows than ranks x rows per rank): "no candidate" only
-        idx = torch.empty(q_all.shape[0], 0, dtype=torch.int64, device=q_all.device)
-        sc = torch.empty(q_all.shape[0], 0, dtype=torch.float32, device=q_all.device)
-    if k_loc < k:  # a block smaller than k: pad with "no candidate"
-        pad = k - k_loc
-        idx = torch.cat([idx, idx.new_full((idx.shape[0], pad), -1)], dim=1)
-        sc = torch.cat([sc, sc.new_zeros((sc.shape[0], pad))], dim=1)
-    if W > 1:
+    k_try = first_try_k(k, W) if W > 1 else k
+    while True:
+        k_loc = min(k_try, n_local)
+        if k_loc > 0:
+            idx, sc = topk(q_all, corpus_block, k_loc)  # [W*B, k_loc], local row numbers
+            idx = idx + row_offset
+        else:  # this rank's block is empty (fewer corpus rows than ranks x rows per rank): "no candidate" only
+            idx = torch.empty(q_all.shape[0], 0, dtype=torch.int64, device=q_all.device)
+            sc = torch.empty(q_all.shape[0], 0, dtype=torch.float32, device=q_all.device)
+        if k_loc < k_try:  # a block smaller than k': pad with "no candidate"
+            pad = k_try - k_loc
+            idx = torch.cat([idx, idx.new_full((idx.shape[0], pad), -1)], dim=1)
+            sc = torch.cat([sc, sc.new_zeros((sc.shape[0], pad))], dim=1)
+        if W == 1:
+            return kern.mips_merge(sc, idx, k)
         p_idx = C.all_to_all_rows_start(idx, tag="mips_lists_alltoall")  # chunk r of the send = rank r's queries
         p_sc = C.all_to_all_rows_start(sc, tag="mips_lists_alltoall")
-        _sent("mips_lists_alltoall", (W - 1) * B * k * 12)
-        # received layout [W (source block), B, k] -> per own query the W*k candidates
-        idx = p_idx.wait().view(W, B, k).permute(1, 0, 2).reshape(B, W * k)
-        sc = p_sc.wait().view(W, B, k).permute(1, 0, 2).reshape(B, W * k)
-    return kern.mips_merge(sc, idx, k)
+        _sent("mips_lists_alltoall", (W - 1) * B * k_try * 12)
+        ridx, rsc = p_idx.wait().view(W, B, k_try), p_sc.wait().view(W, B, k_try)  # [source block, own query, candidate]
+        out_idx, out_sc = kern.mips_merge(rsc.permute(1, 0, 2).reshape(B, W * k_try),
+                                          ridx.permute(1, 0, 2).reshape(B, W * k_try), k)
+        if k_try >= k:
+            return out_idx, out_sc
+        # was k' enough?  block b may hide a member of query q's top-k only behind a last candidate that is itself inside it
+        last_i, last_s = ridx[:, :, -1], rsc[:, :, -1]  # [W, B]
+        kth_i, kth_s = out_idx[:, k - 1].unsqueeze(0), out_sc[:, k - 1].unsqueeze(0)  # [1, B]
+        before = (last_s > kth_s) | ((last_s == kth_s) & (last_i < kth_i)) | (kth_i < 0)
+        short = ((last_i >= 0) & before).any().to(torch.int32).reshape(1)
+        if not bool(C._timed_sync("mips_enough_allreduce", C.all_reduce_, short, op=dist.ReduceOp.MAX).item()):
+            return out_idx, out_sc
+        k_try = k  # (adversarial placement: most of a query's answer in one block) -- the plain form
 
 
 class _Block:
