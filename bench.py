@@ -1204,6 +1204,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 roof["hbm_copy_GBps"] = f"unavailable ({type(e).__name__}: {e})"
             roof["clocks"] = {"before": clocks_before, "after": clocks_after}
+            roof["table_arena"] = getattr(opt, "arena_note", None)  # candidate allocations timed at the first step, the one kept
             roof["sweep_workgroups"] = opt._sweep_wgs or 768
             roof["sweep_level_decided_by"] = opt.sweep_level_note()
             # With the tables sharded over many GPUs the sweep shrinks 1/N while the global-negative

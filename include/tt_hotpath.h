@@ -55,6 +55,9 @@ int tt_profile_read(const char* kernel, double* total_ms, int64_t* launches);
  * kernel and its neighbours on the stream and delays what follows it by a few microseconds -- enough to change which of
  * two streams' kernels reaches the CUs first -- so a measurement brackets the kernel it reports and nothing else. */
 int tt_profile_filter(const char* kernels);
+/* Suspend / resume the bracketing WITHOUT clearing what was recorded (the optimiser's one-off timing of candidate table
+ * arenas at its first step is not part of the caller's measurement). */
+int tt_profile_pause(int paused);
 
 /* ---------------------------------------------------------------- K1 gather
  * out[i, 0:dim] = table[ids[i], 0:dim]          (out row stride ld_out >= dim)

@@ -67,5 +67,5 @@ def test_scheduling_switches_do_not_change_results():
     assert sched["in_arena"] is False and sched["side_grads"] is False and sched["sweep_note"] == "fixed by TT_SWEEP_WGS" and sched["comm_size"] == [0, 1]
     assert sched["losses"] == base["losses"] and sched["checksum"] == base["checksum"]
     # the debias head as the hook's tensor expressions instead of the fused kernels: same maths, another summation order
-    unfused, _ = _run({"TT_DEBIAS_NO_FUSED": "1"})
+    unfused, _ = _run({"TT_DEBIAS_NO_FUSED": "1", "TT_ADAM_ARENA_TRIES": "1"})
     assert all(abs(a - b) <= 2e-6 * abs(b) for a, b in zip(unfused["losses"], base["losses"])), (unfused["losses"], base["losses"])

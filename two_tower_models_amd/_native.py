@@ -85,6 +85,7 @@ SIGNATURES = {
     "tt_profile_enable": (_int, [_int]),
     "tt_profile_read": (_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "tt_profile_filter": (_int, [C.c_char_p]),
+    "tt_profile_pause": (_int, [_int]),
     "tt_gather_rows": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "tt_gemm_workspace_bytes": (_i64, [_int, _i64, _i64, _i64]),
     "tt_gemm_f32": (_int, [_int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _int, _vp,

@@ -16,6 +16,7 @@ struct Slot {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
 };
 bool g_on = false;
+bool g_paused = false;  // tt_profile_pause: launches the library makes for its OWN measurements are not the caller's
 std::string g_only;  // "" = every bracketed kernel; else ",name,name," (tt_profile_filter)
 std::vector<Slot> g_slots;
 Slot& slot_for(const char* name) {
@@ -32,7 +33,7 @@ void clear_all() {
 }  // namespace
 
 ProfScope::ProfScope(const char* name, hipStream_t st) : st_(st), slot_(-1), idx_(-1) {
-  if (!g_on) return;
+  if (!g_on || g_paused) return;
   if (!g_only.empty() && g_only.find("," + std::string(name) + ",") == std::string::npos) return;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
@@ -53,6 +54,11 @@ ProfScope::~ProfScope() {
 extern "C" int tt_profile_enable(int on) {
   tt::clear_all();
   tt::g_on = on != 0;
+  return 0;
+}
+
+extern "C" int tt_profile_pause(int paused) {
+  tt::g_paused = paused != 0;
   return 0;
 }
 

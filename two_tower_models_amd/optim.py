@@ -182,43 +182,85 @@ class DenseExactAdam(torch.optim.Optimizer):
 
     def _home_tables_in_one_arena(self) -> None:
         """Every table's p, m, v in ONE device allocation, back to back on 2 MiB boundaries (the Parameter keeps its identity:
-        `p.data` becomes a view of the arena).  Measured, not aesthetic (profiles/r06_sweep_placement.txt): the sweep streams
-        the six arrays of the P tables at 6.56-6.62 TB/s from any of 40 random placements inside one allocation, and at
-        6.0-6.15 TB/s -- 7 % less -- from six allocations of torch's caching allocator IN THE SAME PROCESS on the same box;
-        which of the two a process gets from separate allocations is a lottery per process (two bench.py processes on one
-        box: 5.42 and 5.87 ms per step), and it is the 8 % "slow mode" the driver's round-5 line hit.  Costs one transient
-        copy of the tables at the first step.  A caller that saves `model.state_dict()` on its own afterwards stores the
-        arena's bytes (tables + moments); `{k: v.clone() for k, v in model.state_dict().items()}` stores the tables only."""
+        `p.data` becomes a view of the arena) -- and the allocation itself CHOSEN BY MEASUREMENT.  What the sweep streams at is
+        a property of the allocation it runs over, decided when the driver backs it with physical pages, and it differs by
+        7-8 % between allocations of one process on one box (profiles/r06_sweep_placement.txt: 40 random placements of the six
+        arrays inside one allocation 6.56-6.62 TB/s, six separate allocations of the same process 6.0-6.15; two bench.py
+        processes on one box 5.39 and 5.85 ms per step -- the "slow mode" of the driver's round-5 line; the streaming copy
+        beside it does not move).  So up to TT_ADAM_ARENA_TRIES (default 4) candidate arenas are held at once, the sweep
+        kernel itself is timed over each (three launches on uninitialised memory: values do not matter, it is overwritten
+        below), the fastest one is kept and the others go back to the driver.  Costs ~0.1 s and one transient copy of the
+        tables at the first step; skipped for candidates that do not fit next to each other (C4: one 154 GB arena).
+        A caller that saves `model.state_dict()` on its own afterwards stores the arena's bytes (tables + moments);
+        `{k: v.clone() for k, v in model.state_dict().items()}` stores the tables only."""
         A = 2 << 20
         sizes = [(p.numel() * 4 + A - 1) // A * A for p in self._tables]
+        nbytes = 3 * sum(sizes) + A
+        dev = self._tables[0].device
+
+        def views(arena):
+            off, out = (-arena.data_ptr()) % A, []
+            for p, size in zip(self._tables, sizes):
+                row = []
+                for _ in range(3):
+                    row.append(arena[off:off + p.numel() * 4].view(torch.float32).view(p.shape))
+                    off += size
+                out.append(row)
+            return out
+
+        tries = max(1, int(os.environ.get("TT_ADAM_ARENA_TRIES", "4")))
+        free, _total = torch.cuda.mem_get_info(dev)
+        tries = max(1, min(tries, int((free * 0.8) // nbytes)))
+        cands = []
         try:
-            arena = torch.empty(3 * sum(sizes) + A, dtype=torch.uint8, device=self._tables[0].device)
-        except torch.OutOfMemoryError:  # no room for the transient second copy of the tables: stay where they are
+            for _ in range(tries):
+                cands.append(torch.empty(nbytes, dtype=torch.uint8, device=dev))
+        except torch.OutOfMemoryError:
+            pass
+        if not cands:  # no room even for the transient second copy of the tables: they stay where they are
             for p in self._tables:
                 for key in ("exp_avg", "exp_avg_sq"):
                     self.state[p].setdefault(key, torch.zeros_like(p))
             return
-        off = (-arena.data_ptr()) % A
-
-        def take(p, size):
-            nonlocal off
-            v = arena[off:off + p.numel() * 4].view(torch.float32).view(p.shape)
-            off += size
-            return v
-
+        rates = []
+        if len(cands) > 1:
+            lib = N.load()
+            lib.tt_profile_pause(1)  # these launches are this method's own measurement, not a caller's (tt_profile_*)
+            for arena in cands:
+                vs = views(arena)
+                descs = (N.AdamTensor * len(vs))()
+                for i, (w, m, v) in enumerate(vs):
+                    descs[i].p, descs[i].g, descs[i].m, descs[i].v, descs[i].n = w.data_ptr(), None, m.data_ptr(), v.data_ptr(), w.numel()
+                evs = []
+                for _ in range(4):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    N.check(lib.tt_adam_tables_sweep(descs, len(vs), self._hyper.data_ptr(), 0, N.stream()), "tt_adam_tables_sweep")
+                    e1.record()
+                    evs.append((e0, e1))
+                evs[-1][1].synchronize()
+                ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs[1:])  # (the first launch touches the pages)
+                rates.append(24.0 * sum(p.numel() for p in self._tables) / (ms[0] * 1e-3) / 1e9)
+            lib.tt_profile_pause(0)
+            best = max(range(len(cands)), key=lambda i: rates[i])
+        else:
+            best = 0
+        arena = cands[best]
+        del cands
+        if rates:
+            torch.cuda.empty_cache()  # the losing candidates go back to the DRIVER, not into torch's block cache
+        self.arena_note = {"candidates_GBps": [round(r, 1) for r in rates], "kept": best, "bytes": nbytes}
         with torch.no_grad():
-            for p, size in zip(self._tables, sizes):
+            for p, (home, m, v) in zip(self._tables, views(arena)):
                 st = self.state[p]
-                home = take(p, size)
                 home.copy_(p.data)
                 p.data = home
-                for key in ("exp_avg", "exp_avg_sq"):
-                    v = take(p, size)
+                for key, t in (("exp_avg", m), ("exp_avg_sq", v)):
                     if key in st:
-                        v.copy_(st[key])  # what a loaded checkpoint supplied
+                        t.copy_(st[key])  # what a loaded checkpoint supplied
                     else:
-                        v.zero_()
-                    st[key] = v
+                        t.zero_()
+                    st[key] = t
         self._arena = arena
 
     # ------------------------------------------------------------------ deferred schedule
