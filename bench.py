@@ -1136,6 +1136,7 @@ def main():
         run(args.warmup + i)
     if args.adam == "lazy" and not use_sharded:
         opt.flush()  # every deferred row update is paid for inside the timed region
+    clocks_during = sysfs_clocks()  # the host has enqueued the steps and the GPU is still running them: clocks UNDER LOAD
     barrier()
     dt = time.perf_counter() - t0
     clocks_after = sysfs_clocks()
@@ -1203,7 +1204,8 @@ def main():
                             frac_of_copy=round(achieved / cal["GBps"], 4), hbm_copy=cal)
             except Exception as e:  # noqa: BLE001
                 roof["hbm_copy_GBps"] = f"unavailable ({type(e).__name__}: {e})"
-            roof["clocks"] = {"before": clocks_before, "after": clocks_after}
+            # (before / after are read with the device idle between launches -- the shader clock may already have dropped)
+            roof["clocks"] = {"before": clocks_before, "during": clocks_during, "after": clocks_after}
             roof["table_arena"] = getattr(opt, "arena_note", None)  # candidate allocations timed at the first step, the one kept
             roof["sweep_workgroups"] = opt._sweep_wgs or 768
             roof["sweep_level_decided_by"] = opt.sweep_level_note()

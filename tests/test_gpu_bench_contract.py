@@ -100,7 +100,11 @@ def test_sharded_module_path_at_world1_matches_the_single_gpu_headline():
     sh = run(["--sharded"])
     assert sh["n_ranks"] == 1 and sh["dist_backend"] == "nccl"
     ratio = sh["ms_per_step"] / mod["ms_per_step"]
-    assert 0.95 <= ratio <= 1.05, (sh["ms_per_step"], mod["ms_per_step"])
+    # (two separate processes: what a process's allocations stream at differs by several per cent on one box even after the
+    # optimiser's arena tournament, profiles/r06_sweep_placement.txt -- the message carries both processes' own calibration)
+    assert 0.93 <= ratio <= 1.07, (sh["ms_per_step"], mod["ms_per_step"],
+                                   {k: sh["roofline"].get(k) for k in ("frac", "hbm_copy_GBps", "frac_of_copy", "table_arena")},
+                                   {k: mod["roofline"].get(k) for k in ("frac", "hbm_copy_GBps", "frac_of_copy", "table_arena")})
     comm = sh["comm"]
     assert comm["ms_per_step"] and "lookup_rows_alltoall" in comm["ms_per_step"] and comm["schedule"]["sweep_workgroups"] > 0
     assert mod["roofline"]["traffic"] is not None  # profiles/pmc_traffic.json resolves for the default workload
@@ -109,7 +113,8 @@ def test_sharded_module_path_at_world1_matches_the_single_gpu_headline():
     roof = mod["roofline"]
     assert 3000 < roof["hbm_copy_GBps"] < 8000 and abs(roof["frac_of_copy"] - roof["achieved"] / roof["hbm_copy_GBps"]) < 2e-3
     assert 0.85 < roof["frac_of_copy"] < 1.2, roof  # the sweep streams what this box can stream
-    assert set(roof["clocks"]) == {"before", "after"} and roof["sweep_workgroups"] > 0
+    assert set(roof["clocks"]) == {"before", "during", "after"} and roof["sweep_workgroups"] > 0
+    assert roof["table_arena"]["bytes"] > 16e9 and len(roof["table_arena"]["candidates_GBps"]) >= 2  # the placement tournament ran
     # what RCCL itself says about the group
     assert sh["rccl"]["ncclCommCount"] == 1 and len(sh["rccl"]["ranks"]) == 1 and "pci" in sh["rccl"]["ranks"][0]
 

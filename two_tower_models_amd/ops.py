@@ -170,7 +170,16 @@ def note_generic(path: str, why: str) -> None:
 # (The third stream, not a new one: ROCm multiplexes HIP streams onto a handful of hardware queues in creation order, and
 # one more stream can land on the sweep's queue -- measured on the row-sharded step, round 4.)
 _SIDE_GRADS = os.environ.get("TT_WGRAD_MAIN") is None  # TT_WGRAD_MAIN=1: everything in line (the safe mode under DDP-style reducers)
-_side_state = {"held": [], "armed": False, "dev": None, "encoder": False, "leaves": set()}  # "encoder": a HistoryEncoder forward ran since the last join
+_side_state = {"held": [], "armed": False, "dev": None, "encoder": False, "leaves": set()}  # "encoder": the towers' weight gradients go aside too -- a HistoryEncoder forward ran since the last join, or the step is logits-bound (towers_wgrad_aside)
+
+
+def towers_wgrad_aside() -> None:
+    """The towers' weight gradients of the NEXT backward pass go to the third stream as well (until its join).  Called by
+    the row-sharded forward in the logits-bound regime (thin row blocks, W*B negatives): after the backward logits kernel
+    the main stream is a serial tail of small kernels -- slab reduce, two tower backwards, two weight-gradient products with
+    their reduces, row-gradient gathers -- and, on a real node, the points where the exchanges are issued; the two
+    weight-gradient products (60 us each) leave it."""
+    _side_state["encoder"] = True
 
 
 def _join_side_grads() -> None:

@@ -287,6 +287,8 @@ class TwoTowerBaseRetrieval(nn.Module):
             sweep_ms = sum(parallel.shard_of(t).n_local * t.shape[1] for t in tables) * 24.0 / 6.0e9
             hold = sweep_ms < 0.75 * (8.0 * B * B * world * self.item_id_embedding_arch.weight.shape[1] / 125.0e9)
             plan = parallel.begin_lookups(plan)
+            if hold and torch.is_grad_enabled():
+                ops.towers_wgrad_aside()
         ref = getattr(self.item_id_embedding_arch.weight, "_tt_optimizer", None)
         opt = ref() if ref is not None else None
         if opt is not None:
