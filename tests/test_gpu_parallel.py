@@ -33,6 +33,10 @@ CASES = {
     "hist": ("hist", dict(n_users=211, n_items=307, D=128, F=8, B=40, H=6)),
     # the BASELINE history length (attention tiles padded to 64) and a table smaller than one rank's history list
     "hist50": ("hist", dict(n_users=90, n_items=131, D=128, F=8, B=24, H=50)),
+    # BASELINE's history length at a real per-rank batch, ids drawn from 40 items: every item row is looked up ~320 times per
+    # rank and step (B*H = 12 800 history lookups + 256 item ids per rank), by all ranks -- the routed exchange at its most
+    # duplicated (SURVEY section 7 "History all-to-all volume")
+    "hist50_dup": ("hist", dict(n_users=90, n_items=40, D=128, F=8, B=256, H=50)),
     # an item table with fewer rows than ranks x rows-per-rank: the last rank owns NO item row
     "hist_empty_block": ("hist", dict(n_users=338, n_items=9, D=64, F=20, B=33, H=1)),
     # BASELINE config 5's model in training: the fused debias head on the gathered batch
@@ -258,6 +262,7 @@ def check_against_oracle(case, res, world, outlier_frac=2e-3):
     (2, "base_d128", "gloo", "torch", False), (3, "base_ragged", "gloo", "torch", False),
     (3, "base_crowded", "gloo", "torch", True), (2, "base_labels1d", "gloo", "torch", False),
     (2, "hist", "gloo", "torch", False), (3, "hist50", "gloo", "torch", True), (4, "hist_empty_block", "gloo", "torch", False),
+    (3, "hist50_dup", "gloo", "torch", False),
     (2, "debias", "gloo", "torch", False), (3, "debias_small", "gloo", "torch", True),
     # RCCL, one device per rank: skipped on the 1-GPU test boxes, run on any multi-GPU node
     (2, "base_d128", "nccl", "torch", False), ("all", "base_d128", "nccl", "torch", True),
