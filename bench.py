@@ -178,21 +178,25 @@ def mfma_sustained_peak(lib, N, device, dtype, iters=4000):
 
 
 def rccl_identity(device, world):
-    """What the collective library ITSELF reports about the group this process is in (so that "RCCL saw N ranks" can be
-    read off the line): a communicator made by the C ABI's tt_comm_* over the running process group, asked for
-    ncclCommCount / ncclCommUserRank; every rank's device ordinal and PCI bus id, gathered."""
+    """What the collective library reports about the group this process is in (so that "RCCL saw N ranks" can be read off
+    the line): the sum of a ones-vector all-reduced over the RCCL process group (= the number of ranks that took part in an
+    RCCL collective), ncclCommCount / ncclCommUserRank of the C ABI's own communicator when that is the transport
+    (`--transport native`; no second communicator is created just to ask), and every rank's device ordinal and PCI bus id."""
     import ctypes
     import torch.distributed as dist
     from two_tower_models_amd import collectives
-    out = {}
+    out = {"backend": dist.get_backend(), "process_group_world_size": dist.get_world_size()}
+    ones = torch.ones(1, device=device)
+    dist.all_reduce(ones)
+    out["ranks_in_an_allreduce_of_ones"] = int(ones.item())
     try:
-        from two_tower_models_amd.comm import NativeComm
-        c = collectives._NATIVE or NativeComm.from_torch_distributed(device)
-        out["ncclCommUserRank"], out["ncclCommCount"] = c.size()
-        if c is not collectives._NATIVE:
-            c.close()
-    except Exception as e:  # noqa: BLE001
-        out["ncclCommCount"] = f"unavailable ({type(e).__name__}: {e})"
+        out["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001
+        pass
+    if collectives._NATIVE is not None:
+        out["ncclCommUserRank"], out["ncclCommCount"] = collectives._NATIVE.size()
+    else:
+        out["ncclCommCount"] = None  # (reported by the tt_comm_* communicator: run with --transport native)
     bus = "unknown"
     try:
         hip = ctypes.CDLL("libamdhip64.so")
@@ -896,12 +900,13 @@ def main_c5(args, cfg, device, world, rank, dist_backend, use_sharded):
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", RANK="0", WORLD_SIZE="1")
         if dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
-            ident = rccl_identity(device, world)
         else:
             dist.init_process_group(dist_backend)
         if args.transport == "native" and world > 1 and dist_backend == "nccl":
             from two_tower_models_amd.comm import NativeComm
             collectives.use_native_transport(NativeComm.from_torch_distributed(device))
+        if dist_backend == "nccl":
+            ident = rccl_identity(device, world)
     rec = timed_c5(cfg, device, world, rank, args.steps, args.warmup, use_sharded)
     rec.pop("model")
     dt = rec["seconds"]

@@ -116,7 +116,8 @@ def test_sharded_module_path_at_world1_matches_the_single_gpu_headline():
     assert set(roof["clocks"]) == {"before", "during", "after"} and roof["sweep_workgroups"] > 0
     assert roof["table_arena"]["bytes"] > 16e9 and len(roof["table_arena"]["candidates_GBps"]) >= 2  # the placement tournament ran
     # what RCCL itself says about the group
-    assert sh["rccl"]["ncclCommCount"] == 1 and len(sh["rccl"]["ranks"]) == 1 and "pci" in sh["rccl"]["ranks"][0]
+    assert sh["rccl"]["ranks_in_an_allreduce_of_ones"] == 1 and len(sh["rccl"]["ranks"]) == 1 and "pci" in sh["rccl"]["ranks"][0]
+    assert sh["rccl"]["backend"] == "nccl" and sh["rccl"]["distinct_pci_bus_ids"] == 1
 
 
 def test_config5_line_single_gpu_and_two_ranks():
