@@ -127,6 +127,15 @@ def sysfs_clocks():
                 break
             except (OSError, ValueError, IndexError):
                 continue
+    # (the DPM level marked '*' is an instantaneous sample and reads the idle level more often than not, even with work queued;
+    # hwmon's freq inputs -- where the driver exposes them -- are the clocks actually running)
+    for key, name in (("sclk_hwmon_MHz", "freq1_input"), ("mclk_hwmon_MHz", "freq2_input")):
+        for path in sorted(glob.glob(f"/sys/class/drm/card*/device/hwmon/hwmon*/{name}")):
+            try:
+                out[key] = round(int(open(path).read()) / 1e6)
+                break
+            except (OSError, ValueError):
+                continue
     for path in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average")):
         try:
             out["power_W"] = round(int(open(path).read()) / 1e6, 1)

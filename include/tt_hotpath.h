@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 2
+#define TT_ABI_VERSION 3
 
 #define TT_E_BADARG (-1)      /* null pointer / negative size / unsupported shape */
 #define TT_E_WORKSPACE (-2)   /* ws_bytes smaller than tt_*_workspace_bytes()     */

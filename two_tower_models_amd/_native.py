@@ -24,7 +24,7 @@ TT_COMM_ID_BYTES = 128
 TT_COMM_F32, TT_COMM_I32, TT_COMM_I64, TT_COMM_U8 = 0, 1, 2, 3
 TT_COMM_SUM, TT_COMM_MAX = 0, 1
 TT_MAX_GRAD_SOURCES = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp, _i64, _i32, _int = C.c_void_p, C.c_int64, C.c_int32, C.c_int
 
