@@ -872,3 +872,32 @@ def test_sweep_throttle_does_not_change_results(golden):
         outs.append({k: v.clone() for k, v in model.state_dict().items()})
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k]), k
+
+
+@pytest.mark.parametrize("kind,name", [("base", "g2_base_aligned"), ("hist", "g4_hist_d128")])
+def test_inference_between_train_steps_leaves_training_alone(golden, kind, name):
+    """model.forward() -- the reference's inference entry (ref:src/two_tower_base_retrieval.py:221-249), called WITHOUT
+    torch.no_grad() like upstream's own tests do -- between two train steps of the forward-announced optimiser schedule: the
+    training run is bit-identical to the one without the call (its lookups are not recorded for the table step)."""
+    import two_tower_models_amd as A
+    g = golden(name)
+
+    def run(serve):
+        model = make_model(kind, g)
+        opt = A.DenseExactAdam(model.parameters(), lr=1e-3)
+        b = batch_of(g)
+        losses = []
+        for _ in range(3):
+            loss = model.train_forward(*b)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+            if serve:
+                top = model(b[0], b[1], b[2])
+                assert top.dtype == torch.int64 and top.shape[1] == 10 and not top.requires_grad
+        return losses, {k: v.clone() for k, v in model.state_dict().items()}
+
+    l0, s0 = run(False)
+    l1, s1 = run(True)
+    assert l0 == l1 and all(torch.equal(s0[k], s1[k]) for k in s0)

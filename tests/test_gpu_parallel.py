@@ -347,8 +347,8 @@ def _mips_worker(rank, world, port, outdir, C, K, D, bf16, how, backend="gloo", 
         g = torch.Generator().manual_seed(100 + rank)
         uid = torch.randint(0, n_users, (B,), generator=g)
         batch = (uid.to(dev), torch.randn(B, 8, generator=g).to(dev), torch.randint(0, 50, (B, 4), generator=g).to(dev))
+        top = model(*batch)  # TwoTowerWithDebiasing.forward (ref:src/two_tower_base_retrieval.py:221-249), sharded; no optimiser, no no_grad
         with torch.no_grad():
-            top = model(*batch)  # TwoTowerWithDebiasing.forward (ref:src/two_tower_base_retrieval.py:221-249), sharded
             q = model.compute_user_embedding(*batch)
             idx, sc, emb = m(query_embedding=q, num_items=K)  # the reference's call, 3-tuple
         torch.save({"uid": uid, "top": top.cpu(), "q": q.cpu(), "idx": idx.cpu(), "sc": sc.cpu(), "emb": emb.cpu(),

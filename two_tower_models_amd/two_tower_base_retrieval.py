@@ -137,7 +137,11 @@ class TwoTowerBaseRetrieval(nn.Module):
     # ------------------------------------------------------------------ inference
     def forward(self, user_id: torch.Tensor, user_features: torch.Tensor, user_history: torch.Tensor) -> torch.Tensor:
         """Top ``num_items`` MIPS row indices per user, [B, num_items] int64 (ref :221-249)."""
-        user_embedding = self.compute_user_embedding(user_id, user_features, user_history)
+        # (the result is an index tensor: nothing to differentiate.  Under no_grad the lookups are not recorded for the
+        # optimiser's table step -- an inference call between two train steps, with or without the caller's own no_grad,
+        # leaves the training bookkeeping alone, and a row-sharded model needs no optimiser to be served)
+        with torch.no_grad():
+            user_embedding = self.compute_user_embedding(user_id, user_features, user_history)
         if type(self.mips_module).forward is BaselineMIPSModule.forward:
             # this package's module: the reference discards the scores and the [B, K, DI] rows (ref :246-248) -- do not
             # gather (row-sharded corpus: do not exchange) half a gigabyte of rows at B = 1024, K = 1000 to drop them
