@@ -187,7 +187,7 @@ class DenseExactAdam(torch.optim.Optimizer):
         7-8 % between allocations of one process on one box (profiles/r06_sweep_placement.txt: 40 random placements of the six
         arrays inside one allocation 6.56-6.62 TB/s, six separate allocations of the same process 6.0-6.15; two bench.py
         processes on one box 5.39 and 5.85 ms per step -- the "slow mode" of the driver's round-5 line; the streaming copy
-        beside it does not move).  So up to TT_ADAM_ARENA_TRIES (default 4) candidate arenas are held at once, the sweep
+        beside it does not move).  So up to TT_ADAM_ARENA_TRIES (default 6: three of four candidates of one process have been seen slow) candidate arenas are held at once, the sweep
         kernel itself is timed over each (three launches on uninitialised memory: values do not matter, it is overwritten
         below), the fastest one is kept and the others go back to the driver.  Costs ~0.1 s and one transient copy of the
         tables at the first step; skipped for candidates that do not fit next to each other (C4: one 154 GB arena).
@@ -208,7 +208,7 @@ class DenseExactAdam(torch.optim.Optimizer):
                 out.append(row)
             return out
 
-        tries = max(1, int(os.environ.get("TT_ADAM_ARENA_TRIES", "4")))
+        tries = max(1, int(os.environ.get("TT_ADAM_ARENA_TRIES", "6")))
         free, _total = torch.cuda.mem_get_info(dev)
         tries = max(1, min(tries, int((free * 0.8) // nbytes)))
         cands = []
