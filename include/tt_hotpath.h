@@ -135,6 +135,30 @@ int tt_tower_bwd_weights(const float* dy, int64_t ldy, const float* tin, const f
  * (ref:src/two_tower_with_user_history_encoder.py:81-83 the Linear(2*DU + 2*DI -> DI), :85-122 the cat).  W3 / dW3 are
  * [D, 2D + E] row-major, tin_out stays [B, 2D] (the extra block is the caller's own tensor), d_extra [B, E] is the
  * gradient that flows back into the encoder. */
+/* BOTH towers of TwoTowerBaseRetrieval per launch (user tower = sides[0], item tower = sides[1]; blockIdx.y picks the tower,
+ * the arithmetic is tt_tower_fwd / _bwd_data / _bwd_weights' own, so the results are the same bits): for steps that run on
+ * ONE stream -- a whole-step hipGraph, batches too small for the two-stream fork -- where two launches of a 128-workgroup
+ * kernel ran back to back on a 256-CU chip.  Same shape limits, D the same for both towers, no third input block.
+ * ref:src/two_tower_base_retrieval.py:129-219 (both towers' forward), their autograd. */
+typedef struct {
+  const float* table; int64_t n_rows; const int64_t* ids; const float* feats; int64_t ldf; int64_t F;
+  const float *W1, *b1, *W2, *b2, *W3, *b3;
+  float* y; int64_t ldy; float* h_out; float* tin_out;
+} tt_tower_fwd_side;
+typedef struct {
+  const float* dy; int64_t ldy; const float *W2, *W3, *h;
+  float* d_emb; int64_t ld_demb; float* d_f; float* dh;
+} tt_tower_bwd_side;
+typedef struct {
+  const float* dy; int64_t ldy; const float *tin, *d_f, *h, *dh, *feats; int64_t ldf; int64_t F;
+  float *dW1, *db1, *dW2, *db2, *dW3, *db3;
+  void* ws; int64_t ws_bytes; /* tt_tower_bwd_weights_workspace_bytes(B, D, F, hidden), one per side */
+} tt_tower_wgrad_side;
+int tt_tower_fwd_pair(const tt_tower_fwd_side* sides /*host, 2*/, int64_t B, int64_t D, int64_t hidden, int32_t* oob_flag,
+                      tt_stream_t stream);
+int tt_tower_bwd_data_pair(const tt_tower_bwd_side* sides /*host, 2*/, int64_t B, int64_t D, int64_t hidden, tt_stream_t stream);
+int tt_tower_bwd_weights_pair(const tt_tower_wgrad_side* sides /*host, 2*/, int64_t B, int64_t D, int64_t hidden,
+                              tt_stream_t stream);
 int tt_tower_x_supported(int64_t D, int64_t F, int64_t hidden, int64_t d_out, int64_t E);
 int tt_tower_fwd_x(const float* table, int64_t n_rows, const int64_t* ids, const float* feats, int64_t ldf, int64_t B,
                    int64_t D, int64_t F, int64_t hidden, const float* W1, const float* b1, const float* W2, const float* b2,

@@ -61,6 +61,28 @@ class AdamFinishJob(C.Structure):
                 ("side_bytes", _i64)]
 
 
+class TowerFwdSide(C.Structure):
+    """tt_tower_fwd_side."""
+
+    _fields_ = [("table", _vp), ("n_rows", _i64), ("ids", _vp), ("feats", _vp), ("ldf", _i64), ("F", _i64), ("W1", _vp), ("b1", _vp),
+                ("W2", _vp), ("b2", _vp), ("W3", _vp), ("b3", _vp), ("y", _vp), ("ldy", _i64), ("h_out", _vp), ("tin_out", _vp)]
+
+
+class TowerBwdSide(C.Structure):
+    """tt_tower_bwd_side."""
+
+    _fields_ = [("dy", _vp), ("ldy", _i64), ("W2", _vp), ("W3", _vp), ("h", _vp), ("d_emb", _vp), ("ld_demb", _i64), ("d_f", _vp),
+                ("dh", _vp)]
+
+
+class TowerWgradSide(C.Structure):
+    """tt_tower_wgrad_side."""
+
+    _fields_ = [("dy", _vp), ("ldy", _i64), ("tin", _vp), ("d_f", _vp), ("h", _vp), ("dh", _vp), ("feats", _vp), ("ldf", _i64),
+                ("F", _i64), ("dW1", _vp), ("db1", _vp), ("dW2", _vp), ("db2", _vp), ("dW3", _vp), ("db3", _vp), ("ws", _vp),
+                ("ws_bytes", _i64)]
+
+
 TT_ROUTE_MAX_JOBS = 8
 
 
@@ -174,6 +196,9 @@ SIGNATURES = {
     "tt_stream_copy": (_int, [_vp, _vp, _i64, _vp]),
     "tt_mfma_probe_flops": (_i64, [_int, _i32]),
     "tt_mfma_probe": (_int, [_int, _i32, _vp, _i64, _vp]),
+    "tt_tower_fwd_pair": (_int, [C.POINTER(TowerFwdSide), _i64, _i64, _i64, _vp, _vp]),
+    "tt_tower_bwd_data_pair": (_int, [C.POINTER(TowerBwdSide), _i64, _i64, _i64, _vp]),
+    "tt_tower_bwd_weights_pair": (_int, [C.POINTER(TowerWgradSide), _i64, _i64, _i64, _vp]),
     "tt_route_workspace_bytes": (_i64, [_i64, _i32]),
     "tt_route_count": (_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tt_route_build": (_int, [_vp, _i64, _i64, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),

@@ -84,7 +84,7 @@ __device__ __forceinline__ void tw_load_t(float (&xr)[DP8][4], const float* __re
 // RT = 32-row tiles per workgroup: 2 (64 batch rows) when that still gives every CU a workgroup, else 1 -- at B = 8192 the
 // 64-row form is 128 workgroups on a 256-CU chip, and the tower is latency-bound (weights from L2, three dependent stages).
 template <int DE8, bool XTRA, int RT>  // D = 8 * DE8
-__global__ __launch_bounds__(256) void tower_fwd_kernel(const TowerFwdArgs p) {
+__device__ __forceinline__ void tower_fwd_body(const TowerFwdArgs& p) {
   constexpr int ROWS = 32 * RT;
   constexpr int D = 8 * DE8, K3 = 2 * D, LDH = TW_HID + 4, LDT = K3 + 4, LDW3 = XTRA ? 2 * K3 : K3;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -201,6 +201,15 @@ __global__ __launch_bounds__(256) void tower_fwd_kernel(const TowerFwdArgs p) {
   }
 }
 
+template <int DE8, bool XTRA, int RT>
+__global__ __launch_bounds__(256) void tower_fwd_kernel(const TowerFwdArgs p) { tower_fwd_body<DE8, XTRA, RT>(p); }
+// BOTH towers of the base model in one launch (blockIdx.y = tower; tt_tower_fwd_pair): the same body, so the same bits.  One
+// tower is at most 128 workgroups -- half the chip -- and a step that runs on ONE stream (a hipGraph capture, batches too
+// small for the two-stream fork) paid for the two launches back to back.
+struct TowerFwdArgs2 { TowerFwdArgs t[2]; };
+template <int DE8, int RT>
+__global__ __launch_bounds__(256) void tower_fwd_pair_kernel(const TowerFwdArgs2 q) { tower_fwd_body<DE8, false, RT>(q.t[blockIdx.y]); }
+
 struct TowerBwdArgs {
   const float* dy; int64_t ldy;
   int64_t B;
@@ -213,7 +222,7 @@ struct TowerBwdArgs {
 };
 
 template <int DE8, bool XTRA, int RT>
-__global__ __launch_bounds__(256) void tower_bwd_kernel(const TowerBwdArgs p) {
+__device__ __forceinline__ void tower_bwd_body(const TowerBwdArgs& p) {
   constexpr int ROWS = 32 * RT;
   constexpr int D = 8 * DE8, K3 = 2 * D, LDY = D + 4, LDW3 = XTRA ? 2 * K3 : K3;
   __shared__ __attribute__((aligned(16))) float dyT[ROWS * LDY];
@@ -289,6 +298,12 @@ __global__ __launch_bounds__(256) void tower_bwd_kernel(const TowerBwdArgs p) {
   }
 }
 
+template <int DE8, bool XTRA, int RT>
+__global__ __launch_bounds__(256) void tower_bwd_kernel(const TowerBwdArgs p) { tower_bwd_body<DE8, XTRA, RT>(p); }
+struct TowerBwdArgs2 { TowerBwdArgs t[2]; };
+template <int DE8, int RT>
+__global__ __launch_bounds__(256) void tower_bwd_pair_kernel(const TowerBwdArgs2 q) { tower_bwd_body<DE8, false, RT>(q.t[blockIdx.y]); }
+
 // ---------------------------------------------------------------- weight gradients of one tower
 // dW3 = dy^T tin, dW2 = d_f^T h, dW1 = dh^T x and the three bias sums: reductions over the batch.  As three
 // tt_gemm_tn_colsum_f32 calls they were six launches per tower (split-K product + slab reduce each).  Here ONE launch
@@ -324,7 +339,7 @@ __device__ __forceinline__ void tw_tn_tile(const float* At, const float* Bt, int
 }
 
 template <int DE8, bool XTRA>
-__global__ __launch_bounds__(256) void tower_wgrad_kernel(const TowerWgradArgs p) {
+__device__ __forceinline__ void tower_wgrad_body(const TowerWgradArgs& p) {
   constexpr int D = 8 * DE8, K3 = 2 * D, LDW3 = XTRA ? 2 * K3 : K3;
   extern __shared__ __attribute__((aligned(16))) float tw_smem[];
   float* At = tw_smem;                   // [64][D]     dy, then d_f
@@ -400,13 +415,19 @@ __global__ __launch_bounds__(256) void tower_wgrad_kernel(const TowerWgradArgs p
   }
 }
 
+template <int DE8, bool XTRA>
+__global__ __launch_bounds__(256) void tower_wgrad_kernel(const TowerWgradArgs p) { tower_wgrad_body<DE8, XTRA>(p); }
+struct TowerWgradArgs2 { TowerWgradArgs t[2]; };
+template <int DE8>
+__global__ __launch_bounds__(256) void tower_wgrad_pair_kernel(const TowerWgradArgs2 q) { tower_wgrad_body<DE8, false>(q.t[blockIdx.y]); }
+
 // out = sum over the blocks' partials, in a FIXED order (deterministic): 64 elements of the six tensors per 1024-thread
 // workgroup, sixteen threads per element -- thread (q, t) adds blocks q, q + 16, ... with eight independent loads in
 // flight, the sixteen slices are combined in order through LDS.  (One thread per element walking all the blocks was a
 // chain of ~128 loads issued a few at a time: 32 us for 35 MB, 270-310 us next to the table sweep.)
-__global__ __launch_bounds__(1024) void tower_wgrad_reduce_kernel(const float* __restrict__ part, int n_blocks, int64_t part_floats,
-                                                                  int64_t n3, int64_t n2, int64_t n1, int64_t D, float* dW3,
-                                                                  float* dW2, float* dW1, float* db3, float* db2, float* db1) {
+__device__ __forceinline__ void tower_wgrad_reduce_body(const float* __restrict__ part, int n_blocks, int64_t part_floats,
+                                                        int64_t n3, int64_t n2, int64_t n1, int64_t D, float* dW3,
+                                                        float* dW2, float* dW1, float* db3, float* db2, float* db1) {
   __shared__ float sh[16][64];
   const int t = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + t;
@@ -441,6 +462,23 @@ __global__ __launch_bounds__(1024) void tower_wgrad_reduce_kernel(const float* _
   if (j < D) { db2[j] = tot; return; }
   j -= D;
   db1[j] = tot;
+}
+
+__global__ __launch_bounds__(1024) void tower_wgrad_reduce_kernel(const float* __restrict__ part, int n_blocks, int64_t part_floats,
+                                                                  int64_t n3, int64_t n2, int64_t n1, int64_t D, float* dW3,
+                                                                  float* dW2, float* dW1, float* db3, float* db2, float* db1) {
+  tower_wgrad_reduce_body(part, n_blocks, part_floats, n3, n2, n1, D, dW3, dW2, dW1, db3, db2, db1);
+}
+struct TowerReduceArgs2 {
+  const float* part[2];
+  int64_t part_floats[2], n3[2], n2[2], n1[2];
+  float *dW3[2], *dW2[2], *dW1[2], *db3[2], *db2[2], *db1[2];
+};
+__global__ __launch_bounds__(1024) void tower_wgrad_reduce_pair_kernel(const TowerReduceArgs2 q, int n_blocks, int64_t D) {
+  const int k = blockIdx.y;
+  if ((int64_t)blockIdx.x * 64 >= q.part_floats[k]) return;  // (the grid is sized for the larger of the two partials)
+  tower_wgrad_reduce_body(q.part[k], n_blocks, q.part_floats[k], q.n3[k], q.n2[k], q.n1[k], D, q.dW3[k], q.dW2[k], q.dW1[k], q.db3[k],
+                          q.db2[k], q.db1[k]);
 }
 
 // 32-row tiles per workgroup of the forward / backward-data kernels: one (32 batch rows) up to B = 4096, else two.  Either
@@ -602,4 +640,124 @@ extern "C" int tt_tower_bwd_weights(const float* dy, int64_t ldy, const float* t
                                     void* ws, int64_t ws_bytes, tt_stream_t stream) {
   return tt_tower_bwd_weights_x(dy, ldy, tin, d_f, h, dh, feats, ldf, nullptr, 0, 0, B, D, F, hidden, dW1, db1, dW2, db2, dW3, db3,
                                 ws, ws_bytes, stream);
+}
+
+// ---------------------------------------------------------------- both towers of the base model per launch
+static int pair_shape_check(const char* who, int64_t B, int64_t D, int64_t hidden, int64_t F0, int64_t F1) {
+  if (B <= 0) return fail_arg(who);
+  if (!tower_shape_ok(D, F0, hidden, D) || !tower_shape_ok(D, F1, hidden, D)) {
+    set_error("%s: needs hidden = 256, D in {32, 64, 128} (the same for both towers), F <= 64", who);
+    return TT_E_UNSUPPORTED;
+  }
+  return 0;
+}
+
+extern "C" int tt_tower_fwd_pair(const tt_tower_fwd_side* sides, int64_t B, int64_t D, int64_t hidden, int32_t* oob_flag,
+                                 tt_stream_t stream) {
+  if (!sides) return fail_arg("tt_tower_fwd_pair: null pointer");
+  int rc = pair_shape_check("tt_tower_fwd_pair", B, D, hidden, sides[0].F, sides[1].F);
+  if (rc) return rc;
+  TowerFwdArgs2 q{};
+  int64_t Fmax = 0;
+  for (int k = 0; k < 2; ++k) {
+    const tt_tower_fwd_side& s = sides[k];
+    if (!s.table || !s.ids || !s.feats || !s.W1 || !s.b1 || !s.W2 || !s.b2 || !s.W3 || !s.b3 || !s.y || !s.h_out || !s.tin_out)
+      return fail_arg("tt_tower_fwd_pair: null pointer");
+    if (s.n_rows <= 0 || s.ldf < s.F || s.ldy < D) return fail_arg("tt_tower_fwd_pair: sizes");
+    if (s.ldy % 4 || !al16p(s.table) || !al16p(s.W2) || !al16p(s.W3) || !al16p(s.y) || !al16p(s.h_out) || !al16p(s.tin_out)) {
+      set_error("tt_tower_fwd_pair: 16-B aligned operands");
+      return TT_E_UNSUPPORTED;
+    }
+    q.t[k] = TowerFwdArgs{s.table, s.n_rows, s.ids, s.feats, s.ldf, B, s.F, s.W1, s.b1, s.W2, s.b2, s.W3, s.b3, s.y, s.ldy,
+                          s.h_out, s.tin_out, oob_flag, nullptr, 0};
+    Fmax = s.F > Fmax ? s.F : Fmax;
+  }
+  hipStream_t st = S(stream);
+  const int rt = tower_row_tiles(B);
+  const int rows = 32 * rt;
+  const dim3 grid((unsigned)ceil_div(B, rows), 2);
+  const size_t lds = (size_t)(rows * (TW_HID + 4) + rows * (2 * D + 4) + rows * Fmax) * sizeof(float);
+#define TT_TWP1(E8, R)                                                                                                   \
+  {                                                                                                                      \
+    if (lds > 64 * 1024) {                                                                                               \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tower_fwd_pair_kernel<E8, R>),                   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+      if (e != hipSuccess) { set_error("tower_fwd_pair_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
+    }                                                                                                                    \
+    tower_fwd_pair_kernel<E8, R><<<grid, 256, lds, st>>>(q);                                                             \
+  }
+#define TT_TWP(E8) { if (rt == 1) TT_TWP1(E8, 1) else TT_TWP1(E8, 2) }
+  if (D == 32) TT_TWP(4) else if (D == 64) TT_TWP(8) else TT_TWP(16)
+#undef TT_TWP
+#undef TT_TWP1
+  return check_launch("tower_fwd_pair_kernel");
+}
+
+extern "C" int tt_tower_bwd_data_pair(const tt_tower_bwd_side* sides, int64_t B, int64_t D, int64_t hidden, tt_stream_t stream) {
+  if (!sides) return fail_arg("tt_tower_bwd_data_pair: null pointer");
+  int rc = pair_shape_check("tt_tower_bwd_data_pair", B, D, hidden, 1, 1);
+  if (rc) return rc;
+  TowerBwdArgs2 q{};
+  for (int k = 0; k < 2; ++k) {
+    const tt_tower_bwd_side& s = sides[k];
+    if (!s.dy || !s.W2 || !s.W3 || !s.h || !s.d_emb || !s.d_f || !s.dh) return fail_arg("tt_tower_bwd_data_pair: null pointer");
+    if (s.ldy < D || s.ld_demb < D) return fail_arg("tt_tower_bwd_data_pair: sizes");
+    if (s.ldy % 4 || s.ld_demb % 4 || !al16p(s.dy) || !al16p(s.h) || !al16p(s.d_emb) || !al16p(s.d_f) || !al16p(s.dh) || !al16p(s.W3)) {
+      set_error("tt_tower_bwd_data_pair: 16-B aligned operands");
+      return TT_E_UNSUPPORTED;
+    }
+    q.t[k] = TowerBwdArgs{s.dy, s.ldy, B, s.W2, s.W3, s.h, s.d_emb, s.ld_demb, s.d_f, s.dh, nullptr, 0};
+  }
+  hipStream_t st = S(stream);
+  const int rt = tower_row_tiles(B);
+  const dim3 grid((unsigned)ceil_div(B, 32 * rt), 2);
+#define TT_TBP(E8) { if (rt == 1) tower_bwd_pair_kernel<E8, 1><<<grid, 256, 0, st>>>(q); else tower_bwd_pair_kernel<E8, 2><<<grid, 256, 0, st>>>(q); }
+  if (D == 32) TT_TBP(4) else if (D == 64) TT_TBP(8) else TT_TBP(16)
+#undef TT_TBP
+  return check_launch("tower_bwd_pair_kernel");
+}
+
+extern "C" int tt_tower_bwd_weights_pair(const tt_tower_wgrad_side* sides, int64_t B, int64_t D, int64_t hidden, tt_stream_t stream) {
+  if (!sides) return fail_arg("tt_tower_bwd_weights_pair: null pointer");
+  int rc = pair_shape_check("tt_tower_bwd_weights_pair", B, D, hidden, sides[0].F, sides[1].F);
+  if (rc) return rc;
+  TowerWgradArgs2 q{};
+  TowerReduceArgs2 r{};
+  int64_t Fmax = 0, part_max = 0;
+  for (int k = 0; k < 2; ++k) {
+    const tt_tower_wgrad_side& s = sides[k];
+    if (!s.dy || !s.tin || !s.d_f || !s.h || !s.dh || !s.feats || !s.dW1 || !s.db1 || !s.dW2 || !s.db2 || !s.dW3 || !s.db3 || !s.ws)
+      return fail_arg("tt_tower_bwd_weights_pair: null pointer");
+    if (s.ldy < D || s.ldf < s.F) return fail_arg("tt_tower_bwd_weights_pair: sizes");
+    if (s.ldy % 4 || !al16p(s.dy) || !al16p(s.tin) || !al16p(s.d_f) || !al16p(s.h) || !al16p(s.dh)) {
+      set_error("tt_tower_bwd_weights_pair: 16-B aligned operands");
+      return TT_E_UNSUPPORTED;
+    }
+    if (s.ws_bytes < tt_tower_bwd_weights_x_workspace_bytes(B, D, s.F, hidden, 0)) { set_error("tt_tower_bwd_weights_pair: workspace"); return TT_E_WORKSPACE; }
+    q.t[k] = TowerWgradArgs{s.dy, s.ldy, s.tin, s.d_f, s.h, s.dh, s.feats, s.ldf, s.F, B, reinterpret_cast<float*>(s.ws), nullptr, 0};
+    r.part[k] = reinterpret_cast<const float*>(s.ws);
+    r.part_floats[k] = tower_part_floats(D, s.F, 0);
+    r.n3[k] = D * 2 * D; r.n2[k] = D * TW_HID; r.n1[k] = TW_HID * s.F;
+    r.dW3[k] = s.dW3; r.dW2[k] = s.dW2; r.dW1[k] = s.dW1; r.db3[k] = s.db3; r.db2[k] = s.db2; r.db1[k] = s.db1;
+    Fmax = s.F > Fmax ? s.F : Fmax;
+    part_max = r.part_floats[k] > part_max ? r.part_floats[k] : part_max;
+  }
+  hipStream_t st = S(stream);
+  const unsigned blocks = (unsigned)ceil_div(B, TW_ROWS);
+  const size_t lds = (size_t)(TW_ROWS * D + TW_ROWS * TW_HID + TW_ROWS * Fmax) * sizeof(float);
+#define TT_TGP(E8)                                                                                                       \
+  {                                                                                                                      \
+    if (lds > 64 * 1024) {                                                                                               \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tower_wgrad_pair_kernel<E8>),                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+      if (e != hipSuccess) { set_error("tower_wgrad_pair_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
+    }                                                                                                                    \
+    tower_wgrad_pair_kernel<E8><<<dim3(blocks, 2), 256, lds, st>>>(q);                                                   \
+  }
+  if (D == 32) TT_TGP(4) else if (D == 64) TT_TGP(8) else TT_TGP(16)
+#undef TT_TGP
+  rc = check_launch("tower_wgrad_pair_kernel");
+  if (rc) return rc;
+  tower_wgrad_reduce_pair_kernel<<<dim3((unsigned)ceil_div(part_max, 64), 2), 1024, 0, st>>>(r, (int)blocks, D);
+  return check_launch("tower_wgrad_reduce_pair_kernel");
 }

@@ -44,9 +44,14 @@ class GraphedTrainStep:
         self.static_inputs = [t.clone() for t in example_batch]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # eager warm-up on a side stream: lazy state, workspaces, kernel attributes
-            for _ in range(max(1, warmup)):
-                self._body()
+        from . import ops
+        forks, ops._CONCURRENT_TOWERS = ops._CONCURRENT_TOWERS, False  # warm up on the schedule that will be captured: one
+        try:                                                           # stream, both towers per launch (ops.FusedTowerPair)
+            with torch.cuda.stream(side):  # eager warm-up on a side stream: lazy state, workspaces, kernel attributes
+                for _ in range(max(1, warmup)):
+                    self._body()
+        finally:
+            ops._CONCURRENT_TOWERS = forks
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.warmup_steps = max(1, warmup)

@@ -734,6 +734,99 @@ class FusedTower(_LookupFunction):
 
 
 
+class FusedTowerPair(_LookupFunction):
+    """FusedTower for BOTH towers of the base model with one launch per direction (tt_tower_*_pair: blockIdx.y picks the
+    tower; the kernels' bodies are FusedTower's, so the bits are too).  For steps that run on ONE stream -- a whole-step
+    hipGraph, batches too small for the two-stream fork -- where one tower's 128 workgroups left half the chip idle twice in
+    a row.  Inputs: the user tower's nine FusedTower arguments, then the item tower's; returns (user_emb, item_emb)."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        u, i = args[:9], args[9:]
+        dev = N.require_device(*args)
+        lib = N.load()
+        sides = (N.TowerFwdSide * 2)()
+        keep, saved, outs = [], [], []
+        ctx.lookup_index, ctx.tower_weight = [], []
+        caller_grad = _caller_grad_mode[0]
+        for k, (weight, ids, feats, W1, b1, W2, b2, W3, b3) in enumerate((u, i)):
+            feats = _rowmajor(feats)
+            B, F = feats.shape
+            D, Hd = weight.shape[1], W1.shape[0]
+            if ids.dtype == torch.int32:
+                ids = ids.to(torch.int64)
+            if ids.dtype != torch.int64:
+                raise TypeError("ids must be int64 or int32 (nn.Embedding's index types)")
+            recording = bool(ctx.needs_input_grad[9 * k]) and caller_grad
+            src, row_ids, idx = lookup_source(weight, ids, recording)
+            row_ids = row_ids.contiguous()
+            y = torch.empty(B, W3.shape[0], dtype=torch.float32, device=dev)
+            h = torch.empty(B, Hd, dtype=torch.float32, device=dev)
+            tin = torch.empty(B, 2 * D, dtype=torch.float32, device=dev)
+            W1c, W2c, W3c = W1.contiguous(), W2.contiguous(), W3.contiguous()
+            sd = sides[k]
+            sd.table, sd.n_rows, sd.ids, sd.feats, sd.ldf, sd.F = src.data_ptr(), src.shape[0], row_ids.data_ptr(), feats.data_ptr(), feats.stride(0), F
+            sd.W1, sd.b1, sd.W2, sd.b2, sd.W3, sd.b3 = W1c.data_ptr(), b1.data_ptr(), W2c.data_ptr(), b2.data_ptr(), W3c.data_ptr(), b3.data_ptr()
+            sd.y, sd.ldy, sd.h_out, sd.tin_out = y.data_ptr(), y.stride(0), h.data_ptr(), tin.data_ptr()
+            keep += [src, row_ids, feats, W1c, W2c, W3c]
+            saved += [ids, feats, h, tin, W2c, W3c]
+            outs.append(y)
+            ctx.lookup_index.append(idx)
+            ctx.tower_weight.append(weight)
+        N.check(lib.tt_tower_fwd_pair(sides, B, D, Hd, N.oob.flag(dev).data_ptr(), N.stream()), "tt_tower_fwd_pair")
+        ctx.save_for_backward(*saved)
+        return outs[0], outs[1]
+
+    @staticmethod
+    def backward(ctx, dy_u, dy_i):
+        t = ctx.saved_tensors
+        lib = N.load()
+        dev = t[2].device
+        bsides, wsides = (N.TowerBwdSide * 2)(), (N.TowerWgradSide * 2)()
+        keep, per = [], []
+        for k, dy in enumerate((dy_u, dy_i)):
+            ids, feats, h, tin, W2, W3 = t[6 * k: 6 * k + 6]
+            B, F = feats.shape
+            D, Hd = tin.shape[1] // 2, h.shape[1]
+            if dy is None:  # (an output nobody differentiated)
+                dy = torch.zeros(B, D, dtype=torch.float32, device=dev)
+            _resolve_pending(dy)
+            dy = dy.contiguous()
+            d_emb = torch.empty(B, D, dtype=torch.float32, device=dev)
+            d_f = torch.empty(B, D, dtype=torch.float32, device=dev)
+            dh = torch.empty(B, Hd, dtype=torch.float32, device=dev)
+            dW1, db1 = torch.empty(Hd, F, dtype=torch.float32, device=dev), torch.empty(Hd, dtype=torch.float32, device=dev)
+            dW2, db2 = torch.empty(D, Hd, dtype=torch.float32, device=dev), torch.empty(D, dtype=torch.float32, device=dev)
+            dW3, db3 = torch.empty(D, 2 * D, dtype=torch.float32, device=dev), torch.empty(D, dtype=torch.float32, device=dev)
+            wsp, wsn = _ws(dev, lib.tt_tower_bwd_weights_workspace_bytes(B, D, F, Hd), "tower_wgrad_pair%d" % k)
+            b = bsides[k]
+            b.dy, b.ldy, b.W2, b.W3, b.h = dy.data_ptr(), dy.stride(0), W2.data_ptr(), W3.data_ptr(), h.data_ptr()
+            b.d_emb, b.ld_demb, b.d_f, b.dh = d_emb.data_ptr(), D, d_f.data_ptr(), dh.data_ptr()
+            w = wsides[k]
+            w.dy, w.ldy, w.tin, w.d_f, w.h, w.dh = dy.data_ptr(), dy.stride(0), tin.data_ptr(), d_f.data_ptr(), h.data_ptr(), dh.data_ptr()
+            w.feats, w.ldf, w.F = feats.data_ptr(), feats.stride(0), F
+            w.dW1, w.db1, w.dW2, w.db2, w.dW3, w.db3 = (x.data_ptr() for x in (dW1, db1, dW2, db2, dW3, db3))
+            w.ws, w.ws_bytes = wsp, wsn
+            keep.append(dy)
+            per.append((ids, d_emb, dW1, db1, dW2, db2, dW3, db3))
+        N.check(lib.tt_tower_bwd_data_pair(bsides, B, D, Hd, N.stream()), "tt_tower_bwd_data_pair")
+        N.check(lib.tt_tower_bwd_weights_pair(wsides, B, D, Hd, N.stream()), "tt_tower_bwd_weights_pair")
+        grads = []
+        for k, (ids, d_emb, dW1, db1, dW2, db2, dW3, db3) in enumerate(per):
+            dweight = None
+            if ctx.needs_input_grad[9 * k]:
+                dweight = _route_table_grad(ctx.tower_weight[k], ids.reshape(-1), d_emb, ctx.lookup_index[k])
+            grads += [dweight, None, None, dW1, db1, dW2, db2, dW3, db3]
+        return tuple(grads)
+
+
+def fused_tower_pair_supported(user_args, item_args) -> bool:
+    """Both towers on the tuned kernels, the same batch size, widths and hidden size, contiguous fp32 features."""
+    (wu, _, fu, W1u, _, W2u, _, W3u, _), (wi, _, fi, W1i, _, W2i, _, W3i, _) = user_args, item_args
+    return (wu.shape[1] == wi.shape[1] and fu.shape[0] == fi.shape[0] and W1u.shape[0] == W1i.shape[0]
+            and W3u.shape[0] == W3i.shape[0] and W3u.shape[1] == 2 * wu.shape[1] and W3i.shape[1] == 2 * wi.shape[1])
+
+
 def tower_weight_grads(dy, tin, d_f, h, dh, feats, out=None, extra=None, side=False):
     """(dW1, db1, dW2, db2, dW3, db3) of one tower: dW3 = dy^T [tin | extra], dW2 = d_f^T h, dW1 = dh^T feats and the
     bias sums, one product launch + one reduce (tt_tower_bwd_weights_x) instead of three tt_gemm_tn_colsum_f32 calls.

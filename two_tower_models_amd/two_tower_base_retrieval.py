@@ -271,6 +271,23 @@ class TwoTowerBaseRetrieval(nn.Module):
                                parallel.AllGatherRows.apply(user_embedding, "head_user_emb_allgather"))
         return parallel.ReplicatedLoss.apply(loss)
 
+    def _tower_pair_args(self, user_id, user_features, item_id, item_features):
+        """(user tower's FusedTower arguments, item tower's) when BOTH towers are this class's own fused form -- no hook
+        overridden, no third input block, shapes the pair kernels take -- else None."""
+        cls = type(self)
+        if not (cls.process_user_features is TwoTowerBaseRetrieval.process_user_features
+                and cls.get_user_embedding is TwoTowerBaseRetrieval.get_user_embedding
+                and cls.compute_user_embedding is TwoTowerBaseRetrieval.compute_user_embedding
+                and cls.compute_item_embeddings is TwoTowerBaseRetrieval.compute_item_embeddings):
+            return None
+        um, ut, im, it = self.user_features_arch, self.user_tower_arch, self.item_features_arch, self.item_tower_arch
+        uw, iw = self.user_id_embedding_arch.weight, self.item_id_embedding_arch.weight
+        if not (user_features.is_cuda and ops.fused_tower_supported(uw, user_features, um[0].weight, um[2].weight, ut.weight)):
+            return None
+        u = (uw, user_id, user_features, um[0].weight, um[0].bias, um[2].weight, um[2].bias, ut.weight, ut.bias)
+        i = (iw, item_id, item_features, im[0].weight, im[0].bias, im[2].weight, im[2].bias, it.weight, it.bias)
+        return (u, i) if ops.fused_tower_pair_supported(u, i) else None
+
     def _lookup_plan(self, user_id, user_history, item_id):
         """{table: [id blocks in the order this model's forward looks them up]}."""
         return {self.user_id_embedding_arch.weight: [user_id], self.item_id_embedding_arch.weight: [item_id]}
@@ -334,12 +351,27 @@ class TwoTowerBaseRetrieval(nn.Module):
             own = type(self).compute_item_embeddings is TwoTowerBaseRetrieval.compute_item_embeddings
             tuned = own and item_features.is_cuda and ops.fused_tower_supported(
                 self.item_id_embedding_arch.weight, item_features, mlp[0].weight, mlp[2].weight, self.item_tower_arch.weight)
-            fork = ops.AuxFork(user_id.device, rows=user_id.numel() if tuned else 0)
-            user_embedding = self.compute_user_embedding(user_id, user_features, user_history)
-            with fork:
-                fork.uses(item_id, item_features)
-                item_embeddings = self.compute_item_embeddings(item_id, item_features)
-            item_embeddings = fork.joined(item_embeddings)
+            # Two ways to run the towers next to each other: two streams (AuxFork) or both towers per launch
+            # (ops.FusedTowerPair).  Next to the dense table sweep the fork wins (C2 1.10-1.12 vs 1.16-1.19 ms: 256 tower
+            # workgroups at once keep the row plan's big-LDS workgroup waiting); with nothing else on the chip -- the deferred
+            # optimiser schedule -- the pair does (P shape 1.07-1.09 vs 1.17-1.19 ms), and on ONE stream (a whole-step
+            # hipGraph capture, batches too small for the fork to pay) it is the only way (graphed 1.13 -> 1.02 ms)
+            ref = getattr(self.item_id_embedding_arch.weight, "_tt_optimizer", None)
+            opt = ref() if ref is not None else None
+            no_sweep = opt is not None and getattr(opt, "lazy", False)
+            pair = self._tower_pair_args(user_id, user_features, item_id, item_features) if (tuned and no_sweep) else None
+            fork = ops.AuxFork(user_id.device, rows=user_id.numel() if (tuned and pair is None) else 0)
+            if tuned and pair is None and not fork.on:
+                pair = self._tower_pair_args(user_id, user_features, item_id, item_features)
+            if pair is not None:
+                N.oob.poll(user_id.device)
+                user_embedding, item_embeddings = ops.FusedTowerPair.apply(*pair[0], *pair[1])
+            else:
+                user_embedding = self.compute_user_embedding(user_id, user_features, user_history)
+                with fork:
+                    fork.uses(item_id, item_features)
+                    item_embeddings = self.compute_item_embeddings(item_id, item_features)
+                item_embeddings = fork.joined(item_embeddings)
         return self.compute_training_loss(
             user_embedding=user_embedding, item_embeddings=item_embeddings, position=position, labels=labels
         )
