@@ -168,10 +168,10 @@ class TwoTowerBaseRetrieval(nn.Module):
         if sharded:
             w = self.item_id_embedding_arch.weight
             sh = parallel.shard_of(w)
-            mine = torch.ones(1, dtype=torch.int32, device=item_id.device)
+            foreign = torch.zeros(1, dtype=torch.int32, device=item_id.device)  # (MAX, not MIN: what tt_comm_* reduces)
             if item_id.numel():
-                mine = ((item_id >= sh.lo) & (item_id < sh.hi)).all().to(torch.int32).reshape(1)
-            local_only = bool(parallel.C.all_reduce_(mine, op=parallel.dist.ReduceOp.MIN).item())  # one decision for the group
+                foreign = ((item_id < sh.lo) | (item_id >= sh.hi)).any().to(torch.int32).reshape(1)
+            local_only = int(parallel.C.all_reduce_(foreign, op=parallel.dist.ReduceOp.MAX).item()) == 0  # one decision for the group
             # every rank runs the same number of chunks (routed lookups are collective); a rank whose block is shorter
             # looks up row 0 once per surplus chunk and drops the result
             per = torch.tensor([item_id.shape[0]], dtype=torch.int64, device=item_id.device)
