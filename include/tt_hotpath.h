@@ -332,6 +332,16 @@ int64_t tt_rowgrad_workspace_bytes(int64_t n_ids);
 int tt_rowgrad_plan(const int64_t* ids, int64_t n_ids, int64_t n_rows, int32_t* sorted_ids,
                     int32_t* perm, int32_t* seg_begin, int32_t* n_unique, int32_t* oob_flag,
                     void* ws, int64_t ws_bytes, tt_stream_t stream);
+/* tt_rowgrad_plan for SEVERAL tables' id lists in one launch (one workgroup per list): lists of at most 10 240 ids
+ * (tt_rowgrad_plan_jobs_supported), which is every lookup of the base model up to B = 10 240 -- the two sorts of a step
+ * (user ids, item ids) otherwise run back to back.  Same outputs as tt_rowgrad_plan, no workspace. */
+#define TT_PLAN_MAX_JOBS 4
+typedef struct {
+  const int64_t* ids; int64_t n_ids; int64_t n_rows;
+  int32_t *sorted_ids, *perm, *seg_begin, *n_unique;
+} tt_plan_job;
+int tt_rowgrad_plan_jobs_supported(int64_t n_ids);
+int tt_rowgrad_plan_jobs(const tt_plan_job* jobs /*host*/, int32_t n_jobs, int32_t* oob_flag, tt_stream_t stream);
 
 /* up to TT_MAX_GRAD_SOURCES row-gradient blocks; occurrence p in [0,n_ids) lives in
  * the block whose [first, first+rows) range contains p (e.g. item_id rows then

@@ -957,3 +957,29 @@ def test_tower_pair_launches_are_the_single_tower_kernels_bit_for_bit(B, D, Fu, 
     torch.autograd.backward([pu, pi], [gu, gi])
     got = grads()
     assert all(torch.equal(a, b) for a, b in zip(got, want))
+
+
+def test_row_plans_of_several_tables_in_one_launch_match_the_single_plans():
+    """tt_rowgrad_plan_jobs (one workgroup per id list: ops.RowPlan.build_many) against tt_rowgrad_plan list by list:
+    sorted ids, permutation, run starts and run count identical -- incl. a list of one id, heavy duplication, the longest
+    list the one-workgroup sort takes (10 240) and a mix with a longer list (falls back to one plan after the other)."""
+    from two_tower_models_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    cases = [(8192, 10_000_000), (8192, 1_000_000), (1, 7), (300, 50), (10240, (1 << 31) - 5)]
+    lists = [torch.randint(0, rows, (n,), generator=g).to(dev) for n, rows in cases]
+    single = [ops.RowPlan([ids], rows) for ids, (_, rows) in zip(lists, cases)]
+
+    def same(a, b):
+        nu = int(a.n_unique.item())
+        return (nu == int(b.n_unique.item()) and torch.equal(a.sorted_ids, b.sorted_ids) and torch.equal(a.perm, b.perm)
+                and torch.equal(a.seg_begin[: nu + 1], b.seg_begin[: nu + 1]))
+
+    for lo in (0, 2):  # (at most 4 jobs per launch)
+        many = [ops.RowPlan([ids], rows, defer=True) for ids, (_, rows) in zip(lists[lo:lo + 3], cases[lo:lo + 3])]
+        ops.RowPlan.build_many(many)
+        assert all(same(a, b) for a, b in zip(many, single[lo:lo + 3]))
+    long_ids = torch.randint(0, 1000, (20000,), generator=g).to(dev)
+    mixed = [ops.RowPlan([lists[0]], cases[0][1], defer=True), ops.RowPlan([long_ids], 1000, slot="plan_b", defer=True)]
+    ops.RowPlan.build_many(mixed)
+    assert same(mixed[0], single[0]) and same(mixed[1], ops.RowPlan([long_ids], 1000, slot="plan_c"))

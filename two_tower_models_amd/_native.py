@@ -83,6 +83,13 @@ class TowerWgradSide(C.Structure):
                 ("ws_bytes", _i64)]
 
 
+class PlanJob(C.Structure):
+    """tt_plan_job."""
+
+    _fields_ = [("ids", _vp), ("n_ids", _i64), ("n_rows", _i64), ("sorted_ids", _vp), ("perm", _vp), ("seg_begin", _vp), ("n_unique", _vp)]
+
+
+TT_PLAN_MAX_JOBS = 4
 TT_ROUTE_MAX_JOBS = 8
 
 
@@ -199,6 +206,8 @@ SIGNATURES = {
     "tt_tower_fwd_pair": (_int, [C.POINTER(TowerFwdSide), _i64, _i64, _i64, _vp, _vp]),
     "tt_tower_bwd_data_pair": (_int, [C.POINTER(TowerBwdSide), _i64, _i64, _i64, _vp]),
     "tt_tower_bwd_weights_pair": (_int, [C.POINTER(TowerWgradSide), _i64, _i64, _i64, _vp]),
+    "tt_rowgrad_plan_jobs_supported": (_int, [_i64]),
+    "tt_rowgrad_plan_jobs": (_int, [C.POINTER(PlanJob), _i32, _vp, _vp]),
     "tt_route_workspace_bytes": (_i64, [_i64, _i32]),
     "tt_route_count": (_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tt_route_build": (_int, [_vp, _i64, _i64, _i64, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),

@@ -252,10 +252,10 @@ __device__ __forceinline__ uint32_t ps_block_excl_scan(uint32_t v, uint32_t* wsu
   return woff + inc - v;
 }
 
-__global__ __launch_bounds__(PS_THREADS) void plan_small_kernel(const int64_t* __restrict__ ids, int n, int64_t n_rows, int kpt,
-                                                                int passes, int32_t* __restrict__ sorted_ids,
-                                                                int32_t* __restrict__ perm, int32_t* __restrict__ seg_begin,
-                                                                int32_t* __restrict__ n_unique, int32_t* __restrict__ oob_flag) {
+__device__ __forceinline__ void plan_small_body(const int64_t* __restrict__ ids, int n, int64_t n_rows, int kpt,
+                                                int passes, int32_t* __restrict__ sorted_ids,
+                                                int32_t* __restrict__ perm, int32_t* __restrict__ seg_begin,
+                                                int32_t* __restrict__ n_unique, int32_t* __restrict__ oob_flag) {
   extern __shared__ __attribute__((aligned(16))) uint32_t ps_smem[];
   const int cap = ps_pad(PS_THREADS * kpt) + 1;
   uint32_t* kbuf[2] = {ps_smem, ps_smem + cap};
@@ -329,6 +329,27 @@ __global__ __launch_bounds__(PS_THREADS) void plan_small_kernel(const int64_t* _
     *n_unique = (int32_t)total;
     seg_begin[total] = n;
   }
+}
+
+__global__ __launch_bounds__(PS_THREADS) void plan_small_kernel(const int64_t* __restrict__ ids, int n, int64_t n_rows, int kpt,
+                                                                int passes, int32_t* __restrict__ sorted_ids,
+                                                                int32_t* __restrict__ perm, int32_t* __restrict__ seg_begin,
+                                                                int32_t* __restrict__ n_unique, int32_t* __restrict__ oob_flag) {
+  plan_small_body(ids, n, n_rows, kpt, passes, sorted_ids, perm, seg_begin, n_unique, oob_flag);
+}
+
+// the same one-workgroup sort for SEVERAL tables' id lists in one launch (tt_rowgrad_plan_jobs): one workgroup per list --
+// the two 40-us sorts of a base-model step (user ids, item ids) ran back to back on one stream
+struct PlanSmallJobs {
+  const int64_t* ids[TT_PLAN_MAX_JOBS];
+  int n[TT_PLAN_MAX_JOBS], kpt[TT_PLAN_MAX_JOBS], passes[TT_PLAN_MAX_JOBS];
+  int64_t n_rows[TT_PLAN_MAX_JOBS];
+  int32_t *sorted_ids[TT_PLAN_MAX_JOBS], *perm[TT_PLAN_MAX_JOBS], *seg_begin[TT_PLAN_MAX_JOBS], *n_unique[TT_PLAN_MAX_JOBS];
+};
+__global__ __launch_bounds__(PS_THREADS) void plan_small_jobs_kernel(const PlanSmallJobs q, int32_t* __restrict__ oob_flag) {
+  const int j = blockIdx.x;
+  plan_small_body(q.ids[j], q.n[j], q.n_rows[j], q.kpt[j], q.passes[j], q.sorted_ids[j], q.perm[j], q.seg_begin[j], q.n_unique[j],
+                  oob_flag);
 }
 
 static int radix_passes(int64_t n_rows) {
@@ -407,4 +428,35 @@ extern "C" int tt_rowgrad_plan(const int64_t* ids, int64_t n_ids, int64_t n_rows
   if ((rc = check_launch("seg_scan_kernel"))) return rc;
   seg_write_kernel<<<nseg, 256, 0, st>>>(sorted_ids, n_ids, blk_heads, seg_begin);
   return check_launch("seg_write_kernel");
+}
+
+extern "C" int tt_rowgrad_plan_jobs_supported(int64_t n_ids) { return (n_ids > 0 && n_ids <= PS_MAX) ? 1 : 0; }
+
+extern "C" int tt_rowgrad_plan_jobs(const tt_plan_job* jobs, int32_t n_jobs, int32_t* oob_flag, tt_stream_t stream) {
+  if (!jobs || !oob_flag) return fail_arg("tt_rowgrad_plan_jobs: null pointer");
+  if (n_jobs <= 0 || n_jobs > TT_PLAN_MAX_JOBS) return fail_arg("tt_rowgrad_plan_jobs: 1..4 jobs");
+  PlanSmallJobs q{};
+  size_t lds = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    const tt_plan_job& b = jobs[j];
+    if (!b.ids || !b.sorted_ids || !b.perm || !b.seg_begin || !b.n_unique) return fail_arg("tt_rowgrad_plan_jobs: null pointer");
+    if (b.n_ids <= 0 || b.n_ids > PS_MAX || b.n_rows <= 0 || b.n_rows > ((int64_t)1 << 31)) {
+      set_error("tt_rowgrad_plan_jobs: lists of 1..%d ids (longer ones: tt_rowgrad_plan)", PS_MAX);
+      return TT_E_UNSUPPORTED;
+    }
+    int bits = 1;
+    while (bits < 31 && ((int64_t)1 << bits) < b.n_rows) ++bits;
+    const int kpt = (int)ceil_div(b.n_ids, PS_THREADS);
+    const size_t cap = (size_t)(PS_THREADS * kpt + (PS_THREADS * kpt >> 5)) + 1;
+    const size_t need = 2 * cap * 4 + 2 * cap * 2 + 4 + 16 * PS_THREADS * 2;
+    lds = need > lds ? need : lds;
+    q.ids[j] = b.ids; q.n[j] = (int)b.n_ids; q.n_rows[j] = b.n_rows; q.kpt[j] = kpt; q.passes[j] = b.n_rows > 1 ? (bits + 3) / 4 : 0;
+    q.sorted_ids[j] = b.sorted_ids; q.perm[j] = b.perm; q.seg_begin[j] = b.seg_begin; q.n_unique[j] = b.n_unique;
+  }
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(plan_small_jobs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("plan_small_jobs_kernel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  plan_small_jobs_kernel<<<(unsigned)n_jobs, PS_THREADS, lds, S(stream)>>>(q, oob_flag);
+  return check_launch("plan_small_jobs_kernel");
 }

@@ -352,6 +352,23 @@ class RowPlan:
                                     self.perm.data_ptr(), self.seg_begin.data_ptr(), self.n_unique.data_ptr(),
                                     N.oob.flag(dev).data_ptr(), wsp, wsn, N.stream()), "tt_rowgrad_plan")
 
+    @staticmethod
+    def build_many(plans: Sequence["RowPlan"]) -> None:
+        """build() of several deferred plans: ONE launch when every list fits the one-workgroup sort (tt_rowgrad_plan_jobs:
+        a workgroup per list -- a base-model step's two sorts side by side), else one after the other."""
+        plans = list(plans)
+        lib = N.load()
+        if 2 <= len(plans) <= N.TT_PLAN_MAX_JOBS and all(lib.tt_rowgrad_plan_jobs_supported(p.n) for p in plans):
+            jobs = (N.PlanJob * len(plans))()
+            for j, p in zip(jobs, plans):
+                j.ids, j.n_ids, j.n_rows = p.ids.data_ptr(), p.n, p.n_rows
+                j.sorted_ids, j.perm, j.seg_begin, j.n_unique = (t.data_ptr() for t in (p.sorted_ids, p.perm, p.seg_begin, p.n_unique))
+            dev = plans[0].ids.device
+            N.check(lib.tt_rowgrad_plan_jobs(jobs, len(plans), N.oob.flag(dev).data_ptr(), N.stream()), "tt_rowgrad_plan_jobs")
+            return
+        for p in plans:
+            p.build()
+
     @classmethod
     def from_grads(cls, blocks: Sequence[RowGrad], n_rows: int) -> "RowPlan":
         plan = cls([b.ids for b in blocks], n_rows)

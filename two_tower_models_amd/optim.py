@@ -711,15 +711,13 @@ class DenseExactAdam(torch.optim.Optimizer):
             return
         self._plans_pending = False
         if not side:
-            for ts in self._begun.values():
-                ts.plan.build()
+            ops.RowPlan.build_many([ts.plan for ts in self._begun.values()])
             return
         if self._plan_stream is None:
             self._plan_stream = N.aux_stream(next(iter(self._begun)).device)
         self._plan_stream.wait_event(self._plan_ready)  # the id lists exist
         with torch.cuda.stream(self._plan_stream):
-            for ts in self._begun.values():
-                ts.plan.build()
+            ops.RowPlan.build_many([ts.plan for ts in self._begun.values()])
             self._plan_done = torch.cuda.Event()
             self._plan_done.record(self._plan_stream)
 
@@ -865,6 +863,7 @@ class DenseExactAdam(torch.optim.Optimizer):
                 self._prefetch_done, self._prefetch_keep = None, None
             self._catchup_last.clear()
             self._advance_lazy()
+            todo = []
             for p in self._tables:
                 blocks = p._tt_rowgrads
                 if p.grad is not None:
@@ -873,9 +872,12 @@ class DenseExactAdam(torch.optim.Optimizer):
                     continue
                 if all(b.index is not None for b in blocks):
                     blocks = sorted(blocks, key=lambda b: b.index)
+                todo.append((p, blocks, ops.RowPlan([b.ids for b in blocks], p.shape[0], slot=f"plan{len(todo)}", defer=True)))
+            ops.RowPlan.build_many([plan for _, _, plan in todo])  # every table's sort in one launch where the lists are short
+            for p, blocks, plan in todo:
+                plan.attach([b.rows for b in blocks])
                 st = self.state[p]
                 n_rows, dim = p.shape
-                plan = ops.RowPlan.from_grads(blocks, n_rows)
                 wsp, wsn = ops._ws(p.device, lib.tt_adam_table_workspace_bytes(plan.n, dim), "adam_side")
                 N.check(lib.tt_adam_table_lazy(p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                                n_rows, dim, hyper, C.byref(plan.sources), plan.n,
