@@ -167,14 +167,20 @@ def emulated(W=8, workload="P", steps=30, warmup=25, device=None, verbose=False,
         ops.InBatchSoftmaxCE.forward, ops.InBatchSoftmaxCE.backward = staticmethod(ce_fwd), staticmethod(ce_bwd)
         acc = [0.0] * 5
         try:
-            for i in range(10):
+            # ten steps enqueued back to back, ONE synchronisation at the end: with a synchronisation per step the GPU starts
+            # every step with an empty queue and the front of the step (routing, towers) runs at the HOST's pace -- that is what
+            # rounds 3-5 reported as "lookups_towers 0.42-0.49 ms" (tools/emu_front_probe.py: GPU time per call = host time per call)
+            per_step = []
+            for i in range(12):
                 marks.clear()
                 _ev()
                 step(batches[i % 8], batches[(i + 1) % 8])
                 _ev()
-                torch.cuda.synchronize()
+                per_step.append(list(marks))
+            torch.cuda.synchronize()
+            for m in per_step[2:]:
                 for k in range(5):
-                    acc[k] += marks[k].elapsed_time(marks[k + 1]) / 10
+                    acc[k] += m[k].elapsed_time(m[k + 1]) / 10
         finally:
             ops.InBatchSoftmaxCE.forward, ops.InBatchSoftmaxCE.backward = staticmethod(_fwd), staticmethod(_bwd)
         B, D = cfg["B"], cfg["D"]
