@@ -705,6 +705,31 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int splits, 
   }
 }
 
+// the same sums, four columns per lane (16-byte loads and stores; D % 4 == 0, 16-byte aligned rows): the scalar form moved
+// 100 MB in 66 us at the 8-GPU shape (2 slabs of [65 536, 128]) -- 1.5 TB/s, a fifth of what the copy reaches
+__global__ __launch_bounds__(256) void slab_reduce4_kernel(const float4* __restrict__ slabs, int splits, int64_t rows, int64_t D4,
+                                                           float4* __restrict__ out, int64_t ldo4) {
+  const int64_t total = rows * D4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 v = slabs[i];
+    for (int z = 1; z < splits; ++z) {
+      const float4 w = slabs[(int64_t)z * total + i];
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    out[(i / D4) * ldo4 + (i % D4)] = v;
+  }
+}
+static int launch_slab_reduce(const float* slabs, int splits, int64_t rows, int64_t D, float* out, int64_t ldo, hipStream_t st) {
+  if (D % 4 == 0 && ldo % 4 == 0 && ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    const int64_t blocks = ceil_div(rows * (D / 4), 256);
+    slab_reduce4_kernel<<<(unsigned)(blocks < 8192 ? blocks : 8192), 256, 0, st>>>(reinterpret_cast<const float4*>(slabs), splits, rows, D / 4,
+                                                                                 reinterpret_cast<float4*>(out), ldo / 4);
+  } else {
+    slab_reduce_kernel<<<(unsigned)(ceil_div(rows * D, 256) < 2048 ? ceil_div(rows * D, 256) : 2048), 256, 0, st>>>(slabs, splits, rows, D, out, ldo);
+  }
+  return check_launch("slab_reduce_kernel");
+}
+
 // out[i, :] = x[i, :] * coef[i]  (dU = dL/dce (.) du_unit, the chain-rule step behind tt_inbatch_ce_fwd_du)
 __global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ coef,
                                                          int64_t rows, int64_t D, float* __restrict__ out, int64_t ldo) {
@@ -1123,8 +1148,7 @@ extern "C" int tt_inbatch_ce_bwd(const float* U, int64_t ldu, const float* I, in
     rc = dispatch_bwd<false>(pu.dp8, can_dma(I, ldi, D, pu.dp8), a, grid, st);
     if (rc) return rc;
     if (pu.splits > 1) {
-      slab_reduce_kernel<<<(unsigned)(ceil_div(M * D, 256) < 2048 ? ceil_div(M * D, 256) : 2048), 256, 0, st>>>(slab_u, pu.splits, M, D, dU, lddu);
-      if ((rc = check_launch("slab_reduce_kernel"))) return rc;
+      if ((rc = launch_slab_reduce(slab_u, pu.splits, M, D, dU, lddu, st))) return rc;
     }
   }
   {  // dI: stationary items, streamed users
@@ -1137,8 +1161,7 @@ extern "C" int tt_inbatch_ce_bwd(const float* U, int64_t ldu, const float* I, in
     rc = dispatch_bwd<true>(pi.dp8, can_dma(U, ldu, D, pi.dp8), a, grid, st);
     if (rc) return rc;
     if (pi.splits > 1) {
-      slab_reduce_kernel<<<(unsigned)(ceil_div(N * D, 256) < 2048 ? ceil_div(N * D, 256) : 2048), 256, 0, st>>>(slab_i, pi.splits, N, D, dI, lddi);
-      if ((rc = check_launch("slab_reduce_kernel"))) return rc;
+      if ((rc = launch_slab_reduce(slab_i, pi.splits, N, D, dI, lddi, st))) return rc;
     }
   }
   return 0;
@@ -1170,8 +1193,7 @@ extern "C" int tt_inbatch_ce_bwd_kept(const float* U, int64_t ldu, int64_t M, in
   int rc = pi.dp8 == 4 ? launch_bwd_kept<4>(a, grid, st) : pi.dp8 == 8 ? launch_bwd_kept<8>(a, grid, st) : launch_bwd_kept<16>(a, grid, st);
   if (rc) return rc;
   if (pi.splits > 1) {
-    slab_reduce_kernel<<<(unsigned)(ceil_div(N * D, 256) < 2048 ? ceil_div(N * D, 256) : 2048), 256, 0, st>>>(slab_i, pi.splits, N, D, dI, lddi);
-    if ((rc = check_launch("slab_reduce_kernel"))) return rc;
+    if ((rc = launch_slab_reduce(slab_i, pi.splits, N, D, dI, lddi, st))) return rc;
   }
   return 0;
 }
