@@ -35,7 +35,7 @@ for s in range(4):
     opt.zero_grad(); loss.backward(); opt.step()
     losses.append(float(loss))
 w = m.item_id_embedding_arch.weight
-out = {"losses": losses, "side_grads": ops._SIDE_GRADS, "sweep_note": opt.sweep_level_note(),
+out = {"losses": losses, "side_grads": ops._SIDE_GRADS, "concurrent_towers": ops._CONCURRENT_TOWERS, "sweep_note": opt.sweep_level_note(),
        "in_arena": w.untyped_storage().nbytes() > w.numel() * 4,
        "checksum": float(sum(p.double().sum() for p in m.parameters()))}
 if os.environ.get("TT_RCCL_PATH"):
@@ -63,7 +63,8 @@ def test_scheduling_switches_do_not_change_results():
     # on, RCCL loaded from an explicit path: scheduling only -> bit-identical
     # ... the tables and moments left where torch allocated them instead of re-homed into one arena
     sched, err = _run({"TT_WGRAD_MAIN": "1", "TT_SWEEP_WGS": "256", "TT_TUNE_DEBUG": "1", "TT_RCCL_PATH": "/opt/rocm/lib/librccl.so.1",
-                       "TT_ADAM_NO_ARENA": "1"})
+                       "TT_ADAM_NO_ARENA": "1", "TT_TOWERS_SERIAL": "1"})
+    assert base["concurrent_towers"] is True and sched["concurrent_towers"] is False  # item tower on the main stream
     assert sched["in_arena"] is False and sched["side_grads"] is False and sched["sweep_note"] == "fixed by TT_SWEEP_WGS" and sched["comm_size"] == [0, 1]
     assert sched["losses"] == base["losses"] and sched["checksum"] == base["checksum"]
     # the debias head as the hook's tensor expressions instead of the fused kernels: same maths, another summation order
