@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 3
+#define TT_ABI_VERSION 4
 
 #define TT_E_BADARG (-1)      /* null pointer / negative size / unsupported shape */
 #define TT_E_WORKSPACE (-2)   /* ws_bytes smaller than tt_*_workspace_bytes()     */
@@ -405,6 +405,19 @@ int tt_adam_table_sweep(float* W, float* M, float* V, int64_t n_rows, int64_t di
 struct tt_adam_tensor_s;
 int tt_adam_tables_sweep(const struct tt_adam_tensor_s* tables /*host*/, int32_t n_tables, const double* hyper,
                          int32_t n_wgs, tt_stream_t stream);
+/* Steps that look up MANY rows (the history model: 213 K of 1 M item rows) MARK them instead of parking them: one bit per
+ * row in `marks` (tt_adam_marks_words(n_rows) 32-bit words, cleared and set by tt_adam_mark_rows from the step's id list; ids
+ * outside [0, n_rows) are ignored), tt_adam_tables_sweep_marked steps over marked rows (marks[t] == NULL: no row of table t
+ * is marked), and tt_adam_table_finish / tt_adam_tables_finish with side == NULL read the rows' old p, m, v from the table
+ * itself.  Same arithmetic per row as the parked schedule: the same bits.  dims[t] = row width, a power of two in
+ * [32, 4096] (tt_adam_marked_supported), 16-byte aligned tables.  (ref:train/train.py:123-125: the dense Adam step.) */
+int64_t tt_adam_marks_words(int64_t n_rows);
+int tt_adam_marked_supported(int64_t dim);
+int tt_adam_mark_rows(const int64_t* ids, int64_t n_ids, int64_t n_rows, uint32_t* marks, int64_t marks_words,
+                      tt_stream_t stream);
+int tt_adam_tables_sweep_marked(const struct tt_adam_tensor_s* tables /*host*/, const int64_t* dims /*host*/,
+                                const uint32_t* const* marks /*host array of device pointers*/, int32_t n_tables,
+                                const double* hyper, int32_t n_wgs, tt_stream_t stream);
 int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows, int64_t dim, const double* hyper,
                          const tt_grad_sources* src /*host*/, int64_t n_ids, const int32_t* sorted_ids,
                          const int32_t* perm, const int32_t* seg_begin, const int32_t* n_unique,

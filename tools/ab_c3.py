@@ -15,6 +15,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "C3"
 mod_name, attr = (sys.argv[2] if len(sys.argv) > 2 else "optim._HOLD_SWEEP").split(".")
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 blocks = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+VALUES = [int(v) for v in sys.argv[5].split(",")] if len(sys.argv) > 5 else None  # integer settings instead of off / on
 mod = importlib.import_module("two_tower_models_amd." + mod_name)
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
@@ -47,6 +48,7 @@ def run(flag):
     evs.append(e)
     torch.cuda.synchronize()
     ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+    opt_level[0] = opt.sweep_level_note()
     del model, opt
     torch.cuda.empty_cache()
     return ms[steps // 2], sum(ms) / steps, opt_level[0]
@@ -54,6 +56,6 @@ def run(flag):
 
 opt_level = [None]
 for b in range(blocks):
-    for flag in (False, True):
-        p50, mean, _ = run(flag)
-        print(f"{wl} {attr}={flag}: p50 {p50:.3f} ms, mean {mean:.3f} ms", flush=True)
+    for flag in (VALUES or (False, True)):
+        p50, mean, note = run(flag)
+        print(f"{wl} {attr}={flag}: p50 {p50:.3f} ms, mean {mean:.3f} ms   [sweep: {note}]", flush=True)

@@ -24,7 +24,7 @@ TT_COMM_ID_BYTES = 128
 TT_COMM_F32, TT_COMM_I32, TT_COMM_I64, TT_COMM_U8 = 0, 1, 2, 3
 TT_COMM_SUM, TT_COMM_MAX = 0, 1
 TT_MAX_GRAD_SOURCES = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _vp, _i64, _i32, _int = C.c_void_p, C.c_int64, C.c_int32, C.c_int
 
@@ -176,6 +176,10 @@ SIGNATURES = {
     "tt_adam_table_stash_ids": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "tt_adam_table_sweep": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "tt_adam_tables_sweep": (_int, [C.POINTER(AdamTensor), _i32, _vp, _i32, _vp]),
+    "tt_adam_marks_words": (_i64, [_i64]),
+    "tt_adam_marked_supported": (_int, [_i64]),
+    "tt_adam_mark_rows": (_int, [_vp, _i64, _i64, _vp, _i64, _vp]),
+    "tt_adam_tables_sweep_marked": (_int, [C.POINTER(AdamTensor), C.POINTER(_i64), C.POINTER(_vp), _i32, _vp, _i32, _vp]),
     "tt_adam_table_finish": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, C.POINTER(GradSources), _i64, _vp, _vp, _vp,
                                     _vp, _vp, _i64, _vp]),
     "tt_adam_advance_tab": (_int, [_vp, _vp, _i64, _vp]),

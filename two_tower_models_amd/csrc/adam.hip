@@ -295,12 +295,14 @@ __device__ __forceinline__ void adam_finish_body(float* __restrict__ W, float* _
   const int64_t row = sorted_ids[t0];
   if (row >= n_rows) return;  // sentinel run
   const int64_t n4 = dim / 4;
-  const float4* sp = reinterpret_cast<const float4*>(side + (int64_t)perm[t0] * dim);
-  const float4* sm = sp + cap * n4;
-  const float4* sv = sm + cap * n4;
   float4* wp = reinterpret_cast<float4*>(W + row * dim);
   float4* wm = reinterpret_cast<float4*>(M + row * dim);
   float4* wv = reinterpret_cast<float4*>(V + row * dim);
+  // side == nullptr: the rows were MARKED, not parked (tt_adam_mark_rows + tt_adam_tables_sweep_marked): the sweep left
+  // them alone and their old p, m, v are where they always were
+  const float4* sp = side ? reinterpret_cast<const float4*>(side + (int64_t)perm[t0] * dim) : wp;
+  const float4* sm = side ? sp + cap * n4 : wm;
+  const float4* sv = side ? sm + cap * n4 : wv;
   for (int64_t d = sub; d < n4; d += LPR) {
     float4 p = sp[d], m = sm[d], v = sv[d];
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -489,6 +491,89 @@ __global__ __launch_bounds__(256) void adam_sweep_tables_kernel(const SweepTable
       __threadfence();
     }
   }
+}
+
+// The sweep for steps that look up MANY rows (history model: 213 K of 1 M item rows per step).  Parking such a step's rows
+// (p, m, v out to a side buffer before the sweep, back in afterwards) moved 0.67 GB in front of the sweep and the sweep
+// then spent another 0.58 GB on rows whose result the finish overwrites.  Here the looked-up rows are MARKED in a bitmap
+// (one bit per row, tt_adam_mark_rows) and the sweep steps over them: they keep their old p, m, v until the finish
+// (side == nullptr above) gives them their real update.  Same arithmetic for every row, so the same bits as the parked
+// schedule.  A chunk (256 x ITERS float4) covers (1024 >> sh) whole rows, sh = log2(dim / 4) in [3, 10]: at most 128 rows
+// = 4 words of the bitmap, fetched with scalar loads (the chunk index is made wave-uniform first).  The unmarked form
+// above stays what it is: the headline's sweep touches 16 K of 11 M rows and parks them.
+struct SweepTablesMarked {
+  SweepTables t;
+  const unsigned* marks[SWEEP_MAX_TABLES];
+  int sh[SWEEP_MAX_TABLES];
+};
+template <int ITERS, bool NT>
+__global__ __launch_bounds__(256) void adam_sweep_tables_marked_kernel(const SweepTablesMarked tm, const double* __restrict__ hyper,
+                                                                       unsigned* __restrict__ ctr) {
+  const AdamConst c = load_hyper(hyper);
+  const unsigned n_chunks = tm.t.first_chunk[tm.t.n];
+  __shared__ unsigned s_next[2];
+  if (threadIdx.x == 0) s_next[0] = atomicAdd(&ctr[0], 1u);
+  __syncthreads();
+  unsigned ch = s_next[0];
+  int par = 0;
+  while (ch < n_chunks) {
+    if (threadIdx.x == 0) s_next[par ^ 1] = atomicAdd(&ctr[0], 1u);
+    const unsigned chu = __builtin_amdgcn_readfirstlane(ch);
+    int t = 0;
+#pragma unroll
+    for (int q = 1; q < SWEEP_MAX_TABLES; ++q)
+      if (q < tm.t.n && chu >= tm.t.first_chunk[q]) t = q;
+    float4* __restrict__ W = tm.t.W[t];
+    float4* __restrict__ M = tm.t.M[t];
+    float4* __restrict__ V = tm.t.V[t];
+    const int64_t n4 = tm.t.n4[t];
+    const unsigned lc = chu - tm.t.first_chunk[t];
+    const int sh = tm.sh[t];
+    const int64_t r0 = (int64_t)lc * ((256 * ITERS) >> sh);  // first row of the chunk
+    const unsigned* __restrict__ mk = tm.marks[t];
+    unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    if (mk) {  // (the bitmap is padded by four words)
+      const unsigned* mw = mk + (r0 >> 5);
+      w0 = mw[0]; w1 = mw[1]; w2 = mw[2]; w3 = mw[3];
+    }
+    const int64_t base = (int64_t)lc * (256 * ITERS) + threadIdx.x;
+    // (the loop of the unmarked kernel, plus the test: written with all ITERS loads up front it took 92 registers instead of
+    // 44, and three such waves per SIMD no longer leave room for a 256-register forward / backward wave next to them --
+    // the second in-projection of the history encoder ran 651 us instead of 211)
+#pragma unroll ITERS
+    for (int k = 0; k < ITERS; ++k) {
+      const int64_t i = base + (int64_t)k * 256;
+      if (i >= n4) break;
+      const int64_t row = r0 + ((k * 256 + (int)threadIdx.x) >> sh);
+      const int wj = (int)((row >> 5) - (r0 >> 5));
+      const unsigned word = wj == 0 ? w0 : wj == 1 ? w1 : wj == 2 ? w2 : w3;
+      if ((word >> (row & 31)) & 1u) continue;
+      float4 p = sweep_load<NT>(W + i), m = sweep_load<NT>(M + i), v = sweep_load<NT>(V + i);
+      adam_elem_zero_grad(p.x, m.x, v.x, c);
+      adam_elem_zero_grad(p.y, m.y, v.y, c);
+      adam_elem_zero_grad(p.z, m.z, v.z, c);
+      adam_elem_zero_grad(p.w, m.w, v.w, c);
+      sweep_store<NT>(p, W + i); sweep_store<NT>(m, M + i); sweep_store<NT>(v, V + i);
+    }
+    __syncthreads();
+    par ^= 1;
+    ch = s_next[par];
+  }
+  if (threadIdx.x == 0) {
+    if (atomicAdd(&ctr[1], 1u) == gridDim.x - 1) {
+      ctr[0] = 0;
+      ctr[1] = 0;
+      __threadfence();
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_mark_rows_kernel(const int64_t* __restrict__ ids, int64_t n_ids, int64_t n_rows,
+                                                             unsigned* __restrict__ marks) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_ids) return;
+  const int64_t row = ids[i];
+  if (row >= 0 && row < n_rows) atomicOr(&marks[row >> 5], 1u << (row & 31));  // ids of another rank's rows / invalid ids: nothing
 }
 
 __global__ __launch_bounds__(256) void adam_sweep_scalar_kernel(float* __restrict__ W, float* __restrict__ M,
@@ -884,6 +969,62 @@ extern "C" int tt_adam_tables_sweep(const tt_adam_tensor* tables, int32_t n_tabl
   return check_launch("adam_sweep_tables_kernel");
 }
 
+extern "C" int64_t tt_adam_marks_words(int64_t n_rows) { return n_rows > 0 ? (n_rows + 31) / 32 + 4 : 4; }
+
+extern "C" int tt_adam_mark_rows(const int64_t* ids, int64_t n_ids, int64_t n_rows, uint32_t* marks, int64_t marks_words,
+                                 tt_stream_t stream) {
+  if (!ids || !marks) return fail_arg("tt_adam_mark_rows: null pointer");
+  if (n_ids <= 0 || n_rows <= 0) return fail_arg("tt_adam_mark_rows: sizes");
+  if (marks_words < tt_adam_marks_words(n_rows)) { set_error("tt_adam_mark_rows: bitmap of %lld words < %lld", (long long)marks_words, (long long)tt_adam_marks_words(n_rows)); return TT_E_WORKSPACE; }
+  hipStream_t st = S(stream);
+  // cleared HERE, every step, not by the finish: a step that is abandoned between its begin and its finish leaves nothing behind
+  hipError_t e = hipMemsetAsync(marks, 0, (size_t)marks_words * 4, st);
+  if (e != hipSuccess) { set_error("tt_adam_mark_rows: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+  adam_mark_rows_kernel<<<(unsigned)ceil_div(n_ids, 256), 256, 0, st>>>(ids, n_ids, n_rows, marks);
+  return check_launch("adam_mark_rows_kernel");
+}
+
+extern "C" int tt_adam_marked_supported(int64_t dim) {
+  if (dim < 32 || dim > 4096 || (dim & (dim - 1))) return 0;  // whole rows per 16 KB chunk, at most 128 of them
+  return 1;
+}
+
+extern "C" int tt_adam_tables_sweep_marked(const tt_adam_tensor* tables, const int64_t* dims, const uint32_t* const* marks,
+                                           int32_t n_tables, const double* hyper, int32_t n_wgs, tt_stream_t stream) {
+  if (!tables || !dims || !marks || !hyper) return fail_arg("tt_adam_tables_sweep_marked: null pointer");
+  if (n_tables <= 0 || n_tables > SWEEP_MAX_TABLES) return fail_arg("tt_adam_tables_sweep_marked: 1..4 tables");
+  SweepTablesMarked tm{};
+  unsigned chunks = 0;
+  for (int t = 0; t < n_tables; ++t) {
+    const tt_adam_tensor& d = tables[t];
+    if (!d.p || !d.m || !d.v || d.n <= 0) return fail_arg("tt_adam_tables_sweep_marked: descriptor");
+    if (!tt_adam_marked_supported(dims[t]) || d.n % dims[t]) return fail_arg("tt_adam_tables_sweep_marked: dim must be a power of two in [32, 4096]");
+    if ((reinterpret_cast<uintptr_t>(d.p) | reinterpret_cast<uintptr_t>(d.m) | reinterpret_cast<uintptr_t>(d.v)) & 15)
+      return fail_arg("tt_adam_tables_sweep_marked: 16-byte aligned tables");
+    tm.t.W[t] = reinterpret_cast<float4*>(d.p); tm.t.M[t] = reinterpret_cast<float4*>(d.m); tm.t.V[t] = reinterpret_cast<float4*>(d.v);
+    tm.t.n4[t] = d.n / 4;
+    tm.t.first_chunk[t] = chunks;
+    const int64_t c = ceil_div(d.n / 4, 256 * 4);
+    if (c + chunks >= (1ll << 32)) return fail_arg("tt_adam_tables_sweep_marked: too many chunks");
+    chunks += (unsigned)c;
+    tm.marks[t] = marks[t];  // NULL: no row of this table is marked
+    int sh = 0;
+    while ((4ll << sh) < dims[t]) ++sh;
+    tm.sh[t] = sh;
+  }
+  tm.t.first_chunk[n_tables] = chunks;
+  tm.t.n = n_tables;
+  static const int wgs_env = getenv("TT_SWEEP_WGS") ? atoi(getenv("TT_SWEEP_WGS")) : 0;
+  const int want = getenv("TT_SWEEP_WGS") ? wgs_env : n_wgs;
+  unsigned* ctr = reinterpret_cast<unsigned*>(const_cast<double*>(hyper) + 7);
+  unsigned grid = (unsigned)(device_cu_count() * SWEEP_DEFAULT_PERSIST);
+  if (want > 0 && (unsigned)want < grid) grid = (unsigned)want;
+  hipStream_t st = S(stream);
+  ProfScope prof("adam_sweep_kernel", st);
+  adam_sweep_tables_marked_kernel<4, true><<<grid, 256, 0, st>>>(tm, hyper, ctr);
+  return check_launch("adam_sweep_tables_marked_kernel");
+}
+
 // A HIP stream of the device's LEAST priority for the sweep: the backward kernels on the
 // caller's (normal-priority) stream win the dispatcher whenever both have work.
 extern "C" int tt_stream_create_low_priority(void** out) {
@@ -908,11 +1049,12 @@ extern "C" int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows
                                     const tt_grad_sources* src, int64_t n_ids, const int32_t* sorted_ids,
                                     const int32_t* perm, const int32_t* seg_begin, const int32_t* n_unique,
                                     void* side, int64_t side_bytes, tt_stream_t stream) {
-  if (!W || !M || !V || !hyper || !sorted_ids || !perm || !seg_begin || !n_unique || !side)
+  if (!W || !M || !V || !hyper || !sorted_ids || !perm || !seg_begin || !n_unique)
     return fail_arg("tt_adam_table_finish: null pointer");
   if (n_rows <= 0 || dim <= 0 || n_ids <= 0) return fail_arg("tt_adam_table_finish: sizes");
   if (!check_sources(src, n_ids, dim)) return fail_arg("tt_adam_table_finish: gradient sources");
-  if (side_bytes < tt_adam_table_workspace_bytes(n_ids, dim)) { set_error("tt_adam_table_finish: side buffer"); return TT_E_WORKSPACE; }
+  // side == NULL: the rows were marked, not parked (tt_adam_tables_sweep_marked); vector form only
+  if (side && side_bytes < tt_adam_table_workspace_bytes(n_ids, dim)) { set_error("tt_adam_table_finish: side buffer"); return TT_E_WORKSPACE; }
   hipStream_t st = S(stream);
   float* sd = reinterpret_cast<float*>(side);
   bool vec = dim % 4 == 0 && ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(M) | reinterpret_cast<uintptr_t>(V) |
@@ -925,6 +1067,7 @@ extern "C" int tt_adam_table_finish(float* W, float* M, float* V, int64_t n_rows
     else adam_finish_kernel<64><<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, sd, n_ids);
     return check_launch("adam_finish_kernel");
   }
+  if (!side) return fail_arg("tt_adam_table_finish: marked rows (side == NULL) need dim % 4 == 0 and 16-byte aligned operands");
   adam_touched_kernel<true><<<(unsigned)ceil_div(n_ids, 4), 256, 0, st>>>(W, M, V, n_rows, dim, hyper, *src, sorted_ids, perm, seg_begin, n_unique, sd, n_ids);
   int rc = check_launch("adam_touched_kernel");
   if (rc) return rc;
@@ -939,11 +1082,11 @@ extern "C" int tt_adam_tables_finish(const tt_adam_finish_job* jobs, int32_t n_j
   int lpr = 0;
   for (int i = 0; i < n_jobs; ++i) {
     const tt_adam_finish_job& j = jobs[i];
-    if (!j.W || !j.M || !j.V || !j.src || !j.sorted_ids || !j.perm || !j.seg_begin || !j.n_unique || !j.side)
+    if (!j.W || !j.M || !j.V || !j.src || !j.sorted_ids || !j.perm || !j.seg_begin || !j.n_unique)
       return fail_arg("tt_adam_tables_finish: null pointer");
     if (j.n_rows <= 0 || j.dim <= 0 || j.n_ids <= 0) return fail_arg("tt_adam_tables_finish: sizes");
     if (!check_sources(j.src, j.n_ids, j.dim)) return fail_arg("tt_adam_tables_finish: gradient sources");
-    if (j.side_bytes < tt_adam_table_workspace_bytes(j.n_ids, j.dim)) { set_error("tt_adam_tables_finish: side buffer"); return TT_E_WORKSPACE; }
+    if (j.side && j.side_bytes < tt_adam_table_workspace_bytes(j.n_ids, j.dim)) { set_error("tt_adam_tables_finish: side buffer"); return TT_E_WORKSPACE; }
     bool vec = j.dim % 4 == 0 && ((reinterpret_cast<uintptr_t>(j.W) | reinterpret_cast<uintptr_t>(j.M) | reinterpret_cast<uintptr_t>(j.V) |
                                    reinterpret_cast<uintptr_t>(j.side)) & 15) == 0;
     for (int k = 0; vec && k < j.src->n_sources; ++k)

@@ -1279,12 +1279,18 @@ class HistoryEncoder(_LookupFunction):
                                        N.ptr(pe), x.data_ptr(),
                                        pooled.data_ptr(), 2 * D, N.oob.flag(dev).data_ptr(), N.stream()),
                 "tt_hist_embed_pool")
+        sweep_opt = None
         if ids is not None:
-            # the step's big gather is queued: a table sweep the optimiser held back for it may start now (optim.py)
+            # the step's big gather is queued: a table sweep the optimiser held back for it may start now (optim.py) -- unless
+            # the sweep steps over this step's rows (marked schedule): nothing orders it against the lookups then, and it
+            # starts behind the first in-projection below
             ref = getattr(source, "_tt_optimizer", None)
             opt = ref() if ref is not None else None
             if opt is not None:
-                opt.release_sweep()
+                if opt.held_sweep_is_marked():
+                    sweep_opt = opt
+                else:
+                    opt.release_sweep()
         saved: List[torch.Tensor] = []
         # the last layer is consumed at row 0 only: one query per (sample, head), K / V projections folded into two D-wide
         # vectors per (sample, head) (csrc/encoder_last.hip)
@@ -1361,6 +1367,15 @@ class HistoryEncoder(_LookupFunction):
                 folded_w[l] = w_eff
             else:
                 gemm(N.TT_GEMM_NT, x, w_in, qkv, B * H, 3 * D, D, bias=b_in)
+            if sweep_opt is not None:
+                # Measured over every launch of the C3 step as the release point, each at its best sweep width
+                # (tools/sweep_release_scan.py, profiles/r06_sweep_release_scan.txt): behind the history gather 3.41-3.48 ms,
+                # behind THIS product 3.21-3.25, behind the attention kernel 3.47, behind the second layer's product 3.27,
+                # later 3.25-3.6; parked rows (which start the sweep about here: the moments' gather ran in front of it) 3.31-3.34
+                started = torch.cuda.Event()
+                started.record()
+                sweep_opt.release_sweep(after=started)
+                sweep_opt = None
             ctx_t, lse = _attn_fwd(qkv, B, H, D, heads)
             saved += [x, qkv, ctx_t, lse]
             if (l + 2 == L and fold_last) or folded_in(l + 1):
@@ -1372,6 +1387,8 @@ class HistoryEncoder(_LookupFunction):
                 gemm(N.TT_GEMM_NT, ctx_t.view(B, H * D)[:, :D], w_out, out[:, 0, :], B, D, D, bias=b_out)
         if L == 0:
             out[:, 0, :].copy_(x.view(B, H, D)[:, 0, :])
+        if sweep_opt is not None:  # no full layer ran
+            sweep_opt.release_sweep()
         ctx.dims = (B, H, D, L, heads)
         ctx.collapsed_last = collapsed_last
         ctx.folded = {l: w for l, w in folded_w.items()}  # layer -> its composed in-projection weight W_in W_o(prev)

@@ -63,16 +63,19 @@ from . import ops
 
 
 _RELEASE_AT_LOGITS = True  # a sweep held for the backward logits kernel is released BY that kernel's Function (A/B switch)
+_SPLIT_MIN_IDS = 65536  # looked-up rows per step from which the moments leave the main stream's begin launch (tests lower it)
+_MARK_ROWS = True  # ... and are not parked at all: the sweep steps over the step's rows (tools/ab_c3.py flips it)
 _HOLD_SWEEP = True  # (tools/ab_c3.py flips it: the held-back sweep start against the immediate one, same process, same box)
 
 
 class _TableStep:
     """State of one table between the overlapped begin (in zero_grad) and finish (in step)."""
 
-    __slots__ = ("plan", "side", "announced")
+    __slots__ = ("plan", "side", "announced", "marked")
 
     def __init__(self, plan, side, announced=False):
         self.plan, self.side, self.announced = plan, side, announced
+        self.marked = False  # the looked-up rows are marked for the sweep to step over, not parked (_begin_overlapped)
 
 
 class _LazyRows:
@@ -146,6 +149,7 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._begun: Optional[Dict[torch.nn.Parameter, _TableStep]] = None
         self._sweep_done: Optional[torch.cuda.Event] = None
         self._side_bufs: Dict[int, torch.Tensor] = {}
+        self._marks: Dict[int, torch.Tensor] = {}  # table -> one bit per row: the rows this step looks up (marked schedule)
         self._sweep_events = None  # keep_sweep_events(): (start, end) event pairs of the table sweep launches
         self._catchup_last: Dict[int, tuple] = {}  # deferred schedule: table -> (event, stream) of its latest catch-up this step
 
@@ -447,18 +451,27 @@ class DenseExactAdam(torch.optim.Optimizer):
             # forward can start -- the moments are parked on the sweep's stream, in front of the sweep (C3: 0.15 ms at the
             # head of the step become 0.05).  Small lookups keep the single launch.
             n_stashed = sum(j[6] for j in stash_jobs)
-            split_planes = not capturing and 0 < len(stash_jobs) <= 4 and n_stashed >= 65536
+            split_planes = not capturing and 0 < len(stash_jobs) <= 4 and n_stashed >= _SPLIT_MIN_IDS
+            # ... and the moments are not parked at all where the sweep can step over the looked-up rows instead (a bitmap of
+            # the step's rows, tt_adam_mark_rows): no 0.4 GB gather in front of the sweep, no sweep traffic for rows the
+            # finish overwrites, the finish reads the rows' old p, m, v from the table.  The p plane is still "parked": it IS
+            # the forward's lookup.
+            marked = (split_planes and _MARK_ROWS and all(lib.tt_adam_marked_supported(j[4]) for j in stash_jobs)
+                      and all((j[0] | j[1] | j[2]) % 16 == 0 for j in stash_jobs))
             if split_planes:
                 N.check(lib.tt_adam_begin_ids_planes(hyper, None, 0, jobs, len(stash_jobs), 1, N.stream()), "tt_adam_begin_ids_planes")
             else:
                 N.check(lib.tt_adam_begin_ids(hyper, None, 0, jobs, len(stash_jobs), N.stream()), "tt_adam_begin_ids")
         else:
-            split_planes = False
+            split_planes = marked = False
+        for p, ts in begun.items():
+            ts.marked = marked
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(main)  # lookups (or none yet, forward mode) + stashes are complete here
 
-        def launch_sweep(held_back=False, after=None, ready=ready, begun=begun, split_planes=split_planes, capturing=capturing):
+        def launch_sweep(held_back=False, after=None, ready=ready, begun=begun, split_planes=split_planes, capturing=capturing,
+                         marked=marked):
             self._side_stream.wait_event(ready)
             if held_back:  # ... and after what was queued since (the big gather this was held back for) / after `after`
                 later = after
@@ -466,7 +479,19 @@ class DenseExactAdam(torch.optim.Optimizer):
                     later = torch.cuda.Event()
                     later.record(torch.cuda.current_stream())
                 self._side_stream.wait_event(later)
-            if split_planes:
+            mark_ptrs = None
+            if marked:
+                mark_ptrs = (C.c_void_p * len(begun))()
+                for i, (p, ts) in enumerate(begun.items()):
+                    n_local = stash_jobs[i][3]
+                    words = lib.tt_adam_marks_words(n_local)
+                    bm = self._marks.get(id(p))
+                    if bm is None or bm.numel() < words:
+                        bm = self._marks[id(p)] = torch.empty(words, dtype=torch.int32, device=p.device)
+                    N.check(lib.tt_adam_mark_rows(ts.plan.ids.data_ptr(), ts.plan.n, n_local, bm.data_ptr(), bm.numel(),
+                                                  self._side_stream.cuda_stream), "tt_adam_mark_rows")
+                    mark_ptrs[i] = bm.data_ptr()
+            elif split_planes:
                 N.check(lib.tt_adam_begin_ids_planes(hyper, None, 0, jobs, len(stash_jobs), 6, self._side_stream.cuda_stream),
                         "tt_adam_begin_ids_planes")
             ev_s0 = None
@@ -481,8 +506,13 @@ class DenseExactAdam(torch.optim.Optimizer):
                     shard = getattr(p, "_tt_shard", None)
                     descs[i].m, descs[i].v = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
                     descs[i].n = p.numel() if shard is None else shard.n_local * p.shape[1]
-                N.check(lib.tt_adam_tables_sweep(descs, len(begun), hyper, self._sweep_wgs, self._side_stream.cuda_stream),
-                        "tt_adam_tables_sweep")
+                if mark_ptrs is not None:
+                    dims = (C.c_int64 * len(begun))(*[p.shape[1] for p in begun])
+                    N.check(lib.tt_adam_tables_sweep_marked(descs, dims, mark_ptrs, len(begun), hyper, self._sweep_wgs,
+                                                            self._side_stream.cuda_stream), "tt_adam_tables_sweep_marked")
+                else:
+                    N.check(lib.tt_adam_tables_sweep(descs, len(begun), hyper, self._sweep_wgs, self._side_stream.cuda_stream),
+                            "tt_adam_tables_sweep")
             self._sweep_done = torch.cuda.Event(enable_timing=not capturing)
             self._sweep_done.record(self._side_stream)
             if self._tune is not None:
@@ -503,6 +533,7 @@ class DenseExactAdam(torch.optim.Optimizer):
         # logits from HBM anyway -- loses less than that (round 4: 4.10 vs 4.26 ms per emulated W = 8 step)
         if _HOLD_SWEEP and announced is not None and not capturing and ((n_announced >= 65536 and not self._sharded) or hold_sweep):
             self._sweep_pending = launch_sweep
+            self._sweep_pending_marked = marked
             # hold_sweep: until the BACKWARD logits kernel is in the main stream's queue (ops.InBatchSoftmaxCE.backward
             # releases it, ordered behind an event recorded in front of that kernel): both become runnable at the same
             # moment and the kernel, already queued on the normal-priority stream, takes its workgroup slots first.  Released
@@ -539,6 +570,10 @@ class DenseExactAdam(torch.optim.Optimizer):
             total += a.elapsed_time(b)
             n += 1
         return total, n
+
+    def held_sweep_is_marked(self) -> bool:
+        """A sweep is held back AND it will step over this step's looked-up rows (so the lookups need not be queued first)."""
+        return getattr(self, "_sweep_pending", None) is not None and bool(getattr(self, "_sweep_pending_marked", False))
 
     def release_sweep(self, after: Optional[torch.cuda.Event] = None) -> None:
         """Start the table sweep a forward-announced step held back (see _begin_overlapped); no-op otherwise.
@@ -847,7 +882,7 @@ class DenseExactAdam(torch.optim.Optimizer):
                     j.dim, j.src, j.n_ids = p.shape[1], C.pointer(ts.plan.sources), ts.plan.n
                     j.sorted_ids, j.perm = ts.plan.sorted_ids.data_ptr(), ts.plan.perm.data_ptr()
                     j.seg_begin, j.n_unique = ts.plan.seg_begin.data_ptr(), ts.plan.n_unique.data_ptr()
-                    j.side, j.side_bytes = ts.side.data_ptr(), ts.side.numel()
+                    j.side, j.side_bytes = (None, 0) if ts.marked else (ts.side.data_ptr(), ts.side.numel())
                 N.check(lib.tt_adam_tables_finish(jobs, len(self._begun), hyper, N.stream()), "tt_adam_tables_finish")
             self._begun = None
             if self._tune is not None:
