@@ -619,6 +619,74 @@ def test_adam_table_equals_dense_adam(T, n_rows, D, n1, n2):
     assert float(hyper[4]) == 3.0
 
 
+@pytest.mark.parametrize("n_rows,D,n", [(5003, 128, 900), (1000, 64, 700), (777, 32, 300), (300, 256, 100), (40000, 128, 30000)])
+def test_adam_marked_sweep_equals_the_single_call(T, n_rows, D, n):
+    """The marked schedule (tt_adam_mark_rows, tt_adam_tables_sweep_marked, finish with side == NULL: the sweep steps over
+    the looked-up rows and the finish reads their old p, m, v from the table) vs tt_adam_table (park, sweep, write back) on
+    the same tables: p, m, v bit for bit -- duplicate ids, ids outside the block, row counts that are no multiple of 32 or
+    of a chunk, a second table of the same launch with no marks at all."""
+    import ctypes as C
+    ops, N = T
+    lib = N.load()
+    assert lib.tt_adam_marked_supported(D) == 1 and lib.tt_adam_marked_supported(96) == 0 and lib.tt_adam_marked_supported(16) == 0
+    g2 = torch.Generator().manual_seed(n_rows + D)
+    W0 = torch.randn(n_rows, D, generator=g2)
+    M0, V0 = torch.randn(n_rows, D, generator=g2) * 0.01, torch.rand(n_rows, D, generator=g2) * 1e-4
+    X0 = torch.randn(3 * 1024 + 40, generator=g2)  # the unmarked second table: three chunks and a bit
+    ids = torch.randint(0, n_rows, (n,), generator=g2)
+    ids[:7] = ids[7:14]
+    ids[20] = n_rows + 5
+    ids[21] = n_rows - 1
+    ids[22] = 0
+    rows = (torch.randn(n, D, generator=g2) * 0.01).to(DEV)
+    ids = ids.to(DEV)
+
+    def fresh():
+        hyper = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 6, 0, 0, 0], dtype=torch.float64, device=DEV)
+        N.check(lib.tt_adam_advance(hyper.data_ptr(), N.stream()), "advance")
+        plan = ops.RowPlan([ids], n_rows + 8)
+        plan.attach([rows])
+        return hyper, [t.clone().to(DEV) for t in (W0, M0, V0)], [X0.clone().to(DEV) for _ in range(3)], plan
+
+    hyper, (W, M, V), (X, Y, Z), plan = fresh()
+    wsn = lib.tt_adam_table_workspace_bytes(n, D)
+    ws = torch.empty(wsn, dtype=torch.uint8, device=DEV)
+    N.check(lib.tt_adam_table(W.data_ptr(), M.data_ptr(), V.data_ptr(), n_rows, D, hyper.data_ptr(), C.byref(plan.sources), n,
+                              plan.sorted_ids.data_ptr(), plan.perm.data_ptr(), plan.seg_begin.data_ptr(), plan.n_unique.data_ptr(),
+                              ws.data_ptr(), wsn, N.stream()), "tt_adam_table")
+    N.check(lib.tt_adam_table_sweep(X.data_ptr(), Y.data_ptr(), Z.data_ptr(), X.numel() // 8, 8, hyper.data_ptr(), N.stream()), "sweep")
+
+    hyper2, (W2, M2, V2), (X2, Y2, Z2), plan2 = fresh()
+    words = lib.tt_adam_marks_words(n_rows)
+    marks = torch.full((words,), -1, dtype=torch.int32, device=DEV)  # stale bits everywhere: mark_rows clears first
+    N.check(lib.tt_adam_mark_rows(ids.data_ptr(), n, n_rows, marks.data_ptr(), words, N.stream()), "mark_rows")
+    descs = (N.AdamTensor * 2)()
+    descs[0].p, descs[0].m, descs[0].v, descs[0].n = W2.data_ptr(), M2.data_ptr(), V2.data_ptr(), W2.numel()
+    descs[1].p, descs[1].m, descs[1].v, descs[1].n = X2.data_ptr(), Y2.data_ptr(), Z2.data_ptr(), X2.numel() // 32 * 32
+    dims = (C.c_int64 * 2)(D, 32)
+    mp = (C.c_void_p * 2)(marks.data_ptr(), None)
+    N.check(lib.tt_adam_tables_sweep_marked(descs, dims, mp, 2, hyper2.data_ptr(), 0, N.stream()), "sweep_marked")
+    tail = X2.numel() // 32 * 32  # (the second table's last 8 elements are no whole 32-wide row: swept by the plain call)
+    N.check(lib.tt_adam_table_sweep(X2[tail:].data_ptr(), Y2[tail:].data_ptr(), Z2[tail:].data_ptr(), 1, X2.numel() - tail,
+                                    hyper2.data_ptr(), N.stream()), "sweep tail")
+    fj = (N.AdamFinishJob * 1)()
+    j = fj[0]
+    j.W, j.M, j.V, j.n_rows, j.dim, j.src, j.n_ids = W2.data_ptr(), M2.data_ptr(), V2.data_ptr(), n_rows, D, C.pointer(plan2.sources), n
+    j.sorted_ids, j.perm, j.seg_begin, j.n_unique = (plan2.sorted_ids.data_ptr(), plan2.perm.data_ptr(),
+                                                     plan2.seg_begin.data_ptr(), plan2.n_unique.data_ptr())
+    j.side, j.side_bytes = None, 0
+    N.check(lib.tt_adam_tables_finish(fj, 1, hyper2.data_ptr(), N.stream()), "tables_finish")
+    torch.cuda.synchronize()
+    for a, b, name in ((W, W2, "p"), (M, M2, "m"), (V, V2, "v"), (X, X2, "p'"), (Y, Y2, "m'"), (Z, Z2, "v'")):
+        assert torch.equal(a, b), name
+    assert not torch.equal(W.cpu(), W0)
+    got = marks.cpu().numpy().view("uint32")
+    want = torch.zeros(words * 32, dtype=torch.bool)
+    want[ids.cpu()[ids.cpu() < n_rows]] = True
+    import numpy as np
+    assert np.array_equal(np.unpackbits(got.view("uint8"), bitorder="little").astype(bool), want.numpy())
+
+
 @pytest.mark.parametrize("dims", [(128, 128), (128, 64), (50, 50), (128,), (128, 128, 128, 128, 128)])
 def test_adam_merged_begin_and_finish_equal_the_separate_calls(T, dims):
     """tt_adam_begin_ids (advance + every table's plan-free stash) and tt_adam_tables_finish (every table's looked-up

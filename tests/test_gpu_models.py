@@ -566,6 +566,52 @@ def test_overlapped_sweep_is_bit_identical_to_serial(golden, kind, name):
     assert opt._begun is None
 
 
+@pytest.mark.parametrize("kind,name", [("base", "g2_base_aligned"), ("hist", "g4_hist_d128")])
+def test_marked_sweep_is_bit_identical_to_parked_and_serial(golden, kind, name, monkeypatch):
+    """Steps that look up many rows (>= optim._SPLIT_MIN_IDS: 65 536, lowered here) do not park them: the rows are marked,
+    the sweep steps over them, the lookups read the table, the finish takes the rows' old p / m / v from the table
+    (csrc/adam.hip, SweepTablesMarked).  Same bits as the parked forward schedule and as the serial one, and a lookup the
+    optimiser was not told about is refused -- its rows could be mid-update."""
+    import two_tower_models_amd as A
+    from two_tower_models_amd import optim
+    g = golden(name)
+    monkeypatch.setattr(optim, "_SPLIT_MIN_IDS", 1)
+    finals = []
+    for mode in ("marked", "parked", "serial"):
+        monkeypatch.setattr(optim, "_MARK_ROWS", mode == "marked")
+        model = make_model(kind, g)
+        opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep=False if mode == "serial" else "forward")
+        b = batch_of(g)
+        for _ in range(4):
+            loss = model.train_forward(*b)
+            if mode != "serial":
+                assert all(ts.marked == (mode == "marked") for ts in opt._begun.values()) and opt._begun
+                act = model.item_id_embedding_arch.weight._tt_active
+                assert (act.p_plane is None) == (mode == "marked")
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            assert opt._begun is None and model.item_id_embedding_arch.weight._tt_active is None
+        torch.cuda.synchronize()
+        finals.append({k: v.clone() for k, v in model.state_dict().items()})
+        finals[-1].update({f"m{i}": opt.state[p]["exp_avg"].clone() for i, p in enumerate(opt._tables)})
+        finals[-1].update({f"v{i}": opt.state[p]["exp_avg_sq"].clone() for i, p in enumerate(opt._tables)})
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
+        assert torch.equal(finals[0][k], finals[2][k]), k
+    # marked rows: a lookup that was not announced must not read the table
+    monkeypatch.setattr(optim, "_MARK_ROWS", True)
+    b = batch_of(g)
+    from two_tower_models_amd import ops
+    model = make_model(kind, g)
+    opt = A.DenseExactAdam(model.parameters(), lr=1e-3, overlap_sweep="forward")
+    assert opt.begin_step(model._lookup_plan(b[0], b[2], b[3]))
+    with pytest.raises(RuntimeError, match="not told about"):
+        ops.EmbeddingLookup.apply(model.item_id_embedding_arch.weight, b[3][:3])
+    opt.release_sweep()
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("kind,name", [("base", "g2_base_aligned"), ("hist", "g4_hist_d128"), ("base", "g1_base_tiny")])
 def test_lazy_adam_is_bit_identical_to_dense(golden, kind, name):
     """DenseExactAdam(lazy=True) replays the zero-gradient steps of a row when the row is next

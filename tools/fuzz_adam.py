@@ -21,7 +21,10 @@ from oracle import cpu_ref as R
 DEV = "cuda:0"
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-SCHEDULES = [dict(overlap_sweep=False), dict(overlap_sweep=True), dict(overlap_sweep="forward"), dict(lazy=True)]
+# "marked": the forward schedule with the big-lookup threshold lowered to 1 -- rows marked for the sweep to step over where the
+# row width allows (32 / 64 / 128), moments parked on the sweep's stream otherwise
+SCHEDULES = [dict(overlap_sweep=False), dict(overlap_sweep=True), dict(overlap_sweep="forward"), dict(lazy=True),
+             dict(overlap_sweep="forward", marked=True)]
 t0, n, bad = time.time(), 0, 0
 while time.time() - t0 < budget:
     kind = str(rng.choice(["base", "base", "hist"]))
@@ -63,7 +66,8 @@ while time.time() - t0 < budget:
             model = make()
             model.load_state_dict(init)
             model = model.to(DEV)
-            opt = A.DenseExactAdam(model.parameters(), lr=1e-3, **sched)
+            A.optim._SPLIT_MIN_IDS = 1 if sched.get("marked") else 65536
+            opt = A.DenseExactAdam(model.parameters(), lr=1e-3, **{k: v for k, v in sched.items() if k != "marked"})
             losses = []
             for b in batches:
                 loss = model.train_forward(*[t.to(DEV) for t in b])

@@ -449,6 +449,21 @@ class ActiveStash:
         return self.positions[self.offsets[index]: self.offsets[index + 1]]
 
 
+class ActiveMarks:
+    """Attached to a table (`weight._tt_active`) while its looked-up rows are MARKED for the sweep to step over (optim.py):
+    lookups read the table itself -- the marked rows keep their old values until the finish -- but only the lookups the
+    optimiser was told about: any other row may be mid-update."""
+
+    p_plane = None
+
+    def __init__(self, block_sizes: Sequence[int]):
+        self.block_sizes = list(block_sizes)
+
+    def slots_for(self, index: int, n: int) -> None:
+        if index >= len(self.block_sizes) or self.block_sizes[index] != n:
+            raise RuntimeError("forward performed a lookup the optimiser was not told about (begin_step mismatch)")
+
+
 def lookup_source(weight: torch.Tensor, ids: torch.Tensor, recording: bool):
     """-> (rows_table [n, D], row_ids int64 [numel], lookup_index).  Registers the lookup with the
     table's optimiser when the forward is being recorded."""
@@ -463,7 +478,9 @@ def lookup_source(weight: torch.Tensor, ids: torch.Tensor, recording: bool):
     idx = register_lookup(weight, ids) if recording else None
     act = getattr(weight, "_tt_active", None)
     if act is not None and idx is not None:
-        return act.p_plane, act.slots_for(idx, ids.numel()), idx
+        slots = act.slots_for(idx, ids.numel())
+        if act.p_plane is not None:
+            return act.p_plane, slots, idx
     return weight, ids.reshape(-1), idx
 
 

@@ -458,7 +458,12 @@ class DenseExactAdam(torch.optim.Optimizer):
             # the forward's lookup.
             marked = (split_planes and _MARK_ROWS and all(lib.tt_adam_marked_supported(j[4]) for j in stash_jobs)
                       and all((j[0] | j[1] | j[2]) % 16 == 0 for j in stash_jobs))
-            if split_planes:
+            if marked:  # nothing is parked: the lookups read the table, whose marked rows keep their old values until the finish
+                N.check(lib.tt_adam_advance(hyper, N.stream()), "tt_adam_advance")
+                for p, ts in begun.items():
+                    if getattr(p, "_tt_shard", None) is None:
+                        p._tt_active = ops.ActiveMarks(ts.plan.block_sizes)
+            elif split_planes:
                 N.check(lib.tt_adam_begin_ids_planes(hyper, None, 0, jobs, len(stash_jobs), 1, N.stream()), "tt_adam_begin_ids_planes")
             else:
                 N.check(lib.tt_adam_begin_ids(hyper, None, 0, jobs, len(stash_jobs), N.stream()), "tt_adam_begin_ids")
