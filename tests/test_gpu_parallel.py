@@ -37,6 +37,11 @@ CASES = {
     # rank and step (B*H = 12 800 history lookups + 256 item ids per rank), by all ranks -- the routed exchange at its most
     # duplicated (SURVEY section 7 "History all-to-all volume")
     "hist50_dup": ("hist", dict(n_users=90, n_items=40, D=128, F=8, B=256, H=50)),
+    # the MARKED sweep on row blocks (optim._SPLIT_MIN_IDS lowered from 65 536: the owners mark the rows they serve instead
+    # of parking them; the padding slots' sentinel ids and other ranks' rows are ignored by the marking)
+    "hist_marked": ("hist", dict(n_users=211, n_items=307, D=128, F=8, B=40, H=6, mark_from=1)),
+    "hist50_dup_marked": ("hist", dict(n_users=90, n_items=40, D=64, F=8, B=256, H=50, mark_from=1)),
+    "base_marked": ("base", dict(n_users=300, n_items=500, D=128, F=8, B=64, H=2, mark_from=1)),
     # an item table with fewer rows than ranks x rows-per-rank: the last rank owns NO item row
     "hist_empty_block": ("hist", dict(n_users=338, n_items=9, D=64, F=20, B=33, H=1)),
     # BASELINE config 5's model in training: the fused debias head on the gathered batch
@@ -154,6 +159,10 @@ def _worker(rank, world, port, outdir, case, backend, transport, sharded_init, p
     from two_tower_models_amd import collectives, parallel
     dev = init_pg(backend, rank, world, port)
     restore = perturb_host_timing(perturb_seed + rank) if perturb_seed is not None else (lambda: None)
+    mark_from = _case(case)[1].get("mark_from")
+    if mark_from is not None:
+        from two_tower_models_amd import optim
+        optim._SPLIT_MIN_IDS = mark_from
     try:
         if transport == "native":
             from two_tower_models_amd.comm import NativeComm
@@ -183,6 +192,7 @@ def _worker(rank, world, port, outdir, case, backend, transport, sharded_init, p
         losses = []
         for i, b in enumerate(batches):
             loss = model.train_forward(*b)
+            assert mark_from is None or all(ts.marked for ts in opt._begun.values())
             if i % 3 == 0 and i + 1 < len(batches):  # batch 1 is announced (routes planned one step ahead); batch 2 arrives unannounced
                 parallel.plan_ahead(model._lookup_plan(batches[i + 1][0], batches[i + 1][2], batches[i + 1][3]))
             opt.zero_grad()
@@ -263,6 +273,7 @@ def check_against_oracle(case, res, world, outlier_frac=2e-3):
     (3, "base_crowded", "gloo", "torch", True), (2, "base_labels1d", "gloo", "torch", False),
     (2, "hist", "gloo", "torch", False), (3, "hist50", "gloo", "torch", True), (4, "hist_empty_block", "gloo", "torch", False),
     (3, "hist50_dup", "gloo", "torch", False),
+    (2, "hist_marked", "gloo", "torch", False), (3, "hist50_dup_marked", "gloo", "torch", True), (2, "base_marked", "gloo", "torch", False),
     (2, "debias", "gloo", "torch", False), (3, "debias_small", "gloo", "torch", True),
     # RCCL, one device per rank: skipped on the 1-GPU test boxes, run on any multi-GPU node
     (2, "base_d128", "nccl", "torch", False), ("all", "base_d128", "nccl", "torch", True),
