@@ -95,8 +95,11 @@ while time.time() - t0 < budget:
                 noise_only = k in ("item_tower_arch.bias", "item_features_arch.2.bias") or k.endswith("in_proj_bias")
                 if float(err.max()) > 2.2e-3 * steps:
                     msgs.append(f"{tag}: {k}: max err {float(err.max()):.2e}")
-                elif k == "item_features_arch.0.bias" and int((err > 5e-6).sum()) <= 8:
-                    pass  # units active for every item of a batch: analytically zero bias gradient
+                elif k == "item_features_arch.0.bias" and int((err > 5e-6).sum()) <= (8 if B > 16 else 16):
+                    # units active for every item of a batch: analytically zero bias gradient.  With 16
+                    # items and 3 features a dozen of the 256 units can be (seeds 611 / 612: 10 and 9 of them, every schedule
+                    # alike, the serial one included)
+                    pass
                 elif not noise_only and int((err > 5e-6).sum()) > max(2, int(5e-3 * err.numel())):
                     msgs.append(f"{tag}: {k}: {int((err > 5e-6).sum())} of {err.numel()} beyond 5e-6")
         for i in range(1, len(results)):  # the schedules are the same arithmetic in a different order of launches
