@@ -71,11 +71,12 @@ _HOLD_SWEEP = True  # (tools/ab_c3.py flips it: the held-back sweep start agains
 class _TableStep:
     """State of one table between the overlapped begin (in zero_grad) and finish (in step)."""
 
-    __slots__ = ("plan", "side", "announced", "marked")
+    __slots__ = ("plan", "side", "announced", "marked", "n_rows")
 
-    def __init__(self, plan, side, announced=False):
+    def __init__(self, plan, side, announced=False, marked=False, n_rows=0):
         self.plan, self.side, self.announced = plan, side, announced
-        self.marked = False  # the looked-up rows are marked for the sweep to step over, not parked (_begin_overlapped)
+        self.marked = marked  # the looked-up rows are marked for the sweep to step over, not parked (_begin_overlapped): no side buffer
+        self.n_rows = n_rows  # rows of the table this process owns
 
 
 class _LazyRows:
@@ -150,6 +151,8 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._sweep_done: Optional[torch.cuda.Event] = None
         self._side_bufs: Dict[int, torch.Tensor] = {}
         self._marks: Dict[int, torch.Tensor] = {}  # table -> one bit per row: the rows this step looks up (marked schedule)
+        self._sweep_pending = None  # a sweep held back for a later point of the step (release_sweep)
+        self._sweep_pending_marked = False
         self._sweep_events = None  # keep_sweep_events(): (start, end) event pairs of the table sweep launches
         self._catchup_last: Dict[int, tuple] = {}  # deferred schedule: table -> (event, stream) of its latest catch-up this step
 
@@ -413,27 +416,43 @@ class DenseExactAdam(torch.optim.Optimizer):
         self._host_steps += 1
         begun: Dict[torch.nn.Parameter, _TableStep] = {}
         stash_jobs = []  # forward mode: the step-count advance and every table's stash go out as ONE launch
+        todo = []  # (table, id blocks, rows it owns)
         for p in self._tables:
             blocks = announced.get(id(p)) if announced is not None else p._tt_lookups
             if not blocks:
                 continue
-            n_rows, dim = p.shape
             shard = getattr(p, "_tt_shard", None)
-            if shard is not None:
-                # this rank's block: `blocks` are the local ids the lookup exchange delivered, with the sentinel n_local
-                # for padding slots -- the plan sorts it last (n_rows + 1 "rows") and the Adam kernels skip its run
-                n_rows = shard.n_local
-                if n_rows <= 0:  # fewer rows than ranks: nothing to park, sweep or finish on this rank
-                    continue
+            # a row block: `blocks` are the local ids the lookup exchange delivered, with the sentinel n_local for padding
+            # slots -- the plan sorts it last (n_rows + 1 "rows") and the Adam kernels skip its run
+            n_rows = p.shape[0] if shard is None else shard.n_local
+            if n_rows > 0:  # (fewer rows than ranks: nothing to park, sweep or finish on this rank)
+                todo.append((p, blocks, n_rows))
+        # Many looked-up rows (history model: 217 K, 0.67 GB of p / m / v to park): only the p plane is needed before the
+        # forward can start -- the moments are parked on the sweep's stream, in front of the sweep (C3: 0.15 ms at the head
+        # of the step become 0.05).  Small lookups keep the single launch.
+        n_stashed = sum(sum(b.numel() for b in blocks) for _, blocks, _ in todo)
+        split_planes = announced is not None and not capturing and 0 < len(todo) <= 4 and n_stashed >= _SPLIT_MIN_IDS
+        # ... and nothing is parked at all where the sweep can step over the looked-up rows instead (a bitmap of the step's
+        # rows, tt_adam_mark_rows): no gather in front of the sweep, no sweep traffic for rows the finish overwrites; the
+        # lookups read the table, whose marked rows keep their old values until the finish, and the finish reads p, m, v there
+        marked = (split_planes and _MARK_ROWS and all(lib.tt_adam_marked_supported(p.shape[1]) for p, _, _ in todo)
+                  and all((p.data_ptr() | self.state[p]["exp_avg"].data_ptr() | self.state[p]["exp_avg_sq"].data_ptr()) % 16 == 0
+                          for p, _, _ in todo))
+        for p, blocks, n_rows in todo:
+            dim = p.shape[1]
+            shard = getattr(p, "_tt_shard", None)
             st = self.state[p]
             # forward mode: the ids alone are enough to park the rows (slot = occurrence), so the
             # sort is deferred until the sweep is running
             plan = ops.RowPlan(blocks, n_rows + (1 if shard is not None else 0), slot=f"plan{id(p)}", defer=announced is not None)
-            side = self._side(p, lib.tt_adam_table_workspace_bytes(plan.n, dim))
-            if announced is not None:
+            side = None if marked else self._side(p, lib.tt_adam_table_workspace_bytes(plan.n, dim))
+            if marked:
+                if shard is None:  # (a sharded table's lookups were served from the table before this point: parallel.begin_lookups)
+                    p._tt_active = ops.ActiveMarks(plan.block_sizes)
+            elif announced is not None:
                 stash_jobs.append((p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), n_rows, dim,
                                    plan.ids.data_ptr(), plan.n, side.data_ptr(), side.numel()))
-                if shard is None:  # (a sharded table's lookups were served from the table before this point: parallel.begin_lookups)
+                if shard is None:
                     p_plane = side[: plan.n * dim * 4].view(torch.float32).view(plan.n, dim)
                     p._tt_active = ops.ActiveStash(p_plane, plan.block_sizes)
             else:
@@ -441,36 +460,18 @@ class DenseExactAdam(torch.optim.Optimizer):
                                                 n_rows, dim, plan.n, plan.sorted_ids.data_ptr(), plan.perm.data_ptr(),
                                                 plan.seg_begin.data_ptr(), plan.n_unique.data_ptr(), side.data_ptr(),
                                                 side.numel(), N.stream()), "tt_adam_table_stash")
-            begun[p] = _TableStep(plan, side, announced is not None)
-        if announced is not None:
+            begun[p] = _TableStep(plan, side, announced is not None, marked, n_rows)
+        if marked:
+            N.check(lib.tt_adam_advance(hyper, N.stream()), "tt_adam_advance")
+        elif announced is not None:
             jobs = (N.AdamStashJob * max(len(stash_jobs), 1))()
             for i, j in enumerate(stash_jobs):
                 (jobs[i].W, jobs[i].M, jobs[i].V, jobs[i].n_rows, jobs[i].dim, jobs[i].ids, jobs[i].n_ids, jobs[i].side,
                  jobs[i].side_bytes) = j
-            # Many looked-up rows (history model: 217 K, 0.67 GB of p / m / v to park): only the p plane is needed before the
-            # forward can start -- the moments are parked on the sweep's stream, in front of the sweep (C3: 0.15 ms at the
-            # head of the step become 0.05).  Small lookups keep the single launch.
-            n_stashed = sum(j[6] for j in stash_jobs)
-            split_planes = not capturing and 0 < len(stash_jobs) <= 4 and n_stashed >= _SPLIT_MIN_IDS
-            # ... and the moments are not parked at all where the sweep can step over the looked-up rows instead (a bitmap of
-            # the step's rows, tt_adam_mark_rows): no 0.4 GB gather in front of the sweep, no sweep traffic for rows the
-            # finish overwrites, the finish reads the rows' old p, m, v from the table.  The p plane is still "parked": it IS
-            # the forward's lookup.
-            marked = (split_planes and _MARK_ROWS and all(lib.tt_adam_marked_supported(j[4]) for j in stash_jobs)
-                      and all((j[0] | j[1] | j[2]) % 16 == 0 for j in stash_jobs))
-            if marked:  # nothing is parked: the lookups read the table, whose marked rows keep their old values until the finish
-                N.check(lib.tt_adam_advance(hyper, N.stream()), "tt_adam_advance")
-                for p, ts in begun.items():
-                    if getattr(p, "_tt_shard", None) is None:
-                        p._tt_active = ops.ActiveMarks(ts.plan.block_sizes)
-            elif split_planes:
+            if split_planes:
                 N.check(lib.tt_adam_begin_ids_planes(hyper, None, 0, jobs, len(stash_jobs), 1, N.stream()), "tt_adam_begin_ids_planes")
             else:
                 N.check(lib.tt_adam_begin_ids(hyper, None, 0, jobs, len(stash_jobs), N.stream()), "tt_adam_begin_ids")
-        else:
-            split_planes = marked = False
-        for p, ts in begun.items():
-            ts.marked = marked
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(main)  # lookups (or none yet, forward mode) + stashes are complete here
@@ -488,7 +489,7 @@ class DenseExactAdam(torch.optim.Optimizer):
             if marked:
                 mark_ptrs = (C.c_void_p * len(begun))()
                 for i, (p, ts) in enumerate(begun.items()):
-                    n_local = stash_jobs[i][3]
+                    n_local = ts.n_rows
                     words = lib.tt_adam_marks_words(n_local)
                     bm = self._marks.get(id(p))
                     if bm is None or bm.numel() < words:
