@@ -499,14 +499,15 @@ __global__ __launch_bounds__(256) void adam_sweep_tables_kernel(const SweepTable
 // (one bit per row, tt_adam_mark_rows) and the sweep steps over them: they keep their old p, m, v until the finish
 // (side == nullptr above) gives them their real update.  Same arithmetic for every row, so the same bits as the parked
 // schedule.  A chunk (256 x ITERS float4) covers (1024 >> sh) whole rows, sh = log2(dim / 4) in [3, 10]: at most 128 rows
-// = 4 words of the bitmap, fetched with scalar loads (the chunk index is made wave-uniform first).  The unmarked form
-// above stays what it is: the headline's sweep touches 16 K of 11 M rows and parks them.
+// = 4 words of the bitmap, fetched once per chunk (the chunk index is made wave-uniform first).  The unmarked form above stays
+// what it is: the headline's sweep touches 16 K of 11 M rows and parks them (this kernel with no row marked in its place:
+// P 5.436 -> 5.429 ms, C2 1.086 -> 1.082, i.e. nothing).
 struct SweepTablesMarked {
   SweepTables t;
   const unsigned* marks[SWEEP_MAX_TABLES];
   int sh[SWEEP_MAX_TABLES];
 };
-template <int ITERS, bool NT>
+template <int ITERS, int PAIR, bool NT>
 __global__ __launch_bounds__(256) void adam_sweep_tables_marked_kernel(const SweepTablesMarked tm, const double* __restrict__ hyper,
                                                                        unsigned* __restrict__ ctr) {
   const AdamConst c = load_hyper(hyper);
@@ -537,23 +538,40 @@ __global__ __launch_bounds__(256) void adam_sweep_tables_marked_kernel(const Swe
       w0 = mw[0]; w1 = mw[1]; w2 = mw[2]; w3 = mw[3];
     }
     const int64_t base = (int64_t)lc * (256 * ITERS) + threadIdx.x;
-    // (the loop of the unmarked kernel, plus the test: written with all ITERS loads up front it took 92 registers instead of
-    // 44, and three such waves per SIMD no longer leave room for a 256-register forward / backward wave next to them --
-    // the second in-projection of the history encoder ran 651 us instead of 211)
-#pragma unroll ITERS
-    for (int k = 0; k < ITERS; ++k) {
-      const int64_t i = base + (int64_t)k * 256;
-      if (i >= n4) break;
-      const int64_t row = r0 + ((k * 256 + (int)threadIdx.x) >> sh);
-      const int wj = (int)((row >> 5) - (r0 >> 5));
-      const unsigned word = wj == 0 ? w0 : wj == 1 ? w1 : wj == 2 ? w2 : w3;
-      if ((word >> (row & 31)) & 1u) continue;
-      float4 p = sweep_load<NT>(W + i), m = sweep_load<NT>(M + i), v = sweep_load<NT>(V + i);
-      adam_elem_zero_grad(p.x, m.x, v.x, c);
-      adam_elem_zero_grad(p.y, m.y, v.y, c);
-      adam_elem_zero_grad(p.z, m.z, v.z, c);
-      adam_elem_zero_grad(p.w, m.w, v.w, c);
-      sweep_store<NT>(p, W + i); sweep_store<NT>(m, M + i); sweep_store<NT>(v, V + i);
+    // Register budget: the kernels that run NEXT TO this sweep fill the register file -- the encoder's in-projection holds
+    // 2 x 218 of a SIMD's 512 registers, so a CU takes it together with sweep waves of <= 76 registers per SIMD in total, and
+    // the attention backward (2 x 250) with none.  All ITERS loads up front (92 registers) shut the in-projection out of every
+    // CU with a sweep workgroup (651 us instead of 211); one row triple at a time (46) lets ONE sweep wave per SIMD in, so that
+    // a sweep wide enough to finish in time (1.5 workgroups per CU) halved the in-projection's CUs.  PAIR triples in flight per
+    // wave: half as many waves stream as much.
+#pragma unroll
+    for (int k = 0; k < ITERS; k += PAIR) {
+      float4 p[PAIR], m[PAIR], v[PAIR];
+      bool live[PAIR];
+#pragma unroll
+      for (int q = 0; q < PAIR; ++q) {
+        const int64_t i = base + (int64_t)(k + q) * 256;
+        const int64_t row = r0 + (((k + q) * 256 + (int)threadIdx.x) >> sh);
+        const int wj = (int)((row >> 5) - (r0 >> 5));
+        const unsigned word = wj == 0 ? w0 : wj == 1 ? w1 : wj == 2 ? w2 : w3;
+        live[q] = i < n4 && !((word >> (row & 31)) & 1u);
+      }
+#pragma unroll
+      for (int q = 0; q < PAIR; ++q) {
+        const int64_t i = base + (int64_t)(k + q) * 256;
+        if (live[q]) { p[q] = sweep_load<NT>(W + i); m[q] = sweep_load<NT>(M + i); v[q] = sweep_load<NT>(V + i); }
+      }
+#pragma unroll
+      for (int q = 0; q < PAIR; ++q) {
+        const int64_t i = base + (int64_t)(k + q) * 256;
+        if (live[q]) {
+          adam_elem_zero_grad(p[q].x, m[q].x, v[q].x, c);
+          adam_elem_zero_grad(p[q].y, m[q].y, v[q].y, c);
+          adam_elem_zero_grad(p[q].z, m[q].z, v[q].z, c);
+          adam_elem_zero_grad(p[q].w, m[q].w, v[q].w, c);
+          sweep_store<NT>(p[q], W + i); sweep_store<NT>(m[q], M + i); sweep_store<NT>(v[q], V + i);
+        }
+      }
     }
     __syncthreads();
     par ^= 1;
@@ -1021,7 +1039,9 @@ extern "C" int tt_adam_tables_sweep_marked(const tt_adam_tensor* tables, const i
   if (want > 0 && (unsigned)want < grid) grid = (unsigned)want;
   hipStream_t st = S(stream);
   ProfScope prof("adam_sweep_kernel", st);
-  adam_sweep_tables_marked_kernel<4, true><<<grid, 256, 0, st>>>(tm, hyper, ctr);
+  // two row triples in flight per wave: 62 registers (see the kernel); one at a time (46) 3.27 ms per C3 step at its best
+  // width (384 workgroups), two 3.09 (256), four (92 registers) 3.34 (128) -- one process each, profiles/r06_marked_sweep_AB.txt
+  adam_sweep_tables_marked_kernel<4, 2, true><<<grid, 256, 0, st>>>(tm, hyper, ctr);
   return check_launch("adam_sweep_tables_marked_kernel");
 }
 
