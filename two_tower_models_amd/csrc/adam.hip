@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void adam_sweep_tables_marked_kernel(const Swe
     }
     const int64_t base = (int64_t)lc * (256 * ITERS) + threadIdx.x;
     // Register budget: the kernels that run NEXT TO this sweep fill the register file -- the encoder's in-projection holds
-    // 2 x 218 of a SIMD's 512 registers, so a CU takes it together with sweep waves of <= 76 registers per SIMD in total, and
+    // 2 x 218 (allocated as 2 x 224) of a SIMD's 512 registers, so a CU takes it together with sweep waves of <= 64 registers per SIMD in total, and
     // the attention backward (2 x 250) with none.  All ITERS loads up front (92 registers) shut the in-projection out of every
     // CU with a sweep workgroup (651 us instead of 211); one row triple at a time (46) lets ONE sweep wave per SIMD in, so that
     // a sweep wide enough to finish in time (1.5 workgroups per CU) halved the in-projection's CUs.  PAIR triples in flight per
