@@ -86,6 +86,10 @@ def run(label, name, occ):
     print(f"{wl} sweep released after {label}: p50 {ms[steps // 2]:.3f} ms   [{note}]", flush=True)
 
 
+only = os.environ.get("SCAN_ONLY")  # one release point (its label), e.g. under rocprofv3 for a timeline
+if only:
+    run(*[pt for pt in POINTS if pt[0] == only][0])
+    sys.exit(0)
 for label, name, occ in POINTS:
     run(label, name, occ)
 run(*POINTS[0])
