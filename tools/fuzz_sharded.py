@@ -38,6 +38,8 @@ if __name__ == "__main__":
                    D=int(rng.choice([32, 64, 128])) if hist else int(rng.choice([8, 24, 40, 64, 128, 160])),
                    F=int(rng.integers(4, 24)), B=int(rng.choice([16, 33, 64, 100])),
                    H=int(rng.choice([2, 4, 9, 50])) if hist else 2)
+        if cfg["D"] in (32, 64, 128) and rng.random() < 0.5:
+            cfg["mark_from"] = 1  # the owners MARK the rows they serve (optim._SPLIT_MIN_IDS lowered), see tests/test_gpu_parallel.py
         world = int(rng.choice([2, 3, 4]))
         what = f"case {n}: W={world} {kind} {cfg}"
         try:
