@@ -1386,9 +1386,10 @@ class HistoryEncoder(_LookupFunction):
                 gemm(N.TT_GEMM_NT, x, w_in, qkv, B * H, 3 * D, D, bias=b_in)
             if sweep_opt is not None:
                 # Measured over every launch of the C3 step as the release point, each at its best sweep width
-                # (tools/sweep_release_scan.py, profiles/r06_sweep_release_scan.txt): behind the history gather 3.41-3.48 ms,
-                # behind THIS product 3.21-3.25, behind the attention kernel 3.47, behind the second layer's product 3.27,
-                # later 3.25-3.6; parked rows (which start the sweep about here: the moments' gather ran in front of it) 3.31-3.34
+                # (tools/sweep_release_scan.py, profiles/r06_sweep_release_scan.txt): behind the history gather 3.14-3.15 ms,
+                # behind THIS product 3.11-3.12, behind the attention kernel 3.22-3.25, behind the second layer's product
+                # 3.18-3.22, later 3.2-3.5; parked rows (which start the sweep about here: the moments' gather ran in front of
+                # it) 3.32-3.37
                 started = torch.cuda.Event()
                 started.record()
                 sweep_opt.release_sweep(after=started)
